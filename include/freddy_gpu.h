@@ -1,0 +1,167 @@
+/*
+ * freddy_gpu.h -- C ABI of the MI355X (gfx950) search library behind the FREDDY UDFs.
+ *
+ * This is the drop-in boundary for the reference's hot path: the bodies of the
+ * PostgreSQL SRFs in freddy_extension/freddy.c and freddy_extension/ivpq_search_in.c
+ * stop scanning SPI tuples and call these entry points instead (INTEGRATION.md shows
+ * the binding).  Plain pointers and sizes only; caller allocates every host buffer;
+ * the library never retains a host pointer after a call returns, never throws and
+ * never longjmps.  Every function returns 0 on success and a negative FREDDY_E_* code
+ * on failure, with a message available from freddy_gpu_last_error().
+ *
+ * Threading: one caller thread per process (a PostgreSQL backend is single threaded,
+ * SURVEY 8b).  HIP is initialised lazily on the first pin call -- never at library
+ * load -- so a postmaster can dlopen() the extension and fork() safely.
+ *
+ * Numerics: all distances are IEEE binary32, computed with separately rounded
+ * sub/mul/add in the reference's summation order (index_utils.c:500-508, :1126-1133);
+ * result lists follow the reference's insertion rule including its tie behaviour
+ * (index_utils.c:19-33), with the canonical scan order "ascending id".
+ */
+#ifndef FREDDY_GPU_H
+#define FREDDY_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FREDDY_OK 0
+#define FREDDY_E_ARG (-1)      /* bad argument (NULL, shape mismatch, unsupported size) */
+#define FREDDY_E_HIP (-2)      /* HIP runtime / device failure */
+#define FREDDY_E_NOMEM (-3)    /* host or device allocation failed */
+#define FREDDY_E_KIND (-4)     /* index handle of the wrong kind for this call */
+#define FREDDY_E_LIMIT (-5)    /* parameter beyond what this build supports (see message) */
+
+/* found_rule for freddy_gpu_ivfadc_search */
+#define FREDDY_FOUND_ROWS 0      /* ivfadc_search:       found += rows retrieved  (freddy.c:377) */
+#define FREDDY_FOUND_ACCEPTED 1  /* ivfadc_batch_search: found += insertions      (freddy.c:971) */
+
+/* calculationMethod, index_utils.h:111 */
+#define FREDDY_METHOD_PQ 0
+#define FREDDY_METHOD_EXACT 1
+#define FREDDY_METHOD_PQ_PV 2
+
+typedef struct freddy_gpu_index freddy_gpu_index_t; /* opaque, library-owned, HBM-resident */
+
+/* ---- what gets pinned: the tables the reference re-reads through SPI on EVERY call ----- */
+
+/* pq_codebook + pq_quantization.  Replaces getCodebook(CODEBOOK) (freddy.c:69,
+ * index_utils.c:577-630) and "SELECT id, vector FROM pq_quantization" (freddy.c:96-100). */
+typedef struct freddy_pq_desc {
+  int32_t d;             /* vector dimensionality (300) */
+  int32_t m;             /* sub-quantizers = codebook positions */
+  int32_t K;             /* codes per sub-quantizer */
+  int64_t N;             /* rows */
+  const float* codebook; /* [m][K][d/m]  entry (pos, code) -> its centroid */
+  const int32_t* ids;    /* [N] row ids, rows in canonical scan order (ascending id, unique) */
+  const int16_t* codes;  /* [N][m] as stored in the bytea column (int16, index_utils.c:1088) */
+} freddy_pq_desc;
+
+/* coarse_quantization + residual_codebook + fine_quantization.  Replaces getCodebook +
+ * getCoarseQuantizer (freddy.c:239-241,746-749; index_utils.c:531-575) and the per-round
+ * "SELECT id, vector, coarse_id FROM fine_quantization WHERE coarse_id IN (...)"
+ * (freddy.c:324-342, 915-935).  Rows are grouped into inverted lists by coarse id. */
+typedef struct freddy_ivf_desc {
+  int32_t d, m, K;
+  int32_t C;               /* coarse cells; coarse id == array index (freddy.c:309,873) */
+  int64_t N;
+  const float* coarse;     /* [C][d] */
+  const float* codebook;   /* [m][K][d/m] residual codebook */
+  const int32_t* list_off; /* [C+1] CSR offsets into ids/codes */
+  const int32_t* ids;      /* [N] ascending and unique inside each list, unique overall, >= 0 */
+  const int16_t* codes;    /* [N][m] */
+} freddy_ivf_desc;
+
+/* codebook_ivpq + coarse_quantization_ivpq (2-position multi index) +
+ * fine_quantization_ivpq (+ the normalised vectors the reference JOINs in for methods
+ * 1 and 2) + the stat_* table.  Replaces getCodebook x2, getStatistics
+ * (ivpq_search_in.c:218-232) and the per-iteration SELECT (ivpq_search_in.c:352-401). */
+typedef struct freddy_ivpq_desc {
+  int32_t d, m, K;
+  int32_t coarse_positions; /* must be 2 (index_utils.c:322) */
+  int32_t coarse_codes;     /* cells = coarse_codes^2, cell = code0 + coarse_codes*code1 */
+  int64_t N;
+  const float* codebook;    /* [m][K][d/m] */
+  const float* coarse;      /* [2][coarse_codes][d/2] */
+  const int32_t* ids;       /* [N] ascending, unique */
+  const int32_t* coarse_id; /* [N] */
+  const int16_t* codes;     /* [N][m] */
+  const float* vectors;     /* [N][d] row-aligned with ids; NULL if methods 1/2 are never used */
+  const float* stats;       /* [cells+1] coarse_freq; last = total count (freddy--0.0.1.sql:158-168) */
+} freddy_ivpq_desc;
+
+/* Copy the tables into HBM once (layouts re-organised for the kernels).  The host
+ * arrays may be freed as soon as the call returns. */
+int freddy_gpu_pin_pq(const freddy_pq_desc* desc, int device, freddy_gpu_index_t** out);
+int freddy_gpu_pin_ivf(const freddy_ivf_desc* desc, int device, freddy_gpu_index_t** out);
+int freddy_gpu_pin_ivpq(const freddy_ivpq_desc* desc, int device, freddy_gpu_index_t** out);
+int freddy_gpu_unpin(freddy_gpu_index_t* index);
+
+/* ---- searches (host buffers in, host buffers out, synchronous) --------------------------- */
+
+/* Body of pq_search (freddy.c:28-152), pq_search_in (freddy.c:1028-1157) and
+ * pq_search_in_batch (freddy.c:414-653): exhaustive ADC over all rows
+ * (subset_ids == NULL) or over the rows whose id is in subset_ids ("WHERE id IN (...)":
+ * duplicates and unknown ids are ignored), for Q query vectors at once.
+ * sentinel: 100.0 for pq_search, 1000.0 for the _in variants.
+ * out_ids/out_dist: [Q][k]; unfilled slots hold (-1, sentinel). */
+int freddy_gpu_pq_search(freddy_gpu_index_t* pq, const float* queries, int32_t Q, int32_t k,
+                         float sentinel, const int32_t* subset_ids, int64_t n_subset,
+                         int32_t* out_ids, float* out_dist);
+
+/* Body of ivfadc_search (freddy.c:174-393) for Q independent queries; with W == 1,
+ * sentinel 100.0 and FREDDY_FOUND_ACCEPTED it is the body of ivfadc_batch_search
+ * (freddy.c:679-999).  Each round probes the W nearest not-yet-used cells; rounds repeat
+ * while found < k (found_rule).  out_*: [Q][k]. */
+int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ivf, const float* queries, int32_t Q, int32_t k,
+                             int32_t W, float sentinel, int32_t found_rule, int32_t* out_ids,
+                             float* out_dist);
+
+/* Body of ivpq_search_in (ivpq_search_in.c:61-699), the kNN-join.  Arguments are the
+ * SRF's own (ivpq_search_in.c:168-208).  iterations_out (may be NULL) receives the
+ * number of alpha-doubling rounds.  out_*: [Q][k], sentinel 1000.0. */
+int freddy_gpu_knn_join(freddy_gpu_index_t* ivpq, const float* queries, int32_t Q, int32_t k,
+                        const int32_t* target_ids, int64_t n_targets, int32_t alpha, int32_t pvf,
+                        int32_t method, int32_t use_target_lists, float confidence,
+                        int32_t double_threshold, int32_t* out_ids, float* out_dist,
+                        int32_t* iterations_out);
+
+/* ---- device-resident variant used for throughput measurement ----------------------------
+ * Same as freddy_gpu_ivfadc_search, but queries / outputs are DEVICE pointers on the
+ * index's device and all work is enqueued on `hip_stream` (a hipStream_t; NULL = the
+ * library's own stream) without synchronising.  d_status[0] is set non-zero by the
+ * device if some query needs a further probing round (rare: its first W cells hold
+ * fewer than k rows); such queries keep partial results and the caller should re-run
+ * them through freddy_gpu_ivfadc_search.  Single round only. */
+int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ivf, const float* d_queries, int32_t Q,
+                                 int32_t k, int32_t W, float sentinel, int32_t found_rule,
+                                 int32_t* d_out_ids, float* d_out_dist, int32_t* d_status,
+                                 void* hip_stream);
+int freddy_gpu_pq_search_dev(freddy_gpu_index_t* pq, const float* d_queries, int32_t Q, int32_t k,
+                             float sentinel, int32_t* d_out_ids, float* d_out_dist,
+                             void* hip_stream);
+
+/* ---- diagnostics ------------------------------------------------------------------------ */
+
+/* Thread-local message of the last failing call; valid until the next call. */
+const char* freddy_gpu_last_error(void);
+
+/* Per-kernel timing with HIP events on the launch stream.  enable=1 starts recording
+ * (and clears earlier records); freddy_gpu_profile_read() synchronises, then reports up
+ * to `cap` kernels: name, number of launches, total milliseconds.  Returns the number
+ * of distinct kernels (or <0). */
+int freddy_gpu_profile_enable(freddy_gpu_index_t* index, int32_t enable);
+int freddy_gpu_profile_read(freddy_gpu_index_t* index, int32_t cap, char (*names)[64],
+                            int64_t* launches, double* total_ms);
+
+/* Sizes the caller may want for roofline arithmetic. */
+int64_t freddy_gpu_index_bytes(const freddy_gpu_index_t* index);   /* HBM footprint of the pinned index */
+/* Sum of list lengths the last ivfadc call scanned (all queries, all probes). */
+int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* index);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREDDY_GPU_H */

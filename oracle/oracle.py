@@ -1,0 +1,225 @@
+"""ctypes binding of the CPU oracle (oracle/libfreddy_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- may be imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product package.  PARITY UNPINNED (see
+freddy_oracle.h): the oracle restates the reference, it was never run against it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libfreddy_oracle.so")
+
+ENTRY = np.dtype([("id", np.int32), ("dist", np.float32)])
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("freddy_oracle.c", "freddy_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+class PQTable(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("N", C.c_int64),
+                ("codebook", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p)]
+
+
+class IVFTable(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("C", C.c_int32),
+                ("N", C.c_int64), ("coarse", C.c_void_p), ("codebook", C.c_void_p),
+                ("list_off", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p)]
+
+
+class IVPQTable(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("cpos", C.c_int32),
+                ("ccodes", C.c_int32), ("N", C.c_int64), ("codebook", C.c_void_p),
+                ("coarse", C.c_void_p), ("ids", C.c_void_p), ("coarse_id", C.c_void_p),
+                ("codes", C.c_void_p), ("vectors", C.c_void_p), ("stats", C.c_void_p)]
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """Thin, array-in/array-out access to every oracle entry point."""
+
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        L.fo_sqdist.restype = C.c_float
+        L.fo_sqdist.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.fo_adc.restype = C.c_float
+        L.fo_adc.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.fo_confidence_hyp.restype = C.c_float
+        L.fo_confidence_hyp.argtypes = [C.c_int, C.c_int, C.c_float, C.c_int]
+        L.fo_emit_roundtrip.restype = C.c_float
+        L.fo_emit_roundtrip.argtypes = [C.c_float]
+        L.fo_topk_insert.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int32]
+        L.fo_offer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int32]
+        L.fo_offer.restype = C.c_int
+        L.fo_ivfadc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.fo_ivfadc_search_many.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                            C.c_int, C.c_int, C.c_void_p]
+        L.fo_ivpq_search_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                        C.c_void_p, C.c_void_p]
+        L.fo_multi_index_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                            C.c_float, C.c_void_p, C.c_void_p]
+
+    # ---- primitives ------------------------------------------------------------------
+    def sqdist(self, a, b):
+        a, b = _f32(a), _f32(b)
+        return np.float32(self.lib.fo_sqdist(_p(a), _p(b), a.size))
+
+    def lut(self, q, codebook):
+        cb = _f32(codebook)
+        m, K, s = cb.shape
+        q = _f32(q)
+        out = np.empty(m * K, np.float32)
+        self.lib.fo_lut(_p(out), m, K, s, _p(q), _p(cb))
+        return out
+
+    def lut_entries(self, q, K, pos, code, vectors):
+        pos, code, vectors, q = _i32(pos), _i32(code), _f32(vectors), _f32(q)
+        n, s = vectors.shape
+        out = np.full(n, np.nan, np.float32)
+        self.lib.fo_lut_entries(_p(out), n, K, s, _p(q), _p(pos), _p(code), _p(vectors))
+        return out
+
+    def lut_double(self, q, codebook):
+        cb = _f32(codebook)
+        m, K, s = cb.shape
+        q = _f32(q)
+        out = np.empty((m // 2) * K * K, np.float32)
+        self.lib.fo_lut_double(_p(out), m, K, s, _p(q), _p(cb))
+        return out
+
+    def adc(self, lut, codes, K):
+        lut, codes = _f32(lut), _i16(codes)
+        return np.float32(self.lib.fo_adc(_p(lut), _p(codes), codes.size, K))
+
+    def topk_stream(self, dists, ids, k, sentinel):
+        """offer() a whole candidate stream (a5 + guard) and return the final list."""
+        tk = np.empty(k, ENTRY)
+        self.lib.fo_topk_init(_p(tk), k, C.c_float(sentinel))
+        maxd = np.array([sentinel], np.float32)
+        for dd, ii in zip(np.asarray(dists, np.float32), np.asarray(ids, np.int32)):
+            self.lib.fo_offer(_p(tk), k, _p(maxd), C.c_float(float(dd)), int(ii))
+        return tk
+
+    def confidence_hyp(self, expect, size, p, stat_size):
+        return np.float32(self.lib.fo_confidence_hyp(int(expect), int(size), C.c_float(float(p)), int(stat_size)))
+
+    def emit_roundtrip(self, dist):
+        return np.float32(self.lib.fo_emit_roundtrip(C.c_float(float(dist))))
+
+    # ---- tables ----------------------------------------------------------------------
+    @staticmethod
+    def pq_table(codebook, ids, codes):
+        cb, ids, codes = _f32(codebook), _i32(ids), _i16(codes)
+        m, K, s = cb.shape
+        t = PQTable(m * s, m, K, ids.size, _p(cb), _p(ids), _p(codes))
+        t._keep = (cb, ids, codes)
+        return t
+
+    @staticmethod
+    def ivf_table(coarse, codebook, list_off, ids, codes):
+        cq, cb, lo, ids, codes = _f32(coarse), _f32(codebook), _i32(list_off), _i32(ids), _i16(codes)
+        m, K, s = cb.shape
+        t = IVFTable(m * s, m, K, cq.shape[0], ids.size, _p(cq), _p(cb), _p(lo), _p(ids), _p(codes))
+        t._keep = (cq, cb, lo, ids, codes)
+        return t
+
+    @staticmethod
+    def ivpq_table(codebook, coarse, ids, coarse_id, codes, vectors, stats):
+        cb, cq, ids, cid, codes, st = _f32(codebook), _f32(coarse), _i32(ids), _i32(coarse_id), _i16(codes), _f32(stats)
+        vec = None if vectors is None else _f32(vectors)
+        m, K, s = cb.shape
+        cpos, ccodes, _ = cq.shape
+        t = IVPQTable(m * s, m, K, cpos, ccodes, ids.size, _p(cb), _p(cq), _p(ids), _p(cid), _p(codes),
+                      None if vec is None else _p(vec), _p(st))
+        t._keep = (cb, cq, ids, cid, codes, vec, st)
+        return t
+
+    # ---- drivers ---------------------------------------------------------------------
+    def pq_search(self, t, q, k):
+        q = _f32(q)
+        out = np.empty(k, ENTRY)
+        rc = self.lib.fo_pq_search(C.byref(t), _p(q), k, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def pq_search_in(self, t, q, k, input_ids):
+        q, iid = _f32(q), _i32(input_ids)
+        out = np.empty(k, ENTRY)
+        rc = self.lib.fo_pq_search_in(C.byref(t), _p(q), k, _p(iid), iid.size, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def pq_search_in_batch(self, t, queries, k, input_ids, use_target_lists=True):
+        qs, iid = _f32(queries), _i32(input_ids)
+        out = np.empty((qs.shape[0], k), ENTRY)
+        rc = self.lib.fo_pq_search_in_batch(C.byref(t), _p(qs), qs.shape[0], k, _p(iid), iid.size,
+                                            int(use_target_lists), _p(out))
+        assert rc == 0, rc
+        return out
+
+    def ivfadc_search(self, t, q, k, W, sentinel=1000.0, found_rule=0):
+        q = _f32(q)
+        out = np.empty(k, ENTRY)
+        rc = self.lib.fo_ivfadc_search(C.byref(t), _p(q), k, W, C.c_float(sentinel), found_rule, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def ivfadc_search_many(self, t, queries, k, W, sentinel=1000.0, found_rule=0, n_threads=1):
+        qs = _f32(queries)
+        out = np.empty((qs.shape[0], k), ENTRY)
+        rc = self.lib.fo_ivfadc_search_many(C.byref(t), _p(qs), qs.shape[0], k, W, C.c_float(sentinel),
+                                            found_rule, n_threads, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def ivfadc_batch_search(self, t, queries, k):
+        qs = _f32(queries)
+        out = np.empty((qs.shape[0], k), ENTRY)
+        rc = self.lib.fo_ivfadc_batch_search(C.byref(t), _p(qs), qs.shape[0], k, _p(out))
+        assert rc == 0, rc
+        return out
+
+    def multi_index_select(self, t, queries, active, n_targets, min_target_count, confidence):
+        qs, act = _f32(queries), _i32(active)
+        cells = t.ccodes * t.ccodes
+        out = np.full((act.size, cells), -1, np.int32)
+        cnt = np.zeros(act.size, np.int32)
+        last = self.lib.fo_multi_index_select(C.byref(t), _p(qs), _p(act), act.size, n_targets,
+                                              min_target_count, C.c_float(confidence), _p(out), _p(cnt))
+        assert last >= 0, last
+        return [out[i, :cnt[i]].copy() for i in range(act.size)], bool(last)
+
+    def ivpq_search_in(self, t, queries, k, target_ids, alpha, pvf, method, use_target_lists=True,
+                       confidence=0.8, double_threshold=10000000):
+        qs, tid = _f32(queries), _i32(target_ids)
+        out = np.empty((qs.shape[0], k), ENTRY)
+        iters = C.c_int(0)
+        rc = self.lib.fo_ivpq_search_in(C.byref(t), _p(qs), qs.shape[0], k, _p(tid), tid.size, alpha, pvf,
+                                        method, int(use_target_lists), C.c_float(confidence),
+                                        double_threshold, _p(out), C.byref(iters))
+        assert rc == 0, rc
+        return out, iters.value

@@ -1,0 +1,727 @@
+// freddy_gpu.hip -- C ABI (include/freddy_gpu.h) over the HIP kernels in kernels.h.
+//
+// Host-side responsibilities only: lay the pinned tables out for the kernels, size
+// workspaces, order the launches of a probing round on one HIP stream, and run the
+// (rare) extra rounds of the reference's "while (foundInstances < k)" loop
+// (freddy.c:262, :835).  No arithmetic that influences a result happens on the host
+// for the PQ / IVFADC calls.
+#include "../../include/freddy_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "join.h"
+
+using namespace freddy;
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+extern "C" const char* freddy_gpu_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(FREDDY_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// index object
+// ---------------------------------------------------------------------------------------
+enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3 };
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+    cap = want;
+    return 0;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct ProfRec {
+  int64_t launches = 0;
+  double ms = 0.0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> open;
+};
+
+struct freddy_gpu_index {
+  int kind = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int d = 0, m = 0, K = 0, C = 0, S = 0, M2 = 0;
+  int64_t N = 0;
+  int64_t n_blocks = 0;
+  int max_list_blocks = 0;
+  int64_t bytes = 0;
+  int64_t last_scanned_rows = 0;
+  int last_Q = 0;
+  // pinned tables
+  float* coarse = nullptr;      // [C][d]
+  float* cbT = nullptr;         // [m][S][K]
+  int32_t* list_off = nullptr;  // [lists+1] rows
+  int32_t* blk_off = nullptr;   // [lists+1] row blocks
+  uint32_t* packed = nullptr;   // [blocks][M2][64]
+  int32_t* pos = nullptr;       // [blocks*64]
+  int32_t* ids = nullptr;       // PQ: [N] position -> id
+  std::vector<int32_t> h_ids;   // PQ: ascending ids for "id IN (...)" resolution
+  std::vector<int32_t> h_list_off;
+  // ivpq extras
+  JoinIndex join;
+  // workspaces
+  DevBuf w_q, w_qT, w_distT, w_used, w_sel, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
+      w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
+      w_sub_packed, w_sub_pos, w_sub_blk, w_status;
+  // profiling
+  bool profiling = false;
+  std::map<std::string, ProfRec> prof;
+};
+
+static size_t lut_budget_bytes() {
+  const char* e = getenv("FREDDY_GPU_LUT_BUDGET_MB");
+  size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 1024;
+  if (mb < 1) mb = 1;
+  return mb << 20;
+}
+
+template <class F>
+static inline void timed_launch(freddy_gpu_index* ix, hipStream_t s, const char* name, F&& f) {
+  if (!ix->profiling) { f(); return; }
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  (void)hipEventRecord(a, s);
+  f();
+  (void)hipEventRecord(b, s);
+  ProfRec& r = ix->prof[name];
+  r.launches++;
+  r.open.emplace_back(a, b);
+}
+
+template <class T>
+static int upload(T** dst, const T* src, size_t n, int64_t* bytes) {
+  *dst = nullptr;
+  size_t sz = sizeof(T) * (n ? n : 1);
+  if (hipMalloc((void**)dst, sz) != hipSuccess) return -1;
+  if (n && hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice) != hipSuccess) return -2;
+  if (bytes) *bytes += (int64_t)sz;
+  return 0;
+}
+
+static void free_index(freddy_gpu_index* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  void* ptrs[] = {ix->coarse, ix->cbT, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  join_free(&ix->join);
+  DevBuf* bufs[] = {&ix->w_q, &ix->w_qT, &ix->w_distT, &ix->w_used, &ix->w_sel, &ix->w_item_cell,
+                    &ix->w_item_query, &ix->w_rows, &ix->w_resid, &ix->w_lut, &ix->w_part,
+                    &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
+                    &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
+                    &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_status};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& kv : ix->prof)
+    for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  if (ix->stream) (void)hipStreamDestroy(ix->stream);
+  delete ix;
+}
+
+// transpose codebook [m][K][S] -> [m][S][K]
+static std::vector<float> transpose_codebook(const float* cb, int m, int K, int S) {
+  std::vector<float> t((size_t)m * S * K);
+  for (int p = 0; p < m; ++p)
+    for (int c = 0; c < K; ++c)
+      for (int j = 0; j < S; ++j) t[((size_t)p * S + j) * K + c] = cb[((size_t)p * K + c) * S + j];
+  return t;
+}
+
+// Pack rows of `n_lists` inverted lists into 64-row blocks: [block][M2][64] dwords, two
+// int16 codes per dword, plus one scan-position dword per row (-1 on padding rows).
+static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off, const int16_t* codes,
+                      const int32_t* row_pos /*NULL: row index*/) {
+  const int m = ix->m, K = ix->K, M2 = ix->M2;
+  std::vector<int32_t> blk_off(n_lists + 1, 0);
+  int max_blocks = 0;
+  for (int c = 0; c < n_lists; ++c) {
+    const int64_t len = (int64_t)list_off[c + 1] - list_off[c];
+    if (len < 0) return fail(FREDDY_E_ARG, "list_off is not non-decreasing at list %d", c);
+    const int nb = (int)((len + 63) / 64);
+    blk_off[c + 1] = blk_off[c] + nb;
+    max_blocks = std::max(max_blocks, nb);
+  }
+  const int64_t n_blocks = blk_off[n_lists];
+  std::vector<uint32_t> packed((size_t)std::max<int64_t>(n_blocks, 1) * M2 * 64, 0u);
+  std::vector<int32_t> pos((size_t)std::max<int64_t>(n_blocks, 1) * 64, -1);
+  for (int c = 0; c < n_lists; ++c) {
+    for (int64_t r = list_off[c]; r < list_off[c + 1]; ++r) {
+      const int64_t i = r - list_off[c];
+      const int64_t b = blk_off[c] + i / 64;
+      const int lane = (int)(i % 64);
+      const int16_t* row = codes + (size_t)r * m;
+      for (int l = 0; l < m; ++l) {
+        if (row[l] < 0 || row[l] >= K)
+          return fail(FREDDY_E_ARG, "code %d at row %lld position %d is outside [0,%d)", (int)row[l],
+                      (long long)r, l, K);
+      }
+      for (int j = 0; j < M2; ++j) {
+        const uint32_t lo = (uint16_t)row[2 * j];
+        const uint32_t hi = (2 * j + 1 < m) ? (uint16_t)row[2 * j + 1] : 0u;
+        packed[((size_t)b * M2 + j) * 64 + lane] = lo | (hi << 16);
+      }
+      pos[(size_t)b * 64 + lane] = row_pos ? row_pos[r] : (int32_t)r;
+    }
+  }
+  ix->n_blocks = n_blocks;
+  ix->max_list_blocks = max_blocks;
+  ix->h_list_off.assign(list_off, list_off + n_lists + 1);
+  if (upload(&ix->blk_off, blk_off.data(), blk_off.size(), &ix->bytes) ||
+      upload(&ix->list_off, list_off, (size_t)n_lists + 1, &ix->bytes) ||
+      upload(&ix->packed, packed.data(), packed.size(), &ix->bytes) ||
+      upload(&ix->pos, pos.data(), pos.size(), &ix->bytes))
+    return fail(FREDDY_E_NOMEM, "device allocation/copy failed while pinning the lists");
+  return 0;
+}
+
+static int open_device(freddy_gpu_index* ix, int device) {
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (device < 0 || device >= n) return fail(FREDDY_E_ARG, "device %d out of range (%d visible)", device, n);
+  HIP_TRY(hipSetDevice(device));
+  ix->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  return 0;
+}
+
+static int check_pq_shape(int d, int m, int K, int64_t N) {
+  if (d <= 0 || m <= 0 || K <= 0 || N < 0) return fail(FREDDY_E_ARG, "non-positive dimension");
+  if (d % m) return fail(FREDDY_E_ARG, "d=%d is not a multiple of m=%d", d, m);
+  if (K > 65536) return fail(FREDDY_E_LIMIT, "K=%d does not fit a 16-bit code", K);
+  if ((size_t)m * K * 4 + 4096 > 160 * 1024)
+    return fail(FREDDY_E_LIMIT, "LUT of m*K=%d floats does not fit the 160 KiB LDS", m * K);
+  if (N > (int64_t)INT32_MAX - 64) return fail(FREDDY_E_LIMIT, "N too large for 32-bit row positions");
+  return 0;
+}
+
+extern "C" int freddy_gpu_pin_pq(const freddy_pq_desc* t, int device, freddy_gpu_index_t** out) {
+  if (!t || !out || !t->codebook || (t->N && (!t->ids || !t->codes))) return fail(FREDDY_E_ARG, "NULL argument");
+  if (int rc = check_pq_shape(t->d, t->m, t->K, t->N)) return rc;
+  for (int64_t r = 1; r < t->N; ++r)
+    if (t->ids[r] <= t->ids[r - 1])
+      return fail(FREDDY_E_ARG, "ids must be strictly ascending (canonical scan order); violated at row %lld", (long long)r);
+  freddy_gpu_index* ix = new freddy_gpu_index();
+  ix->kind = KIND_PQ;
+  ix->d = t->d; ix->m = t->m; ix->K = t->K; ix->S = t->d / t->m; ix->M2 = (t->m + 1) / 2; ix->N = t->N;
+  int rc = open_device(ix, device);
+  if (!rc) {
+    std::vector<float> cbT = transpose_codebook(t->codebook, ix->m, ix->K, ix->S);
+    if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes) || upload(&ix->ids, t->ids, (size_t)t->N, &ix->bytes))
+      rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+  }
+  if (!rc) {
+    const int32_t off[2] = {0, (int32_t)t->N};
+    rc = pack_lists(ix, 1, off, t->codes, nullptr);
+  }
+  if (!rc) ix->h_ids.assign(t->ids, t->ids + t->N);
+  if (rc) { free_index(ix); return rc; }
+  *out = ix;
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_gpu_index_t** out) {
+  if (!t || !out || !t->codebook || !t->coarse || !t->list_off || (t->N && (!t->ids || !t->codes)))
+    return fail(FREDDY_E_ARG, "NULL argument");
+  if (int rc = check_pq_shape(t->d, t->m, t->K, t->N)) return rc;
+  if (t->C <= 0) return fail(FREDDY_E_ARG, "C must be positive");
+  if (t->list_off[0] != 0 || t->list_off[t->C] != t->N) return fail(FREDDY_E_ARG, "list_off must span [0, N]");
+  for (int c = 0; c < t->C; ++c)
+    for (int64_t r = t->list_off[c]; r < t->list_off[c + 1]; ++r) {
+      if (t->ids[r] < 0) return fail(FREDDY_E_ARG, "negative id at row %lld", (long long)r);
+      if (r > t->list_off[c] && t->ids[r] <= t->ids[r - 1])
+        return fail(FREDDY_E_ARG, "ids must be strictly ascending inside list %d (row %lld)", c, (long long)r);
+    }
+  freddy_gpu_index* ix = new freddy_gpu_index();
+  ix->kind = KIND_IVF;
+  ix->d = t->d; ix->m = t->m; ix->K = t->K; ix->S = t->d / t->m; ix->M2 = (t->m + 1) / 2; ix->N = t->N; ix->C = t->C;
+  int rc = open_device(ix, device);
+  if (!rc) {
+    std::vector<float> cbT = transpose_codebook(t->codebook, ix->m, ix->K, ix->S);
+    if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes) ||
+        upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes))
+      rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+  }
+  if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
+  if (rc) { free_index(ix); return rc; }
+  *out = ix;
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_pin_ivpq(const freddy_ivpq_desc* t, int device, freddy_gpu_index_t** out) {
+  if (!t || !out || !t->codebook || !t->coarse || !t->stats || (t->N && (!t->ids || !t->codes || !t->coarse_id)))
+    return fail(FREDDY_E_ARG, "NULL argument");
+  if (t->d <= 0 || t->m <= 0 || t->K <= 0 || t->d % t->m) return fail(FREDDY_E_ARG, "bad d/m/K");
+  if (t->coarse_positions != 2) return fail(FREDDY_E_LIMIT, "only 2 coarse positions are supported (as in the reference, index_utils.c:322)");
+  if (t->coarse_codes <= 0 || t->d % 2) return fail(FREDDY_E_ARG, "bad coarse multi-index shape");
+  freddy_gpu_index* ix = new freddy_gpu_index();
+  ix->kind = KIND_IVPQ;
+  ix->d = t->d; ix->m = t->m; ix->K = t->K; ix->S = t->d / t->m; ix->N = t->N;
+  int rc = open_device(ix, device);
+  if (!rc) {
+    rc = join_pin(&ix->join, t, &ix->bytes);
+    if (rc) rc = fail(rc, "%s", join_error());
+  }
+  if (rc) { free_index(ix); return rc; }
+  *out = ix;
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_unpin(freddy_gpu_index_t* ix) {
+  free_index(ix);
+  return FREDDY_OK;
+}
+
+extern "C" int64_t freddy_gpu_index_bytes(const freddy_gpu_index_t* ix) { return ix ? ix->bytes : 0; }
+extern "C" int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* ix) {
+  // rows retrieved in the most recent probing round (last query chunk): read back on demand
+  if (!ix || ix->kind != KIND_IVF || ix->last_Q <= 0 || !ix->w_rows.p) return 0;
+  if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+  std::vector<int32_t> rows((size_t)ix->last_Q);
+  if (hipMemcpy(rows.data(), ix->w_rows.p, sizeof(int32_t) * rows.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  int64_t sum = 0;
+  for (int32_t r : rows) if (r > 0) sum += r;
+  return sum;
+}
+
+extern "C" int freddy_gpu_profile_enable(freddy_gpu_index_t* ix, int32_t enable) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  for (auto& kv : ix->prof)
+    for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  ix->prof.clear();
+  ix->profiling = enable != 0;
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_profile_read(freddy_gpu_index_t* ix, int32_t cap, char (*names)[64],
+                                       int64_t* launches, double* total_ms) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int n = 0;
+  for (auto& kv : ix->prof) {
+    ProfRec& r = kv.second;
+    for (auto& ev : r.open) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) r.ms += ms;
+      (void)hipEventDestroy(ev.first);
+      (void)hipEventDestroy(ev.second);
+    }
+    r.open.clear();
+    if (n < cap) {
+      if (names) { strncpy(names[n], kv.first.c_str(), 63); names[n][63] = 0; }
+      if (launches) launches[n] = r.launches;
+      if (total_ms) total_ms[n] = r.ms;
+    }
+    ++n;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------------------
+// kernel dispatch helpers
+// ---------------------------------------------------------------------------------------
+static int pick_V(int L) {
+  if (L <= 64) return 1;
+  if (L <= 128) return 2;
+  if (L <= 256) return 4;
+  if (L <= 512) return 8;
+  if (L <= 1024) return 16;
+  return 0;
+}
+
+template <int M, int V>
+static int launch_scan_mv(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, dim3 grid, size_t lds) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&adc_scan_kernel<M, V>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  timed_launch(ix, s, "adc_scan", [&] { hipLaunchKernelGGL((adc_scan_kernel<M, V>), grid, dim3(WG), lds, s, a); });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int M>
+static int launch_scan_m(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, dim3 grid, size_t lds, int V) {
+  switch (V) {
+    case 1: return launch_scan_mv<M, 1>(ix, s, a, grid, lds);
+    case 2: return launch_scan_mv<M, 2>(ix, s, a, grid, lds);
+    case 4: return launch_scan_mv<M, 4>(ix, s, a, grid, lds);
+    case 8: return launch_scan_mv<M, 8>(ix, s, a, grid, lds);
+    case 16: return launch_scan_mv<M, 16>(ix, s, a, grid, lds);
+  }
+  return fail(FREDDY_E_LIMIT, "unsupported selection width");
+}
+
+static int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_items) {
+  if (n_items <= 0 || a.nchunk <= 0) return 0;
+  const size_t lds = (((size_t)a.m * a.K * 4 + 15) & ~(size_t)15) + (size_t)WAVES * 64 * sizeof(u64);
+  dim3 grid((unsigned)a.nchunk, (unsigned)n_items);
+  const int V = pick_V(a.L);
+  if (a.m == 12) return launch_scan_m<12>(ix, s, a, grid, lds, V);
+  return launch_scan_m<0>(ix, s, a, grid, lds, V);
+}
+
+static int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a) {
+  if (a.n_active <= 0) return 0;
+  const int V = pick_V(a.L);
+  dim3 grid((unsigned)a.n_active), block(64);
+  timed_launch(ix, s, "merge_replay", [&] {
+    switch (V) {
+      case 1: hipLaunchKernelGGL((merge_replay_kernel<1>), grid, block, 0, s, a); break;
+      case 2: hipLaunchKernelGGL((merge_replay_kernel<2>), grid, block, 0, s, a); break;
+      case 4: hipLaunchKernelGGL((merge_replay_kernel<4>), grid, block, 0, s, a); break;
+      case 8: hipLaunchKernelGGL((merge_replay_kernel<8>), grid, block, 0, s, a); break;
+      case 16: hipLaunchKernelGGL((merge_replay_kernel<16>), grid, block, 0, s, a); break;
+    }
+  });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int32_t* item_cell,
+                      float* lut, int n_items) {
+  if (n_items <= 0) return 0;
+  // enough workgroups to fill 256 CUs several times over, while amortising the register
+  // fill of the codebook slice over as many items as possible
+  int ipw = (int)std::max<int64_t>(1, ((int64_t)ix->m * n_items + 4095) / 4096);
+  ipw = std::min(ipw, 64);
+  dim3 grid((unsigned)ix->m, (unsigned)((n_items + ipw - 1) / ipw));
+  const int m = ix->m, K = ix->K, d = ix->d, S = ix->S;
+  timed_launch(ix, s, "lut_build", [&] {
+    if (S == 25) hipLaunchKernelGGL((lut_build_kernel<25, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d);
+    else if (S == 10) hipLaunchKernelGGL((lut_build_kernel<10, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d);
+    else if (S == 20) hipLaunchKernelGGL((lut_build_kernel<20, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d);
+    else hipLaunchKernelGGL(lut_build_generic_kernel, grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d, S);
+  });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// IVFADC
+// ---------------------------------------------------------------------------------------
+// One chunk of queries (device pointers).  sync_rounds: run the extra rounds with a host
+// sync per round; otherwise only round one is enqueued and d_status reports stragglers.
+static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, int W,
+                        float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
+                        int32_t* d_status, bool sync_rounds) {
+  const int d = ix->d, C = ix->C, m = ix->m, K = ix->K;
+  const int L = std::min(2 * k, 64 * 16);
+  const int Qpad = (Q + WG - 1) / WG * WG;
+  const int used_words = (C + 31) / 32;
+  const size_t lutN = (size_t)m * K;
+  const int chunk_blocks = 64;
+  const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
+  const size_t items = (size_t)Q * W;
+
+  if (ix->w_qT.ensure(sizeof(float) * (size_t)d * Qpad) || ix->w_distT.ensure(sizeof(float) * (size_t)C * Qpad) ||
+      ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) || ix->w_sel.ensure(sizeof(float) * items) ||
+      ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
+      ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_resid.ensure(sizeof(float) * items * d) ||
+      ix->w_lut.ensure(sizeof(float) * items * lutN) ||
+      ix->w_part.ensure(sizeof(u64) * items * nchunk * WAVES * L) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
+      ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+
+  HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
+  HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
+
+  timed_launch(ix, s, "transpose_queries", [&] {
+    hipLaunchKernelGGL(transpose_queries_kernel, dim3(Qpad / WG, d), dim3(WG), 0, s, d_q, ix->w_qT.as<float>(), Q, Qpad, d);
+  });
+  timed_launch(ix, s, "coarse_dist", [&] {
+    hipLaunchKernelGGL((coarse_dist_kernel<4>), dim3(Qpad / WG, (C + 3) / 4), dim3(WG), 0, s, ix->w_qT.as<float>(),
+                       ix->coarse, ix->w_distT.as<float>(), Qpad, C, d);
+  });
+  HIP_TRY(hipGetLastError());
+
+  ix->last_Q = Q;
+  int n_active = Q;
+  const int32_t* active = nullptr;
+  int32_t* next = ix->w_act0.as<int32_t>();
+  bool first = true;
+  const int max_rounds = (C + W - 1) / W + 1;
+  for (int round = 0; round < max_rounds && n_active > 0; ++round) {
+    const int n_items = n_active * W;
+    PlanArgs pa;
+    pa.distT = ix->w_distT.as<float>(); pa.active = active; pa.list_off = ix->list_off;
+    pa.used = ix->w_used.as<uint32_t>(); pa.sel_dist = ix->w_sel.as<float>();
+    pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
+    pa.round_rows = ix->w_rows.as<int32_t>();
+    pa.n_active = n_active; pa.Qpad = Qpad; pa.C = C; pa.W = W; pa.used_words = used_words;
+    timed_launch(ix, s, "probe_plan", [&] {
+      hipLaunchKernelGGL(probe_plan_kernel, dim3((n_active + 63) / 64), dim3(64), 0, s, pa);
+    });
+    timed_launch(ix, s, "residual", [&] {
+      hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
+                         ix->w_resid.as<float>(), d);
+    });
+    HIP_TRY(hipGetLastError());
+    if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
+
+    HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
+    ScanArgs sa;
+    sa.lut = ix->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
+    sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ix->w_part.as<u64>();
+    sa.cand_count = ix->w_cand.as<int32_t>();
+    sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
+    memcpy(&sa.sentinel_bits, &sentinel, 4);
+    if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
+
+    MergeArgs ma;
+    ma.part = sa.part; ma.active = active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
+    ma.cand_count = sa.cand_count; ma.out_ids = d_out_ids; ma.out_dist = d_out_dist;
+    ma.found = ix->w_found.as<int32_t>(); ma.next_active = next; ma.n_next = ix->w_cnt.as<int32_t>();
+    ma.status = d_status;
+    ma.n_active = n_active; ma.parts_per_query = W * nchunk * WAVES; ma.L = L; ma.k = k;
+    ma.found_rule = found_rule; ma.first_round = first ? 1 : 0; ma.sentinel = sentinel;
+    if (int rc = launch_merge(ix, s, ma)) return rc;
+    first = false;
+    if (!sync_rounds) break;
+
+    int32_t n_next = 0;
+    HIP_TRY(hipMemcpyAsync(&n_next, ix->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (n_next <= 0) break;
+    HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t), s));
+    active = next;
+    next = (next == ix->w_act0.as<int32_t>()) ? ix->w_act1.as<int32_t>() : ix->w_act0.as<int32_t>();
+    n_active = n_next;
+  }
+  return 0;
+}
+
+static int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q, int k, const void* oi,
+                             const void* od) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  if (ix->kind != kind) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  if (Q < 0 || k <= 0) return fail(FREDDY_E_ARG, "Q must be >= 0 and k > 0");
+  if (Q > 0 && (!q || !oi || !od)) return fail(FREDDY_E_ARG, "NULL buffer");
+  if (2 * k > 1024) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 512", k);
+  return 0;
+}
+
+static int max_queries_per_chunk(const freddy_gpu_index* ix, int W) {
+  const size_t per_query = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
+  size_t n = lut_budget_bytes() / std::max<size_t>(per_query, 1);
+  if (n < 1) n = 1;
+  if (n > (1u << 20)) n = 1u << 20;
+  return (int)n;
+}
+
+extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float* d_queries, int32_t Q, int32_t k,
+                                            int32_t W, float sentinel, int32_t found_rule, int32_t* d_out_ids,
+                                            float* d_out_dist, int32_t* d_status, void* hip_stream) {
+  if (int rc = check_search_args(ix, KIND_IVF, d_queries, Q, k, d_out_ids, d_out_dist)) return rc;
+  if (W <= 0) return fail(FREDDY_E_ARG, "W must be positive");
+  if (W > ix->C) W = ix->C;
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ix->stream;
+  const int qc = max_queries_per_chunk(ix, W);
+  for (int q0 = 0; q0 < Q; q0 += qc) {
+    const int n = std::min(qc, Q - q0);
+    if (int rc = ivfadc_chunk(ix, s, d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+                              d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_status, false))
+      return rc;
+  }
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k, int32_t W,
+                                        float sentinel, int32_t found_rule, int32_t* out_ids, float* out_dist) {
+  if (int rc = check_search_args(ix, KIND_IVF, queries, Q, k, out_ids, out_dist)) return rc;
+  if (W <= 0) return fail(FREDDY_E_ARG, "W must be positive");
+  if (W > ix->C) W = ix->C;
+  if (Q == 0) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = ix->stream;
+  if (ix->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ix->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
+  const int qc = max_queries_per_chunk(ix, W);
+  for (int q0 = 0; q0 < Q; q0 += qc) {
+    const int n = std::min(qc, Q - q0);
+    if (int rc = ivfadc_chunk(ix, s, ix->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+                              ix->w_out_ids.as<int32_t>() + (size_t)q0 * k, ix->w_out_dist.as<float>() + (size_t)q0 * k,
+                              nullptr, true))
+      return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_dist, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FREDDY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// exhaustive / subset PQ
+// ---------------------------------------------------------------------------------------
+static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
+                    const int32_t* blk_off, const uint32_t* packed, const int32_t* pos, int64_t n_blocks,
+                    int32_t* d_out_ids, float* d_out_dist) {
+  const int m = ix->m, K = ix->K;
+  const int L = std::min(2 * k, 64 * 16);
+  const size_t lutN = (size_t)m * K;
+  // enough (query, chunk) workgroups to fill the chip, but chunks long enough to amortise
+  // the 48 KiB LUT staging
+  int chunk_blocks = 64;
+  while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)Q > 16384 && chunk_blocks < 4096) chunk_blocks *= 2;
+  const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
+  if (ix->w_lut.ensure(sizeof(float) * (size_t)Q * lutN) ||
+      ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * WAVES * L))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (int rc = launch_lut(ix, s, d_q, nullptr, ix->w_lut.as<float>(), Q)) return rc;
+  ScanArgs sa;
+  sa.lut = ix->w_lut.as<float>(); sa.item_list = nullptr; sa.item_query = nullptr;
+  sa.blk_off = blk_off; sa.packed = packed; sa.pos = pos; sa.part = ix->w_part.as<u64>();
+  sa.cand_count = nullptr;
+  sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
+  memcpy(&sa.sentinel_bits, &sentinel, 4);
+  if (int rc = launch_scan(ix, s, sa, Q)) return rc;
+  MergeArgs ma;
+  ma.part = sa.part; ma.active = nullptr; ma.pos_to_id = ix->ids; ma.round_rows = nullptr; ma.cand_count = nullptr;
+  ma.out_ids = d_out_ids; ma.out_dist = d_out_dist; ma.found = nullptr; ma.next_active = nullptr; ma.n_next = nullptr;
+  ma.status = nullptr;
+  ma.n_active = Q; ma.parts_per_query = nchunk * WAVES; ma.L = L; ma.k = k; ma.found_rule = 0; ma.first_round = 1;
+  ma.sentinel = sentinel;
+  return launch_merge(ix, s, ma);
+}
+
+extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_queries, int32_t Q, int32_t k,
+                                        float sentinel, int32_t* d_out_ids, float* d_out_dist, void* hip_stream) {
+  if (int rc = check_search_args(ix, KIND_PQ, d_queries, Q, k, d_out_ids, d_out_dist)) return rc;
+  if (Q == 0) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ix->stream;
+  const int qc = max_queries_per_chunk(ix, 1);
+  for (int q0 = 0; q0 < Q; q0 += qc) {
+    const int n = std::min(qc, Q - q0);
+    if (int rc = pq_chunk(ix, s, d_queries + (size_t)q0 * ix->d, n, k, sentinel, ix->blk_off, ix->packed, ix->pos,
+                          ix->n_blocks, d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k))
+      return rc;
+  }
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k, float sentinel,
+                                    const int32_t* subset_ids, int64_t n_subset, int32_t* out_ids, float* out_dist) {
+  if (int rc = check_search_args(ix, KIND_PQ, queries, Q, k, out_ids, out_dist)) return rc;
+  if (n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FREDDY_E_ARG, "bad subset");
+  if (Q == 0) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = ix->stream;
+  if (ix->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ix->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
+
+  const int32_t* blk_off = ix->blk_off;
+  const uint32_t* packed = ix->packed;
+  const int32_t* pos = ix->pos;
+  int64_t n_blocks = ix->n_blocks;
+  if (subset_ids) {
+    // "WHERE id IN (...)": unknown ids vanish, duplicates collapse, order = table order
+    std::vector<int32_t> rows;
+    rows.reserve((size_t)n_subset);
+    for (int64_t i = 0; i < n_subset; ++i) {
+      auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), subset_ids[i]);
+      if (it != ix->h_ids.end() && *it == subset_ids[i]) rows.push_back((int32_t)(it - ix->h_ids.begin()));
+    }
+    std::sort(rows.begin(), rows.end());
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    const int n_rows = (int)rows.size();
+    const int nb = (n_rows + 63) / 64;
+    const int n_pad = nb * 64;
+    const int32_t h_blk[2] = {0, nb};
+    if (ix->w_sub_rows.ensure(sizeof(int32_t) * std::max(n_rows, 1)) ||
+        ix->w_sub_packed.ensure(sizeof(uint32_t) * (size_t)std::max(nb, 1) * ix->M2 * 64) ||
+        ix->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max(n_pad, 1)) || ix->w_sub_blk.ensure(sizeof(int32_t) * 2))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    if (n_rows) HIP_TRY(hipMemcpyAsync(ix->w_sub_rows.p, rows.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ix->w_sub_blk.p, h_blk, sizeof(h_blk), hipMemcpyHostToDevice, s));
+    if (n_pad) {
+      timed_launch(ix, s, "gather_rows", [&] {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((n_pad + WG - 1) / WG), dim3(WG), 0, s, ix->w_sub_rows.as<int32_t>(),
+                           n_rows, ix->packed, ix->w_sub_packed.as<uint32_t>(), ix->w_sub_pos.as<int32_t>(), ix->M2, n_pad);
+      });
+      HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(s));  // rows / h_blk are stack/heap temporaries
+    blk_off = ix->w_sub_blk.as<int32_t>();
+    packed = ix->w_sub_packed.as<uint32_t>();
+    pos = ix->w_sub_pos.as<int32_t>();
+    n_blocks = nb;
+  }
+  const int qc = max_queries_per_chunk(ix, 1);
+  for (int q0 = 0; q0 < Q; q0 += qc) {
+    const int n = std::min(qc, Q - q0);
+    if (int rc = pq_chunk(ix, s, ix->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel, blk_off, packed, pos, n_blocks,
+                          ix->w_out_ids.as<int32_t>() + (size_t)q0 * k, ix->w_out_dist.as<float>() + (size_t)q0 * k))
+      return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_dist, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return FREDDY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// kNN-join (ivpq_search_in): host loop in join.h
+// ---------------------------------------------------------------------------------------
+extern "C" int freddy_gpu_knn_join(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k,
+                                   const int32_t* target_ids, int64_t n_targets, int32_t alpha, int32_t pvf,
+                                   int32_t method, int32_t use_target_lists, float confidence, int32_t double_threshold,
+                                   int32_t* out_ids, float* out_dist, int32_t* iterations_out) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  if (ix->kind != KIND_IVPQ) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  if (Q < 0 || k <= 0 || n_targets < 0) return fail(FREDDY_E_ARG, "bad sizes");
+  if (Q > 0 && (!queries || !out_ids || !out_dist)) return fail(FREDDY_E_ARG, "NULL buffer");
+  if (n_targets > 0 && !target_ids) return fail(FREDDY_E_ARG, "NULL target ids");
+  HIP_TRY(hipSetDevice(ix->device));
+  int rc = join_run(&ix->join, ix->stream, queries, Q, k, target_ids, n_targets, alpha, pvf, method,
+                    use_target_lists, confidence, double_threshold, out_ids, out_dist, iterations_out);
+  if (rc) return fail(rc, "%s", join_error());
+  return FREDDY_OK;
+}

@@ -1,0 +1,454 @@
+// kernels.h -- hand-written HIP kernels (gfx950 / CDNA4) for the PQ / IVFADC hot path.
+//
+// Every floating-point distance is produced by separately rounded binary32 sub, mul and
+// add in the reference's order (index_utils.c:500-508 squareDistance, :445-455
+// getPrecomputedDistances, :1126-1133 computePQDistanceInt16).  This translation unit
+// must be compiled with -ffp-contract=off; there is deliberately no fmaf and no MFMA
+// here (an FMA rounds once where the reference rounds twice).
+//
+// Pipeline of one probing round (host side: freddy_gpu.hip):
+//   transpose_queries -> coarse_dist -> probe_plan -> residual -> lut_build
+//   -> adc_scan (per-wave top-L by (distance, scan position)) -> merge_replay
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wave_topk.h"
+
+namespace freddy {
+
+static constexpr int WG = 256;           // 4 waves per workgroup
+static constexpr int WAVES = WG / 64;
+static constexpr int ROWS_PER_BLOCK = 64;  // one row block = one wave-wide coalesced load
+
+// ---------------------------------------------------------------------------------------
+// queries [Q][d] row-major -> qT [d][Qpad]  (so the coarse kernel reads lane-contiguous)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void transpose_queries_kernel(const float* __restrict__ q,
+                                                              float* __restrict__ qT, int Q,
+                                                              int Qpad, int d) {
+  const int i = blockIdx.y;                        // dimension
+  const int qi = blockIdx.x * WG + threadIdx.x;    // query
+  if (qi < Qpad) qT[(size_t)i * Qpad + qi] = (qi < Q) ? q[(size_t)qi * d + i] : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------
+// a6/a7 distances: distT[j][q] = squareDistance(query q, coarse centroid j)
+//   freddy.c:272-283, :855-866 ; index_utils.c:500-508
+// lane <-> query (coalesced qT reads, coalesced distT writes); the centroid row is
+// wave-uniform and comes through the scalar cache.  CJ centroids per thread give CJ
+// independent add chains per lane.
+// ---------------------------------------------------------------------------------------
+template <int CJ>
+__global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict__ qT,
+                                                        const float* __restrict__ coarse,
+                                                        float* __restrict__ distT, int Qpad, int C,
+                                                        int d) {
+  const int qi = blockIdx.x * WG + threadIdx.x;
+  const int j0 = blockIdx.y * CJ;
+  if (qi >= Qpad) return;
+  float acc[CJ];
+#pragma unroll
+  for (int c = 0; c < CJ; ++c) acc[c] = 0.0f;
+  for (int i = 0; i < d; ++i) {
+    const float qv = qT[(size_t)i * Qpad + qi];
+#pragma unroll
+    for (int c = 0; c < CJ; ++c) {
+      const int j = (j0 + c < C) ? (j0 + c) : (C - 1);
+      const float t = qv - coarse[(size_t)j * d + i];
+      const float p = t * t;
+      acc[c] = acc[c] + p;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CJ; ++c)
+    if (j0 + c < C) distT[(size_t)(j0 + c) * Qpad + qi] = acc[c];
+}
+
+// ---------------------------------------------------------------------------------------
+// a7 probe plan: one thread per active query replays the reference's cell selection
+//   (freddy.c:266-293): walk the cells in ascending id, skip used ones, keep the W
+//   best through updateTopK's insertion rule (list sentinel 100.0, threshold 1000.0),
+//   then mark them used.  W == 1 is exactly the batch UDF's strict-< argmin
+//   (freddy.c:853-866).  Emits W work items per query (cell -1 = no cell left).
+// ---------------------------------------------------------------------------------------
+struct PlanArgs {
+  const float* distT;       // [C][Qpad]
+  const int32_t* active;    // [n_active] query indices (NULL = identity)
+  const int32_t* list_off;  // [C+1]
+  uint32_t* used;           // [Q][used_words] bitmap of cells already probed
+  float* sel_dist;          // [n_active][W] scratch
+  int32_t* item_cell;       // [n_active*W]
+  int32_t* item_query;      // [n_active*W]
+  int32_t* round_rows;      // [n_active] rows retrieved this round, -1 = no cell was left
+  int n_active, Qpad, C, W, used_words;
+};
+
+__global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  if (x >= a.n_active) return;
+  const int q = a.active ? a.active[x] : x;
+  float* sd = a.sel_dist + (size_t)x * a.W;
+  int32_t* sc = a.item_cell + (size_t)x * a.W;
+  uint32_t* used = a.used + (size_t)q * a.used_words;
+  const int W = a.W;
+  for (int i = 0; i < W; ++i) { sd[i] = 100.0f; sc[i] = -1; }
+  float mind = 1000.0f;
+  for (int j = 0; j < a.C; ++j) {
+    if ((used[j >> 5] >> (j & 31)) & 1u) continue;
+    const float dist = a.distT[(size_t)j * a.Qpad + q];
+    if (dist < mind) {
+      int slot = W - 1;                                  // updateTopK, index_utils.c:19-33
+      while (slot >= 0 && !(sd[slot] < dist)) --slot;
+      ++slot;
+      if (slot < W) {
+        for (int t = W - 2; t >= slot; --t) { sd[t + 1] = sd[t]; sc[t + 1] = sc[t]; }
+        sd[slot] = dist;
+        sc[slot] = j;
+      }
+      mind = sd[W - 1];
+    }
+  }
+  int rows = 0, n_cells = 0;
+  for (int i = 0; i < W; ++i) {
+    const int c = sc[i];
+    a.item_query[(size_t)x * W + i] = q;
+    if (c >= 0) {
+      used[c >> 5] |= 1u << (c & 31);
+      rows += a.list_off[c + 1] - a.list_off[c];
+      ++n_cells;
+    }
+  }
+  a.round_rows[x] = n_cells ? rows : -1;   // -1: every cell already used, query retires
+}
+
+// ---------------------------------------------------------------------------------------
+// a8 residual r = q - cq[cell], elementwise binary32 (freddy.c:296-303, :876-879)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void residual_kernel(const float* __restrict__ queries,
+                                                     const float* __restrict__ coarse,
+                                                     const int32_t* __restrict__ item_cell,
+                                                     const int32_t* __restrict__ item_query,
+                                                     float* __restrict__ resid, int d) {
+  const int item = blockIdx.x;
+  const int cell = item_cell[item];
+  if (cell < 0) return;
+  const float* q = queries + (size_t)item_query[item] * d;
+  const float* c = coarse + (size_t)cell * d;
+  for (int i = threadIdx.x; i < d; i += WG) resid[(size_t)item * d + i] = q[i] - c[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// a2 LUT build: lut[item][pos*K + code] = squareDistance(r_item[pos*S..], cb[pos][code], S)
+//   index_utils.c:445-455.  This is the arithmetic-heavy phase (m*K*S*3 separately rounded
+//   ops per item, no FMA allowed), so the codebook slice of E codes per thread is pulled
+//   into registers ONCE per workgroup and reused for `items_per_wg` residuals; the
+//   residual sub-vector is wave-uniform and arrives through the scalar cache.
+//   cbT layout: [m][S][K] (code contiguous -> coalesced register fill, coalesced LUT store).
+// ---------------------------------------------------------------------------------------
+template <int S, int E>
+__global__ __launch_bounds__(WG) void lut_build_kernel(const float* __restrict__ vecs,   // [items][d] residuals (or queries)
+                                                      const int32_t* __restrict__ item_cell,  // NULL: every item valid
+                                                      const float* __restrict__ cbT,
+                                                      float* __restrict__ lut, int n_items,
+                                                      int items_per_wg, int m, int K, int d) {
+  const int p = blockIdx.x;
+  const int it0 = blockIdx.y * items_per_wg;
+  const int it1 = (it0 + items_per_wg < n_items) ? it0 + items_per_wg : n_items;
+  const size_t lutN = (size_t)m * K;
+  for (int c0 = 0; c0 < K; c0 += WG * E) {
+    float cb[E][S];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int c = c0 + e * WG + (int)threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < S; ++j) cb[e][j] = (c < K) ? cbT[((size_t)p * S + j) * K + c] : 0.0f;
+    }
+    for (int it = it0; it < it1; ++it) {
+      if (item_cell && item_cell[it] < 0) continue;
+      const float* r = vecs + (size_t)it * d + (size_t)p * S;
+      float acc[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < S; ++j) {
+        const float rj = r[j];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const float t = rj - cb[e][j];
+          const float pr = t * t;
+          acc[e] = acc[e] + pr;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int c = c0 + e * WG + (int)threadIdx.x;
+        if (c < K) lut[(size_t)it * lutN + (size_t)p * K + c] = acc[e];
+      }
+    }
+  }
+}
+
+// generic sub-vector size (runtime S): no register cache, codebook streamed from L2
+__global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __restrict__ vecs,
+                                                              const int32_t* __restrict__ item_cell,
+                                                              const float* __restrict__ cbT,
+                                                              float* __restrict__ lut, int n_items,
+                                                              int items_per_wg, int m, int K, int d,
+                                                              int S) {
+  const int p = blockIdx.x;
+  const int it0 = blockIdx.y * items_per_wg;
+  const int it1 = (it0 + items_per_wg < n_items) ? it0 + items_per_wg : n_items;
+  const size_t lutN = (size_t)m * K;
+  for (int it = it0; it < it1; ++it) {
+    if (item_cell && item_cell[it] < 0) continue;
+    const float* r = vecs + (size_t)it * d + (size_t)p * S;
+    for (int c = threadIdx.x; c < K; c += WG) {
+      float acc = 0.0f;
+      for (int j = 0; j < S; ++j) {
+        const float t = r[j] - cbT[((size_t)p * S + j) * K + c];
+        const float pr = t * t;
+        acc = acc + pr;
+      }
+      lut[(size_t)it * lutN + (size_t)p * K + c] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// a4 + a5 ADC scan with fused selection.
+//   One workgroup = one (item, chunk of row blocks).  The item's LUT (m*K floats, 48 KiB for
+//   m=12, K=1024) is staged in LDS with 16-byte loads; each wave then walks 64-row blocks:
+//   per row M2 coalesced dwords of packed int16 codes + one dword of scan position, m LDS
+//   gathers summed in position order (index_utils.c:1126-1133), and a streaming per-wave
+//   top-L on the 64-bit (distance, position) key: keys below the wave's running threshold
+//   are compacted through a 64-entry LDS staging row and absorbed by a bitonic merge only
+//   when the row fills (rare once the threshold has tightened).
+//   Output: each wave's L smallest keys -> part[((item*nchunk + chunk)*4 + wave)*L + r].
+// ---------------------------------------------------------------------------------------
+struct ScanArgs {
+  const float* lut;           // [items][m*K]
+  const int32_t* item_list;   // [items] list (cell) of the item; NULL = list 0; -1 = skip
+  const int32_t* item_query;  // [items] query of the item; NULL = item
+  const int32_t* blk_off;     // [n_lists+1] first row block of each list
+  const uint32_t* packed;     // [blocks][M2][64] two int16 codes per dword
+  const int32_t* pos;         // [blocks*64] scan position (row id / row index), -1 = padding
+  u64* part;                  // [items][nchunk][4][L]
+  int32_t* cand_count;        // [Q] += candidates with dist < sentinel (FOUND_ACCEPTED rule)
+  int m, K, chunk_blocks, nchunk, L;
+  uint32_t sentinel_bits;
+};
+
+template <int M, int V>
+__global__ __launch_bounds__(WG) void adc_scan_kernel(ScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int m = (M > 0) ? M : a.m;
+  const int K = a.K;
+  const int lutN = m * K;
+  float* lut = reinterpret_cast<float*>(smem);
+  u64* stage = reinterpret_cast<u64*>(smem + (((size_t)lutN * 4 + 15) & ~(size_t)15));
+
+  const int item = blockIdx.y, chunk = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int list = a.item_list ? a.item_list[item] : 0;
+
+  u64 acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = KEY_INF;
+  int accepted = 0;
+
+  int b0 = 0, b1 = 0;
+  if (list >= 0) {
+    b0 = a.blk_off[list] + chunk * a.chunk_blocks;
+    b1 = a.blk_off[list + 1];
+    if (b0 + a.chunk_blocks < b1) b1 = b0 + a.chunk_blocks;
+  }
+  if (b0 < b1) {  // workgroup-uniform
+    const float* src = a.lut + (size_t)item * lutN;
+    if ((lutN & 3) == 0) {
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      float4* d4 = reinterpret_cast<float4*>(lut);
+      for (int i = threadIdx.x; i < (lutN >> 2); i += WG) d4[i] = s4[i];
+    } else {
+      for (int i = threadIdx.x; i < lutN; i += WG) lut[i] = src[i];
+    }
+    __syncthreads();
+
+    const int M2 = (m + 1) >> 1;
+    u64* my_stage = stage + wave * 64;
+    const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
+    u64 tau = sentinel_key;
+    int pending = 0;   // wave-uniform
+    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    for (int b = b0 + wave; b < b1; b += WAVES) {
+      const uint32_t* pk = a.packed + (size_t)b * M2 * 64 + lane;
+      const int32_t p = a.pos[(size_t)b * 64 + lane];
+      float dist = 0.0f;
+      if (M > 0) {
+        uint32_t w[(M > 0 ? (M + 1) / 2 : 1)];
+#pragma unroll
+        for (int j = 0; j < (M + 1) / 2; ++j) w[j] = pk[j * 64];
+#pragma unroll
+        for (int l = 0; l < M; ++l) {
+          const uint32_t code = (l & 1) ? (w[l >> 1] >> 16) : (w[l >> 1] & 0xffffu);
+          dist = dist + lut[l * K + code];
+        }
+      } else {
+        for (int l = 0; l < m; l += 2) {
+          const uint32_t w = pk[(l >> 1) * 64];
+          dist = dist + lut[l * K + (w & 0xffffu)];
+          if (l + 1 < m) dist = dist + lut[(l + 1) * K + (w >> 16)];
+        }
+      }
+      const u64 key = make_key(dist, (uint32_t)p);
+      const bool valid = (p >= 0);
+      accepted += __popcll(__ballot(valid && key < sentinel_key));
+      const bool pass = valid && key < tau;
+      const u64 mask = __ballot(pass);
+      const int n = __popcll(mask);
+      if (n) {
+        if (pending + n > 64) {
+          const u64 batch = (lane < pending) ? my_stage[lane] : KEY_INF;
+          wave_topk_absorb<V>(acc, batch);
+          const u64 t = wave_topk_at<V>(acc, a.L - 1);
+          tau = (t < tau) ? t : tau;
+          pending = 0;
+          __builtin_amdgcn_wave_barrier();
+        }
+        if (pass) my_stage[pending + __popcll(mask & lt_mask)] = key;
+        pending += n;
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (pending) {
+      const u64 batch = (lane < pending) ? my_stage[lane] : KEY_INF;
+      wave_topk_absorb<V>(acc, batch);
+    }
+  }
+  u64* out = a.part + (((size_t)item * a.nchunk + chunk) * WAVES + wave) * a.L;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int r = v * 64 + lane;
+    if (r < a.L) out[r] = acc[v];
+  }
+  if (a.cand_count && lane == 0 && accepted)
+    atomicAdd(a.cand_count + (a.item_query ? a.item_query[item] : item), accepted);
+}
+
+// ---------------------------------------------------------------------------------------
+// a5 / a-T merge + replay: one wave per active query.
+//   Merges the query's partial lists down to its 2k smallest (distance, position) keys,
+//   orders those by scan position and lets lane 0 replay the reference's guarded
+//   insertion (updateTopK + "dist < maxDist", index_utils.c:19-33, freddy.c:128-131)
+//   on top of the query's carried list.  Candidates outside the 2k smallest keys can
+//   never influence the final list ("tie contract"), so this equals the
+//   reference's sequential pass over every scanned row.
+// ---------------------------------------------------------------------------------------
+struct MergeArgs {
+  const u64* part;             // [n_active][parts_per_query][L]
+  const int32_t* active;       // [n_active] or NULL
+  const int32_t* pos_to_id;    // NULL: position is the id; else id = pos_to_id[position]
+  const int32_t* round_rows;   // [n_active] rows retrieved this round
+  const int32_t* cand_count;   // [Q] accepted-candidate count this round
+  int32_t* out_ids;            // [Q][k]  carried list (state) and final result
+  float* out_dist;             // [Q][k]
+  int32_t* found;              // [Q] accumulated over rounds
+  int32_t* next_active;        // [Q] queries needing another round
+  int32_t* n_next;             // [1]
+  int32_t* status;             // [1] optional flag for the async API
+  int n_active, parts_per_query, L, k, found_rule, first_round;
+  float sentinel;
+};
+
+template <int V>
+__global__ __launch_bounds__(64) void merge_replay_kernel(MergeArgs a) {
+  __shared__ u64 cand[64 * V];
+  __shared__ int32_t s_id[64 * V > 32 ? 64 * V : 32];
+  __shared__ float s_d[64 * V > 32 ? 64 * V : 32];
+  const int x = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int q = a.active ? a.active[x] : x;
+  const int k = a.k;
+
+  u64 acc[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) acc[v] = KEY_INF;
+  const u64* src = a.part + (size_t)x * a.parts_per_query * a.L;
+  const int total = a.parts_per_query * a.L;
+  u64 tau = KEY_INF;
+  for (int base = 0; base < total; base += 64) {
+    u64 key = (base + lane < total) ? src[base + lane] : KEY_INF;
+    if (!(key < tau)) key = KEY_INF;
+    if (__ballot(key != KEY_INF) == 0ull) continue;
+    wave_topk_absorb<V>(acc, key);
+    tau = wave_topk_at<V>(acc, a.L - 1);
+  }
+  // order the survivors by scan position: re-key as (position, distance bits) and sort
+  u64 byp[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    byp[v] = (acc[v] == KEY_INF || v * 64 + lane >= a.L) ? KEY_INF : ((acc[v] << 32) | (acc[v] >> 32));
+  wave_sort_full<V>(byp);
+#pragma unroll
+  for (int v = 0; v < V; ++v) cand[v * 64 + lane] = byp[v];
+  // carried list
+  for (int i = lane; i < k; i += 64) {
+    s_id[i] = a.first_round ? -1 : a.out_ids[(size_t)q * k + i];
+    s_d[i] = a.first_round ? a.sentinel : a.out_dist[(size_t)q * k + i];
+  }
+  __syncthreads();
+  if (lane == 0) {
+    float maxd = s_d[k - 1];
+    for (int e = 0; e < a.L; ++e) {
+      const u64 c = cand[e];
+      if (c == KEY_INF) break;
+      const float dist = __uint_as_float((uint32_t)c);
+      const uint32_t p = (uint32_t)(c >> 32);
+      if (dist < maxd) {
+        int slot = k - 1;
+        while (slot >= 0 && !(s_d[slot] < dist)) --slot;
+        ++slot;
+        for (int t = k - 2; t >= slot; --t) { s_d[t + 1] = s_d[t]; s_id[t + 1] = s_id[t]; }
+        s_d[slot] = dist;
+        s_id[slot] = a.pos_to_id ? a.pos_to_id[p] : (int32_t)p;
+        maxd = s_d[k - 1];
+      }
+    }
+    // bookkeeping of "found" (freddy.c:377 rows rule, :971 accepted rule)
+    int f = a.first_round ? 0 : a.found[q];
+    const int rows = a.round_rows ? a.round_rows[x] : 0;
+    f += (a.found_rule == 1 && a.cand_count) ? a.cand_count[q] : (rows > 0 ? rows : 0);
+    if (a.found) a.found[q] = f;
+    if (a.next_active && f < k && rows >= 0) {   // rows < 0: no cell left, the query retires
+      const int slot = atomicAdd(a.n_next, 1);
+      a.next_active[slot] = q;
+      if (a.status) a.status[0] = 1;
+    }
+  }
+  __syncthreads();
+  for (int i = lane; i < k; i += 64) {
+    a.out_ids[(size_t)q * k + i] = s_id[i];
+    a.out_dist[(size_t)q * k + i] = s_d[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// pq_search_in: gather the packed codes of a row subset into a temporary list
+// ("SELECT id, vector FROM pq_quantization WHERE id IN (...)", freddy.c:1100-1114)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(WG) void gather_rows_kernel(const int32_t* __restrict__ rows, int n_rows,
+                                                        const uint32_t* __restrict__ packed,
+                                                        uint32_t* __restrict__ packed_out,
+                                                        int32_t* __restrict__ pos_out, int M2,
+                                                        int n_out_padded) {
+  const int i = blockIdx.x * WG + threadIdx.x;
+  if (i >= n_out_padded) return;
+  if (i >= n_rows) { pos_out[i] = -1; for (int j = 0; j < M2; ++j) packed_out[((size_t)(i >> 6) * M2 + j) * 64 + (i & 63)] = 0u; return; }
+  const int r = rows[i];
+  pos_out[i] = r;
+  for (int j = 0; j < M2; ++j)
+    packed_out[((size_t)(i >> 6) * M2 + j) * 64 + (i & 63)] = packed[((size_t)(r >> 6) * M2 + j) * 64 + (r & 63)];
+}
+
+}  // namespace freddy

@@ -1,0 +1,134 @@
+// wave_topk.h -- wavefront-wide (64 lanes) selection of the smallest 64-bit keys.
+//
+// A candidate is one 64-bit key  (float_bits(distance) << 32) | scan_position.
+// Distances on this path are sums of squares (>= +0, never -0), so the IEEE bit pattern
+// orders exactly like the float; the scan position (row id / row index) makes every key
+// unique, i.e. the order is total.  That is what lets a parallel selection reproduce the
+// reference's order-dependent insertion list (index_utils.c:19-33): the device selects
+// the 2k smallest keys, a single lane then replays the reference's insertion over them
+// in scan order (merge_replay kernel).
+//
+// The accumulator holds 64*V keys, ascending over index (v*64 + lane).  gfx950 only:
+// wave size is 64, cross-lane moves are ds_bpermute/DPP via __shfl.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace freddy {
+
+typedef unsigned long long u64;
+static constexpr u64 KEY_INF = ~0ull;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ u64 make_key(float dist, uint32_t pos) {
+  return ((u64)__float_as_uint(dist) << 32) | (u64)pos;
+}
+__device__ __forceinline__ float key_dist(u64 key) { return __uint_as_float((uint32_t)(key >> 32)); }
+__device__ __forceinline__ uint32_t key_pos(u64 key) { return (uint32_t)key; }
+
+__device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
+
+// Full ascending bitonic sort of 64 keys, one per lane.
+__device__ __forceinline__ u64 wave_sort64(u64 key) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const u64 other = __shfl_xor(key, j, 64);
+      const bool up = ((lane & k) == 0);
+      const bool lower = ((lane & j) == 0);
+      key = (lower == up) ? umin64(key, other) : umax64(key, other);
+    }
+  }
+  return key;
+}
+
+// Sort a bitonic sequence of 64*V keys (index v*64+lane) into ascending order.
+template <int V>
+__device__ __forceinline__ void wave_bitonic_merge(u64 (&a)[V]) {
+  const int lane = lane_id();
+  // strides >= 64 pair registers of the same lane (static indices after unrolling)
+#pragma unroll
+  for (int jv = V >> 1; jv > 0; jv >>= 1) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if ((v & jv) == 0) {
+        const u64 lo = umin64(a[v], a[v | jv]);
+        const u64 hi = umax64(a[v], a[v | jv]);
+        a[v] = lo;
+        a[v | jv] = hi;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) {
+    const bool lower = ((lane & j) == 0);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const u64 other = __shfl_xor(a[v], j, 64);
+      a[v] = lower ? umin64(a[v], other) : umax64(a[v], other);
+    }
+  }
+}
+
+// acc: 64*V smallest keys so far, ascending.  batch: up to 64 new keys, one per lane
+// (KEY_INF where empty), in any order.  Afterwards acc holds the 64*V smallest keys of
+// the union, ascending.  (min(acc_i, reversed(batch)_i) keeps exactly the smallest
+// 64*V of the union and is bitonic; only the top register can meet a real batch key.)
+template <int V>
+__device__ __forceinline__ void wave_topk_absorb(u64 (&acc)[V], u64 batch) {
+  batch = wave_sort64(batch);
+  const u64 rev = __shfl(batch, 63 - lane_id(), 64);
+  acc[V - 1] = umin64(acc[V - 1], rev);
+  wave_bitonic_merge<V>(acc);
+}
+
+// Key at global rank r (0-based) of the accumulator, broadcast to all lanes.
+template <int V>
+__device__ __forceinline__ u64 wave_topk_at(const u64 (&acc)[V], int r) {
+  u64 out = KEY_INF;
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const u64 x = __shfl(acc[v], r & 63, 64);
+    if ((r >> 6) == v) out = x;
+  }
+  return out;
+}
+
+// Full ascending bitonic sort of 64*V keys (index v*64 + lane).
+template <int V>
+__device__ __forceinline__ void wave_sort_full(u64 (&a)[V]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= 64 * V; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {
+        const int jv = j >> 6;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          if ((v & jv) == 0) {
+            const bool up = ((v & (k >> 6)) == 0);
+            const u64 lo = umin64(a[v], a[v | jv]);
+            const u64 hi = umax64(a[v], a[v | jv]);
+            a[v] = up ? lo : hi;
+            a[v | jv] = up ? hi : lo;
+          }
+        }
+      } else {
+        const bool lower = ((lane & j) == 0);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const u64 other = __shfl_xor(a[v], j, 64);
+          const bool up = (((v * 64 + lane) & k) == 0);
+          a[v] = (lower == up) ? umin64(a[v], other) : umax64(a[v], other);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace freddy

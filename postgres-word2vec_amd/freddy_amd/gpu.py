@@ -1,0 +1,238 @@
+"""ctypes binding of the C ABI in include/freddy_gpu.h (libfreddy_gpu.so).
+
+The library is the product; this module only marshals numpy arrays / device pointers
+into it.  There is NO CPU fallback: if the shared object is missing or a call fails the
+error is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libfreddy_gpu.so")
+
+FOUND_ROWS = 0
+FOUND_ACCEPTED = 1
+METHOD_PQ, METHOD_EXACT, METHOD_PQ_PV = 0, 1, 2
+
+EXPORTS = [
+    "freddy_gpu_pin_pq", "freddy_gpu_pin_ivf", "freddy_gpu_pin_ivpq", "freddy_gpu_unpin",
+    "freddy_gpu_pq_search", "freddy_gpu_ivfadc_search", "freddy_gpu_knn_join",
+    "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
+    "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
+    "freddy_gpu_last_scanned_rows",
+]
+
+
+class FreddyGpuError(RuntimeError):
+    pass
+
+
+class PQDesc(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("N", C.c_int64),
+                ("codebook", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p)]
+
+
+class IVFDesc(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("C", C.c_int32),
+                ("N", C.c_int64), ("coarse", C.c_void_p), ("codebook", C.c_void_p),
+                ("list_off", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p)]
+
+
+class IVPQDesc(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32),
+                ("coarse_positions", C.c_int32), ("coarse_codes", C.c_int32), ("N", C.c_int64),
+                ("codebook", C.c_void_p), ("coarse", C.c_void_p), ("ids", C.c_void_p),
+                ("coarse_id", C.c_void_p), ("codes", C.c_void_p), ("vectors", C.c_void_p),
+                ("stats", C.c_void_p)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FreddyGpuError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.freddy_gpu_last_error.restype = C.c_char_p
+    lib.freddy_gpu_index_bytes.restype = C.c_int64
+    lib.freddy_gpu_index_bytes.argtypes = [C.c_void_p]
+    lib.freddy_gpu_last_scanned_rows.restype = C.c_int64
+    lib.freddy_gpu_last_scanned_rows.argtypes = [C.c_void_p]
+    lib.freddy_gpu_pin_pq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.freddy_gpu_pin_ivf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.freddy_gpu_pin_ivpq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.freddy_gpu_unpin.argtypes = [C.c_void_p]
+    lib.freddy_gpu_pq_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                         C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_ivfadc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                             C.c_float, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_knn_join.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_ivfadc_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                 C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p]
+    lib.freddy_gpu_pq_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.freddy_gpu_profile_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise FreddyGpuError(f"freddy_gpu error {rc}: {load().freddy_gpu_last_error().decode()}")
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, dtype=np.int16)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _Index:
+    kind = "?"
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        self.lib = load()
+
+    def close(self):
+        if self.h:
+            self.lib.freddy_gpu_unpin(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def nbytes(self):
+        return int(self.lib.freddy_gpu_index_bytes(self.h))
+
+    def profile_enable(self, on=True):
+        _check(self.lib.freddy_gpu_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        cap = 32
+        names = ((C.c_char * 64) * cap)()
+        launches = (C.c_int64 * cap)()
+        ms = (C.c_double * cap)()
+        n = self.lib.freddy_gpu_profile_read(self.h, cap, names, launches, ms)
+        if n < 0:
+            _check(n)
+        return {names[i].value.decode(): (int(launches[i]), float(ms[i])) for i in range(min(n, cap))}
+
+
+class PQIndex(_Index):
+    """pq_codebook + pq_quantization pinned in HBM."""
+    kind = "pq"
+
+    def __init__(self, codebook, ids, codes, device=0):
+        super().__init__()
+        cb, ids, codes = _f32(codebook), _i32(ids), _i16(codes)
+        m, K, s = cb.shape
+        assert codes.shape == (ids.size, m)
+        self.d, self.m, self.K, self.N = m * s, m, K, ids.size
+        desc = PQDesc(self.d, m, K, ids.size, _p(cb), _p(ids), _p(codes))
+        _check(self.lib.freddy_gpu_pin_pq(C.byref(desc), device, C.byref(self.h)))
+
+    def search(self, queries, k, sentinel=100.0, subset_ids=None):
+        """(ids[Q,k], dist[Q,k]); subset_ids=None -> pq_search, else pq_search_in[_batch]."""
+        qs = _f32(queries).reshape(-1, self.d)
+        Q = qs.shape[0]
+        out_i = np.empty((Q, k), np.int32)
+        out_d = np.empty((Q, k), np.float32)
+        sub = None if subset_ids is None else _i32(subset_ids)
+        _check(self.lib.freddy_gpu_pq_search(self.h, _p(qs), Q, k, C.c_float(sentinel), _p(sub),
+                                             0 if sub is None else sub.size, _p(out_i), _p(out_d)))
+        return out_i, out_d
+
+    def search_dev(self, d_queries_ptr, Q, k, sentinel, d_out_ids_ptr, d_out_dist_ptr, stream=None):
+        _check(self.lib.freddy_gpu_pq_search_dev(self.h, C.c_void_p(d_queries_ptr), Q, k, C.c_float(sentinel),
+                                                 C.c_void_p(d_out_ids_ptr), C.c_void_p(d_out_dist_ptr),
+                                                 C.c_void_p(stream or 0)))
+
+
+class IVFIndex(_Index):
+    """coarse_quantization + residual_codebook + fine_quantization pinned in HBM."""
+    kind = "ivf"
+
+    def __init__(self, coarse, codebook, list_off, ids, codes, device=0):
+        super().__init__()
+        cq, cb, lo, ids, codes = _f32(coarse), _f32(codebook), _i32(list_off), _i32(ids), _i16(codes)
+        m, K, s = cb.shape
+        assert cq.shape[1] == m * s and lo.size == cq.shape[0] + 1
+        self.d, self.m, self.K, self.C, self.N = m * s, m, K, cq.shape[0], ids.size
+        desc = IVFDesc(self.d, m, K, self.C, ids.size, _p(cq), _p(cb), _p(lo), _p(ids), _p(codes))
+        _check(self.lib.freddy_gpu_pin_ivf(C.byref(desc), device, C.byref(self.h)))
+
+    def search(self, queries, k, W, sentinel=1000.0, found_rule=FOUND_ROWS):
+        qs = _f32(queries).reshape(-1, self.d)
+        Q = qs.shape[0]
+        out_i = np.empty((Q, k), np.int32)
+        out_d = np.empty((Q, k), np.float32)
+        _check(self.lib.freddy_gpu_ivfadc_search(self.h, _p(qs), Q, k, W, C.c_float(sentinel), found_rule,
+                                                 _p(out_i), _p(out_d)))
+        return out_i, out_d
+
+    def search_dev(self, d_queries_ptr, Q, k, W, sentinel, found_rule, d_out_ids_ptr, d_out_dist_ptr,
+                   d_status_ptr=0, stream=None):
+        _check(self.lib.freddy_gpu_ivfadc_search_dev(self.h, C.c_void_p(d_queries_ptr), Q, k, W,
+                                                     C.c_float(sentinel), found_rule,
+                                                     C.c_void_p(d_out_ids_ptr), C.c_void_p(d_out_dist_ptr),
+                                                     C.c_void_p(d_status_ptr or 0), C.c_void_p(stream or 0)))
+
+    def last_scanned_rows(self):
+        return int(self.lib.freddy_gpu_last_scanned_rows(self.h))
+
+
+class IVPQIndex(_Index):
+    """codebook_ivpq + coarse multi-index + fine_quantization_ivpq (+vectors, stats) in HBM."""
+    kind = "ivpq"
+
+    def __init__(self, codebook, coarse, ids, coarse_id, codes, vectors, stats, device=0):
+        super().__init__()
+        cb, cq, ids, cid, codes, st = (_f32(codebook), _f32(coarse), _i32(ids), _i32(coarse_id),
+                                       _i16(codes), _f32(stats))
+        vec = None if vectors is None else _f32(vectors)
+        m, K, s = cb.shape
+        cpos, ccodes, _ = cq.shape
+        self.d, self.m, self.K, self.N = m * s, m, K, ids.size
+        desc = IVPQDesc(self.d, m, K, cpos, ccodes, ids.size, _p(cb), _p(cq), _p(ids), _p(cid), _p(codes),
+                        _p(vec), _p(st))
+        _check(self.lib.freddy_gpu_pin_ivpq(C.byref(desc), device, C.byref(self.h)))
+
+    def knn_join(self, queries, k, target_ids, alpha, pvf, method, use_target_lists=True, confidence=0.8,
+                 double_threshold=10000000):
+        qs = _f32(queries).reshape(-1, self.d)
+        tid = _i32(target_ids)
+        Q = qs.shape[0]
+        out_i = np.empty((Q, k), np.int32)
+        out_d = np.empty((Q, k), np.float32)
+        iters = C.c_int32(0)
+        _check(self.lib.freddy_gpu_knn_join(self.h, _p(qs), Q, k, _p(tid), tid.size, alpha, pvf, method,
+                                            1 if use_target_lists else 0, C.c_float(confidence),
+                                            double_threshold, _p(out_i), _p(out_d), C.byref(iters)))
+        return out_i, out_d, iters.value

@@ -1,0 +1,118 @@
+"""-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded
+tables.  Bar: bit-exact (id, rank) AND bit-exact binary32 distance for every ADC result
+(the ADC distance is an order-fixed fp32 sum, so there is no tolerance to grant)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from freddy_amd import gpu as g
+    g.load()
+    return g
+
+
+@pytest.mark.parametrize("K", [256, 1024])
+def test_pq_search_matches_oracle(gpu, oracle, K):
+    N = 20000
+    t = util.pq_tables(N=N, K=K)
+    ot = oracle.pq_table(t["codebook"], t["ids"], t["codes"])
+    idx = gpu.PQIndex(t["codebook"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 16)
+    for k in (1, 5, 17):
+        gi, gd = idx.search(qs, k, sentinel=100.0)
+        exp = np.stack([oracle.pq_search(ot, q, k) for q in qs])
+        util.assert_same_lists(gi, gd, exp, f"pq_search K={K} k={k}")
+    idx.close()
+
+
+def test_pq_search_in_and_batch(gpu, oracle):
+    N = 20000
+    t = util.pq_tables(N=N, K=256)
+    ot = oracle.pq_table(t["codebook"], t["ids"], t["codes"])
+    idx = gpu.PQIndex(t["codebook"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 12)
+    rng = np.random.default_rng(3)
+    targets = rng.choice(np.arange(1, N + 1), size=3000, replace=False).astype(np.int32)
+    targets = np.concatenate([targets, targets[:50], np.array([N + 5, -3], np.int32)])  # dups + unknown ids
+    k = 5
+    gi, gd = idx.search(qs, k, sentinel=1000.0, subset_ids=targets)
+    exp_b = oracle.pq_search_in_batch(ot, qs, k, targets, use_target_lists=True)
+    exp_n = oracle.pq_search_in_batch(ot, qs, k, targets, use_target_lists=False)
+    assert np.array_equal(exp_b, exp_n)
+    util.assert_same_lists(gi, gd, exp_b, "pq_search_in_batch")
+    exp_1 = oracle.pq_search_in(ot, qs[0], k, targets)
+    util.assert_same_lists(gi[:1], gd[:1], exp_1, "pq_search_in")
+    # fewer targets than k: sentinel rows survive
+    gi, gd = idx.search(qs[:2], 7, sentinel=1000.0, subset_ids=targets[:3])
+    exp = np.stack([oracle.pq_search_in(ot, q, 7, targets[:3]) for q in qs[:2]])
+    util.assert_same_lists(gi, gd, exp, "pq_search_in short")
+    # empty subset
+    gi, gd = idx.search(qs[:2], 3, sentinel=1000.0, subset_ids=np.array([N + 9], np.int32))
+    assert (gi == -1).all() and (gd == np.float32(1000.0)).all()
+    idx.close()
+
+
+@pytest.mark.parametrize("K,W", [(256, 1), (256, 3), (256, 10), (1024, 3)])
+def test_ivfadc_matches_oracle(gpu, oracle, K, W):
+    N = 20000
+    t = util.ivf_tables(N=N, C=32, K=K)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 64)
+    for k in (1, 5, 20):
+        gi, gd = idx.search(qs, k, W, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"ivfadc K={K} W={W} k={k}")
+    idx.close()
+
+
+def test_ivfadc_batch_udf_semantics(gpu, oracle):
+    """W=1, sentinel 100.0, found = accepted insertions == ivfadc_batch_search (freddy.c:679-999)."""
+    N = 20000
+    t = util.ivf_tables(N=N, C=32, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 100)
+    gi, gd = idx.search(qs, 5, 1, sentinel=100.0, found_rule=gpu.FOUND_ACCEPTED)
+    exp = oracle.ivfadc_batch_search(ot, qs, 5)
+    util.assert_same_lists(gi, gd, exp, "ivfadc_batch_search")
+    idx.close()
+
+
+def test_ivfadc_multi_round_tiny_cells(gpu, oracle):
+    """Cells with fewer than k rows force the reference's extra probing rounds (freddy.c:262,:377)."""
+    N = 600
+    x = util.corpus(N)
+    from freddy_amd import index_build as ib
+    t = ib.build_ivf_index(x, C=150, m=12, K=64, train_size=N, iters=3, seed=9)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    qs = x.numpy()[::7].astype(np.float32)
+    for W, k, rule, sent in [(1, 10, 0, 1000.0), (2, 25, 0, 1000.0), (1, 10, 1, 100.0), (3, 40, 1, 100.0), (200, 5, 0, 1000.0)]:
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        exp = oracle.ivfadc_search_many(ot, qs, k, min(W, 150), sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"multi-round W={W} k={k} rule={rule}")
+    # k larger than the whole table: every row is returned, the rest stays sentinel
+    gi, gd = idx.search(qs[:3], 64 * 8, 150, sentinel=1000.0, found_rule=0)
+    exp = oracle.ivfadc_search_many(ot, qs[:3], 64 * 8, 150, sentinel=1000.0, found_rule=0)
+    util.assert_same_lists(gi, gd, exp, "k > N")
+    idx.close()
+
+
+def test_large_k(gpu, oracle):
+    """k*pvf-sized requests of the SQL post-verification wrappers (freddy--0.0.1.sql:556-591)."""
+    N = 20000
+    t = util.ivf_tables(N=N, C=32, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 6)
+    for k in (33, 100, 500):
+        gi, gd = idx.search(qs, k, 3, sentinel=1000.0, found_rule=0)
+        exp = oracle.ivfadc_search_many(ot, qs, k, 3, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"large k={k}")
+    idx.close()
