@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- batched IVFADC kNN throughput (BASELINE.json metric) on N MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic queries that are already
+resident in HBM: coarse distances -> probe plan -> residuals -> LUT build -> ADC scan with
+fused top-k -> merge/replay (+ the RCCL gather of the per-shard top-k when N > 1).
+
+Workload (BASELINE.json configs[2]): 3,000,000 x 300-d synthetic GoogleNews-shaped corpus,
+C=1000 coarse cells, m=12, K=1024 residual PQ, nprobe W=10, k=5, 1024 queries per GPU
+(replicated index, queries sharded by rank -> "weak" scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  "roofline":     dominant kernel, algorithmic bytes / its HIP-event duration vs 8 TB/s HBM
+  "cpu_baseline": the CPU oracle (oracle/, a port of the reference loops) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "postgres-word2vec_amd")]
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--N", type=int, default=3_000_000)
+    ap.add_argument("--Q", type=int, default=1024, help="queries per GPU per step")
+    ap.add_argument("--C", type=int, default=1000)
+    ap.add_argument("--m", type=int, default=12)
+    ap.add_argument("--K", type=int, default=1024)
+    ap.add_argument("--nprobe", type=int, default=10)
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--no-recall", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from freddy_amd import gpu, index_build as ib
+
+    def log(*x):
+        if rank == 0:
+            print("[bench]", *x, file=sys.stderr, flush=True)
+
+    # ---- synthetic corpus + index (every rank builds the identical replica) -----------------
+    t0 = time.time()
+    x = ib.make_corpus(a.N, d=300, seed=20260101, device=dev)
+    tab = ib.build_ivf_index(x, C=a.C, m=a.m, K=a.K, train_size=100000, iters=10, seed=2)
+    log(f"corpus+index built in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=local_rank)
+    log(f"pinned {index.nbytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
+
+    # queries = indexed vectors themselves (ivfadc_batch_search takes ids), distinct per rank
+    rng = np.random.default_rng(7 + rank)
+    qids = np.sort(rng.choice(np.arange(1, a.N + 1), size=a.Q, replace=False)).astype(np.int64)
+    d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
+    d_ids = torch.empty((a.Q, a.k), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((a.Q, a.k), dtype=torch.float32, device=dev)
+    d_status = torch.zeros(4, dtype=torch.int32, device=dev)
+    if world > 1:
+        g_ids = torch.empty((world * a.Q, a.k), dtype=torch.int32, device=dev)
+        g_dist = torch.empty((world * a.Q, a.k), dtype=torch.float32, device=dev)
+
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        index.search_dev(d_q.data_ptr(), a.Q, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, d_ids.data_ptr(),
+                         d_dist.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(g_ids, d_ids)
+            dist.all_gather_into_tensor(g_dist, d_dist)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    qps = world * a.Q * a.steps / dt
+
+    # ---- per-kernel durations with HIP events on the launch stream (instrumented re-run) ----
+    index.profile_enable(True)
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    prof = index.profile_read()
+    index.profile_enable(False)
+    scanned_rows = index.last_scanned_rows()
+    straggler = int(d_status[0].item())
+
+    out = None
+    if rank == 0:
+        # algorithmic bytes per query: sum of probed list lengths * (m*2 + 4) + query + result
+        bytes_per_launch = scanned_rows * (a.m * 2 + 4) + a.Q * (300 * 4 + a.k * 8)
+        kern = {n: {"launches": l, "avg_us": 1e3 * ms / max(l, 1)} for n, (l, ms) in prof.items()}
+        dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
+        roof = None
+        if dom:
+            avg_s = prof[dom][1] / max(prof[dom][0], 1) / 1e3
+            ach = bytes_per_launch / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                    "avg_launch_us": round(avg_s * 1e6, 2)}
+
+        # ---- recall@5 vs exact search, and parity of a sample against the oracle ---------------
+        recall = None
+        if not a.no_recall:
+            exact = ib.exact_topk(x, d_q, a.k)
+            recall = ib.recall_at_k(d_ids.cpu().numpy(), exact)
+
+        cpu = None
+        if a.cpu_sample > 0:
+            from oracle.oracle import Oracle
+            o = Oracle()
+            ot = o.ivf_table(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"])
+            ns = min(a.cpu_sample, a.Q)
+            cores = os.cpu_count() or 1
+            qs = d_q[:ns].cpu().numpy()
+            t0 = time.perf_counter()
+            exp = o.ivfadc_search_many(ot, qs, a.k, a.nprobe, sentinel=1000.0, found_rule=0, n_threads=cores)
+            cdt = time.perf_counter() - t0
+            got_i = d_ids[:ns].cpu().numpy()
+            got_d = d_dist[:ns].cpu().numpy()
+            parity = bool(np.array_equal(exp["id"], got_i) and
+                          np.array_equal(exp["dist"].view(np.uint32), got_d.view(np.uint32)))
+            cpu = {"value": round(ns / cdt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                   "sample": f"first {ns} of the {a.Q} bench queries, same index, nprobe={a.nprobe}, k={a.k}; "
+                             f"oracle/ (C port of freddy.c:174-393 loops, gcc -O2, OpenMP over queries)",
+                   "parity_with_gpu_on_sample": parity}
+
+        out = {
+            "metric": "batched IVFADC kNN queries/sec (k=5) + recall@5, 3Mx300d",
+            "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "IVFADC batch (ivfadc_batch_search generalised to nprobe), "
+                                   f"{a.N}x300d, C={a.C}, m={a.m}, K={a.K}, nprobe={a.nprobe}, k={a.k}, "
+                                   f"batch={a.Q} queries per GPU, replicated index, queries sharded by rank",
+                       "N": a.N, "d": 300, "C": a.C, "m": a.m, "K": a.K, "nprobe": a.nprobe, "k": a.k,
+                       "batch_per_gpu": a.Q, "parallelism": f"dp{world}"},
+            "recall_at_5": None if recall is None else round(recall, 4),
+            "queries_needing_extra_round": straggler,
+            "roofline": roof, "kernels": kern, "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

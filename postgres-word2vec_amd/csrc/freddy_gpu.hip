@@ -88,6 +88,8 @@ struct freddy_gpu_index {
   int last_Q = 0;
   // pinned tables
   float* coarse = nullptr;      // [C][d]
+  float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
+  int Cpad = 0;
   float* cbT = nullptr;         // [m][S][K]
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
@@ -99,7 +101,7 @@ struct freddy_gpu_index {
   // ivpq extras
   JoinIndex join;
   // workspaces
-  DevBuf w_q, w_qT, w_distT, w_used, w_sel, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
+  DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
       w_sub_packed, w_sub_pos, w_sub_blk, w_status;
   // profiling
@@ -142,10 +144,10 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->coarse, ix->cbT, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->coarse, ix->coarseT, ix->cbT, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
-  DevBuf* bufs[] = {&ix->w_q, &ix->w_qT, &ix->w_distT, &ix->w_used, &ix->w_sel, &ix->w_item_cell,
+  DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
                     &ix->w_item_query, &ix->w_rows, &ix->w_resid, &ix->w_lut, &ix->w_part,
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
@@ -276,8 +278,13 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
   int rc = open_device(ix, device);
   if (!rc) {
     std::vector<float> cbT = transpose_codebook(t->codebook, ix->m, ix->K, ix->S);
+    ix->Cpad = (t->C + WG - 1) / WG * WG;
+    std::vector<float> cT((size_t)t->d * ix->Cpad, 0.0f);
+    for (int c = 0; c < t->C; ++c)
+      for (int i = 0; i < t->d; ++i) cT[(size_t)i * ix->Cpad + c] = t->coarse[(size_t)c * t->d + i];
     if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes) ||
-        upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes))
+        upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes) ||
+        upload(&ix->coarseT, cT.data(), cT.size(), &ix->bytes))
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
@@ -376,7 +383,7 @@ static int launch_scan_mv(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  timed_launch(ix, s, "adc_scan", [&] { hipLaunchKernelGGL((adc_scan_kernel<M, V>), grid, dim3(WG), lds, s, a); });
+  timed_launch(ix, s, "adc_scan", [&] { hipLaunchKernelGGL((adc_scan_kernel<M, V>), grid, dim3(SCAN_WG), lds, s, a); });
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -395,7 +402,7 @@ static int launch_scan_m(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a,
 
 static int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_items) {
   if (n_items <= 0 || a.nchunk <= 0) return 0;
-  const size_t lds = (((size_t)a.m * a.K * 4 + 15) & ~(size_t)15) + (size_t)WAVES * 64 * sizeof(u64);
+  const size_t lds = (((size_t)a.m * a.K * 4 + 15) & ~(size_t)15) + (size_t)SCAN_WAVES * 64 * sizeof(u64);
   dim3 grid((unsigned)a.nchunk, (unsigned)n_items);
   const int V = pick_V(a.L);
   if (a.m == 12) return launch_scan_m<12>(ix, s, a, grid, lds, V);
@@ -448,19 +455,21 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                         int32_t* d_status, bool sync_rounds) {
   const int d = ix->d, C = ix->C, m = ix->m, K = ix->K;
   const int L = std::min(2 * k, 64 * 16);
-  const int Qpad = (Q + WG - 1) / WG * WG;
+  (void)d;
+  const int Cpad = ix->Cpad;
   const int used_words = (C + 31) / 32;
   const size_t lutN = (size_t)m * K;
-  const int chunk_blocks = 64;
+  const int chunk_blocks = 256;   // one workgroup per (query, probed cell) unless the list is huge
   const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
   const size_t items = (size_t)Q * W;
+  if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
 
-  if (ix->w_qT.ensure(sizeof(float) * (size_t)d * Qpad) || ix->w_distT.ensure(sizeof(float) * (size_t)C * Qpad) ||
-      ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) || ix->w_sel.ensure(sizeof(float) * items) ||
+  if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
+      ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
       ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_resid.ensure(sizeof(float) * items * d) ||
       ix->w_lut.ensure(sizeof(float) * items * lutN) ||
-      ix->w_part.ensure(sizeof(u64) * items * nchunk * WAVES * L) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * L) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
       ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
       ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
@@ -468,12 +477,9 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
   HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
 
-  timed_launch(ix, s, "transpose_queries", [&] {
-    hipLaunchKernelGGL(transpose_queries_kernel, dim3(Qpad / WG, d), dim3(WG), 0, s, d_q, ix->w_qT.as<float>(), Q, Qpad, d);
-  });
   timed_launch(ix, s, "coarse_dist", [&] {
-    hipLaunchKernelGGL((coarse_dist_kernel<4>), dim3(Qpad / WG, (C + 3) / 4), dim3(WG), 0, s, ix->w_qT.as<float>(),
-                       ix->coarse, ix->w_distT.as<float>(), Qpad, C, d);
+    hipLaunchKernelGGL((coarse_dist_kernel<8>), dim3(Cpad / WG, (Q + 7) / 8), dim3(WG), 0, s, d_q, ix->coarseT,
+                       ix->w_distT.as<float>(), Q, Cpad, d);
   });
   HIP_TRY(hipGetLastError());
 
@@ -486,14 +492,24 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   for (int round = 0; round < max_rounds && n_active > 0; ++round) {
     const int n_items = n_active * W;
     PlanArgs pa;
-    pa.distT = ix->w_distT.as<float>(); pa.active = active; pa.list_off = ix->list_off;
-    pa.used = ix->w_used.as<uint32_t>(); pa.sel_dist = ix->w_sel.as<float>();
+    pa.dist = ix->w_distT.as<float>(); pa.active = active; pa.list_off = ix->list_off;
+    pa.used = ix->w_used.as<uint32_t>();
     pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
     pa.round_rows = ix->w_rows.as<int32_t>();
-    pa.n_active = n_active; pa.Qpad = Qpad; pa.C = C; pa.W = W; pa.used_words = used_words;
-    timed_launch(ix, s, "probe_plan", [&] {
-      hipLaunchKernelGGL(probe_plan_kernel, dim3((n_active + 63) / 64), dim3(64), 0, s, pa);
-    });
+    pa.n_active = n_active; pa.Cpad = Cpad; pa.C = C; pa.W = W; pa.used_words = used_words;
+    {
+      const int PV = pick_V(2 * W);
+      const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
+      timed_launch(ix, s, "probe_plan", [&] {
+        switch (PV) {
+          case 1: hipLaunchKernelGGL((probe_plan_kernel<1>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
+          case 2: hipLaunchKernelGGL((probe_plan_kernel<2>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
+          case 4: hipLaunchKernelGGL((probe_plan_kernel<4>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
+          case 8: hipLaunchKernelGGL((probe_plan_kernel<8>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
+          default: hipLaunchKernelGGL((probe_plan_kernel<16>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
+        }
+      });
+    }
     timed_launch(ix, s, "residual", [&] {
       hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
                          ix->w_resid.as<float>(), d);
@@ -515,7 +531,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     ma.cand_count = sa.cand_count; ma.out_ids = d_out_ids; ma.out_dist = d_out_dist;
     ma.found = ix->w_found.as<int32_t>(); ma.next_active = next; ma.n_next = ix->w_cnt.as<int32_t>();
     ma.status = d_status;
-    ma.n_active = n_active; ma.parts_per_query = W * nchunk * WAVES; ma.L = L; ma.k = k;
+    ma.n_active = n_active; ma.parts_per_query = W * nchunk * SCAN_WAVES; ma.L = L; ma.k = k;
     ma.found_rule = found_rule; ma.first_round = first ? 1 : 0; ma.sentinel = sentinel;
     if (int rc = launch_merge(ix, s, ma)) return rc;
     first = false;
@@ -610,7 +626,7 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)Q > 16384 && chunk_blocks < 4096) chunk_blocks *= 2;
   const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
   if (ix->w_lut.ensure(sizeof(float) * (size_t)Q * lutN) ||
-      ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * WAVES * L))
+      ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * SCAN_WAVES * L))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   if (int rc = launch_lut(ix, s, d_q, nullptr, ix->w_lut.as<float>(), Q)) return rc;
   ScanArgs sa;
@@ -624,7 +640,7 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   ma.part = sa.part; ma.active = nullptr; ma.pos_to_id = ix->ids; ma.round_rows = nullptr; ma.cand_count = nullptr;
   ma.out_ids = d_out_ids; ma.out_dist = d_out_dist; ma.found = nullptr; ma.next_active = nullptr; ma.n_next = nullptr;
   ma.status = nullptr;
-  ma.n_active = Q; ma.parts_per_query = nchunk * WAVES; ma.L = L; ma.k = k; ma.found_rule = 0; ma.first_round = 1;
+  ma.n_active = Q; ma.parts_per_query = nchunk * SCAN_WAVES; ma.L = L; ma.k = k; ma.found_rule = 0; ma.first_round = 1;
   ma.sentinel = sentinel;
   return launch_merge(ix, s, ma);
 }

@@ -18,108 +18,149 @@
 namespace freddy {
 
 static constexpr int WG = 256;           // 4 waves per workgroup
-static constexpr int WAVES = WG / 64;
 static constexpr int ROWS_PER_BLOCK = 64;  // one row block = one wave-wide coalesced load
 
 // ---------------------------------------------------------------------------------------
-// queries [Q][d] row-major -> qT [d][Qpad]  (so the coarse kernel reads lane-contiguous)
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void transpose_queries_kernel(const float* __restrict__ q,
-                                                              float* __restrict__ qT, int Q,
-                                                              int Qpad, int d) {
-  const int i = blockIdx.y;                        // dimension
-  const int qi = blockIdx.x * WG + threadIdx.x;    // query
-  if (qi < Qpad) qT[(size_t)i * Qpad + qi] = (qi < Q) ? q[(size_t)qi * d + i] : 0.0f;
-}
-
-// ---------------------------------------------------------------------------------------
-// a6/a7 distances: distT[j][q] = squareDistance(query q, coarse centroid j)
+// a6/a7 distances: dist[q][j] = squareDistance(query q, coarse centroid j)
 //   freddy.c:272-283, :855-866 ; index_utils.c:500-508
-// lane <-> query (coalesced qT reads, coalesced distT writes); the centroid row is
-// wave-uniform and comes through the scalar cache.  CJ centroids per thread give CJ
-// independent add chains per lane.
+// lane <-> cell (coarseT is [d][Cpad], so reads and the dist row writes are coalesced);
+// the query row is workgroup-uniform and comes through the scalar cache.  QJ queries per
+// thread share every centroid load and give QJ independent add chains per lane.
 // ---------------------------------------------------------------------------------------
-template <int CJ>
-__global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict__ qT,
-                                                        const float* __restrict__ coarse,
-                                                        float* __restrict__ distT, int Qpad, int C,
+template <int QJ>
+__global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict__ queries,
+                                                        const float* __restrict__ coarseT,
+                                                        float* __restrict__ dist, int Q, int Cpad,
                                                         int d) {
-  const int qi = blockIdx.x * WG + threadIdx.x;
-  const int j0 = blockIdx.y * CJ;
-  if (qi >= Qpad) return;
-  float acc[CJ];
+  const int j = blockIdx.x * WG + threadIdx.x;
+  const int q0 = blockIdx.y * QJ;
+  float acc[QJ];
+  const float* qrow[QJ];
 #pragma unroll
-  for (int c = 0; c < CJ; ++c) acc[c] = 0.0f;
-  for (int i = 0; i < d; ++i) {
-    const float qv = qT[(size_t)i * Qpad + qi];
+  for (int t = 0; t < QJ; ++t) {
+    acc[t] = 0.0f;
+    qrow[t] = queries + (size_t)((q0 + t < Q) ? (q0 + t) : (Q - 1)) * d;
+  }
+  int i = 0;
+  for (; i + 4 <= d; i += 4) {   // 4 dimensions per trip: wide scalar loads, 4 vector loads in flight
+    float cv[4];
 #pragma unroll
-    for (int c = 0; c < CJ; ++c) {
-      const int j = (j0 + c < C) ? (j0 + c) : (C - 1);
-      const float t = qv - coarse[(size_t)j * d + i];
-      const float p = t * t;
-      acc[c] = acc[c] + p;
+    for (int u = 0; u < 4; ++u) cv[u] = coarseT[(size_t)(i + u) * Cpad + j];
+#pragma unroll
+    for (int t = 0; t < QJ; ++t) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float df = qrow[t][i + u] - cv[u];
+        const float p = df * df;
+        acc[t] = acc[t] + p;
+      }
+    }
+  }
+  for (; i < d; ++i) {
+    const float cv = coarseT[(size_t)i * Cpad + j];
+#pragma unroll
+    for (int t = 0; t < QJ; ++t) {
+      const float df = qrow[t][i] - cv;
+      const float p = df * df;
+      acc[t] = acc[t] + p;
     }
   }
 #pragma unroll
-  for (int c = 0; c < CJ; ++c)
-    if (j0 + c < C) distT[(size_t)(j0 + c) * Qpad + qi] = acc[c];
+  for (int t = 0; t < QJ; ++t)
+    if (q0 + t < Q) dist[(size_t)(q0 + t) * Cpad + j] = acc[t];
 }
 
 // ---------------------------------------------------------------------------------------
-// a7 probe plan: one thread per active query replays the reference's cell selection
-//   (freddy.c:266-293): walk the cells in ascending id, skip used ones, keep the W
-//   best through updateTopK's insertion rule (list sentinel 100.0, threshold 1000.0),
-//   then mark them used.  W == 1 is exactly the batch UDF's strict-< argmin
-//   (freddy.c:853-866).  Emits W work items per query (cell -1 = no cell left).
+// a7 probe plan: one wave per active query reproduces the reference's cell selection
+//   (freddy.c:266-293): cells are offered in ascending id, used ones skipped, and the W
+//   best kept through updateTopK's insertion rule.  (The reference starts its threshold
+//   at 1000.0 over a list of 100.0 sentinels; a cell at distance >= 100 can never be
+//   inserted, so this is the guarded insertion with sentinel 100.0.)  W == 1 is the batch
+//   UDF's strict-< argmin (freddy.c:853-866).
+//   Parallel form: the 2W smallest (distance, cell id) keys are selected by the wave,
+//   ordered by cell id and replayed by lane 0 -- same argument as merge_replay below.
+//   Emits W work items per query (cell -1 = no cell left) and marks the cells used.
 // ---------------------------------------------------------------------------------------
 struct PlanArgs {
-  const float* distT;       // [C][Qpad]
+  const float* dist;        // [Q][Cpad]
   const int32_t* active;    // [n_active] query indices (NULL = identity)
   const int32_t* list_off;  // [C+1]
   uint32_t* used;           // [Q][used_words] bitmap of cells already probed
-  float* sel_dist;          // [n_active][W] scratch
   int32_t* item_cell;       // [n_active*W]
   int32_t* item_query;      // [n_active*W]
   int32_t* round_rows;      // [n_active] rows retrieved this round, -1 = no cell was left
-  int n_active, Qpad, C, W, used_words;
+  int n_active, Cpad, C, W, used_words;
 };
 
+template <int V>
 __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  if (x >= a.n_active) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64* stage = reinterpret_cast<u64*>(smem);                 // [64]
+  u64* cand = stage + 64;                                    // [64*V]
+  float* sd = reinterpret_cast<float*>(cand + 64 * V);       // [W]
+  int32_t* sc = reinterpret_cast<int32_t*>(sd + a.W);        // [W]
+  const int x = blockIdx.x;
+  const int lane = threadIdx.x;
   const int q = a.active ? a.active[x] : x;
-  float* sd = a.sel_dist + (size_t)x * a.W;
-  int32_t* sc = a.item_cell + (size_t)x * a.W;
-  uint32_t* used = a.used + (size_t)q * a.used_words;
   const int W = a.W;
-  for (int i = 0; i < W; ++i) { sd[i] = 100.0f; sc[i] = -1; }
-  float mind = 1000.0f;
-  for (int j = 0; j < a.C; ++j) {
-    if ((used[j >> 5] >> (j & 31)) & 1u) continue;
-    const float dist = a.distT[(size_t)j * a.Qpad + q];
-    if (dist < mind) {
-      int slot = W - 1;                                  // updateTopK, index_utils.c:19-33
-      while (slot >= 0 && !(sd[slot] < dist)) --slot;
-      ++slot;
-      if (slot < W) {
+  const int L = 2 * W;
+  uint32_t* used = a.used + (size_t)q * a.used_words;
+  const float* drow = a.dist + (size_t)q * a.Cpad;
+
+  WaveSelect<V> sel;
+  sel.init(stage, (u64)__float_as_uint(100.0f) << 32, L);
+  for (int base = 0; base < a.C; base += 64) {
+    const int j = base + lane;
+    bool valid = j < a.C;
+    float dv = 0.0f;
+    if (valid) {
+      valid = !((used[j >> 5] >> (j & 31)) & 1u);
+      dv = drow[j];
+    }
+    sel.push(make_key(dv, (uint32_t)j), valid);
+  }
+  sel.finish();
+  u64 byp[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+    byp[v] = (sel.acc[v] == KEY_INF || v * 64 + lane >= L) ? KEY_INF : ((sel.acc[v] << 32) | (sel.acc[v] >> 32));
+  wave_sort_full<V>(byp);
+#pragma unroll
+  for (int v = 0; v < V; ++v) cand[v * 64 + lane] = byp[v];
+  for (int i = lane; i < W; i += 64) { sd[i] = 100.0f; sc[i] = -1; }
+  __syncthreads();
+  if (lane == 0) {
+    float maxd = 100.0f;
+    for (int e = 0; e < L; ++e) {
+      const u64 c = cand[e];
+      if (c == KEY_INF) break;
+      const float dv = __uint_as_float((uint32_t)c);
+      if (dv < maxd) {
+        int slot = W - 1;                                  // updateTopK, index_utils.c:19-33
+        while (slot >= 0 && !(sd[slot] < dv)) --slot;
+        ++slot;
         for (int t = W - 2; t >= slot; --t) { sd[t + 1] = sd[t]; sc[t + 1] = sc[t]; }
-        sd[slot] = dist;
-        sc[slot] = j;
+        sd[slot] = dv;
+        sc[slot] = (int32_t)(c >> 32);
+        maxd = sd[W - 1];
       }
-      mind = sd[W - 1];
     }
+    int rows = 0, n_cells = 0;
+    for (int i = 0; i < W; ++i) {
+      const int c = sc[i];
+      if (c >= 0) {
+        used[c >> 5] |= 1u << (c & 31);
+        rows += a.list_off[c + 1] - a.list_off[c];
+        ++n_cells;
+      }
+    }
+    a.round_rows[x] = n_cells ? rows : -1;   // -1: every cell already used, the query retires
   }
-  int rows = 0, n_cells = 0;
-  for (int i = 0; i < W; ++i) {
-    const int c = sc[i];
+  __syncthreads();
+  for (int i = lane; i < W; i += 64) {
+    a.item_cell[(size_t)x * W + i] = sc[i];
     a.item_query[(size_t)x * W + i] = q;
-    if (c >= 0) {
-      used[c >> 5] |= 1u << (c & 31);
-      rows += a.list_off[c + 1] - a.list_off[c];
-      ++n_cells;
-    }
   }
-  a.round_rows[x] = n_cells ? rows : -1;   // -1: every cell already used, query retires
 }
 
 // ---------------------------------------------------------------------------------------
@@ -217,15 +258,17 @@ __global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __re
 
 // ---------------------------------------------------------------------------------------
 // a4 + a5 ADC scan with fused selection.
-//   One workgroup = one (item, chunk of row blocks).  The item's LUT (m*K floats, 48 KiB for
-//   m=12, K=1024) is staged in LDS with 16-byte loads; each wave then walks 64-row blocks:
-//   per row M2 coalesced dwords of packed int16 codes + one dword of scan position, m LDS
-//   gathers summed in position order (index_utils.c:1126-1133), and a streaming per-wave
-//   top-L on the 64-bit (distance, position) key: keys below the wave's running threshold
-//   are compacted through a 64-entry LDS staging row and absorbed by a bitonic merge only
-//   when the row fills (rare once the threshold has tightened).
-//   Output: each wave's L smallest keys -> part[((item*nchunk + chunk)*4 + wave)*L + r].
+//   One workgroup (8 waves) = one (item, chunk of row blocks).  The item's LUT (m*K floats,
+//   48 KiB for m=12, K=1024) is staged in LDS with 16-byte loads issued back to back; each
+//   wave then walks 64-row blocks with the next block's loads in flight: per row M2
+//   coalesced dwords of packed int16 codes + one dword of scan position, m LDS gathers
+//   summed in position order (index_utils.c:1126-1133), then WaveSelect on the 64-bit
+//   (distance, position) key.
+//   Output: each wave's L smallest keys -> part[((item*nchunk + chunk)*SCAN_WAVES + wave)*L + r].
 // ---------------------------------------------------------------------------------------
+static constexpr int SCAN_WG = 512;
+static constexpr int SCAN_WAVES = SCAN_WG / 64;
+
 struct ScanArgs {
   const float* lut;           // [items][m*K]
   const int32_t* item_list;   // [items] list (cell) of the item; NULL = list 0; -1 = skip
@@ -233,15 +276,22 @@ struct ScanArgs {
   const int32_t* blk_off;     // [n_lists+1] first row block of each list
   const uint32_t* packed;     // [blocks][M2][64] two int16 codes per dword
   const int32_t* pos;         // [blocks*64] scan position (row id / row index), -1 = padding
-  u64* part;                  // [items][nchunk][4][L]
+  u64* part;                  // [items][nchunk][SCAN_WAVES][L]
   int32_t* cand_count;        // [Q] += candidates with dist < sentinel (FOUND_ACCEPTED rule)
   int m, K, chunk_blocks, nchunk, L;
   uint32_t sentinel_bits;
 };
 
+template <int M2T>
+struct RowBlock {
+  uint32_t w[M2T];
+  int32_t p;
+};
+
 template <int M, int V>
-__global__ __launch_bounds__(WG) void adc_scan_kernel(ScanArgs a) {
+__global__ __launch_bounds__(SCAN_WG) void adc_scan_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int M2T = (M > 0) ? (M + 1) / 2 : 1;
   const int m = (M > 0) ? M : a.m;
   const int K = a.K;
   const int lutN = m * K;
@@ -252,9 +302,9 @@ __global__ __launch_bounds__(WG) void adc_scan_kernel(ScanArgs a) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int list = a.item_list ? a.item_list[item] : 0;
 
-  u64 acc[V];
-#pragma unroll
-  for (int v = 0; v < V; ++v) acc[v] = KEY_INF;
+  WaveSelect<V> sel;
+  const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
+  sel.init(stage + wave * 64, sentinel_key, a.L);
   int accepted = 0;
 
   int b0 = 0, b1 = 0;
@@ -268,69 +318,78 @@ __global__ __launch_bounds__(WG) void adc_scan_kernel(ScanArgs a) {
     if ((lutN & 3) == 0) {
       const float4* s4 = reinterpret_cast<const float4*>(src);
       float4* d4 = reinterpret_cast<float4*>(lut);
-      for (int i = threadIdx.x; i < (lutN >> 2); i += WG) d4[i] = s4[i];
+      const int n4 = lutN >> 2;
+      for (int i0 = 0; i0 < n4; i0 += SCAN_WG * 6) {   // six 16-byte loads in flight per lane
+        float4 t[6];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int i = i0 + u * SCAN_WG + (int)threadIdx.x;
+          if (i < n4) t[u] = s4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          const int i = i0 + u * SCAN_WG + (int)threadIdx.x;
+          if (i < n4) d4[i] = t[u];
+        }
+      }
     } else {
-      for (int i = threadIdx.x; i < lutN; i += WG) lut[i] = src[i];
+      for (int i = threadIdx.x; i < lutN; i += SCAN_WG) lut[i] = src[i];
     }
     __syncthreads();
 
-    const int M2 = (m + 1) >> 1;
-    u64* my_stage = stage + wave * 64;
-    const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
-    u64 tau = sentinel_key;
-    int pending = 0;   // wave-uniform
-    const u64 lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-
-    for (int b = b0 + wave; b < b1; b += WAVES) {
-      const uint32_t* pk = a.packed + (size_t)b * M2 * 64 + lane;
-      const int32_t p = a.pos[(size_t)b * 64 + lane];
-      float dist = 0.0f;
-      if (M > 0) {
-        uint32_t w[(M > 0 ? (M + 1) / 2 : 1)];
+    if (M > 0) {
+      RowBlock<M2T> cur, nxt;
+      int b = b0 + wave;
+      if (b < b1) {
+        const uint32_t* pk = a.packed + (size_t)b * M2T * 64 + lane;
 #pragma unroll
-        for (int j = 0; j < (M + 1) / 2; ++j) w[j] = pk[j * 64];
+        for (int j = 0; j < M2T; ++j) cur.w[j] = pk[j * 64];
+        cur.p = a.pos[(size_t)b * 64 + lane];
+      }
+      for (; b < b1; b += SCAN_WAVES) {
+        const int bn = b + SCAN_WAVES;
+        if (bn < b1) {   // wave-uniform: next block's loads fly during this block's gathers
+          const uint32_t* pk = a.packed + (size_t)bn * M2T * 64 + lane;
+#pragma unroll
+          for (int j = 0; j < M2T; ++j) nxt.w[j] = pk[j * 64];
+          nxt.p = a.pos[(size_t)bn * 64 + lane];
+        }
+        float dist = 0.0f;
 #pragma unroll
         for (int l = 0; l < M; ++l) {
-          const uint32_t code = (l & 1) ? (w[l >> 1] >> 16) : (w[l >> 1] & 0xffffu);
+          const uint32_t code = (l & 1) ? (cur.w[l >> 1] >> 16) : (cur.w[l >> 1] & 0xffffu);
           dist = dist + lut[l * K + code];
         }
-      } else {
+        const u64 key = make_key(dist, (uint32_t)cur.p);
+        const bool valid = (cur.p >= 0);
+        accepted += __popcll(__ballot(valid && key < sentinel_key));
+        sel.push(key, valid);
+        cur = nxt;
+      }
+    } else {
+      const int M2 = (m + 1) >> 1;
+      for (int b = b0 + wave; b < b1; b += SCAN_WAVES) {
+        const uint32_t* pk = a.packed + (size_t)b * M2 * 64 + lane;
+        const int32_t p = a.pos[(size_t)b * 64 + lane];
+        float dist = 0.0f;
         for (int l = 0; l < m; l += 2) {
           const uint32_t w = pk[(l >> 1) * 64];
           dist = dist + lut[l * K + (w & 0xffffu)];
           if (l + 1 < m) dist = dist + lut[(l + 1) * K + (w >> 16)];
         }
-      }
-      const u64 key = make_key(dist, (uint32_t)p);
-      const bool valid = (p >= 0);
-      accepted += __popcll(__ballot(valid && key < sentinel_key));
-      const bool pass = valid && key < tau;
-      const u64 mask = __ballot(pass);
-      const int n = __popcll(mask);
-      if (n) {
-        if (pending + n > 64) {
-          const u64 batch = (lane < pending) ? my_stage[lane] : KEY_INF;
-          wave_topk_absorb<V>(acc, batch);
-          const u64 t = wave_topk_at<V>(acc, a.L - 1);
-          tau = (t < tau) ? t : tau;
-          pending = 0;
-          __builtin_amdgcn_wave_barrier();
-        }
-        if (pass) my_stage[pending + __popcll(mask & lt_mask)] = key;
-        pending += n;
-        __builtin_amdgcn_wave_barrier();
+        const u64 key = make_key(dist, (uint32_t)p);
+        const bool valid = (p >= 0);
+        accepted += __popcll(__ballot(valid && key < sentinel_key));
+        sel.push(key, valid);
       }
     }
-    if (pending) {
-      const u64 batch = (lane < pending) ? my_stage[lane] : KEY_INF;
-      wave_topk_absorb<V>(acc, batch);
-    }
+    sel.finish();
   }
-  u64* out = a.part + (((size_t)item * a.nchunk + chunk) * WAVES + wave) * a.L;
+  u64* out = a.part + (((size_t)item * a.nchunk + chunk) * SCAN_WAVES + wave) * a.L;
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     const int r = v * 64 + lane;
-    if (r < a.L) out[r] = acc[v];
+    if (r < a.L) out[r] = sel.acc[v];
   }
   if (a.cand_count && lane == 0 && accepted)
     atomicAdd(a.cand_count + (a.item_query ? a.item_query[item] : item), accepted);

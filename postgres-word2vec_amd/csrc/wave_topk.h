@@ -131,4 +131,52 @@ __device__ __forceinline__ void wave_sort_full(u64 (&a)[V]) {
   }
 }
 
+// Streaming selection of the L smallest keys seen by one wave.  Keys below the running
+// threshold are compacted into a 64-entry LDS staging row (ballot + prefix popcount) and
+// absorbed by a bitonic merge only when the row fills up, which becomes rare once the
+// threshold has tightened (expected number of passing keys ~ L * ln(n / L)).
+template <int V>
+struct WaveSelect {
+  u64 acc[V];
+  u64 tau;      // keys >= tau can no longer enter the result
+  u64* stage;   // this wave's 64-entry LDS row
+  int pending;  // wave-uniform fill level of the row
+  int L;
+
+  __device__ __forceinline__ void init(u64* stage_row, u64 limit_key, int L_) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = KEY_INF;
+    tau = limit_key;
+    stage = stage_row;
+    pending = 0;
+    L = L_;
+  }
+  __device__ __forceinline__ void flush() {
+    const u64 batch = (lane_id() < pending) ? stage[lane_id()] : KEY_INF;
+    wave_topk_absorb<V>(acc, batch);
+    const u64 t = wave_topk_at<V>(acc, L - 1);
+    tau = (t < tau) ? t : tau;
+    pending = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  // every lane of the wave must call this (valid=false for idle lanes)
+  __device__ __forceinline__ void push(u64 key, bool valid) {
+    const bool pass = valid && key < tau;
+    const u64 mask = __ballot(pass);
+    const int n = __popcll(mask);
+    if (n) {
+      if (pending + n > 64) flush();
+      const int lane = lane_id();
+      const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+      // after a flush tau may have dropped; a key that no longer passes is still harmless
+      if (pass) stage[pending + __popcll(mask & lt)] = key;
+      pending += n;
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (pending) flush();
+  }
+};
+
 }  // namespace freddy

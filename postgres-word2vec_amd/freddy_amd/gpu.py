@@ -56,6 +56,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # torch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+        # runtimes in one process fight over the device, so when torch is around let its copy
+        # be the one the dynamic loader binds first.  (A PostgreSQL backend has no torch and
+        # simply uses /opt/rocm's runtime.)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
     if not os.path.exists(LIB_PATH):
         raise FreddyGpuError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

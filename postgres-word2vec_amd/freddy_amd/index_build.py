@@ -16,7 +16,7 @@ def _gen(seed, device):
     return g
 
 
-def make_corpus(N, d=300, seed=20260101, n_clusters=None, latent=50, spread=0.35, noise=0.02,
+def make_corpus(N, d=300, seed=20260101, n_clusters=None, latent=30, spread=0.35, noise=0.01,
                 dup_frac=0.001, device="cpu", chunk=1 << 18):
     """N x d float32, L2-normalised rows (the reference searches google_vecs_norm).
 
