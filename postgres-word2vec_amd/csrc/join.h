@@ -1,14 +1,642 @@
-// join.h -- kNN-join (ivpq_search_in) device index and host loop.  (placeholder: filled in below)
+// join.h -- kNN-join: the body of ivpq_search_in (ivpq_search_in.c:61-699) on gfx950.
+//
+// Split of work
+//   GPU  sub_dist_kernel : the 2 x coarse_codes sub-distances of every query to the
+//                          multi-index centroids (index_utils.c:297-305), fp32 sequential.
+//   host multi-index cell selection with statistics (index_utils.c:252-443): per-position
+//        stable sort, heap traversal, getConfidenceHyp (:673-682) in the host's libm --
+//        a confidence that lands on the other side of the threshold changes the candidate
+//        set, so erf/sqrt stay where the reference evaluates them.
+//   host "WHERE coarse_id IN (...) AND id IN (...)" (ivpq_search_in.c:352-401): targets are
+//        bucketed by cell once per call; a query's candidates are the buckets of its cells.
+//   GPU  join_query_kernel : one workgroup per query: LUT (index_utils.c:445-455, pair LUT
+//        :457-475) in LDS, ADC / exact distances of the query's candidates, selection by
+//        (distance, row) key, post verification (index_utils.c:477-498) and the final
+//        insertion replay -- everything that touches a distance.
+//   host alpha-doubling retry loop (ivpq_search_in.c:299-684), target-count skip rule
+//        (:553-557), re-queue of queries whose list is still at MAX_DIST (:639-669).
+//
+// Closed forms used on the device (proved in DESIGN.md, checked against the oracle's
+// literal restatement in tests/):
+//   method 0/1: final list = insertion replay, in ascending id, over the 2k smallest
+//               (distance, id) keys of the query's candidates.
+//   method 2:   the reference's append-buffer-and-qsort (updateTopKPVFast/reorderTopKPV,
+//               ivpq_search_in.c:40-57) keeps exactly the k*pvf smallest (ADC distance,
+//               arrival) keys, ascending -- given a stable qsort (glibc <= 2.36) -- and
+//               postverify walks them in that order.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
 #include "../../include/freddy_gpu.h"
+#include "wave_topk.h"
 
 namespace freddy {
-struct JoinIndex { int dummy = 0; };
-static inline const char* join_error() { return "kNN-join is not built yet"; }
-static inline int join_pin(JoinIndex*, const freddy_ivpq_desc*, int64_t*) { return FREDDY_E_LIMIT; }
-static inline void join_free(JoinIndex*) {}
-static inline int join_run(JoinIndex*, hipStream_t, const float*, int, int, const int32_t*, int64_t, int, int, int, int,
-                           float, int, int32_t*, float*, int32_t*) { return FREDDY_E_LIMIT; }
+
+static constexpr float JOIN_MAX_DIST = 1000.0f;   // ivpq_search_in.c:62
+static constexpr int JOIN_WG = 256;
+static constexpr int JOIN_WAVES = JOIN_WG / 64;
+
+static thread_local char g_join_err[384] = "";
+static inline const char* join_error() { return g_join_err; }
+static inline int join_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_join_err, sizeof(g_join_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define JOIN_HIP(expr)                                                                          \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess)                                                                       \
+      return join_fail(FREDDY_E_HIP, "%s failed: %s (join.h:%d)", #expr, hipGetErrorString(e_), __LINE__); \
+  } while (0)
+
+struct JoinIndex {
+  int d = 0, m = 0, K = 0, S = 0, Kc = 0, cells = 0;
+  int64_t N = 0;
+  bool has_vectors = false;
+  // device
+  float* cbT = nullptr;       // [m][S][K]
+  float* coarseT = nullptr;   // [2][d/2][Kc]
+  int32_t* ids = nullptr;     // [N]
+  int16_t* codes = nullptr;   // [N][m]
+  float* vectors = nullptr;   // [N][d]
+  // host
+  std::vector<int32_t> h_ids, h_cell;
+  std::vector<float> h_stats;
+  // workspaces
+  void* w[12] = {nullptr};
+  size_t wcap[12] = {0};
+};
+
+static inline int join_buf(JoinIndex* j, int slot, size_t bytes, void** out) {
+  if (bytes > j->wcap[slot]) {
+    if (j->w[slot]) (void)hipFree(j->w[slot]);
+    j->w[slot] = nullptr;
+    j->wcap[slot] = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    if (hipMalloc(&j->w[slot], want) != hipSuccess) return join_fail(FREDDY_E_NOMEM, "workspace allocation of %zu bytes failed", want);
+    j->wcap[slot] = want;
+  }
+  *out = j->w[slot];
+  return 0;
+}
+
+static inline void join_free(JoinIndex* j) {
+  void* ptrs[] = {j->cbT, j->coarseT, j->ids, j->codes, j->vectors};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (int i = 0; i < 12; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
+  *j = JoinIndex();
+}
+
+template <class T>
+static inline int join_upload(T** dst, const T* src, size_t n, int64_t* bytes) {
+  size_t sz = sizeof(T) * (n ? n : 1);
+  if (hipMalloc((void**)dst, sz) != hipSuccess) return -1;
+  if (n && hipMemcpy(*dst, src, sizeof(T) * n, hipMemcpyHostToDevice) != hipSuccess) return -1;
+  *bytes += (int64_t)sz;
+  return 0;
+}
+
+static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* bytes) {
+  j->d = t->d; j->m = t->m; j->K = t->K; j->S = t->d / t->m; j->Kc = t->coarse_codes;
+  j->cells = t->coarse_codes * t->coarse_codes;
+  j->N = t->N;
+  j->has_vectors = t->vectors != nullptr;
+  if (t->K > 32767) return join_fail(FREDDY_E_LIMIT, "K=%d does not fit an int16 code", t->K);
+  for (int64_t r = 0; r < t->N; ++r) {
+    if (r && t->ids[r] <= t->ids[r - 1]) return join_fail(FREDDY_E_ARG, "ids must be strictly ascending (row %lld)", (long long)r);
+    if (t->coarse_id[r] < 0 || t->coarse_id[r] >= j->cells) return join_fail(FREDDY_E_ARG, "coarse_id %d out of range at row %lld", t->coarse_id[r], (long long)r);
+    for (int l = 0; l < t->m; ++l) {
+      const int c = t->codes[(size_t)r * t->m + l];
+      if (c < 0 || c >= t->K) return join_fail(FREDDY_E_ARG, "code %d out of range at row %lld", c, (long long)r);
+    }
+  }
+  const int m = j->m, K = j->K, S = j->S, half = j->d / 2, Kc = j->Kc;
+  std::vector<float> cbT((size_t)m * S * K);
+  for (int p = 0; p < m; ++p)
+    for (int c = 0; c < K; ++c)
+      for (int i = 0; i < S; ++i) cbT[((size_t)p * S + i) * K + c] = t->codebook[((size_t)p * K + c) * S + i];
+  std::vector<float> cqT((size_t)2 * half * Kc);
+  for (int p = 0; p < 2; ++p)
+    for (int c = 0; c < Kc; ++c)
+      for (int i = 0; i < half; ++i) cqT[((size_t)p * half + i) * Kc + c] = t->coarse[((size_t)p * Kc + c) * half + i];
+  if (join_upload(&j->cbT, cbT.data(), cbT.size(), bytes) || join_upload(&j->coarseT, cqT.data(), cqT.size(), bytes) ||
+      join_upload(&j->ids, t->ids, (size_t)t->N, bytes) || join_upload(&j->codes, t->codes, (size_t)t->N * m, bytes) ||
+      (t->vectors && join_upload(&j->vectors, t->vectors, (size_t)t->N * t->d, bytes)))
+    return join_fail(FREDDY_E_NOMEM, "device allocation failed while pinning the ivpq tables");
+  j->h_ids.assign(t->ids, t->ids + t->N);
+  j->h_cell.assign(t->coarse_id, t->coarse_id + t->N);
+  j->h_stats.assign(t->stats, t->stats + j->cells + 1);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// sub-distances of every query to the multi-index centroids       index_utils.c:297-305
+// out[q][pos][code]; lane <-> code (coalesced centroid reads), query half-vector via scalar cache
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sub_dist_kernel(const float* __restrict__ queries,
+                                                     const float* __restrict__ coarseT,
+                                                     float* __restrict__ out, int d, int Kc) {
+  const int q = blockIdx.x, pos = blockIdx.y;
+  const int half = d / 2;
+  const float* qv = queries + (size_t)q * d + (size_t)pos * half;
+  for (int c = threadIdx.x; c < Kc; c += 64) {
+    float acc = 0.0f;
+    for (int i = 0; i < half; ++i) {
+      const float t = qv[i] - coarseT[((size_t)pos * half + i) * Kc + c];
+      const float p = t * t;
+      acc = acc + p;
+    }
+    out[((size_t)q * 2 + pos) * Kc + c] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// one workgroup per scanned query
+// ---------------------------------------------------------------------------------------
+struct JoinArgs {
+  const float* queries;       // [Q][d]
+  const int32_t* scan_query;  // [n_scan] query index
+  const int32_t* qcell_off;   // [n_scan+1] offsets into qcells
+  const int32_t* qcells;      // cells probed by each scanned query
+  const int32_t* tcell_off;   // [cells+1] target buckets by cell
+  const int32_t* trow;        // target rows, ascending inside a bucket
+  const int32_t* ids;         // [N]
+  const int16_t* codes;       // [N][m]
+  const float* vectors;       // [N][d]
+  const float* cbT;           // [m][S][K]
+  int32_t* out_ids;           // [n_scan][k]
+  float* out_dist;            // [n_scan][k]
+  int d, m, K, S, k, L, method, double_codes;
+};
+
+__device__ __forceinline__ float sqdist_seq(const float* a, const float* __restrict__ b, int n) {
+  float acc = 0.0f;                                   // index_utils.c:500-508
+  for (int i = 0; i < n; ++i) {
+    const float t = a[i] - b[i];
+    const float p = t * t;
+    acc = acc + p;
+  }
+  return acc;
+}
+
+template <int V>
+__global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int d = a.d, m = a.m, K = a.K, S = a.S, k = a.k, L = a.L;
+  const int lutN = m * K;
+  const int n_codes = a.double_codes ? m / 2 : m;
+  const int range = a.double_codes ? K * K : K;
+  // LDS carve (all offsets multiples of 16 bytes)
+  size_t off = 0;
+  float* qv = reinterpret_cast<float*>(smem + off);            off += ((size_t)d * 4 + 15) & ~(size_t)15;
+  float* lut = reinterpret_cast<float*>(smem + off);           off += ((size_t)lutN * 4 + 15) & ~(size_t)15;
+  float* lut2 = reinterpret_cast<float*>(smem + off);          off += a.double_codes ? (((size_t)n_codes * range * 4 + 15) & ~(size_t)15) : 0;
+  u64* stage = reinterpret_cast<u64*>(smem + off);             off += (size_t)JOIN_WAVES * 64 * 8;
+  u64* lists = reinterpret_cast<u64*>(smem + off);             off += (size_t)JOIN_WAVES * 64 * V * 8;
+  float* exact = reinterpret_cast<float*>(smem + off);         off += ((size_t)64 * V * 4 + 15) & ~(size_t)15;
+  float* s_d = reinterpret_cast<float*>(smem + off);           off += ((size_t)k * 4 + 15) & ~(size_t)15;
+  int32_t* s_id = reinterpret_cast<int32_t*>(smem + off);
+
+  const int x = blockIdx.x;
+  const int q = a.scan_query[x];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+
+  for (int i = threadIdx.x; i < d; i += JOIN_WG) qv[i] = a.queries[(size_t)q * d + i];
+  __syncthreads();
+  if (a.method != FREDDY_METHOD_EXACT) {
+    // getPrecomputedDistances, index_utils.c:445-455
+    for (int e = threadIdx.x; e < lutN; e += JOIN_WG) {
+      const int p = e / K, c = e - p * K;
+      float acc = 0.0f;
+      for (int i = 0; i < S; ++i) {
+        const float t = qv[p * S + i] - a.cbT[((size_t)p * S + i) * K + c];
+        const float pr = t * t;
+        acc = acc + pr;
+      }
+      lut[e] = acc;
+    }
+    __syncthreads();
+    if (a.double_codes) {
+      // getPrecomputedDistancesDouble, index_utils.c:457-475: sum of the two rounded sub-distances
+      for (int e = threadIdx.x; e < n_codes * range; e += JOIN_WG) {
+        const int i = e / range, j = e - i * range;
+        const int c0 = j % K, c1 = j / K;
+        lut2[e] = lut[(2 * i) * K + c0] + lut[(2 * i + 1) * K + c1];
+      }
+      __syncthreads();
+    }
+  }
+  const float* tab = a.double_codes ? lut2 : lut;
+
+  WaveSelect<V> sel;
+  sel.init(stage + wave * 64, (u64)__float_as_uint(JOIN_MAX_DIST) << 32, L);
+  const int c_begin = a.qcell_off[x], c_end = a.qcell_off[x + 1];
+  for (int ci = c_begin + wave; ci < c_end; ci += JOIN_WAVES) {
+    const int cell = a.qcells[ci];
+    const int r0 = a.tcell_off[cell], r1 = a.tcell_off[cell + 1];
+    for (int base = r0; base < r1; base += 64) {
+      const int t = base + lane;
+      const bool valid = t < r1;
+      float dist = 0.0f;
+      int32_t row = 0;
+      if (valid) {
+        row = a.trow[t];
+        if (a.method == FREDDY_METHOD_EXACT) {
+          dist = sqdist_seq(qv, a.vectors + (size_t)row * d, d);
+        } else {
+          const int16_t* cd = a.codes + (size_t)row * m;
+          if (a.double_codes) {
+            for (int l = 0; l < n_codes; ++l) {                 // ivpq_search_in.c:446-451 (int16 pair code)
+              const int pc = (int16_t)(cd[2 * l] + cd[2 * l + 1] * K);
+              dist = dist + tab[range * l + pc];
+            }
+          } else {
+            for (int l = 0; l < m; ++l) dist = dist + tab[K * l + cd[l]];   // index_utils.c:1126-1133
+          }
+        }
+      }
+      sel.push(make_key(dist, (uint32_t)row), valid);
+    }
+  }
+  sel.finish();
+  // gather the four waves' lists; wave 0 merges them
+#pragma unroll
+  for (int v = 0; v < V; ++v) lists[(size_t)wave * 64 * V + v * 64 + lane] = sel.acc[v];
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < JOIN_WAVES; ++w) {
+      for (int v = 0; v < V; ++v) {
+        const u64 key = lists[(size_t)w * 64 * V + v * 64 + lane];
+        if (__ballot(key != KEY_INF) == 0ull) break;   // lists are ascending: the rest is empty too
+        wave_topk_absorb<V>(sel.acc, key);
+      }
+    }
+    if (a.method == FREDDY_METHOD_PQ_PV) {
+      // survivors stay in (ADC distance, row) order: that is the order postverify walks them
+#pragma unroll
+      for (int v = 0; v < V; ++v) lists[v * 64 + lane] = (v * 64 + lane < L) ? sel.acc[v] : KEY_INF;
+    } else {
+      u64 byp[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v)
+        byp[v] = (sel.acc[v] == KEY_INF || v * 64 + lane >= L) ? KEY_INF : ((sel.acc[v] << 32) | (sel.acc[v] >> 32));
+      wave_sort_full<V>(byp);
+#pragma unroll
+      for (int v = 0; v < V; ++v) lists[v * 64 + lane] = byp[v];
+    }
+  }
+  for (int i = threadIdx.x; i < k; i += JOIN_WG) { s_d[i] = JOIN_MAX_DIST; s_id[i] = -1; }
+  __syncthreads();
+  if (a.method == FREDDY_METHOD_PQ_PV) {
+    // postverify, index_utils.c:477-498: exact distance of each of the k*pvf survivors
+    for (int e = threadIdx.x; e < L; e += JOIN_WG) {
+      const u64 c = lists[e];
+      exact[e] = (c == KEY_INF) ? 0.0f : sqdist_seq(qv, a.vectors + (size_t)key_pos(c) * d, d);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float maxd = JOIN_MAX_DIST;
+    for (int e = 0; e < L; ++e) {
+      const u64 c = lists[e];
+      if (c == KEY_INF) break;
+      float dist;
+      uint32_t row;
+      if (a.method == FREDDY_METHOD_PQ_PV) { dist = exact[e]; row = key_pos(c); }
+      else { dist = __uint_as_float((uint32_t)c); row = (uint32_t)(c >> 32); }
+      if (dist < maxd) {
+        int slot = k - 1;                                // updateTopK, index_utils.c:19-33
+        while (slot >= 0 && !(s_d[slot] < dist)) --slot;
+        ++slot;
+        for (int t = k - 2; t >= slot; --t) { s_d[t + 1] = s_d[t]; s_id[t + 1] = s_id[t]; }
+        s_d[slot] = dist;
+        s_id[slot] = a.ids[row];
+        maxd = s_d[k - 1];
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += JOIN_WG) {
+    a.out_ids[(size_t)x * k + i] = s_id[i];
+    a.out_dist[(size_t)x * k + i] = s_d[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// host: a10 multi-index traversal                               index_utils.c:252-443
+// ---------------------------------------------------------------------------------------
+static inline float join_confidence_hyp(int expect, int size, float p, int stat_size) {
+  // getConfidenceHyp, index_utils.c:673-682 (float variables, double sub-expressions)
+  if (expect > size) return 0;
+  float mu = size * p;
+  float sig = sqrt(size * p * (1.0 - p)) * (((float)stat_size - size) / ((float)stat_size - 1.0));
+  return 1.0 - 0.5 * (1.0 + erf((((float)expect) - 0.5 - mu) / (sig * sqrt(2))));
+}
+
+struct JoinSide { float dist; int code; };
+struct JoinNode { float key; int cell, p0, p1; };
+
+// per-query scratch reused between calls of one worker thread
+struct JoinTraversal {
+  std::vector<JoinNode> heap;
+  std::vector<uint32_t> traversed, queued;
+  std::vector<float> cell_dist;
+};
+
+// sides: the query's two sub-distance arrays stably sorted ascending (qsort + cmpTopKEntry,
+// index_utils.c:104-116,317-319; stable as glibc <= 2.36).  Appends visited cells to `out`.
+// Returns true iff the query exhausted every cell.
+static inline bool join_select_cells(const JoinSide* s0, const JoinSide* s1, const float* d0, const float* d1, int Kc,
+                                     const float* stats, int n_targets, int min_target, float confidence,
+                                     JoinTraversal& w, std::vector<int32_t>& out) {
+  const int cells = Kc * Kc;
+  w.cell_dist.resize(cells);
+  for (int c = 0; c < cells; ++c) {        // 0 + D0[c0] + D1[c1], index_utils.c:306-313
+    float acc = 0;
+    acc += d0[c % Kc];
+    acc += d1[c / Kc];
+    w.cell_dist[c] = acc;
+  }
+  w.traversed.assign(cells / 32 + 1, 0u);
+  w.queued.assign(cells / 32 + 1, 0u);
+  w.heap.resize(cells + 1);
+  JoinNode* h = w.heap.data();
+  int len = 1;
+  h[0].p0 = 0; h[0].p1 = 0;
+  h[0].cell = s0[0].code + Kc * s1[0].code;
+  h[0].key = w.cell_dist[h[0].cell];
+  float prob = 0.0f;
+  int emitted = 0;
+  const int stat_size = (int)stats[cells];
+  auto push = [&](const JoinNode& nd) {     // index_utils.c:118-131
+    int i = len, parent = (i - 1) / 2;
+    while (i > 0 && h[parent].key > nd.key) { h[i] = h[parent]; i = parent; parent = (parent - 1) / 2; }
+    h[i] = nd;
+    ++len;
+  };
+  auto pop = [&]() {                        // index_utils.c:133-155
+    JoinNode top = h[0];
+    h[0] = h[len - 1];
+    --len;
+    const int n = len;
+    int i = 0;
+    while (i != n) {
+      int pick = n;
+      const int child = 1 + 2 * i;
+      if (child <= n - 1 && h[child].key < h[pick].key) pick = child;
+      if (child <= n - 1 && h[child + 1].key < h[pick].key) pick = child + 1;
+      h[i] = h[pick];
+      i = pick;
+    }
+    return top;
+  };
+  while (join_confidence_hyp(min_target, n_targets, prob, stat_size) < confidence && emitted < cells) {
+    const JoinNode cur = pop();
+    const int here = cur.p0 + Kc * cur.p1;
+    w.traversed[here / 32] |= 1u << (here % 32);
+    int diag = cur.p0 + 1 + Kc * (cur.p1 - 1);
+    if (cur.p0 < Kc - 1 && (cur.p1 == 0 || (w.traversed[diag / 32] & (1u << (diag % 32))))) {
+      const int np0 = cur.p0 + 1, np1 = cur.p1, npi = np0 + Kc * np1;
+      if (!(w.queued[npi / 32] & (1u << (npi % 32)))) {
+        JoinNode nd; nd.p0 = np0; nd.p1 = np1; nd.cell = s0[np0].code + Kc * s1[np1].code; nd.key = w.cell_dist[nd.cell];
+        push(nd);
+        w.queued[npi / 32] |= 1u << (npi % 32);
+      }
+    }
+    diag = cur.p0 - 1 + Kc * (cur.p1 + 1);
+    if (cur.p1 < Kc - 1 && (cur.p0 == 0 || (w.traversed[diag / 32] & (1u << (diag % 32))))) {
+      const int np0 = cur.p0, np1 = cur.p1 + 1, npi = np0 + Kc * np1;
+      if (!(w.queued[npi / 32] & (1u << (npi % 32)))) {
+        JoinNode nd; nd.p0 = np0; nd.p1 = np1; nd.cell = s0[np0].code + Kc * s1[np1].code; nd.key = w.cell_dist[nd.cell];
+        push(nd);
+        w.queued[npi / 32] |= 1u << (npi % 32);
+      }
+    }
+    prob += stats[cur.cell];
+    out.push_back(cur.cell);
+    ++emitted;
+  }
+  return emitted >= cells;
+}
+
+static inline void join_stable_sort(JoinSide* a, int n, JoinSide* tmp) {
+  for (int width = 1; width < n; width *= 2) {
+    for (int lo = 0; lo < n; lo += 2 * width) {
+      const int mid = std::min(lo + width, n), hi = std::min(lo + 2 * width, n);
+      int i = lo, j = mid, o = lo;
+      while (i < mid && j < hi) { if (a[j].dist < a[i].dist) tmp[o++] = a[j++]; else tmp[o++] = a[i++]; }
+      while (i < mid) tmp[o++] = a[i++];
+      while (j < hi) tmp[o++] = a[j++];
+    }
+    memcpy(a, tmp, sizeof(JoinSide) * (size_t)n);
+  }
+}
+
+template <class F>
+static inline void join_parallel_for(int n, F&& f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<unsigned>(hw ? hw : 1, 32);
+  if (n < 256 || nt <= 1) { f(0, n, 0); return; }
+  std::vector<std::thread> th;
+  const int per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int lo = t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([=, &f] { f(lo, hi, t); });
+  }
+  for (auto& x : th) x.join();
+}
+
+static inline int join_pick_V(int L) {
+  if (L <= 64) return 1;
+  if (L <= 128) return 2;
+  if (L <= 256) return 4;
+  if (L <= 512) return 8;
+  if (L <= 1024) return 16;
+  return 0;
+}
+
+static inline int join_launch(hipStream_t s, const JoinArgs& a, int n_scan, int V, size_t lds) {
+  dim3 grid((unsigned)n_scan), block(JOIN_WG);
+#define JOIN_CASE(v)                                                                                         \
+  case v: {                                                                                                  \
+    static bool attr = false;                                                                                \
+    if (!attr) {                                                                                             \
+      JOIN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&join_query_kernel<v>),                     \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
+      attr = true;                                                                                           \
+    }                                                                                                        \
+    hipLaunchKernelGGL((join_query_kernel<v>), grid, block, lds, s, a);                                      \
+  } break;
+  switch (V) {
+    JOIN_CASE(1) JOIN_CASE(2) JOIN_CASE(4) JOIN_CASE(8) JOIN_CASE(16)
+    default: return join_fail(FREDDY_E_LIMIT, "unsupported selection width");
+  }
+#undef JOIN_CASE
+  JOIN_HIP(hipGetLastError());
+  return 0;
+}
+
+static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, int Q, int k, const int32_t* target_ids,
+                           int64_t n_targets, int alpha, int pvf, int method, int use_tl, float confidence,
+                           int double_threshold, int32_t* out_ids, float* out_dist, int32_t* iterations_out) {
+  if (method < 0 || method > 2) return join_fail(FREDDY_E_ARG, "Unknown computation method!");   // ivpq_search_in.c:374-376
+  if (method != FREDDY_METHOD_PQ && !j->has_vectors) return join_fail(FREDDY_E_ARG, "methods 1 and 2 need the vectors to be pinned");
+  if (n_targets > INT32_MAX) return join_fail(FREDDY_E_LIMIT, "too many targets");
+  const int d = j->d, m = j->m, K = j->K, Kc = j->Kc, cells = j->cells;
+  const int alpha_original = alpha;
+  if (pvf < 1) pvf = 1;                                                                       // :207-209
+  bool double_codes = false;
+  if (method != FREDDY_METHOD_EXACT) double_codes = ((int64_t)alpha * k > double_threshold);  // :262-266
+  if (double_codes && (int64_t)K * K > 32768) return join_fail(FREDDY_E_LIMIT, "pair codes of K=%d overflow the reference's int16", K);
+  const int64_t Lw = (method == FREDDY_METHOD_PQ_PV) ? (int64_t)k * pvf : 2 * (int64_t)k;
+  if (Lw > 1024) return join_fail(FREDDY_E_LIMIT, "k*pvf=%lld (or 2k) exceeds this build's limit of 1024", (long long)Lw);
+  const int L = (int)Lw;
+  const int V = join_pick_V(L);
+  for (int i = 0; i < Q * k; ++i) { out_ids[i] = -1; out_dist[i] = JOIN_MAX_DIST; }            // initTopKs :238
+  if (iterations_out) *iterations_out = 0;
+  if (Q == 0) return 0;
+
+  const int n_codes = double_codes ? m / 2 : m;
+  const int range = double_codes ? K * K : K;
+  auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+  size_t lds = r16((size_t)d * 4) + r16((size_t)m * K * 4) + (double_codes ? r16((size_t)n_codes * range * 4) : 0) +
+               (size_t)JOIN_WAVES * 64 * 8 + (size_t)JOIN_WAVES * 64 * V * 8 + r16((size_t)64 * V * 4) + r16((size_t)k * 4) +
+               r16((size_t)k * 4);
+  if (lds > 160 * 1024) return join_fail(FREDDY_E_LIMIT, "LDS need of %zu bytes exceeds 160 KiB (m=%d K=%d k*pvf=%d)", lds, m, K, L);
+
+  // "fq.id IN (targets)": rows ascending, de-duplicated; bucketed by cell (ascending row inside)
+  std::vector<int32_t> trows;
+  trows.reserve((size_t)n_targets);
+  for (int64_t i = 0; i < n_targets; ++i) {
+    auto it = std::lower_bound(j->h_ids.begin(), j->h_ids.end(), target_ids[i]);
+    if (it != j->h_ids.end() && *it == target_ids[i]) trows.push_back((int32_t)(it - j->h_ids.begin()));
+  }
+  std::sort(trows.begin(), trows.end());
+  trows.erase(std::unique(trows.begin(), trows.end()), trows.end());
+  std::vector<int32_t> tcell_off(cells + 1, 0), trow_by_cell(trows.size());
+  for (int32_t r : trows) tcell_off[j->h_cell[r] + 1]++;
+  for (int c = 0; c < cells; ++c) tcell_off[c + 1] += tcell_off[c];
+  {
+    std::vector<int32_t> cur(tcell_off.begin(), tcell_off.end() - 1);
+    for (int32_t r : trows) trow_by_cell[cur[j->h_cell[r]]++] = r;
+  }
+
+  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells, *d_oi, *d_od;
+  if (join_buf(j, 0, sizeof(float) * (size_t)Q * d, &d_q) || join_buf(j, 1, sizeof(float) * (size_t)Q * 2 * Kc, &d_sub) ||
+      join_buf(j, 2, sizeof(int32_t) * (size_t)(cells + 1), &d_tcell) ||
+      join_buf(j, 3, sizeof(int32_t) * std::max<size_t>(trow_by_cell.size(), 1), &d_trow) ||
+      join_buf(j, 4, sizeof(int32_t) * (size_t)Q, &d_scan) || join_buf(j, 5, sizeof(int32_t) * (size_t)(Q + 1), &d_qoff) ||
+      join_buf(j, 7, sizeof(int32_t) * (size_t)Q * k, &d_oi) || join_buf(j, 8, sizeof(float) * (size_t)Q * k, &d_od))
+    return FREDDY_E_NOMEM;
+  JOIN_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
+  JOIN_HIP(hipMemcpyAsync(d_tcell, tcell_off.data(), sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyHostToDevice, s));
+  if (!trow_by_cell.empty())
+    JOIN_HIP(hipMemcpyAsync(d_trow, trow_by_cell.data(), sizeof(int32_t) * trow_by_cell.size(), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc);
+  JOIN_HIP(hipGetLastError());
+  std::vector<float> sub((size_t)Q * 2 * Kc);
+  JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
+  JOIN_HIP(hipStreamSynchronize(s));
+
+  // per-query sorted sides (they do not depend on alpha)
+  std::vector<JoinSide> sides((size_t)Q * 2 * Kc);
+  join_parallel_for(Q, [&](int lo, int hi, int) {
+    std::vector<JoinSide> tmp(Kc);
+    for (int q = lo; q < hi; ++q)
+      for (int p = 0; p < 2; ++p) {
+        JoinSide* sp = sides.data() + ((size_t)q * 2 + p) * Kc;
+        for (int c = 0; c < Kc; ++c) { sp[c].dist = sub[((size_t)q * 2 + p) * Kc + c]; sp[c].code = c; }
+        join_stable_sort(sp, Kc, tmp.data());
+      }
+  });
+
+  std::vector<int32_t> active(Q), target_count(Q, 0);
+  for (int i = 0; i < Q; ++i) active[i] = i;
+  std::vector<std::vector<int32_t>> qcells(Q);
+  std::vector<int32_t> scan, qoff, flat, h_oi;
+  std::vector<float> h_od;
+  int iterations = 0;
+  while (!active.empty()) {                                                                 // :299
+    ++iterations;
+    const int n_active = (int)active.size();
+    std::atomic<int> all_last(1);
+    join_parallel_for(n_active, [&](int lo, int hi, int) {                                    // :327-331
+      JoinTraversal w;
+      for (int x = lo; x < hi; ++x) {
+        const int q = active[x];
+        qcells[q].clear();
+        const bool exhausted = join_select_cells(sides.data() + ((size_t)q * 2) * Kc, sides.data() + ((size_t)q * 2 + 1) * Kc,
+                                                 sub.data() + ((size_t)q * 2) * Kc, sub.data() + ((size_t)q * 2 + 1) * Kc, Kc,
+                                                 j->h_stats.data(), (int)n_targets, k * alpha, confidence, w, qcells[q]);
+        if (!exhausted) all_last.store(0);
+      }
+    });
+    const bool last = all_last.load() != 0;
+    // targetCounts (:459) and the target-list skip rule (:553-557)
+    scan.clear(); qoff.assign(1, 0); flat.clear();
+    for (int x = 0; x < n_active; ++x) {
+      const int q = active[x];
+      int64_t cnt = 0;
+      for (int32_t c : qcells[q]) cnt += tcell_off[c + 1] - tcell_off[c];
+      target_count[q] += (int)cnt;
+      if (use_tl && target_count[q] < k * alpha_original && !last) { target_count[q] = 0; continue; }
+      scan.push_back(q);
+      for (int32_t c : qcells[q]) if (tcell_off[c + 1] > tcell_off[c]) flat.push_back(c);
+      qoff.push_back((int32_t)flat.size());
+    }
+    const int n_scan = (int)scan.size();
+    if (n_scan > 0) {
+      if (join_buf(j, 6, sizeof(int32_t) * std::max<size_t>(flat.size(), 1), &d_qcells)) return FREDDY_E_NOMEM;
+      JOIN_HIP(hipMemcpyAsync(d_scan, scan.data(), sizeof(int32_t) * n_scan, hipMemcpyHostToDevice, s));
+      JOIN_HIP(hipMemcpyAsync(d_qoff, qoff.data(), sizeof(int32_t) * (n_scan + 1), hipMemcpyHostToDevice, s));
+      if (!flat.empty()) JOIN_HIP(hipMemcpyAsync(d_qcells, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, s));
+      JoinArgs a;
+      a.queries = (const float*)d_q; a.scan_query = (const int32_t*)d_scan; a.qcell_off = (const int32_t*)d_qoff;
+      a.qcells = (const int32_t*)d_qcells; a.tcell_off = (const int32_t*)d_tcell; a.trow = (const int32_t*)d_trow;
+      a.ids = j->ids; a.codes = j->codes; a.vectors = j->vectors; a.cbT = j->cbT;
+      a.out_ids = (int32_t*)d_oi; a.out_dist = (float*)d_od;
+      a.d = d; a.m = m; a.K = K; a.S = j->S; a.k = k; a.L = L; a.method = method; a.double_codes = double_codes ? 1 : 0;
+      if (int rc = join_launch(s, a, n_scan, V, lds)) return rc;
+      h_oi.resize((size_t)n_scan * k);
+      h_od.resize((size_t)n_scan * k);
+      JOIN_HIP(hipMemcpyAsync(h_oi.data(), d_oi, sizeof(int32_t) * h_oi.size(), hipMemcpyDeviceToHost, s));
+      JOIN_HIP(hipMemcpyAsync(h_od.data(), d_od, sizeof(float) * h_od.size(), hipMemcpyDeviceToHost, s));
+      JOIN_HIP(hipStreamSynchronize(s));
+      for (int x = 0; x < n_scan; ++x) {
+        memcpy(out_ids + (size_t)scan[x] * k, h_oi.data() + (size_t)x * k, sizeof(int32_t) * k);
+        memcpy(out_dist + (size_t)scan[x] * k, h_od.data() + (size_t)x * k, sizeof(float) * k);
+      }
+    }
+    if (!last) {                                                                            // :639-669
+      std::vector<int32_t> next;
+      for (int q : active) {
+        if (out_dist[(size_t)q * k + k - 1] == JOIN_MAX_DIST) {
+          for (int i = 0; i < k; ++i) { out_ids[(size_t)q * k + i] = -1; out_dist[(size_t)q * k + i] = JOIN_MAX_DIST; }
+          next.push_back(q);
+        }
+      }
+      active.swap(next);
+    } else {
+      active.clear();
+    }
+    alpha += alpha;                                                                         // :680
+  }
+  if (iterations_out) *iterations_out = iterations;
+  return 0;
+}
+
 }  // namespace freddy

@@ -116,3 +116,80 @@ def test_large_k(gpu, oracle):
         exp = oracle.ivfadc_search_many(ot, qs, k, 3, sentinel=1000.0, found_rule=0)
         util.assert_same_lists(gi, gd, exp, f"large k={k}")
     idx.close()
+
+
+def _join_setup(oracle, gpu, N=20000, k_coarse=8, K=32, m=30):
+    t = util.ivpq_tables(N=N, m=m, K=K, k_coarse=k_coarse)
+    ot = oracle.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    idx = gpu.IVPQIndex(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    return t, ot, idx
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+@pytest.mark.parametrize("use_tl", [True, False])
+def test_knn_join_matches_oracle(gpu, oracle, method, use_tl):
+    """ivpq_search_in (ivpq_search_in.c:61-699): ids and ranks bit-exact; distances bit-exact
+    (ADC and exact distances are both order-fixed fp32 sums, so 1e-5 is not even needed)."""
+    N = 20000
+    t, ot, idx = _join_setup(oracle, gpu, N)
+    _, qs = util.queries_from_corpus(N, 120, seed=21)
+    rng = np.random.default_rng(5)
+    targets = rng.choice(np.arange(1, N + 1), size=4000, replace=False).astype(np.int32)
+    for (k, alpha, pvf) in [(5, 3, 20), (5, 100, 20), (3, 1, 4), (10, 10, 7)]:
+        gi, gd, git = idx.knn_join(qs, k, targets, alpha, pvf, method, use_target_lists=use_tl, confidence=0.8)
+        exp, eit = oracle.ivpq_search_in(ot, qs, k, targets, alpha, pvf, method, use_target_lists=use_tl, confidence=0.8)
+        assert git == eit, (git, eit)
+        util.assert_same_lists(gi, gd, exp, f"knn_join method={method} tl={use_tl} k={k} alpha={alpha} pvf={pvf}")
+    idx.close()
+
+
+def test_knn_join_edge_cases(gpu, oracle):
+    N = 20000
+    t, ot, idx = _join_setup(oracle, gpu, N)
+    _, qs = util.queries_from_corpus(N, 40, seed=22)
+    rng = np.random.default_rng(6)
+    targets = rng.choice(np.arange(1, N + 1), size=300, replace=False).astype(np.int32)
+    # few targets (k*alpha > |targets| -> confidence 0 -> every cell), duplicates, unknown ids
+    t2 = np.concatenate([targets[:7], targets[:3], np.array([N + 100], np.int32)])
+    for method in (0, 1, 2):
+        for tg, k, alpha in [(t2, 5, 3), (targets, 5, 1000), (targets[:2], 5, 1), (targets, 200, 2)]:
+            pvf = 3
+            gi, gd, git = idx.knn_join(qs, k, tg, alpha, pvf, method)
+            exp, eit = oracle.ivpq_search_in(ot, qs, k, tg, alpha, pvf, method)
+            assert git == eit
+            util.assert_same_lists(gi, gd, exp, f"edge method={method} k={k} alpha={alpha} T={tg.size}")
+    # pair LUT ("double codes", ivpq_search_in.c:262-279): alpha*k > threshold
+    for method in (0, 2):
+        gi, gd, git = idx.knn_join(qs, 5, targets, 10, 4, method, double_threshold=20)
+        exp, eit = oracle.ivpq_search_in(ot, qs, 5, targets, 10, 4, method, double_threshold=20)
+        assert git == eit
+        util.assert_same_lists(gi, gd, exp, f"double codes method={method}")
+    # confidence sweep changes the probed cell sets
+    for conf in (0.1, 0.5, 0.95, 0.999):
+        gi, gd, git = idx.knn_join(qs, 5, targets, 4, 5, 2, confidence=conf)
+        exp, eit = oracle.ivpq_search_in(ot, qs, 5, targets, 4, 5, 2, confidence=conf)
+        assert git == eit
+        util.assert_same_lists(gi, gd, exp, f"confidence={conf}")
+    idx.close()
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_knn_join_alpha_doubling_rounds(gpu, oracle, method):
+    """Low confidence + few targets: queries come back with fewer than k results and are
+    re-queued with alpha doubled (ivpq_search_in.c:639-680), incl. the target-list skip rule."""
+    N = 20000
+    t, ot, idx = _join_setup(oracle, gpu, N)
+    _, qs = util.queries_from_corpus(N, 40, seed=22)
+    rng = np.random.default_rng(6)
+    targets = rng.choice(np.arange(1, N + 1), size=300, replace=False).astype(np.int32)
+    seen_multi = False
+    for (T, k, alpha, conf) in [(300, 5, 1, 0.3), (100, 3, 1, 0.5), (60, 5, 1, 0.2), (300, 20, 1, 0.05)]:
+        for use_tl in (True, False):
+            gi, gd, git = idx.knn_join(qs, k, targets[:T], alpha, 3, method, use_target_lists=use_tl, confidence=conf)
+            exp, eit = oracle.ivpq_search_in(ot, qs, k, targets[:T], alpha, 3, method, use_target_lists=use_tl,
+                                             confidence=conf)
+            assert git == eit
+            seen_multi |= eit > 1
+            util.assert_same_lists(gi, gd, exp, f"rounds method={method} T={T} k={k} conf={conf} tl={use_tl}")
+    assert seen_multi
+    idx.close()
