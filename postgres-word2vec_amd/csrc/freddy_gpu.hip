@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "fused.h"
 #include "join.h"
 
 using namespace freddy;
@@ -103,7 +104,7 @@ struct freddy_gpu_index {
   // workspaces
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_status;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_status, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -151,7 +152,8 @@ static void free_index(freddy_gpu_index* ix) {
                     &ix->w_item_query, &ix->w_rows, &ix->w_resid, &ix->w_lut, &ix->w_part,
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
-                    &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_status};
+                    &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_status, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
+                    &ix->w_surv, &ix->w_surv_cnt};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
     for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -464,15 +466,30 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   const size_t items = (size_t)Q * W;
   if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
 
+  // Fused LUT+scan path: residual PQ with m=12, S=25, K<=1024 and a selection width that one
+  // wave holds (2k <= 64).  Everything else takes the generic lut_build + adc_scan kernels.
+  const char* fenv = getenv("FREDDY_GPU_FUSED");
+  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && L <= 64;
+  const int upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  const int surv_cap = upi * std::min(64 * L, FUSED_UNIT_BLOCKS * 64);
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
       ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_resid.ensure(sizeof(float) * items * d) ||
-      ix->w_lut.ensure(sizeof(float) * items * lutN) ||
-      ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * L) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ix->w_cand.ensure(sizeof(int32_t) * Q) ||
       ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
       ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  if (fused) {
+    // cell_count[C] + cell_fill[C] + cell_start[C]; group table: 3 arrays of (items/G + C) entries
+    if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * items) ||
+        ix->w_groups.ensure(sizeof(int32_t) * 3 * (items / FUSED_G + (size_t)C + 1)) ||
+        ix->w_surv.ensure(sizeof(u64) * items * surv_cap) || ix->w_surv_cnt.ensure(sizeof(int32_t) * items))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  } else {
+    if (ix->w_lut.ensure(sizeof(float) * items * lutN) || ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * L))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  }
 
   HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
   HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
@@ -497,6 +514,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
     pa.round_rows = ix->w_rows.as<int32_t>();
     pa.n_active = n_active; pa.Cpad = Cpad; pa.C = C; pa.W = W; pa.used_words = used_words;
+    pa.cell_count = fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
+    if (fused) HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
     {
       const int PV = pick_V(2 * W);
       const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
@@ -515,25 +534,84 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                          ix->w_resid.as<float>(), d);
     });
     HIP_TRY(hipGetLastError());
-    if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
-
     HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
-    ScanArgs sa;
-    sa.lut = ix->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
-    sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ix->w_part.as<u64>();
-    sa.cand_count = ix->w_cand.as<int32_t>();
-    sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
-    memcpy(&sa.sentinel_bits, &sentinel, 4);
-    if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
+    if (fused) {
+      HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * n_items, s));
+      const size_t max_groups = (size_t)n_items / FUSED_G + (size_t)C + 1;
+      int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
+      int32_t* cell_fill = cell_count + C;
+      int32_t* cell_start = cell_count + 2 * (size_t)C;
+      int32_t* group_cell = ix->w_groups.as<int32_t>();
+      int32_t* group_first = group_cell + max_groups;
+      int32_t* group_cnt = group_first + max_groups;
+      int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
+      timed_launch(ix, s, "group_items", [&] {
+        hipLaunchKernelGGL(group_table_kernel, dim3(1), dim3(64), 0, s, cell_count, C, cell_start, group_cell, group_first,
+                           group_cnt, n_groups);
+        hipLaunchKernelGGL(bucket_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, pa.item_cell, n_items,
+                           cell_start, cell_fill, ix->w_sorted.as<int32_t>());
+      });
+      HIP_TRY(hipGetLastError());
+      FusedArgs fa;
+      fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query;
+      fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cell; fa.group_first = group_first;
+      fa.group_cnt = group_cnt; fa.n_groups = n_groups;
+      fa.cbT = ix->cbT; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
+      fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
+      fa.cand_count = (found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
+      fa.d = d; fa.K = K; fa.L = L; fa.cap = surv_cap;
+      memcpy(&fa.sentinel_bits, &sentinel, 4);
+      const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
+      const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(u64) + 64 * sizeof(u64);
+      const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
+      const size_t flds = desc_off + FUSED_G * sizeof(int32_t);
+      fa.desc_offset = (uint32_t)desc_off;
+      { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
+      static bool fattr = false;
+      if (!fattr) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_fused_kernel<25, 12, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_fused_kernel<25, 12, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        fattr = true;
+      }
+      timed_launch(ix, s, "ivf_fused", [&] {
+        if (K == FUSED_T * FUSED_E)
+          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3((unsigned)max_groups, (unsigned)upi), dim3(FUSED_T), flds, s, fa);
+        else
+          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3((unsigned)max_groups, (unsigned)upi), dim3(FUSED_T), flds, s, fa);
+      });
+      HIP_TRY(hipGetLastError());
+      MergeSurvArgs ms;
+      ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = active; ms.round_rows = pa.round_rows;
+      ms.cand_count = fa.cand_count; ms.out_ids = d_out_ids; ms.out_dist = d_out_dist;
+      ms.found = ix->w_found.as<int32_t>(); ms.next_active = next; ms.n_next = ix->w_cnt.as<int32_t>();
+      ms.status = d_status;
+      ms.n_active = n_active; ms.W = W; ms.cap = surv_cap; ms.L = L; ms.k = k; ms.found_rule = found_rule;
+      ms.first_round = first ? 1 : 0; ms.sentinel = sentinel;
+      timed_launch(ix, s, "merge_replay", [&] {
+        hipLaunchKernelGGL(merge_surv_kernel, dim3(n_active), dim3(64), 0, s, ms);
+      });
+      HIP_TRY(hipGetLastError());
+    } else {
+      if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
+      ScanArgs sa;
+      sa.lut = ix->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
+      sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ix->w_part.as<u64>();
+      sa.cand_count = ix->w_cand.as<int32_t>();
+      sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
+      memcpy(&sa.sentinel_bits, &sentinel, 4);
+      if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
 
-    MergeArgs ma;
-    ma.part = sa.part; ma.active = active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
-    ma.cand_count = sa.cand_count; ma.out_ids = d_out_ids; ma.out_dist = d_out_dist;
-    ma.found = ix->w_found.as<int32_t>(); ma.next_active = next; ma.n_next = ix->w_cnt.as<int32_t>();
-    ma.status = d_status;
-    ma.n_active = n_active; ma.parts_per_query = W * nchunk * SCAN_WAVES; ma.L = L; ma.k = k;
-    ma.found_rule = found_rule; ma.first_round = first ? 1 : 0; ma.sentinel = sentinel;
-    if (int rc = launch_merge(ix, s, ma)) return rc;
+      MergeArgs ma;
+      ma.part = sa.part; ma.active = active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
+      ma.cand_count = sa.cand_count; ma.out_ids = d_out_ids; ma.out_dist = d_out_dist;
+      ma.found = ix->w_found.as<int32_t>(); ma.next_active = next; ma.n_next = ix->w_cnt.as<int32_t>();
+      ma.status = d_status;
+      ma.n_active = n_active; ma.parts_per_query = W * nchunk * SCAN_WAVES; ma.L = L; ma.k = k;
+      ma.found_rule = found_rule; ma.first_round = first ? 1 : 0; ma.sentinel = sentinel;
+      if (int rc = launch_merge(ix, s, ma)) return rc;
+    }
     first = false;
     if (!sync_rounds) break;
 

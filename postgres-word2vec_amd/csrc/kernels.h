@@ -89,6 +89,7 @@ struct PlanArgs {
   int32_t* item_cell;       // [n_active*W]
   int32_t* item_query;      // [n_active*W]
   int32_t* round_rows;      // [n_active] rows retrieved this round, -1 = no cell was left
+  int32_t* cell_count;      // [C] fused path only (NULL otherwise): += items probing each cell
   int n_active, Cpad, C, W, used_words;
 };
 
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
         used[c >> 5] |= 1u << (c & 31);
         rows += a.list_off[c + 1] - a.list_off[c];
         ++n_cells;
+        if (a.cell_count) atomicAdd(a.cell_count + c, 1);
       }
     }
     a.round_rows[x] = n_cells ? rows : -1;   // -1: every cell already used, the query retires

@@ -57,8 +57,11 @@ def test_pq_search_in_and_batch(gpu, oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("K,W", [(256, 1), (256, 3), (256, 10), (1024, 3)])
-def test_ivfadc_matches_oracle(gpu, oracle, K, W):
+def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
+    """fused=1: ivf_fused_kernel (LUT slabs in LDS); fused=0: lut_build + adc_scan kernels."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
     N = 20000
     t = util.ivf_tables(N=N, C=32, K=K)
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
@@ -71,8 +74,10 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W):
     idx.close()
 
 
-def test_ivfadc_batch_udf_semantics(gpu, oracle):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_ivfadc_batch_udf_semantics(gpu, oracle, fused, monkeypatch):
     """W=1, sentinel 100.0, found = accepted insertions == ivfadc_batch_search (freddy.c:679-999)."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
     N = 20000
     t = util.ivf_tables(N=N, C=32, K=256)
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
@@ -84,8 +89,10 @@ def test_ivfadc_batch_udf_semantics(gpu, oracle):
     idx.close()
 
 
-def test_ivfadc_multi_round_tiny_cells(gpu, oracle):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_ivfadc_multi_round_tiny_cells(gpu, oracle, fused, monkeypatch):
     """Cells with fewer than k rows force the reference's extra probing rounds (freddy.c:262,:377)."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
     N = 600
     x = util.corpus(N)
     from freddy_amd import index_build as ib
@@ -192,4 +199,19 @@ def test_knn_join_alpha_doubling_rounds(gpu, oracle, method):
             seen_multi |= eit > 1
             util.assert_same_lists(gi, gd, exp, f"rounds method={method} T={T} k={k} conf={conf} tl={use_tl}")
     assert seen_multi
+    idx.close()
+
+
+def test_ivfadc_long_lists_overflow_units(gpu, oracle):
+    """Lists longer than 4096 rows are split into several work units of the fused kernel."""
+    N = 20000
+    t = util.ivf_tables(N=N, C=3, K=256)      # ~6.7k rows per list
+    assert np.diff(t["list_off"]).max() > 4096
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 50)
+    for W, k in [(1, 5), (2, 10), (3, 32)]:
+        gi, gd = idx.search(qs, k, W)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W)
+        util.assert_same_lists(gi, gd, exp, f"long lists W={W} k={k}")
     idx.close()
