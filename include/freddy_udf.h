@@ -1,0 +1,103 @@
+/*
+ * freddy_udf.h -- host-side mirror of the FREDDY search UDFs (C ABI, libfreddy_host.so).
+ *
+ * PostgreSQL is not available in this image, so this library stands where the extension's
+ * SRF hosts (freddy_extension/freddy.c, ivpq_search_in.c) stand: it owns what the SQL layer
+ * owns -- the tables, the set_*()/get_*() "config functions" (freddy--0.0.1.sql:5-132,188-194),
+ * id -> vector lookup, "WHERE id IN (...)" semantics, row emission -- and forwards the search
+ * itself through the device C ABI (include/freddy_gpu.h).  Function names, argument order and
+ * meaning, result row shapes and error messages follow the reference UDFs, so a test written
+ * against this header reads like a SQL call of the extension.
+ *
+ * Every function returns 0 or a negative code; freddy_udf_last_error() gives the message the
+ * reference would have raised with elog(ERROR, ...).
+ */
+#ifndef FREDDY_UDF_H
+#define FREDDY_UDF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct freddy_session freddy_session_t;
+
+/* result rows: (Id, Distance)  freddy.c:142-146 ; (QueryId, TargetId|Id, Distance)  freddy.c:643-649,988-994 */
+typedef struct freddy_row2 { int32_t id; float distance; } freddy_row2;
+typedef struct freddy_row3 { int32_t query_id; int32_t id; float distance; } freddy_row3;
+
+int freddy_session_open(int device, freddy_session_t** out);
+int freddy_session_close(freddy_session_t* s);
+const char* freddy_udf_last_error(void);
+
+/* ---- tables (what the index_creation scripts insert; rows may come in any order) -------- */
+/* google_vecs_norm (id, vector)                                   vec2database.py:47-58 */
+int freddy_load_vecs_norm(freddy_session_t* s, const int32_t* ids, const float* vectors, int64_t N, int32_t d);
+/* pq_codebook (pos, code, vector) + pq_quantization (id, vector)   pq_index.py:25-26 */
+int freddy_load_pq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* cb_code, const float* cb_vectors,
+                   int32_t n_entries, int32_t sub_dim, const int32_t* ids, const int16_t* codes, int64_t N);
+/* coarse_quantization (id, vector) + residual_codebook + fine_quantization (id, coarse_id, vector)  ivfadc.py:28-30 */
+int freddy_load_ivfadc(freddy_session_t* s, const int32_t* coarse_ids_tbl, const float* coarse_vectors, int32_t C,
+                       const int32_t* cb_pos, const int32_t* cb_code, const float* cb_vectors, int32_t n_entries,
+                       int32_t sub_dim, const int32_t* ids, const int32_t* coarse_id, const int16_t* codes, int64_t N);
+/* codebook_ivpq + coarse_quantization_ivpq (pos, code, vector) + fine_quantization_ivpq (id, coarse_id, vector)
+ * + stat table (coarse_id, coarse_freq); vectors for methods 1/2 come from google_vecs_norm.   ivpq.py:18-38 */
+int freddy_load_ivpq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* cb_code, const float* cb_vectors,
+                     int32_t n_entries, int32_t sub_dim, const int32_t* cq_pos, const int32_t* cq_code,
+                     const float* cq_vectors, int32_t n_cq_entries, const int32_t* ids, const int32_t* coarse_id,
+                     const int16_t* codes, int64_t N, const int32_t* stat_coarse_id, const float* stat_freq,
+                     int32_t n_stat);
+
+/* ---- config functions                                    freddy--0.0.1.sql:21-132, 188-194 */
+int freddy_set_w(freddy_session_t* s, int32_t w);                       /* default 3 */
+int freddy_set_pvf(freddy_session_t* s, int32_t pvf);                   /* default 20 */
+int freddy_set_alpha(freddy_session_t* s, int32_t alpha);               /* default 3 */
+int freddy_set_confidence_value(freddy_session_t* s, float c);          /* default 0.8 */
+int freddy_set_long_codes_threshold(freddy_session_t* s, int32_t t);    /* default 10000000 */
+int freddy_set_method_flag(freddy_session_t* s, int32_t m);             /* default 0 */
+int freddy_set_use_targetlist(freddy_session_t* s, int32_t flag);       /* default true */
+int32_t freddy_get_w(const freddy_session_t* s);
+int32_t freddy_get_pvf(const freddy_session_t* s);
+int32_t freddy_get_alpha(const freddy_session_t* s);
+float freddy_get_confidence_value(const freddy_session_t* s);
+int32_t freddy_get_long_codes_threshold(const freddy_session_t* s);
+int32_t freddy_get_method_flag(const freddy_session_t* s);
+int32_t freddy_get_use_targetlist(const freddy_session_t* s);
+
+/* ---- the UDFs (out arrays are caller-allocated; *n_rows receives the number of rows) ----- */
+/* pq_search(bytea, int) -> SETOF (Id, Distance)                              freddy.c:28-171 */
+int pq_search(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+/* ivfadc_search(bytea, int) -> SETOF (Id, Distance); W = get_w()            freddy.c:174-410 */
+int ivfadc_search(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+/* pq_search_in(bytea, int, int[]) -> SETOF (Id, Distance)                  freddy.c:1028-1174 */
+int pq_search_in(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids,
+                 int32_t n_ids, freddy_row2* out, int32_t* n_rows);
+/* pq_search_in_batch(bytea[], int[], int, int[], bool) -> SETOF (QueryId, TargetId, Distance)  freddy.c:412-676
+ * out holds n_queries*k rows, query-major, rank-minor. */
+int pq_search_in_batch(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim,
+                       const int32_t* query_ids, int32_t n_query_ids, int32_t k, const int32_t* input_ids,
+                       int32_t n_ids, int32_t use_target_lists, freddy_row3* out, int32_t* n_rows);
+/* ivfadc_batch_search(int[], int) -> SETOF (QueryId, Id, Distance)          freddy.c:677-1025
+ * queries = rows of google_vecs_norm whose id is in query_ids, in table order (ascending id),
+ * duplicates and unknown ids dropped; out must hold n_query_ids*k rows. */
+int ivfadc_batch_search(freddy_session_t* s, const int32_t* query_ids, int32_t n_query_ids, int32_t k,
+                        freddy_row3* out, int32_t* n_rows);
+/* ivpq_search_in(bytea[], int[], int, int[], int, int, int, bool, float4, int)   ivpq_search_in.c:59-721 */
+int ivpq_search_in(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim, const int32_t* query_ids,
+                   int32_t n_query_ids, int32_t k, const int32_t* input_ids, int32_t n_ids, int32_t alpha, int32_t pvf,
+                   int32_t method, int32_t use_target_lists, float confidence, int32_t double_threshold,
+                   freddy_row3* out, int32_t* n_rows);
+/* knn_in_ivpq_batch's parameter plumbing (freddy--0.0.1.sql:720-828): ivpq_search_in with
+ * alpha/pvf/method/use_targetlist/confidence/long_codes_threshold taken from the getters. */
+int knn_join(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim, const int32_t* query_ids,
+             int32_t k, const int32_t* input_ids, int32_t n_ids, freddy_row3* out, int32_t* n_rows);
+
+/* per-call row emit: snprintf("%d") / snprintf("%f") into 16-byte buffers   freddy.c:154-169,1001-1023 */
+void freddy_emit_row2(const freddy_row2* row, char values[2][16]);
+void freddy_emit_row3(const freddy_row3* row, char values[3][16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FREDDY_UDF_H */

@@ -1,0 +1,190 @@
+"""Python face of the host-side UDF mirror (libfreddy_host.so, include/freddy_udf.h).
+
+Function names and arguments are the reference's SQL-visible C functions
+(freddy--0.0.1.sql:334-424): `pq_search(query, k)`, `ivfadc_search(query, k)`,
+`pq_search_in(query, k, ids)`, `pq_search_in_batch(queries, query_ids, k, ids, use_targetlist)`,
+`ivfadc_batch_search(ids, k)`, `ivpq_search_in(...)`, plus `knn_join` with the parameters
+taken from the `set_*()` config functions.  Rows come back as numpy structured arrays shaped
+like the SRF records.  No CPU fallback: a missing library raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import gpu as _gpu
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "libfreddy_host.so")
+
+ROW2 = np.dtype([("id", np.int32), ("distance", np.float32)])
+ROW3 = np.dtype([("query_id", np.int32), ("id", np.int32), ("distance", np.float32)])
+
+_lib = None
+
+
+class FreddyError(RuntimeError):
+    """What the reference raises with elog(ERROR, ...)."""
+
+
+def load():
+    global _lib
+    if _lib is None:
+        _gpu.load()   # same HIP runtime ordering rule as the device library
+        if not os.path.exists(LIB_PATH):
+            raise FreddyError(f"{LIB_PATH} is missing (python -c 'import __graft_entry__ as g; g.build()')")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.freddy_udf_last_error.restype = C.c_char_p
+        _lib.freddy_get_confidence_value.restype = C.c_float
+        _lib.freddy_set_confidence_value.argtypes = [C.c_void_p, C.c_float]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, np.float32)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def _i16(a):
+    return np.ascontiguousarray(a, np.int16)
+
+
+def _entries(codebook):
+    """dense [m][K][s] -> the (pos, code, vector) rows of a codebook table."""
+    cb = _f32(codebook)
+    m, K, s = cb.shape
+    pos, code = np.divmod(np.arange(m * K, dtype=np.int32), K)
+    return _i32(pos), _i32(code), cb.reshape(m * K, s), m * K, s
+
+
+class Session:
+    """One "database": tables + config functions + the UDFs."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.h = C.c_void_p()
+        self._check(self.lib.freddy_session_open(device, C.byref(self.h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FreddyError(self.lib.freddy_udf_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.lib.freddy_session_close(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- tables ------------------------------------------------------------------------
+    def load_vecs_norm(self, ids, vectors):
+        ids, v = _i32(ids), _f32(vectors)
+        self._check(self.lib.freddy_load_vecs_norm(self.h, _p(ids), _p(v), C.c_int64(ids.size), v.shape[1]))
+
+    def load_pq(self, codebook, ids, codes):
+        pos, code, vec, n, s = _entries(codebook)
+        ids, codes = _i32(ids), _i16(codes)
+        self._check(self.lib.freddy_load_pq(self.h, _p(pos), _p(code), _p(vec), n, s, _p(ids), _p(codes),
+                                            C.c_int64(ids.size)))
+
+    def load_ivfadc(self, coarse, codebook, ids, coarse_id, codes):
+        pos, code, vec, n, s = _entries(codebook)
+        cq = _f32(coarse)
+        cids = _i32(np.arange(cq.shape[0]))
+        ids, cid, codes = _i32(ids), _i32(coarse_id), _i16(codes)
+        self._check(self.lib.freddy_load_ivfadc(self.h, _p(cids), _p(cq), cq.shape[0], _p(pos), _p(code), _p(vec), n, s,
+                                                _p(ids), _p(cid), _p(codes), C.c_int64(ids.size)))
+
+    def load_ivpq(self, codebook, coarse, ids, coarse_id, codes, stats):
+        pos, code, vec, n, s = _entries(codebook)
+        cpos, ccode, cvec, cn, _ = _entries(coarse)
+        ids, cid, codes = _i32(ids), _i32(coarse_id), _i16(codes)
+        st = _f32(stats)
+        sid = _i32(np.arange(st.size))
+        self._check(self.lib.freddy_load_ivpq(self.h, _p(pos), _p(code), _p(vec), n, s, _p(cpos), _p(ccode), _p(cvec), cn,
+                                              _p(ids), _p(cid), _p(codes), C.c_int64(ids.size), _p(sid), _p(st), st.size))
+
+    # ---- config functions ----------------------------------------------------------------
+    def set_w(self, v): self._check(self.lib.freddy_set_w(self.h, int(v)))
+    def set_pvf(self, v): self._check(self.lib.freddy_set_pvf(self.h, int(v)))
+    def set_alpha(self, v): self._check(self.lib.freddy_set_alpha(self.h, int(v)))
+    def set_confidence_value(self, v): self._check(self.lib.freddy_set_confidence_value(self.h, C.c_float(v)))
+    def set_long_codes_threshold(self, v): self._check(self.lib.freddy_set_long_codes_threshold(self.h, int(v)))
+    def set_method_flag(self, v): self._check(self.lib.freddy_set_method_flag(self.h, int(v)))
+    def set_use_targetlist(self, v): self._check(self.lib.freddy_set_use_targetlist(self.h, 1 if v else 0))
+    def get_w(self): return self.lib.freddy_get_w(self.h)
+    def get_pvf(self): return self.lib.freddy_get_pvf(self.h)
+    def get_alpha(self): return self.lib.freddy_get_alpha(self.h)
+    def get_confidence_value(self): return self.lib.freddy_get_confidence_value(self.h)
+
+    # ---- UDFs ------------------------------------------------------------------------------
+    def pq_search(self, query, k):
+        q = _f32(query)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(self.lib.pq_search(self.h, _p(q), q.size, k, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def ivfadc_search(self, query, k):
+        q = _f32(query)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(self.lib.ivfadc_search(self.h, _p(q), q.size, k, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def pq_search_in(self, query, k, input_ids):
+        q, ids = _f32(query), _i32(input_ids)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(self.lib.pq_search_in(self.h, _p(q), q.size, k, _p(ids), ids.size, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def pq_search_in_batch(self, queries, query_ids, k, input_ids, use_targetlist=True):
+        qs, qid, ids = _f32(queries), _i32(query_ids), _i32(input_ids)
+        out = np.empty(max(qs.shape[0], 1) * k, ROW3)
+        n = C.c_int32(0)
+        self._check(self.lib.pq_search_in_batch(self.h, _p(qs), qs.shape[0], qs.shape[1], _p(qid), qid.size, k, _p(ids),
+                                                ids.size, int(use_targetlist), _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def ivfadc_batch_search(self, query_ids, k):
+        qid = _i32(query_ids)
+        out = np.empty(max(qid.size, 1) * k, ROW3)
+        n = C.c_int32(0)
+        self._check(self.lib.ivfadc_batch_search(self.h, _p(qid), qid.size, k, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def ivpq_search_in(self, queries, query_ids, k, input_ids, alpha, pvf, method, use_targetlist, confidence,
+                       double_threshold):
+        qs, qid, ids = _f32(queries), _i32(query_ids), _i32(input_ids)
+        out = np.empty(max(qs.shape[0], 1) * k, ROW3)
+        n = C.c_int32(0)
+        self._check(self.lib.ivpq_search_in(self.h, _p(qs), qs.shape[0], qs.shape[1], _p(qid), qid.size, k, _p(ids),
+                                            ids.size, alpha, pvf, method, int(use_targetlist), C.c_float(confidence),
+                                            double_threshold, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def knn_join(self, queries, query_ids, k, input_ids):
+        qs, qid, ids = _f32(queries), _i32(query_ids), _i32(input_ids)
+        out = np.empty(max(qs.shape[0], 1) * k, ROW3)
+        n = C.c_int32(0)
+        self._check(self.lib.knn_join(self.h, _p(qs), qs.shape[0], qs.shape[1], _p(qid), k, _p(ids), ids.size, _p(out),
+                                      C.byref(n)))
+        return out[:n.value]
+
+    def emit_row3(self, row):
+        vals = ((C.c_char * 16) * 3)()
+        r = np.array([row], ROW3)
+        self.lib.freddy_emit_row3(_p(r), vals)
+        return tuple(v.value.decode() for v in vals)

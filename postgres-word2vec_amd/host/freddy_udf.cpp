@@ -1,0 +1,363 @@
+// freddy_udf.cpp -- host-side mirror of the FREDDY search UDFs (include/freddy_udf.h).
+//
+// Stands where freddy_extension/freddy.c and ivpq_search_in.c stand in a PostgreSQL backend:
+// keeps the tables and the config functions, resolves ids, pins the tables into HBM once
+// (the reference re-reads them through SPI on every call: freddy.c:69,239-241,746-749;
+// ivpq_search_in.c:218-232) and forwards every search through the device C ABI.  No distance
+// is computed here.
+#include "../../include/freddy_udf.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "../../include/freddy_gpu.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int gpu_fail(int rc) { return fail(rc, "%s", freddy_gpu_last_error()); }
+
+// CodebookCompound from an entry list: slot from each entry's own (pos, code); positions and
+// codeSize are max+1 as in getCodebook (index_utils.c:577-630)
+struct Codebook {
+  int m = 0, K = 0, s = 0;
+  std::vector<float> dense;   // [m][K][s]
+  int build(const int32_t* pos, const int32_t* code, const float* vec, int n, int sub) {
+    if (n <= 0 || sub <= 0 || !pos || !code || !vec) return fail(-1, "empty codebook");
+    m = 0; K = 0; s = sub;
+    for (int i = 0; i < n; ++i) {
+      if (pos[i] < 0 || code[i] < 0) return fail(-1, "negative pos/code in codebook");
+      m = std::max(m, pos[i] + 1);
+      K = std::max(K, code[i] + 1);
+    }
+    if ((int64_t)m * K != n) return fail(-1, "codebook has %d entries, expected positions*codes = %d*%d", n, m, K);
+    dense.assign((size_t)m * K * s, 0.0f);
+    for (int i = 0; i < n; ++i)
+      memcpy(&dense[((size_t)pos[i] * K + code[i]) * s], vec + (size_t)i * s, sizeof(float) * s);
+    return 0;
+  }
+};
+
+// permutation that sorts row ids ascending (table scan order = canonical order)
+std::vector<int64_t> order_by_id(const int32_t* ids, int64_t N) {
+  std::vector<int64_t> ord((size_t)N);
+  std::iota(ord.begin(), ord.end(), 0);
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return ids[a] < ids[b]; });
+  return ord;
+}
+
+}  // namespace
+
+struct freddy_session {
+  int device = 0;
+  // config functions, defaults from freddy--0.0.1.sql:188-194
+  int w = 3, pvf = 20, alpha = 3, long_codes_threshold = 10000000, method_flag = 0, use_targetlist = 1;
+  float confidence = 0.8f;
+  // google_vecs_norm
+  int d = 0;
+  std::vector<int32_t> norm_ids;      // ascending
+  std::vector<float> norm_vecs;       // [N][d] in that order
+  // pinned tables
+  freddy_gpu_index_t* pq = nullptr;
+  freddy_gpu_index_t* ivf = nullptr;
+  freddy_gpu_index_t* ivpq = nullptr;
+  int pq_d = 0, ivf_d = 0, ivpq_d = 0;
+};
+
+extern "C" {
+
+const char* freddy_udf_last_error(void) { return g_err; }
+
+int freddy_session_open(int device, freddy_session_t** out) {
+  if (!out) return fail(-1, "NULL argument");
+  freddy_session* s = new freddy_session();
+  s->device = device;
+  *out = s;
+  return 0;
+}
+
+int freddy_session_close(freddy_session_t* s) {
+  if (!s) return 0;
+  if (s->pq) freddy_gpu_unpin(s->pq);
+  if (s->ivf) freddy_gpu_unpin(s->ivf);
+  if (s->ivpq) freddy_gpu_unpin(s->ivpq);
+  delete s;
+  return 0;
+}
+
+int freddy_load_vecs_norm(freddy_session_t* s, const int32_t* ids, const float* vectors, int64_t N, int32_t d) {
+  if (!s || !ids || !vectors || N < 0 || d <= 0) return fail(-1, "bad argument");
+  std::vector<int64_t> ord = order_by_id(ids, N);
+  s->d = d;
+  s->norm_ids.resize((size_t)N);
+  s->norm_vecs.resize((size_t)N * d);
+  for (int64_t i = 0; i < N; ++i) {
+    s->norm_ids[i] = ids[ord[i]];
+    memcpy(&s->norm_vecs[(size_t)i * d], vectors + (size_t)ord[i] * d, sizeof(float) * d);
+  }
+  return 0;
+}
+
+int freddy_load_pq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* cb_code, const float* cb_vectors,
+                   int32_t n_entries, int32_t sub_dim, const int32_t* ids, const int16_t* codes, int64_t N) {
+  if (!s || !ids || !codes) return fail(-1, "bad argument");
+  Codebook cb;
+  if (int rc = cb.build(cb_pos, cb_code, cb_vectors, n_entries, sub_dim)) return rc;
+  std::vector<int64_t> ord = order_by_id(ids, N);
+  std::vector<int32_t> sid((size_t)N);
+  std::vector<int16_t> scodes((size_t)N * cb.m);
+  for (int64_t i = 0; i < N; ++i) {
+    sid[i] = ids[ord[i]];
+    memcpy(&scodes[(size_t)i * cb.m], codes + (size_t)ord[i] * cb.m, sizeof(int16_t) * cb.m);
+  }
+  freddy_pq_desc desc = {cb.m * cb.s, cb.m, cb.K, N, cb.dense.data(), sid.data(), scodes.data()};
+  if (s->pq) { freddy_gpu_unpin(s->pq); s->pq = nullptr; }
+  if (int rc = freddy_gpu_pin_pq(&desc, s->device, &s->pq)) return gpu_fail(rc);
+  s->pq_d = cb.m * cb.s;
+  return 0;
+}
+
+int freddy_load_ivfadc(freddy_session_t* s, const int32_t* coarse_ids_tbl, const float* coarse_vectors, int32_t C,
+                       const int32_t* cb_pos, const int32_t* cb_code, const float* cb_vectors, int32_t n_entries,
+                       int32_t sub_dim, const int32_t* ids, const int32_t* coarse_id, const int16_t* codes, int64_t N) {
+  if (!s || !coarse_ids_tbl || !coarse_vectors || C <= 0 || !ids || !coarse_id || !codes) return fail(-1, "bad argument");
+  Codebook cb;
+  if (int rc = cb.build(cb_pos, cb_code, cb_vectors, n_entries, sub_dim)) return rc;
+  const int d = cb.m * cb.s;
+  // coarse ids must be 0..C-1: the C code indexes the array by id (freddy.c:309,367,873,908)
+  std::vector<float> coarse((size_t)C * d);
+  std::vector<char> seen((size_t)C, 0);
+  for (int i = 0; i < C; ++i) {
+    const int id = coarse_ids_tbl[i];
+    if (id < 0 || id >= C || seen[id]) return fail(-1, "coarse_quantization ids must be exactly 0..%d", C - 1);
+    seen[id] = 1;
+    memcpy(&coarse[(size_t)id * d], coarse_vectors + (size_t)i * d, sizeof(float) * d);
+  }
+  // "ORDER BY coarse_id, id": inverted lists with ascending ids inside
+  std::vector<int64_t> ord((size_t)N);
+  std::iota(ord.begin(), ord.end(), 0);
+  for (int64_t i = 0; i < N; ++i)
+    if (coarse_id[i] < 0 || coarse_id[i] >= C) return fail(-1, "coarse_id %d out of range at row %lld", coarse_id[i], (long long)i);
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) {
+    return coarse_id[a] != coarse_id[b] ? coarse_id[a] < coarse_id[b] : ids[a] < ids[b];
+  });
+  std::vector<int32_t> list_off((size_t)C + 1, 0), sid((size_t)N);
+  std::vector<int16_t> scodes((size_t)N * cb.m);
+  for (int64_t i = 0; i < N; ++i) {
+    list_off[coarse_id[ord[i]] + 1]++;
+    sid[i] = ids[ord[i]];
+    memcpy(&scodes[(size_t)i * cb.m], codes + (size_t)ord[i] * cb.m, sizeof(int16_t) * cb.m);
+  }
+  for (int c = 0; c < C; ++c) list_off[c + 1] += list_off[c];
+  freddy_ivf_desc desc = {d, cb.m, cb.K, C, N, coarse.data(), cb.dense.data(), list_off.data(), sid.data(), scodes.data()};
+  if (s->ivf) { freddy_gpu_unpin(s->ivf); s->ivf = nullptr; }
+  if (int rc = freddy_gpu_pin_ivf(&desc, s->device, &s->ivf)) return gpu_fail(rc);
+  s->ivf_d = d;
+  return 0;
+}
+
+int freddy_load_ivpq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* cb_code, const float* cb_vectors,
+                     int32_t n_entries, int32_t sub_dim, const int32_t* cq_pos, const int32_t* cq_code,
+                     const float* cq_vectors, int32_t n_cq_entries, const int32_t* ids, const int32_t* coarse_id,
+                     const int16_t* codes, int64_t N, const int32_t* stat_coarse_id, const float* stat_freq,
+                     int32_t n_stat) {
+  if (!s || !ids || !coarse_id || !codes || !stat_coarse_id || !stat_freq) return fail(-1, "bad argument");
+  Codebook cb;
+  if (int rc = cb.build(cb_pos, cb_code, cb_vectors, n_entries, sub_dim)) return rc;
+  const int d = cb.m * cb.s;
+  int cpos = 0;
+  for (int i = 0; i < n_cq_entries; ++i) cpos = std::max(cpos, cq_pos[i] + 1);
+  if (cpos != 2) return fail(-1, "the multi-index coarse quantizer must have 2 positions (index_utils.c:322)");
+  Codebook cq;
+  if (int rc = cq.build(cq_pos, cq_code, cq_vectors, n_cq_entries, d / 2)) return rc;
+  const int cells = cq.K * cq.K;
+  // getStatistics (index_utils.c:632-665): result[coarse_id] = coarse_freq
+  if (n_stat != cells + 1) return fail(-1, "statistics table has %d rows, expected %d", n_stat, cells + 1);
+  std::vector<float> stats((size_t)cells + 1, 0.0f);
+  for (int i = 0; i < n_stat; ++i) {
+    if (stat_coarse_id[i] < 0 || stat_coarse_id[i] > cells) return fail(-1, "statistics coarse_id out of range");
+    stats[stat_coarse_id[i]] = stat_freq[i];
+  }
+  std::vector<int64_t> ord = order_by_id(ids, N);
+  std::vector<int32_t> sid((size_t)N), scell((size_t)N);
+  std::vector<int16_t> scodes((size_t)N * cb.m);
+  std::vector<float> svec;
+  const bool have_vecs = !s->norm_ids.empty() && s->d == d;
+  if (have_vecs) svec.resize((size_t)N * d);
+  for (int64_t i = 0; i < N; ++i) {
+    const int64_t r = ord[i];
+    sid[i] = ids[r];
+    scell[i] = coarse_id[r];
+    memcpy(&scodes[(size_t)i * cb.m], codes + (size_t)r * cb.m, sizeof(int16_t) * cb.m);
+    if (have_vecs) {   // "INNER JOIN vecs ON fq.id = vecs.id" (ivpq_search_in.c:361-371)
+      auto it = std::lower_bound(s->norm_ids.begin(), s->norm_ids.end(), ids[r]);
+      if (it == s->norm_ids.end() || *it != ids[r]) return fail(-1, "id %d of fine_quantization_ivpq has no vector", ids[r]);
+      memcpy(&svec[(size_t)i * d], &s->norm_vecs[(size_t)(it - s->norm_ids.begin()) * d], sizeof(float) * d);
+    }
+  }
+  freddy_ivpq_desc desc = {d, cb.m, cb.K, 2, cq.K, N, cb.dense.data(), cq.dense.data(), sid.data(), scell.data(),
+                           scodes.data(), have_vecs ? svec.data() : nullptr, stats.data()};
+  if (s->ivpq) { freddy_gpu_unpin(s->ivpq); s->ivpq = nullptr; }
+  if (int rc = freddy_gpu_pin_ivpq(&desc, s->device, &s->ivpq)) return gpu_fail(rc);
+  s->ivpq_d = d;
+  return 0;
+}
+
+// ---- config functions ------------------------------------------------------------------------
+#define SETTER(name, field, type) \
+  int freddy_set_##name(freddy_session_t* s, type v) { if (!s) return fail(-1, "NULL session"); s->field = v; return 0; }
+SETTER(w, w, int32_t)
+SETTER(pvf, pvf, int32_t)
+SETTER(alpha, alpha, int32_t)
+SETTER(confidence_value, confidence, float)
+SETTER(long_codes_threshold, long_codes_threshold, int32_t)
+SETTER(method_flag, method_flag, int32_t)
+SETTER(use_targetlist, use_targetlist, int32_t)
+#undef SETTER
+int32_t freddy_get_w(const freddy_session_t* s) { return s->w; }
+int32_t freddy_get_pvf(const freddy_session_t* s) { return s->pvf; }
+int32_t freddy_get_alpha(const freddy_session_t* s) { return s->alpha; }
+float freddy_get_confidence_value(const freddy_session_t* s) { return s->confidence; }
+int32_t freddy_get_long_codes_threshold(const freddy_session_t* s) { return s->long_codes_threshold; }
+int32_t freddy_get_method_flag(const freddy_session_t* s) { return s->method_flag; }
+int32_t freddy_get_use_targetlist(const freddy_session_t* s) { return s->use_targetlist; }
+
+// ---- UDFs ------------------------------------------------------------------------------------
+static int emit2(const std::vector<int32_t>& ids, const std::vector<float>& dist, int k, freddy_row2* out, int32_t* n_rows) {
+  for (int i = 0; i < k; ++i) { out[i].id = ids[i]; out[i].distance = dist[i]; }
+  if (n_rows) *n_rows = k;   // the SRF returns k rows, unfilled ones are (-1, sentinel)  freddy.c:154-169
+  return 0;
+}
+
+int pq_search(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  if (!s || !s->pq) return fail(-1, "pq_quantization / pq_codebook are not loaded");
+  if (dim != s->pq_d) return fail(-1, "query has %d dimensions, index has %d", dim, s->pq_d);
+  if (k <= 0 || !query || !out) return fail(-1, "bad argument");
+  std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+  if (int rc = freddy_gpu_pq_search(s->pq, query, 1, k, 100.0f, nullptr, 0, ids.data(), dist.data())) return gpu_fail(rc);
+  return emit2(ids, dist, k, out, n_rows);
+}
+
+int pq_search_in(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids,
+                 int32_t n_ids, freddy_row2* out, int32_t* n_rows) {
+  if (!s || !s->pq) return fail(-1, "pq_quantization / pq_codebook are not loaded");
+  if (dim != s->pq_d) return fail(-1, "query has %d dimensions, index has %d", dim, s->pq_d);
+  if (k <= 0 || !query || !out || n_ids < 0) return fail(-1, "bad argument");
+  std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+  const int32_t none = -1;   // empty IN-list: nothing matches
+  if (int rc = freddy_gpu_pq_search(s->pq, query, 1, k, 1000.0f, n_ids ? input_ids : &none, n_ids ? n_ids : 1, ids.data(),
+                                    dist.data()))
+    return gpu_fail(rc);
+  return emit2(ids, dist, k, out, n_rows);
+}
+
+int ivfadc_search(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  if (!s || !s->ivf) return fail(-1, "coarse_quantization / residual_codebook / fine_quantization are not loaded");
+  if (dim != s->ivf_d) return fail(-1, "query has %d dimensions, index has %d", dim, s->ivf_d);
+  if (k <= 0 || !query || !out) return fail(-1, "bad argument");
+  std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+  if (int rc = freddy_gpu_ivfadc_search(s->ivf, query, 1, k, s->w, 1000.0f, FREDDY_FOUND_ROWS, ids.data(), dist.data()))
+    return gpu_fail(rc);
+  return emit2(ids, dist, k, out, n_rows);
+}
+
+static int emit3(const int32_t* qids, int Q, int k, const std::vector<int32_t>& ids, const std::vector<float>& dist,
+                 freddy_row3* out, int32_t* n_rows) {
+  // iter / k -> query, iter % k -> rank   (freddy.c:654-674, 1001-1023; ivpq_search_in.c:700-720)
+  for (int i = 0; i < Q * k; ++i) { out[i].query_id = qids[i / k]; out[i].id = ids[i]; out[i].distance = dist[i]; }
+  if (n_rows) *n_rows = Q * k;
+  return 0;
+}
+
+int pq_search_in_batch(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim,
+                       const int32_t* query_ids, int32_t n_query_ids, int32_t k, const int32_t* input_ids,
+                       int32_t n_ids, int32_t use_target_lists, freddy_row3* out, int32_t* n_rows) {
+  (void)use_target_lists;   // both branches of the reference give identical lists (freddy.c:596-628)
+  if (!s || !s->pq) return fail(-1, "pq_quantization / pq_codebook are not loaded");
+  if (n_query_ids != n_queries) return fail(-1, "Number of query vectors and query vector ids differs!");   // freddy.c:495
+  if (dim != s->pq_d) return fail(-1, "query has %d dimensions, index has %d", dim, s->pq_d);
+  if (k <= 0 || n_queries < 0 || n_ids < 0) return fail(-1, "bad argument");
+  std::vector<int32_t> ids((size_t)n_queries * k); std::vector<float> dist((size_t)n_queries * k);
+  const int32_t none = -1;
+  if (int rc = freddy_gpu_pq_search(s->pq, queries, n_queries, k, 1000.0f, n_ids ? input_ids : &none, n_ids ? n_ids : 1,
+                                    ids.data(), dist.data()))
+    return gpu_fail(rc);
+  return emit3(query_ids, n_queries, k, ids, dist, out, n_rows);
+}
+
+int ivfadc_batch_search(freddy_session_t* s, const int32_t* query_ids, int32_t n_query_ids, int32_t k, freddy_row3* out,
+                        int32_t* n_rows) {
+  if (!s || !s->ivf) return fail(-1, "coarse_quantization / residual_codebook / fine_quantization are not loaded");
+  if (s->norm_ids.empty() || s->d != s->ivf_d) return fail(-1, "google_vecs_norm is not loaded");
+  if (k <= 0 || n_query_ids < 0 || !out) return fail(-1, "bad argument");
+  // "SELECT id, vector FROM <norm> WHERE id IN (...)": table order, duplicates collapse,
+  // unknown ids vanish (freddy.c:767-804)
+  std::vector<int32_t> rows;
+  for (int i = 0; i < n_query_ids; ++i) {
+    auto it = std::lower_bound(s->norm_ids.begin(), s->norm_ids.end(), query_ids[i]);
+    if (it != s->norm_ids.end() && *it == query_ids[i]) rows.push_back((int32_t)(it - s->norm_ids.begin()));
+  }
+  std::sort(rows.begin(), rows.end());
+  rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+  const int Q = (int)rows.size();
+  const int d = s->d;
+  std::vector<float> qv((size_t)Q * d);
+  std::vector<int32_t> qid((size_t)Q);
+  for (int i = 0; i < Q; ++i) {
+    qid[i] = s->norm_ids[rows[i]];
+    memcpy(&qv[(size_t)i * d], &s->norm_vecs[(size_t)rows[i] * d], sizeof(float) * d);
+  }
+  std::vector<int32_t> ids((size_t)Q * k); std::vector<float> dist((size_t)Q * k);
+  if (Q > 0)
+    if (int rc = freddy_gpu_ivfadc_search(s->ivf, qv.data(), Q, k, 1, 100.0f, FREDDY_FOUND_ACCEPTED, ids.data(), dist.data()))
+      return gpu_fail(rc);
+  return emit3(qid.data(), Q, k, ids, dist, out, n_rows);
+}
+
+int ivpq_search_in(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim, const int32_t* query_ids,
+                   int32_t n_query_ids, int32_t k, const int32_t* input_ids, int32_t n_ids, int32_t alpha, int32_t pvf,
+                   int32_t method, int32_t use_target_lists, float confidence, int32_t double_threshold,
+                   freddy_row3* out, int32_t* n_rows) {
+  if (!s || !s->ivpq) return fail(-1, "the ivpq tables are not loaded");
+  if (n_query_ids != n_queries)   // ivpq_search_in.c:180
+    return fail(-1, "Number of query vectors and query vector ids differs! ( %d, %d)", n_query_ids, n_queries);
+  if (dim != s->ivpq_d) return fail(-1, "query has %d dimensions, index has %d", dim, s->ivpq_d);
+  if (k <= 0 || n_queries < 0 || n_ids < 0) return fail(-1, "bad argument");
+  std::vector<int32_t> ids((size_t)n_queries * k); std::vector<float> dist((size_t)n_queries * k);
+  if (int rc = freddy_gpu_knn_join(s->ivpq, queries, n_queries, k, input_ids, n_ids, alpha, pvf, method, use_target_lists,
+                                   confidence, double_threshold, ids.data(), dist.data(), nullptr))
+    return gpu_fail(rc);
+  return emit3(query_ids, n_queries, k, ids, dist, out, n_rows);
+}
+
+int knn_join(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim, const int32_t* query_ids,
+             int32_t k, const int32_t* input_ids, int32_t n_ids, freddy_row3* out, int32_t* n_rows) {
+  if (!s) return fail(-1, "NULL session");
+  return ivpq_search_in(s, queries, n_queries, dim, query_ids, n_queries, k, input_ids, n_ids, s->alpha, s->pvf,
+                        s->method_flag, s->use_targetlist, s->confidence, s->long_codes_threshold, out, n_rows);
+}
+
+void freddy_emit_row2(const freddy_row2* row, char values[2][16]) {
+  snprintf(values[0], 16, "%d", row->id);
+  snprintf(values[1], 16, "%f", row->distance);
+}
+
+void freddy_emit_row3(const freddy_row3* row, char values[3][16]) {
+  snprintf(values[0], 16, "%d", row->query_id);
+  snprintf(values[1], 16, "%d", row->id);
+  snprintf(values[2], 16, "%f", row->distance);
+}
+
+}  // extern "C"

@@ -45,3 +45,36 @@ def test_product_never_references_the_oracle():
                 assert "freddy_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
     so = open(os.path.join(pkg, "libfreddy_gpu.so"), "rb").read()
     assert b"fo_sqdist" not in so and b"libfreddy_oracle" not in so
+
+
+def test_host_mirror_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from freddy_amd import udf
+    lib = udf.load()
+    src = open(os.path.join(ROOT, "include", "freddy_udf.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\(freddy_session_t\b|\b(freddy_[a-z0-9_]+)\s*\(", src)))
+    flat = sorted({n for pair in names for n in pair if n})
+    assert {"pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search",
+            "ivpq_search_in", "knn_join"} <= set(flat)
+    for n in flat:
+        assert hasattr(lib, n), f"{n} declared in include/freddy_udf.h but not exported"
+
+
+def test_host_mirror_config_functions_and_errors():
+    """set_*/get_* defaults (freddy--0.0.1.sql:188-194) and error texts, no GPU needed."""
+    from freddy_amd import udf
+    s = udf.Session()
+    assert (s.get_w(), s.get_pvf(), s.get_alpha()) == (3, 20, 3)
+    assert abs(s.get_confidence_value() - 0.8) < 1e-7
+    s.set_w(7); s.set_pvf(5); s.set_alpha(11); s.set_confidence_value(0.5)
+    assert (s.get_w(), s.get_pvf(), s.get_alpha()) == (7, 5, 11)
+    import numpy as np
+    import pytest
+    with pytest.raises(udf.FreddyError, match="not loaded"):
+        s.pq_search(np.zeros(300, np.float32), 5)
+    with pytest.raises(udf.FreddyError, match="not loaded"):
+        s.ivfadc_batch_search([1, 2, 3], 5)
+    assert s.emit_row3((7, 42, 0.1234567)) == ("7", "42", "0.123457")
+    s.close()

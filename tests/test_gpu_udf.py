@@ -1,0 +1,101 @@
+"""-m gpu tests through the host-side UDF mirror (libfreddy_host.so): the calls read like the
+reference's SQL (`SELECT * FROM ivfadc_batch_search('{...}'::int[], k)`), results are compared
+with the oracle drivers of the same UDFs."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+N = 20000
+
+
+@pytest.fixture(scope="module")
+def db(oracle):
+    from freddy_amd import udf
+    x = util.corpus(N).numpy()
+    ids_all = np.arange(1, N + 1, dtype=np.int32)
+    s = udf.Session()
+    # rows are handed over shuffled: the host has to establish the canonical (id) order itself
+    perm = np.random.default_rng(1).permutation(N)
+    s.load_vecs_norm(ids_all[perm], x[perm])
+    pq = util.pq_tables(N=N, K=256)
+    s.load_pq(pq["codebook"], pq["ids"][perm], pq["codes"][perm])
+    ivf = util.ivf_tables(N=N, C=32, K=256)
+    cell_of = np.repeat(np.arange(32), np.diff(ivf["list_off"])).astype(np.int32)
+    p2 = np.random.default_rng(2).permutation(N)
+    s.load_ivfadc(ivf["coarse"], ivf["codebook"], ivf["ids"][p2], cell_of[p2], ivf["codes"][p2])
+    iv = util.ivpq_tables(N=N)
+    s.load_ivpq(iv["codebook"], iv["coarse"], iv["ids"][perm], iv["coarse_id"][perm], iv["codes"][perm], iv["stats"])
+    tabs = dict(x=x, pq=oracle.pq_table(pq["codebook"], pq["ids"], pq["codes"]),
+                ivf=oracle.ivf_table(ivf["coarse"], ivf["codebook"], ivf["list_off"], ivf["ids"], ivf["codes"]),
+                ivpq=oracle.ivpq_table(iv["codebook"], iv["coarse"], iv["ids"], iv["coarse_id"], iv["codes"],
+                                       iv["vectors"], iv["stats"]))
+    yield s, tabs
+    s.close()
+
+
+def same(rows, exp):
+    assert np.array_equal(rows["id"], exp["id"].ravel())
+    assert np.array_equal(rows["distance"].view(np.uint32), exp["dist"].ravel().view(np.uint32))
+
+
+def test_pq_search_and_pq_search_in(db, oracle):
+    s, t = db
+    q = t["x"][123]
+    same(s.pq_search(q, 5), oracle.pq_search(t["pq"], q, 5))
+    ids = [5, 17, 17, 900, 19999, 20001, -4]
+    same(s.pq_search_in(q, 4, ids), oracle.pq_search_in(t["pq"], q, 4, ids))
+    rows = s.pq_search_in(q, 3, [])                       # empty IN-list: k sentinel rows
+    assert (rows["id"] == -1).all() and (rows["distance"] == np.float32(1000.0)).all()
+
+
+def test_pq_search_in_batch(db, oracle):
+    s, t = db
+    qids = np.array([11, 500, 7777], np.int32)
+    qs = t["x"][qids - 1]
+    targets = np.arange(1, N + 1, 13).astype(np.int32)
+    rows = s.pq_search_in_batch(qs, qids, 5, targets, True)
+    exp = oracle.pq_search_in_batch(t["pq"], qs, 5, targets)
+    same(rows, exp)
+    assert rows["query_id"].tolist() == np.repeat(qids, 5).tolist()
+    from freddy_amd import udf
+    with pytest.raises(udf.FreddyError, match="Number of query vectors and query vector ids differs"):
+        s.pq_search_in_batch(qs, qids[:2], 5, targets, True)
+
+
+def test_ivfadc_search_uses_get_w(db, oracle):
+    s, t = db
+    q = t["x"][4321]
+    for w in (1, 3, 8):
+        s.set_w(w)
+        same(s.ivfadc_search(q, 5), oracle.ivfadc_search(t["ivf"], q, 5, w))
+    s.set_w(3)
+
+
+def test_ivfadc_batch_search(db, oracle):
+    """query ids arrive unordered, with a duplicate and an unknown id: rows come back in table
+    order of the found ids (freddy.c:767-804, 986)."""
+    s, t = db
+    asked = np.array([900, 17, 17, 15000, 25000, 3], np.int32)
+    rows = s.ivfadc_batch_search(asked, 5)
+    found = np.array([3, 17, 900, 15000], np.int32)
+    assert rows["query_id"].tolist() == np.repeat(found, 5).tolist()
+    same(rows, oracle.ivfadc_batch_search(t["ivf"], t["x"][found - 1], 5))
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_ivpq_search_in_and_knn_join(db, oracle, method):
+    s, t = db
+    qids = np.arange(100, 160, dtype=np.int32)
+    qs = t["x"][qids - 1]
+    targets = np.random.default_rng(3).choice(np.arange(1, N + 1), 3000, replace=False).astype(np.int32)
+    rows = s.ivpq_search_in(qs, qids, 5, targets, 10, 4, method, True, 0.8, 10000000)
+    exp, _ = oracle.ivpq_search_in(t["ivpq"], qs, 5, targets, 10, 4, method)
+    same(rows, exp)
+    s.set_alpha(10); s.set_pvf(4); s.set_method_flag(method)
+    same(s.knn_join(qs, qids, 5, targets), exp)
+    from freddy_amd import udf
+    with pytest.raises(udf.FreddyError, match="Unknown computation method"):
+        s.ivpq_search_in(qs, qids, 5, targets, 10, 4, 7, True, 0.8, 10000000)
