@@ -468,8 +468,12 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
 
   // Fused LUT+scan path: residual PQ with m=12, S=25, K<=1024 and a selection width that one
   // wave holds (2k <= 64).  Everything else takes the generic lut_build + adc_scan kernels.
+  // FREDDY_GPU_FUSED=0 forces the generic lut_build + adc_scan kernels (tests run both).  The
+  // fused kernel pays off once several (query, cell) items share a cell, i.e. for batches.
   const char* fenv = getenv("FREDDY_GPU_FUSED");
-  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && L <= 64;
+  const bool force_fused = fenv && fenv[0] == '1';
+  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && L <= 64 &&
+                     (force_fused || items >= 256);
   const int upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   const int surv_cap = upi * std::min(64 * L, FUSED_UNIT_BLOCKS * 64);
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||

@@ -60,7 +60,7 @@ def test_pq_search_in_and_batch(gpu, oracle):
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("K,W", [(256, 1), (256, 3), (256, 10), (1024, 3)])
 def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
-    """fused=1: ivf_fused_kernel (LUT slabs in LDS); fused=0: lut_build + adc_scan kernels."""
+    """FREDDY_GPU_FUSED=1: ivf_fused_kernel (LUT slabs in LDS); 0: lut_build + adc_scan kernels."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
     N = 20000
     t = util.ivf_tables(N=N, C=32, K=K)
