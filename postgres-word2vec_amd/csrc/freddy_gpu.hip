@@ -92,6 +92,7 @@ struct freddy_gpu_index {
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
   int Cpad = 0;
   float* cbT = nullptr;         // [m][S][K]
+  float* cbP = nullptr;         // fused kernel layout [m][SP/4][512][4][2] (NULL unless K <= 1024)
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
   uint32_t* packed = nullptr;   // [blocks][M2][64]
@@ -145,7 +146,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->coarse, ix->coarseT, ix->cbT, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -288,6 +289,21 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
         upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes) ||
         upload(&ix->coarseT, cT.data(), cT.size(), &ix->bytes))
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    if (!rc && ix->K <= FUSED_T * FUSED_E) {
+      // paired layout of the fused kernel: lane t holds codes (t, t+512); 4 dims x 2 codes per 32 bytes
+      const int SP = (ix->S + 3) & ~3, SPq = SP / 4;
+      std::vector<float> cbP((size_t)ix->m * SPq * FUSED_T * 8, 0.0f);
+      for (int p = 0; p < ix->m; ++p)
+        for (int jb = 0; jb < SPq; ++jb)
+          for (int tl = 0; tl < FUSED_T; ++tl)
+            for (int u = 0; u < 4; ++u)
+              for (int e = 0; e < 2; ++e) {
+                const int j = jb * 4 + u, c = tl + e * FUSED_T;
+                if (j < ix->S && c < ix->K)
+                  cbP[((((size_t)p * SPq + jb) * FUSED_T + tl) * 4 + u) * 2 + e] = t->codebook[((size_t)p * ix->K + c) * ix->S + j];
+              }
+      if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    }
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
   if (rc) { free_index(ix); return rc; }
@@ -472,14 +488,14 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   // fused kernel pays off once several (query, cell) items share a cell, i.e. for batches.
   const char* fenv = getenv("FREDDY_GPU_FUSED");
   const bool force_fused = fenv && fenv[0] == '1';
-  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && L <= 64 &&
+  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && L <= 64 &&
                      (force_fused || items >= 256);
   const int upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   const int surv_cap = upi * std::min(64 * L, FUSED_UNIT_BLOCKS * 64);
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
-      ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_resid.ensure(sizeof(float) * items * d) ||
+      ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_resid.ensure(sizeof(float) * items * (size_t)m * ((ix->S + 3) & ~3)) ||
       ix->w_cand.ensure(sizeof(int32_t) * Q) ||
       ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
       ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
@@ -535,7 +551,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     }
     timed_launch(ix, s, "residual", [&] {
       hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
-                         ix->w_resid.as<float>(), d);
+                         ix->w_resid.as<float>(), d, ix->S, fused ? ((ix->S + 3) & ~3) : ix->S);
     });
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
@@ -560,7 +576,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query;
       fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cell; fa.group_first = group_first;
       fa.group_cnt = group_cnt; fa.n_groups = n_groups;
-      fa.cbT = ix->cbT; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
+      fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
       fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
       fa.cand_count = (found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
       fa.d = d; fa.K = K; fa.L = L; fa.cap = surv_cap;
@@ -568,7 +584,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
       const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(u64) + 64 * sizeof(u64);
       const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
-      const size_t flds = desc_off + FUSED_G * sizeof(int32_t);
+      const size_t flds = desc_off + 64 + (size_t)FUSED_G * 12 * 28 * sizeof(float);   // + item ids + padded residuals
       fa.desc_offset = (uint32_t)desc_off;
       { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
       static bool fattr = false;

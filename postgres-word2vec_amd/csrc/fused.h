@@ -89,14 +89,14 @@ __global__ __launch_bounds__(256) void bucket_items_kernel(const int32_t* __rest
 }
 
 struct FusedArgs {
-  const float* resid;          // [items][d] residuals (freddy.c:296-303)
+  const float* resid;          // [items][m][SP] residuals, each position padded to SP floats (freddy.c:296-303)
   const int32_t* item_query;   // [items]
   const int32_t* sorted_item;  // items in cell order
   const int32_t* group_cell;   // [groups]
   const int32_t* group_first;
   const int32_t* group_cnt;
   const int32_t* n_groups;     // [1]
-  const float* cbT;            // [m][S][K]
+  const float* cbP;            // [m][SP/4][512][4 dims][2 codes] (see load_cb)
   const int32_t* blk_off;      // [C+1]
   const uint32_t* packed;      // [blocks][M2][64]
   const int32_t* pos;          // [blocks*64]
@@ -146,7 +146,16 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   if (nblk > FUSED_UNIT_BLOCKS) nblk = FUSED_UNIT_BLOCKS;
 
   int32_t* desc = reinterpret_cast<int32_t*>(smem + a.desc_offset);   // [G] item ids
+  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 64);   // [G][M][SP] residuals
   if (tid < G) desc[tid] = (tid < cnt) ? a.sorted_item[first + tid] : -1;
+  __syncthreads();
+  {
+    constexpr int ROW4 = M * ((S + 3) & ~3) / 4;   // float4 per item
+    for (int i = tid; i < cnt * ROW4; i += T) {
+      const int g = i / ROW4, o = i - g * ROW4;
+      reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)desc[g] * ROW4 + o];
+    }
+  }
   __syncthreads();
 
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -164,58 +173,84 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     return (uint32_t)(blk0 + (b < nblk - 1 ? b : nblk - 1));
   };
   static_assert(E == 2, "two codes per lane");
+  // cbP layout [m][SP/4][T][4 dims][2 codes]: this lane's codes (tid, tid+T) interleaved, so two
+  // 16-byte loads bring four dimensions of both codes already in (x, y) pair order (codes >= K
+  // are zero-padded by the host).  14 wide loads per position instead of 50 dword loads.
   auto load_cb = [&](int p) {
+    constexpr int SPq = ((S + 3) & ~3) / 4;
 #pragma unroll
-    for (int j = 0; j < S; ++j) {
-      const uint32_t base = ((uint32_t)p * S + j) * (uint32_t)K;
-      cb[j].x = (FULLK || tid < K) ? a.cbT[base + tid] : 0.0f;
-      cb[j].y = (FULLK || tid + T < K) ? a.cbT[base + tid + T] : 0.0f;
+    for (int jb = 0; jb < SPq; ++jb) {
+      const float4* src = reinterpret_cast<const float4*>(a.cbP) + (((size_t)p * SPq + jb) * T + tid) * 2;
+      const float4 lo = src[0], hi = src[1];
+      if (jb * 4 + 0 < S) cb[jb * 4 + 0] = v2f{lo.x, lo.y};
+      if (jb * 4 + 1 < S) cb[jb * 4 + 1] = v2f{lo.z, lo.w};
+      if (jb * 4 + 2 < S) cb[jb * 4 + 2] = v2f{hi.x, hi.y};
+      if (jb * 4 + 3 < S) cb[jb * 4 + 3] = v2f{hi.z, hi.w};
     }
   };
   auto load_codes = [&](int pair) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) cw[r] = a.packed[(row_block(r) * M2 + (uint32_t)pair) * 64u + (uint32_t)lane];
   };
-  auto slab_entry = [&](const float (&rc)[S], int g, float* dst) {
-    // IEEE binary32 per component: v_pk_add/v_pk_mul round each half exactly like the scalar ops
-    // blocks of 5 dimensions: the subs and muls of a block are independent, only the adds chain
-    v2f sum = {0.0f, 0.0f};
-    constexpr int JB = 5;
-#pragma unroll
-    for (int j0 = 0; j0 < S; j0 += JB) {
-      v2f pr[JB];
-#pragma unroll
-      for (int u = 0; u < JB; ++u) {
-        if (j0 + u < S) {
-          const v2f rj = {rc[j0 + u], rc[j0 + u]};
-          const v2f t = rj - cb[j0 + u];
-          pr[u] = t * t;
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < JB; ++u)
-        if (j0 + u < S) sum = sum + pr[u];
-    }
-    if (FULLK || tid < K) dst[g * K + tid] = sum.x;
-    if (FULLK || tid + T < K) dst[g * K + tid + T] = sum.y;
-  };
-  auto load_resid = [&](float (&rr)[S], int g, int p) {
-    const int it = __builtin_amdgcn_readfirstlane(desc[g < cnt ? g : cnt - 1]);
-    const float* r = a.resid + (size_t)it * a.d + (size_t)p * S;   // wave-uniform -> scalar loads
-#pragma unroll
-    for (int j = 0; j < S; ++j) rr[j] = r[j];
-  };
+  // Residual sub-vectors of the group's items live in LDS, padded to SP floats per position so
+  // that a lane fetches four dimensions with one aligned ds_read_b128 (all lanes read the same
+  // address: a broadcast, no bank conflict).  Two items are built together: their two packed
+  // chains are independent, which is what keeps the VALU pipe full with only 2 waves per SIMD.
+  constexpr int SP = (S + 3) & ~3;
   auto build_slab = [&](int p, float* dst) {
-    // two residual buffers, alternating: item g+1's slice is fetched while item g is computed
-    float ra[S], rb[S];
-    load_resid(ra, 0, p);
 #pragma unroll 1
     for (int g = 0; g < cnt; g += 2) {
-      load_resid(rb, g + 1, p);
-      slab_entry(ra, g, dst);
-      load_resid(ra, g + 2, p);
-      if (g + 1 < cnt) slab_entry(rb, g + 1, dst);
+      const float4* R0 = reinterpret_cast<const float4*>(res + ((size_t)g * M + p) * SP);
+      const float4* R1 = reinterpret_cast<const float4*>(res + ((size_t)(g + 1 < cnt ? g + 1 : g) * M + p) * SP);
+      // One dimension of both items per step, written out as six packed instructions in a fixed
+      // order (sub, sub, mul, mul, add, add): the two chains alternate, so every instruction's
+      // operands were produced two issues earlier (covers the 1-wait-state VALU->v_pk hazard
+      // without s_nop) and the pipe always has an independent instruction to issue.  hipcc's
+      // scheduler otherwise serialises one chain after the other under this register pressure.
+      // a + (-b) with the neg modifier is the IEEE subtraction; each half rounds like the scalar op.
+      v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f};
+      float4 n0 = R0[0], n1 = R1[0];
+#pragma unroll
+      for (int jb = 0; jb < SP / 4; ++jb) {
+        const float4 c0 = n0, c1 = n1;
+        if (jb + 1 < SP / 4) { n0 = R0[jb + 1]; n1 = R1[jb + 1]; }
+        const v2f a0[2] = {{c0.x, c0.y}, {c0.z, c0.w}};
+        const v2f a1[2] = {{c1.x, c1.y}, {c1.z, c1.w}};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = jb * 4 + u;
+          if (j < S) {
+            v2f t0, t1;
+            if ((u & 1) == 0) {
+              asm volatile(
+                  "v_pk_add_f32 %2, %4, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %3, %5, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_mul_f32 %2, %2, %2\n\t"
+                  "v_pk_mul_f32 %3, %3, %3\n\t"
+                  "v_pk_add_f32 %0, %0, %2\n\t"
+                  "v_pk_add_f32 %1, %1, %3"
+                  : "+v"(s0), "+v"(s1), "=&v"(t0), "=&v"(t1)
+                  : "v"(a0[u >> 1]), "v"(a1[u >> 1]), "v"(cb[j]));
+            } else {
+              asm volatile(
+                  "v_pk_add_f32 %2, %4, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %3, %5, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_mul_f32 %2, %2, %2\n\t"
+                  "v_pk_mul_f32 %3, %3, %3\n\t"
+                  "v_pk_add_f32 %0, %0, %2\n\t"
+                  "v_pk_add_f32 %1, %1, %3"
+                  : "+v"(s0), "+v"(s1), "=&v"(t0), "=&v"(t1)
+                  : "v"(a0[u >> 1]), "v"(a1[u >> 1]), "v"(cb[j]));
+            }
+          }
+        }
+      }
+      if (FULLK || tid < K) dst[g * K + tid] = s0.x;
+      if (FULLK || tid + T < K) dst[g * K + tid + T] = s0.y;
+      if (g + 1 < cnt) {
+        if (FULLK || tid < K) dst[(g + 1) * K + tid] = s1.x;
+        if (FULLK || tid + T < K) dst[(g + 1) * K + tid + T] = s1.y;
+      }
     }
   };
   auto gather = [&](int p, const float* cur) {
@@ -232,6 +267,10 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     }
   };
 
+  // scan positions (row ids) of this lane's rows: needed only by the selection, fetched now
+  int32_t pid[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
   load_cb(0);
   load_codes(0);
   build_slab(0, slab);
@@ -270,13 +309,9 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   u64* exch = reinterpret_cast<u64*>(smem);          // [G][T], aliases the slabs (all reads done)
   u64* tau_s = exch + (size_t)G * T;                 // [G]
   const u64 sentinel_key = (u64)a.sentinel_bits << 32;
-  int32_t pid[RMAX];
   bool live[RMAX];
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
-    pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
-    live[r] = ((r * NW + wave) < nblk) && pid[r] >= 0;
-  }
+  for (int r = 0; r < RMAX; ++r) live[r] = ((r * NW + wave) < nblk) && pid[r] >= 0;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     u64 mn = KEY_INF;
@@ -307,24 +342,33 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     if (g < cnt) {
       const u64 tau = tau_s[g];
       const int it = __builtin_amdgcn_readfirstlane(desc[g]);
-      int accepted = 0;
+      // a lane can only hold survivors if its own best key passes; most waves hold none at all
+      const u64 mine = exch[(size_t)g * T + tid];
+      if (a.cand_count) {
+        int accepted = 0;
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
-        const bool ok = live[r] && key < sentinel_key;
-        accepted += __popcll(__ballot(ok));
-        const bool pass = ok && key <= tau;
-        const u64 mask = __ballot(pass);
-        const int n = __popcll(mask);
-        if (n) {
-          int base = 0;
-          if (lane == 0) base = atomicAdd(a.surv_count + it, n);
-          base = __shfl(base, 0, 64);
-          const int idx = base + __popcll(mask & lt);
-          if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = key;
+        for (int r = 0; r < RMAX; ++r) {
+          const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
+          accepted += __popcll(__ballot(live[r] && key < sentinel_key));
+        }
+        if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[it], accepted);
+      }
+      if (__ballot(mine <= tau && mine < sentinel_key) != 0ull) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
+          const bool pass = live[r] && key < sentinel_key && key <= tau;
+          const u64 mask = __ballot(pass);
+          const int n = __popcll(mask);
+          if (n) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.surv_count + it, n);
+            base = __shfl(base, 0, 64);
+            const int idx = base + __popcll(mask & lt);
+            if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = key;
+          }
         }
       }
-      if (a.cand_count && lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[it], accepted);
     }
   }
 }

@@ -168,17 +168,22 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
 // ---------------------------------------------------------------------------------------
 // a8 residual r = q - cq[cell], elementwise binary32 (freddy.c:296-303, :876-879)
 // ---------------------------------------------------------------------------------------
+// Output row layout: [m][SP] with each position's S values padded to SP (SP == S: dense [d]).
 __global__ __launch_bounds__(WG) void residual_kernel(const float* __restrict__ queries,
                                                      const float* __restrict__ coarse,
                                                      const int32_t* __restrict__ item_cell,
                                                      const int32_t* __restrict__ item_query,
-                                                     float* __restrict__ resid, int d) {
+                                                     float* __restrict__ resid, int d, int S, int SP) {
   const int item = blockIdx.x;
   const int cell = item_cell[item];
   if (cell < 0) return;
   const float* q = queries + (size_t)item_query[item] * d;
   const float* c = coarse + (size_t)cell * d;
-  for (int i = threadIdx.x; i < d; i += WG) resid[(size_t)item * d + i] = q[i] - c[i];
+  const int row = (d / S) * SP;
+  for (int o = threadIdx.x; o < row; o += WG) {
+    const int p = o / SP, j = o - p * SP;
+    resid[(size_t)item * row + o] = (j < S) ? q[p * S + j] - c[p * S + j] : 0.0f;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
