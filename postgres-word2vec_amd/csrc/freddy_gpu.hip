@@ -515,7 +515,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
 
   timed_launch(ix, s, "coarse_dist", [&] {
-    hipLaunchKernelGGL((coarse_dist_kernel<8>), dim3(Cpad / WG, (Q + 7) / 8), dim3(WG), 0, s, d_q, ix->coarseT,
+    hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, d_q, ix->coarseT,
                        ix->w_distT.as<float>(), Q, Cpad, d);
   });
   HIP_TRY(hipGetLastError());

@@ -32,37 +32,54 @@ __global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict
                                                         const float* __restrict__ coarseT,
                                                         float* __restrict__ dist, int Q, int Cpad,
                                                         int d) {
+  // QJ query rows are staged in LDS transposed to [dim][QJ]: per dimension every lane then reads
+  // the QJ query values with QJ/4 broadcast ds_read_b128 (same address in all lanes) instead of
+  // QJ dependent scalar loads, and runs QJ independent add chains.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);   // [d][QJ]
   const int j = blockIdx.x * WG + threadIdx.x;
   const int q0 = blockIdx.y * QJ;
+  for (int i = threadIdx.x; i < d * QJ; i += WG) {
+    const int t = i / d, dim = i - t * d;       // coalesced over dim inside a query row
+    const int q = (q0 + t < Q) ? (q0 + t) : (Q - 1);
+    qs[dim * QJ + t] = queries[(size_t)q * d + dim];
+  }
+  __syncthreads();
   float acc[QJ];
-  const float* qrow[QJ];
 #pragma unroll
-  for (int t = 0; t < QJ; ++t) {
-    acc[t] = 0.0f;
-    qrow[t] = queries + (size_t)((q0 + t < Q) ? (q0 + t) : (Q - 1)) * d;
-  }
-  int i = 0;
-  for (; i + 4 <= d; i += 4) {   // 4 dimensions per trip: wide scalar loads, 4 vector loads in flight
-    float cv[4];
+  for (int t = 0; t < QJ; ++t) acc[t] = 0.0f;
+  // centroid values are fetched DB dimensions ahead of their use (one wave per SIMD here, so
+  // nothing else would hide the L2 latency)
+  constexpr int DB = 8;
+  float cn[DB];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) cv[u] = coarseT[(size_t)(i + u) * Cpad + j];
+  for (int u = 0; u < DB; ++u) cn[u] = (u < d) ? coarseT[(size_t)u * Cpad + j] : 0.0f;
+  for (int i0 = 0; i0 < d; i0 += DB) {
+    float cc[DB];
 #pragma unroll
-    for (int t = 0; t < QJ; ++t) {
+    for (int u = 0; u < DB; ++u) cc[u] = cn[u];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float df = qrow[t][i + u] - cv[u];
-        const float p = df * df;
-        acc[t] = acc[t] + p;
-      }
+    for (int u = 0; u < DB; ++u) {
+      const int in = i0 + DB + u;
+      cn[u] = (in < d) ? coarseT[(size_t)in * Cpad + j] : 0.0f;
     }
-  }
-  for (; i < d; ++i) {
-    const float cv = coarseT[(size_t)i * Cpad + j];
 #pragma unroll
-    for (int t = 0; t < QJ; ++t) {
-      const float df = qrow[t][i] - cv;
-      const float p = df * df;
-      acc[t] = acc[t] + p;
+    for (int u = 0; u < DB; ++u) {
+      const int i = i0 + u;
+      if (i < d) {
+        const float4* qrow = reinterpret_cast<const float4*>(qs + i * QJ);
+#pragma unroll
+        for (int t4 = 0; t4 < QJ / 4; ++t4) {
+          const float4 qv = qrow[t4];
+          const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const float df = qa[w] - cc[u];
+            const float p = df * df;
+            acc[t4 * 4 + w] = acc[t4 * 4 + w] + p;
+          }
+        }
+      }
     }
   }
 #pragma unroll
