@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--K", type=int, default=1024)
     ap.add_argument("--nprobe", type=int, default=10)
     ap.add_argument("--k", type=int, default=5)
-    ap.add_argument("--cpu-sample", type=int, default=256, help="queries timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
     return ap.parse_args()
 
@@ -129,14 +129,26 @@ def main():
     if rank == 0:
         # algorithmic bytes per query: sum of probed list lengths * (m*2 + 4) + query + result
         bytes_per_launch = scanned_rows * (a.m * 2 + 4) + a.Q * (300 * 4 + a.k * 8)
-        kern = {n: {"launches": l, "avg_us": 1e3 * ms / max(l, 1)} for n, (l, ms) in prof.items()}
+        kern = {n: {"launches": l, "avg_us": round(1e3 * ms / max(l, 1), 2)} for n, (l, ms) in prof.items()}
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
         roof = None
         if dom:
             avg_s = prof[dom][1] / max(prof[dom][0], 1) / 1e3
             ach = bytes_per_launch / avg_s / 1e9
+            # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes of this same
+            # command (profiles/latest_pmc.json, written by tools/profile_round.sh): 2 x FETCH_SIZE
+            # (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KiB -> bytes.
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+                kname = {"ivf_fused": "ivf_fused_kernel", "adc_scan": "adc_scan_kernel", "lut_build": "lut_build_kernel",
+                         "coarse_dist": "coarse_dist_kernel", "probe_plan": "probe_plan_kernel"}.get(dom, dom)
+                if kname in pmc:
+                    traffic = int((2 * pmc[kname].get("fetch_kib", 0) + pmc[kname].get("write_kib", 0)) * 1024)
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
                     "avg_launch_us": round(avg_s * 1e6, 2)}
 

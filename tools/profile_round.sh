@@ -1,0 +1,31 @@
+#!/bin/bash
+# GPU-box helper: the three rocprofv3 passes behind profiles/<tag>_* (kernel trace + stats, and one
+# PMC pass each for FETCH_SIZE and WRITE_SIZE -- they do not fit one pass on gfx950), condensed to
+# small text/JSON files under gpurun_out/prof/.
+#   usage: tools/profile_round.sh <tag> [extra bench.py args]
+set -u
+TAG=${1:-rXX}; shift || true
+export TMPDIR=/tmp
+T=/tmp/prof_$TAG; rm -rf $T; mkdir -p $T gpurun_out/prof
+B="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall $*"
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -o r -- $B > gpurun_out/prof/${TAG}_bench_under_trace.json 2> $T/trace.err
+python3 tools/prof_summary.py stats $T/trace gpurun_out/prof/${TAG}_kernel_stats.txt > /dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/fetch -o r -- $B > /dev/null 2> $T/fetch.err
+python3 tools/prof_summary.py FETCH_SIZE $T/fetch gpurun_out/prof/${TAG}_pmc_fetch_size.txt > /dev/null
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $T/write -o r -- $B > /dev/null 2> $T/write.err
+python3 tools/prof_summary.py WRITE_SIZE $T/write gpurun_out/prof/${TAG}_pmc_write_size.txt > /dev/null
+python3 - "$TAG" <<'PY'
+import json, re, sys
+tag = sys.argv[1]
+out = {}
+for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
+    for line in open(f"gpurun_out/prof/{tag}_pmc_{name}.txt"):
+        m = re.match(r"(.*?)\s+dispatches=\s*(\d+)\s+avg=\s*([0-9.]+)", line)
+        if m:
+            k = m.group(1).split("(")[0].replace("void ", "").replace("freddy::", "").strip()
+            k = re.sub(r"<.*", "", k)
+            out.setdefault(k, {})[key] = float(m.group(3))
+json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
+print(json.dumps(out))
+PY
+cat gpurun_out/prof/${TAG}_kernel_stats.txt
