@@ -125,6 +125,17 @@ def main():
     scanned_rows = index.last_scanned_rows()
     straggler = int(d_status[0].item())
 
+    # ---- the same batch through the synchronous host-buffer ABI (H2D of queries, D2H of results,
+    # one stream sync per call): reported beside `value`, never as `value`
+    host_qps = None
+    if rank == 0:
+        h_q = d_q.cpu().numpy()
+        index.search(h_q, a.k, a.nprobe)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            index.search(h_q, a.k, a.nprobe)
+        host_qps = 10 * a.Q / (time.perf_counter() - t0)
+
     out = None
     if rank == 0:
         # algorithmic bytes per query: sum of probed list lengths * (m*2 + 4) + query + result
@@ -190,6 +201,7 @@ def main():
                        "batch_per_gpu": a.Q, "parallelism": f"dp{world}"},
             "recall_at_5": None if recall is None else round(recall, 4),
             "queries_needing_extra_round": straggler,
+            "host_buffer_abi_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "roofline": roof, "kernels": kern, "cpu_baseline": cpu,
         }
     if world > 1:
