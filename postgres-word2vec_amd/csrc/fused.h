@@ -192,6 +192,13 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) cw[r] = a.packed[(row_block(r) * M2 + (uint32_t)pair) * 64u + (uint32_t)lane];
   };
+  // Slab layout: [code][G items] floats (64 bytes per code).  A row's four 16-byte chunks are
+  // stored at chunk index (q ^ ((code >> 1) & 3)): readers (one random row per lane) are not
+  // affected, writers (64 consecutive rows per wave, same item) spread over 8 bank groups
+  // instead of 2.
+  static_assert(G == 16, "slab rows hold 16 items");
+  auto slab_at = [&](int code, int g) { return code * G + ((((g >> 2) ^ ((code >> 1) & 3))) << 2) + (g & 3); };
+
   // Residual sub-vectors of the group's items live in LDS, padded to SP floats per position so
   // that a lane fetches four dimensions with one aligned ds_read_b128 (all lanes read the same
   // address: a broadcast, no bank conflict).  Two items are built together: their two packed
@@ -245,24 +252,29 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
           }
         }
       }
-      if (FULLK || tid < K) dst[g * K + tid] = s0.x;
-      if (FULLK || tid + T < K) dst[g * K + tid + T] = s0.y;
-      if (g + 1 < cnt) {
-        if (FULLK || tid < K) dst[(g + 1) * K + tid] = s1.x;
-        if (FULLK || tid + T < K) dst[(g + 1) * K + tid + T] = s1.y;
-      }
+      // slab layout [code][16 items], 16-byte item chunks XOR-swizzled by the code row (see
+      // slab_at): the pair (g, g+1) of one code is one aligned 8-byte store.  An unused odd slot
+      // (g+1 == cnt) receives a value nobody reads.
+      if (FULLK || tid < K) *reinterpret_cast<v2f*>(dst + slab_at(tid, g)) = v2f{s0.x, s1.x};
+      if (FULLK || tid + T < K) *reinterpret_cast<v2f*>(dst + slab_at(tid + T, g)) = v2f{s0.y, s1.y};
     }
   };
   auto gather = [&](int p, const float* cur) {
     const int sh = (p & 1) * 16;
-    uint32_t code[RMAX];
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) code[r] = (cw[r] >> sh) & 0xffffu;
+    for (int r = 0; r < RMAX; ++r) {
+      const int code = (int)((cw[r] >> sh) & 0xffffu);
+      const int sw = (code >> 1) & 3;
+      const float* row = cur + code * G;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (g < cnt) {   // workgroup-uniform; only LDS reads inside
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) acc[g][r] = acc[g][r] + cur[g * K + (int)code[r]];
+      for (int q = 0; q < G / 4; ++q) {
+        if (q * 4 < cnt) {   // workgroup-uniform; a row's 4 items of chunk q in ONE 16-byte LDS read
+          const float4 v = *reinterpret_cast<const float4*>(row + ((q ^ sw) << 2));
+          acc[q * 4 + 0][r] = acc[q * 4 + 0][r] + v.x;
+          acc[q * 4 + 1][r] = acc[q * 4 + 1][r] + v.y;
+          acc[q * 4 + 2][r] = acc[q * 4 + 2][r] + v.z;
+          acc[q * 4 + 3][r] = acc[q * 4 + 3][r] + v.w;
+        }
       }
     }
   };
