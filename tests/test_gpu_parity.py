@@ -215,3 +215,42 @@ def test_ivfadc_long_lists_overflow_units(gpu, oracle):
         exp = oracle.ivfadc_search_many(ot, qs, k, W)
         util.assert_same_lists(gi, gd, exp, f"long lists W={W} k={k}")
     idx.close()
+
+
+@pytest.mark.parametrize("fused", ["1", "0", "auto"])
+def test_ivfadc_randomised_small_indexes(gpu, oracle, fused, monkeypatch):
+    """FREDDY_GPU_FUSED=1 forces the fused kernel even for tiny batches, 0 the generic kernels,
+    unset lets the library choose.  Many small random tables with deliberately nasty shapes: empty cells, cells longer than one
+    4096-row chunk, more than 16 queries probing one cell (several fused groups per cell), heavy
+    distance ties (few distinct code rows), k up to 32, W up to C."""
+    if fused != "auto":
+        monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
+    rng = np.random.default_rng(123)
+    d, m = 300, 12
+    for trial in range(12):
+        K = int(rng.choice([4, 16, 64, 256]))
+        C = int(rng.choice([1, 2, 5, 9]))
+        N = int(rng.choice([50, 700, 9000]))
+        coarse = rng.standard_normal((C, d)).astype(np.float32)
+        codebook = (rng.standard_normal((m, K, 25)) * 0.3).astype(np.float32)
+        cell = rng.integers(0, C, size=N) if trial % 3 else np.zeros(N, np.int64)   # every 3rd: all rows in one cell
+        if C > 2:
+            cell[cell == 1] = 0                                                      # cell 1 stays empty
+        order = np.argsort(cell, kind="stable")
+        ids = (np.arange(N) * 3 + 7).astype(np.int32)[order]                         # non-contiguous ids
+        n_distinct = int(rng.choice([1, 3, 50]))
+        pool = rng.integers(0, K, size=(n_distinct, m)).astype(np.int16)
+        codes = pool[rng.integers(0, n_distinct, size=N)][order]
+        list_off = np.zeros(C + 1, np.int32)
+        list_off[1:] = np.cumsum(np.bincount(cell, minlength=C))
+        ids_sorted = np.concatenate([np.sort(ids[list_off[c]:list_off[c + 1]]) for c in range(C)]).astype(np.int32)
+        ot = oracle.ivf_table(coarse, codebook, list_off, ids_sorted, codes)
+        idx = gpu.IVFIndex(coarse, codebook, list_off, ids_sorted, codes)
+        Q = int(rng.choice([1, 40, 300]))
+        qs = (coarse[rng.integers(0, C, size=Q)] + 0.2 * rng.standard_normal((Q, d))).astype(np.float32)
+        for k, W in [(1, 1), (5, min(3, C)), (32, C)]:
+            for rule, sent in [(0, 1000.0), (1, 100.0)]:
+                gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+                exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+                util.assert_same_lists(gi, gd, exp, f"random trial={trial} K={K} C={C} N={N} Q={Q} k={k} W={W} rule={rule}")
+        idx.close()
