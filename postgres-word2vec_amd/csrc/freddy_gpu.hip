@@ -503,7 +503,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   if (fused) {
     // cell_count[C] + cell_fill[C] + cell_start[C]; group table: 3 arrays of (items/G + C) entries
     if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * items) ||
-        ix->w_groups.ensure(sizeof(int32_t) * 3 * (items / FUSED_G + (size_t)C + 1)) ||
+        ix->w_groups.ensure(sizeof(int32_t) * 3 * (items / FUSED_G + (size_t)C + 1) * upi) ||
         ix->w_surv.ensure(sizeof(u64) * items * surv_cap) || ix->w_surv_cnt.ensure(sizeof(int32_t) * items))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
@@ -557,7 +557,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
     if (fused) {
       HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * n_items, s));
-      const size_t max_groups = (size_t)n_items / FUSED_G + (size_t)C + 1;
+      const size_t max_groups = ((size_t)n_items / FUSED_G + (size_t)C + 1) * upi;   // (group, chunk) work entries
       int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
       int32_t* cell_fill = cell_count + C;
       int32_t* cell_start = cell_count + 2 * (size_t)C;
@@ -566,8 +566,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       int32_t* group_cnt = group_first + max_groups;
       int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
       timed_launch(ix, s, "group_items", [&] {
-        hipLaunchKernelGGL(group_table_kernel, dim3(1), dim3(64), 0, s, cell_count, C, cell_start, group_cell, group_first,
-                           group_cnt, n_groups);
+        hipLaunchKernelGGL(group_table_kernel, dim3(1), dim3(64), 0, s, cell_count, C, ix->blk_off, cell_start, group_cell,
+                           group_first, group_cnt, n_groups);
         hipLaunchKernelGGL(bucket_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, pa.item_cell, n_items,
                            cell_start, cell_fill, ix->w_sorted.as<int32_t>());
       });
@@ -597,9 +597,9 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       }
       timed_launch(ix, s, "ivf_fused", [&] {
         if (K == FUSED_T * FUSED_E)
-          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3((unsigned)max_groups, (unsigned)upi), dim3(FUSED_T), flds, s, fa);
+          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3((unsigned)max_groups), dim3(FUSED_T), flds, s, fa);
         else
-          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3((unsigned)max_groups, (unsigned)upi), dim3(FUSED_T), flds, s, fa);
+          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3((unsigned)max_groups), dim3(FUSED_T), flds, s, fa);
       });
       HIP_TRY(hipGetLastError());
       MergeSurvArgs ms;

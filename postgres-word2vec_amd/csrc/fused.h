@@ -40,11 +40,14 @@ static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row bloc
 // one cell; bucket_items scatters the items into cell order.  (Order inside a cell is
 // irrelevant: every item is selected and merged on its own.)
 // ---------------------------------------------------------------------------------------
+// One work entry per (group of <= FUSED_G items of a cell, 4096-row chunk of the cell's list), so
+// the fused kernel's grid has no holes: entries past n_groups[0] sit at the end of the grid.
 __global__ __launch_bounds__(64) void group_table_kernel(const int32_t* __restrict__ cell_count, int C,
+                                                        const int32_t* __restrict__ blk_off,
                                                         int32_t* __restrict__ cell_start,   // [C]
-                                                        int32_t* __restrict__ group_cell,   // [max groups]
+                                                        int32_t* __restrict__ group_cell,   // [max work]
                                                         int32_t* __restrict__ group_first,  // index into sorted items
-                                                        int32_t* __restrict__ group_cnt,
+                                                        int32_t* __restrict__ group_cnt,    // items | chunk << 8
                                                         int32_t* __restrict__ n_groups) {
   const int lane = threadIdx.x;
   const int per = (C + 63) / 64;
@@ -52,8 +55,9 @@ __global__ __launch_bounds__(64) void group_table_kernel(const int32_t* __restri
   int items = 0, groups = 0;
   for (int c = c0; c < c1; ++c) {
     const int n = cell_count[c];
+    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
     items += n;
-    groups += (n + FUSED_G - 1) / FUSED_G;
+    groups += ((n + FUSED_G - 1) / FUSED_G) * chunks;
   }
   int it_off = items, gr_off = groups;   // inclusive wave scan
 #pragma unroll
@@ -66,12 +70,15 @@ __global__ __launch_bounds__(64) void group_table_kernel(const int32_t* __restri
   gr_off -= groups;
   for (int c = c0; c < c1; ++c) {
     const int n = cell_count[c];
+    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
     cell_start[c] = it_off;
     for (int f = 0; f < n; f += FUSED_G) {
-      group_cell[gr_off] = c;
-      group_first[gr_off] = it_off + f;
-      group_cnt[gr_off] = (n - f < FUSED_G) ? n - f : FUSED_G;
-      ++gr_off;
+      for (int ch = 0; ch < chunks; ++ch) {
+        group_cell[gr_off] = c;
+        group_first[gr_off] = it_off + f;
+        group_cnt[gr_off] = ((n - f < FUSED_G) ? n - f : FUSED_G) | (ch << 8);
+        ++gr_off;
+      }
     }
     it_off += n;
   }
@@ -135,11 +142,12 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int K = a.K;
-  const int gid = blockIdx.x, chunk = blockIdx.y;
+  const int gid = blockIdx.x;
   if (gid >= a.n_groups[0]) return;
   const int cell = a.group_cell[gid];
   const int first = a.group_first[gid];
-  const int cnt = a.group_cnt[gid];
+  const int cnt = a.group_cnt[gid] & 0xff;
+  const int chunk = a.group_cnt[gid] >> 8;
   const int blk0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
   int nblk = a.blk_off[cell + 1] - blk0;
   if (nblk <= 0) return;
