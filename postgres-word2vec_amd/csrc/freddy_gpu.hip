@@ -87,6 +87,7 @@ struct freddy_gpu_index {
   int64_t bytes = 0;
   int64_t last_scanned_rows = 0;
   int last_Q = 0;
+  int n_cus = 256;
   // pinned tables
   float* coarse = nullptr;      // [C][d]
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
@@ -225,6 +226,8 @@ static int open_device(freddy_gpu_index* ix, int device) {
   HIP_TRY(hipSetDevice(device));
   ix->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ix->n_cus = prop.multiProcessorCount;
   return 0;
 }
 
@@ -575,7 +578,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       FusedArgs fa;
       fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query;
       fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cell; fa.group_first = group_first;
-      fa.group_cnt = group_cnt; fa.n_groups = n_groups;
+      fa.group_cnt = group_cnt; fa.n_groups = n_groups; fa.work_counter = ix->w_cnt.as<int32_t>() + 2;
+      HIP_TRY(hipMemsetAsync(ix->w_cnt.as<int32_t>() + 2, 0, sizeof(int32_t), s));
       fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
       fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
       fa.cand_count = (found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
@@ -584,7 +588,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
       const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(u64) + 64 * sizeof(u64);
       const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
-      const size_t flds = desc_off + 64 + (size_t)FUSED_G * 12 * 28 * sizeof(float);   // + item ids + padded residuals
+      const size_t flds = desc_off + 128 + (size_t)FUSED_G * 12 * 28 * sizeof(float);   // + item ids + padded residuals
       fa.desc_offset = (uint32_t)desc_off;
       { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
       static bool fattr = false;
@@ -595,11 +599,13 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         fattr = true;
       }
+      // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
+      const unsigned n_persist = (unsigned)std::min<size_t>(max_groups, (size_t)ix->n_cus);
       timed_launch(ix, s, "ivf_fused", [&] {
         if (K == FUSED_T * FUSED_E)
-          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3((unsigned)max_groups), dim3(FUSED_T), flds, s, fa);
+          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
         else
-          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3((unsigned)max_groups), dim3(FUSED_T), flds, s, fa);
+          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
       });
       HIP_TRY(hipGetLastError());
       MergeSurvArgs ms;

@@ -102,7 +102,8 @@ struct FusedArgs {
   const int32_t* group_cell;   // [groups]
   const int32_t* group_first;
   const int32_t* group_cnt;
-  const int32_t* n_groups;     // [1]
+  const int32_t* n_groups;     // [1] number of (group, chunk) work entries
+  int32_t* work_counter;       // [1] zeroed before the launch
   const float* cbP;            // [m][SP/4][512][4 dims][2 codes] (see load_cb)
   const int32_t* blk_off;      // [C+1]
   const uint32_t* packed;      // [blocks][M2][64]
@@ -142,19 +143,23 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int K = a.K;
-  const int gid = blockIdx.x;
-  if (gid >= a.n_groups[0]) return;
+  // persistent workgroups: one per CU, work entries are pulled from a device-wide counter
+  const int n_work = a.n_groups[0];
+  int32_t* desc = reinterpret_cast<int32_t*>(smem + a.desc_offset);   // [G] item ids, [G] = next work index
+  for (;;) {
+  if (tid == 0) desc[G] = atomicAdd(a.work_counter, 1);
+  __syncthreads();
+  const int gid = desc[G];
+  if (gid >= n_work) break;
   const int cell = a.group_cell[gid];
   const int first = a.group_first[gid];
   const int cnt = a.group_cnt[gid] & 0xff;
   const int chunk = a.group_cnt[gid] >> 8;
   const int blk0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
   int nblk = a.blk_off[cell + 1] - blk0;
-  if (nblk <= 0) return;
-  if (nblk > FUSED_UNIT_BLOCKS) nblk = FUSED_UNIT_BLOCKS;
+  if (nblk > FUSED_UNIT_BLOCKS) nblk = FUSED_UNIT_BLOCKS;   // (>= 1 by construction of the work table)
 
-  int32_t* desc = reinterpret_cast<int32_t*>(smem + a.desc_offset);   // [G] item ids
-  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 64);   // [G][M][SP] residuals
+  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 128);  // [G][M][SP] residuals
   if (tid < G) desc[tid] = (tid < cnt) ? a.sorted_item[first + tid] : -1;
   __syncthreads();
   {
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     }
     lds_barrier();
   }
-  if (a.ablate & 4) return;
+  if (a.ablate & 4) { __syncthreads(); continue; }
 
   // ---- selection -------------------------------------------------------------------------
   u64* exch = reinterpret_cast<u64*>(smem);          // [G][T], aliases the slabs (all reads done)
@@ -391,6 +396,8 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
       }
     }
   }
+  __syncthreads();   // the LDS regions are reused by the next work entry
+  }  // persistent loop
 }
 
 // ---------------------------------------------------------------------------------------
