@@ -45,9 +45,12 @@ __global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict
     qs[dim * QJ + t] = queries[(size_t)q * d + dim];
   }
   __syncthreads();
-  float acc[QJ];
+  // packed fp32 math: two queries per instruction (each half is an IEEE binary32 op, so the
+  // sub/mul/add chain of every (query, cell) pair rounds exactly like squareDistance)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f acc2[QJ / 2];
 #pragma unroll
-  for (int t = 0; t < QJ; ++t) acc[t] = 0.0f;
+  for (int t = 0; t < QJ / 2; ++t) acc2[t] = v2f{0.0f, 0.0f};
   // centroid values are fetched DB dimensions ahead of their use (one wave per SIMD here, so
   // nothing else would hide the L2 latency)
   constexpr int DB = 8;
@@ -68,20 +71,22 @@ __global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict
       const int i = i0 + u;
       if (i < d) {
         const float4* qrow = reinterpret_cast<const float4*>(qs + i * QJ);
+        const v2f c2 = {cc[u], cc[u]};
 #pragma unroll
         for (int t4 = 0; t4 < QJ / 4; ++t4) {
           const float4 qv = qrow[t4];
-          const float qa[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const float df = qa[w] - cc[u];
-            const float p = df * df;
-            acc[t4 * 4 + w] = acc[t4 * 4 + w] + p;
-          }
+          const v2f qa = {qv.x, qv.y}, qb = {qv.z, qv.w};
+          const v2f da = qa - c2, db = qb - c2;
+          const v2f pa = da * da, pb = db * db;
+          acc2[t4 * 2 + 0] = acc2[t4 * 2 + 0] + pa;
+          acc2[t4 * 2 + 1] = acc2[t4 * 2 + 1] + pb;
         }
       }
     }
   }
+  float acc[QJ];
+#pragma unroll
+  for (int t = 0; t < QJ / 2; ++t) { acc[2 * t] = acc2[t].x; acc[2 * t + 1] = acc2[t].y; }
 #pragma unroll
   for (int t = 0; t < QJ; ++t)
     if (q0 + t < Q) dist[(size_t)(q0 + t) * Cpad + j] = acc[t];
