@@ -79,12 +79,14 @@ def main():
     rng = np.random.default_rng(7 + rank)
     qids = np.sort(rng.choice(np.arange(1, a.N + 1), size=a.Q, replace=False)).astype(np.int64)
     d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
-    d_ids = torch.empty((a.Q, a.k), dtype=torch.int32, device=dev)
-    d_dist = torch.empty((a.Q, a.k), dtype=torch.float32, device=dev)
+    # ids and distances of the shard live in ONE buffer so that the per-shard top-k crosses xGMI
+    # in a single RCCL all_gather (the payload is 40 KB per rank: pure latency)
+    d_res = torch.empty((2, a.Q, a.k), dtype=torch.int32, device=dev)
+    d_ids = d_res[0]
+    d_dist = d_res[1].view(torch.float32)
     d_status = torch.zeros(4, dtype=torch.int32, device=dev)
     if world > 1:
-        g_ids = torch.empty((world * a.Q, a.k), dtype=torch.int32, device=dev)
-        g_dist = torch.empty((world * a.Q, a.k), dtype=torch.float32, device=dev)
+        g_res = torch.empty((world, 2, a.Q, a.k), dtype=torch.int32, device=dev)
 
     stream = torch.cuda.current_stream(dev)
 
@@ -92,8 +94,7 @@ def main():
         index.search_dev(d_q.data_ptr(), a.Q, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, d_ids.data_ptr(),
                          d_dist.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_ids, d_ids)
-            dist.all_gather_into_tensor(g_dist, d_dist)
+            dist.all_gather_into_tensor(g_res, d_res)
 
     def barrier():
         torch.cuda.synchronize(dev)
