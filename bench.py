@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     return ap.parse_args()
 
 
@@ -52,13 +53,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in single-GPU dry runs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
 
     from freddy_amd import gpu, index_build as ib
 
@@ -72,7 +77,7 @@ def main():
     tab = ib.build_ivf_index(x, C=a.C, m=a.m, K=a.K, train_size=100000, iters=10, seed=2)
     log(f"corpus+index built in {time.time() - t0:.1f}s")
     t0 = time.time()
-    index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=local_rank)
+    index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=dev_index)
     log(f"pinned {index.nbytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
 
     # queries = indexed vectors themselves (ivfadc_batch_search takes ids), distinct per rank
@@ -94,7 +99,7 @@ def main():
         index.search_dev(d_q.data_ptr(), a.Q, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, d_ids.data_ptr(),
                          d_dist.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_res, d_res)
+            dist.all_gather_into_tensor(g_res.view(-1), d_res.view(-1))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -171,7 +176,7 @@ def main():
             recall = ib.recall_at_k(d_ids.cpu().numpy(), exact)
 
         cpu = None
-        if a.cpu_sample > 0:
+        if a.cpu_sample > 0 and world == 1:   # reported at N=1 only
             from oracle.oracle import Oracle
             o = Oracle()
             ot = o.ivf_table(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"])
