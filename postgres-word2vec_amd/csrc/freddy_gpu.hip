@@ -506,7 +506,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   if (fused) {
     // cell_count[C] + cell_fill[C] + cell_start[C]; group table: 3 arrays of (items/G + C) entries
     if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * items) ||
-        ix->w_groups.ensure(sizeof(int32_t) * 3 * (items / FUSED_G + (size_t)C + 1) * upi) ||
+        ix->w_groups.ensure(sizeof(int32_t) * 6 * (items / FUSED_G + (size_t)C + 1) * upi) ||
         ix->w_surv.ensure(sizeof(u64) * items * surv_cap) || ix->w_surv_cnt.ensure(sizeof(int32_t) * items))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
@@ -573,12 +573,14 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                            group_first, group_cnt, n_groups);
         hipLaunchKernelGGL(bucket_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, pa.item_cell, n_items,
                            cell_start, cell_fill, ix->w_sorted.as<int32_t>());
+        hipLaunchKernelGGL(sort_work_kernel, dim3(1), dim3(256), 0, s, n_groups, ix->blk_off, group_cell, group_first, group_cnt,
+                           group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups);
       });
       HIP_TRY(hipGetLastError());
       FusedArgs fa;
       fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query;
-      fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cell; fa.group_first = group_first;
-      fa.group_cnt = group_cnt; fa.n_groups = n_groups; fa.work_counter = ix->w_cnt.as<int32_t>() + 2;
+      fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cnt + max_groups;
+      fa.group_first = group_cnt + 2 * max_groups; fa.group_cnt = group_cnt + 3 * max_groups; fa.n_groups = n_groups; fa.work_counter = ix->w_cnt.as<int32_t>() + 2;
       HIP_TRY(hipMemsetAsync(ix->w_cnt.as<int32_t>() + 2, 0, sizeof(int32_t), s));
       fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
       fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();

@@ -84,6 +84,42 @@ __global__ __launch_bounds__(64) void group_table_kernel(const int32_t* __restri
   }
 }
 
+// Longest-processing-time-first order for the persistent workgroups: entries with more items
+// (more slab arithmetic) are pulled first, so the tail of the launch is made of small entries.
+// One workgroup; counting sort on (items, rows) classes; order inside a class is irrelevant.
+__global__ __launch_bounds__(256) void sort_work_kernel(const int32_t* __restrict__ n_work_p,
+                                                       const int32_t* __restrict__ blk_off,
+                                                       const int32_t* __restrict__ in_cell, const int32_t* __restrict__ in_first,
+                                                       const int32_t* __restrict__ in_cnt, int32_t* __restrict__ out_cell,
+                                                       int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt) {
+  constexpr int NB = FUSED_G * 4 + 4;   // class = (items, quarter of a full chunk), descending
+  __shared__ int hist[NB];
+  __shared__ int start[NB];
+  const int n = n_work_p[0];
+  for (int i = threadIdx.x; i < NB; i += 256) hist[i] = 0;
+  __syncthreads();
+  auto klass = [&](int e) {
+    const int cnt = in_cnt[e] & 0xff, chunk = in_cnt[e] >> 8, c = in_cell[e];
+    int nb = blk_off[c + 1] - blk_off[c] - chunk * FUSED_UNIT_BLOCKS;
+    nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
+    const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
+    return (FUSED_G - cnt) * 4 + (3 - rq);                     // small class index = big entry
+  };
+  for (int e = threadIdx.x; e < n; e += 256) atomicAdd(&hist[klass(e)], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int b = 0; b < NB; ++b) { start[b] = acc; acc += hist[b]; }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int slot = atomicAdd(&start[klass(e)], 1);
+    out_cell[slot] = in_cell[e];
+    out_first[slot] = in_first[e];
+    out_cnt[slot] = in_cnt[e];
+  }
+}
+
 __global__ __launch_bounds__(256) void bucket_items_kernel(const int32_t* __restrict__ item_cell, int n_items,
                                                           const int32_t* __restrict__ cell_start,
                                                           int32_t* __restrict__ cell_fill,
