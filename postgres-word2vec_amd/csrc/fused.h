@@ -187,6 +187,10 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   __syncthreads();
   const int gid = desc[G];
   if (gid >= n_work) break;
+  // opaque per iteration: stops LICM from hoisting (and then spilling) one 64-bit codebook address
+  // per position out of the persistent loop
+  const float* cbp = a.cbP;
+  asm volatile("" : "+s"(cbp));
   const int cell = a.group_cell[gid];
   const int first = a.group_first[gid];
   const int cnt = a.group_cnt[gid] & 0xff;
@@ -229,8 +233,11 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     constexpr int SPq = ((S + 3) & ~3) / 4;
 #pragma unroll
     for (int jb = 0; jb < SPq; ++jb) {
-      const float4* src = reinterpret_cast<const float4*>(a.cbP) + (((size_t)p * SPq + jb) * T + tid) * 2;
-      const float4 lo = src[0], hi = src[1];
+      // 32-bit element offset from the (scalar) table base: keeps the address in one VGPR instead of
+      // a hoisted 64-bit pointer per position
+      const uint32_t off = ((uint32_t)(p * SPq + jb) * T + (uint32_t)tid) * 2u;
+      const float4* base4 = reinterpret_cast<const float4*>(cbp);
+      const float4 lo = base4[off], hi = base4[off + 1u];
       if (jb * 4 + 0 < S) cb[jb * 4 + 0] = v2f{lo.x, lo.y};
       if (jb * 4 + 1 < S) cb[jb * 4 + 1] = v2f{lo.z, lo.w};
       if (jb * 4 + 2 < S) cb[jb * 4 + 2] = v2f{hi.x, hi.y};
@@ -328,10 +335,6 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     }
   };
 
-  // scan positions (row ids) of this lane's rows: needed only by the selection, fetched now
-  int32_t pid[RMAX];
-#pragma unroll
-  for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
   load_cb(0);
   load_codes(0);
   build_slab(0, slab);
@@ -365,6 +368,10 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     lds_barrier();
   }
   if (a.ablate & 4) { __syncthreads(); continue; }
+  // scan positions (row ids) of this lane's rows: only the selection needs them
+  int32_t pid[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
 
   // ---- selection -------------------------------------------------------------------------
   u64* exch = reinterpret_cast<u64*>(smem);          // [G][T], aliases the slabs (all reads done)
@@ -397,14 +404,17 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     if (lane == 0) tau_s[g] = t;
   }
   __syncthreads();
+  // Survivors {key <= tau} go to the items' buffers.  Pass 1 only counts them per (wave, item);
+  // then lane g reserves the wave's slots of item g with ONE atomic for all 16 items at once (a
+  // returning atomic per hit would serialise ~1 us round trips); pass 2 writes the keys.
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int my_n = 0;        // lane g: this wave's survivor count of item g
+  u64 any_mask = 0;    // bit g: this wave holds survivors of item g
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (g < cnt) {
       const u64 tau = tau_s[g];
-      const int it = __builtin_amdgcn_readfirstlane(desc[g]);
-      // a lane can only hold survivors if its own best key passes; most waves hold none at all
-      const u64 mine = exch[(size_t)g * T + tid];
+      const u64 mine = exch[(size_t)g * T + tid];   // a lane holds survivors only if its best key passes
       if (a.cand_count) {
         int accepted = 0;
 #pragma unroll
@@ -412,23 +422,36 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
           const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
           accepted += __popcll(__ballot(live[r] && key < sentinel_key));
         }
-        if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[it], accepted);
+        if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[desc[g]], accepted);
       }
       if (__ballot(mine <= tau && mine < sentinel_key) != 0ull) {
+        int n = 0;
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
           const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
-          const bool pass = live[r] && key < sentinel_key && key <= tau;
-          const u64 mask = __ballot(pass);
-          const int n = __popcll(mask);
-          if (n) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(a.surv_count + it, n);
-            base = __shfl(base, 0, 64);
-            const int idx = base + __popcll(mask & lt);
-            if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = key;
-          }
+          n += __popcll(__ballot(live[r] && key < sentinel_key && key <= tau));
         }
+        if (lane == g) my_n = n;
+        any_mask |= (1ull << g);
+      }
+    }
+  }
+  int my_base = 0;
+  if (lane < G && my_n > 0) my_base = atomicAdd(a.surv_count + desc[lane], my_n);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    if ((any_mask >> g) & 1ull) {   // wave-uniform
+      const u64 tau = tau_s[g];
+      const int it = __builtin_amdgcn_readfirstlane(desc[g]);
+      int run = __shfl(my_base, g, 64);
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
+        const bool pass = live[r] && key < sentinel_key && key <= tau;
+        const u64 mask = __ballot(pass);
+        const int idx = run + __popcll(mask & lt);
+        if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = key;
+        run += __popcll(mask);
       }
     }
   }
