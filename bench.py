@@ -190,7 +190,12 @@ def main():
             got_d = d_dist[:ns].cpu().numpy()
             parity = bool(np.array_equal(exp["id"], got_i) and
                           np.array_equal(exp["dist"].view(np.uint32), got_d.view(np.uint32)))
+            n1 = min(64, ns)   # one thread = one PostgreSQL backend
+            t0 = time.perf_counter()
+            o.ivfadc_search_many(ot, qs[:n1], a.k, a.nprobe, sentinel=1000.0, found_rule=0, n_threads=1)
+            one_core = n1 / (time.perf_counter() - t0)
             cpu = {"value": round(ns / cdt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
+                   "value_1_core": round(one_core, 2),
                    "sample": f"first {ns} of the {a.Q} bench queries, same index, nprobe={a.nprobe}, k={a.k}; "
                              f"oracle/ (C port of freddy.c:174-393 loops, gcc -O2, OpenMP over queries)",
                    "parity_with_gpu_on_sample": parity}
