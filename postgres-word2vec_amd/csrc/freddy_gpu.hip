@@ -423,7 +423,9 @@ static int launch_scan_m(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a,
 
 static int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_items) {
   if (n_items <= 0 || a.nchunk <= 0) return 0;
-  const size_t lds = (((size_t)a.m * a.K * 4 + 15) & ~(size_t)15) + (size_t)SCAN_WAVES * 64 * sizeof(u64);
+  const int Vl = pick_V(a.L);
+  const size_t lds = std::max((((size_t)a.m * a.K * 4 + 15) & ~(size_t)15) + (size_t)SCAN_WAVES * 64 * sizeof(u64),
+                              (size_t)SCAN_WAVES * 64 * Vl * sizeof(u64));
   dim3 grid((unsigned)a.nchunk, (unsigned)n_items);
   const int V = pick_V(a.L);
   if (a.m == 12) return launch_scan_m<12>(ix, s, a, grid, lds, V);
@@ -636,7 +638,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       ma.cand_count = sa.cand_count; ma.out_ids = d_out_ids; ma.out_dist = d_out_dist;
       ma.found = ix->w_found.as<int32_t>(); ma.next_active = next; ma.n_next = ix->w_cnt.as<int32_t>();
       ma.status = d_status;
-      ma.n_active = n_active; ma.parts_per_query = W * nchunk * SCAN_WAVES; ma.L = L; ma.k = k;
+      ma.n_active = n_active; ma.parts_per_query = W * nchunk; ma.L = L; ma.k = k;
       ma.found_rule = found_rule; ma.first_round = first ? 1 : 0; ma.sentinel = sentinel;
       if (int rc = launch_merge(ix, s, ma)) return rc;
     }
@@ -728,8 +730,8 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   const size_t lutN = (size_t)m * K;
   // enough (query, chunk) workgroups to fill the chip, but chunks long enough to amortise
   // the 48 KiB LUT staging
-  int chunk_blocks = 64;
-  while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)Q > 16384 && chunk_blocks < 4096) chunk_blocks *= 2;
+  int chunk_blocks = 64;   // 4096 rows; longer chunks once there are enough (query, chunk) workgroups
+  while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)Q > 4096 && chunk_blocks < 8192) chunk_blocks *= 2;
   const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
   if (ix->w_lut.ensure(sizeof(float) * (size_t)Q * lutN) ||
       ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * SCAN_WAVES * L))
@@ -746,7 +748,7 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   ma.part = sa.part; ma.active = nullptr; ma.pos_to_id = ix->ids; ma.round_rows = nullptr; ma.cand_count = nullptr;
   ma.out_ids = d_out_ids; ma.out_dist = d_out_dist; ma.found = nullptr; ma.next_active = nullptr; ma.n_next = nullptr;
   ma.status = nullptr;
-  ma.n_active = Q; ma.parts_per_query = nchunk * SCAN_WAVES; ma.L = L; ma.k = k; ma.found_rule = 0; ma.first_round = 1;
+  ma.n_active = Q; ma.parts_per_query = nchunk; ma.L = L; ma.k = k; ma.found_rule = 0; ma.first_round = 1;
   ma.sentinel = sentinel;
   return launch_merge(ix, s, ma);
 }

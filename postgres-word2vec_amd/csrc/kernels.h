@@ -293,7 +293,7 @@ __global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __re
 //   coalesced dwords of packed int16 codes + one dword of scan position, m LDS gathers
 //   summed in position order (index_utils.c:1126-1133), then WaveSelect on the 64-bit
 //   (distance, position) key.
-//   Output: each wave's L smallest keys -> part[((item*nchunk + chunk)*SCAN_WAVES + wave)*L + r].
+//   Output: the workgroup's L smallest keys -> part[(item*nchunk + chunk)*L + r].
 // ---------------------------------------------------------------------------------------
 static constexpr int SCAN_WG = 512;
 static constexpr int SCAN_WAVES = SCAN_WG / 64;
@@ -305,7 +305,7 @@ struct ScanArgs {
   const int32_t* blk_off;     // [n_lists+1] first row block of each list
   const uint32_t* packed;     // [blocks][M2][64] two int16 codes per dword
   const int32_t* pos;         // [blocks*64] scan position (row id / row index), -1 = padding
-  u64* part;                  // [items][nchunk][SCAN_WAVES][L]
+  u64* part;                  // [items][nchunk][L]
   int32_t* cand_count;        // [Q] += candidates with dist < sentinel (FOUND_ACCEPTED rule)
   int m, K, chunk_blocks, nchunk, L;
   uint32_t sentinel_bits;
@@ -414,11 +414,27 @@ __global__ __launch_bounds__(SCAN_WG) void adc_scan_kernel(ScanArgs a) {
     }
     sel.finish();
   }
-  u64* out = a.part + (((size_t)item * a.nchunk + chunk) * SCAN_WAVES + wave) * a.L;
+  // the 8 waves' lists meet in LDS (the LUT is dead by now) and wave 0 merges them, so the
+  // workgroup emits ONE list of L keys
+  __syncthreads();
+  u64* lists = reinterpret_cast<u64*>(smem);   // [SCAN_WAVES][64*V]
 #pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const int r = v * 64 + lane;
-    if (r < a.L) out[r] = sel.acc[v];
+  for (int v = 0; v < V; ++v) lists[((size_t)wave * V + v) * 64 + lane] = sel.acc[v];
+  __syncthreads();
+  if (wave == 0) {
+    for (int w = 1; w < SCAN_WAVES; ++w) {
+      for (int v = 0; v < V; ++v) {
+        const u64 key = lists[((size_t)w * V + v) * 64 + lane];
+        if (__ballot(key != KEY_INF) == 0ull) break;   // ascending: the rest of this list is empty too
+        wave_topk_absorb<V>(sel.acc, key);
+      }
+    }
+    u64* out = a.part + ((size_t)item * a.nchunk + chunk) * a.L;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int r = v * 64 + lane;
+      if (r < a.L) out[r] = sel.acc[v];
+    }
   }
   if (a.cand_count && lane == 0 && accepted)
     atomicAdd(a.cand_count + (a.item_query ? a.item_query[item] : item), accepted);
