@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -75,6 +76,8 @@ struct JoinIndex {
   // host
   std::vector<int32_t> h_ids, h_cell;
   std::vector<float> h_stats;
+  std::vector<uint8_t> h_mark;   // [N] scratch of the "id IN (targets)" resolution, all zero between calls
+  bool ids_affine = false;       // ids[r] == ids[0] + r: O(1) id -> row
   // workspaces
   void* w[12] = {nullptr};
   size_t wcap[12] = {0};
@@ -139,6 +142,8 @@ static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* byt
   j->h_ids.assign(t->ids, t->ids + t->N);
   j->h_cell.assign(t->coarse_id, t->coarse_id + t->N);
   j->h_stats.assign(t->stats, t->stats + j->cells + 1);
+  j->h_mark.assign((size_t)t->N, 0);
+  j->ids_affine = t->N > 0 && (int64_t)t->ids[t->N - 1] - t->ids[0] == t->N - 1;   // strictly ascending => consecutive
   return 0;
 }
 
@@ -498,6 +503,16 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   if (n_targets > INT32_MAX) return join_fail(FREDDY_E_LIMIT, "too many targets");
   const int d = j->d, m = j->m, K = j->K, Kc = j->Kc, cells = j->cells;
   const int alpha_original = alpha;
+  // stage timers in the spirit of the reference's elog(INFO, "TRACK ...") lines (FREDDY_GPU_JOIN_TRACE=1)
+  const bool trace = getenv("FREDDY_GPU_JOIN_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto t_last = now();
+  auto track = [&](const char* what) {
+    if (!trace) return;
+    auto t = now();
+    fprintf(stderr, "TRACK %s %f\n", what, std::chrono::duration<double>(t - t_last).count());
+    t_last = t;
+  };
   if (pvf < 1) pvf = 1;                                                                       // :207-209
   bool double_codes = false;
   if (method != FREDDY_METHOD_EXACT) double_codes = ((int64_t)alpha * k > double_threshold);  // :262-266
@@ -518,23 +533,42 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
                r16((size_t)k * 4);
   if (lds > 160 * 1024) return join_fail(FREDDY_E_LIMIT, "LDS need of %zu bytes exceeds 160 KiB (m=%d K=%d k*pvf=%d)", lds, m, K, L);
 
-  // "fq.id IN (targets)": rows ascending, de-duplicated; bucketed by cell (ascending row inside)
-  std::vector<int32_t> trows;
-  trows.reserve((size_t)n_targets);
-  for (int64_t i = 0; i < n_targets; ++i) {
-    auto it = std::lower_bound(j->h_ids.begin(), j->h_ids.end(), target_ids[i]);
-    if (it != j->h_ids.end() && *it == target_ids[i]) trows.push_back((int32_t)(it - j->h_ids.begin()));
-  }
-  std::sort(trows.begin(), trows.end());
-  trows.erase(std::unique(trows.begin(), trows.end()), trows.end());
-  std::vector<int32_t> tcell_off(cells + 1, 0), trow_by_cell(trows.size());
-  for (int32_t r : trows) tcell_off[j->h_cell[r] + 1]++;
-  for (int c = 0; c < cells; ++c) tcell_off[c + 1] += tcell_off[c];
+  // "fq.id IN (targets)": rows ascending, de-duplicated; bucketed by cell (ascending row inside).
+  // Ids are looked up in parallel and marked in a per-index byte map; one ordered sweep over the
+  // marked range then yields the rows already sorted, a counting sort by cell buckets them.
+  std::vector<int32_t> tcell_off(cells + 1, 0), trow_by_cell;
   {
+    uint8_t* mark = j->h_mark.data();
+    const int64_t N = j->N;
+    std::atomic<int64_t> lo_row(N), hi_row(-1);
+    join_parallel_for((int)n_targets, [&](int lo, int hi, int) {
+      int64_t mn = N, mx = -1;
+      for (int i = lo; i < hi; ++i) {
+        int64_t r = -1;
+        if (j->ids_affine) {
+          const int64_t c = (int64_t)target_ids[i] - j->h_ids[0];
+          if (c >= 0 && c < N) r = c;
+        } else {
+          auto it = std::lower_bound(j->h_ids.begin(), j->h_ids.end(), target_ids[i]);
+          if (it != j->h_ids.end() && *it == target_ids[i]) r = it - j->h_ids.begin();
+        }
+        if (r >= 0) { mark[r] = 1; mn = std::min(mn, r); mx = std::max(mx, r); }
+      }
+      int64_t cur = lo_row.load();
+      while (mn < cur && !lo_row.compare_exchange_weak(cur, mn)) {}
+      cur = hi_row.load();
+      while (mx > cur && !hi_row.compare_exchange_weak(cur, mx)) {}
+    });
+    const int64_t r0 = lo_row.load(), r1 = hi_row.load();
+    for (int64_t r = r0; r <= r1; ++r) if (mark[r]) tcell_off[j->h_cell[r] + 1]++;
+    for (int c = 0; c < cells; ++c) tcell_off[c + 1] += tcell_off[c];
+    trow_by_cell.resize((size_t)tcell_off[cells]);
     std::vector<int32_t> cur(tcell_off.begin(), tcell_off.end() - 1);
-    for (int32_t r : trows) trow_by_cell[cur[j->h_cell[r]]++] = r;
+    for (int64_t r = r0; r <= r1; ++r)
+      if (mark[r]) { trow_by_cell[cur[j->h_cell[r]]++] = (int32_t)r; mark[r] = 0; }
   }
 
+  track("target_resolution_time");
   void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells, *d_oi, *d_od;
   if (join_buf(j, 0, sizeof(float) * (size_t)Q * d, &d_q) || join_buf(j, 1, sizeof(float) * (size_t)Q * 2 * Kc, &d_sub) ||
       join_buf(j, 2, sizeof(int32_t) * (size_t)(cells + 1), &d_tcell) ||
@@ -552,6 +586,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
   JOIN_HIP(hipStreamSynchronize(s));
 
+  track("sub_distance_time");
   // per-query sorted sides (they do not depend on alpha)
   std::vector<JoinSide> sides((size_t)Q * 2 * Kc);
   join_parallel_for(Q, [&](int lo, int hi, int) {
@@ -564,6 +599,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       }
   });
 
+  track("side_sort_time");
   std::vector<int32_t> active(Q), target_count(Q, 0);
   for (int i = 0; i < Q; ++i) active[i] = i;
   std::vector<std::vector<int32_t>> qcells(Q);
@@ -586,6 +622,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       }
     });
     const bool last = all_last.load() != 0;
+    track("determine_coarse_quantization_time");
     // targetCounts (:459) and the target-list skip rule (:553-557)
     scan.clear(); qoff.assign(1, 0); flat.clear();
     for (int x = 0; x < n_active; ++x) {
@@ -599,6 +636,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       qoff.push_back((int32_t)flat.size());
     }
     const int n_scan = (int)scan.size();
+    track("query_construction_time");
     if (n_scan > 0) {
       if (join_buf(j, 6, sizeof(int32_t) * std::max<size_t>(flat.size(), 1), &d_qcells)) return FREDDY_E_NOMEM;
       JOIN_HIP(hipMemcpyAsync(d_scan, scan.data(), sizeof(int32_t) * n_scan, hipMemcpyHostToDevice, s));
@@ -621,6 +659,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
         memcpy(out_dist + (size_t)scan[x] * k, h_od.data() + (size_t)x * k, sizeof(float) * k);
       }
     }
+    track("computation_time");
     if (!last) {                                                                            // :639-669
       std::vector<int32_t> next;
       for (int q : active) {

@@ -254,3 +254,22 @@ def test_ivfadc_randomised_small_indexes(gpu, oracle, fused, monkeypatch):
                 exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
                 util.assert_same_lists(gi, gd, exp, f"random trial={trial} K={K} C={C} N={N} Q={Q} k={k} W={W} rule={rule}")
         idx.close()
+
+
+def test_knn_join_non_contiguous_ids(gpu, oracle):
+    """Row ids with gaps (the O(1) id -> row shortcut for consecutive ids must not be taken)."""
+    N = 20000
+    t = dict(util.ivpq_tables(N=N))
+    t["ids"] = (t["ids"].astype(np.int64) * 3 + 7).astype(np.int32)
+    ot = oracle.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    idx = gpu.IVPQIndex(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    _, qs = util.queries_from_corpus(N, 50, seed=31)
+    rng = np.random.default_rng(9)
+    targets = t["ids"][rng.choice(N, 3000, replace=False)]
+    targets = np.concatenate([targets, targets[:20], np.array([8, 9, 5, 10**8], np.int32)])   # dups, gaps, unknown
+    for method in (0, 2):
+        gi, gd, git = idx.knn_join(qs, 5, targets, 10, 4, method)
+        exp, eit = oracle.ivpq_search_in(ot, qs, 5, targets, 10, 4, method)
+        assert git == eit
+        util.assert_same_lists(gi, gd, exp, f"non-contiguous ids method={method}")
+    idx.close()
