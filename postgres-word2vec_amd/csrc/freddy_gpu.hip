@@ -85,7 +85,6 @@ struct freddy_gpu_index {
   int64_t n_blocks = 0;
   int max_list_blocks = 0;
   int64_t bytes = 0;
-  int64_t last_scanned_rows = 0;
   int last_Q = 0;
   int n_cus = 256;
   // pinned tables
@@ -106,7 +105,7 @@ struct freddy_gpu_index {
   // workspaces
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_status, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -154,7 +153,7 @@ static void free_index(freddy_gpu_index* ix) {
                     &ix->w_item_query, &ix->w_rows, &ix->w_resid, &ix->w_lut, &ix->w_part,
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
-                    &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_status, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
+                    &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
                     &ix->w_surv, &ix->w_surv_cnt};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
@@ -478,7 +477,6 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                         int32_t* d_status, bool sync_rounds) {
   const int d = ix->d, C = ix->C, m = ix->m, K = ix->K;
   const int L = std::min(2 * k, 64 * 16);
-  (void)d;
   const int Cpad = ix->Cpad;
   const int used_words = (C + 31) / 32;
   const size_t lutN = (size_t)m * K;
