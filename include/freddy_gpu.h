@@ -128,6 +128,25 @@ int freddy_gpu_knn_join(freddy_gpu_index_t* ivpq, const float* queries, int32_t 
                         int32_t double_threshold, int32_t* out_ids, float* out_dist,
                         int32_t* iterations_out);
 
+/* ---- next row after the PQ / IVFADC / kNN-join path: exact brute-force kNN --------
+ * google_vecs_norm pinned as raw vectors.  Replaces the SQL of k_nearest_neighbour
+ * (freddy--0.0.1.sql:426-454) and knn_in_exact (:991-1084):
+ *   ORDER BY cosine_similarity_bytea(q, v.vector) DESC FETCH FIRST k ROWS ONLY
+ * with cosine_similarity_bytea = the binary32 chain "scalar += v1[i] * v2[i]"
+ * (core_functions.c:67-81), reproduced bit for bit.  Equal similarities are returned in
+ * ascending id (PostgreSQL leaves their order unspecified). */
+typedef struct freddy_vec_desc {
+  int32_t d;
+  int64_t N;
+  const int32_t* ids;     /* [N] strictly ascending */
+  const float* vectors;   /* [N][d] */
+} freddy_vec_desc;
+int freddy_gpu_pin_vectors(const freddy_vec_desc* desc, int device, freddy_gpu_index_t** out);
+/* subset_ids == NULL: all rows; else "id = ANY(subset_ids)" (duplicates / unknown ids ignored).
+ * out_ids/out_sim: [Q][k]; slots beyond the number of rows hold (-1, -inf). */
+int freddy_gpu_exact_search(freddy_gpu_index_t* vecs, const float* queries, int32_t Q, int32_t k,
+                            const int32_t* subset_ids, int64_t n_subset, int32_t* out_ids, float* out_sim);
+
 /* ---- device-resident variant used for throughput measurement ----------------------------
  * Same as freddy_gpu_ivfadc_search, but queries / outputs are DEVICE pointers on the
  * index's device and all work is enqueued on `hip_stream` (a hipStream_t; NULL = the

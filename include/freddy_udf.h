@@ -93,6 +93,15 @@ int ivpq_search_in(freddy_session_t* s, const float* queries, int32_t n_queries,
 int knn_join(freddy_session_t* s, const float* queries, int32_t n_queries, int32_t dim, const int32_t* query_ids,
              int32_t k, const int32_t* input_ids, int32_t n_ids, freddy_row3* out, int32_t* n_rows);
 
+/* Next row: the exact brute-force functions, by row id instead of word.
+ * k_nearest_neighbour(bytea, int)             freddy--0.0.1.sql:426-439
+ * knn_in_exact(bytea, int, integer[])         freddy--0.0.1.sql:1041-1054
+ * ORDER BY cosine_similarity_bytea(q, vector) DESC FETCH FIRST k ROWS ONLY over google_vecs_norm;
+ * row.distance carries the SIMILARITY; *n_rows <= k (fewer when fewer rows qualify). */
+int k_nearest_neighbour(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+int knn_in_exact(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
+                 freddy_row2* out, int32_t* n_rows);
+
 /* per-call row emit: snprintf("%d") / snprintf("%f") into 16-byte buffers   freddy.c:154-169,1001-1023 */
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]);
 void freddy_emit_row3(const freddy_row3* row, char values[3][16]);

@@ -813,3 +813,40 @@ int fo_ivpq_search_in(const fo_ivpq_table* t, const float* queries, int Q, int k
   free(luts); free(pv); free(fill); free(target_count); free(maxd);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * next row 8f-1: exact kNN
+ * cosine_similarity_bytea                                        core_functions.c:67-81
+ * ------------------------------------------------------------------------------------ */
+float fo_cosine_similarity_bytea(const float* v1, const float* v2, int n) {
+  float scalar = 0;
+  for (int i = 0; i < n; ++i) {
+    float p = v1[i] * v2[i];
+    scalar = scalar + p;
+  }
+  return scalar;
+}
+
+/* ORDER BY similarity DESC (ties: ascending id) FETCH FIRST k   freddy--0.0.1.sql:426-454,991-1084 */
+int fo_exact_knn(const float* vectors, const int32_t* ids, int64_t N, int d, const float* q, int k,
+                 const int32_t* input_ids, int n_ids, fo_entry* out) {
+  int64_t* rows = NULL;
+  int64_t n_rows = N;
+  if (input_ids) n_rows = rows_for_ids(ids, N, input_ids, n_ids, &rows);
+  int n_out = 0;
+  for (int64_t x = 0; x < n_rows; ++x) {
+    const int64_t r = rows ? rows[x] : x;
+    const float sim = fo_cosine_similarity_bytea(q, vectors + (size_t)r * d, d);
+    /* insertion into a descending list; rows arrive in ascending id, an equal similarity stays behind */
+    int slot = n_out;
+    while (slot > 0 && out[slot - 1].dist < sim) --slot;
+    if (slot >= k) continue;
+    const int last = (n_out < k) ? n_out : k - 1;
+    for (int j = last; j > slot; --j) out[j] = out[j - 1];
+    out[slot].id = ids[r];
+    out[slot].dist = sim;
+    if (n_out < k) ++n_out;
+  }
+  free(rows);
+  return n_out;
+}

@@ -162,6 +162,19 @@ int fo_ivpq_search_in(const fo_ivpq_table* t, const float* queries, int Q, int k
 void fo_postverify(const float* q, int d, int k, int n_cand, const int32_t* cand_ids,
                    const float* const* cand_vecs, float sentinel, fo_entry* tk);
 
+/* ---- next row: exact brute-force kNN ------------------------------------------
+ * cosine_similarity_bytea                 core_functions.c:67-81
+ * float scalar = 0; scalar += v1[i] * v2[i]  (binary32 mul, then binary32 add, i ascending) */
+float fo_cosine_similarity_bytea(const float* v1, const float* v2, int n);
+
+/* k_nearest_neighbour / knn_in_exact      freddy--0.0.1.sql:426-454, 991-1084
+ * "ORDER BY cosine_similarity_bytea(q, v.vector) DESC FETCH FIRST k ROWS ONLY" over all rows
+ * (input_ids == NULL) or "WHERE v.id = ANY(input_ids)".  PostgreSQL leaves the order of equal
+ * similarities unspecified; pinned here to ascending id.  ids ascending; out[i].dist holds
+ * the SIMILARITY.  Returns the number of rows produced (<= k). */
+int fo_exact_knn(const float* vectors, const int32_t* ids, int64_t N, int d, const float* q, int k,
+                 const int32_t* input_ids, int n_ids, fo_entry* out);
+
 /* SRF emit text round trip               freddy.c:164 ("%f" into a 16-byte buffer) */
 float fo_emit_roundtrip(float dist);
 

@@ -54,7 +54,7 @@ def _i16(a):
 
 
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p)
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
 class Oracle:
@@ -80,6 +80,10 @@ class Oracle:
         L.fo_ivpq_search_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                         C.c_void_p, C.c_void_p]
+        L.fo_cosine_similarity_bytea.restype = C.c_float
+        L.fo_cosine_similarity_bytea.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.fo_exact_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                   C.c_void_p]
         L.fo_multi_index_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.c_void_p, C.c_void_p]
 
@@ -123,6 +127,19 @@ class Oracle:
         for dd, ii in zip(np.asarray(dists, np.float32), np.asarray(ids, np.int32)):
             self.lib.fo_offer(_p(tk), k, _p(maxd), C.c_float(float(dd)), int(ii))
         return tk
+
+    def cosine_similarity_bytea(self, a, b):
+        a, b = _f32(a), _f32(b)
+        return np.float32(self.lib.fo_cosine_similarity_bytea(_p(a), _p(b), a.size))
+
+    def exact_knn(self, vectors, ids, q, k, input_ids=None):
+        """(entries[:n]) with .dist = similarity, ORDER BY similarity DESC, id ASC."""
+        v, ids, q = _f32(vectors), _i32(ids), _f32(q)
+        out = np.empty(k, ENTRY)
+        sub = None if input_ids is None else _i32(input_ids)
+        n = self.lib.fo_exact_knn(_p(v), _p(ids), ids.size, v.shape[1], _p(q), k, _p(sub),
+                                  0 if sub is None else sub.size, _p(out))
+        return out[:n]
 
     def confidence_hyp(self, expect, size, p, stat_size):
         return np.float32(self.lib.fo_confidence_hyp(int(expect), int(size), C.c_float(float(p)), int(stat_size)))

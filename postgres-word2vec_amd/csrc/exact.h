@@ -1,0 +1,165 @@
+// exact.h -- exact brute-force kNN (the first "next row" after the PQ / IVFADC
+// / kNN-join path): ORDER BY cosine_similarity_bytea(q, v) DESC FETCH FIRST k over all rows
+// (k_nearest_neighbour, freddy--0.0.1.sql:426-454) or over "id = ANY(input_set)" (knn_in_exact,
+// :991-1084).
+//
+// cosine_similarity_bytea (core_functions.c:67-81) is "scalar += v1[i] * v2[i]" in binary32 with
+// PGXS default flags: a separately rounded multiply and add per dimension, i ascending.  The
+// kernel keeps exactly that chain (v_pk_mul_f32 + v_pk_add_f32 over query pairs, each half an
+// IEEE op), so similarities are bit-identical to the reference arithmetic.  (An fp32 MFMA would
+// be ~5x faster but is an fma chain -- one rounding per term -- and would only match to ~1e-6;
+// left as the documented alternative.)
+//
+// Layout: vectors are pinned in 64-row blocks xb[block][dim][64] so that lane <-> row reads are
+// coalesced; the QT queries of a workgroup sit in LDS as [dim][QT] (broadcast ds_read_b128).
+// Ordering: key = (~ordered(sim) << 32) | row, smallest key first = largest similarity first,
+// equal similarities by ascending row (= ascending id).  PostgreSQL leaves that tie order
+// unspecified; this is the pinned choice (oracle: fo_exact_knn).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "wave_topk.h"
+
+namespace freddy {
+
+static constexpr int EX_WG = 256;
+static constexpr int EX_WAVES = EX_WG / 64;
+static constexpr int EX_QT = 8;       // queries per workgroup
+
+__device__ __forceinline__ u64 sim_key(float sim, uint32_t row) {
+  const uint32_t b = __float_as_uint(sim);
+  const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // ascending with the float
+  return ((u64)(~ord) << 32) | (u64)row;                              // descending similarity
+}
+__device__ __forceinline__ float key_sim(u64 key) {
+  const uint32_t ord = ~(uint32_t)(key >> 32);
+  return __uint_as_float((ord & 0x80000000u) ? (ord ^ 0x80000000u) : ~ord);
+}
+
+// rows [N][d] -> xb[block][d][64] (zero padded); pos_out[i] = source row or -1
+__global__ __launch_bounds__(256) void block_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ rows,
+                                                        int64_t n_rows, float* __restrict__ xb, int32_t* __restrict__ pos_out,
+                                                        int d) {
+  const int64_t i = (int64_t)blockIdx.x * 64 + (threadIdx.x & 63);   // output row
+  const int part = threadIdx.x >> 6;                                   // 4 dimension slices
+  const int64_t r = (i < n_rows) ? (rows ? rows[i] : i) : -1;
+  if (part == 0 && pos_out) pos_out[i] = (int32_t)r;
+  for (int dim = part; dim < d; dim += 4)
+    xb[((int64_t)blockIdx.x * d + dim) * 64 + (threadIdx.x & 63)] = (r >= 0) ? src[r * d + dim] : 0.0f;
+}
+
+struct ExactArgs {
+  const float* xb;          // [blocks][d][64]
+  const int32_t* pos;       // [blocks*64] row of each slot (-1 padding) or NULL: slot index, valid below n_rows
+  const float* queries;     // [Q][d]
+  u64* part;                // [Q][nchunk][EX_WAVES][L]
+  int64_t n_rows;
+  int n_blocks, chunk_blocks, nchunk, Q, d, L;
+};
+
+template <int V>
+__global__ __launch_bounds__(EX_WG) void exact_scan_kernel(ExactArgs a) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int QT = EX_QT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* qs = reinterpret_cast<float*>(smem);                                              // [d][QT]
+  u64* stage = reinterpret_cast<u64*>(smem + (((size_t)a.d * QT * 4 + 15) & ~(size_t)15)); // [waves][QT][64]
+  const int chunk = blockIdx.x, q0 = blockIdx.y * QT;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int d = a.d;
+  for (int i = threadIdx.x; i < d * QT; i += EX_WG) {
+    const int t = i / d, dim = i - t * d;
+    const int q = (q0 + t < a.Q) ? (q0 + t) : (a.Q - 1);
+    qs[dim * QT + t] = a.queries[(size_t)q * d + dim];
+  }
+  __syncthreads();
+  WaveSelect<V> sel[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) sel[t].init(stage + ((size_t)wave * QT + t) * 64, KEY_INF, a.L);
+
+  const int b0 = chunk * a.chunk_blocks;
+  const int b1 = (b0 + a.chunk_blocks < a.n_blocks) ? b0 + a.chunk_blocks : a.n_blocks;
+  for (int b = b0 + wave; b < b1; b += EX_WAVES) {
+    const float* xrow = a.xb + (size_t)b * d * 64 + lane;
+    v2f acc[QT / 2];
+#pragma unroll
+    for (int t = 0; t < QT / 2; ++t) acc[t] = v2f{0.0f, 0.0f};
+    constexpr int DB = 8;   // row values fetched DB dimensions ahead
+    float xn[DB];
+#pragma unroll
+    for (int u = 0; u < DB; ++u) xn[u] = (u < d) ? xrow[(size_t)u * 64] : 0.0f;
+    for (int i0 = 0; i0 < d; i0 += DB) {
+      float xc[DB];
+#pragma unroll
+      for (int u = 0; u < DB; ++u) xc[u] = xn[u];
+#pragma unroll
+      for (int u = 0; u < DB; ++u) xn[u] = (i0 + DB + u < d) ? xrow[(size_t)(i0 + DB + u) * 64] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < DB; ++u) {
+        const int i = i0 + u;
+        if (i < d) {
+          const float4* qrow = reinterpret_cast<const float4*>(qs + i * QT);
+          const v2f x2 = {xc[u], xc[u]};
+#pragma unroll
+          for (int t4 = 0; t4 < QT / 4; ++t4) {
+            const float4 qv = qrow[t4];
+            const v2f qa = {qv.x, qv.y}, qb = {qv.z, qv.w};
+            const v2f pa = qa * x2, pb = qb * x2;          // core_functions.c:77: v1[i] * v2[i]
+            acc[t4 * 2 + 0] = acc[t4 * 2 + 0] + pa;        //                     scalar += ...
+            acc[t4 * 2 + 1] = acc[t4 * 2 + 1] + pb;
+          }
+        }
+      }
+    }
+    const int64_t slot = (int64_t)b * 64 + lane;
+    const int32_t row = a.pos ? a.pos[slot] : (slot < a.n_rows ? (int32_t)slot : -1);
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      const float sim = (t & 1) ? acc[t >> 1].y : acc[t >> 1].x;
+      sel[t].push(sim_key(sim, (uint32_t)row), row >= 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    sel[t].finish();
+    if (q0 + t < a.Q) {
+      u64* out = a.part + (((size_t)(q0 + t) * a.nchunk + chunk) * EX_WAVES + wave) * a.L;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int r = v * 64 + lane;
+        if (r < a.L) out[r] = sel[t].acc[v];
+      }
+    }
+  }
+}
+
+// one wave per query: k best keys of its partial lists, in order -> (id, similarity)
+template <int V>
+__global__ __launch_bounds__(64) void exact_merge_kernel(const u64* __restrict__ part, int parts_per_query, int L, int k,
+                                                        const int32_t* __restrict__ ids, int32_t* __restrict__ out_ids,
+                                                        float* __restrict__ out_sim) {
+  __shared__ u64 stage[64];
+  const int q = blockIdx.x, lane = threadIdx.x;
+  WaveSelect<V> sel;
+  sel.init(stage, KEY_INF, L);
+  const u64* src = part + (size_t)q * parts_per_query * L;
+  const int total = parts_per_query * L;
+  for (int base = 0; base < total; base += 64) {
+    const bool valid = base + lane < total;
+    const u64 key = valid ? src[base + lane] : KEY_INF;
+    sel.push(key, valid && key != KEY_INF);
+  }
+  sel.finish();
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int r = v * 64 + lane;
+    if (r < k) {
+      const u64 key = sel.acc[v];
+      out_ids[(size_t)q * k + r] = (key == KEY_INF) ? -1 : ids[key_pos(key)];
+      out_sim[(size_t)q * k + r] = (key == KEY_INF) ? -__builtin_huge_valf() : key_sim(key);
+    }
+  }
+}
+
+}  // namespace freddy

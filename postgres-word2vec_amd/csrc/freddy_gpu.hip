@@ -21,6 +21,7 @@
 
 #include "kernels.h"
 #include "fused.h"
+#include "exact.h"
 #include "join.h"
 
 using namespace freddy;
@@ -51,7 +52,7 @@ extern "C" const char* freddy_gpu_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------
 // index object
 // ---------------------------------------------------------------------------------------
-enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3 };
+enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3, KIND_VEC = 4 };
 
 struct DevBuf {
   void* p = nullptr;
@@ -100,6 +101,8 @@ struct freddy_gpu_index {
   int32_t* ids = nullptr;       // PQ: [N] position -> id
   std::vector<int32_t> h_ids;   // PQ: ascending ids for "id IN (...)" resolution
   std::vector<int32_t> h_list_off;
+  // raw vectors (exact kNN): 64-row blocks [block][d][64]
+  float* xb = nullptr;
   // ivpq extras
   JoinIndex join;
   // workspaces
@@ -146,7 +149,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -845,5 +848,128 @@ extern "C" int freddy_gpu_knn_join(freddy_gpu_index_t* ix, const float* queries,
   int rc = join_run(&ix->join, ix->stream, queries, Q, k, target_ids, n_targets, alpha, pvf, method,
                     use_target_lists, confidence, double_threshold, out_ids, out_dist, iterations_out);
   if (rc) return fail(rc, "%s", join_error());
+  return FREDDY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// exact brute-force kNN
+// ---------------------------------------------------------------------------------------
+extern "C" int freddy_gpu_pin_vectors(const freddy_vec_desc* t, int device, freddy_gpu_index_t** out) {
+  if (!t || !out || t->d <= 0 || t->N < 0 || (t->N && (!t->ids || !t->vectors))) return fail(FREDDY_E_ARG, "bad argument");
+  if (t->N > (int64_t)INT32_MAX - 64) return fail(FREDDY_E_LIMIT, "N too large for 32-bit row positions");
+  for (int64_t r = 1; r < t->N; ++r)
+    if (t->ids[r] <= t->ids[r - 1]) return fail(FREDDY_E_ARG, "ids must be strictly ascending (row %lld)", (long long)r);
+  freddy_gpu_index* ix = new freddy_gpu_index();
+  ix->kind = KIND_VEC;
+  ix->d = t->d; ix->N = t->N;
+  int rc = open_device(ix, device);
+  if (!rc) {
+    ix->n_blocks = (t->N + 63) / 64;
+    const size_t xb_bytes = sizeof(float) * (size_t)std::max<int64_t>(ix->n_blocks, 1) * t->d * 64;
+    if (hipMalloc((void**)&ix->xb, xb_bytes) != hipSuccess) rc = fail(FREDDY_E_NOMEM, "device allocation of %zu bytes failed", xb_bytes);
+    else ix->bytes += (int64_t)xb_bytes;
+    if (!rc && upload(&ix->ids, t->ids, (size_t)t->N, &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    // row-major rows go up in slices and are re-blocked on the device
+    const int64_t slice = 1 << 16;
+    DevBuf tmp;
+    for (int64_t r0 = 0; !rc && r0 < t->N; r0 += slice) {
+      const int64_t n = std::min(slice, t->N - r0);
+      if (tmp.ensure(sizeof(float) * (size_t)n * t->d)) { rc = fail(FREDDY_E_NOMEM, "device allocation failed"); break; }
+      if (hipMemcpy(tmp.p, t->vectors + (size_t)r0 * t->d, sizeof(float) * (size_t)n * t->d, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(FREDDY_E_HIP, "hipMemcpy failed"); break;
+      }
+      hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ix->stream, tmp.as<float>(), nullptr, n,
+                         ix->xb + (size_t)(r0 / 64) * t->d * 64, nullptr, t->d);
+      if (hipStreamSynchronize(ix->stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "re-blocking kernel failed"); break; }
+    }
+    tmp.release();
+  }
+  if (!rc) {
+    ix->h_ids.assign(t->ids, t->ids + t->N);
+    // the source rows are only needed again for "id = ANY(...)" subsets: keep them row-major too
+    if (t->N && upload(&ix->coarse, t->vectors, (size_t)t->N * t->d, &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+  }
+  if (rc) { free_index(ix); return rc; }
+  *out = ix;
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k,
+                                       const int32_t* subset_ids, int64_t n_subset, int32_t* out_ids, float* out_sim) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  if (ix->kind != KIND_VEC) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  if (Q < 0 || k <= 0 || n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FREDDY_E_ARG, "bad sizes");
+  if (Q > 0 && (!queries || !out_ids || !out_sim)) return fail(FREDDY_E_ARG, "NULL buffer");
+  if (k > 1024) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 1024", k);
+  if (Q == 0) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = ix->stream;
+  const int d = ix->d, L = k, V = pick_V(L);
+  const float* xb = ix->xb;
+  const int32_t* pos = nullptr;
+  int64_t n_rows = ix->N, n_blocks = ix->n_blocks;
+  if (subset_ids) {
+    std::vector<int32_t> rows;
+    rows.reserve((size_t)n_subset);
+    for (int64_t i = 0; i < n_subset; ++i) {
+      auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), subset_ids[i]);
+      if (it != ix->h_ids.end() && *it == subset_ids[i]) rows.push_back((int32_t)(it - ix->h_ids.begin()));
+    }
+    std::sort(rows.begin(), rows.end());
+    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+    n_rows = (int64_t)rows.size();
+    n_blocks = (n_rows + 63) / 64;
+    if (ix->w_sub_rows.ensure(sizeof(int32_t) * std::max<size_t>(rows.size(), 1)) ||
+        ix->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(n_blocks, 1) * 64) ||
+        ix->w_resid.ensure(sizeof(float) * (size_t)std::max<int64_t>(n_blocks, 1) * d * 64))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    if (n_rows) {
+      HIP_TRY(hipMemcpyAsync(ix->w_sub_rows.p, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, ix->coarse, ix->w_sub_rows.as<int32_t>(), n_rows,
+                         ix->w_resid.as<float>(), ix->w_sub_pos.as<int32_t>(), d);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(s));   // `rows` is a host temporary
+    }
+    xb = ix->w_resid.as<float>();
+    pos = ix->w_sub_pos.as<int32_t>();
+  }
+  int chunk_blocks = 8;   // 512 rows per workgroup-chunk; longer chunks once the grid is large enough
+  const int qgroups = (Q + EX_QT - 1) / EX_QT;
+  while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)qgroups > 8192 && chunk_blocks < 1024) chunk_blocks *= 2;
+  const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
+  if (ix->w_q.ensure(sizeof(float) * (size_t)Q * d) || ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ix->w_out_dist.ensure(sizeof(float) * (size_t)Q * k) ||
+      ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * EX_WAVES * L))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
+  ExactArgs ea;
+  ea.xb = xb; ea.pos = pos; ea.queries = ix->w_q.as<float>(); ea.part = ix->w_part.as<u64>();
+  ea.n_rows = n_rows; ea.n_blocks = (int)n_blocks; ea.chunk_blocks = chunk_blocks; ea.nchunk = nchunk; ea.Q = Q; ea.d = d; ea.L = L;
+  const size_t lds = (((size_t)d * EX_QT * 4 + 15) & ~(size_t)15) + (size_t)EX_WAVES * EX_QT * 64 * sizeof(u64);
+  dim3 grid((unsigned)nchunk, (unsigned)qgroups);
+  timed_launch(ix, s, "exact_scan", [&] {
+    switch (V) {
+      case 1: hipLaunchKernelGGL((exact_scan_kernel<1>), grid, dim3(EX_WG), lds, s, ea); break;
+      case 2: hipLaunchKernelGGL((exact_scan_kernel<2>), grid, dim3(EX_WG), lds, s, ea); break;
+      case 4: hipLaunchKernelGGL((exact_scan_kernel<4>), grid, dim3(EX_WG), lds, s, ea); break;
+      case 8: hipLaunchKernelGGL((exact_scan_kernel<8>), grid, dim3(EX_WG), lds, s, ea); break;
+      default: hipLaunchKernelGGL((exact_scan_kernel<16>), grid, dim3(EX_WG), lds, s, ea); break;
+    }
+  });
+  HIP_TRY(hipGetLastError());
+  const int ppq = nchunk * EX_WAVES;
+  timed_launch(ix, s, "exact_merge", [&] {
+    switch (V) {
+      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+    }
+  });
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_sim, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return FREDDY_OK;
 }

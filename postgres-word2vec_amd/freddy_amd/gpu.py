@@ -21,7 +21,7 @@ EXPORTS = [
     "freddy_gpu_pq_search", "freddy_gpu_ivfadc_search", "freddy_gpu_knn_join",
     "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
-    "freddy_gpu_last_scanned_rows",
+    "freddy_gpu_last_scanned_rows", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search",
 ]
 
 
@@ -38,6 +38,10 @@ class IVFDesc(C.Structure):
     _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("C", C.c_int32),
                 ("N", C.c_int64), ("coarse", C.c_void_p), ("codebook", C.c_void_p),
                 ("list_off", C.c_void_p), ("ids", C.c_void_p), ("codes", C.c_void_p)]
+
+
+class VecDesc(C.Structure):
+    _fields_ = [("d", C.c_int32), ("N", C.c_int64), ("ids", C.c_void_p), ("vectors", C.c_void_p)]
 
 
 class IVPQDesc(C.Structure):
@@ -78,6 +82,9 @@ def load():
     lib.freddy_gpu_pin_ivf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivpq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_unpin.argtypes = [C.c_void_p]
+    lib.freddy_gpu_pin_vectors.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.freddy_gpu_exact_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
+                                            C.c_void_p, C.c_void_p]
     lib.freddy_gpu_pq_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                          C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.freddy_gpu_ivfadc_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
@@ -181,6 +188,29 @@ class PQIndex(_Index):
         _check(self.lib.freddy_gpu_pq_search_dev(self.h, C.c_void_p(d_queries_ptr), Q, k, C.c_float(sentinel),
                                                  C.c_void_p(d_out_ids_ptr), C.c_void_p(d_out_dist_ptr),
                                                  C.c_void_p(stream or 0)))
+
+
+class VectorIndex(_Index):
+    """google_vecs_norm pinned as raw vectors: exact brute-force kNN."""
+    kind = "vec"
+
+    def __init__(self, ids, vectors, device=0):
+        super().__init__()
+        ids, v = _i32(ids), _f32(vectors)
+        self.d, self.N = v.shape[1], ids.size
+        desc = VecDesc(self.d, ids.size, _p(ids), _p(v))
+        _check(self.lib.freddy_gpu_pin_vectors(C.byref(desc), device, C.byref(self.h)))
+
+    def search(self, queries, k, subset_ids=None):
+        """(ids[Q,k], similarity[Q,k]) ORDER BY cosine_similarity_bytea DESC, id ASC."""
+        qs = _f32(queries).reshape(-1, self.d)
+        Q = qs.shape[0]
+        out_i = np.empty((Q, k), np.int32)
+        out_s = np.empty((Q, k), np.float32)
+        sub = None if subset_ids is None else _i32(subset_ids)
+        _check(self.lib.freddy_gpu_exact_search(self.h, _p(qs), Q, k, _p(sub), 0 if sub is None else sub.size,
+                                                _p(out_i), _p(out_s)))
+        return out_i, out_s
 
 
 class IVFIndex(_Index):

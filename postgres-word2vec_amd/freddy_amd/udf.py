@@ -150,6 +150,22 @@ class Session:
         self._check(self.lib.pq_search_in(self.h, _p(q), q.size, k, _p(ids), ids.size, _p(out), C.byref(n)))
         return out[:n.value]
 
+    def k_nearest_neighbour(self, query, k):
+        """freddy--0.0.1.sql:426-439, rows carry (id, similarity)."""
+        q = _f32(query)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(self.lib.k_nearest_neighbour(self.h, _p(q), q.size, k, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def knn_in_exact(self, query, k, input_ids):
+        """freddy--0.0.1.sql:1041-1054, rows carry (id, similarity)."""
+        q, ids = _f32(query), _i32(input_ids)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(self.lib.knn_in_exact(self.h, _p(q), q.size, k, _p(ids), ids.size, _p(out), C.byref(n)))
+        return out[:n.value]
+
     def pq_search_in_batch(self, queries, query_ids, k, input_ids, use_targetlist=True):
         qs, qid, ids = _f32(queries), _i32(query_ids), _i32(input_ids)
         out = np.empty(max(qs.shape[0], 1) * k, ROW3)

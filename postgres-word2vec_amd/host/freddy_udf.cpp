@@ -73,6 +73,7 @@ struct freddy_session {
   freddy_gpu_index_t* pq = nullptr;
   freddy_gpu_index_t* ivf = nullptr;
   freddy_gpu_index_t* ivpq = nullptr;
+  freddy_gpu_index_t* vecs = nullptr;  // google_vecs_norm pinned for the exact kNN functions (lazily)
   int pq_d = 0, ivf_d = 0, ivpq_d = 0;
 };
 
@@ -93,6 +94,7 @@ int freddy_session_close(freddy_session_t* s) {
   if (s->pq) freddy_gpu_unpin(s->pq);
   if (s->ivf) freddy_gpu_unpin(s->ivf);
   if (s->ivpq) freddy_gpu_unpin(s->ivpq);
+  if (s->vecs) freddy_gpu_unpin(s->vecs);
   delete s;
   return 0;
 }
@@ -107,6 +109,7 @@ int freddy_load_vecs_norm(freddy_session_t* s, const int32_t* ids, const float* 
     s->norm_ids[i] = ids[ord[i]];
     memcpy(&s->norm_vecs[(size_t)i * d], vectors + (size_t)ord[i] * d, sizeof(float) * d);
   }
+  if (s->vecs) { freddy_gpu_unpin(s->vecs); s->vecs = nullptr; }
   return 0;
 }
 
@@ -347,6 +350,36 @@ int knn_join(freddy_session_t* s, const float* queries, int32_t n_queries, int32
   if (!s) return fail(-1, "NULL session");
   return ivpq_search_in(s, queries, n_queries, dim, query_ids, n_queries, k, input_ids, n_ids, s->alpha, s->pvf,
                         s->method_flag, s->use_targetlist, s->confidence, s->long_codes_threshold, out, n_rows);
+}
+
+// ---- exact brute force -------------------------------------------------------------
+static int exact_common(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids,
+                        int32_t n_ids, bool subset, freddy_row2* out, int32_t* n_rows) {
+  if (!s || s->norm_ids.empty()) return fail(-1, "google_vecs_norm is not loaded");
+  if (dim != s->d) return fail(-1, "query has %d dimensions, table has %d", dim, s->d);
+  if (k <= 0 || !query || !out || n_ids < 0) return fail(-1, "bad argument");
+  if (!s->vecs) {
+    freddy_vec_desc desc = {s->d, (int64_t)s->norm_ids.size(), s->norm_ids.data(), s->norm_vecs.data()};
+    if (int rc = freddy_gpu_pin_vectors(&desc, s->device, &s->vecs)) return gpu_fail(rc);
+  }
+  std::vector<int32_t> ids((size_t)k); std::vector<float> sim((size_t)k);
+  const int32_t none = -1;
+  const int32_t* sub = subset ? (n_ids ? input_ids : &none) : nullptr;
+  if (int rc = freddy_gpu_exact_search(s->vecs, query, 1, k, sub, subset ? (n_ids ? n_ids : 1) : 0, ids.data(), sim.data()))
+    return gpu_fail(rc);
+  int n = 0;   // FETCH FIRST k ROWS ONLY returns fewer rows when fewer exist
+  while (n < k && ids[n] >= 0) { out[n].id = ids[n]; out[n].distance = sim[n]; ++n; }
+  if (n_rows) *n_rows = n;
+  return 0;
+}
+
+int k_nearest_neighbour(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  return exact_common(s, query, dim, k, nullptr, 0, false, out, n_rows);
+}
+
+int knn_in_exact(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
+                 freddy_row2* out, int32_t* n_rows) {
+  return exact_common(s, query, dim, k, input_ids, n_ids, true, out, n_rows);
 }
 
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]) {

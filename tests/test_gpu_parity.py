@@ -273,3 +273,33 @@ def test_knn_join_non_contiguous_ids(gpu, oracle):
         assert git == eit
         util.assert_same_lists(gi, gd, exp, f"non-contiguous ids method={method}")
     idx.close()
+
+
+def test_exact_knn_matches_oracle(gpu, oracle):
+    """SURVEY 8f-1 (next row): k_nearest_neighbour / knn_in_exact.  The similarity is the same
+    order-fixed binary32 chain as cosine_similarity_bytea, so ids, ranks and similarities are
+    bit-exact (ties by ascending id)."""
+    N = 20000
+    x = util.corpus(N).numpy()
+    ids = (np.arange(N) * 2 + 3).astype(np.int32)
+    idx = gpu.VectorIndex(ids, x)
+    qs = x[::997][:16].copy()
+    qs[3] = -qs[3]                       # negative similarities
+    for k in (1, 5, 64, 200):
+        gi, gs = idx.search(qs, k)
+        for qi, q in enumerate(qs):
+            exp = oracle.exact_knn(x, ids, q, k)
+            assert gi[qi].tolist() == exp["id"].tolist(), (k, qi)
+            assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32)), (k, qi)
+    rng = np.random.default_rng(2)
+    sub = np.concatenate([ids[rng.choice(N, 700, replace=False)], np.array([4, 10**8], np.int32)])
+    gi, gs = idx.search(qs, 10, subset_ids=sub)
+    for qi, q in enumerate(qs):
+        exp = oracle.exact_knn(x, ids, q, 10, sub)
+        assert gi[qi].tolist() == exp["id"].tolist()
+        assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32))
+    gi, gs = idx.search(qs[:2], 8, subset_ids=ids[:3])          # fewer rows than k
+    assert (gi[:, 3:] == -1).all() and np.isneginf(gs[:, 3:]).all()
+    exp = oracle.exact_knn(x, ids, qs[0], 8, ids[:3])
+    assert gi[0, :3].tolist() == exp["id"].tolist()
+    idx.close()

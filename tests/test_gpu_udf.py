@@ -99,3 +99,21 @@ def test_ivpq_search_in_and_knn_join(db, oracle, method):
     from freddy_amd import udf
     with pytest.raises(udf.FreddyError, match="Unknown computation method"):
         s.ivpq_search_in(qs, qids, 5, targets, 10, 4, 7, True, 0.8, 10000000)
+
+
+def test_k_nearest_neighbour_and_knn_in_exact(db, oracle):
+    """Next row 8f-1: `SELECT * FROM k_nearest_neighbour(vec, k)` / `knn_in_exact(vec, k, '{..}'::int[])`
+    (freddy--0.0.1.sql:426-439, 1041-1054), keyed by row id."""
+    s, t = db
+    ids_all = np.arange(1, N + 1, dtype=np.int32)
+    q = t["x"][777]
+    rows = s.k_nearest_neighbour(q, 7)
+    exp = oracle.exact_knn(t["x"], ids_all, q, 7)
+    same(rows, exp)
+    assert rows["id"][0] == 778
+    sub = [5, 17, 17, 900, 19999, 20001, -4]
+    rows = s.knn_in_exact(q, 10, sub)
+    exp = oracle.exact_knn(t["x"], ids_all, q, 10, sub)
+    assert len(rows) == 4                                   # FETCH FIRST returns only existing rows
+    same(rows, exp)
+    assert len(s.knn_in_exact(q, 3, [])) == 0

@@ -398,3 +398,32 @@ def test_emit_text_roundtrip(oracle):
     assert oracle.emit_roundtrip(0.1234567) == f32(0.123457)
     assert oracle.emit_roundtrip(100.0) == f32(100.0)
     assert oracle.emit_roundtrip(1e-8) == f32(0.0)
+
+
+def test_exact_knn_oracle(oracle):
+    """cosine_similarity_bytea (core_functions.c:67-81) and ORDER BY ... DESC FETCH FIRST k."""
+    x = util.corpus(3000).numpy()
+    ids = np.arange(1, 3001, dtype=np.int32)
+    q = x[10]
+    sims = np.empty(3000, f32)
+    for r in range(3000):
+        acc = f32(0)
+        for a_, b_ in zip(q, x[r]):
+            acc = f32(acc + f32(a_ * b_))
+        sims[r] = acc
+        if r < 50:
+            assert oracle.cosine_similarity_bytea(q, x[r]).view(np.uint32) == acc.view(np.uint32)
+    for k in (1, 5, 64):
+        order = np.lexsort((ids, -sims.astype(np.float64)))[:k]
+        got = oracle.exact_knn(x, ids, q, k)
+        assert got["id"].tolist() == ids[order].tolist()
+        assert np.array_equal(got["dist"].view(np.uint32), sims[order].view(np.uint32))
+    sub = np.array([5, 11, 12, 9000, 11, -3], np.int32)
+    got = oracle.exact_knn(x, ids, q, 5, sub)
+    assert got["id"].tolist() == [11, 12, 5] or set(got["id"].tolist()) == {11, 12, 5}
+    assert len(got) == 3
+    # duplicated rows tie exactly: ascending id decides
+    x2 = np.concatenate([x[:20], x[5:6], x[5:6]])
+    ids2 = np.arange(1, 23, dtype=np.int32)
+    got = oracle.exact_knn(x2, ids2, x[5], 3)
+    assert got["id"].tolist() == [6, 21, 22]
