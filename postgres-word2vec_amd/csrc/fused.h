@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "wave_topk.h"
 
 namespace freddy {
@@ -212,14 +214,13 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   __syncthreads();
 
   typedef float v2f __attribute__((ext_vector_type(2)));
-  float acc[G][RMAX];
+  v2f acc[G / 2][RMAX];   // ADC sums: acc[h][r] = items (2h, 2h+1) of this lane's row r
   uint32_t cw[RMAX];
   v2f cb[S];   // .x: code tid, .y: code tid + T  (packed so the two chains run as v_pk_* ops)
 #pragma unroll
-  for (int g = 0; g < G; ++g)
+  for (int h = 0; h < G / 2; ++h)
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) acc[g][r] = 0.0f;
-
+    for (int r = 0; r < RMAX; ++r) acc[h][r] = v2f{0.0f, 0.0f};
   // rows past the end of the chunk re-read its last block (always in bounds); masked at the end
   auto row_block = [&](int r) {
     const int b = r * NW + wave;
@@ -315,24 +316,40 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
       if (FULLK || tid + T < K) *reinterpret_cast<v2f*>(dst + slab_at(tid + T, g)) = v2f{s0.y, s1.y};
     }
   };
-  auto gather = [&](int p, const float* cur) {
+  // gather slab(p): lane <-> row.  NQ = number of 4-item chunks in use (workgroup-uniform, chosen
+  // once per entry): inside one instantiation there is no branch, so the 2*NQ ds_read_b128 of two
+  // rows are in flight together and the adds of one row pair overlap the reads of the next.  (With
+  // a per-chunk `if` every read sat in its own basic block behind an lgkmcnt(0).)
+  auto gather_n = [&](auto nq_tag, int p, const float* cur) {
+    constexpr int NQ = decltype(nq_tag)::value;
     const int sh = (p & 1) * 16;
 #pragma unroll
-    for (int r = 0; r < RMAX; ++r) {
-      const int code = (int)((cw[r] >> sh) & 0xffffu);
-      const int sw = (code >> 1) & 3;
-      const float* row = cur + code * G;
+    for (int r0 = 0; r0 < RMAX; r0 += 2) {
+      float4 v[2][NQ];
 #pragma unroll
-      for (int q = 0; q < G / 4; ++q) {
-        if (q * 4 < cnt) {   // workgroup-uniform; a row's 4 items of chunk q in ONE 16-byte LDS read
-          const float4 v = *reinterpret_cast<const float4*>(row + ((q ^ sw) << 2));
-          acc[q * 4 + 0][r] = acc[q * 4 + 0][r] + v.x;
-          acc[q * 4 + 1][r] = acc[q * 4 + 1][r] + v.y;
-          acc[q * 4 + 2][r] = acc[q * 4 + 2][r] + v.z;
-          acc[q * 4 + 3][r] = acc[q * 4 + 3][r] + v.w;
-        }
+      for (int rr = 0; rr < 2; ++rr) {
+        const int code = (int)((cw[r0 + rr] >> sh) & 0xffffu);
+        const int sw = (code >> 1) & 3;
+        const float* row = cur + code * G;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) v[rr][q] = *reinterpret_cast<const float4*>(row + ((q ^ sw) << 2));
       }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          acc[q * 2 + 0][r0 + rr] = acc[q * 2 + 0][r0 + rr] + v2f{v[rr][q].x, v[rr][q].y};
+          acc[q * 2 + 1][r0 + rr] = acc[q * 2 + 1][r0 + rr] + v2f{v[rr][q].z, v[rr][q].w};
+        }
+      __builtin_amdgcn_sched_barrier(0);   // keep it at two rows in flight (register budget)
     }
+  };
+  // All four 4-item chunks are always fetched (unused item slots hold stale finite-or-not values
+  // nobody reads): choosing between instantiations per entry makes the register allocator copy the
+  // 128 sums around at the joins.
+  auto gather = [&](int p, const float* cur) {
+    if (a.ablate & 2) return;
+    gather_n(std::integral_constant<int, 4>{}, p, cur);
   };
 
   load_cb(0);
@@ -345,113 +362,143 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   // the LDS busy with the gathers of slab(p).  Both orders only read buffer p&1 and write the
   // other one, so one barrier per position still suffices.
   const bool gather_first = (wave >> 2) & 1;
-  for (int p = 0; p < M; ++p) {
+  for (int p = 0; p + 1 < M; ++p) {
     float* nxt = slab + (size_t)((p + 1) & 1) * G * K;
     const float* cur = slab + (size_t)(p & 1) * G * K;
+    if (!gather_first) {
+      if (!(a.ablate & 1)) build_slab(p + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      if (p + 2 < M && !(a.ablate & 8)) load_cb(p + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    gather(p, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    if ((p & 1) && !(a.ablate & 8)) load_codes((p + 1) >> 1);
+    __builtin_amdgcn_sched_barrier(0);
     if (gather_first) {
-      if (!(a.ablate & 2)) gather(p, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      if ((p & 1) && p + 1 < M && !(a.ablate & 8)) load_codes((p + 1) >> 1);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p + 1 < M && !(a.ablate & 1)) build_slab(p + 1, nxt);
+      if (!(a.ablate & 1)) build_slab(p + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
       if (p + 2 < M && !(a.ablate & 8)) load_cb(p + 2);
-    } else {
-      if (p + 1 < M && !(a.ablate & 1)) build_slab(p + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      if (p + 2 < M && !(a.ablate & 8)) load_cb(p + 2);
-      __builtin_amdgcn_sched_barrier(0);
-      if (!(a.ablate & 2)) gather(p, cur);
-      __builtin_amdgcn_sched_barrier(0);
-      if ((p & 1) && p + 1 < M && !(a.ablate & 8)) load_codes((p + 1) >> 1);
     }
     lds_barrier();
   }
-  if (a.ablate & 4) { __syncthreads(); continue; }
-  // scan positions (row ids) of this lane's rows: only the selection needs them
+  // last position: nothing left to build, the codebook registers are free -> fetch the row ids
+  // (scan positions) the selection needs underneath the last gather
   int32_t pid[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
+  gather(M - 1, slab + (size_t)((M - 1) & 1) * G * K);
+  if (a.ablate & 4) { __syncthreads(); continue; }
+  lds_barrier();   // every wave is done reading the slabs: the selection scratch aliases them
 
   // ---- selection -------------------------------------------------------------------------
+  // Keys are (distance bits << 32 | row id); distances are >= +0, so bit patterns order like the
+  // floats and everything below works on the two 32-bit halves separately (64-bit VALU compares
+  // are slow).  A lane's rows have ascending ids in r, so "first strictly smaller" is the key order.
   u64* exch = reinterpret_cast<u64*>(smem);          // [G][T], aliases the slabs (all reads done)
   u64* tau_s = exch + (size_t)G * T;                 // [G]
   const u64 sentinel_key = (u64)a.sentinel_bits << 32;
-  bool live[RMAX];
+  auto bits = [&](int g, int r) { return __float_as_uint((g & 1) ? acc[g >> 1][r].y : acc[g >> 1][r].x); };
+  {
+    bool dead[RMAX];
+    bool some = false;
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) live[r] = ((r * NW + wave) < nblk) && pid[r] >= 0;
+    for (int r = 0; r < RMAX; ++r) { dead[r] = !(((r * NW + wave) < nblk) && pid[r] >= 0); some |= dead[r]; }
+    if (__ballot(some) != 0ull) {   // only the last chunk of a list has padding rows: park them at +NaN
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+        for (int h = 0; h < G / 2; ++h)
+          if (dead[r]) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+    }
+  }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    u64 mn = KEY_INF;
     if (g < cnt) {
+      uint32_t best = bits(g, 0);
+      uint32_t bp = (uint32_t)pid[0];
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
-        if (live[r] && key < mn) mn = key;
+      for (int r = 1; r < RMAX; ++r) {
+        const uint32_t b = bits(g, r);
+        const bool c = b < best;
+        best = c ? b : best;
+        bp = c ? (uint32_t)pid[r] : bp;
       }
+      exch[(size_t)g * T + tid] = ((u64)best << 32) | (u64)bp;
     }
-    exch[(size_t)g * T + tid] = mn;
   }
   __syncthreads();
 #pragma unroll
   for (int h = 0; h < G / NW; ++h) {   // each wave finds the threshold of G/NW items
     const int g = wave + h * NW;
-    u64 col = KEY_INF;
+    if (g < cnt) {
+      u64 col = KEY_INF;
 #pragma unroll
-    for (int w2 = 0; w2 < NW; ++w2) col = umin64(col, exch[(size_t)g * T + w2 * 64 + lane]);
-    col = wave_sort64(col);
-    const u64 t = __shfl(col, a.L - 1, 64);
-    if (lane == 0) tau_s[g] = t;
+      for (int w2 = 0; w2 < NW; ++w2) col = umin64(col, exch[(size_t)g * T + w2 * 64 + lane]);
+      col = wave_sort64(col);
+      const u64 t = __shfl(col, a.L - 1, 64);
+      // survivors are {key <= tau and key < sentinel}: fold both into one bound
+      if (lane == 0) tau_s[g] = umin64(t, sentinel_key - 1ull);
+    }
   }
   __syncthreads();
-  // Survivors {key <= tau} go to the items' buffers.  Pass 1 only counts them per (wave, item);
-  // then lane g reserves the wave's slots of item g with ONE atomic for all 16 items at once (a
-  // returning atomic per hit would serialise ~1 us round trips); pass 2 writes the keys.
+  // Survivors go to the items' buffers.  Pass 1 counts them per (wave, item) -- one 32-bit compare
+  // and a scalar branch per (item, row slot), the exact test only where some lane passes it -- and
+  // remembers the hit slots; then lane g reserves the wave's slots of item g with ONE atomic for all
+  // 16 items at once (a returning atomic per hit would serialise ~1 us round trips); pass 2 revisits
+  // the hit slots and writes the keys.
   const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int my_n = 0;        // lane g: this wave's survivor count of item g
-  u64 any_mask = 0;    // bit g: this wave holds survivors of item g
+  int my_n = 0;                       // lane g: this wave's survivor count of item g
+  uint32_t hit[G / 4] = {0, 0, 0, 0}; // wave-uniform: bit (g&3)*8 + r of hit[g>>2] = slot (g, r) holds survivors
+  auto passes = [&](int g, int r, uint32_t thi, uint32_t tlo) {
+    const uint32_t b = bits(g, r);
+    return (bool)((int)(b < thi) | ((int)(b == thi) & (int)((uint32_t)pid[r] <= tlo)));
+  };
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     if (g < cnt) {
       const u64 tau = tau_s[g];
-      const u64 mine = exch[(size_t)g * T + tid];   // a lane holds survivors only if its best key passes
-      if (a.cand_count) {
+      const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tau >> 32));
+      const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tau);
+      if (a.cand_count) {   // freddy.c:971 counts the rows that pass the sentinel guard
         int accepted = 0;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
-          accepted += __popcll(__ballot(live[r] && key < sentinel_key));
-        }
+        for (int r = 0; r < RMAX; ++r) accepted += __popcll(__ballot(bits(g, r) < a.sentinel_bits));
         if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[desc[g]], accepted);
       }
-      if (__ballot(mine <= tau && mine < sentinel_key) != 0ull) {
-        int n = 0;
+      int n = 0;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
-          n += __popcll(__ballot(live[r] && key < sentinel_key && key <= tau));
+      for (int r = 0; r < RMAX; ++r) {
+        if (__ballot(bits(g, r) <= thi) != 0ull) {
+          const u64 m = __ballot(passes(g, r, thi, tlo));
+          if (m != 0ull) {
+            n += __popcll(m);
+            hit[g >> 2] |= 1u << ((g & 3) * 8 + r);
+          }
         }
-        if (lane == g) my_n = n;
-        any_mask |= (1ull << g);
       }
+      if (lane == g) my_n = n;
     }
   }
   int my_base = 0;
   if (lane < G && my_n > 0) my_base = atomicAdd(a.surv_count + desc[lane], my_n);
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    if ((any_mask >> g) & 1ull) {   // wave-uniform
+    if ((hit[g >> 2] >> ((g & 3) * 8)) & 0xffu) {   // wave-uniform
       const u64 tau = tau_s[g];
+      const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tau >> 32));
+      const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tau);
       const int it = __builtin_amdgcn_readfirstlane(desc[g]);
-      int run = __shfl(my_base, g, 64);
+      int run = __builtin_amdgcn_readlane(my_base, g);
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) {
-        const u64 key = make_key(acc[g][r], (uint32_t)pid[r]);
-        const bool pass = live[r] && key < sentinel_key && key <= tau;
-        const u64 mask = __ballot(pass);
-        const int idx = run + __popcll(mask & lt);
-        if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = key;
-        run += __popcll(mask);
+        if ((hit[g >> 2] >> ((g & 3) * 8 + r)) & 1u) {
+          const bool pass = passes(g, r, thi, tlo);
+          const u64 mask = __ballot(pass);
+          const int idx = run + __popcll(mask & lt);
+          if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = ((u64)bits(g, r) << 32) | (u64)(uint32_t)pid[r];
+          run += __popcll(mask);
+        }
       }
     }
   }
@@ -480,9 +527,6 @@ struct MergeSurvArgs {
 
 __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
   __shared__ u64 stage[64];
-  __shared__ u64 cand[64];
-  __shared__ int32_t s_id[32];
-  __shared__ float s_d[32];
   const int x = blockIdx.x, lane = threadIdx.x;
   const int q = a.active ? a.active[x] : x;
   const int k = a.k;
@@ -503,28 +547,15 @@ __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
   sel.finish();
   u64 byp = (sel.acc[0] == KEY_INF || lane >= a.L) ? KEY_INF : ((sel.acc[0] << 32) | (sel.acc[0] >> 32));
   byp = wave_sort64(byp);
-  cand[lane] = byp;
-  for (int i = lane; i < k; i += 64) {
-    s_id[i] = a.first_round ? -1 : a.out_ids[(size_t)q * k + i];
-    s_d[i] = a.first_round ? a.sentinel : a.out_dist[(size_t)q * k + i];
+  // lane i = slot i of the carried list (k <= 32 on this path); candidates replayed in scan order
+  float d_slot = (a.first_round || lane >= k) ? a.sentinel : a.out_dist[(size_t)q * k + lane];
+  int32_t id_slot = (a.first_round || lane >= k) ? -1 : a.out_ids[(size_t)q * k + lane];
+  wave_list_replay(d_slot, id_slot, k, byp, a.L, [](uint32_t hi) { return (int32_t)hi; });
+  if (lane < k) {
+    a.out_ids[(size_t)q * k + lane] = id_slot;
+    a.out_dist[(size_t)q * k + lane] = d_slot;
   }
-  __syncthreads();
   if (lane == 0) {
-    float maxd = s_d[k - 1];
-    for (int e = 0; e < a.L; ++e) {
-      const u64 c = cand[e];
-      if (c == KEY_INF) break;
-      const float dist = __uint_as_float((uint32_t)c);
-      if (dist < maxd) {
-        int slot = k - 1;                                // updateTopK, index_utils.c:19-33
-        while (slot >= 0 && !(s_d[slot] < dist)) --slot;
-        ++slot;
-        for (int t = k - 2; t >= slot; --t) { s_d[t + 1] = s_d[t]; s_id[t + 1] = s_id[t]; }
-        s_d[slot] = dist;
-        s_id[slot] = (int32_t)(uint32_t)(c >> 32);
-        maxd = s_d[k - 1];
-      }
-    }
     int f = a.first_round ? 0 : a.found[q];
     const int rows = a.round_rows[x];
     f += (a.found_rule == 1 && a.cand_count) ? a.cand_count[q] : (rows > 0 ? rows : 0);
@@ -534,11 +565,6 @@ __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
       a.next_active[slot] = q;
       if (a.status) a.status[0] = 1;
     }
-  }
-  __syncthreads();
-  for (int i = lane; i < k; i += 64) {
-    a.out_ids[(size_t)q * k + i] = s_id[i];
-    a.out_dist[(size_t)q * k + i] = s_d[i];
   }
 }
 

@@ -92,6 +92,84 @@ __global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict
     if (q0 + t < Q) dist[(size_t)(q0 + t) * Cpad + j] = acc[t];
 }
 
+// Tiled form of the same computation for batches: a workgroup produces a 64-query x 64-cell tile,
+// every thread a 4x4 block of it.  Queries and centroids are staged through LDS CT_DK dimensions
+// at a time (double buffered, one barrier per chunk), so per dimension a thread issues two
+// ds_read_b128 for 24 packed VALU instructions (8 independent sub/mul/add chains) and the tables
+// cross the L2 once per tile.  Dimensions past d are staged as zeros: (0-0)^2 adds +0, which
+// leaves every partial sum bit-identical.  Order per (query, cell): dimensions ascending, as
+// squareDistance (index_utils.c:500-508).
+static constexpr int CT_DK = 16;
+__global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restrict__ queries,
+                                                         const float* __restrict__ coarseT,
+                                                         float* __restrict__ dist, int Q, int Cpad, int d) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float As[2][CT_DK][64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][CT_DK][64];
+  const int tid = threadIdx.x;
+  const int tc = tid & 15, tq = tid >> 4;
+  const int c0 = blockIdx.x * 64, q0 = blockIdx.y * 64;
+  // staging roles
+  const int aq = tid >> 2, adim = (tid & 3) * 4;      // query aq, dims adim..adim+3 of the chunk
+  const int bdim = tid >> 4, bc = (tid & 15) * 4;     // dim bdim, cells bc..bc+3
+  const int aqg = (q0 + aq < Q) ? q0 + aq : Q - 1;
+  const float* arow = queries + (size_t)aqg * d;
+  float ra[4];
+  float4 rb;
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ra[u] = (k0 + adim + u < d) ? arow[k0 + adim + u] : 0.0f;
+    rb = (k0 + bdim < d) ? *reinterpret_cast<const float4*>(coarseT + (size_t)(k0 + bdim) * Cpad + c0 + bc)
+                         : float4{0.0f, 0.0f, 0.0f, 0.0f};
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) As[buf][adim + u][aq] = ra[u];
+    *reinterpret_cast<float4*>(&Bs[buf][bdim][bc]) = rb;
+  };
+  v2f acc[4][2];   // [cell i][query pair j]
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = v2f{0.0f, 0.0f};
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (int k0 = 0; k0 < d; k0 += CT_DK) {
+    const bool more = k0 + CT_DK < d;
+    if (more) fetch(k0 + CT_DK);
+#pragma unroll
+    for (int dd = 0; dd < CT_DK; ++dd) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][dd][tq * 4]);
+      const float4 b4 = *reinterpret_cast<const float4*>(&Bs[buf][dd][tc * 4]);
+      const v2f qa = {a4.x, a4.y}, qb = {a4.z, a4.w};
+      const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const v2f c2 = {bv[i], bv[i]};
+        const v2f da = qa - c2, db = qb - c2;
+        const v2f pa = da * da, pb = db * db;
+        acc[i][0] = acc[i][0] + pa;
+        acc[i][1] = acc[i][1] + pb;
+      }
+    }
+    if (more) stash(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int q = q0 + tq * 4 + j;
+    if (q < Q) {
+      float4 o;
+      o.x = (j & 1) ? acc[0][j >> 1].y : acc[0][j >> 1].x;
+      o.y = (j & 1) ? acc[1][j >> 1].y : acc[1][j >> 1].x;
+      o.z = (j & 1) ? acc[2][j >> 1].y : acc[2][j >> 1].x;
+      o.w = (j & 1) ? acc[3][j >> 1].y : acc[3][j >> 1].x;
+      *reinterpret_cast<float4*>(dist + (size_t)q * Cpad + c0 + tc * 4) = o;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // a7 probe plan: one wave per active query reproduces the reference's cell selection
 //   (freddy.c:266-293): cells are offered in ascending id, used ones skipped, and the W
@@ -130,17 +208,36 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
   uint32_t* used = a.used + (size_t)q * a.used_words;
   const float* drow = a.dist + (size_t)q * a.Cpad;
 
-  WaveSelect<V> sel;
-  sel.init(stage, (u64)__float_as_uint(100.0f) << 32, L);
-  for (int base = 0; base < a.C; base += 64) {
-    const int j = base + lane;
-    bool valid = j < a.C;
+  const u64 limit = (u64)__float_as_uint(100.0f) << 32;
+  auto load_key = [&](int j, bool& valid) {
+    valid = j < a.C;
     float dv = 0.0f;
     if (valid) {
       valid = !((used[j >> 5] >> (j & 31)) & 1u);
       dv = drow[j];
     }
-    sel.push(make_key(dv, (uint32_t)j), valid);
+    return make_key(dv, (uint32_t)j);
+  };
+  // Pre-pass: the L-th smallest of the 64 per-lane minima bounds the L-th smallest key from above,
+  // so the selection below starts with a tight threshold and (almost always) a single merge.
+  u64 tau0 = limit;
+  if (L <= 64) {
+    u64 mn = KEY_INF;
+    for (int base = 0; base < a.C; base += 64) {
+      bool valid;
+      const u64 key = load_key(base + lane, valid);
+      if (valid && key < mn) mn = key;
+    }
+    mn = wave_sort64(mn);
+    const u64 t = __shfl(mn, L - 1, 64);
+    if (t != KEY_INF && t + 1 < tau0) tau0 = t + 1;   // keys are unique: "< t+1" keeps t itself
+  }
+  WaveSelect<V> sel;
+  sel.init(stage, tau0, L);
+  for (int base = 0; base < a.C; base += 64) {
+    bool valid;
+    const u64 key = load_key(base + lane, valid);
+    sel.push(key, valid);
   }
   sel.finish();
   u64 byp[V];
@@ -148,6 +245,27 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
   for (int v = 0; v < V; ++v)
     byp[v] = (sel.acc[v] == KEY_INF || v * 64 + lane >= L) ? KEY_INF : ((sel.acc[v] << 32) | (sel.acc[v] >> 32));
   wave_sort_full<V>(byp);
+  if (V == 1 && W <= 64) {
+    // lane i = slot i of the W-entry list; candidates replayed in cell order
+    float d_slot = 100.0f;
+    int32_t c_slot = -1;
+    wave_list_replay(d_slot, c_slot, W, byp[0], L, [](uint32_t hi) { return (int32_t)hi; });
+    const bool have = lane < W && c_slot >= 0;
+    int rows = have ? (a.list_off[c_slot + 1] - a.list_off[c_slot]) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rows += __shfl_xor(rows, o, 64);
+    if (have) {
+      atomicOr(used + (c_slot >> 5), 1u << (c_slot & 31));
+      if (a.cell_count) atomicAdd(a.cell_count + c_slot, 1);
+    }
+    const bool any_cell = __ballot(have) != 0ull;
+    if (lane == 0) a.round_rows[x] = any_cell ? rows : -1;   // -1: every cell already used, the query retires
+    if (lane < W) {
+      a.item_cell[(size_t)x * W + lane] = c_slot;
+      a.item_query[(size_t)x * W + lane] = q;
+    }
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < V; ++v) cand[v * 64 + lane] = byp[v];
   for (int i = lane; i < W; i += 64) { sd[i] = 100.0f; sc[i] = -1; }
@@ -494,6 +612,31 @@ __global__ __launch_bounds__(64) void merge_replay_kernel(MergeArgs a) {
   for (int v = 0; v < V; ++v)
     byp[v] = (acc[v] == KEY_INF || v * 64 + lane >= a.L) ? KEY_INF : ((acc[v] << 32) | (acc[v] >> 32));
   wave_sort_full<V>(byp);
+  auto bookkeeping = [&]() {   // "found" (freddy.c:377 rows rule, :971 accepted rule); one lane
+    int f = a.first_round ? 0 : a.found[q];
+    const int rows = a.round_rows ? a.round_rows[x] : 0;
+    f += (a.found_rule == 1 && a.cand_count) ? a.cand_count[q] : (rows > 0 ? rows : 0);
+    if (a.found) a.found[q] = f;
+    if (a.next_active && f < k && rows >= 0) {   // rows < 0: no cell left, the query retires
+      const int slot = atomicAdd(a.n_next, 1);
+      a.next_active[slot] = q;
+      if (a.status) a.status[0] = 1;
+    }
+  };
+  if (V == 1 && k <= 64) {
+    // lane i = slot i of the carried list; candidates replayed in scan order
+    float d_slot = (a.first_round || lane >= k) ? a.sentinel : a.out_dist[(size_t)q * k + lane];
+    int32_t id_slot = (a.first_round || lane >= k) ? -1 : a.out_ids[(size_t)q * k + lane];
+    wave_list_replay(d_slot, id_slot, k, byp[0], a.L < 64 ? a.L : 64, [&](uint32_t p) {
+      return a.pos_to_id ? a.pos_to_id[p] : (int32_t)p;
+    });
+    if (lane < k) {
+      a.out_ids[(size_t)q * k + lane] = id_slot;
+      a.out_dist[(size_t)q * k + lane] = d_slot;
+    }
+    if (lane == 0) bookkeeping();
+    return;
+  }
 #pragma unroll
   for (int v = 0; v < V; ++v) cand[v * 64 + lane] = byp[v];
   // carried list
@@ -519,16 +662,7 @@ __global__ __launch_bounds__(64) void merge_replay_kernel(MergeArgs a) {
         maxd = s_d[k - 1];
       }
     }
-    // bookkeeping of "found" (freddy.c:377 rows rule, :971 accepted rule)
-    int f = a.first_round ? 0 : a.found[q];
-    const int rows = a.round_rows ? a.round_rows[x] : 0;
-    f += (a.found_rule == 1 && a.cand_count) ? a.cand_count[q] : (rows > 0 ? rows : 0);
-    if (a.found) a.found[q] = f;
-    if (a.next_active && f < k && rows >= 0) {   // rows < 0: no cell left, the query retires
-      const int slot = atomicAdd(a.n_next, 1);
-      a.next_active[slot] = q;
-      if (a.status) a.status[0] = 1;
-    }
+    bookkeeping();
   }
   __syncthreads();
   for (int i = lane; i < k; i += 64) {

@@ -131,6 +131,51 @@ __device__ __forceinline__ void wave_sort_full(u64 (&a)[V]) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The reference's result list (TopK, index_utils.h:17-20) held one entry per lane: lane i owns
+// slot i of a list of n <= 64 entries, ascending.  wave_list_insert is updateTopK
+// (index_utils.c:19-33): the new entry goes in front of the first entry that is not strictly
+// smaller -- the strictly smaller entries are a prefix, so that slot is their count -- everything
+// behind moves one slot down and the last entry falls off.  The caller applies the guard
+// "dist < maxDist" (freddy.c:128-131) with maxDist = wave_list_max().  Lanes >= n carry junk.
+// One insertion is a ballot, a popcount and two DPP wave shifts instead of a serial walk over LDS.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_list_max(float d_slot, int n) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(d_slot), n - 1));
+}
+__device__ __forceinline__ void wave_list_insert(float& d_slot, int32_t& id_slot, int n, float dist, int32_t id) {
+  const int lane = lane_id();
+  const int slot = __popcll(__ballot(lane < n && d_slot < dist));
+  // wave_shr:1 -- lane i receives lane i-1 (lane 0 keeps its own value)
+  const int up_d = __builtin_amdgcn_update_dpp((int)__float_as_uint(d_slot), (int)__float_as_uint(d_slot), 0x138, 0xf, 0xf, false);
+  const int up_id = __builtin_amdgcn_update_dpp(id_slot, id_slot, 0x138, 0xf, 0xf, false);
+  if (lane > slot) {
+    d_slot = __uint_as_float((uint32_t)up_d);
+    id_slot = up_id;
+  } else if (lane == slot) {
+    d_slot = dist;
+    id_slot = id;
+  }
+}
+// Replays the guarded insertion over `count` candidates held one per lane (64-bit value: low word =
+// distance bits, high word = payload), in lane order; KEY_INF ends the sequence.  `payload(hi)` maps
+// the high word to the id stored in the list.
+template <typename F>
+__device__ __forceinline__ void wave_list_replay(float& d_slot, int32_t& id_slot, int n, u64 cand, int count, F payload) {
+  float maxd = wave_list_max(d_slot, n);
+  const int lo = (int)(uint32_t)cand, hi = (int)(uint32_t)(cand >> 32);
+  for (int e = 0; e < count; ++e) {
+    const uint32_t clo = (uint32_t)__builtin_amdgcn_readlane(lo, e);
+    const uint32_t chi = (uint32_t)__builtin_amdgcn_readlane(hi, e);
+    if (clo == 0xffffffffu && chi == 0xffffffffu) break;
+    const float dist = __uint_as_float(clo);
+    if (dist < maxd) {
+      wave_list_insert(d_slot, id_slot, n, dist, payload(chi));
+      maxd = wave_list_max(d_slot, n);
+    }
+  }
+}
+
 // Streaming selection of the L smallest keys seen by one wave.  Keys below the running
 // threshold are compacted into a 64-entry LDS staging row (ballot + prefix popcount) and
 // absorbed by a bitonic merge only when the row fills up, which becomes rare once the
