@@ -108,7 +108,7 @@ struct freddy_gpu_index {
   // workspaces
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -157,7 +157,7 @@ static void free_index(freddy_gpu_index* ix) {
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
                     &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
-                    &ix->w_surv, &ix->w_surv_cnt};
+                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
     for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -497,7 +497,6 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && L <= 64 &&
                      (force_fused || items >= 256);
   const int upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
-  const int surv_cap = upi * std::min(64 * L, FUSED_UNIT_BLOCKS * 64);
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
@@ -510,7 +509,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     // cell_count[C] + cell_fill[C] + cell_start[C]; group table: 3 arrays of (items/G + C) entries
     if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * items) ||
         ix->w_groups.ensure(sizeof(int32_t) * 6 * (items / FUSED_G + (size_t)C + 1) * upi) ||
-        ix->w_surv.ensure(sizeof(u64) * items * surv_cap) || ix->w_surv_cnt.ensure(sizeof(int32_t) * items))
+        ix->w_surv.ensure(sizeof(u64) * items * upi * FUSED_NW * FUSED_RMAX * 64) ||
+        ix->w_surv_cnt.ensure(sizeof(int32_t) * items * upi * FUSED_NW))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
     if (ix->w_lut.ensure(sizeof(float) * items * lutN) || ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * L))
@@ -566,7 +566,6 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
     if (fused) {
-      HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * n_items, s));
       const size_t max_groups = ((size_t)n_items / FUSED_G + (size_t)C + 1) * upi;   // (group, chunk) work entries
       int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
       int32_t* cell_fill = cell_count + C;
@@ -592,14 +591,20 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
       fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
       fa.cand_count = (found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
-      fa.d = d; fa.K = K; fa.L = L; fa.cap = surv_cap;
+      fa.d = d; fa.K = K; fa.L = L; fa.upi = upi;
       memcpy(&fa.sentinel_bits, &sentinel, 4);
       const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
-      const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(u64) + 64 * sizeof(u64);
+      const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(uint32_t) + 64 * sizeof(uint32_t);
       const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
-      const size_t flds = desc_off + 128 + (size_t)FUSED_G * 12 * 28 * sizeof(float);   // + item ids + padded residuals
+      const size_t flds = desc_off + 256 + (size_t)FUSED_G * 12 * 28 * sizeof(float);   // + entry descriptors + padded residuals
       fa.desc_offset = (uint32_t)desc_off;
       { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
+      fa.prof = nullptr;
+      static const bool want_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
+      if (want_prof) {
+        if (ix->w_prof.ensure(sizeof(long long) * 8 * 1024)) return fail(FREDDY_E_NOMEM, "profile buffer");
+        fa.prof = ix->w_prof.as<long long>();
+      }
       static bool fattr = false;
       if (!fattr) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_fused_kernel<25, 12, true>),
@@ -617,12 +622,27 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
           hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
       });
       HIP_TRY(hipGetLastError());
+      if (fa.prof) {   // debugging aid: per-phase shader-clock sums of every persistent workgroup
+        std::vector<long long> h(8 * (size_t)n_persist);
+        HIP_TRY(hipStreamSynchronize(s));
+        HIP_TRY(hipMemcpy(h.data(), fa.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+        double sum[8] = {0}; long long mx_end = 0, mn_end = -1; double ent = 0;
+        for (unsigned b = 0; b < n_persist; ++b) {
+          for (int i = 0; i < 6; ++i) sum[i] += (double)h[b * 8 + i];
+          ent += (double)h[b * 8 + 7];
+          mx_end = std::max(mx_end, h[b * 8 + 6]);
+          mn_end = mn_end < 0 ? h[b * 8 + 6] : std::min(mn_end, h[b * 8 + 6]);
+        }
+        fprintf(stderr, "[fused prof] wgs=%u entries=%.0f  cycles/entry: stage=%.0f slab0=%.0f loop=%.0f lastgather=%.0f select=%.0f | exit spread=%lld cycles\n",
+                n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[4] / ent, mx_end - mn_end);
+      }
       MergeSurvArgs ms;
       ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = active; ms.round_rows = pa.round_rows;
       ms.cand_count = fa.cand_count; ms.out_ids = d_out_ids; ms.out_dist = d_out_dist;
       ms.found = ix->w_found.as<int32_t>(); ms.next_active = next; ms.n_next = ix->w_cnt.as<int32_t>();
       ms.status = d_status;
-      ms.n_active = n_active; ms.W = W; ms.cap = surv_cap; ms.L = L; ms.k = k; ms.found_rule = found_rule;
+      ms.item_cell = pa.item_cell; ms.blk_off = ix->blk_off;
+      ms.n_active = n_active; ms.W = W; ms.upi = upi; ms.L = L; ms.k = k; ms.found_rule = found_rule;
       ms.first_round = first ? 1 : 0; ms.sentinel = sentinel;
       timed_launch(ix, s, "merge_replay", [&] {
         hipLaunchKernelGGL(merge_surv_kernel, dim3(n_active), dim3(64), 0, s, ms);

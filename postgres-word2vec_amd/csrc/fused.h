@@ -146,13 +146,14 @@ struct FusedArgs {
   const int32_t* blk_off;      // [C+1]
   const uint32_t* packed;      // [blocks][M2][64]
   const int32_t* pos;          // [blocks*64]
-  u64* surv;                   // [items][cap]
-  int32_t* surv_count;         // [items]
+  u64* surv;                   // [items][upi][8 waves][512] survivor keys, one region per (item, chunk, wave)
+  int32_t* surv_count;         // [items][upi][8 waves] written by the kernel for every region of a live item
   int32_t* cand_count;         // [Q] or NULL
-  int d, K, L, cap;
+  int d, K, L, upi;            // upi: chunks per item the buffers are laid out for
   uint32_t sentinel_bits;
   uint32_t desc_offset;        // byte offset of the item-descriptor scratch inside dynamic LDS
   uint32_t ablate;             // timing experiments only (FREDDY_GPU_FUSED_ABLATE)
+  long long* prof;             // NULL, or [gridDim.x][8] cycle sums per phase (FREDDY_GPU_FUSED_PROF)
 };
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() makes hipcc drain vmcnt too,
@@ -181,42 +182,87 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int K = a.K;
-  // persistent workgroups: one per CU, work entries are pulled from a device-wide counter
+  // Persistent workgroups: one per CU, work entries are pulled from a device-wide counter.  The
+  // descriptor of the NEXT entry (work index -> cell, items, row blocks) is fetched underneath the
+  // selection phase of the current one -- three dependent global round trips that used to sit in
+  // front of every entry -- into the other half of a double-buffered LDS descriptor:
+  //   dsc[b*16 + g]      item id of slot g (-1: unused)          b = 0/1
+  //   dsc[32 + b*8 + ..] {work index or -1, items, first block, blocks, chunk}
   const int n_work = a.n_groups[0];
-  int32_t* desc = reinterpret_cast<int32_t*>(smem + a.desc_offset);   // [G] item ids, [G] = next work index
-  for (;;) {
-  if (tid == 0) desc[G] = atomicAdd(a.work_counter, 1);
-  __syncthreads();
-  const int gid = desc[G];
-  if (gid >= n_work) break;
-  // opaque per iteration: stops LICM from hoisting (and then spilling) one 64-bit codebook address
-  // per position out of the persistent loop
+  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset);
+  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 256);  // [G][M][SP] residuals
+  constexpr int ROW4 = M * ((S + 3) & ~3) / 4;                        // float4 per item
+  // opaque: stops LICM from hoisting (and then spilling) one 64-bit codebook address per position
   const float* cbp = a.cbP;
   asm volatile("" : "+s"(cbp));
-  const int cell = a.group_cell[gid];
-  const int first = a.group_first[gid];
-  const int cnt = a.group_cnt[gid] & 0xff;
-  const int chunk = a.group_cnt[gid] >> 8;
-  const int blk0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
-  int nblk = a.blk_off[cell + 1] - blk0;
-  if (nblk > FUSED_UNIT_BLOCKS) nblk = FUSED_UNIT_BLOCKS;   // (>= 1 by construction of the work table)
 
-  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 128);  // [G][M][SP] residuals
-  if (tid < G) desc[tid] = (tid < cnt) ? a.sorted_item[first + tid] : -1;
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f cb[S];   // .x: code tid, .y: code tid + T  (packed so the two chains run as v_pk_* ops)
+  static_assert(E == 2, "two codes per lane");
+  // cbP layout [m][SP/4][T][4 dims][2 codes]: this lane's codes (tid, tid+T) interleaved, so two
+  // 16-byte loads bring four dimensions of both codes already in (x, y) pair order (codes >= K
+  // are zero-padded by the host).  14 wide loads per position instead of 50 dword loads.
+  auto load_cb = [&](int p) {
+    constexpr int SPq = ((S + 3) & ~3) / 4;
+    // explicitly GLOBAL pointers: after the asm above the compiler only knows a generic one and
+    // would emit flat_load, which also counts in lgkmcnt -- every LDS-only barrier would then wait
+    // for the prefetch it is supposed to let fly
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const f4 __attribute__((address_space(1))) * gptr4;
+    typedef const char __attribute__((address_space(1))) * gptrc;
+    const gptrc base = (gptrc)(uintptr_t)cbp + (size_t)(uint32_t)p * (uint32_t)(SPq * T * 32);
+    const uint32_t voff = (uint32_t)tid * 32u;
+#pragma unroll
+    for (int jb = 0; jb < SPq; ++jb) {
+      const gptrc bj = base + (uint32_t)jb * (uint32_t)(T * 32);
+      const f4 lo = *(gptr4)(bj + voff), hi = *(gptr4)(bj + voff + 16u);
+      if (jb * 4 + 0 < S) cb[jb * 4 + 0] = v2f{lo.x, lo.y};
+      if (jb * 4 + 1 < S) cb[jb * 4 + 1] = v2f{lo.z, lo.w};
+      if (jb * 4 + 2 < S) cb[jb * 4 + 2] = v2f{hi.x, hi.y};
+      if (jb * 4 + 3 < S) cb[jb * 4 + 3] = v2f{hi.z, hi.w};
+    }
+  };
+
+  long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
+  auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
+  if (a.prof) pc = clock64();
+  // ---- first entry: fetched serially ----
+  int cur = 0;
+  if (tid == 0) dsc[32] = atomicAdd(a.work_counter, 1);
   __syncthreads();
   {
-    constexpr int ROW4 = M * ((S + 3) & ~3) / 4;   // float4 per item
-    for (int i = tid; i < cnt * ROW4; i += T) {
-      const int g = i / ROW4, o = i - g * ROW4;
-      reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)desc[g] * ROW4 + o];
+    const int gid0 = dsc[32];
+    if (gid0 >= n_work) return;
+    if (wave == 0) {
+      const int cell = a.group_cell[gid0], first = a.group_first[gid0], gc = a.group_cnt[gid0];
+      const int cnt0 = gc & 0xff, chunk0 = gc >> 8;
+      const int b0 = a.blk_off[cell] + chunk0 * FUSED_UNIT_BLOCKS;
+      int nb0 = a.blk_off[cell + 1] - b0;
+      if (nb0 > FUSED_UNIT_BLOCKS) nb0 = FUSED_UNIT_BLOCKS;   // (>= 1 by construction of the work table)
+      if (lane < G) dsc[lane] = (lane < cnt0) ? a.sorted_item[first + lane] : -1;
+      if (lane == 0) { dsc[33] = cnt0; dsc[34] = b0; dsc[35] = nb0; dsc[36] = chunk0; }
     }
   }
   __syncthreads();
+  load_cb(0);
+  for (;;) {   // ---- one work entry per iteration; dsc[cur] is complete and visible here ----
+  const int32_t* desc = dsc + cur * 16;
+  const int cnt = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 1]);
+  const int blk0 = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 2]);
+  const int nblk = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 3]);
+  const int chunk = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 4]);
+  for (int i = tid; i < cnt * ROW4; i += T) {
+    const int g = i / ROW4, o = i - g * ROW4;
+    reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)desc[g] * ROW4 + o];
+  }
+  int ngid = 0;   // thread 0: work index of the next entry, requested now, published at the end
+  if (tid == 0) ngid = atomicAdd(a.work_counter, 1);
+  __syncthreads();
+  tick(0);   // descriptor + residual staging
 
   typedef float v2f __attribute__((ext_vector_type(2)));
   v2f acc[G / 2][RMAX];   // ADC sums: acc[h][r] = items (2h, 2h+1) of this lane's row r
   uint32_t cw[RMAX];
-  v2f cb[S];   // .x: code tid, .y: code tid + T  (packed so the two chains run as v_pk_* ops)
 #pragma unroll
   for (int h = 0; h < G / 2; ++h)
 #pragma unroll
@@ -225,25 +271,6 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   auto row_block = [&](int r) {
     const int b = r * NW + wave;
     return (uint32_t)(blk0 + (b < nblk - 1 ? b : nblk - 1));
-  };
-  static_assert(E == 2, "two codes per lane");
-  // cbP layout [m][SP/4][T][4 dims][2 codes]: this lane's codes (tid, tid+T) interleaved, so two
-  // 16-byte loads bring four dimensions of both codes already in (x, y) pair order (codes >= K
-  // are zero-padded by the host).  14 wide loads per position instead of 50 dword loads.
-  auto load_cb = [&](int p) {
-    constexpr int SPq = ((S + 3) & ~3) / 4;
-#pragma unroll
-    for (int jb = 0; jb < SPq; ++jb) {
-      // 32-bit element offset from the (scalar) table base: keeps the address in one VGPR instead of
-      // a hoisted 64-bit pointer per position
-      const uint32_t off = ((uint32_t)(p * SPq + jb) * T + (uint32_t)tid) * 2u;
-      const float4* base4 = reinterpret_cast<const float4*>(cbp);
-      const float4 lo = base4[off], hi = base4[off + 1u];
-      if (jb * 4 + 0 < S) cb[jb * 4 + 0] = v2f{lo.x, lo.y};
-      if (jb * 4 + 1 < S) cb[jb * 4 + 1] = v2f{lo.z, lo.w};
-      if (jb * 4 + 2 < S) cb[jb * 4 + 2] = v2f{hi.x, hi.y};
-      if (jb * 4 + 3 < S) cb[jb * 4 + 3] = v2f{hi.z, hi.w};
-    }
   };
   auto load_codes = [&](int pair) {
 #pragma unroll
@@ -320,6 +347,15 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   // once per entry): inside one instantiation there is no branch, so the 2*NQ ds_read_b128 of two
   // rows are in flight together and the adds of one row pair overlap the reads of the next.  (With
   // a per-chunk `if` every read sat in its own basic block behind an lgkmcnt(0).)
+  // hipcc's waitcnt pass merges the "load pending" state of the code registers over the loop's
+  // paths and puts a vmcnt(0) in front of the gather -- behind the codebook prefetch that was just
+  // issued.  Re-defining cw with a VALU move at a point where its loads have certainly landed
+  // (build-first waves: where the build waits for its codebook; gather-first waves: after the
+  // build) retires that state, and the gather starts without waiting for the prefetch.
+  auto settle_codes = [&]() {
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) asm volatile("v_mov_b32 %0, %0" : "+v"(cw[r]));
+  };
   auto gather_n = [&](auto nq_tag, int p, const float* cur) {
     constexpr int NQ = decltype(nq_tag)::value;
     const int sh = (p & 1) * 16;
@@ -352,59 +388,79 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
     gather_n(std::integral_constant<int, 4>{}, p, cur);
   };
 
-  load_cb(0);
-  load_codes(0);
+  load_codes(0);   // (the codebook registers of position 0 are already in flight)
   build_slab(0, slab);
   if (M > 1) load_cb(1);
   lds_barrier();
+  tick(1);   // first slab
   // Waves 0-3 build first and gather second, waves 4-7 the other way round (each SIMD hosts one
   // wave of each kind): while one half keeps the VALU busy with slab(p+1), the other half keeps
   // the LDS busy with the gathers of slab(p).  Both orders only read buffer p&1 and write the
   // other one, so one barrier per position still suffices.
+  // The two roles are two separate loops, not one loop with role branches: hipcc's waitcnt pass
+  // merges the "load pending" state of all paths at every join, and with shared code it put a
+  // vmcnt(0) in front of each gather -- behind the codebook prefetch that had just been issued.
   const bool gather_first = (wave >> 2) & 1;
-  for (int p = 0; p + 1 < M; ++p) {
-    float* nxt = slab + (size_t)((p + 1) & 1) * G * K;
-    const float* cur = slab + (size_t)(p & 1) * G * K;
-    if (!gather_first) {
+  if (gather_first) {
+    for (int p = 0; p + 1 < M; ++p) {
+      float* nxt = slab + (size_t)((p + 1) & 1) * G * K;
+      const float* cur = slab + (size_t)(p & 1) * G * K;
+      gather(p, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((p & 1) && !(a.ablate & 8)) load_codes((p + 1) >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(a.ablate & 1)) build_slab(p + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      settle_codes();
+      if (p + 2 < M && !(a.ablate & 8)) load_cb(p + 2);
+      lds_barrier();
+    }
+  } else {
+    for (int p = 0; p + 1 < M; ++p) {
+      float* nxt = slab + (size_t)((p + 1) & 1) * G * K;
+      const float* cur = slab + (size_t)(p & 1) * G * K;
+      settle_codes();
       if (!(a.ablate & 1)) build_slab(p + 1, nxt);
       __builtin_amdgcn_sched_barrier(0);
       if (p + 2 < M && !(a.ablate & 8)) load_cb(p + 2);
       __builtin_amdgcn_sched_barrier(0);
-    }
-    gather(p, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if ((p & 1) && !(a.ablate & 8)) load_codes((p + 1) >> 1);
-    __builtin_amdgcn_sched_barrier(0);
-    if (gather_first) {
-      if (!(a.ablate & 1)) build_slab(p + 1, nxt);
+      gather(p, cur);
       __builtin_amdgcn_sched_barrier(0);
-      if (p + 2 < M && !(a.ablate & 8)) load_cb(p + 2);
+      if ((p & 1) && !(a.ablate & 8)) load_codes((p + 1) >> 1);
+      lds_barrier();
     }
-    lds_barrier();
   }
+  tick(2);   // main loop
   // last position: nothing left to build, the codebook registers are free -> fetch the row ids
-  // (scan positions) the selection needs underneath the last gather
+  // (scan positions) the selection needs, and position 0 of the codebook for the next entry (it does
+  // not depend on the entry), underneath the last gather
   int32_t pid[RMAX];
 #pragma unroll
   for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
+  if (!(a.ablate & 8)) load_cb(0);
   gather(M - 1, slab + (size_t)((M - 1) & 1) * G * K);
-  if (a.ablate & 4) { __syncthreads(); continue; }
+  const int nb = cur ^ 1;
+  if (tid == 0) dsc[32 + nb * 8] = (ngid < n_work) ? ngid : -1;
   lds_barrier();   // every wave is done reading the slabs: the selection scratch aliases them
+  tick(3);   // last gather
 
   // ---- selection -------------------------------------------------------------------------
-  // Keys are (distance bits << 32 | row id); distances are >= +0, so bit patterns order like the
-  // floats and everything below works on the two 32-bit halves separately (64-bit VALU compares
-  // are slow).  A lane's rows have ascending ids in r, so "first strictly smaller" is the key order.
-  u64* exch = reinterpret_cast<u64*>(smem);          // [G][T], aliases the slabs (all reads done)
-  u64* tau_s = exch + (size_t)G * T;                 // [G]
-  const u64 sentinel_key = (u64)a.sentinel_bits << 32;
+  // Works on the distance bits only (distances are >= +0, so the bit patterns order like the
+  // floats).  Per item: the L-th smallest of the 64 column minima (column = lane index over the 8
+  // waves x 8 row slots) is an upper bound tau of the L-th smallest distance of the chunk, so
+  // {distance <= tau} contains the item's L smallest (distance, row id) keys; typically L + a few
+  // rows survive, with many equal distances possibly more, never more than the chunk has rows.
+  // Each wave appends its survivors to its own region of the item's buffer (no atomics), the merge
+  // kernel picks the 2k smallest keys of the query and replays.
+  uint32_t* exch = reinterpret_cast<uint32_t*>(smem);   // [G][T], aliases the slabs
+  uint32_t* tau_s = exch + (size_t)G * T;               // [G]
   auto bits = [&](int g, int r) { return __float_as_uint((g & 1) ? acc[g >> 1][r].y : acc[g >> 1][r].x); };
   {
     bool dead[RMAX];
     bool some = false;
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) { dead[r] = !(((r * NW + wave) < nblk) && pid[r] >= 0); some |= dead[r]; }
-    if (__ballot(some) != 0ull) {   // only the last chunk of a list has padding rows: park them at +NaN
+    if (__ballot(some) != 0ull) {   // only the last chunk of a list has padding rows: park them above everything
 #pragma unroll
       for (int r = 0; r < RMAX; ++r)
 #pragma unroll
@@ -412,106 +468,112 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
           if (dead[r]) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
     }
   }
+  if (!(a.ablate & 4)) {
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    if (g < cnt) {
-      uint32_t best = bits(g, 0);
-      uint32_t bp = (uint32_t)pid[0];
+    for (int g = 0; g < G; ++g) {
+      if (g < cnt) {
+        uint32_t best = bits(g, 0);
 #pragma unroll
-      for (int r = 1; r < RMAX; ++r) {
-        const uint32_t b = bits(g, r);
-        const bool c = b < best;
-        best = c ? b : best;
-        bp = c ? (uint32_t)pid[r] : bp;
+        for (int r = 1; r < RMAX; ++r) best = min(best, bits(g, r));
+        exch[(size_t)g * T + tid] = best;
       }
-      exch[(size_t)g * T + tid] = ((u64)best << 32) | (u64)bp;
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int h = 0; h < G / NW; ++h) {   // each wave finds the threshold of G/NW items
-    const int g = wave + h * NW;
-    if (g < cnt) {
-      u64 col = KEY_INF;
-#pragma unroll
-      for (int w2 = 0; w2 < NW; ++w2) col = umin64(col, exch[(size_t)g * T + w2 * 64 + lane]);
-      col = wave_sort64(col);
-      const u64 t = __shfl(col, a.L - 1, 64);
-      // survivors are {key <= tau and key < sentinel}: fold both into one bound
-      if (lane == 0) tau_s[g] = umin64(t, sentinel_key - 1ull);
-    }
+  // next entry, level 2 of 3: its work-table row (wave 0; every lane reads the same words)
+  const int ngid_l = dsc[32 + nb * 8];
+  int n_cell = 0, n_first = 0, n_gc = 0;
+  if (wave == 0 && ngid_l >= 0) {
+    n_cell = a.group_cell[ngid_l];
+    n_first = a.group_first[ngid_l];
+    n_gc = a.group_cnt[ngid_l];
   }
   __syncthreads();
-  // Survivors go to the items' buffers.  Pass 1 counts them per (wave, item) -- one 32-bit compare
-  // and a scalar branch per (item, row slot), the exact test only where some lane passes it -- and
-  // remembers the hit slots; then lane g reserves the wave's slots of item g with ONE atomic for all
-  // 16 items at once (a returning atomic per hit would serialise ~1 us round trips); pass 2 revisits
-  // the hit slots and writes the keys.
-  const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int my_n = 0;                       // lane g: this wave's survivor count of item g
-  uint32_t hit[G / 4] = {0, 0, 0, 0}; // wave-uniform: bit (g&3)*8 + r of hit[g>>2] = slot (g, r) holds survivors
-  auto passes = [&](int g, int r, uint32_t thi, uint32_t tlo) {
-    const uint32_t b = bits(g, r);
-    return (bool)((int)(b < thi) | ((int)(b == thi) & (int)((uint32_t)pid[r] <= tlo)));
-  };
+  if (!(a.ablate & 4)) {   // each wave finds the thresholds of its two items, the two sorts interleaved
+    static_assert(G == 2 * NW, "two items per wave");
+    const int g0 = wave, g1 = wave + NW;
+    uint32_t c0 = 0xffffffffu, c1 = 0xffffffffu;
+    if (g0 < cnt) {
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    if (g < cnt) {
-      const u64 tau = tau_s[g];
-      const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tau >> 32));
-      const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tau);
-      if (a.cand_count) {   // freddy.c:971 counts the rows that pass the sentinel guard
-        int accepted = 0;
+      for (int w2 = 0; w2 < NW; ++w2) c0 = min(c0, exch[(size_t)g0 * T + w2 * 64 + lane]);
+    }
+    if (g1 < cnt) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) accepted += __popcll(__ballot(bits(g, r) < a.sentinel_bits));
-        if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[desc[g]], accepted);
-      }
-      int n = 0;
+      for (int w2 = 0; w2 < NW; ++w2) c1 = min(c1, exch[(size_t)g1 * T + w2 * 64 + lane]);
+    }
+    wave_sort32_x2(c0, c1);
+    const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
+    // survivors are {bits <= tau and bits < sentinel}: fold both into one bound
+    if (lane == 0) {
+      tau_s[g0] = min(t0, a.sentinel_bits - 1u);
+      tau_s[g1] = min(t1, a.sentinel_bits - 1u);
+    }
+  }
+  // next entry, level 3 of 3: its item ids and row-block range
+  int n_item = -1, n_b0 = 0, n_b1 = 0;
+  if (wave == 0 && ngid_l >= 0) {
+    if (lane < (n_gc & 0xff)) n_item = a.sorted_item[n_first + lane];
+    n_b0 = a.blk_off[n_cell];
+    n_b1 = a.blk_off[n_cell + 1];
+  }
+  __syncthreads();
+  if (!(a.ablate & 4)) {
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        if (__ballot(bits(g, r) <= thi) != 0ull) {
-          const u64 m = __ballot(passes(g, r, thi, tlo));
-          if (m != 0ull) {
-            n += __popcll(m);
-            hit[g >> 2] |= 1u << ((g & 3) * 8 + r);
+    for (int g = 0; g < G; ++g) {
+      if (g < cnt) {
+        const uint32_t tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau_s[g]);
+        const int it = __builtin_amdgcn_readfirstlane(desc[g]);
+        const size_t region = ((size_t)it * a.upi + chunk) * NW + wave;
+        u64* dst = a.surv + region * (size_t)(RMAX * 64);
+        if (a.cand_count) {   // freddy.c:971 counts the rows that pass the sentinel guard
+          int accepted = 0;
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) accepted += __popcll(__ballot(bits(g, r) < a.sentinel_bits));
+          if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[it], accepted);
+        }
+        int run = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const bool pass = bits(g, r) <= tau;
+          const u64 mask = __ballot(pass);
+          if (mask != 0ull) {
+            if (pass) dst[run + __popcll(mask & lt)] = ((u64)bits(g, r) << 32) | (u64)(uint32_t)pid[r];
+            run += __popcll(mask);
           }
         }
-      }
-      if (lane == g) my_n = n;
-    }
-  }
-  int my_base = 0;
-  if (lane < G && my_n > 0) my_base = atomicAdd(a.surv_count + desc[lane], my_n);
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    if ((hit[g >> 2] >> ((g & 3) * 8)) & 0xffu) {   // wave-uniform
-      const u64 tau = tau_s[g];
-      const uint32_t thi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tau >> 32));
-      const uint32_t tlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tau);
-      const int it = __builtin_amdgcn_readfirstlane(desc[g]);
-      int run = __builtin_amdgcn_readlane(my_base, g);
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
-        if ((hit[g >> 2] >> ((g & 3) * 8 + r)) & 1u) {
-          const bool pass = passes(g, r, thi, tlo);
-          const u64 mask = __ballot(pass);
-          const int idx = run + __popcll(mask & lt);
-          if (pass && idx < a.cap) a.surv[(size_t)it * a.cap + idx] = ((u64)bits(g, r) << 32) | (u64)(uint32_t)pid[r];
-          run += __popcll(mask);
-        }
+        if (lane == 0) a.surv_count[region] = run;
       }
     }
   }
-  __syncthreads();   // the LDS regions are reused by the next work entry
+  // publish the next entry's descriptor
+  if (wave == 0 && ngid_l >= 0) {
+    const int cntn = n_gc & 0xff, chn = n_gc >> 8;
+    const int b0 = n_b0 + chn * FUSED_UNIT_BLOCKS;
+    int nbn = n_b1 - b0;
+    if (nbn > FUSED_UNIT_BLOCKS) nbn = FUSED_UNIT_BLOCKS;
+    if (lane < G) dsc[nb * 16 + lane] = n_item;
+    if (lane == 0) { dsc[32 + nb * 8 + 1] = cntn; dsc[32 + nb * 8 + 2] = b0; dsc[32 + nb * 8 + 3] = nbn; dsc[32 + nb * 8 + 4] = chn; }
+  }
+  __syncthreads();   // the LDS regions are reused by the next work entry; its descriptor is visible
+  tick(4);   // selection
+  pt[7] += 1;
+  if (ngid_l < 0) break;
+  cur = nb;
   }  // persistent loop
+  if (a.prof && tid == 0) {
+    for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];
+    a.prof[(size_t)blockIdx.x * 8 + 6] = clock64();
+  }
 }
 
 // ---------------------------------------------------------------------------------------
 // merge + replay over survivor buffers (same contract as merge_replay_kernel)
 // ---------------------------------------------------------------------------------------
 struct MergeSurvArgs {
-  const u64* surv;             // [n_active*W][cap]
-  const int32_t* surv_count;   // [n_active*W]
+  const u64* surv;             // [n_active*W][upi][8][512]
+  const int32_t* surv_count;   // [n_active*W][upi][8]
+  const int32_t* item_cell;    // [n_active*W] probed cell of each item (-1: none)
+  const int32_t* blk_off;      // [C+1]
   const int32_t* active;
   const int32_t* round_rows;
   const int32_t* cand_count;
@@ -521,10 +583,13 @@ struct MergeSurvArgs {
   int32_t* next_active;
   int32_t* n_next;
   int32_t* status;
-  int n_active, W, cap, L, k, found_rule, first_round;
+  int n_active, W, upi, L, k, found_rule, first_round;
   float sentinel;
 };
 
+// One wave per query.  Lane <-> survivor region: the query's W items x upi chunks x 8 waves regions
+// mostly hold one or two keys each, so the lanes walk their own regions in lock step and feed the
+// streaming selection one key per lane and step.
 __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
   __shared__ u64 stage[64];
   const int x = blockIdx.x, lane = threadIdx.x;
@@ -533,15 +598,31 @@ __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
 
   WaveSelect<1> sel;
   sel.init(stage, KEY_INF, a.L);
-  for (int i = 0; i < a.W; ++i) {
-    const int it = x * a.W + i;
-    int cnt = a.surv_count[it];
-    cnt = cnt > a.cap ? a.cap : cnt;
-    const u64* src = a.surv + (size_t)it * a.cap;
-    for (int base = 0; base < cnt; base += 64) {
-      const bool valid = base + lane < cnt;
-      const u64 key = valid ? src[base + lane] : KEY_INF;
-      sel.push(key, valid);
+  const int per_item = a.upi * FUSED_NW;
+  const int R = a.W * per_item;
+  for (int jb = 0; jb < R; jb += 64) {
+    const int j = jb + lane;
+    int c = 0;
+    const u64* src = a.surv;
+    if (j < R) {
+      const int i = j / per_item, rem = j - i * per_item;
+      const int item = x * a.W + i;
+      const int cell = a.item_cell[item];
+      if (cell >= 0) {
+        const int nch = (a.blk_off[cell + 1] - a.blk_off[cell] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+        if (rem / FUSED_NW < nch) {
+          const size_t region = (size_t)item * per_item + rem;
+          c = a.surv_count[region];
+          src = a.surv + region * (size_t)(FUSED_RMAX * 64);
+        }
+      }
+    }
+    int maxc = c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+    for (int t = 0; t < maxc; ++t) {
+      const bool valid = t < c;
+      sel.push(valid ? src[t] : KEY_INF, valid);
     }
   }
   sel.finish();
