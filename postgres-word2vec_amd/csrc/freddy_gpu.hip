@@ -21,6 +21,7 @@
 
 #include "kernels.h"
 #include "fused.h"
+#include "fused2.h"
 #include "exact.h"
 #include "join.h"
 
@@ -93,7 +94,7 @@ struct freddy_gpu_index {
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
   int Cpad = 0;
   float* cbT = nullptr;         // [m][S][K]
-  float* cbP = nullptr;         // fused kernel layout [m][SP/4][512][4][2] (NULL unless K <= 1024)
+  float* cbP = nullptr;         // fused kernel layout [m][SP/4][512 slots][4 dims][2 codes] (NULL unless K <= 1024)
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
   uint32_t* packed = nullptr;   // [blocks][M2][64]
@@ -295,7 +296,9 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
         upload(&ix->coarseT, cT.data(), cT.size(), &ix->bytes))
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     if (!rc && ix->K <= FUSED_T * FUSED_E) {
-      // paired layout of the fused kernel: lane t holds codes (t, t+512); 4 dims x 2 codes per 32 bytes
+      // paired layout of the fused kernels: slot t holds codes (t, t+512); 4 dims x 2 codes per 32 bytes.
+      // (Splitting the two 16-byte halves of a slot into separate contiguous arrays measured SLOWER: the
+      // second load of a slot then no longer hits the lines the first one brought in.)
       const int SP = (ix->S + 3) & ~3, SPq = SP / 4;
       std::vector<float> cbP((size_t)ix->m * SPq * FUSED_T * 8, 0.0f);
       for (int p = 0; p < ix->m; ++p)
@@ -595,9 +598,9 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       memcpy(&fa.sentinel_bits, &sentinel, 4);
       const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
       const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(uint32_t) + 64 * sizeof(uint32_t);
-      const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
-      const size_t flds = desc_off + 256 + (size_t)FUSED_G * 12 * 28 * sizeof(float);   // + entry descriptors + padded residuals
-      fa.desc_offset = (uint32_t)desc_off;
+      const size_t res_bytes = (size_t)FUSED_G * 12 * 28 * sizeof(float);   // padded residuals of one entry
+      // FREDDY_GPU_FUSED_KERNEL=1: the symmetric kernel of fused.h; default: the role-specialised one
+      static const bool symmetric = getenv("FREDDY_GPU_FUSED_KERNEL") && getenv("FREDDY_GPU_FUSED_KERNEL")[0] == '1';
       { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
       fa.prof = nullptr;
       static const bool want_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -611,16 +614,35 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_fused_kernel<25, 12, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec_kernel<25, 12, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec_kernel<25, 12, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         fattr = true;
       }
       // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
       const unsigned n_persist = (unsigned)std::min<size_t>(max_groups, (size_t)ix->n_cus);
-      timed_launch(ix, s, "ivf_fused", [&] {
-        if (K == FUSED_T * FUSED_E)
-          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
-        else
-          hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
-      });
+      if (symmetric) {
+        const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
+        const size_t flds = desc_off + 256 + res_bytes;   // + entry descriptors + padded residuals
+        fa.desc_offset = (uint32_t)desc_off;
+        timed_launch(ix, s, "ivf_fused", [&] {
+          if (K == FUSED_T * FUSED_E)
+            hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
+          else
+            hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
+        });
+      } else {
+        const size_t desc_off = (slab_bytes + 15) & ~(size_t)15;
+        const size_t flds = desc_off + 4096 + 64 + 256 + res_bytes;   // + column minima, thresholds, descriptors, residuals
+        fa.desc_offset = (uint32_t)desc_off;
+        timed_launch(ix, s, "ivf_fused", [&] {
+          if (K == 1024)
+            hipLaunchKernelGGL((ivf_spec_kernel<25, 12, true>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
+          else
+            hipLaunchKernelGGL((ivf_spec_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
+        });
+      }
       HIP_TRY(hipGetLastError());
       if (fa.prof) {   // debugging aid: per-phase shader-clock sums of every persistent workgroup
         std::vector<long long> h(8 * (size_t)n_persist);
@@ -633,8 +655,13 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
           mx_end = std::max(mx_end, h[b * 8 + 6]);
           mn_end = mn_end < 0 ? h[b * 8 + 6] : std::min(mn_end, h[b * 8 + 6]);
         }
-        fprintf(stderr, "[fused prof] wgs=%u entries=%.0f  cycles/entry: stage=%.0f slab0=%.0f loop=%.0f lastgather=%.0f select=%.0f | exit spread=%lld cycles\n",
-                n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[4] / ent, mx_end - mn_end);
+        if (symmetric)
+          fprintf(stderr, "[fused prof] wgs=%u entries=%.0f  cycles/entry: stage=%.0f slab0=%.0f loop=%.0f lastgather=%.0f select=%.0f\n",
+                  n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[4] / ent);
+        else
+          fprintf(stderr, "[spec prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f\n",
+                  n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent);
+        (void)mx_end; (void)mn_end;
       }
       MergeSurvArgs ms;
       ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = active; ms.round_rows = pa.round_rows;

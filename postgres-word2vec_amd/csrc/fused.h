@@ -142,7 +142,7 @@ struct FusedArgs {
   const int32_t* group_cnt;
   const int32_t* n_groups;     // [1] number of (group, chunk) work entries
   int32_t* work_counter;       // [1] zeroed before the launch
-  const float* cbP;            // [m][SP/4][512][4 dims][2 codes] (see load_cb)
+  const float* cbP;            // [m][SP/4][512 slots][4 dims][2 codes] (see load_cb)
   const int32_t* blk_off;      // [C+1]
   const uint32_t* packed;      // [blocks][M2][64]
   const int32_t* pos;          // [blocks*64]
@@ -199,9 +199,9 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   v2f cb[S];   // .x: code tid, .y: code tid + T  (packed so the two chains run as v_pk_* ops)
   static_assert(E == 2, "two codes per lane");
-  // cbP layout [m][SP/4][T][4 dims][2 codes]: this lane's codes (tid, tid+T) interleaved, so two
-  // 16-byte loads bring four dimensions of both codes already in (x, y) pair order (codes >= K
-  // are zero-padded by the host).  14 wide loads per position instead of 50 dword loads.
+  // cbP layout [m][SP/4][T slots][4 dims][2 codes]: slot tid = codes (tid, tid+T) interleaved, so two
+  // 16-byte loads bring four dimensions of both codes already in (x, y) pair order (codes >= K are
+  // zero-padded by the host).  14 wide loads per position instead of 50 dword loads.
   auto load_cb = [&](int p) {
     constexpr int SPq = ((S + 3) & ~3) / 4;
     // explicitly GLOBAL pointers: after the asm above the compiler only knows a generic one and

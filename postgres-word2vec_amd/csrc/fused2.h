@@ -1,0 +1,414 @@
+// fused2.h -- IVFADC LUT build + ADC scan + selection, ROLE-SPECIALISED workgroups (gfx950).
+//
+// Same work decomposition, LDS slab layout, numerics and outputs as fused.h (ivf_fused_kernel): a
+// work entry = up to 16 (query, cell) items of ONE cell x one 4096-row chunk of its list; per
+// position the 16 x K slab of LUT values is built in LDS and immediately added to the rows' ADC
+// sums, positions in order (index_utils.c:1126-1133), every slab value the sequential
+// squareDistance over the sub-vector (index_utils.c:445-455, :500-508).
+//
+// What changed is who does what.  In ivf_fused_kernel all 8 waves alternate between building
+// (VALU-bound) and gathering/selecting (LDS- and latency-bound); the in-kernel profile showed the
+// phases simply adding up (about half of an entry's time was not slab arithmetic).  Here a
+// workgroup has 12 waves, three per SIMD:
+//   waves 0-3   BUILDERS   one per SIMD; lane <-> 4 codes (two packed pairs), 100 codebook VGPRs;
+//                          two items at a time = FOUR independent packed chains, which is what one
+//                          wave needs to keep the packed-fp32 pipe full on its own
+//   waves 4-11  GATHERERS  lane <-> 8 rows x 16 items ADC sums (128 VGPRs), gather slab(p) while the
+//                          builders write slab(p+1); afterwards threshold + survivor selection
+// Builders never wait for gathers: per position one LDS-only barrier; while the gatherers run the
+// selection of entry e the builders already stage the residuals and build slab 0 of entry e+1 (the
+// slab buffers are free then).  The next entry's descriptor is fetched by builder wave 0 in the
+// shadow of the main loop.
+//
+// Barrier schedule per entry (every wave executes exactly these, in this order):
+//   P(0..M-2)  B: build slab(p+1) -> buf (p+1)&1          G: gather slab(p) <- buf p&1
+//   P(M-1)     B: stage residuals of the next entry        G: gather slab(M-1), column minima
+//   S1         B: next slab(0), first half of the items    G: thresholds
+//   S2         B: next slab(0), second half                G: survivors -> memory, reset
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fused.h"
+
+namespace freddy {
+
+static constexpr int SPEC_T = 768;
+static constexpr int SPEC_NB = 4;    // builder waves
+static constexpr int SPEC_NG = 8;    // gatherer waves (== FUSED_NW: survivor regions are per gatherer wave)
+static_assert(SPEC_NG == FUSED_NW, "survivor region layout");
+
+template <int S, int M, bool FULLK>
+__global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
+  constexpr int G = FUSED_G, RMAX = FUSED_RMAX, NG = SPEC_NG;
+  constexpr int M2 = M / 2;
+  constexpr int SP = (S + 3) & ~3;
+  constexpr int SPq = SP / 4;
+  constexpr int ROW4 = M * SP / 4;   // float4 per item of the residual table
+  static_assert(M % 2 == 0 && G == 16, "layout");
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* slab = reinterpret_cast<float*>(smem);                                   // [2][K][G]
+  uint32_t* colmin = reinterpret_cast<uint32_t*>(smem + a.desc_offset);           // [G][64]
+  uint32_t* tau_s = colmin + G * 64;                                              // [G]
+  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // see fused.h
+  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 4096 + 64 + 256);  // [G][M][SP]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool builder = wave < SPEC_NB;
+  const int K = a.K;
+  const int n_work = a.n_groups[0];
+  auto slab_at = [&](int code, int g) { return code * G + ((((g >> 2) ^ ((code >> 1) & 3))) << 2) + (g & 3); };
+
+  // ---- first entry: fetched serially by everybody ----
+  int cur = 0;
+  if (tid == 0) dsc[32] = atomicAdd(a.work_counter, 1);
+  for (int i = tid; i < G * 64; i += SPEC_T) colmin[i] = 0xffffffffu;
+  __syncthreads();
+  {
+    const int gid0 = dsc[32];
+    if (gid0 >= n_work) return;
+    if (wave == 0) {
+      const int cell = a.group_cell[gid0], first = a.group_first[gid0], gc = a.group_cnt[gid0];
+      const int cnt0 = gc & 0xff, chunk0 = gc >> 8;
+      const int b0 = a.blk_off[cell] + chunk0 * FUSED_UNIT_BLOCKS;
+      int nb0 = a.blk_off[cell + 1] - b0;
+      if (nb0 > FUSED_UNIT_BLOCKS) nb0 = FUSED_UNIT_BLOCKS;
+      if (lane < G) dsc[lane] = (lane < cnt0) ? a.sorted_item[first + lane] : -1;
+      if (lane == 0) { dsc[33] = cnt0; dsc[34] = b0; dsc[35] = nb0; dsc[36] = chunk0; }
+    }
+  }
+  __syncthreads();
+  {
+    const int cnt0 = dsc[33];
+    for (int i = tid; i < cnt0 * ROW4; i += SPEC_T) {
+      const int g = i / ROW4, o = i - g * ROW4;
+      reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)dsc[g] * ROW4 + o];
+    }
+  }
+  __syncthreads();
+
+  if (builder) {
+    // =====================================================================================
+    // BUILDERS
+    // =====================================================================================
+    const int b = tid;   // 0..255: codes b, b+512 (pair A) and b+256, b+768 (pair B)
+    v2f cbA[S], cbB[S];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const f4 __attribute__((address_space(1))) * gptr4;
+    typedef const char __attribute__((address_space(1))) * gptrc;
+    // cbP layout [m][SP/4][512 slots][4 dims][2 codes]: slot i holds codes (i, i+512) interleaved
+    auto load_cb_quad = [&](int p, int jb) {   // dimensions 4*jb .. 4*jb+3 of position p, both code pairs
+      const gptrc base = (gptrc)(uintptr_t)a.cbP + (size_t)(uint32_t)p * (uint32_t)(SPq * 512 * 32);
+      uint32_t voff = (uint32_t)b * 32u;
+      asm volatile("" : "+v"(voff));   // opaque: keeps hoisted 64-bit addresses out of the register budget
+      const gptrc bj = base + (uint32_t)jb * (uint32_t)(512 * 32);
+      const f4 alo = *(gptr4)(bj + voff), ahi = *(gptr4)(bj + voff + 16u);
+      const f4 blo = *(gptr4)(bj + voff + 256u * 32u), bhi = *(gptr4)(bj + voff + 256u * 32u + 16u);
+      if (jb * 4 + 0 < S) { cbA[jb * 4 + 0] = v2f{alo.x, alo.y}; cbB[jb * 4 + 0] = v2f{blo.x, blo.y}; }
+      if (jb * 4 + 1 < S) { cbA[jb * 4 + 1] = v2f{alo.z, alo.w}; cbB[jb * 4 + 1] = v2f{blo.z, blo.w}; }
+      if (jb * 4 + 2 < S) { cbA[jb * 4 + 2] = v2f{ahi.x, ahi.y}; cbB[jb * 4 + 2] = v2f{bhi.x, bhi.y}; }
+      if (jb * 4 + 3 < S) { cbA[jb * 4 + 3] = v2f{ahi.z, ahi.w}; cbB[jb * 4 + 3] = v2f{bhi.z, bhi.w}; }
+    };
+    auto load_cb = [&](int p) {
+#pragma unroll
+      for (int jb = 0; jb < SPq; ++jb) load_cb_quad(p, jb);
+    };
+    // slab(p) of the items [g_lo, g_hi) (g_lo even), two items per step = four accumulators:
+    // (pair A, item g), (pair B, item g), (pair A, item g+1), (pair B, item g+1).  Only the adds of a
+    // squareDistance are a loop-carried chain; the subtraction and the square of a later dimension do
+    // not depend on it.  So the three stages are software-pipelined over the dimensions: one block of
+    // twelve packed instructions does  s += q (dimension j),  q = d*d (j+1),  d = r - c (j+2)  for the
+    // four accumulators.  Every operand was produced eight or more issues earlier, which is what lets
+    // ONE wave per SIMD run the packed-fp32 pipe at its issue rate.  The arithmetic per accumulator is
+    // unchanged: sub, mul, add, each rounded on its own, dimensions in order (index_utils.c:500-508);
+    // a + (-b) with the neg modifier is the IEEE subtraction.
+    auto build_slab = [&](int p, float* dst, int g_lo, int g_hi, int cnt) {
+#pragma unroll 1
+      for (int g = g_lo; g < g_hi; g += 2) {
+        const float4* R0 = reinterpret_cast<const float4*>(res + ((size_t)g * M + p) * SP);
+        const float4* R1 = reinterpret_cast<const float4*>(res + ((size_t)(g + 1 < cnt ? g + 1 : g) * M + p) * SP);
+        v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f}, s2 = {0.0f, 0.0f}, s3 = {0.0f, 0.0f};
+        v2f d0, d1, d2, d3, q0, q1, q2, q3;
+        float4 rr0[SPq], rr1[SPq];   // (only two or three quads are live at a time)
+        rr0[0] = R0[0]; rr1[0] = R1[0];
+        if (SPq > 1) { rr0[1] = R0[1]; rr1[1] = R1[1]; }
+#pragma unroll
+        for (int step = 0; step < S + 2; ++step) {
+          if (step >= 2) {   // s += q          (dimension step-2)
+            asm volatile(
+                "v_pk_add_f32 %0, %0, %4\n\t"
+                "v_pk_add_f32 %1, %1, %5\n\t"
+                "v_pk_add_f32 %2, %2, %6\n\t"
+                "v_pk_add_f32 %3, %3, %7"
+                : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)
+                : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
+          }
+          if (step >= 1 && step <= S) {   // q = d * d      (dimension step-1)
+            asm volatile(
+                "v_pk_mul_f32 %0, %4, %4\n\t"
+                "v_pk_mul_f32 %1, %5, %5\n\t"
+                "v_pk_mul_f32 %2, %6, %6\n\t"
+                "v_pk_mul_f32 %3, %7, %7"
+                : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                : "v"(d0), "v"(d1), "v"(d2), "v"(d3));
+          }
+          if (step < S) {   // d = r - c      (dimension step)
+            const int j = step, jb = j >> 2, u = j & 3;
+            if (u == 0 && jb + 2 < SPq) { rr0[jb + 2] = R0[jb + 2]; rr1[jb + 2] = R1[jb + 2]; }
+            const v2f a0 = (u < 2) ? v2f{rr0[jb].x, rr0[jb].y} : v2f{rr0[jb].z, rr0[jb].w};
+            const v2f a1 = (u < 2) ? v2f{rr1[jb].x, rr1[jb].y} : v2f{rr1[jb].z, rr1[jb].w};
+            if ((u & 1) == 0) {
+              asm volatile(
+                  "v_pk_add_f32 %0, %4, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %1, %4, %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %2, %5, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %3, %5, %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
+                  : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                  : "v"(a0), "v"(a1), "v"(cbA[j]), "v"(cbB[j]));
+            } else {
+              asm volatile(
+                  "v_pk_add_f32 %0, %4, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %1, %4, %7 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %2, %5, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                  "v_pk_add_f32 %3, %5, %7 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
+                  : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
+                  : "v"(a0), "v"(a1), "v"(cbA[j]), "v"(cbB[j]));
+            }
+          }
+        }
+        // slab layout [code][16 items], 16-byte item chunks XOR-swizzled by the code row: the pair
+        // (g, g+1) of one code is one aligned 8-byte store (an unused odd slot receives a value
+        // nobody reads)
+        if (FULLK || b < K) *reinterpret_cast<v2f*>(dst + slab_at(b, g)) = v2f{s0.x, s2.x};
+        if (FULLK || b + 512 < K) *reinterpret_cast<v2f*>(dst + slab_at(b + 512, g)) = v2f{s0.y, s2.y};
+        if (FULLK || b + 256 < K) *reinterpret_cast<v2f*>(dst + slab_at(b + 256, g)) = v2f{s1.x, s3.x};
+        if (FULLK || b + 768 < K) *reinterpret_cast<v2f*>(dst + slab_at(b + 768, g)) = v2f{s1.y, s3.y};
+      }
+    };
+
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
+    if (a.prof) pc = clock64();
+    // slab(0) of the first entry, unoverlapped
+    int cnt = __builtin_amdgcn_readfirstlane(dsc[33]);
+    load_cb(0);
+    build_slab(0, slab, 0, cnt, cnt);
+    load_cb(1);
+    lds_barrier();
+    for (;;) {
+      int ngid = 0;       // wave 0: next work index (requested now, used from P(2) on)
+      int n_cell = 0, n_first = 0, n_gc = 0, n_item = -1, n_b0 = 0, n_b1 = 0;
+      const int nb = cur ^ 1;
+      if (tid == 0) ngid = atomicAdd(a.work_counter, 1);
+      for (int p = 0; p + 1 < M; ++p) {
+        float* nxt = slab + (size_t)((p + 1) & 1) * G * K;
+        tick(5);
+        if (!(a.ablate & 1)) build_slab(p + 1, nxt, 0, cnt, cnt);
+        tick(0);   // builds of the main loop
+        __builtin_amdgcn_sched_barrier(0);
+        // (issued in one go: a builder wave blocks while the 28 wide loads enter the memory pipe, ~2.9k
+        // cycles per position measured; spreading them over the last item pair's pass only moved the stall)
+        load_cb(p + 2 < M ? p + 2 : 0);   // position 0: the next entry's
+        // next entry's descriptor, one dependent global round trip per position (wave 0 only)
+        if (wave == 0) {
+          if (p == 1) {
+            ngid = __builtin_amdgcn_readfirstlane(ngid);
+            if (ngid < n_work) {
+              n_cell = a.group_cell[ngid];
+              n_first = a.group_first[ngid];
+              n_gc = a.group_cnt[ngid];
+            }
+          } else if (p == 3) {
+            if (ngid < n_work) {
+              if (lane < (n_gc & 0xff)) n_item = a.sorted_item[n_first + lane];
+              n_b0 = a.blk_off[n_cell];
+              n_b1 = a.blk_off[n_cell + 1];
+            }
+          } else if (p == 5) {
+            if (ngid < n_work) {
+              const int cntn = n_gc & 0xff, chn = n_gc >> 8;
+              const int b0 = n_b0 + chn * FUSED_UNIT_BLOCKS;
+              int nbn = n_b1 - b0;
+              if (nbn > FUSED_UNIT_BLOCKS) nbn = FUSED_UNIT_BLOCKS;
+              if (lane < G) dsc[nb * 16 + lane] = n_item;
+              if (lane == 0) {
+                dsc[32 + nb * 8 + 0] = ngid; dsc[32 + nb * 8 + 1] = cntn; dsc[32 + nb * 8 + 2] = b0;
+                dsc[32 + nb * 8 + 3] = nbn; dsc[32 + nb * 8 + 4] = chn;
+              }
+            } else if (lane == 0) {
+              dsc[32 + nb * 8 + 0] = -1;
+            }
+          }
+        }
+        tick(5);
+        lds_barrier();
+        tick(1);   // waiting at the main loop's barriers
+      }
+      // P(M-1): the residual table is free (slab(M-1) was built in P(M-2)): stage the next entry's
+      const int next_gid = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
+      const int next_cnt = next_gid >= 0 ? __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8 + 1]) : 0;
+      for (int i = tid; i < next_cnt * ROW4; i += SPEC_NB * 64) {
+        const int g = i / ROW4, o = i - g * ROW4;
+        reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)dsc[nb * 16 + g] * ROW4 + o];
+      }
+      lds_barrier();
+      tick(2);   // P(M-1)
+      // S1 / S2: slab(0) of the next entry in two halves (buffer 0 is free: the gatherers are selecting)
+      const int half = ((next_cnt + 3) >> 2) << 1;   // even split point
+      if (!(a.ablate & 1)) build_slab(0, slab, 0, half < next_cnt ? half : next_cnt, next_cnt);
+      lds_barrier();
+      if (!(a.ablate & 1)) build_slab(0, slab, half, next_cnt, next_cnt);
+      load_cb(1);
+      lds_barrier();
+      tick(3);   // S1 + S2
+      pt[7] += 1;
+      if (next_gid < 0) break;
+      cur = nb;
+      cnt = next_cnt;
+    }
+    if (a.prof && tid == 0) {
+      for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];
+    }
+  } else {
+    // =====================================================================================
+    // GATHERERS
+    // =====================================================================================
+    const int gw = wave - SPEC_NB;   // 0..7
+    v2f acc[G / 2][RMAX];            // ADC sums: acc[h][r] = items (2h, 2h+1) of this lane's row r
+    uint32_t cw[RMAX];
+    auto bits = [&](int g, int r) { return __float_as_uint((g & 1) ? acc[g >> 1][r].y : acc[g >> 1][r].x); };
+    lds_barrier();   // (pairs with the builders' barrier after the first slab)
+    for (;;) {
+      const int32_t* desc = dsc + cur * 16;
+      const int cnt = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 1]);
+      const int blk0 = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 2]);
+      const int nblk = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 3]);
+      const int chunk = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 4]);
+      const int nb = cur ^ 1;
+      // rows past the end of the chunk re-read its last block (always in bounds); masked at the end
+      auto row_block = [&](int r) {
+        const int bl = r * NG + gw;
+        return (uint32_t)(blk0 + (bl < nblk - 1 ? bl : nblk - 1));
+      };
+      auto load_codes = [&](int pair) {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) cw[r] = a.packed[(row_block(r) * M2 + (uint32_t)pair) * 64u + (uint32_t)lane];
+      };
+      // one row at a time: 4 ds_read_b128 (a row's 16 item values, chunk order swizzled by the code)
+      auto gather = [&](int p, const float* curs) {
+        const int sh = (p & 1) * 16;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const int code = (int)((cw[r] >> sh) & 0xffffu);
+          const int sw = (code >> 1) & 3;
+          const float* row = curs + code * G;
+          float4 v[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(row + ((q ^ sw) << 2));
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[q * 2 + 0][r] = acc[q * 2 + 0][r] + v2f{v[q].x, v[q].y};
+            acc[q * 2 + 1][r] = acc[q * 2 + 1][r] + v2f{v[q].z, v[q].w};
+          }
+        }
+      };
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h)
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) acc[h][r] = v2f{0.0f, 0.0f};
+      load_codes(0);
+      for (int p = 0; p + 1 < M; ++p) {
+        if (!(a.ablate & 2)) gather(p, slab + (size_t)(p & 1) * G * K);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p & 1) load_codes((p + 1) >> 1);
+        lds_barrier();
+      }
+      // P(M-1)
+      if (!(a.ablate & 2)) gather(M - 1, slab + (size_t)((M - 1) & 1) * G * K);
+      int32_t pid[RMAX];
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
+      // Selection on the distance bits (>= +0, so they order like the floats); see fused.h.  Column
+      // minima (column = lane index over the 8 gatherer waves x 8 row slots) via LDS atomics.
+      {
+        bool dead[RMAX];
+        bool some = false;
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { dead[r] = !(((r * NG + gw) < nblk) && pid[r] >= 0); some |= dead[r]; }
+        if (__ballot(some) != 0ull) {   // only the last chunk of a list has padding rows: park them above everything
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+            for (int h = 0; h < G / 2; ++h)
+              if (dead[r]) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+        }
+      }
+      if (!(a.ablate & 4)) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g < cnt) {
+            uint32_t best = bits(g, 0);
+#pragma unroll
+            for (int r = 1; r < RMAX; ++r) best = min(best, bits(g, r));
+            atomicMin(colmin + g * 64 + lane, best);
+          }
+        }
+      }
+      lds_barrier();
+      // S1: thresholds, two items per gatherer wave, the two sorts interleaved
+      if (!(a.ablate & 4)) {
+        static_assert(G == 2 * NG, "two items per gatherer wave");
+        const int g0 = gw, g1 = gw + NG;
+        uint32_t c0 = colmin[g0 * 64 + lane], c1 = colmin[g1 * 64 + lane];
+        wave_sort32_x2(c0, c1);
+        const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
+        // survivors are {bits <= tau and bits < sentinel}: fold both into one bound
+        if (lane == 0) {
+          tau_s[g0] = min(t0, a.sentinel_bits - 1u);
+          tau_s[g1] = min(t1, a.sentinel_bits - 1u);
+        }
+        colmin[g0 * 64 + lane] = 0xffffffffu;   // ready for the next entry
+        colmin[g1 * 64 + lane] = 0xffffffffu;
+      }
+      lds_barrier();
+      // S2: survivors -> this wave's region of each item's buffer
+      if (!(a.ablate & 4)) {
+        const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g < cnt) {
+            const uint32_t tau = (uint32_t)__builtin_amdgcn_readfirstlane((int)tau_s[g]);
+            const int it = __builtin_amdgcn_readfirstlane(desc[g]);
+            const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
+            u64* dst = a.surv + region * (size_t)(RMAX * 64);
+            if (a.cand_count) {   // freddy.c:971 counts the rows that pass the sentinel guard
+              int accepted = 0;
+#pragma unroll
+              for (int r = 0; r < RMAX; ++r) accepted += __popcll(__ballot(bits(g, r) < a.sentinel_bits));
+              if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[it], accepted);
+            }
+            int run = 0;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+              const bool pass = bits(g, r) <= tau;
+              const u64 mask = __ballot(pass);
+              if (mask != 0ull) {
+                if (pass) dst[run + __popcll(mask & lt)] = ((u64)bits(g, r) << 32) | (u64)(uint32_t)pid[r];
+                run += __popcll(mask);
+              }
+            }
+            if (lane == 0) a.surv_count[region] = run;
+          }
+        }
+      }
+      const int next_gid = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
+      lds_barrier();
+      if (next_gid < 0) break;
+      cur = nb;
+    }
+  }
+}
+
+}  // namespace freddy
