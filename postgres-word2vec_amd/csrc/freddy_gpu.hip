@@ -509,8 +509,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   if (fused) {
-    // cell_count[C] + cell_fill[C] + cell_start[C]; group table: 3 arrays of (items/G + C) entries
-    if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * items) ||
+    // cell_count[C]; cell_items[C][Q]; group table: 2 x 3 arrays of (items/G + C) * upi entries
+    if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
         ix->w_groups.ensure(sizeof(int32_t) * 6 * (items / FUSED_G + (size_t)C + 1) * upi) ||
         ix->w_surv.ensure(sizeof(u64) * items * upi * FUSED_NW * FUSED_RMAX * 64) ||
         ix->w_surv_cnt.ensure(sizeof(int32_t) * items * upi * FUSED_NW))
@@ -548,6 +548,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     pa.round_rows = ix->w_rows.as<int32_t>();
     pa.n_active = n_active; pa.Cpad = Cpad; pa.C = C; pa.W = W; pa.used_words = used_words;
     pa.cell_count = fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
+    pa.cell_items = fused ? ix->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = n_active;
     if (fused) HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
     {
       const int PV = pick_V(2 * W);
@@ -562,32 +563,31 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         }
       });
     }
-    timed_launch(ix, s, "residual", [&] {
-      hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
-                         ix->w_resid.as<float>(), d, ix->S, fused ? ((ix->S + 3) & ~3) : ix->S);
-    });
-    HIP_TRY(hipGetLastError());
+    // FREDDY_GPU_FUSED_KERNEL=1: the symmetric kernel of fused.h; default: the role-specialised one, which
+    // forms the residuals itself
+    static const bool symmetric = getenv("FREDDY_GPU_FUSED_KERNEL") && getenv("FREDDY_GPU_FUSED_KERNEL")[0] == '1';
+    if (!fused || symmetric) {
+      timed_launch(ix, s, "residual", [&] {
+        hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
+                           ix->w_resid.as<float>(), d, ix->S, fused ? ((ix->S + 3) & ~3) : ix->S);
+      });
+      HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
     if (fused) {
       const size_t max_groups = ((size_t)n_items / FUSED_G + (size_t)C + 1) * upi;   // (group, chunk) work entries
       int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
-      int32_t* cell_fill = cell_count + C;
-      int32_t* cell_start = cell_count + 2 * (size_t)C;
       int32_t* group_cell = ix->w_groups.as<int32_t>();
       int32_t* group_first = group_cell + max_groups;
       int32_t* group_cnt = group_first + max_groups;
       int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
       timed_launch(ix, s, "group_items", [&] {
-        hipLaunchKernelGGL(group_table_kernel, dim3(1), dim3(64), 0, s, cell_count, C, ix->blk_off, cell_start, group_cell,
-                           group_first, group_cnt, n_groups);
-        hipLaunchKernelGGL(bucket_items_kernel, dim3((n_items + 255) / 256), dim3(256), 0, s, pa.item_cell, n_items,
-                           cell_start, cell_fill, ix->w_sorted.as<int32_t>());
-        hipLaunchKernelGGL(sort_work_kernel, dim3(1), dim3(256), 0, s, n_groups, ix->blk_off, group_cell, group_first, group_cnt,
-                           group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups);
+        hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(256), 0, s, cell_count, C, n_active, ix->blk_off, group_cell, group_first,
+                           group_cnt, group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups);
       });
       HIP_TRY(hipGetLastError());
       FusedArgs fa;
-      fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query;
+      fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query; fa.queries = d_q; fa.coarse = ix->coarse;
       fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cnt + max_groups;
       fa.group_first = group_cnt + 2 * max_groups; fa.group_cnt = group_cnt + 3 * max_groups; fa.n_groups = n_groups; fa.work_counter = ix->w_cnt.as<int32_t>() + 2;
       HIP_TRY(hipMemsetAsync(ix->w_cnt.as<int32_t>() + 2, 0, sizeof(int32_t), s));
@@ -599,8 +599,6 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
       const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(uint32_t) + 64 * sizeof(uint32_t);
       const size_t res_bytes = (size_t)FUSED_G * 12 * 28 * sizeof(float);   // padded residuals of one entry
-      // FREDDY_GPU_FUSED_KERNEL=1: the symmetric kernel of fused.h; default: the role-specialised one
-      static const bool symmetric = getenv("FREDDY_GPU_FUSED_KERNEL") && getenv("FREDDY_GPU_FUSED_KERNEL")[0] == '1';
       { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
       fa.prof = nullptr;
       static const bool want_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -634,7 +632,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         });
       } else {
         const size_t desc_off = (slab_bytes + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + 256 + res_bytes;   // + column minima, thresholds, descriptors, residuals
+        const size_t flds = desc_off + 4096 + 64 + 512 + res_bytes;   // + column minima, thresholds, descriptors, residuals
         fa.desc_offset = (uint32_t)desc_off;
         timed_launch(ix, s, "ivf_fused", [&] {
           if (K == 1024)

@@ -133,8 +133,80 @@ __global__ __launch_bounds__(256) void bucket_items_kernel(const int32_t* __rest
   sorted_item[cell_start[c] + atomicAdd(cell_fill + c, 1)] = it;
 }
 
+// group_table + sort_work in ONE launch for the bucketed form (the probe plan has already written
+// each cell's items to cell_items[cell][0..count)): one workgroup of 256 threads turns the per-cell
+// counts into work entries (group of <= FUSED_G items of a cell x 4096-row chunk; first = index into
+// cell_items) and orders them largest first.
+__global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap,
+                                                        const int32_t* __restrict__ blk_off,
+                                                        int32_t* __restrict__ tmp_cell, int32_t* __restrict__ tmp_first,
+                                                        int32_t* __restrict__ tmp_cnt, int32_t* __restrict__ out_cell,
+                                                        int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
+                                                        int32_t* __restrict__ n_groups) {
+  constexpr int NB = FUSED_G * 4 + 4;   // class = (items, quarter of a full chunk), descending
+  __shared__ int scan[256];
+  __shared__ int hist[NB];
+  __shared__ int start[NB];
+  const int tid = threadIdx.x;
+  const int per = (C + 255) / 256;
+  const int c0 = tid * per, c1 = (c0 + per < C) ? c0 + per : C;
+  int groups = 0;
+  for (int c = c0; c < c1; ++c) {
+    const int n = cell_count[c];
+    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+    groups += ((n + FUSED_G - 1) / FUSED_G) * chunks;
+  }
+  scan[tid] = groups;
+  for (int i = tid; i < NB; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
+    const int v = (tid >= o) ? scan[tid - o] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  const int total = scan[255];
+  if (tid == 0) n_groups[0] = total;
+  int gr_off = scan[tid] - groups;
+  auto klass = [&](int cnt, int chunk, int c) {
+    int nb = blk_off[c + 1] - blk_off[c] - chunk * FUSED_UNIT_BLOCKS;
+    nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
+    const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
+    return (FUSED_G - cnt) * 4 + (3 - rq);                     // small class index = big entry
+  };
+  for (int c = c0; c < c1; ++c) {
+    const int n = cell_count[c];
+    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+    for (int f = 0; f < n; f += FUSED_G) {
+      const int cnt = (n - f < FUSED_G) ? n - f : FUSED_G;
+      for (int ch = 0; ch < chunks; ++ch) {
+        tmp_cell[gr_off] = c;
+        tmp_first[gr_off] = c * cell_cap + f;
+        tmp_cnt[gr_off] = cnt | (ch << 8);
+        atomicAdd(&hist[klass(cnt, ch, c)], 1);
+        ++gr_off;
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int b = 0; b < NB; ++b) { start[b] = acc; acc += hist[b]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < total; e += 256) {
+    const int cnt = tmp_cnt[e] & 0xff, chunk = tmp_cnt[e] >> 8, c = tmp_cell[e];
+    const int slot = atomicAdd(&start[klass(cnt, chunk, c)], 1);
+    out_cell[slot] = c;
+    out_first[slot] = tmp_first[e];
+    out_cnt[slot] = tmp_cnt[e];
+  }
+}
+
 struct FusedArgs {
-  const float* resid;          // [items][m][SP] residuals, each position padded to SP floats (freddy.c:296-303)
+  const float* resid;          // [items][m][SP] residuals, each position padded to SP floats (freddy.c:296-303); symmetric kernel
+  const float* queries;        // [Q][d]   the role-specialised kernel forms r = q - coarse[cell] itself while staging
+  const float* coarse;         // [C][d]
   const int32_t* item_query;   // [items]
   const int32_t* sorted_item;  // items in cell order
   const int32_t* group_cell;   // [groups]

@@ -44,15 +44,14 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
   constexpr int M2 = M / 2;
   constexpr int SP = (S + 3) & ~3;
   constexpr int SPq = SP / 4;
-  constexpr int ROW4 = M * SP / 4;   // float4 per item of the residual table
   static_assert(M % 2 == 0 && G == 16, "layout");
   typedef float v2f __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* slab = reinterpret_cast<float*>(smem);                                   // [2][K][G]
   uint32_t* colmin = reinterpret_cast<uint32_t*>(smem + a.desc_offset);           // [G][64]
   uint32_t* tau_s = colmin + G * 64;                                              // [G]
-  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // see fused.h
-  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 4096 + 64 + 256);  // [G][M][SP]
+  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // see fused.h; + [64 + b*16 + g] query of slot g, [32 + b*8 + 5] cell
+  float* res = reinterpret_cast<float*>(smem + a.desc_offset + 4096 + 64 + 512);  // [G][M][SP]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,6 +59,29 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
   const int K = a.K;
   const int n_work = a.n_groups[0];
   auto slab_at = [&](int code, int g) { return code * G + ((((g >> 2) ^ ((code >> 1) & 3))) << 2) + (g & 3); };
+
+  // Residuals r = q - coarse[cell] (freddy.c:296-303: one binary32 subtraction per dimension) are formed
+  // while staging: thread <-> (position, dimension) slot of the padded [M][SP] row, the cell's centroid
+  // value is loaded once and serves all items of the entry.  nthr threads take part (t = 0..nthr-1).
+  auto stage_residuals = [&](int b, int cnt, int t, int nthr, int p_lo, int p_hi) {   // positions [p_lo, p_hi)
+    const int cell = dsc[32 + b * 8 + 5];
+    const float* crow = a.coarse + (size_t)cell * a.d;
+    for (int o = p_lo * SP + t; o < p_hi * SP; o += nthr) {
+      const int p = o / SP, j = o - p * SP;
+      if (j < S) {
+        const float cv = crow[p * S + j];
+        for (int g = 0; g < cnt; ++g) res[(size_t)g * (M * SP) + o] = a.queries[(size_t)dsc[64 + b * 16 + g] * a.d + p * S + j] - cv;
+      } else {
+        for (int g = 0; g < cnt; ++g) res[(size_t)g * (M * SP) + o] = 0.0f;
+      }
+    }
+  };
+  // The NEXT entry's residual rows are staged by the gatherers, which have time to spare inside the
+  // main loop: the rows of position q are dead as soon as slab(q) of the current entry is built (in
+  // P(q-1)), so from P(STAGE_P0) on -- the next descriptor is complete by then -- the gatherers fill
+  // positions <= p during P(p); only the last position is left to the builders in P(M-1).
+  constexpr int STAGE_P0 = 8;
+  static_assert(M - 2 >= STAGE_P0, "descriptor prefetch schedule assumes M >= 10");
 
   // ---- first entry: fetched serially by everybody ----
   int cur = 0;
@@ -75,18 +97,16 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
       const int b0 = a.blk_off[cell] + chunk0 * FUSED_UNIT_BLOCKS;
       int nb0 = a.blk_off[cell + 1] - b0;
       if (nb0 > FUSED_UNIT_BLOCKS) nb0 = FUSED_UNIT_BLOCKS;
-      if (lane < G) dsc[lane] = (lane < cnt0) ? a.sorted_item[first + lane] : -1;
-      if (lane == 0) { dsc[33] = cnt0; dsc[34] = b0; dsc[35] = nb0; dsc[36] = chunk0; }
+      if (lane < G) {
+        const int it = (lane < cnt0) ? a.sorted_item[first + lane] : -1;
+        dsc[lane] = it;
+        dsc[64 + lane] = it >= 0 ? a.item_query[it] : 0;
+      }
+      if (lane == 0) { dsc[33] = cnt0; dsc[34] = b0; dsc[35] = nb0; dsc[36] = chunk0; dsc[37] = cell; }
     }
   }
   __syncthreads();
-  {
-    const int cnt0 = dsc[33];
-    for (int i = tid; i < cnt0 * ROW4; i += SPEC_T) {
-      const int g = i / ROW4, o = i - g * ROW4;
-      reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)dsc[g] * ROW4 + o];
-    }
-  }
+  stage_residuals(0, dsc[33], tid, SPEC_T, 0, M);
   __syncthreads();
 
   if (builder) {
@@ -115,66 +135,64 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
 #pragma unroll
       for (int jb = 0; jb < SPq; ++jb) load_cb_quad(p, jb);
     };
-    // slab(p) of the items [g_lo, g_hi) (g_lo even), two items per step = four accumulators:
-    // (pair A, item g), (pair B, item g), (pair A, item g+1), (pair B, item g+1).  Only the adds of a
-    // squareDistance are a loop-carried chain; the subtraction and the square of a later dimension do
-    // not depend on it.  So the three stages are software-pipelined over the dimensions: one block of
-    // twelve packed instructions does  s += q (dimension j),  q = d*d (j+1),  d = r - c (j+2)  for the
-    // four accumulators.  Every operand was produced eight or more issues earlier, which is what lets
-    // ONE wave per SIMD run the packed-fp32 pipe at its issue rate.  The arithmetic per accumulator is
-    // unchanged: sub, mul, add, each rounded on its own, dimensions in order (index_utils.c:500-508);
-    // a + (-b) with the neg modifier is the IEEE subtraction.
+    // slab(p) of the items [g_lo, g_hi) (g_lo even), two items per step as four interleaved chains:
+    // (pair A, item g), (pair B, item g), (pair A, item g+1), (pair B, item g+1).  Twelve packed
+    // instructions per dimension in the order sub x4, mul x4, add x4: every instruction's operands
+    // were produced four issues earlier.  a + (-b) with the neg modifier is the IEEE subtraction; each
+    // half rounds like the scalar op; dimensions in order (index_utils.c:500-508).  (Software-pipelining
+    // the three stages over the dimensions -- operands eight issues apart -- measured the same: a single
+    // wave is limited by its issue rate of packed ops, ~3.1 ns each, not by the dependencies.)
     auto build_slab = [&](int p, float* dst, int g_lo, int g_hi, int cnt) {
 #pragma unroll 1
       for (int g = g_lo; g < g_hi; g += 2) {
         const float4* R0 = reinterpret_cast<const float4*>(res + ((size_t)g * M + p) * SP);
         const float4* R1 = reinterpret_cast<const float4*>(res + ((size_t)(g + 1 < cnt ? g + 1 : g) * M + p) * SP);
         v2f s0 = {0.0f, 0.0f}, s1 = {0.0f, 0.0f}, s2 = {0.0f, 0.0f}, s3 = {0.0f, 0.0f};
-        v2f d0, d1, d2, d3, q0, q1, q2, q3;
-        float4 rr0[SPq], rr1[SPq];   // (only two or three quads are live at a time)
-        rr0[0] = R0[0]; rr1[0] = R1[0];
-        if (SPq > 1) { rr0[1] = R0[1]; rr1[1] = R1[1]; }
+        float4 n0 = R0[0], n1 = R1[0];
 #pragma unroll
-        for (int step = 0; step < S + 2; ++step) {
-          if (step >= 2) {   // s += q          (dimension step-2)
-            asm volatile(
-                "v_pk_add_f32 %0, %0, %4\n\t"
-                "v_pk_add_f32 %1, %1, %5\n\t"
-                "v_pk_add_f32 %2, %2, %6\n\t"
-                "v_pk_add_f32 %3, %3, %7"
-                : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3)
-                : "v"(q0), "v"(q1), "v"(q2), "v"(q3));
-          }
-          if (step >= 1 && step <= S) {   // q = d * d      (dimension step-1)
-            asm volatile(
-                "v_pk_mul_f32 %0, %4, %4\n\t"
-                "v_pk_mul_f32 %1, %5, %5\n\t"
-                "v_pk_mul_f32 %2, %6, %6\n\t"
-                "v_pk_mul_f32 %3, %7, %7"
-                : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
-                : "v"(d0), "v"(d1), "v"(d2), "v"(d3));
-          }
-          if (step < S) {   // d = r - c      (dimension step)
-            const int j = step, jb = j >> 2, u = j & 3;
-            if (u == 0 && jb + 2 < SPq) { rr0[jb + 2] = R0[jb + 2]; rr1[jb + 2] = R1[jb + 2]; }
-            const v2f a0 = (u < 2) ? v2f{rr0[jb].x, rr0[jb].y} : v2f{rr0[jb].z, rr0[jb].w};
-            const v2f a1 = (u < 2) ? v2f{rr1[jb].x, rr1[jb].y} : v2f{rr1[jb].z, rr1[jb].w};
-            if ((u & 1) == 0) {
-              asm volatile(
-                  "v_pk_add_f32 %0, %4, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                  "v_pk_add_f32 %1, %4, %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                  "v_pk_add_f32 %2, %5, %6 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                  "v_pk_add_f32 %3, %5, %7 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]"
-                  : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-                  : "v"(a0), "v"(a1), "v"(cbA[j]), "v"(cbB[j]));
-            } else {
-              asm volatile(
-                  "v_pk_add_f32 %0, %4, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                  "v_pk_add_f32 %1, %4, %7 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                  "v_pk_add_f32 %2, %5, %6 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                  "v_pk_add_f32 %3, %5, %7 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
-                  : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3)
-                  : "v"(a0), "v"(a1), "v"(cbA[j]), "v"(cbB[j]));
+        for (int jb = 0; jb < SPq; ++jb) {
+          const float4 c0 = n0, c1 = n1;
+          if (jb + 1 < SPq) { n0 = R0[jb + 1]; n1 = R1[jb + 1]; }
+          const v2f a0[2] = {{c0.x, c0.y}, {c0.z, c0.w}};
+          const v2f a1[2] = {{c1.x, c1.y}, {c1.z, c1.w}};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int j = jb * 4 + u;
+            if (j < S) {
+              v2f t0, t1, t2, t3;
+              if ((u & 1) == 0) {
+                asm volatile(
+                    "v_pk_add_f32 %4, %8, %10 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_add_f32 %5, %8, %11 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_add_f32 %6, %9, %10 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_add_f32 %7, %9, %11 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_mul_f32 %4, %4, %4\n\t"
+                    "v_pk_mul_f32 %5, %5, %5\n\t"
+                    "v_pk_mul_f32 %6, %6, %6\n\t"
+                    "v_pk_mul_f32 %7, %7, %7\n\t"
+                    "v_pk_add_f32 %0, %0, %4\n\t"
+                    "v_pk_add_f32 %1, %1, %5\n\t"
+                    "v_pk_add_f32 %2, %2, %6\n\t"
+                    "v_pk_add_f32 %3, %3, %7"
+                    : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                    : "v"(a0[u >> 1]), "v"(a1[u >> 1]), "v"(cbA[j]), "v"(cbB[j]));
+              } else {
+                asm volatile(
+                    "v_pk_add_f32 %4, %8, %10 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_add_f32 %5, %8, %11 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_add_f32 %6, %9, %10 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_add_f32 %7, %9, %11 op_sel:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                    "v_pk_mul_f32 %4, %4, %4\n\t"
+                    "v_pk_mul_f32 %5, %5, %5\n\t"
+                    "v_pk_mul_f32 %6, %6, %6\n\t"
+                    "v_pk_mul_f32 %7, %7, %7\n\t"
+                    "v_pk_add_f32 %0, %0, %4\n\t"
+                    "v_pk_add_f32 %1, %1, %5\n\t"
+                    "v_pk_add_f32 %2, %2, %6\n\t"
+                    "v_pk_add_f32 %3, %3, %7"
+                    : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                    : "v"(a0[u >> 1]), "v"(a1[u >> 1]), "v"(cbA[j]), "v"(cbB[j]));
+              }
             }
           }
         }
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
     lds_barrier();
     for (;;) {
       int ngid = 0;       // wave 0: next work index (requested now, used from P(2) on)
-      int n_cell = 0, n_first = 0, n_gc = 0, n_item = -1, n_b0 = 0, n_b1 = 0;
+      int n_cell = 0, n_first = 0, n_gc = 0, n_item = -1, n_b0 = 0, n_b1 = 0, n_q = 0;
       const int nb = cur ^ 1;
       if (tid == 0) ngid = atomicAdd(a.work_counter, 1);
       for (int p = 0; p + 1 < M; ++p) {
@@ -208,8 +226,10 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
         if (!(a.ablate & 1)) build_slab(p + 1, nxt, 0, cnt, cnt);
         tick(0);   // builds of the main loop
         __builtin_amdgcn_sched_barrier(0);
-        // (issued in one go: a builder wave blocks while the 28 wide loads enter the memory pipe, ~2.9k
-        // cycles per position measured; spreading them over the last item pair's pass only moved the stall)
+        // (Issued in one go.  The builder wave blocks ~2.8k cycles per position while the 28 wide loads
+        // enter the memory pipe.  Two alternatives were measured and were no faster, the stall just moved
+        // into the build: spreading the loads over the last item pair's pass, and building every slab in
+        // two passes over the dimensions with the codebook registers refilled half by half.)
         load_cb(p + 2 < M ? p + 2 : 0);   // position 0: the next entry's
         // next entry's descriptor, one dependent global round trip per position (wave 0 only)
         if (wave == 0) {
@@ -232,14 +252,16 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
               const int b0 = n_b0 + chn * FUSED_UNIT_BLOCKS;
               int nbn = n_b1 - b0;
               if (nbn > FUSED_UNIT_BLOCKS) nbn = FUSED_UNIT_BLOCKS;
+              if (n_item >= 0) n_q = a.item_query[n_item];   // (published at p == 7)
               if (lane < G) dsc[nb * 16 + lane] = n_item;
               if (lane == 0) {
-                dsc[32 + nb * 8 + 0] = ngid; dsc[32 + nb * 8 + 1] = cntn; dsc[32 + nb * 8 + 2] = b0;
-                dsc[32 + nb * 8 + 3] = nbn; dsc[32 + nb * 8 + 4] = chn;
+                dsc[32 + nb * 8 + 1] = cntn; dsc[32 + nb * 8 + 2] = b0;
+                dsc[32 + nb * 8 + 3] = nbn; dsc[32 + nb * 8 + 4] = chn; dsc[32 + nb * 8 + 5] = n_cell;
               }
-            } else if (lane == 0) {
-              dsc[32 + nb * 8 + 0] = -1;
             }
+          } else if (p == 7) {
+            if (lane < G) dsc[64 + nb * 16 + lane] = n_q;
+            if (lane == 0) dsc[32 + nb * 8 + 0] = (ngid < n_work) ? ngid : -1;
           }
         }
         tick(5);
@@ -249,10 +271,7 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
       // P(M-1): the residual table is free (slab(M-1) was built in P(M-2)): stage the next entry's
       const int next_gid = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
       const int next_cnt = next_gid >= 0 ? __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8 + 1]) : 0;
-      for (int i = tid; i < next_cnt * ROW4; i += SPEC_NB * 64) {
-        const int g = i / ROW4, o = i - g * ROW4;
-        reinterpret_cast<float4*>(res)[i] = reinterpret_cast<const float4*>(a.resid)[(size_t)dsc[nb * 16 + g] * ROW4 + o];
-      }
+      stage_residuals(nb, next_cnt, tid, SPEC_NB * 64, M - 1, M);
       lds_barrier();
       tick(2);   // P(M-1)
       // S1 / S2: slab(0) of the next entry in two halves (buffer 0 is free: the gatherers are selecting)
@@ -323,6 +342,13 @@ __global__ __launch_bounds__(SPEC_T) void ivf_spec_kernel(FusedArgs a) {
         if (!(a.ablate & 2)) gather(p, slab + (size_t)(p & 1) * G * K);
         __builtin_amdgcn_sched_barrier(0);
         if (p & 1) load_codes((p + 1) >> 1);
+        if (p >= STAGE_P0) {
+          const int ngid_s = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
+          if (ngid_s >= 0) {
+            const int ncnt_s = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8 + 1]);
+            stage_residuals(nb, ncnt_s, tid - SPEC_NB * 64, NG * 64, p == STAGE_P0 ? 0 : p, p + 1);
+          }
+        }
         lds_barrier();
       }
       // P(M-1)

@@ -190,6 +190,8 @@ struct PlanArgs {
   int32_t* item_query;      // [n_active*W]
   int32_t* round_rows;      // [n_active] rows retrieved this round, -1 = no cell was left
   int32_t* cell_count;      // [C] fused path only (NULL otherwise): += items probing each cell
+  int32_t* cell_items;      // [C][cell_cap] fused path: the items of each cell, in arrival order (any order is fine)
+  int cell_cap;             // >= number of active queries (a query probes a cell at most once)
   int n_active, Cpad, C, W, used_words;
 };
 
@@ -256,7 +258,10 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
     for (int o = 32; o > 0; o >>= 1) rows += __shfl_xor(rows, o, 64);
     if (have) {
       atomicOr(used + (c_slot >> 5), 1u << (c_slot & 31));
-      if (a.cell_count) atomicAdd(a.cell_count + c_slot, 1);
+      if (a.cell_count) {
+        const int at = atomicAdd(a.cell_count + c_slot, 1);
+        a.cell_items[(size_t)c_slot * a.cell_cap + at] = x * W + lane;
+      }
     }
     const bool any_cell = __ballot(have) != 0ull;
     if (lane == 0) a.round_rows[x] = any_cell ? rows : -1;   // -1: every cell already used, the query retires
@@ -293,7 +298,10 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
         used[c >> 5] |= 1u << (c & 31);
         rows += a.list_off[c + 1] - a.list_off[c];
         ++n_cells;
-        if (a.cell_count) atomicAdd(a.cell_count + c, 1);
+        if (a.cell_count) {
+          const int at = atomicAdd(a.cell_count + c, 1);
+          a.cell_items[(size_t)c * a.cell_cap + at] = x * W + i;
+        }
       }
     }
     a.round_rows[x] = n_cells ? rows : -1;   // -1: every cell already used, the query retires
