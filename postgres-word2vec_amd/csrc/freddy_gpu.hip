@@ -525,7 +525,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
 
   timed_launch(ix, s, "coarse_dist", [&] {
     if (Q >= 32)
-      hipLaunchKernelGGL(coarse_tile_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
+      hipLaunchKernelGGL((coarse_tile_kernel<2>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
                          ix->w_distT.as<float>(), Q, Cpad, d);
     else
       hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, d_q,

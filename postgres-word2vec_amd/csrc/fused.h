@@ -672,29 +672,47 @@ __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
   sel.init(stage, KEY_INF, a.L);
   const int per_item = a.upi * FUSED_NW;
   const int R = a.W * per_item;
-  for (int jb = 0; jb < R; jb += 64) {
-    const int j = jb + lane;
-    int c = 0;
-    const u64* src = a.surv;
-    if (j < R) {
-      const int i = j / per_item, rem = j - i * per_item;
-      const int item = x * a.W + i;
-      const int cell = a.item_cell[item];
-      if (cell >= 0) {
-        const int nch = (a.blk_off[cell + 1] - a.blk_off[cell] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-        if (rem / FUSED_NW < nch) {
-          const size_t region = (size_t)item * per_item + rem;
-          c = a.surv_count[region];
-          src = a.surv + region * (size_t)(FUSED_RMAX * 64);
-        }
-      }
-    }
-    int maxc = c;
+  constexpr int NBATCH = 4;   // region rounds whose (dependent) descriptor loads are issued together
+  for (int jb = 0; jb < R; jb += 64 * NBATCH) {
+    int c[NBATCH], cell[NBATCH], nb[NBATCH];
+    size_t region[NBATCH];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
-    for (int t = 0; t < maxc; ++t) {
-      const bool valid = t < c;
-      sel.push(valid ? src[t] : KEY_INF, valid);
+    for (int u = 0; u < NBATCH; ++u) {
+      const int j = jb + u * 64 + lane;
+      const int i = j / per_item;
+      region[u] = (size_t)(x * a.W + i) * per_item + (j - i * per_item);
+      cell[u] = (j < R) ? a.item_cell[x * a.W + i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NBATCH; ++u) nb[u] = (cell[u] >= 0) ? a.blk_off[cell[u] + 1] - a.blk_off[cell[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < NBATCH; ++u) {
+      const int j = jb + u * 64 + lane;
+      const int ch = (j % per_item) / FUSED_NW;
+      const int nch = (nb[u] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+      c[u] = (ch < nch) ? a.surv_count[region[u]] : 0;
+    }
+    // a region typically holds 0-2 keys: fetch the first two of every region up front (independent
+    // loads), only longer regions go back to memory inside the loop
+    u64 k0[NBATCH], k1[NBATCH];
+#pragma unroll
+    for (int u = 0; u < NBATCH; ++u) {
+      const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
+      k0[u] = (c[u] > 0) ? src[0] : KEY_INF;
+      k1[u] = (c[u] > 1) ? src[1] : KEY_INF;
+    }
+#pragma unroll
+    for (int u = 0; u < NBATCH; ++u) {
+      const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
+      int maxc = c[u];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+      if (maxc > 0) sel.push(k0[u], c[u] > 0);
+      if (maxc > 1) sel.push(k1[u], c[u] > 1);
+      for (int t = 2; t < maxc; ++t) {
+        const bool valid = t < c[u];
+        sel.push(valid ? src[t] : KEY_INF, valid);
+      }
     }
   }
   sel.finish();
