@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "fused.h"
 #include "fused2.h"
+#include "fused3.h"
 #include "exact.h"
 #include "join.h"
 
@@ -511,7 +512,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   if (fused) {
     // cell_count[C]; cell_items[C][Q]; group table: 2 x 3 arrays of (items/G + C) * upi entries
     if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
-        ix->w_groups.ensure(sizeof(int32_t) * 6 * (items / FUSED_G + (size_t)C + 1) * upi) ||
+        ix->w_groups.ensure(sizeof(int32_t) * 6 * (items / SPEC2_G + (size_t)C + 1) * upi) ||
         ix->w_surv.ensure(sizeof(u64) * items * upi * FUSED_NW * FUSED_RMAX * 64) ||
         ix->w_surv_cnt.ensure(sizeof(int32_t) * items * upi * FUSED_NW))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
@@ -565,7 +566,11 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     }
     // FREDDY_GPU_FUSED_KERNEL=1: the symmetric kernel of fused.h; default: the role-specialised one, which
     // forms the residuals itself
-    static const bool symmetric = getenv("FREDDY_GPU_FUSED_KERNEL") && getenv("FREDDY_GPU_FUSED_KERNEL")[0] == '1';
+    // FREDDY_GPU_FUSED_KERNEL: 1 = symmetric kernel (fused.h), 2 = one builder wave per SIMD (fused2.h),
+    // default 3 = two builder waves per SIMD, 12 items per entry (fused3.h)
+    static const int fvariant = getenv("FREDDY_GPU_FUSED_KERNEL") ? atoi(getenv("FREDDY_GPU_FUSED_KERNEL")) : 3;
+    static const bool symmetric = fvariant == 1;
+    const int gsz = (fvariant == 3) ? SPEC2_G : FUSED_G;
     if (!fused || symmetric) {
       timed_launch(ix, s, "residual", [&] {
         hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
@@ -575,14 +580,14 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     }
     HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
     if (fused) {
-      const size_t max_groups = ((size_t)n_items / FUSED_G + (size_t)C + 1) * upi;   // (group, chunk) work entries
+      const size_t max_groups = ((size_t)n_items / gsz + (size_t)C + 1) * upi;   // (group, chunk) work entries
       int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
       int32_t* group_cell = ix->w_groups.as<int32_t>();
       int32_t* group_first = group_cell + max_groups;
       int32_t* group_cnt = group_first + max_groups;
       int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
       timed_launch(ix, s, "group_items", [&] {
-        hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(256), 0, s, cell_count, C, n_active, ix->blk_off, group_cell, group_first,
+        hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(256), 0, s, cell_count, C, n_active, gsz, ix->blk_off, group_cell, group_first,
                            group_cnt, group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups);
       });
       HIP_TRY(hipGetLastError());
@@ -616,6 +621,10 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec_kernel<25, 12, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec2_kernel<25, 12, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec2_kernel<25, 12, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         fattr = true;
       }
       // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
@@ -630,7 +639,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
           else
             hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
         });
-      } else {
+      } else if (fvariant == 2) {
         const size_t desc_off = (slab_bytes + 15) & ~(size_t)15;
         const size_t flds = desc_off + 4096 + 64 + 512 + res_bytes;   // + column minima, thresholds, descriptors, residuals
         fa.desc_offset = (uint32_t)desc_off;
@@ -639,6 +648,16 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
             hipLaunchKernelGGL((ivf_spec_kernel<25, 12, true>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
           else
             hipLaunchKernelGGL((ivf_spec_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
+        });
+      } else {
+        const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
+        const size_t flds = desc_off + 4096 + 64 + 512 + (size_t)SPEC2_G * 12 * 28 * sizeof(float);
+        fa.desc_offset = (uint32_t)desc_off;
+        timed_launch(ix, s, "ivf_fused", [&] {
+          if (K == 1024)
+            hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
+          else
+            hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
         });
       }
       HIP_TRY(hipGetLastError());

@@ -135,9 +135,9 @@ __global__ __launch_bounds__(256) void bucket_items_kernel(const int32_t* __rest
 
 // group_table + sort_work in ONE launch for the bucketed form (the probe plan has already written
 // each cell's items to cell_items[cell][0..count)): one workgroup of 256 threads turns the per-cell
-// counts into work entries (group of <= FUSED_G items of a cell x 4096-row chunk; first = index into
-// cell_items) and orders them largest first.
-__global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap,
+// counts into work entries (group of <= gsz <= FUSED_G items of a cell x 4096-row chunk; first = index
+// into cell_items) and orders them largest first.
+__global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
                                                         const int32_t* __restrict__ blk_off,
                                                         int32_t* __restrict__ tmp_cell, int32_t* __restrict__ tmp_first,
                                                         int32_t* __restrict__ tmp_cnt, int32_t* __restrict__ out_cell,
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restri
   for (int c = c0; c < c1; ++c) {
     const int n = cell_count[c];
     const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-    groups += ((n + FUSED_G - 1) / FUSED_G) * chunks;
+    groups += ((n + gsz - 1) / gsz) * chunks;
   }
   scan[tid] = groups;
   for (int i = tid; i < NB; i += 256) hist[i] = 0;
@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restri
   for (int c = c0; c < c1; ++c) {
     const int n = cell_count[c];
     const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-    for (int f = 0; f < n; f += FUSED_G) {
-      const int cnt = (n - f < FUSED_G) ? n - f : FUSED_G;
+    for (int f = 0; f < n; f += gsz) {
+      const int cnt = (n - f < gsz) ? n - f : gsz;
       for (int ch = 0; ch < chunks; ++ch) {
         tmp_cell[gr_off] = c;
         tmp_first[gr_off] = c * cell_cap + f;
