@@ -568,8 +568,9 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     // forms the residuals itself
     // FREDDY_GPU_FUSED_KERNEL: 1 = symmetric kernel (fused.h), 2 = one builder wave per SIMD (fused2.h),
     // default 3 = two builder waves per SIMD, 12 items per entry (fused3.h)
-    static const int fvariant = getenv("FREDDY_GPU_FUSED_KERNEL") ? atoi(getenv("FREDDY_GPU_FUSED_KERNEL")) : 3;
-    static const bool symmetric = fvariant == 1;
+    const char* fvenv = getenv("FREDDY_GPU_FUSED_KERNEL");   // read per call: the tests switch it
+    const int fvariant = (fvenv && fvenv[0] >= '1' && fvenv[0] <= '2') ? fvenv[0] - '0' : 3;
+    const bool symmetric = fvariant == 1;
     const int gsz = (fvariant == 3) ? SPEC2_G : FUSED_G;
     if (!fused || symmetric) {
       timed_launch(ix, s, "residual", [&] {

@@ -74,6 +74,27 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
     idx.close()
 
 
+@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("K", [256, 1024])
+def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
+    """The three fused kernels (FREDDY_GPU_FUSED_KERNEL: 1 symmetric fused.h, 2 one builder wave per SIMD
+    fused2.h, 3 = default, two builder waves per SIMD and 12-item entries fused3.h) against the oracle:
+    many queries per cell (entries of every size incl. split cells), both found rules, k up to 32."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    monkeypatch.setenv("FREDDY_GPU_FUSED_KERNEL", variant)
+    N = 20000
+    t = util.ivf_tables(N=N, C=32, K=K)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 200)      # 200 x W items over 32 cells: up to ~60 items per cell
+    for k, W, rule in ((5, 4, 0), (32, 2, 0), (3, 1, 1)):
+        gi, gd = idx.search(qs, k, W, sentinel=1000.0 if rule == 0 else 100.0,
+                            found_rule=gpu.FOUND_ROWS if rule == 0 else gpu.FOUND_ACCEPTED)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0 if rule == 0 else 100.0, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"variant {variant} K={K} k={k} W={W} rule={rule}")
+    idx.close()
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_ivfadc_batch_udf_semantics(gpu, oracle, fused, monkeypatch):
     """W=1, sentinel 100.0, found = accepted insertions == ivfadc_batch_search (freddy.c:679-999)."""
