@@ -1003,6 +1003,7 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
     pos = ix->w_sub_pos.as<int32_t>();
   }
   int chunk_blocks = 8;   // 512 rows per workgroup-chunk; longer chunks once the grid is large enough
+  const int EX_QT = ex_qt(V, Q);
   const int qgroups = (Q + EX_QT - 1) / EX_QT;
   while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)qgroups > 8192 && chunk_blocks < 1024) chunk_blocks *= 2;
   const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
@@ -1018,22 +1019,28 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
   dim3 grid((unsigned)nchunk, (unsigned)qgroups);
   timed_launch(ix, s, "exact_scan", [&] {
     switch (V) {
-      case 1: hipLaunchKernelGGL((exact_scan_kernel<1>), grid, dim3(EX_WG), lds, s, ea); break;
-      case 2: hipLaunchKernelGGL((exact_scan_kernel<2>), grid, dim3(EX_WG), lds, s, ea); break;
-      case 4: hipLaunchKernelGGL((exact_scan_kernel<4>), grid, dim3(EX_WG), lds, s, ea); break;
-      case 8: hipLaunchKernelGGL((exact_scan_kernel<8>), grid, dim3(EX_WG), lds, s, ea); break;
-      default: hipLaunchKernelGGL((exact_scan_kernel<16>), grid, dim3(EX_WG), lds, s, ea); break;
+      case 1: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<1, 16>), grid, dim3(EX_WG), lds, s, ea);
+              else hipLaunchKernelGGL((exact_scan_kernel<1, 8>), grid, dim3(EX_WG), lds, s, ea);
+              break;
+      case 2: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<2, 16>), grid, dim3(EX_WG), lds, s, ea);
+              else hipLaunchKernelGGL((exact_scan_kernel<2, 8>), grid, dim3(EX_WG), lds, s, ea);
+              break;
+      case 4: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<4, 16>), grid, dim3(EX_WG), lds, s, ea);
+              else hipLaunchKernelGGL((exact_scan_kernel<4, 8>), grid, dim3(EX_WG), lds, s, ea);
+              break;
+      case 8: hipLaunchKernelGGL((exact_scan_kernel<8, 8>), grid, dim3(EX_WG), lds, s, ea); break;
+      default: hipLaunchKernelGGL((exact_scan_kernel<16, 8>), grid, dim3(EX_WG), lds, s, ea); break;
     }
   });
   HIP_TRY(hipGetLastError());
   const int ppq = nchunk * EX_WAVES;
   timed_launch(ix, s, "exact_merge", [&] {
     switch (V) {
-      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(64), 0, s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (1 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (2 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (4 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(8 * 64), (size_t)8 * 64 * (8 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (16 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
     }
   });
   HIP_TRY(hipGetLastError());
