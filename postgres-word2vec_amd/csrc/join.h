@@ -27,6 +27,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <math.h>
+
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <stdint.h>
 
 #include <algorithm>
@@ -73,14 +77,15 @@ struct JoinIndex {
   int32_t* ids = nullptr;     // [N]
   int16_t* codes = nullptr;   // [N][m]
   float* vectors = nullptr;   // [N][d]
+  int32_t* cell = nullptr;    // [N] coarse cell of each row
+  uint32_t* markbits = nullptr;  // [ceil(N/32)] scratch bitmap of the "id IN (targets)" resolution
   // host
   std::vector<int32_t> h_ids, h_cell;
   std::vector<float> h_stats;
-  std::vector<uint8_t> h_mark;   // [N] scratch of the "id IN (targets)" resolution, all zero between calls
   bool ids_affine = false;       // ids[r] == ids[0] + r: O(1) id -> row
   // workspaces
-  void* w[12] = {nullptr};
-  size_t wcap[12] = {0};
+  void* w[16] = {nullptr};
+  size_t wcap[16] = {0};
 };
 
 static inline int join_buf(JoinIndex* j, int slot, size_t bytes, void** out) {
@@ -97,9 +102,9 @@ static inline int join_buf(JoinIndex* j, int slot, size_t bytes, void** out) {
 }
 
 static inline void join_free(JoinIndex* j) {
-  void* ptrs[] = {j->cbT, j->coarseT, j->ids, j->codes, j->vectors};
+  void* ptrs[] = {j->cbT, j->coarseT, j->ids, j->codes, j->vectors, j->cell, j->markbits};
   for (void* p : ptrs) if (p) (void)hipFree(p);
-  for (int i = 0; i < 12; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
+  for (int i = 0; i < 16; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
   *j = JoinIndex();
 }
 
@@ -137,12 +142,14 @@ static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* byt
       for (int i = 0; i < half; ++i) cqT[((size_t)p * half + i) * Kc + c] = t->coarse[((size_t)p * Kc + c) * half + i];
   if (join_upload(&j->cbT, cbT.data(), cbT.size(), bytes) || join_upload(&j->coarseT, cqT.data(), cqT.size(), bytes) ||
       join_upload(&j->ids, t->ids, (size_t)t->N, bytes) || join_upload(&j->codes, t->codes, (size_t)t->N * m, bytes) ||
+      join_upload(&j->cell, t->coarse_id, (size_t)t->N, bytes) ||
       (t->vectors && join_upload(&j->vectors, t->vectors, (size_t)t->N * t->d, bytes)))
     return join_fail(FREDDY_E_NOMEM, "device allocation failed while pinning the ivpq tables");
   j->h_ids.assign(t->ids, t->ids + t->N);
   j->h_cell.assign(t->coarse_id, t->coarse_id + t->N);
   j->h_stats.assign(t->stats, t->stats + j->cells + 1);
-  j->h_mark.assign((size_t)t->N, 0);
+  if (hipMalloc((void**)&j->markbits, sizeof(uint32_t) * (size_t)((t->N + 31) / 32 + 1)) != hipSuccess)
+    return join_fail(FREDDY_E_NOMEM, "device allocation failed while pinning the ivpq tables");
   j->ids_affine = t->N > 0 && (int64_t)t->ids[t->N - 1] - t->ids[0] == t->N - 1;   // strictly ascending => consecutive
   return 0;
 }
@@ -166,6 +173,81 @@ __global__ __launch_bounds__(64) void sub_dist_kernel(const float* __restrict__ 
     }
     out[((size_t)q * 2 + pos) * Kc + c] = acc;
   }
+}
+
+// Stable ascending order of one side's Kc sub-distances (index_utils.c:306-320 sorts each position's
+// distances; equal distances keep their code order): key = (distance bits << 32 | code), one wave per
+// (query, position).  Kc <= 64 * V.
+template <int V>
+__global__ __launch_bounds__(64) void side_sort_kernel(const float* __restrict__ sub, u64* __restrict__ sorted, int Kc) {
+  const size_t row = (size_t)blockIdx.x;   // (query * 2 + position)
+  const int lane = threadIdx.x;
+  u64 key[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c = v * 64 + lane;
+    key[v] = (c < Kc) ? make_key(sub[row * Kc + c], (uint32_t)c) : KEY_INF;
+  }
+  wave_sort_full<V>(key);
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c = v * 64 + lane;
+    if (c < Kc) sorted[row * Kc + c] = (key[v] << 32) | (key[v] >> 32);   // memory layout of JoinSide {float dist; int code}
+  }
+}
+
+// "fq.id IN (targets)" on the device: every target id is resolved to its row (ids ascending: affine
+// shortcut or binary search), duplicates and unknown ids drop out through a bitmap, the survivors are
+// counted per coarse cell, and a second pass scatters them into per-cell buckets.  (Order inside a
+// bucket is arbitrary: the join kernel keys every candidate by (distance, row).)
+__global__ __launch_bounds__(256) void join_mark_kernel(const int32_t* __restrict__ tids, int n, const int32_t* __restrict__ ids,
+                                                       int64_t N, int affine, const int32_t* __restrict__ cell,
+                                                       uint32_t* __restrict__ mark, int32_t* __restrict__ win,
+                                                       int32_t* __restrict__ cnt) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t id = tids[i];
+  int64_t r = -1;
+  if (affine) {
+    const int64_t c = (int64_t)id - ids[0];
+    if (c >= 0 && c < N) r = c;
+  } else {
+    int64_t lo = 0, hi = N;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (ids[mid] < id) lo = mid + 1; else hi = mid; }
+    if (lo < N && ids[lo] == id) r = lo;
+  }
+  int32_t w = -1;
+  if (r >= 0) {
+    const uint32_t bit = 1u << (r & 31);
+    if (!(atomicOr(mark + (r >> 5), bit) & bit)) { w = (int32_t)r; atomicAdd(cnt + cell[r], 1); }
+  }
+  win[i] = w;
+}
+__global__ __launch_bounds__(256) void join_offsets_kernel(const int32_t* __restrict__ cnt, int cells, int32_t* __restrict__ off,
+                                                          int32_t* __restrict__ fill) {
+  __shared__ int scan[256];
+  const int tid = threadIdx.x, per = (cells + 255) / 256;
+  const int c0 = tid * per, c1 = (c0 + per < cells) ? c0 + per : cells;
+  int sum = 0;
+  for (int c = c0; c < c1; ++c) sum += cnt[c];
+  scan[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = (tid >= o) ? scan[tid - o] : 0;
+    __syncthreads();
+    scan[tid] += v;
+    __syncthreads();
+  }
+  int run = scan[tid] - sum;
+  for (int c = c0; c < c1; ++c) { off[c] = run; fill[c] = run; run += cnt[c]; }
+  if (tid == 255) off[cells] = scan[255];
+}
+__global__ __launch_bounds__(256) void join_place_kernel(const int32_t* __restrict__ win, int n, const int32_t* __restrict__ cell,
+                                                        int32_t* __restrict__ fill, int32_t* __restrict__ trow) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int32_t r = win[i];
+  if (r >= 0) trow[atomicAdd(fill + cell[r], 1)] = r;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -313,7 +395,25 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64 && k <= 64) {
+    // insertion replay with the list held one slot per lane (wave_topk.h: wave_list_insert)
+    float d_slot = JOIN_MAX_DIST;
+    int32_t id_slot = -1;
+    float maxd = JOIN_MAX_DIST;
+    for (int e = 0; e < L; ++e) {
+      const u64 c = lists[e];
+      if (c == KEY_INF) break;
+      float dist;
+      uint32_t row;
+      if (a.method == FREDDY_METHOD_PQ_PV) { dist = exact[e]; row = key_pos(c); }
+      else { dist = __uint_as_float((uint32_t)c); row = (uint32_t)(c >> 32); }
+      if (dist < maxd) {
+        wave_list_insert(d_slot, id_slot, k, dist, a.ids[row]);
+        maxd = wave_list_max(d_slot, k);
+      }
+    }
+    if ((int)threadIdx.x < k) { s_d[threadIdx.x] = d_slot; s_id[threadIdx.x] = id_slot; }
+  } else if (threadIdx.x == 0 && k > 64) {
     float maxd = JOIN_MAX_DIST;
     for (int e = 0; e < L; ++e) {
       const u64 c = lists[e];
@@ -450,19 +550,77 @@ static inline void join_stable_sort(JoinSide* a, int n, JoinSide* tmp) {
   }
 }
 
+// Host worker pool for the per-query traversals.  The workers are created on first use (never at
+// library load, so a forking host stays safe) and parked on a condition variable; spawning threads per
+// call cost ~1 ms per join_parallel_for on the GPU box (32 x std::thread), more than the work itself.
+class JoinPool {
+ public:
+  static JoinPool& get() { static JoinPool p; return p; }
+  int size() const { return (int)workers_.size(); }
+  // runs fn(t) for t = 0..n_chunks-1 (n_chunks <= size()+1; chunk 0 runs on the caller)
+  void run(int n_chunks, const std::function<void(int)>& fn) {
+    if (n_chunks <= 1) { if (n_chunks == 1) fn(0); return; }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      fn_ = &fn; chunks_ = n_chunks; pending_ = n_chunks - 1; ++generation_;
+    }
+    cv_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> g(mu_);
+    done_.wait(g, [&] { return pending_ == 0; });
+    fn_ = nullptr;
+  }
+ private:
+  JoinPool() {
+    static const int cap = getenv("FREDDY_GPU_JOIN_THREADS") ? atoi(getenv("FREDDY_GPU_JOIN_THREADS")) : 32;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int n = std::max(0, (int)std::min<unsigned>(hw ? hw : 1, (unsigned)std::max(cap, 1)) - 1);
+    for (int i = 0; i < n; ++i) workers_.emplace_back([this, i] { loop(i + 1); });
+  }
+  ~JoinPool() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; ++generation_; }
+    cv_.notify_all();
+    for (auto& t : workers_) t.join();
+  }
+  void loop(int id) {
+    unsigned long seen = 0;
+    for (;;) {
+      const std::function<void(int)>* fn = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (stop_) return;
+        if (id < chunks_) fn = fn_;
+      }
+      if (fn) {
+        (*fn)(id);
+        std::lock_guard<std::mutex> g(mu_);
+        if (--pending_ == 0) done_.notify_one();
+      }
+    }
+  }
+  std::vector<std::thread> workers_;
+  std::mutex mu_;
+  std::condition_variable cv_, done_;
+  const std::function<void(int)>* fn_ = nullptr;
+  int chunks_ = 0, pending_ = 0;
+  unsigned long generation_ = 0;
+  bool stop_ = false;
+};
+
 template <class F>
 static inline void join_parallel_for(int n, F&& f) {
-  unsigned hw = std::thread::hardware_concurrency();
-  int nt = (int)std::min<unsigned>(hw ? hw : 1, 32);
-  if (n < 256 || nt <= 1) { f(0, n, 0); return; }
-  std::vector<std::thread> th;
+  if (n < 256) { f(0, n, 0); return; }
+  JoinPool& pool = JoinPool::get();
+  const int nt = std::min(pool.size() + 1, (n + 63) / 64);
+  if (nt <= 1) { f(0, n, 0); return; }
   const int per = (n + nt - 1) / nt;
-  for (int t = 0; t < nt; ++t) {
+  const int chunks = (n + per - 1) / per;
+  pool.run(chunks, [&](int t) {
     const int lo = t * per, hi = std::min(n, lo + per);
-    if (lo >= hi) break;
-    th.emplace_back([=, &f] { f(lo, hi, t); });
-  }
-  for (auto& x : th) x.join();
+    if (lo < hi) f(lo, hi, t);
+  });
 }
 
 static inline int join_pick_V(int L) {
@@ -533,72 +691,58 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
                r16((size_t)k * 4);
   if (lds > 160 * 1024) return join_fail(FREDDY_E_LIMIT, "LDS need of %zu bytes exceeds 160 KiB (m=%d K=%d k*pvf=%d)", lds, m, K, L);
 
-  // "fq.id IN (targets)": rows ascending, de-duplicated; bucketed by cell (ascending row inside).
-  // Ids are looked up in parallel and marked in a per-index byte map; one ordered sweep over the
-  // marked range then yields the rows already sorted, a counting sort by cell buckets them.
-  std::vector<int32_t> tcell_off(cells + 1, 0), trow_by_cell;
-  {
-    uint8_t* mark = j->h_mark.data();
-    const int64_t N = j->N;
-    std::atomic<int64_t> lo_row(N), hi_row(-1);
-    join_parallel_for((int)n_targets, [&](int lo, int hi, int) {
-      int64_t mn = N, mx = -1;
-      for (int i = lo; i < hi; ++i) {
-        int64_t r = -1;
-        if (j->ids_affine) {
-          const int64_t c = (int64_t)target_ids[i] - j->h_ids[0];
-          if (c >= 0 && c < N) r = c;
-        } else {
-          auto it = std::lower_bound(j->h_ids.begin(), j->h_ids.end(), target_ids[i]);
-          if (it != j->h_ids.end() && *it == target_ids[i]) r = it - j->h_ids.begin();
-        }
-        if (r >= 0) { mark[r] = 1; mn = std::min(mn, r); mx = std::max(mx, r); }
-      }
-      int64_t cur = lo_row.load();
-      while (mn < cur && !lo_row.compare_exchange_weak(cur, mn)) {}
-      cur = hi_row.load();
-      while (mx > cur && !hi_row.compare_exchange_weak(cur, mx)) {}
-    });
-    const int64_t r0 = lo_row.load(), r1 = hi_row.load();
-    for (int64_t r = r0; r <= r1; ++r) if (mark[r]) tcell_off[j->h_cell[r] + 1]++;
-    for (int c = 0; c < cells; ++c) tcell_off[c + 1] += tcell_off[c];
-    trow_by_cell.resize((size_t)tcell_off[cells]);
-    std::vector<int32_t> cur(tcell_off.begin(), tcell_off.end() - 1);
-    for (int64_t r = r0; r <= r1; ++r)
-      if (mark[r]) { trow_by_cell[cur[j->h_cell[r]]++] = (int32_t)r; mark[r] = 0; }
-  }
-
-  track("target_resolution_time");
-  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells, *d_oi, *d_od;
+  // "fq.id IN (targets)": resolved, de-duplicated and bucketed by cell on the device (see join_mark_kernel)
+  std::vector<int32_t> tcell_off(cells + 1, 0);
+  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells, *d_oi, *d_od, *d_tids, *d_win, *d_cnt, *d_sorted;
   if (join_buf(j, 0, sizeof(float) * (size_t)Q * d, &d_q) || join_buf(j, 1, sizeof(float) * (size_t)Q * 2 * Kc, &d_sub) ||
       join_buf(j, 2, sizeof(int32_t) * (size_t)(cells + 1), &d_tcell) ||
-      join_buf(j, 3, sizeof(int32_t) * std::max<size_t>(trow_by_cell.size(), 1), &d_trow) ||
+      join_buf(j, 3, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_trow) ||
       join_buf(j, 4, sizeof(int32_t) * (size_t)Q, &d_scan) || join_buf(j, 5, sizeof(int32_t) * (size_t)(Q + 1), &d_qoff) ||
-      join_buf(j, 7, sizeof(int32_t) * (size_t)Q * k, &d_oi) || join_buf(j, 8, sizeof(float) * (size_t)Q * k, &d_od))
+      join_buf(j, 7, sizeof(int32_t) * (size_t)Q * k, &d_oi) || join_buf(j, 8, sizeof(float) * (size_t)Q * k, &d_od) ||
+      join_buf(j, 9, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_tids) ||
+      join_buf(j, 10, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_win) ||
+      join_buf(j, 11, sizeof(int32_t) * (size_t)cells * 2, &d_cnt) || join_buf(j, 12, sizeof(u64) * (size_t)Q * 2 * Kc, &d_sorted))
     return FREDDY_E_NOMEM;
+  {
+    int32_t* cnt = (int32_t*)d_cnt;
+    int32_t* fill = cnt + cells;
+    JOIN_HIP(hipMemsetAsync(j->markbits, 0, sizeof(uint32_t) * (size_t)((j->N + 31) / 32 + 1), s));
+    JOIN_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)cells * 2, s));
+    if (n_targets > 0) {
+      JOIN_HIP(hipMemcpyAsync(d_tids, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(join_mark_kernel, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, s, (const int32_t*)d_tids,
+                         (int)n_targets, (const int32_t*)j->ids, j->N, j->ids_affine ? 1 : 0, (const int32_t*)j->cell, j->markbits,
+                         (int32_t*)d_win, cnt);
+    }
+    hipLaunchKernelGGL(join_offsets_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)cnt, cells, (int32_t*)d_tcell, fill);
+    if (n_targets > 0)
+      hipLaunchKernelGGL(join_place_kernel, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, s, (const int32_t*)d_win,
+                         (int)n_targets, (const int32_t*)j->cell, fill, (int32_t*)d_trow);
+    JOIN_HIP(hipGetLastError());
+    JOIN_HIP(hipMemcpyAsync(tcell_off.data(), d_tcell, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToHost, s));
+  }
+  track("target_resolution_time");   // (enqueue only: the device work overlaps what follows)
   JOIN_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
-  JOIN_HIP(hipMemcpyAsync(d_tcell, tcell_off.data(), sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyHostToDevice, s));
-  if (!trow_by_cell.empty())
-    JOIN_HIP(hipMemcpyAsync(d_trow, trow_by_cell.data(), sizeof(int32_t) * trow_by_cell.size(), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc);
   JOIN_HIP(hipGetLastError());
+  const int SV = join_pick_V(Kc);
+  if (SV == 0) return join_fail(FREDDY_E_LIMIT, "coarse_codes=%d exceeds this build's limit of 1024", Kc);
+  switch (SV) {
+    case 1: hipLaunchKernelGGL((side_sort_kernel<1>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+    case 2: hipLaunchKernelGGL((side_sort_kernel<2>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+    case 4: hipLaunchKernelGGL((side_sort_kernel<4>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+    case 8: hipLaunchKernelGGL((side_sort_kernel<8>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+    default: hipLaunchKernelGGL((side_sort_kernel<16>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+  }
+  JOIN_HIP(hipGetLastError());
+  static_assert(sizeof(JoinSide) == 8, "side_sort_kernel writes JoinSide records");
   std::vector<float> sub((size_t)Q * 2 * Kc);
+  std::vector<JoinSide> sides((size_t)Q * 2 * Kc);   // per-query sorted sides (they do not depend on alpha)
   JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
+  JOIN_HIP(hipMemcpyAsync(sides.data(), d_sorted, sizeof(JoinSide) * sides.size(), hipMemcpyDeviceToHost, s));
   JOIN_HIP(hipStreamSynchronize(s));
 
   track("sub_distance_time");
-  // per-query sorted sides (they do not depend on alpha)
-  std::vector<JoinSide> sides((size_t)Q * 2 * Kc);
-  join_parallel_for(Q, [&](int lo, int hi, int) {
-    std::vector<JoinSide> tmp(Kc);
-    for (int q = lo; q < hi; ++q)
-      for (int p = 0; p < 2; ++p) {
-        JoinSide* sp = sides.data() + ((size_t)q * 2 + p) * Kc;
-        for (int c = 0; c < Kc; ++c) { sp[c].dist = sub[((size_t)q * 2 + p) * Kc + c]; sp[c].code = c; }
-        join_stable_sort(sp, Kc, tmp.data());
-      }
-  });
-
   track("side_sort_time");
   std::vector<int32_t> active(Q), target_count(Q, 0);
   for (int i = 0; i < Q; ++i) active[i] = i;
@@ -612,14 +756,16 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     std::atomic<int> all_last(1);
     join_parallel_for(n_active, [&](int lo, int hi, int) {                                    // :327-331
       JoinTraversal w;
+      bool any_open = false;   // (one shared store per worker, not per query: the flag's cache line was ping-ponging)
       for (int x = lo; x < hi; ++x) {
         const int q = active[x];
         qcells[q].clear();
         const bool exhausted = join_select_cells(sides.data() + ((size_t)q * 2) * Kc, sides.data() + ((size_t)q * 2 + 1) * Kc,
                                                  sub.data() + ((size_t)q * 2) * Kc, sub.data() + ((size_t)q * 2 + 1) * Kc, Kc,
                                                  j->h_stats.data(), (int)n_targets, k * alpha, confidence, w, qcells[q]);
-        if (!exhausted) all_last.store(0);
+        if (!exhausted) any_open = true;
       }
+      if (any_open) all_last.store(0);
     });
     const bool last = all_last.load() != 0;
     track("determine_coarse_quantization_time");
