@@ -147,6 +147,18 @@ int freddy_gpu_pin_vectors(const freddy_vec_desc* desc, int device, freddy_gpu_i
 int freddy_gpu_exact_search(freddy_gpu_index_t* vecs, const float* queries, int32_t Q, int32_t k,
                             const int32_t* subset_ids, int64_t n_subset, int32_t* out_ids, float* out_sim);
 
+/* ---- next row: grouping_pq ---------------------------------------------------------
+ * Body of grouping_pq (freddy.c:1176-1401): for every row of the PQ table (subset_ids == NULL) or of
+ * "id IN (subset_ids)" the nearest of G group vectors by ADC distance -- one LUT per group from the PQ
+ * codebook (:1288-1299), positions summed in order (:1346-1351), strict "<" from minDist = 100 so the
+ * first of equally near groups wins (:1337,1353-1356).  group_vectors: [G][d] in the order the caller
+ * wants the ties broken (the reference: ascending group id).  out_ids / out_group: caller-allocated,
+ * one slot per requested row (n_subset, or N); rows come back in table order, out_group[i] is the
+ * group's index or -1 if no group is nearer than 100 (the reference leaves that case undefined).
+ * *n_out receives the number of rows. */
+int freddy_gpu_grouping_pq(freddy_gpu_index_t* pq, const float* group_vectors, int32_t G, const int32_t* subset_ids,
+                           int64_t n_subset, int32_t* out_ids, int32_t* out_group, int64_t* n_out);
+
 /* ---- device-resident variant used for throughput measurement ----------------------------
  * Same as freddy_gpu_ivfadc_search, but queries / outputs are DEVICE pointers on the
  * index's device and all work is enqueued on `hip_stream` (a hipStream_t; NULL = the

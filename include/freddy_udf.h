@@ -26,6 +26,7 @@ typedef struct freddy_session freddy_session_t;
 /* result rows: (Id, Distance)  freddy.c:142-146 ; (QueryId, TargetId|Id, Distance)  freddy.c:643-649,988-994 */
 typedef struct freddy_row2 { int32_t id; float distance; } freddy_row2;
 typedef struct freddy_row3 { int32_t query_id; int32_t id; float distance; } freddy_row3;
+typedef struct freddy_group_row { int32_t id; int32_t group_id; } freddy_group_row;   /* grouping_pq: (Ids, GroupIds) */
 
 int freddy_session_open(int device, freddy_session_t** out);
 int freddy_session_close(freddy_session_t* s);
@@ -101,6 +102,20 @@ int knn_join(freddy_session_t* s, const float* queries, int32_t n_queries, int32
 int k_nearest_neighbour(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
 int knn_in_exact(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
                  freddy_row2* out, int32_t* n_rows);
+
+/* Next row: grouping and analogy on the same kernels, keyed by row id instead of word.
+ * grouping_pq(integer[], integer[]) -> SETOF (Ids, GroupIds)                 freddy.c:1176-1401
+ *   rows of pq_quantization with id IN input_ids (table order), each with the nearest of the groups
+ *   (ADC distance to the group's normalised vector; groups tried in ascending id, first nearest wins;
+ *   group_id -1 if none is nearer than 100).  Error "Group ids do not exist" as the reference.
+ * analogy_3cosadd_pq / analogy_3cosadd_ivfadc                               freddy--0.0.1.sql:1317-1346, 1428-1460
+ *   q = vec_normalize(v3 - v1 + v2); candidates = pq_search / ivfadc_search(q, get_pvf() + 3) minus the
+ *   three inputs; result = the candidate with the largest cosine_similarity_bytea(v3 - v1 + v2, v4)
+ *   (-1: none, the SQL returns NULL). */
+int grouping_pq(freddy_session_t* s, const int32_t* input_ids, int32_t n_ids, const int32_t* group_ids, int32_t n_groups,
+                freddy_group_row* out, int32_t* n_rows);
+int analogy_3cosadd_pq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, int32_t* result);
+int analogy_3cosadd_ivfadc(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, int32_t* result);
 
 /* per-call row emit: snprintf("%d") / snprintf("%f") into 16-byte buffers   freddy.c:154-169,1001-1023 */
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]);

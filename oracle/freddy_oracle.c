@@ -850,3 +850,48 @@ int fo_exact_knn(const float* vectors, const int32_t* ids, int64_t N, int d, con
   free(rows);
   return n_out;
 }
+
+/* ---- next row ------------------------------------------------------------------ */
+void fo_vec_minus(const float* a, const float* b, int n, float* out) {   /* core_functions.c:118-136 */
+  for (int i = 0; i < n; ++i) out[i] = a[i] - b[i];
+}
+void fo_vec_plus(const float* a, const float* b, int n, float* out) {    /* core_functions.c:177-195 */
+  for (int i = 0; i < n; ++i) out[i] = a[i] + b[i];
+}
+void fo_vec_normalize(const float* v, int n, float* out) {               /* core_functions.c:241-266 */
+  float sq_length = 0;
+  float length = 0;
+  for (int i = 0; i < n; ++i) {
+    const float p = v[i] * v[i];
+    sq_length = sq_length + p;
+  }
+  length = (float)sqrt((double)sq_length);
+  for (int i = 0; i < n; ++i) out[i] = v[i] / length;
+}
+
+/* grouping_pq   freddy.c:1176-1401 */
+int fo_grouping_pq(const fo_pq_table* t, const float* group_vecs, int n_groups, const int32_t* input_ids,
+                   int n_ids, int32_t* out_ids, int32_t* out_group) {
+  const int m = t->m, K = t->K, s = t->d / t->m;
+  float* luts = (float*)malloc(sizeof(float) * (size_t)n_groups * m * K);
+  if (!luts && n_groups) return -1;
+  for (int g = 0; g < n_groups; ++g)                                     /* :1288-1299 */
+    fo_lut(luts + (size_t)g * m * K, m, K, s, group_vecs + (size_t)g * t->d, t->codebook);
+  int64_t* rows = NULL;
+  const int64_t n_rows = rows_for_ids(t->ids, t->N, input_ids, n_ids, &rows);
+  for (int64_t x = 0; x < n_rows; ++x) {                                 /* :1325-1358 */
+    const int64_t r = rows[x];
+    float minDist = 100;
+    int nearest = -1;
+    for (int g = 0; g < n_groups; ++g) {
+      float distance = 0;
+      for (int j = 0; j < m; ++j) distance += luts[(size_t)g * m * K + (size_t)j * K + t->codes[(size_t)r * m + j]];
+      if (distance < minDist) { minDist = distance; nearest = g; }
+    }
+    out_ids[x] = t->ids[r];
+    out_group[x] = nearest;
+  }
+  free(rows);
+  free(luts);
+  return (int)n_rows;
+}

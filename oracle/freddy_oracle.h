@@ -175,6 +175,23 @@ float fo_cosine_similarity_bytea(const float* v1, const float* v2, int n);
 int fo_exact_knn(const float* vectors, const int32_t* ids, int64_t N, int d, const float* q, int k,
                  const int32_t* input_ids, int n_ids, fo_entry* out);
 
+/* ---- next row: grouping and analogy on the PQ index ------------------------------
+ * vec_minus_bytea / vec_plus_bytea        core_functions.c:118-136, 177-195   out[i] = a[i] -/+ b[i]
+ * vec_normalize_bytea                     core_functions.c:241-266
+ *   float sq = 0; sq += v[i]*v[i]; length = (float)sqrt((double)sq); out[i] = v[i] / length           */
+void fo_vec_minus(const float* a, const float* b, int n, float* out);
+void fo_vec_plus(const float* a, const float* b, int n, float* out);
+void fo_vec_normalize(const float* v, int n, float* out);
+
+/* grouping_pq                             freddy.c:1176-1401
+ * group_vecs: the groups' vectors in ascending GROUP ID order (the reference sorts the group ids and
+ * fetches "ORDER BY id ASC").  For every row of pq_quantization with id IN input_ids (canonical order,
+ * duplicates / unknown ids dropped): ADC distance to each group's LUT, strict "<" from minDist = 100, so
+ * the first of equally near groups wins.  out_group[i] = index into group_vecs, or -1 when no group is
+ * nearer than 100 (the reference leaves nearestGroup[i] uninitialised there).  Returns the row count. */
+int fo_grouping_pq(const fo_pq_table* t, const float* group_vecs, int n_groups, const int32_t* input_ids,
+                   int n_ids, int32_t* out_ids, int32_t* out_group);
+
 /* SRF emit text round trip               freddy.c:164 ("%f" into a 16-byte buffer) */
 float fo_emit_roundtrip(float dist);
 

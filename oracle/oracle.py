@@ -84,6 +84,10 @@ class Oracle:
         L.fo_cosine_similarity_bytea.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.fo_exact_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                    C.c_void_p]
+        L.fo_vec_minus.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fo_vec_plus.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.fo_vec_normalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.fo_grouping_pq.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.fo_multi_index_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.c_void_p, C.c_void_p]
 
@@ -140,6 +144,26 @@ class Oracle:
         n = self.lib.fo_exact_knn(_p(v), _p(ids), ids.size, v.shape[1], _p(q), k, _p(sub),
                                   0 if sub is None else sub.size, _p(out))
         return out[:n]
+
+    def vec_minus(self, a, b):
+        a, b = _f32(a), _f32(b); out = np.empty_like(a)
+        self.lib.fo_vec_minus(_p(a), _p(b), a.size, _p(out)); return out
+
+    def vec_plus(self, a, b):
+        a, b = _f32(a), _f32(b); out = np.empty_like(a)
+        self.lib.fo_vec_plus(_p(a), _p(b), a.size, _p(out)); return out
+
+    def vec_normalize(self, v):
+        v = _f32(v); out = np.empty_like(v)
+        self.lib.fo_vec_normalize(_p(v), v.size, _p(out)); return out
+
+    def grouping_pq(self, table, group_vecs, input_ids):
+        """(ids, group index) of every row with id IN input_ids; group_vecs in ascending group-id order."""
+        gv, ids = _f32(group_vecs), _i32(input_ids)
+        oi = np.empty(max(ids.size, 1), np.int32); og = np.empty(max(ids.size, 1), np.int32)
+        n = self.lib.fo_grouping_pq(C.byref(table), _p(gv), gv.shape[0], _p(ids), ids.size, _p(oi), _p(og))
+        assert n >= 0
+        return oi[:n], og[:n]
 
     def confidence_hyp(self, expect, size, p, stat_size):
         return np.float32(self.lib.fo_confidence_hyp(int(expect), int(size), C.c_float(float(p)), int(stat_size)))

@@ -839,6 +839,43 @@ extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_q
   return FREDDY_OK;
 }
 
+// "WHERE id IN (...)" over the flat PQ table: unknown ids vanish, duplicates collapse, order = table
+// order; the rows' packed codes are gathered into a temporary one-list table (synchronises the stream).
+static int pq_subset(freddy_gpu_index* ix, hipStream_t s, const int32_t* subset_ids, int64_t n_subset, const int32_t** blk_off,
+                     const uint32_t** packed, const int32_t** pos, int64_t* n_blocks) {
+  std::vector<int32_t> rows;
+  rows.reserve((size_t)n_subset);
+  for (int64_t i = 0; i < n_subset; ++i) {
+    auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), subset_ids[i]);
+    if (it != ix->h_ids.end() && *it == subset_ids[i]) rows.push_back((int32_t)(it - ix->h_ids.begin()));
+  }
+  std::sort(rows.begin(), rows.end());
+  rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
+  const int n_rows = (int)rows.size();
+  const int nb = (n_rows + 63) / 64;
+  const int n_pad = nb * 64;
+  const int32_t h_blk[2] = {0, nb};
+  if (ix->w_sub_rows.ensure(sizeof(int32_t) * std::max(n_rows, 1)) ||
+      ix->w_sub_packed.ensure(sizeof(uint32_t) * (size_t)std::max(nb, 1) * ix->M2 * 64) ||
+      ix->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max(n_pad, 1)) || ix->w_sub_blk.ensure(sizeof(int32_t) * 2))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (n_rows) HIP_TRY(hipMemcpyAsync(ix->w_sub_rows.p, rows.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ix->w_sub_blk.p, h_blk, sizeof(h_blk), hipMemcpyHostToDevice, s));
+  if (n_pad) {
+    timed_launch(ix, s, "gather_rows", [&] {
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((n_pad + WG - 1) / WG), dim3(WG), 0, s, ix->w_sub_rows.as<int32_t>(),
+                         n_rows, ix->packed, ix->w_sub_packed.as<uint32_t>(), ix->w_sub_pos.as<int32_t>(), ix->M2, n_pad);
+    });
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipStreamSynchronize(s));  // rows / h_blk are stack/heap temporaries
+  *blk_off = ix->w_sub_blk.as<int32_t>();
+  *packed = ix->w_sub_packed.as<uint32_t>();
+  *pos = ix->w_sub_pos.as<int32_t>();
+  *n_blocks = nb;
+  return 0;
+}
+
 extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k, float sentinel,
                                     const int32_t* subset_ids, int64_t n_subset, int32_t* out_ids, float* out_dist) {
   if (int rc = check_search_args(ix, KIND_PQ, queries, Q, k, out_ids, out_dist)) return rc;
@@ -855,39 +892,8 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   const uint32_t* packed = ix->packed;
   const int32_t* pos = ix->pos;
   int64_t n_blocks = ix->n_blocks;
-  if (subset_ids) {
-    // "WHERE id IN (...)": unknown ids vanish, duplicates collapse, order = table order
-    std::vector<int32_t> rows;
-    rows.reserve((size_t)n_subset);
-    for (int64_t i = 0; i < n_subset; ++i) {
-      auto it = std::lower_bound(ix->h_ids.begin(), ix->h_ids.end(), subset_ids[i]);
-      if (it != ix->h_ids.end() && *it == subset_ids[i]) rows.push_back((int32_t)(it - ix->h_ids.begin()));
-    }
-    std::sort(rows.begin(), rows.end());
-    rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
-    const int n_rows = (int)rows.size();
-    const int nb = (n_rows + 63) / 64;
-    const int n_pad = nb * 64;
-    const int32_t h_blk[2] = {0, nb};
-    if (ix->w_sub_rows.ensure(sizeof(int32_t) * std::max(n_rows, 1)) ||
-        ix->w_sub_packed.ensure(sizeof(uint32_t) * (size_t)std::max(nb, 1) * ix->M2 * 64) ||
-        ix->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max(n_pad, 1)) || ix->w_sub_blk.ensure(sizeof(int32_t) * 2))
-      return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-    if (n_rows) HIP_TRY(hipMemcpyAsync(ix->w_sub_rows.p, rows.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ix->w_sub_blk.p, h_blk, sizeof(h_blk), hipMemcpyHostToDevice, s));
-    if (n_pad) {
-      timed_launch(ix, s, "gather_rows", [&] {
-        hipLaunchKernelGGL(gather_rows_kernel, dim3((n_pad + WG - 1) / WG), dim3(WG), 0, s, ix->w_sub_rows.as<int32_t>(),
-                           n_rows, ix->packed, ix->w_sub_packed.as<uint32_t>(), ix->w_sub_pos.as<int32_t>(), ix->M2, n_pad);
-      });
-      HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipStreamSynchronize(s));  // rows / h_blk are stack/heap temporaries
-    blk_off = ix->w_sub_blk.as<int32_t>();
-    packed = ix->w_sub_packed.as<uint32_t>();
-    pos = ix->w_sub_pos.as<int32_t>();
-    n_blocks = nb;
-  }
+  if (subset_ids)
+    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
   const int qc = max_queries_per_chunk(ix, 1);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
@@ -898,6 +904,62 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_dist, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return FREDDY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// grouping_pq
+// ---------------------------------------------------------------------------------------
+extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group_vectors, int32_t G, const int32_t* subset_ids,
+                                      int64_t n_subset, int32_t* out_ids, int32_t* out_group, int64_t* n_out) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  if (ix->kind != KIND_PQ) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  if (G <= 0 || !group_vectors || !out_ids || !out_group || !n_out) return fail(FREDDY_E_ARG, "bad argument");
+  if (n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FREDDY_E_ARG, "bad subset");
+  *n_out = 0;
+  HIP_TRY(hipSetDevice(ix->device));
+  hipStream_t s = ix->stream;
+  const int m = ix->m, K = ix->K, d = ix->d;
+  const size_t lutN = (size_t)m * K;
+  if (lutN * sizeof(float) > 160 * 1024) return fail(FREDDY_E_LIMIT, "m*K=%zu LUT entries exceed the 160 KiB of LDS", lutN);
+  const int32_t* blk_off = ix->blk_off;
+  const uint32_t* packed = ix->packed;
+  const int32_t* pos = ix->pos;
+  int64_t n_blocks = ix->n_blocks;
+  if (subset_ids)
+    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
+  (void)blk_off;
+  if (n_blocks == 0) return FREDDY_OK;
+  if (ix->w_q.ensure(sizeof(float) * (size_t)G * d) || ix->w_lut.ensure(sizeof(float) * (size_t)G * lutN) ||
+      ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)n_blocks * 64))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  HIP_TRY(hipMemcpyAsync(ix->w_q.p, group_vectors, sizeof(float) * (size_t)G * d, hipMemcpyHostToDevice, s));
+  if (int rc = launch_lut(ix, s, ix->w_q.as<float>(), nullptr, ix->w_lut.as<float>(), G)) return rc;   // freddy.c:1288-1299
+  static bool gattr = false;
+  if (!gattr) {
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grouping_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grouping_kernel<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grouping_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    gattr = true;
+  }
+  const dim3 grid((unsigned)((n_blocks + GROUP_BLOCKS - 1) / GROUP_BLOCKS));
+  timed_launch(ix, s, "grouping", [&] {
+    if (ix->M2 == 6)
+      hipLaunchKernelGGL((grouping_kernel<6>), grid, dim3(WG), lutN * sizeof(float), s, ix->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ix->w_out_ids.as<int32_t>());
+    else if (ix->M2 == 15)
+      hipLaunchKernelGGL((grouping_kernel<15>), grid, dim3(WG), lutN * sizeof(float), s, ix->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ix->w_out_ids.as<int32_t>());
+    else
+      hipLaunchKernelGGL((grouping_kernel<0>), grid, dim3(WG), lutN * sizeof(float), s, ix->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ix->w_out_ids.as<int32_t>());
+  });
+  HIP_TRY(hipGetLastError());
+  std::vector<int32_t> h_grp((size_t)n_blocks * 64), h_pos((size_t)n_blocks * 64);
+  HIP_TRY(hipMemcpyAsync(h_grp.data(), ix->w_out_ids.p, sizeof(int32_t) * h_grp.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_pos.data(), pos, sizeof(int32_t) * h_pos.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  int64_t n = 0;
+  for (size_t i = 0; i < h_pos.size(); ++i)
+    if (h_pos[i] >= 0) { out_ids[n] = ix->h_ids[(size_t)h_pos[i]]; out_group[n] = h_grp[i]; ++n; }
+  *n_out = n;
   return FREDDY_OK;
 }
 

@@ -711,6 +711,69 @@ __global__ __launch_bounds__(64) void merge_replay_kernel(MergeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// grouping_pq (freddy.c:1176-1401): nearest of G group LUTs for every row.
+//   Per row: for g = 0..G-1 the ADC sum over positions 0..m-1 in order (:1346-1351), nearest by strict
+//   "<" starting from minDist = 100 (:1337,1353-1356) -> the first of equally near groups, -1 if none is
+//   nearer than 100.  A workgroup owns GROUP_BLOCKS row blocks (lane <-> row, 4 rows per thread, their
+//   code dwords stay in registers) and walks the groups, staging one LUT at a time in LDS.
+// ---------------------------------------------------------------------------------------
+static constexpr int GROUP_BLOCKS = 16;
+template <int M2>   // dwords of codes per row; 0: read the codes from memory for every group (any m)
+__global__ __launch_bounds__(WG) void grouping_kernel(const float* __restrict__ lut, int G, int m, int K,
+                                                     const uint32_t* __restrict__ packed, int n_blocks,
+                                                     int32_t* __restrict__ out_group) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* sl = reinterpret_cast<float*>(smem);   // [m][K]
+  constexpr int RPT = GROUP_BLOCKS * 64 / WG;   // rows per thread
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m2 = M2 ? M2 : m / 2;
+  uint32_t cw[RPT][M2 ? M2 : 1];
+  float best[RPT];
+  int bi[RPT];
+  int blk[RPT];
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int b = blockIdx.x * GROUP_BLOCKS + r * (WG / 64) + wave;
+    blk[r] = b < n_blocks ? b : n_blocks - 1;
+    best[r] = 100.0f;
+    bi[r] = -1;
+    if (M2) {
+#pragma unroll
+      for (int j = 0; j < (M2 ? M2 : 1); ++j) cw[r][j] = packed[((size_t)blk[r] * m2 + j) * 64 + lane];
+    }
+  }
+  for (int g = 0; g < G; ++g) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < m * K; i += WG) sl[i] = lut[(size_t)g * m * K + i];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      float dist = 0.0f;
+      if (M2) {
+#pragma unroll
+        for (int j = 0; j < (M2 ? M2 : 1); ++j) {
+          const uint32_t w = cw[r][j];
+          dist = dist + sl[(2 * j) * K + (int)(w & 0xffffu)];
+          dist = dist + sl[(2 * j + 1) * K + (int)(w >> 16)];
+        }
+      } else {
+        for (int j = 0; j < m2; ++j) {
+          const uint32_t w = packed[((size_t)blk[r] * m2 + j) * 64 + lane];
+          dist = dist + sl[(2 * j) * K + (int)(w & 0xffffu)];
+          dist = dist + sl[(2 * j + 1) * K + (int)(w >> 16)];
+        }
+      }
+      if (dist < best[r]) { best[r] = dist; bi[r] = g; }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RPT; ++r) {
+    const int b = blockIdx.x * GROUP_BLOCKS + r * (WG / 64) + wave;
+    if (b < n_blocks) out_group[(size_t)b * 64 + lane] = bi[r];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // pq_search_in: gather the packed codes of a row subset into a temporary list
 // ("SELECT id, vector FROM pq_quantization WHERE id IN (...)", freddy.c:1100-1114)
 // ---------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ EXPORTS = [
     "freddy_gpu_pq_search", "freddy_gpu_ivfadc_search", "freddy_gpu_knn_join",
     "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
-    "freddy_gpu_last_scanned_rows", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search",
+    "freddy_gpu_last_scanned_rows", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
 ]
 
 
@@ -183,6 +183,17 @@ class PQIndex(_Index):
         _check(self.lib.freddy_gpu_pq_search(self.h, _p(qs), Q, k, C.c_float(sentinel), _p(sub),
                                              0 if sub is None else sub.size, _p(out_i), _p(out_d)))
         return out_i, out_d
+
+    def grouping(self, group_vectors, subset_ids=None):
+        """grouping_pq: (ids, group index) of every (requested) row; groups tried in the given order."""
+        gv = _f32(group_vectors).reshape(-1, self.d)
+        sub = None if subset_ids is None else _i32(subset_ids)
+        cap = self.N if sub is None else max(sub.size, 1)
+        oi = np.empty(cap, np.int32); og = np.empty(cap, np.int32)
+        n = C.c_int64(0)
+        _check(self.lib.freddy_gpu_grouping_pq(self.h, _p(gv), gv.shape[0], _p(sub), 0 if sub is None else sub.size,
+                                               _p(oi), _p(og), C.byref(n)))
+        return oi[:n.value], og[:n.value]
 
     def search_dev(self, d_queries_ptr, Q, k, sentinel, d_out_ids_ptr, d_out_dist_ptr, stream=None):
         _check(self.lib.freddy_gpu_pq_search_dev(self.h, C.c_void_p(d_queries_ptr), Q, k, C.c_float(sentinel),

@@ -19,6 +19,7 @@ LIB_PATH = os.path.join(_PKG, "libfreddy_host.so")
 
 ROW2 = np.dtype([("id", np.int32), ("distance", np.float32)])
 ROW3 = np.dtype([("query_id", np.int32), ("id", np.int32), ("distance", np.float32)])
+GROUP_ROW = np.dtype([("id", np.int32), ("group_id", np.int32)])
 
 _lib = None
 
@@ -165,6 +166,24 @@ class Session:
         n = C.c_int32(0)
         self._check(self.lib.knn_in_exact(self.h, _p(q), q.size, k, _p(ids), ids.size, _p(out), C.byref(n)))
         return out[:n.value]
+
+    def grouping_pq(self, input_ids, group_ids):
+        """freddy.c:1176-1401: rows (id, group_id)."""
+        ids, groups = _i32(input_ids), _i32(group_ids)
+        out = np.empty(max(ids.size, 1), GROUP_ROW)
+        n = C.c_int32(0)
+        self._check(self.lib.grouping_pq(self.h, _p(ids), ids.size, _p(groups), groups.size, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def analogy_3cosadd_pq(self, id1, id2, id3):
+        r = C.c_int32(-1)
+        self._check(self.lib.analogy_3cosadd_pq(self.h, int(id1), int(id2), int(id3), C.byref(r)))
+        return r.value
+
+    def analogy_3cosadd_ivfadc(self, id1, id2, id3):
+        r = C.c_int32(-1)
+        self._check(self.lib.analogy_3cosadd_ivfadc(self.h, int(id1), int(id2), int(id3), C.byref(r)))
+        return r.value
 
     def pq_search_in_batch(self, queries, query_ids, k, input_ids, use_targetlist=True):
         qs, qid, ids = _f32(queries), _i32(query_ids), _i32(input_ids)

@@ -8,6 +8,7 @@
 #include "../../include/freddy_udf.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -380,6 +381,88 @@ int k_nearest_neighbour(freddy_session_t* s, const float* query, int32_t dim, in
 int knn_in_exact(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
                  freddy_row2* out, int32_t* n_rows) {
   return exact_common(s, query, dim, k, input_ids, n_ids, true, out, n_rows);
+}
+
+// ---- grouping and analogy on the PQ / IVFADC indexes ---------------------------------------
+static const float* norm_vec_of(const freddy_session* s, int32_t id) {
+  auto it = std::lower_bound(s->norm_ids.begin(), s->norm_ids.end(), id);
+  if (it == s->norm_ids.end() || *it != id) return nullptr;
+  return s->norm_vecs.data() + (size_t)(it - s->norm_ids.begin()) * s->d;
+}
+
+int grouping_pq(freddy_session_t* s, const int32_t* input_ids, int32_t n_ids, const int32_t* group_ids, int32_t n_groups,
+                freddy_group_row* out, int32_t* n_rows) {
+  if (!s || !s->pq) return fail(-1, "pq_quantization / pq_codebook are not loaded");
+  if (s->norm_ids.empty() || s->d != s->pq_d) return fail(-1, "google_vecs_norm is not loaded");
+  if (n_ids < 0 || n_groups <= 0 || !group_ids || !out || (n_ids > 0 && !input_ids)) return fail(-1, "bad argument");
+  std::vector<int32_t> groups(group_ids, group_ids + n_groups);
+  std::sort(groups.begin(), groups.end());                                       // freddy.c:1241
+  std::vector<float> gvec((size_t)n_groups * s->d);
+  for (int g = 0; g < n_groups; ++g) {
+    // "SELECT id, vector ... WHERE id IN (groups) ORDER BY id ASC" must return one row per group id (:1262-1265)
+    const float* v = (g > 0 && groups[g] == groups[g - 1]) ? nullptr : norm_vec_of(s, groups[g]);
+    if (!v) return fail(-1, "Group ids do not exist");
+    memcpy(&gvec[(size_t)g * s->d], v, sizeof(float) * s->d);
+  }
+  if (n_rows) *n_rows = 0;
+  if (n_ids == 0) return 0;
+  std::vector<int32_t> ids((size_t)n_ids), grp((size_t)n_ids);
+  int64_t n = 0;
+  if (int rc = freddy_gpu_grouping_pq(s->pq, gvec.data(), n_groups, input_ids, n_ids, ids.data(), grp.data(), &n)) return gpu_fail(rc);
+  for (int64_t i = 0; i < n; ++i) { out[i].id = ids[i]; out[i].group_id = grp[i] >= 0 ? groups[grp[i]] : -1; }
+  if (n_rows) *n_rows = (int32_t)n;
+  return 0;
+}
+
+// vec_minus_bytea / vec_plus_bytea / vec_normalize_bytea / cosine_similarity_bytea   core_functions.c:118-136,177-195,241-266,67-81
+static void vec3cosadd(const float* v1, const float* v2, const float* v3, int d, std::vector<float>& raw, std::vector<float>& unit) {
+  raw.resize(d); unit.resize(d);
+  for (int i = 0; i < d; ++i) { const float t = v3[i] - v1[i]; raw[i] = t + v2[i]; }
+  float sq = 0;
+  for (int i = 0; i < d; ++i) { const float p = raw[i] * raw[i]; sq = sq + p; }
+  const float length = (float)sqrt((double)sq);
+  for (int i = 0; i < d; ++i) unit[i] = raw[i] / length;
+}
+static float cos_sim_bytea(const float* a, const float* b, int d) {
+  float scalar = 0;
+  for (int i = 0; i < d; ++i) { const float p = a[i] * b[i]; scalar = scalar + p; }
+  return scalar;
+}
+
+// analogy_3cosadd_pq / analogy_3cosadd_ivfadc, by row id   freddy--0.0.1.sql:1317-1346, 1428-1460
+static int analogy_common(freddy_session_t* s, bool ivf, int32_t id1, int32_t id2, int32_t id3, int32_t* result) {
+  if (!s || !result) return fail(-1, "bad argument");
+  if (ivf ? !s->ivf : !s->pq) return fail(-1, ivf ? "coarse_quantization / residual_codebook / fine_quantization are not loaded"
+                                                  : "pq_quantization / pq_codebook are not loaded");
+  if (s->norm_ids.empty() || s->d != (ivf ? s->ivf_d : s->pq_d)) return fail(-1, "google_vecs_norm is not loaded");
+  *result = -1;
+  const float *v1 = norm_vec_of(s, id1), *v2 = norm_vec_of(s, id2), *v3 = norm_vec_of(s, id3);
+  if (!v1 || !v2 || !v3) return 0;            // the cross join over the three words is empty: NULL
+  std::vector<float> raw, unit;
+  vec3cosadd(v1, v2, v3, s->d, raw, unit);
+  const int k = s->pvf + 3;
+  std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+  const int rc = ivf ? freddy_gpu_ivfadc_search(s->ivf, unit.data(), 1, k, s->w, 1000.0f, FREDDY_FOUND_ROWS, ids.data(), dist.data())
+                     : freddy_gpu_pq_search(s->pq, unit.data(), 1, k, 100.0f, nullptr, 0, ids.data(), dist.data());
+  if (rc) return gpu_fail(rc);
+  // ... ORDER BY cosine_similarity_bytea(v3 - v1 + v2, v4.vector) DESC FETCH FIRST 1 ROWS ONLY (ties: lowest id)
+  bool have = false;
+  float best = 0;
+  for (int i = 0; i < k; ++i) {
+    const int32_t id = ids[i];
+    if (id < 0 || id == id1 || id == id2 || id == id3) continue;
+    const float* v4 = norm_vec_of(s, id);
+    if (!v4) continue;
+    const float sim = cos_sim_bytea(raw.data(), v4, s->d);
+    if (!have || sim > best || (sim == best && id < *result)) { have = true; best = sim; *result = id; }
+  }
+  return 0;
+}
+int analogy_3cosadd_pq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, int32_t* result) {
+  return analogy_common(s, false, id1, id2, id3, result);
+}
+int analogy_3cosadd_ivfadc(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, int32_t* result) {
+  return analogy_common(s, true, id1, id2, id3, result);
 }
 
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]) {

@@ -57,7 +57,8 @@ def test_host_mirror_exports_every_declared_symbol():
     names = sorted(set(re.findall(r"\b([a-z_0-9]+)\s*\(freddy_session_t\b|\b(freddy_[a-z0-9_]+)\s*\(", src)))
     flat = sorted({n for pair in names for n in pair if n})
     assert {"pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search",
-            "ivpq_search_in", "knn_join", "k_nearest_neighbour", "knn_in_exact"} <= set(flat)
+            "ivpq_search_in", "knn_join", "k_nearest_neighbour", "knn_in_exact", "grouping_pq",
+            "analogy_3cosadd_pq", "analogy_3cosadd_ivfadc"} <= set(flat)
     for n in flat:
         assert hasattr(lib, n), f"{n} declared in include/freddy_udf.h but not exported"
 

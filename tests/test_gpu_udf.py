@@ -117,3 +117,47 @@ def test_k_nearest_neighbour_and_knn_in_exact(db, oracle):
     assert len(rows) == 4                                   # FETCH FIRST returns only existing rows
     same(rows, exp)
     assert len(s.knn_in_exact(q, 3, [])) == 0
+
+
+def test_grouping_pq(db, oracle):
+    """Next row 8f-3: `SELECT * FROM grouping_pq('{ids}'::int[], '{groups}'::int[])` (freddy.c:1176-1401)."""
+    s, t = db
+    from freddy_amd import udf
+    groups = np.array([9000, 12, 4400, 17017], np.int32)          # unsorted: the UDF sorts them (freddy.c:1241)
+    asked = np.concatenate([np.arange(1, N + 1, 7), [5, 5, N + 10, -1]]).astype(np.int32)
+    rows = s.grouping_pq(asked, groups)
+    sg = np.sort(groups)
+    ids, grp = oracle.grouping_pq(t["pq"], t["x"][sg - 1], asked)
+    assert np.array_equal(rows["id"], ids)
+    assert np.array_equal(rows["group_id"], np.where(grp >= 0, sg[np.maximum(grp, 0)], -1))
+    assert set(np.unique(rows["group_id"]).tolist()) <= set(sg.tolist())
+    assert len(np.unique(rows["group_id"])) > 1
+    assert len(s.grouping_pq([], groups)) == 0
+    with pytest.raises(udf.FreddyError, match="Group ids do not exist"):
+        s.grouping_pq(asked, [12, N + 5])
+    with pytest.raises(udf.FreddyError, match="Group ids do not exist"):
+        s.grouping_pq(asked, [12, 12])
+
+
+@pytest.mark.parametrize("which", ["pq", "ivfadc"])
+def test_analogy_3cosadd(db, oracle, which):
+    """analogy_3cosadd_pq / _ivfadc (freddy--0.0.1.sql:1317-1346, 1428-1460) composed from the oracle's
+    pieces: vec ops, pq_search / ivfadc_search with k = get_pvf() + 3, exact re-ranking."""
+    s, t = db
+    x = t["x"]
+    s.set_pvf(6); s.set_w(3)
+    for (i1, i2, i3) in ((10, 200, 3000), (4321, 4322, 77), (15000, 8, 9)):
+        raw = oracle.vec_plus(oracle.vec_minus(x[i3 - 1], x[i1 - 1]), x[i2 - 1])
+        unit = oracle.vec_normalize(raw)
+        cands = oracle.pq_search(t["pq"], unit, 9) if which == "pq" else oracle.ivfadc_search(t["ivf"], unit, 9, 3)
+        best, bid = None, -1
+        for cid in cands["id"].tolist():
+            if cid < 0 or cid in (i1, i2, i3):
+                continue
+            sim = oracle.cosine_similarity_bytea(raw, x[cid - 1])
+            if best is None or sim > best or (sim == best and cid < bid):
+                best, bid = sim, cid
+        got = s.analogy_3cosadd_pq(i1, i2, i3) if which == "pq" else s.analogy_3cosadd_ivfadc(i1, i2, i3)
+        assert got == bid and got > 0
+    assert s.analogy_3cosadd_pq(1, 2, N + 99) == -1              # unknown word: NULL
+    s.set_pvf(20)

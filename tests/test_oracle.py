@@ -427,3 +427,39 @@ def test_exact_knn_oracle(oracle):
     ids2 = np.arange(1, 23, dtype=np.int32)
     got = oracle.exact_knn(x2, ids2, x[5], 3)
     assert got["id"].tolist() == [6, 21, 22]
+
+
+def test_vec_ops_and_grouping_pq_oracle(oracle):
+    """core_functions.c vec_minus/plus/normalize_bytea and grouping_pq (freddy.c:1176-1401) against
+    step-wise binary32 Python models."""
+    x = util.corpus(3000).numpy()
+    a, b, c = x[1], x[2], x[3]
+    raw = np.array([f32(f32(cc - aa) + bb) for aa, bb, cc in zip(a, b, c)], f32)
+    assert np.array_equal(oracle.vec_plus(oracle.vec_minus(c, a), b).view(np.uint32), raw.view(np.uint32))
+    sq = f32(0)
+    for v in raw:
+        sq = f32(sq + f32(v * v))
+    length = f32(np.sqrt(np.float64(sq)))
+    unit = np.array([f32(v / length) for v in raw], f32)
+    assert np.array_equal(oracle.vec_normalize(raw).view(np.uint32), unit.view(np.uint32))
+
+    t = util.pq_tables(N=3000, K=64)
+    ot = oracle.pq_table(t["codebook"], t["ids"], t["codes"])
+    gvec = x[[10, 500, 2222]]
+    asked = [7, 7, 2999, 1, 5000, -2, 1500]
+    ids, grp = oracle.grouping_pq(ot, gvec, asked)
+    assert ids.tolist() == [1, 7, 1500, 2999]                      # table order, de-duplicated, unknown ids dropped
+    luts = [oracle.lut(g, t["codebook"]) for g in gvec]
+    K = t["codebook"].shape[1]
+    for i, g in zip(ids, grp):
+        best, md = -1, f32(100)
+        for gi, L in enumerate(luts):
+            acc = f32(0)
+            for j, code in enumerate(t["codes"][i - 1]):
+                acc = f32(acc + L[j * K + code])
+            if acc < md:
+                md, best = acc, gi
+        assert best == g
+    # a duplicated group vector: the FIRST of the equally near groups wins (strict <)
+    ids2, grp2 = oracle.grouping_pq(ot, np.stack([gvec[1], gvec[1], gvec[0]]), [501])
+    assert grp2.tolist() in ([0], [2]) and 1 not in grp2.tolist()
