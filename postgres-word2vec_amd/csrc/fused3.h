@@ -430,7 +430,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
       lds_barrier();
       // S2: survivors -> this wave's region of each item's buffer
       if (!(a.ablate & 4)) {
-        const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
@@ -450,7 +449,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
               const bool pass = bits(g, r) <= tau;
               const u64 mask = __ballot(pass);
               if (mask != 0ull) {
-                if (pass) dst[run + __popcll(mask & lt)] = ((u64)bits(g, r) << 32) | (u64)(uint32_t)pid[r];
+                if (pass) dst[run + lanes_below(mask)] = ((u64)bits(g, r) << 32) | (u64)(uint32_t)pid[r];
                 run += __popcll(mask);
               }
             }

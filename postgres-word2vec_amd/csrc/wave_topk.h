@@ -27,6 +27,11 @@ __device__ __forceinline__ u64 make_key(float dist, uint32_t pos) {
 __device__ __forceinline__ float key_dist(u64 key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t key_pos(u64 key) { return (uint32_t)key; }
 
+// number of set bits of a ballot mask below this lane (v_mbcnt: no per-lane mask register to keep alive)
+__device__ __forceinline__ int lanes_below(u64 mask) {
+  return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
 __device__ __forceinline__ u64 umin64(u64 a, u64 b) { return a < b ? a : b; }
 __device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a < b ? b : a; }
 
@@ -229,9 +234,8 @@ struct WaveSelect {
     if (n) {
       if (pending + n > 64) flush();
       const int lane = lane_id();
-      const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
       // after a flush tau may have dropped; a key that no longer passes is still harmless
-      if (pass) stage[pending + __popcll(mask & lt)] = key;
+      if (pass) stage[pending + lanes_below(mask)] = key;
       pending += n;
       __builtin_amdgcn_wave_barrier();
     }
