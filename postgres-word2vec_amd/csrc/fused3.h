@@ -302,13 +302,16 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
       const int next_gid = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
       const int next_cnt = next_gid >= 0 ? __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8 + 1]) : 0;
       stage_residuals(nb, next_cnt, tid, SPEC2_NB * 64, M - 1, M);
+      // ... and slab(0) of the next entry, one block of four items per phase: P(M-1), S1, S2.  Buffer 0 is
+      // free (the gatherers read buffer 1, then select), position 0 of the next residuals was staged in
+      // P(STAGE_P0), position 0 of the codebook was requested after the last build.
+      const int c1 = next_cnt < 4 ? next_cnt : 4, c2 = next_cnt < 8 ? next_cnt : 8;
+      if (!(a.ablate & 1)) build_slab(0, slab, 0, c1, next_cnt);
       lds_barrier();
       tick(2);   // P(M-1)
-      // S1 / S2: slab(0) of the next entry in two halves (buffer 0 is free: the gatherers are selecting)
-      const int half = ((next_cnt + 7) >> 3) << 2;   // split point, a multiple of 4
-      if (!(a.ablate & 1)) build_slab(0, slab, 0, half < next_cnt ? half : next_cnt, next_cnt);
+      if (!(a.ablate & 1)) build_slab(0, slab, c1, c2, next_cnt);
       lds_barrier();
-      if (!(a.ablate & 1)) build_slab(0, slab, half, next_cnt, next_cnt);
+      if (!(a.ablate & 1)) build_slab(0, slab, c2, next_cnt, next_cnt);
       load_cb(1);
       lds_barrier();
       tick(3);   // S1 + S2
