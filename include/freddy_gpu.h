@@ -159,6 +159,21 @@ int freddy_gpu_exact_search(freddy_gpu_index_t* vecs, const float* queries, int3
 int freddy_gpu_grouping_pq(freddy_gpu_index_t* pq, const float* group_vectors, int32_t G, const int32_t* subset_ids,
                            int64_t n_subset, int32_t* out_ids, int32_t* out_group, int64_t* n_out);
 
+/* ---- next row: index build, encoding step --------------------------------------------
+ * What index_creation/pq_index.py:65-92 (create_index / create_index_with_faiss) and ivfadc.py do once
+ * the quantizers are trained: every vector's coarse cell (nearest of C centroids, all d dimensions) and
+ * its PQ code (per position the nearest codeword of the -- residual, if coarse != NULL -- sub-vector),
+ * by squareDistance with the lowest index on ties.  Standalone: no index handle, tables and vectors are
+ * host arrays, results are host arrays.  out_cell may be NULL when coarse is NULL. */
+typedef struct freddy_encode_desc {
+  int32_t d, m, K;
+  const float* codebook;   /* [m][K][d/m] */
+  int32_t C;               /* 0: flat PQ (no coarse quantizer) */
+  const float* coarse;     /* [C][d] or NULL */
+} freddy_encode_desc;
+int freddy_gpu_encode(const freddy_encode_desc* desc, int device, const float* vectors, int64_t N, int32_t* out_cell,
+                      int16_t* out_codes);
+
 /* ---- device-resident variant used for throughput measurement ----------------------------
  * Same as freddy_gpu_ivfadc_search, but queries / outputs are DEVICE pointers on the
  * index's device and all work is enqueued on `hip_stream` (a hipStream_t; NULL = the

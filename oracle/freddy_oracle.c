@@ -895,3 +895,29 @@ int fo_grouping_pq(const fo_pq_table* t, const float* group_vecs, int n_groups, 
   free(luts);
   return (int)n_rows;
 }
+
+/* ---- next row ------------------------------------------------------------------ */
+void fo_encode_pq(const float* codebook, int m, int K, int s, const float* vecs, int64_t n, int16_t* codes) {
+  const int d = m * s;
+  for (int64_t i = 0; i < n; ++i)
+    for (int p = 0; p < m; ++p) {
+      float min_dist = 0;
+      int code = -1;
+      for (int j = 0; j < K; ++j) {                                   /* pq_index.py:78-86 */
+        const float dist = fo_sqdist(vecs + (size_t)i * d + (size_t)p * s, codebook + ((size_t)p * K + j) * s, s);
+        if (code < 0 || dist < min_dist) { min_dist = dist; code = j; }
+      }
+      codes[(size_t)i * m + p] = (int16_t)code;
+    }
+}
+void fo_assign_coarse(const float* coarse, int C, int d, const float* vecs, int64_t n, int32_t* cell) {
+  for (int64_t i = 0; i < n; ++i) {
+    float min_dist = 0;
+    int best = -1;
+    for (int c = 0; c < C; ++c) {
+      const float dist = fo_sqdist(vecs + (size_t)i * d, coarse + (size_t)c * d, d);
+      if (best < 0 || dist < min_dist) { min_dist = dist; best = c; }
+    }
+    cell[i] = best;
+  }
+}

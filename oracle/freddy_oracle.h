@@ -192,6 +192,16 @@ void fo_vec_normalize(const float* v, int n, float* out);
 int fo_grouping_pq(const fo_pq_table* t, const float* group_vecs, int n_groups, const int32_t* input_ids,
                    int n_ids, int32_t* out_ids, int32_t* out_group);
 
+/* ---- next row: index build ------------------------------------------------------------
+ * PQ encoding as index_creation/pq_index.py:65-92 (create_index): per position the code whose codeword
+ * is nearest to the sub-vector, strict "<" over the codes in order = lowest code on ties.  The
+ * reference measures with np.linalg.norm; this restatement uses squareDistance (same argmin up to
+ * rounding; bit-exactness is defined against THIS arithmetic).  codes: [n][m].                          */
+void fo_encode_pq(const float* codebook, int m, int K, int s, const float* vecs, int64_t n, int16_t* codes);
+/* coarse assignment (ivfadc.py / quantizer_creation.py:41-49: faiss IndexFlatL2, k = 1): nearest centroid
+ * by squareDistance over all d dimensions, lowest index on ties. */
+void fo_assign_coarse(const float* coarse, int C, int d, const float* vecs, int64_t n, int32_t* cell);
+
 /* SRF emit text round trip               freddy.c:164 ("%f" into a 16-byte buffer) */
 float fo_emit_roundtrip(float dist);
 

@@ -88,6 +88,8 @@ class Oracle:
         L.fo_vec_plus.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.fo_vec_normalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.fo_grouping_pq.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.fo_encode_pq.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
+        L.fo_assign_coarse.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
         L.fo_multi_index_select.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                             C.c_float, C.c_void_p, C.c_void_p]
 
@@ -164,6 +166,19 @@ class Oracle:
         n = self.lib.fo_grouping_pq(C.byref(table), _p(gv), gv.shape[0], _p(ids), ids.size, _p(oi), _p(og))
         assert n >= 0
         return oi[:n], og[:n]
+
+    def encode_pq(self, codebook, vecs):
+        cb, v = _f32(codebook), _f32(vecs)
+        m, K, s_ = cb.shape
+        out = np.empty((v.shape[0], m), np.int16)
+        self.lib.fo_encode_pq(_p(cb), m, K, s_, _p(v), v.shape[0], _p(out))
+        return out
+
+    def assign_coarse(self, coarse, vecs):
+        c, v = _f32(coarse), _f32(vecs)
+        out = np.empty(v.shape[0], np.int32)
+        self.lib.fo_assign_coarse(_p(c), c.shape[0], c.shape[1], _p(v), v.shape[0], _p(out))
+        return out
 
     def confidence_hyp(self, expect, size, p, stat_size):
         return np.float32(self.lib.fo_confidence_hyp(int(expect), int(size), C.c_float(float(p)), int(stat_size)))

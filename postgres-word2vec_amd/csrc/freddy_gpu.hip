@@ -964,6 +964,84 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
 }
 
 // ---------------------------------------------------------------------------------------
+// index build: encoding
+// ---------------------------------------------------------------------------------------
+extern "C" int freddy_gpu_encode(const freddy_encode_desc* t, int device, const float* vectors, int64_t N, int32_t* out_cell,
+                                 int16_t* out_codes) {
+  if (!t || !t->codebook || !out_codes || N < 0 || (N > 0 && !vectors)) return fail(FREDDY_E_ARG, "NULL argument");
+  if (t->d <= 0 || t->m <= 0 || t->K <= 0 || t->d % t->m) return fail(FREDDY_E_ARG, "bad shape d=%d m=%d K=%d", t->d, t->m, t->K);
+  if (t->K > 32767) return fail(FREDDY_E_LIMIT, "K=%d does not fit an int16 code", t->K);
+  if ((t->C > 0) != (t->coarse != nullptr)) return fail(FREDDY_E_ARG, "coarse and C must be given together");
+  if (t->C > 0 && !out_cell) return fail(FREDDY_E_ARG, "out_cell is required with a coarse quantizer");
+  if (N == 0) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(device));
+  const int d = t->d, m = t->m, K = t->K, S = d / m, C = t->C;
+  const int Cpad = ((C + 63) / 64) * 64;
+  std::vector<float> cbT((size_t)m * S * K);
+  for (int p = 0; p < m; ++p)
+    for (int c = 0; c < K; ++c)
+      for (int i = 0; i < S; ++i) cbT[((size_t)p * S + i) * K + c] = t->codebook[((size_t)p * K + c) * S + i];
+  std::vector<float> cT;
+  if (C) {
+    cT.assign((size_t)d * Cpad, 0.0f);
+    for (int c = 0; c < C; ++c)
+      for (int i = 0; i < d; ++i) cT[(size_t)i * Cpad + c] = t->coarse[(size_t)c * d + i];
+  }
+  const int64_t chunk = std::min<int64_t>(N, 1 << 16);
+  float *d_cbT = nullptr, *d_cT = nullptr, *d_coarse = nullptr, *d_vec = nullptr, *d_res = nullptr;
+  int32_t* d_cell = nullptr;
+  int16_t* d_codes = nullptr;
+  int rc = FREDDY_OK;
+  hipStream_t s = nullptr;
+  auto cleanup = [&] {
+    void* ptrs[] = {d_cbT, d_cT, d_coarse, d_vec, d_res, d_cell, d_codes};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (s) (void)hipStreamDestroy(s);
+  };
+#define ENC_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) { cleanup(); return fail(FREDDY_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } \
+  } while (0)
+  ENC_TRY(hipStreamCreate(&s));
+  ENC_TRY(hipMalloc((void**)&d_cbT, sizeof(float) * cbT.size()));
+  ENC_TRY(hipMalloc((void**)&d_vec, sizeof(float) * (size_t)chunk * d));
+  ENC_TRY(hipMalloc((void**)&d_codes, sizeof(int16_t) * (size_t)chunk * m));
+  ENC_TRY(hipMemcpyAsync(d_cbT, cbT.data(), sizeof(float) * cbT.size(), hipMemcpyHostToDevice, s));
+  if (C) {
+    ENC_TRY(hipMalloc((void**)&d_cT, sizeof(float) * cT.size()));
+    ENC_TRY(hipMalloc((void**)&d_coarse, sizeof(float) * (size_t)C * d));
+    ENC_TRY(hipMalloc((void**)&d_res, sizeof(float) * (size_t)chunk * d));
+    ENC_TRY(hipMalloc((void**)&d_cell, sizeof(int32_t) * (size_t)chunk));
+    ENC_TRY(hipMemcpyAsync(d_cT, cT.data(), sizeof(float) * cT.size(), hipMemcpyHostToDevice, s));
+    ENC_TRY(hipMemcpyAsync(d_coarse, t->coarse, sizeof(float) * (size_t)C * d, hipMemcpyHostToDevice, s));
+  }
+  for (int64_t i0 = 0; i0 < N; i0 += chunk) {
+    const int n = (int)std::min<int64_t>(chunk, N - i0);
+    ENC_TRY(hipMemcpyAsync(d_vec, vectors + (size_t)i0 * d, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice, s));
+    const float* src = d_vec;
+    if (C) {
+      hipLaunchKernelGGL(assign_coarse_kernel, dim3((unsigned)n), dim3(64), 0, s, (const float*)d_vec, (const float*)d_cT, d_cell, n, C, Cpad, d);
+      hipLaunchKernelGGL(residual_kernel, dim3((unsigned)n), dim3(WG), 0, s, (const float*)d_vec, (const float*)d_coarse,
+                         (const int32_t*)d_cell, (const int32_t*)nullptr, d_res, d, S, S);
+      src = d_res;
+    }
+    const int ipw = 64;
+    const dim3 grid((unsigned)m, (unsigned)((n + ipw - 1) / ipw));
+    if (S == 25) hipLaunchKernelGGL((encode_pq_kernel<25, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S);
+    else if (S == 10) hipLaunchKernelGGL((encode_pq_kernel<10, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S);
+    else hipLaunchKernelGGL((encode_pq_kernel<0, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S);
+    ENC_TRY(hipGetLastError());
+    ENC_TRY(hipMemcpyAsync(out_codes + (size_t)i0 * m, d_codes, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, s));
+    if (C) ENC_TRY(hipMemcpyAsync(out_cell + i0, d_cell, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+    ENC_TRY(hipStreamSynchronize(s));
+  }
+#undef ENC_TRY
+  cleanup();
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------
 // kNN-join (ivpq_search_in): host loop in join.h
 // ---------------------------------------------------------------------------------------
 extern "C" int freddy_gpu_knn_join(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k,

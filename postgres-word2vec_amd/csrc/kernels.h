@@ -356,7 +356,7 @@ __global__ __launch_bounds__(WG) void residual_kernel(const float* __restrict__ 
   const int item = blockIdx.x;
   const int cell = item_cell[item];
   if (cell < 0) return;
-  const float* q = queries + (size_t)item_query[item] * d;
+  const float* q = queries + (size_t)(item_query ? item_query[item] : item) * d;   // (NULL: item i is query i)
   const float* c = coarse + (size_t)cell * d;
   const int row = (d / S) * SP;
   for (int o = threadIdx.x; o < row; o += WG) {
@@ -414,6 +414,102 @@ __global__ __launch_bounds__(WG) void lut_build_kernel(const float* __restrict__
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Index build: PQ encoding = exact 1-NN of every sub-vector among its position's K
+// codewords by squareDistance, lowest code on ties (index_creation/pq_index.py:65-92 "create_index":
+// strict "<" over the codes in order).  Same register-cached codebook slice and the same sequential
+// fp32 chain as lut_build_kernel, but the K distances of an item are reduced to their argmin instead of
+// being stored: key = (distance bits << 32 | code), minimum over the lane's codes, the wave, the
+// workgroup.  S == 0: runtime sub-vector size, codebook streamed from L2.
+//   grid (m, ceil(n_items / items_per_wg)); codes[item][p] int16.
+// ---------------------------------------------------------------------------------------
+template <int S, int E>
+__global__ __launch_bounds__(WG) void encode_pq_kernel(const float* __restrict__ vecs, const float* __restrict__ cbT,
+                                                      int16_t* __restrict__ codes, int n_items, int items_per_wg, int m,
+                                                      int K, int d, int S_rt) {
+  __shared__ u64 wmin[WG / 64];
+  const int p = blockIdx.x;
+  const int it0 = blockIdx.y * items_per_wg;
+  const int it1 = (it0 + items_per_wg < n_items) ? it0 + items_per_wg : n_items;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int Sr = S ? S : S_rt;
+  for (int it = it0; it < it1; ++it) {
+    const float* r = vecs + (size_t)it * d + (size_t)p * Sr;
+    u64 best = KEY_INF;
+    for (int c0 = 0; c0 < K; c0 += WG * E) {
+      // (for K <= WG*E, i.e. every configuration of the reference, this loop runs once and the compiler
+      // keeps the codebook slice in registers across the items of the workgroup)
+      float acc[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = 0.0f;
+      if (S) {
+#pragma unroll
+        for (int j = 0; j < (S ? S : 1); ++j) {
+          const float rj = r[j];
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int c = c0 + e * WG + (int)threadIdx.x;
+            const float cv = (c < K) ? cbT[((size_t)p * S + j) * K + c] : 0.0f;
+            const float t = rj - cv;
+            const float pr = t * t;
+            acc[e] = acc[e] + pr;
+          }
+        }
+      } else {
+        for (int j = 0; j < Sr; ++j) {
+          const float rj = r[j];
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const int c = c0 + e * WG + (int)threadIdx.x;
+            const float cv = (c < K) ? cbT[((size_t)p * Sr + j) * K + c] : 0.0f;
+            const float t = rj - cv;
+            const float pr = t * t;
+            acc[e] = acc[e] + pr;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int c = c0 + e * WG + (int)threadIdx.x;
+        if (c < K) best = umin64(best, make_key(acc[e], (uint32_t)c));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = umin64(best, __shfl_xor(best, o, 64));
+    __syncthreads();
+    if (lane == 0) wmin[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      u64 b = wmin[0];
+#pragma unroll
+      for (int w = 1; w < WG / 64; ++w) b = umin64(b, wmin[w]);
+      codes[(size_t)it * m + p] = (int16_t)key_pos(b);
+    }
+  }
+}
+
+// Coarse assignment: nearest of C centroids by squareDistance over all d dimensions, lowest index on
+// ties (faiss IndexFlatL2 search k=1 / ivfadc.py); one wave per vector, lane <-> centroid.
+__global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restrict__ vecs, const float* __restrict__ coarseT,
+                                                          int32_t* __restrict__ cell, int n, int C, int Cpad, int d) {
+  const int it = blockIdx.x, lane = threadIdx.x;
+  if (it >= n) return;
+  const float* v = vecs + (size_t)it * d;
+  u64 best = KEY_INF;
+  for (int c = lane; c < C; c += 64) {
+    float acc = 0.0f;
+    for (int j = 0; j < d; ++j) {
+      const float t = v[j] - coarseT[(size_t)j * Cpad + c];
+      const float pr = t * t;
+      acc = acc + pr;
+    }
+    best = umin64(best, make_key(acc, (uint32_t)c));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = umin64(best, __shfl_xor(best, o, 64));
+  if (lane == 0) cell[it] = (int32_t)key_pos(best);
 }
 
 // generic sub-vector size (runtime S): no register cache, codebook streamed from L2

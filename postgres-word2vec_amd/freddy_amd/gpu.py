@@ -22,6 +22,7 @@ EXPORTS = [
     "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
     "freddy_gpu_last_scanned_rows", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
+    "freddy_gpu_encode",
 ]
 
 
@@ -285,3 +286,24 @@ class IVPQIndex(_Index):
                                             1 if use_target_lists else 0, C.c_float(confidence),
                                             double_threshold, _p(out_i), _p(out_d), C.byref(iters)))
         return out_i, out_d, iters.value
+
+
+class EncodeDesc(C.Structure):
+    _fields_ = [("d", C.c_int32), ("m", C.c_int32), ("K", C.c_int32), ("codebook", C.c_void_p), ("C", C.c_int32),
+                ("coarse", C.c_void_p)]
+
+
+def encode(codebook, vectors, coarse=None, device=0):
+    """Index build, encoding step: (cell[N] or None, codes[N, m]) of `vectors` for a trained
+    codebook [m][K][s] and optional coarse quantizer [C][d] (codes of the residuals then)."""
+    lib = load()
+    cb, v = _f32(codebook), _f32(vectors)
+    m, K, s_ = cb.shape
+    d = m * s_
+    v = v.reshape(-1, d)
+    co = None if coarse is None else _f32(coarse)
+    desc = EncodeDesc(d, m, K, _p(cb), 0 if co is None else co.shape[0], _p(co))
+    codes = np.empty((v.shape[0], m), np.int16)
+    cell = None if co is None else np.empty(v.shape[0], np.int32)
+    _check(lib.freddy_gpu_encode(C.byref(desc), device, _p(v), C.c_int64(v.shape[0]), _p(cell), _p(codes)))
+    return cell, codes

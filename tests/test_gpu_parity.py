@@ -324,3 +324,27 @@ def test_exact_knn_matches_oracle(gpu, oracle):
     exp = oracle.exact_knn(x, ids, qs[0], 8, ids[:3])
     assert gi[0, :3].tolist() == exp["id"].tolist()
     idx.close()
+
+
+@pytest.mark.parametrize("K,m", [(256, 12), (1024, 12), (32, 30)])
+def test_encode_matches_oracle(gpu, oracle, K, m):
+    """Next row 8f-2, encoding step of the index build: cells and PQ codes bit-identical to the oracle
+    (exact 1-NN by squareDistance, lowest index on ties), flat PQ and IVFADC (codes of the residuals)."""
+    N = 3000
+    x = util.corpus(N).numpy()
+    rng = np.random.default_rng(K + m)
+    s = 300 // m
+    cb = (rng.standard_normal((m, K, s)) * 0.05).astype(np.float32)
+    cb[0, K - 1] = cb[0, 1]                              # duplicated codeword
+    cb[2, 5] = x[11, 2 * s:3 * s]                        # an exact hit
+    cell, codes = gpu.encode(cb, x)
+    assert cell is None
+    assert np.array_equal(codes, oracle.encode_pq(cb, x))
+    assert codes[11, 2] == 5 and (codes[:, 0] != K - 1).all()
+    coarse = x[rng.choice(N, 40, replace=False)].copy()
+    coarse[17] = coarse[3]
+    cell, codes = gpu.encode(cb, x, coarse=coarse)
+    exp_cell = oracle.assign_coarse(coarse, x)
+    assert np.array_equal(cell, exp_cell) and (cell != 17).all()
+    res = np.stack([oracle.vec_minus(x[i], coarse[exp_cell[i]]) for i in range(N)])
+    assert np.array_equal(codes, oracle.encode_pq(cb, res))

@@ -463,3 +463,25 @@ def test_vec_ops_and_grouping_pq_oracle(oracle):
     # a duplicated group vector: the FIRST of the equally near groups wins (strict <)
     ids2, grp2 = oracle.grouping_pq(ot, np.stack([gvec[1], gvec[1], gvec[0]]), [501])
     assert grp2.tolist() in ([0], [2]) and 1 not in grp2.tolist()
+
+
+def test_encode_oracle(oracle):
+    """fo_encode_pq / fo_assign_coarse: exact 1-NN by squareDistance, lowest index on ties."""
+    rng = np.random.default_rng(5)
+    m, K, s = 4, 16, 5
+    cb = rng.standard_normal((m, K, s)).astype(f32)
+    cb[1, 9] = cb[1, 3]                                  # duplicated codeword: the lower code wins
+    v = rng.standard_normal((50, m * s)).astype(f32)
+    v[7, s:2 * s] = cb[1, 3]
+    codes = oracle.encode_pq(cb, v)
+    for i in range(50):
+        for p in range(m):
+            ds = [py_sqdist(v[i, p * s:(p + 1) * s], cb[p, j]) for j in range(K)]
+            assert codes[i, p] == int(np.argmin(np.array(ds, f32)))   # argmin returns the first minimum
+    assert codes[7, 1] == 3
+    coarse = rng.standard_normal((9, m * s)).astype(f32)
+    coarse[6] = coarse[2]
+    cell = oracle.assign_coarse(coarse, v)
+    for i in range(50):
+        ds = np.array([py_sqdist(v[i], coarse[c]) for c in range(9)], f32)
+        assert cell[i] == int(np.argmin(ds)) and cell[i] != 6
