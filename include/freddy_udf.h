@@ -50,6 +50,29 @@ int freddy_load_ivpq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* 
                      const int16_t* codes, int64_t N, const int32_t* stat_coarse_id, const float* stat_freq,
                      int32_t n_stat);
 
+/* ---- index files ("Postgres tables -> flat binary -> HBM loader") ------------------------
+ * One little-endian container of named arrays, the tables exactly as the index_creation scripts insert
+ * them (the reference exports a Python pickle, index_manager.py:10-18; this is the language-neutral
+ * counterpart):
+ *   "FRDYIDX1" | uint32 n_arrays | n_arrays x { uint16 name_len | name | uint8 dtype (0 float32, 1 int32,
+ *   2 int16) | uint8 ndim | uint64 dims[ndim] | padding to 8 | data | padding to 8 }
+ * Array names are "<table>.<column>":
+ *   google_vecs_norm.id/.vector | pq_codebook.pos/.code/.vector, pq_quantization.id/.vector |
+ *   coarse_quantization.id/.vector, residual_codebook.pos/.code/.vector, fine_quantization.id/.coarse_id/.vector |
+ *   codebook_ivpq.pos/.code/.vector, coarse_quantization_ivpq.pos/.code/.vector,
+ *   fine_quantization_ivpq.id/.coarse_id/.vector, stat.coarse_id/.coarse_freq
+ * freddy_index_file_write writes the arrays it is given; freddy_import_index reads a file and loads every
+ * table group that is complete in it (same effect as the freddy_load_* calls; google_vecs_norm first). */
+typedef struct freddy_file_array {
+  const char* name;
+  int32_t dtype;        /* 0 float32, 1 int32, 2 int16 */
+  int32_t ndim;         /* 1 or 2 */
+  int64_t dims[2];
+  const void* data;
+} freddy_file_array;
+int freddy_index_file_write(const char* path, const freddy_file_array* arrays, int32_t n_arrays);
+int freddy_import_index(freddy_session_t* s, const char* path);
+
 /* ---- config functions                                    freddy--0.0.1.sql:21-132, 188-194 */
 int freddy_set_w(freddy_session_t* s, int32_t w);                       /* default 3 */
 int freddy_set_pvf(freddy_session_t* s, int32_t pvf);                   /* default 20 */

@@ -116,6 +116,10 @@ class Session:
         self._check(self.lib.freddy_load_ivpq(self.h, _p(pos), _p(code), _p(vec), n, s, _p(cpos), _p(ccode), _p(cvec), cn,
                                               _p(ids), _p(cid), _p(codes), C.c_int64(ids.size), _p(sid), _p(st), st.size))
 
+    def import_index(self, path):
+        """Load every complete table group of an index file (include/freddy_udf.h, FRDYIDX1)."""
+        self._check(self.lib.freddy_import_index(self.h, str(path).encode()))
+
     # ---- config functions ----------------------------------------------------------------
     def set_w(self, v): self._check(self.lib.freddy_set_w(self.h, int(v)))
     def set_pvf(self, v): self._check(self.lib.freddy_set_pvf(self.h, int(v)))
@@ -223,3 +227,54 @@ class Session:
         r = np.array([row], ROW3)
         self.lib.freddy_emit_row3(_p(r), vals)
         return tuple(v.value.decode() for v in vals)
+
+
+class FileArray(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("dtype", C.c_int32), ("ndim", C.c_int32), ("dims", C.c_int64 * 2), ("data", C.c_void_p)]
+
+
+_DT = {np.dtype(np.float32): 0, np.dtype(np.int32): 1, np.dtype(np.int16): 2}
+
+
+def write_index_file(path, arrays):
+    """arrays: {"<table>.<column>": ndarray (float32 / int32 / int16, 1-d or 2-d)} -> FRDYIDX1 file."""
+    lib = load()
+    keep, recs = [], (FileArray * len(arrays))()
+    for i, (name, a) in enumerate(arrays.items()):
+        a = np.ascontiguousarray(a)
+        keep.append(a)
+        dims = (C.c_int64 * 2)(a.shape[0], a.shape[1] if a.ndim == 2 else 0)
+        recs[i] = FileArray(name.encode(), _DT[a.dtype], a.ndim, dims, a.ctypes.data_as(C.c_void_p))
+    if lib.freddy_index_file_write(str(path).encode(), recs, len(arrays)) != 0:
+        raise FreddyError(lib.freddy_udf_last_error().decode())
+
+
+def table_arrays(pq=None, ivfadc=None, ivpq=None, vecs_norm=None):
+    """The PG-table view of the builders' outputs (index_build.py), named as in the index file format."""
+    out = {}
+    if vecs_norm is not None:
+        ids, v = vecs_norm
+        out["google_vecs_norm.id"], out["google_vecs_norm.vector"] = _i32(ids), _f32(v)
+    if pq is not None:
+        pos, code, vec, _, _ = _entries(pq["codebook"])
+        out.update({"pq_codebook.pos": pos, "pq_codebook.code": code, "pq_codebook.vector": vec,
+                    "pq_quantization.id": _i32(pq["ids"]), "pq_quantization.vector": _i16(pq["codes"])})
+    if ivfadc is not None:
+        pos, code, vec, _, _ = _entries(ivfadc["codebook"])
+        cq = _f32(ivfadc["coarse"])
+        cell_of = np.repeat(np.arange(cq.shape[0]), np.diff(ivfadc["list_off"])).astype(np.int32)
+        out.update({"coarse_quantization.id": _i32(np.arange(cq.shape[0])), "coarse_quantization.vector": cq,
+                    "residual_codebook.pos": pos, "residual_codebook.code": code, "residual_codebook.vector": vec,
+                    "fine_quantization.id": _i32(ivfadc["ids"]), "fine_quantization.coarse_id": cell_of,
+                    "fine_quantization.vector": _i16(ivfadc["codes"])})
+    if ivpq is not None:
+        pos, code, vec, _, _ = _entries(ivpq["codebook"])
+        cpos, ccode, cvec, _, _ = _entries(ivpq["coarse"])
+        st = _f32(ivpq["stats"])
+        out.update({"codebook_ivpq.pos": pos, "codebook_ivpq.code": code, "codebook_ivpq.vector": vec,
+                    "coarse_quantization_ivpq.pos": cpos, "coarse_quantization_ivpq.code": ccode,
+                    "coarse_quantization_ivpq.vector": cvec, "fine_quantization_ivpq.id": _i32(ivpq["ids"]),
+                    "fine_quantization_ivpq.coarse_id": _i32(ivpq["coarse_id"]),
+                    "fine_quantization_ivpq.vector": _i16(ivpq["codes"]), "stat.coarse_id": _i32(np.arange(st.size)),
+                    "stat.coarse_freq": st})
+    return out

@@ -8,6 +8,9 @@
 #include "../../include/freddy_udf.h"
 
 #include <algorithm>
+#include <initializer_list>
+#include <string>
+#include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -381,6 +384,152 @@ int k_nearest_neighbour(freddy_session_t* s, const float* query, int32_t dim, in
 int knn_in_exact(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
                  freddy_row2* out, int32_t* n_rows) {
   return exact_common(s, query, dim, k, input_ids, n_ids, true, out, n_rows);
+}
+
+// ---- index files -----------------------------------------------------------------------------
+namespace {
+struct FileArray {
+  int dtype = 0, ndim = 0;
+  int64_t dims[2] = {0, 0};
+  std::vector<unsigned char> data;
+  int64_t rows() const { return dims[0]; }
+  int64_t cols() const { return ndim == 2 ? dims[1] : 1; }
+};
+const size_t kElem[3] = {4, 4, 2};
+
+int read_index_file(const char* path, std::map<std::string, FileArray>& out) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(-1, "cannot open index file %s", path);
+  auto bad = [&](const char* what) { fclose(f); return fail(-1, "index file %s: %s", path, what); };
+  char magic[8];
+  uint32_t n = 0;
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "FRDYIDX1", 8) != 0) return bad("bad magic");
+  if (fread(&n, 4, 1, f) != 1 || n > 4096) return bad("bad array count");
+  size_t off = 12;
+  auto skip_pad = [&]() { while (off % 8) { if (fgetc(f) == EOF) return false; ++off; } return true; };
+  for (uint32_t i = 0; i < n; ++i) {
+    uint16_t nl = 0;
+    if (fread(&nl, 2, 1, f) != 1 || nl == 0 || nl > 255) return bad("bad name length");
+    std::string name(nl, '\0');
+    if (fread(&name[0], 1, nl, f) != nl) return bad("truncated name");
+    unsigned char dt = 0, nd = 0;
+    if (fread(&dt, 1, 1, f) != 1 || fread(&nd, 1, 1, f) != 1 || dt > 2 || nd < 1 || nd > 2) return bad("bad array header");
+    FileArray a;
+    a.dtype = dt; a.ndim = nd;
+    uint64_t dims[2] = {0, 0};
+    if (fread(dims, 8, nd, f) != nd) return bad("truncated dims");
+    off += 2 + nl + 2 + 8 * nd;
+    if (!skip_pad()) return bad("truncated padding");
+    a.dims[0] = (int64_t)dims[0]; a.dims[1] = (int64_t)dims[1];
+    const uint64_t count = dims[0] * (nd == 2 ? dims[1] : 1);
+    if (count > (1ull << 40)) return bad("array too large");
+    a.data.resize((size_t)count * kElem[dt]);
+    if (!a.data.empty() && fread(a.data.data(), 1, a.data.size(), f) != a.data.size()) return bad("truncated data");
+    off += a.data.size();
+    if (i + 1 < n && !skip_pad()) return bad("truncated padding");
+    out[name] = std::move(a);
+  }
+  fclose(f);
+  return 0;
+}
+}  // namespace
+
+int freddy_index_file_write(const char* path, const freddy_file_array* arrays, int32_t n_arrays) {
+  if (!path || n_arrays < 0 || (n_arrays > 0 && !arrays)) return fail(-1, "bad argument");
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(-1, "cannot create index file %s", path);
+  size_t off = 0;
+  auto put = [&](const void* p, size_t n) { off += n; return n == 0 || fwrite(p, 1, n, f) == n; };
+  auto pad = [&]() { static const char z[8] = {0}; const size_t n = (8 - off % 8) % 8; return put(z, n); };
+  const uint32_t n = (uint32_t)n_arrays;
+  bool ok = put("FRDYIDX1", 8) && put(&n, 4);
+  for (int i = 0; ok && i < n_arrays; ++i) {
+    const freddy_file_array& a = arrays[i];
+    const size_t nl = a.name ? strlen(a.name) : 0;
+    if (nl == 0 || nl > 255 || a.dtype < 0 || a.dtype > 2 || a.ndim < 1 || a.ndim > 2 || a.dims[0] < 0 || (a.ndim == 2 && a.dims[1] < 0)) {
+      fclose(f);
+      return fail(-1, "bad array descriptor %d", i);
+    }
+    const uint16_t nl16 = (uint16_t)nl;
+    const unsigned char dt = (unsigned char)a.dtype, nd = (unsigned char)a.ndim;
+    const uint64_t dims[2] = {(uint64_t)a.dims[0], (uint64_t)a.dims[1]};
+    const size_t bytes = (size_t)dims[0] * (nd == 2 ? dims[1] : 1) * kElem[dt];
+    ok = put(&nl16, 2) && put(a.name, nl) && put(&dt, 1) && put(&nd, 1) && put(dims, 8 * nd) && pad() && put(a.data, bytes) &&
+         (i + 1 == n_arrays || pad());
+  }
+  if (fclose(f) != 0) ok = false;
+  return ok ? 0 : fail(-1, "write to index file %s failed", path);
+}
+
+int freddy_import_index(freddy_session_t* s, const char* path) {
+  if (!s || !path) return fail(-1, "bad argument");
+  std::map<std::string, FileArray> t;
+  if (int rc = read_index_file(path, t)) return rc;
+  auto has = [&](std::initializer_list<const char*> names) {
+    for (const char* n : names) if (!t.count(n)) return false;
+    return true;
+  };
+  auto want = [&](const char* name, int dtype, int ndim) -> const FileArray* {
+    const FileArray& a = t[name];
+    if (a.dtype != dtype || a.ndim != ndim) { fail(-1, "index file %s: array %s has the wrong type or rank", path, name); return nullptr; }
+    return &a;
+  };
+#define ARR(var, name, dtype, ndim) const FileArray* var = want(name, dtype, ndim); if (!var) return -1;
+#define I32(a) reinterpret_cast<const int32_t*>((a)->data.data())
+#define F32(a) reinterpret_cast<const float*>((a)->data.data())
+#define I16(a) reinterpret_cast<const int16_t*>((a)->data.data())
+  int loaded = 0;
+  if (has({"google_vecs_norm.id", "google_vecs_norm.vector"})) {
+    ARR(id, "google_vecs_norm.id", 1, 1) ARR(v, "google_vecs_norm.vector", 0, 2)
+    if (v->rows() != id->rows()) return fail(-1, "index file %s: google_vecs_norm columns differ in length", path);
+    if (int rc = freddy_load_vecs_norm(s, I32(id), F32(v), id->rows(), (int32_t)v->cols())) return rc;
+    ++loaded;
+  }
+  if (has({"pq_codebook.pos", "pq_codebook.code", "pq_codebook.vector", "pq_quantization.id", "pq_quantization.vector"})) {
+    ARR(pos, "pq_codebook.pos", 1, 1) ARR(code, "pq_codebook.code", 1, 1) ARR(vec, "pq_codebook.vector", 0, 2)
+    ARR(id, "pq_quantization.id", 1, 1) ARR(q, "pq_quantization.vector", 2, 2)
+    if (pos->rows() != code->rows() || pos->rows() != vec->rows() || id->rows() != q->rows())
+      return fail(-1, "index file %s: pq tables have columns of different lengths", path);
+    if (int rc = freddy_load_pq(s, I32(pos), I32(code), F32(vec), (int32_t)pos->rows(), (int32_t)vec->cols(), I32(id), I16(q), id->rows()))
+      return rc;
+    ++loaded;
+  }
+  if (has({"coarse_quantization.id", "coarse_quantization.vector", "residual_codebook.pos", "residual_codebook.code",
+           "residual_codebook.vector", "fine_quantization.id", "fine_quantization.coarse_id", "fine_quantization.vector"})) {
+    ARR(cid, "coarse_quantization.id", 1, 1) ARR(cv, "coarse_quantization.vector", 0, 2)
+    ARR(pos, "residual_codebook.pos", 1, 1) ARR(code, "residual_codebook.code", 1, 1) ARR(vec, "residual_codebook.vector", 0, 2)
+    ARR(id, "fine_quantization.id", 1, 1) ARR(co, "fine_quantization.coarse_id", 1, 1) ARR(q, "fine_quantization.vector", 2, 2)
+    if (cid->rows() != cv->rows() || pos->rows() != code->rows() || pos->rows() != vec->rows() || id->rows() != co->rows() ||
+        id->rows() != q->rows())
+      return fail(-1, "index file %s: ivfadc tables have columns of different lengths", path);
+    if (int rc = freddy_load_ivfadc(s, I32(cid), F32(cv), (int32_t)cid->rows(), I32(pos), I32(code), F32(vec), (int32_t)pos->rows(),
+                                    (int32_t)vec->cols(), I32(id), I32(co), I16(q), id->rows()))
+      return rc;
+    ++loaded;
+  }
+  if (has({"codebook_ivpq.pos", "codebook_ivpq.code", "codebook_ivpq.vector", "coarse_quantization_ivpq.pos",
+           "coarse_quantization_ivpq.code", "coarse_quantization_ivpq.vector", "fine_quantization_ivpq.id",
+           "fine_quantization_ivpq.coarse_id", "fine_quantization_ivpq.vector", "stat.coarse_id", "stat.coarse_freq"})) {
+    ARR(pos, "codebook_ivpq.pos", 1, 1) ARR(code, "codebook_ivpq.code", 1, 1) ARR(vec, "codebook_ivpq.vector", 0, 2)
+    ARR(qpos, "coarse_quantization_ivpq.pos", 1, 1) ARR(qcode, "coarse_quantization_ivpq.code", 1, 1)
+    ARR(qvec, "coarse_quantization_ivpq.vector", 0, 2)
+    ARR(id, "fine_quantization_ivpq.id", 1, 1) ARR(co, "fine_quantization_ivpq.coarse_id", 1, 1)
+    ARR(q, "fine_quantization_ivpq.vector", 2, 2) ARR(sid, "stat.coarse_id", 1, 1) ARR(sf, "stat.coarse_freq", 0, 1)
+    if (pos->rows() != code->rows() || pos->rows() != vec->rows() || qpos->rows() != qcode->rows() || qpos->rows() != qvec->rows() ||
+        id->rows() != co->rows() || id->rows() != q->rows() || sid->rows() != sf->rows())
+      return fail(-1, "index file %s: ivpq tables have columns of different lengths", path);
+    if (int rc = freddy_load_ivpq(s, I32(pos), I32(code), F32(vec), (int32_t)pos->rows(), (int32_t)vec->cols(), I32(qpos), I32(qcode),
+                                  F32(qvec), (int32_t)qpos->rows(), I32(id), I32(co), I16(q), id->rows(), I32(sid), F32(sf),
+                                  (int32_t)sid->rows()))
+      return rc;
+    ++loaded;
+  }
+#undef ARR
+#undef I32
+#undef F32
+#undef I16
+  if (!loaded) return fail(-1, "index file %s holds no complete table group", path);
+  return 0;
 }
 
 // ---- grouping and analogy on the PQ / IVFADC indexes ---------------------------------------

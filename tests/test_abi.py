@@ -79,3 +79,43 @@ def test_host_mirror_config_functions_and_errors():
         s.ivfadc_batch_search([1, 2, 3], 5)
     assert s.emit_row3((7, 42, 0.1234567)) == ("7", "42", "0.123457")
     s.close()
+
+
+def test_index_file_format_roundtrip(tmp_path):
+    """FRDYIDX1 (include/freddy_udf.h): what freddy_index_file_write emits, parsed here byte by byte."""
+    import struct
+    import numpy as np
+    from freddy_amd import udf
+    rng = np.random.default_rng(0)
+    arrays = {"pq_codebook.pos": np.arange(7, dtype=np.int32),
+              "pq_codebook.vector": rng.standard_normal((7, 5)).astype(np.float32),
+              "pq_quantization.vector": rng.integers(0, 9, (3, 4)).astype(np.int16),
+              "x.empty": np.zeros((0, 3), np.float32)}
+    path = tmp_path / "t.fidx"
+    udf.write_index_file(path, arrays)
+    raw = path.read_bytes()
+    assert raw[:8] == b"FRDYIDX1" and struct.unpack_from("<I", raw, 8)[0] == len(arrays)
+    off, got = 12, {}
+    for _ in range(len(arrays)):
+        (nl,) = struct.unpack_from("<H", raw, off); off += 2
+        name = raw[off:off + nl].decode(); off += nl
+        dt, nd = raw[off], raw[off + 1]; off += 2
+        dims = struct.unpack_from("<%dQ" % nd, raw, off); off += 8 * nd
+        off = (off + 7) // 8 * 8
+        dtype = [np.float32, np.int32, np.int16][dt]
+        count = int(np.prod(dims))
+        got[name] = np.frombuffer(raw, dtype, count, off).reshape(dims)
+        off += count * np.dtype(dtype).itemsize
+        off = (off + 7) // 8 * 8
+    assert off >= len(raw) and set(got) == set(arrays)
+    for k, v in arrays.items():
+        assert got[k].dtype == v.dtype and np.array_equal(got[k], v)
+    s = udf.Session()
+    import pytest
+    with pytest.raises(udf.FreddyError, match="no complete table group"):
+        s.import_index(path)
+    bad = tmp_path / "bad.fidx"
+    bad.write_bytes(b"NOTANIDX" + raw[8:])
+    with pytest.raises(udf.FreddyError, match="bad magic"):
+        s.import_index(bad)
+    s.close()

@@ -161,3 +161,28 @@ def test_analogy_3cosadd(db, oracle, which):
         assert got == bid and got > 0
     assert s.analogy_3cosadd_pq(1, 2, N + 99) == -1              # unknown word: NULL
     s.set_pvf(20)
+
+
+def test_index_file_import(db, oracle, tmp_path):
+    """Next row 8f-2: tables -> FRDYIDX1 file -> a fresh session pinned from the file answers like the
+    session loaded from the arrays."""
+    from freddy_amd import udf
+    s, t = db
+    pq = util.pq_tables(N=N, K=256)
+    ivf = util.ivf_tables(N=N, C=32, K=256)
+    iv = util.ivpq_tables(N=N)
+    ids_all = np.arange(1, N + 1, dtype=np.int32)
+    path = tmp_path / "all.fidx"
+    udf.write_index_file(path, udf.table_arrays(pq=pq, ivfadc=ivf, ivpq=iv, vecs_norm=(ids_all, t["x"])))
+    s2 = udf.Session()
+    s2.import_index(path)
+    q = t["x"][321]
+    same(s2.pq_search(q, 5), oracle.pq_search(t["pq"], q, 5))
+    same(s2.ivfadc_search(q, 5), oracle.ivfadc_search(t["ivf"], q, 5, 3))
+    qids = np.arange(100, 140, dtype=np.int32)
+    targets = np.arange(1, N + 1, 9).astype(np.int32)
+    exp, _ = oracle.ivpq_search_in(t["ivpq"], t["x"][qids - 1], 5, targets, 10, 4, 2)
+    same(s2.ivpq_search_in(t["x"][qids - 1], qids, 5, targets, 10, 4, 2, True, 0.8, 10000000), exp)
+    rows = s2.ivfadc_batch_search([17, 900], 5)
+    same(rows, oracle.ivfadc_batch_search(t["ivf"], t["x"][[16, 899]], 5))
+    s2.close()
