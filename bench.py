@@ -85,23 +85,37 @@ def main():
     qids = np.sort(rng.choice(np.arange(1, a.N + 1), size=a.Q, replace=False)).astype(np.int64)
     d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
     # ids and distances of the shard live in ONE buffer so that the per-shard top-k crosses xGMI
-    # in a single RCCL all_gather (the payload is 40 KB per rank: pure latency)
-    d_res = torch.empty((2, a.Q, a.k), dtype=torch.int32, device=dev)
+    # in a single RCCL all_gather (the payload is 40 KB per rank: pure latency).  Two such buffers
+    # alternate: the gather of step i is asynchronous and only has to be finished before its buffers are
+    # reused by step i+2, so its latency hides under the next step's kernels instead of adding to them.
+    d_res2 = [torch.empty((2, a.Q, a.k), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_res = d_res2[0]
     d_ids = d_res[0]
     d_dist = d_res[1].view(torch.float32)
     d_status = torch.zeros(4, dtype=torch.int32, device=dev)
-    if world > 1:
-        g_res = torch.empty((world, 2, a.Q, a.k), dtype=torch.int32, device=dev)
+    g_res2 = [torch.empty((world, 2, a.Q, a.k), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    step_no = [0]
 
     stream = torch.cuda.current_stream(dev)
 
     def step():
-        index.search_dev(d_q.data_ptr(), a.Q, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, d_ids.data_ptr(),
-                         d_dist.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+        b = step_no[0] & 1
+        step_no[0] += 1
+        if pending[b] is not None:
+            pending[b].wait()
+            pending[b] = None
+        res = d_res2[b]
+        index.search_dev(d_q.data_ptr(), a.Q, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
+                         res[1].data_ptr(), d_status.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(g_res.view(-1), d_res.view(-1))
+            pending[b] = dist.all_gather_into_tensor(g_res2[b].view(-1), res.view(-1), async_op=True)
 
     def barrier():
+        for b in range(2):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -125,9 +139,12 @@ def main():
     index.profile_enable(True)
     for _ in range(a.steps):
         step()
-    torch.cuda.synchronize(dev)
+    barrier()
     prof = index.profile_read()
     index.profile_enable(False)
+    step_no[0] = 0
+    step()      # leave this rank's final results in d_res2[0] (= d_ids / d_dist below)
+    barrier()
     scanned_rows = index.last_scanned_rows()
     straggler = int(d_status[0].item())
 
