@@ -677,9 +677,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
           fprintf(stderr, "[fused prof] wgs=%u entries=%.0f  cycles/entry: stage=%.0f slab0=%.0f loop=%.0f lastgather=%.0f select=%.0f\n",
                   n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[4] / ent);
         else
-          fprintf(stderr, "[spec prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f\n",
-                  n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent);
-        (void)mx_end; (void)mn_end;
+          fprintf(stderr, "[spec prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f | workgroups ran dry over %.1f us\n",
+                  n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent, (mx_end - mn_end) / 100.0);
       }
       MergeSurvArgs ms;
       ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = active; ms.round_rows = pa.round_rows;

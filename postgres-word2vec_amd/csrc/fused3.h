@@ -322,6 +322,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
     }
     if (a.prof && tid == 0) {
       for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];
+      a.prof[(size_t)blockIdx.x * 8 + 6] = wall_clock64();   // 100 MHz, chip-wide: when this workgroup ran dry
     }
   } else {
     // =====================================================================================

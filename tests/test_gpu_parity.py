@@ -348,3 +348,20 @@ def test_encode_matches_oracle(gpu, oracle, K, m):
     assert np.array_equal(cell, exp_cell) and (cell != 17).all()
     res = np.stack([oracle.vec_minus(x[i], coarse[exp_cell[i]]) for i in range(N)])
     assert np.array_equal(codes, oracle.encode_pq(cb, res))
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_ivfadc_many_probes(gpu, oracle, fused, monkeypatch):
+    """W > 64 takes the probe plan's wide selection (V = 4) and its serial replay branch; W = C probes
+    every cell (exhaustive), so the result equals the best over the whole table."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
+    N = 20000
+    t = util.ivf_tables(N=N, C=128, K=64)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 24)
+    for W in (65, 100, 128):
+        gi, gd = idx.search(qs, 4, W, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
+        exp = oracle.ivfadc_search_many(ot, qs, 4, W, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"W={W}")
+    idx.close()
