@@ -498,9 +498,10 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   // fused kernel pays off once several (query, cell) items share a cell, i.e. for batches.
   const char* fenv = getenv("FREDDY_GPU_FUSED");
   const bool force_fused = fenv && fenv[0] == '1';
-  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && L <= 64 &&
-                     (force_fused || items >= 256);
+  // (lists longer than 8 chunks of 4096 rows would need survivor buffers out of proportion: generic path)
   const int upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && L <= 64 && upi <= 8 &&
+                     (force_fused || items >= 256);
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
@@ -737,7 +738,11 @@ static int check_search_args(const freddy_gpu_index* ix, int kind, const void* q
 }
 
 static int max_queries_per_chunk(const freddy_gpu_index* ix, int W) {
-  const size_t per_query = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
+  // workspace per query: the LUTs of its W items (generic path) or their survivor regions (fused path)
+  const size_t upi = (size_t)std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  const size_t lut_bytes = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
+  const size_t surv_bytes = upi <= 8 ? sizeof(u64) * (size_t)W * upi * FUSED_NW * FUSED_RMAX * 64 : 0;
+  const size_t per_query = std::max(lut_bytes, surv_bytes);
   size_t n = lut_budget_bytes() / std::max<size_t>(per_query, 1);
   if (n < 1) n = 1;
   if (n > (1u << 20)) n = 1u << 20;
