@@ -522,13 +522,24 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   }
 
-  HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
-  HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
+  // round-one scratch that must start at zero: the probe bitmaps, the counters (n_next, n_groups, work
+  // counter), the per-cell item counts and the accepted-candidate counts.  The tiled coarse kernel clears
+  // them itself; the small-batch kernel gets memsets.
+  const bool tiled = Q >= 32;
+  if (!tiled) {
+    HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
+    HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
+  }
+  ZeroArgs za;
+  za.p[0] = ix->w_used.as<uint32_t>(); za.n[0] = Q * used_words;
+  za.p[1] = ix->w_cnt.as<uint32_t>(); za.n[1] = 4;
+  za.p[2] = fused ? ix->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = fused ? C * 2 : 0;
+  za.p[3] = ix->w_cand.as<uint32_t>(); za.n[3] = Q;
 
   timed_launch(ix, s, "coarse_dist", [&] {
-    if (Q >= 32)
+    if (tiled)
       hipLaunchKernelGGL((coarse_tile_kernel<2>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
-                         ix->w_distT.as<float>(), Q, Cpad, d);
+                         ix->w_distT.as<float>(), Q, Cpad, d, za);
     else
       hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, d_q,
                          ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);
@@ -551,7 +562,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     pa.n_active = n_active; pa.Cpad = Cpad; pa.C = C; pa.W = W; pa.used_words = used_words;
     pa.cell_count = fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
     pa.cell_items = fused ? ix->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = n_active;
-    if (fused) HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
+    if (fused && !(tiled && first)) HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
     {
       const int PV = pick_V(2 * W);
       const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
@@ -580,7 +591,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       });
       HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
+    if (!(tiled && first)) HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
     if (fused) {
       const size_t max_groups = ((size_t)n_items / gsz + (size_t)C + 1) * upi;   // (group, chunk) work entries
       int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
@@ -597,7 +608,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query; fa.queries = d_q; fa.coarse = ix->coarse;
       fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cnt + max_groups;
       fa.group_first = group_cnt + 2 * max_groups; fa.group_cnt = group_cnt + 3 * max_groups; fa.n_groups = n_groups; fa.work_counter = ix->w_cnt.as<int32_t>() + 2;
-      HIP_TRY(hipMemsetAsync(ix->w_cnt.as<int32_t>() + 2, 0, sizeof(int32_t), s));
+      if (!(tiled && first)) HIP_TRY(hipMemsetAsync(ix->w_cnt.as<int32_t>() + 2, 0, sizeof(int32_t), s));
       fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
       fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
       fa.cand_count = (found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
