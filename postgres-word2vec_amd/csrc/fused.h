@@ -1,24 +1,28 @@
 // fused.h -- IVFADC: LUT build + ADC scan + candidate selection in ONE kernel (gfx950).
 //
+// This file holds what the three fused kernels share (constants, the work table, the argument block,
+// the survivor merge) and the first, SYMMETRIC kernel ivf_fused_kernel (FREDDY_GPU_FUSED_KERNEL=1);
+// fused2.h and fused3.h (default) are the role-specialised successors.
+//
 // Why: with separate kernels the per-(query, cell) LUTs (48 KiB each, 503 MB per 1024-query
 // batch at nprobe=10) are written to memory by lut_build and read back by adc_scan -- the
 // first rocprofv3 pass showed that round trip to be 2/3 of the scan kernel's traffic.  Here a
-// LUT never exists as a whole: the workgroup walks the m positions two at a time, builds
-// the two 4 KiB LUT slabs of G work units in LDS, and every lane immediately adds them to
-// the running ADC sums of its rows, which live in registers.  The sum still runs over
-// positions 0..m-1 in order (index_utils.c:1126-1133), each slab entry is still the
-// sequential squareDistance over the sub-vector (index_utils.c:445-455, :500-508).
+// LUT never exists as a whole: the workgroup walks the m positions, builds the 64 KiB LUT slab of
+// one position for its G items in LDS, and every lane immediately adds it to the running ADC sums
+// of its rows, which live in registers.  The sum still runs over positions 0..m-1 in order
+// (index_utils.c:1126-1133), each slab entry is still the sequential squareDistance over the
+// sub-vector (index_utils.c:445-455, :500-508).
 //
 //   work item  = (query, probed cell); items are grouped by cell, <= 16 per workgroup
 //   workgroup  = 512 threads (8 waves), one 4096-row chunk of the cell's list
 //   LDS        = 2 buffers x 16 items x K floats = 128 KiB (K = 1024)
 //
-// Selection (replaces the per-wave streaming top-L of adc_scan): each lane's best key per unit
-// goes through LDS; one wave per unit takes the column minima over the 16 waves, sorts those
-// 64 keys once and uses the L-th as threshold tau.  The L smallest of 64 distinct candidates
-// bound the L-th smallest of all from above, so {key <= tau} is a superset of the unit's L
-// smallest keys (typically L + a few, never more than 64*L).  Survivors are appended to the
-// item's buffer in memory; merge_replay picks the query's 2k smallest and replays.
+// Selection (replaces the per-wave streaming top-L of adc_scan) works on the distance bits: each
+// lane's smallest distance per item goes through LDS; one wave per item takes the column minima over
+// the 8 waves, sorts those 64 values and uses the L-th as threshold tau.  L rows have a distance
+// <= tau, so {distance <= tau} contains the item's L smallest (distance, row id) keys (typically
+// L + a few rows).  Every wave appends its survivors to its own region of the item's buffer;
+// merge_surv_kernel picks the query's 2k smallest keys and replays the reference's insertion.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -37,106 +41,15 @@ static constexpr int FUSED_E = 2;                                  // codes per 
 static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row blocks = 4096 rows per chunk
 
 // ---------------------------------------------------------------------------------------
-// Cell-major grouping of the round's (query, cell) items: the probe plan counts items per
-// cell; group_table turns the counts into offsets and into groups of <= FUSED_G items of
-// one cell; bucket_items scatters the items into cell order.  (Order inside a cell is
+// Cell-major grouping of the round's (query, cell) items: the probe plan appends every item to its
+// cell's bucket (cell_items[cell][0..count), kernels.h); work_table_kernel turns the per-cell counts
+// into work entries and orders them for the persistent workgroups.  (Order inside a cell is
 // irrelevant: every item is selected and merged on its own.)
 // ---------------------------------------------------------------------------------------
-// One work entry per (group of <= FUSED_G items of a cell, 4096-row chunk of the cell's list), so
-// the fused kernel's grid has no holes: entries past n_groups[0] sit at the end of the grid.
-__global__ __launch_bounds__(64) void group_table_kernel(const int32_t* __restrict__ cell_count, int C,
-                                                        const int32_t* __restrict__ blk_off,
-                                                        int32_t* __restrict__ cell_start,   // [C]
-                                                        int32_t* __restrict__ group_cell,   // [max work]
-                                                        int32_t* __restrict__ group_first,  // index into sorted items
-                                                        int32_t* __restrict__ group_cnt,    // items | chunk << 8
-                                                        int32_t* __restrict__ n_groups) {
-  const int lane = threadIdx.x;
-  const int per = (C + 63) / 64;
-  const int c0 = lane * per, c1 = (c0 + per < C) ? c0 + per : C;
-  int items = 0, groups = 0;
-  for (int c = c0; c < c1; ++c) {
-    const int n = cell_count[c];
-    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-    items += n;
-    groups += ((n + FUSED_G - 1) / FUSED_G) * chunks;
-  }
-  int it_off = items, gr_off = groups;   // inclusive wave scan
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int a = __shfl_up(it_off, d, 64), b = __shfl_up(gr_off, d, 64);
-    if (lane >= d) { it_off += a; gr_off += b; }
-  }
-  if (lane == 63) n_groups[0] = gr_off;
-  it_off -= items;
-  gr_off -= groups;
-  for (int c = c0; c < c1; ++c) {
-    const int n = cell_count[c];
-    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-    cell_start[c] = it_off;
-    for (int f = 0; f < n; f += FUSED_G) {
-      for (int ch = 0; ch < chunks; ++ch) {
-        group_cell[gr_off] = c;
-        group_first[gr_off] = it_off + f;
-        group_cnt[gr_off] = ((n - f < FUSED_G) ? n - f : FUSED_G) | (ch << 8);
-        ++gr_off;
-      }
-    }
-    it_off += n;
-  }
-}
-
-// Longest-processing-time-first order for the persistent workgroups: entries with more items
-// (more slab arithmetic) are pulled first, so the tail of the launch is made of small entries.
-// One workgroup; counting sort on (items, rows) classes; order inside a class is irrelevant.
-__global__ __launch_bounds__(256) void sort_work_kernel(const int32_t* __restrict__ n_work_p,
-                                                       const int32_t* __restrict__ blk_off,
-                                                       const int32_t* __restrict__ in_cell, const int32_t* __restrict__ in_first,
-                                                       const int32_t* __restrict__ in_cnt, int32_t* __restrict__ out_cell,
-                                                       int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt) {
-  constexpr int NB = FUSED_G * 4 + 4;   // class = (items, quarter of a full chunk), descending
-  __shared__ int hist[NB];
-  __shared__ int start[NB];
-  const int n = n_work_p[0];
-  for (int i = threadIdx.x; i < NB; i += 256) hist[i] = 0;
-  __syncthreads();
-  auto klass = [&](int e) {
-    const int cnt = in_cnt[e] & 0xff, chunk = in_cnt[e] >> 8, c = in_cell[e];
-    int nb = blk_off[c + 1] - blk_off[c] - chunk * FUSED_UNIT_BLOCKS;
-    nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
-    const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
-    return (FUSED_G - cnt) * 4 + (3 - rq);                     // small class index = big entry
-  };
-  for (int e = threadIdx.x; e < n; e += 256) atomicAdd(&hist[klass(e)], 1);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int b = 0; b < NB; ++b) { start[b] = acc; acc += hist[b]; }
-  }
-  __syncthreads();
-  for (int e = threadIdx.x; e < n; e += 256) {
-    const int slot = atomicAdd(&start[klass(e)], 1);
-    out_cell[slot] = in_cell[e];
-    out_first[slot] = in_first[e];
-    out_cnt[slot] = in_cnt[e];
-  }
-}
-
-__global__ __launch_bounds__(256) void bucket_items_kernel(const int32_t* __restrict__ item_cell, int n_items,
-                                                          const int32_t* __restrict__ cell_start,
-                                                          int32_t* __restrict__ cell_fill,
-                                                          int32_t* __restrict__ sorted_item) {
-  const int it = blockIdx.x * 256 + threadIdx.x;
-  if (it >= n_items) return;
-  const int c = item_cell[it];
-  if (c < 0) return;
-  sorted_item[cell_start[c] + atomicAdd(cell_fill + c, 1)] = it;
-}
-
-// group_table + sort_work in ONE launch for the bucketed form (the probe plan has already written
-// each cell's items to cell_items[cell][0..count)): one workgroup of 256 threads turns the per-cell
-// counts into work entries (group of <= gsz <= FUSED_G items of a cell x 4096-row chunk; first = index
-// into cell_items) and orders them largest first.
+// One workgroup of 256 threads: per-cell counts -> work entries (group of <= gsz <= FUSED_G items of a
+// cell x 4096-row chunk; first = index into cell_items), so the fused kernels' grids have no holes, in
+// longest-processing-time-first order: entries with more items (more slab arithmetic) are pulled first,
+// the tail of the launch is made of small entries (counting sort on (items, rows) classes).
 __global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
                                                         const int32_t* __restrict__ blk_off,
                                                         int32_t* __restrict__ tmp_cell, int32_t* __restrict__ tmp_first,
