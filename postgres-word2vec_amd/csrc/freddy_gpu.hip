@@ -535,6 +535,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   za.p[1] = ix->w_cnt.as<uint32_t>(); za.n[1] = 4;
   za.p[2] = fused ? ix->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = fused ? C * 2 : 0;
   za.p[3] = ix->w_cand.as<uint32_t>(); za.n[3] = Q;
+  // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
+  za.p[4] = fused ? ix->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = fused ? (int)(items * upi * FUSED_NW) : 0;
 
   timed_launch(ix, s, "coarse_dist", [&] {
     if (tiled)
@@ -562,7 +564,10 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     pa.n_active = n_active; pa.Cpad = Cpad; pa.C = C; pa.W = W; pa.used_words = used_words;
     pa.cell_count = fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
     pa.cell_items = fused ? ix->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = n_active;
-    if (fused && !(tiled && first)) HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
+    if (fused && !(tiled && first)) {
+      HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
+      HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * (size_t)n_items * upi * FUSED_NW, s));
+    }
     {
       const int PV = pick_V(2 * W);
       const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
@@ -697,7 +702,6 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       ms.cand_count = fa.cand_count; ms.out_ids = d_out_ids; ms.out_dist = d_out_dist;
       ms.found = ix->w_found.as<int32_t>(); ms.next_active = next; ms.n_next = ix->w_cnt.as<int32_t>();
       ms.status = d_status;
-      ms.item_cell = pa.item_cell; ms.blk_off = ix->blk_off;
       ms.n_active = n_active; ms.W = W; ms.upi = upi; ms.L = L; ms.k = k; ms.found_rule = found_rule;
       ms.first_round = first ? 1 : 0; ms.sentinel = sentinel;
       timed_launch(ix, s, "merge_replay", [&] {

@@ -555,9 +555,7 @@ __global__ __launch_bounds__(FUSED_T) void ivf_fused_kernel(FusedArgs a) {
 // ---------------------------------------------------------------------------------------
 struct MergeSurvArgs {
   const u64* surv;             // [n_active*W][upi][8][512]
-  const int32_t* surv_count;   // [n_active*W][upi][8]
-  const int32_t* item_cell;    // [n_active*W] probed cell of each item (-1: none)
-  const int32_t* blk_off;      // [C+1]
+  const int32_t* surv_count;   // [n_active*W][upi][8], zero for the regions no workgroup wrote
   const int32_t* active;
   const int32_t* round_rows;
   const int32_t* cand_count;
@@ -586,23 +584,13 @@ __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
   const int R = a.W * per_item;
   constexpr int NBATCH = 4;   // region rounds whose (dependent) descriptor loads are issued together
   for (int jb = 0; jb < R; jb += 64 * NBATCH) {
-    int c[NBATCH], cell[NBATCH], nb[NBATCH];
+    int c[NBATCH];
     size_t region[NBATCH];
 #pragma unroll
     for (int u = 0; u < NBATCH; ++u) {
       const int j = jb + u * 64 + lane;
-      const int i = j / per_item;
-      region[u] = (size_t)(x * a.W + i) * per_item + (j - i * per_item);
-      cell[u] = (j < R) ? a.item_cell[x * a.W + i] : -1;
-    }
-#pragma unroll
-    for (int u = 0; u < NBATCH; ++u) nb[u] = (cell[u] >= 0) ? a.blk_off[cell[u] + 1] - a.blk_off[cell[u]] : 0;
-#pragma unroll
-    for (int u = 0; u < NBATCH; ++u) {
-      const int j = jb + u * 64 + lane;
-      const int ch = (j % per_item) / FUSED_NW;
-      const int nch = (nb[u] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-      c[u] = (ch < nch) ? a.surv_count[region[u]] : 0;
+      region[u] = (size_t)x * R + (size_t)(j < R ? j : 0);
+      c[u] = (j < R) ? a.surv_count[region[u]] : 0;
     }
     // a region typically holds 0-2 keys: fetch the first two of every region up front (independent
     // loads), only longer regions go back to memory inside the loop

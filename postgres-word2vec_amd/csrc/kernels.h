@@ -103,8 +103,8 @@ static constexpr int CT_DK = 16;
 // Scratch words the round's later kernels expect zeroed (probe bitmaps, counters): cleared by the
 // coarse kernel's threads on their way in instead of by four or five separate memset launches.
 struct ZeroArgs {
-  uint32_t* p[4];
-  int n[4];
+  uint32_t* p[5];
+  int n[5];
 };
 // TCW = cells per thread (4: 64x64 tile, one workgroup per CU for Q = C = 1024; 2: 64x32 tile, twice
 // the workgroups -- two waves per SIMD issue packed ops ~25 % faster than one)
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restric
   {
     const int gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, gsz = gridDim.x * gridDim.y * 256;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 5; ++a)
       for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
   }
   constexpr int TCELLS = 16 * TCW;   // cells per tile
