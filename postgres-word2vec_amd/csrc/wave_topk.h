@@ -27,6 +27,25 @@ __device__ __forceinline__ u64 make_key(float dist, uint32_t pos) {
 __device__ __forceinline__ float key_dist(u64 key) { return __uint_as_float((uint32_t)(key >> 32)); }
 __device__ __forceinline__ uint32_t key_pos(u64 key) { return (uint32_t)key; }
 
+// Value of lane (lane ^ j).  Strides 1, 2, 4 and 8 stay inside a row of 16 lanes and are DPP moves
+// (quad_perm, row_half_mirror o quad_perm, row_ror:8) -- a few cycles instead of a trip through the LDS
+// crossbar (ds_bpermute, ~100 cycles); a 64-key bitonic sort has 18 such steps out of 21.  j must be a
+// compile-time constant after unrolling.
+__device__ __forceinline__ int lane_xor(int v, int j) {
+  if (j == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  if (j == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  if (j == 4) {                                                                  // (i ^ 7) then (i ^ 3)
+    const int t = __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);      // row_half_mirror
+    return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);              // quad_perm [3,2,1,0]
+  }
+  if (j == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
+  return __shfl_xor(v, j, 64);
+}
+__device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v, int j) {
+  const uint32_t lo = (uint32_t)lane_xor((int)(uint32_t)v, j), hi = (uint32_t)lane_xor((int)(uint32_t)(v >> 32), j);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
 // number of set bits of a ballot mask below this lane (v_mbcnt: no per-lane mask register to keep alive)
 __device__ __forceinline__ int lanes_below(u64 mask) {
   return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -42,7 +61,7 @@ __device__ __forceinline__ u64 wave_sort64(u64 key) {
   for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      const u64 other = __shfl_xor(key, j, 64);
+      const u64 other = lane_xor64(key, j);
       const bool up = ((lane & k) == 0);
       const bool lower = ((lane & j) == 0);
       key = (lower == up) ? umin64(key, other) : umax64(key, other);
@@ -59,8 +78,8 @@ __device__ __forceinline__ void wave_sort32_x2(uint32_t& x, uint32_t& y) {
   for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
     for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint32_t ox = (uint32_t)__shfl_xor((int)x, j, 64);
-      const uint32_t oy = (uint32_t)__shfl_xor((int)y, j, 64);
+      const uint32_t ox = (uint32_t)lane_xor((int)x, j);
+      const uint32_t oy = (uint32_t)lane_xor((int)y, j);
       const bool take_min = (((lane & k) == 0) == ((lane & j) == 0));
       x = take_min ? min(x, ox) : max(x, ox);
       y = take_min ? min(y, oy) : max(y, oy);
@@ -90,7 +109,7 @@ __device__ __forceinline__ void wave_bitonic_merge(u64 (&a)[V]) {
     const bool lower = ((lane & j) == 0);
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const u64 other = __shfl_xor(a[v], j, 64);
+      const u64 other = lane_xor64(a[v], j);
       a[v] = lower ? umin64(a[v], other) : umax64(a[v], other);
     }
   }
@@ -144,7 +163,7 @@ __device__ __forceinline__ void wave_sort_full(u64 (&a)[V]) {
         const bool lower = ((lane & j) == 0);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          const u64 other = __shfl_xor(a[v], j, 64);
+          const u64 other = lane_xor64(a[v], j);
           const bool up = (((v * 64 + lane) & k) == 0);
           a[v] = (lower == up) ? umin64(a[v], other) : umax64(a[v], other);
         }
