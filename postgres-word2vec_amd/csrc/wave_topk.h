@@ -29,8 +29,8 @@ __device__ __forceinline__ uint32_t key_pos(u64 key) { return (uint32_t)key; }
 
 // Value of lane (lane ^ j).  Strides 1, 2, 4 and 8 stay inside a row of 16 lanes and are DPP moves
 // (quad_perm, row_half_mirror o quad_perm, row_ror:8) -- a few cycles instead of a trip through the LDS
-// crossbar (ds_bpermute, ~100 cycles); a 64-key bitonic sort has 18 such steps out of 21.  j must be a
-// compile-time constant after unrolling.
+// crossbar (ds_bpermute, ~100 cycles); strides 16 and 32 are gfx950's v_permlane16/32_swap.  So none of
+// the 21 steps of a 64-key bitonic sort touches the LDS.  j must be a compile-time constant after unrolling.
 __device__ __forceinline__ int lane_xor(int v, int j) {
   if (j == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
   if (j == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
@@ -39,6 +39,17 @@ __device__ __forceinline__ int lane_xor(int v, int j) {
     return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);              // quad_perm [3,2,1,0]
   }
   if (j == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
+  // gfx950's row swaps (checked on the hardware with tools/ubench5): v_permlane16_swap(v, v) leaves the
+  // even row's value of each row pair in [0] and the odd row's in [1]; v_permlane32_swap the lower half's
+  // in [0] and the upper half's in [1]
+  if (j == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane_id() & 16) ? r[0] : r[1]);
+  }
+  if (j == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane_id() & 32) ? r[0] : r[1]);
+  }
   return __shfl_xor(v, j, 64);
 }
 __device__ __forceinline__ unsigned long long lane_xor64(unsigned long long v, int j) {
