@@ -605,8 +605,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       int32_t* group_cnt = group_first + max_groups;
       int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
       timed_launch(ix, s, "group_items", [&] {
-        hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(256), 0, s, cell_count, C, n_active, gsz, ix->blk_off, group_cell, group_first,
-                           group_cnt, group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups);
+        hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(256), 0, s, cell_count, C, n_active, gsz, ix->blk_off,
+                           group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups);
       });
       HIP_TRY(hipGetLastError());
       FusedArgs fa;

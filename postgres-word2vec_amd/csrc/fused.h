@@ -51,69 +51,51 @@ static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row bloc
 // longest-processing-time-first order: entries with more items (more slab arithmetic) are pulled first,
 // the tail of the launch is made of small entries (counting sort on (items, rows) classes).
 __global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
-                                                        const int32_t* __restrict__ blk_off,
-                                                        int32_t* __restrict__ tmp_cell, int32_t* __restrict__ tmp_first,
-                                                        int32_t* __restrict__ tmp_cnt, int32_t* __restrict__ out_cell,
+                                                        const int32_t* __restrict__ blk_off, int32_t* __restrict__ out_cell,
                                                         int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
                                                         int32_t* __restrict__ n_groups) {
   constexpr int NB = FUSED_G * 4 + 4;   // class = (items, quarter of a full chunk), descending
-  __shared__ int scan[256];
   __shared__ int hist[NB];
   __shared__ int start[NB];
   const int tid = threadIdx.x;
-  const int per = (C + 255) / 256;
-  const int c0 = tid * per, c1 = (c0 + per < C) ? c0 + per : C;
-  int groups = 0;
-  for (int c = c0; c < c1; ++c) {
-    const int n = cell_count[c];
-    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-    groups += ((n + gsz - 1) / gsz) * chunks;
-  }
-  scan[tid] = groups;
   for (int i = tid; i < NB; i += 256) hist[i] = 0;
   __syncthreads();
-  for (int o = 1; o < 256; o <<= 1) {   // inclusive scan
-    const int v = (tid >= o) ? scan[tid - o] : 0;
-    __syncthreads();
-    scan[tid] += v;
-    __syncthreads();
-  }
-  const int total = scan[255];
-  if (tid == 0) n_groups[0] = total;
-  int gr_off = scan[tid] - groups;
-  auto klass = [&](int cnt, int chunk, int c) {
-    int nb = blk_off[c + 1] - blk_off[c] - chunk * FUSED_UNIT_BLOCKS;
-    nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
-    const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
-    return (FUSED_G - cnt) * 4 + (3 - rq);                     // small class index = big entry
-  };
-  for (int c = c0; c < c1; ++c) {
-    const int n = cell_count[c];
-    const int chunks = (blk_off[c + 1] - blk_off[c] + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-    for (int f = 0; f < n; f += gsz) {
-      const int cnt = (n - f < gsz) ? n - f : gsz;
-      for (int ch = 0; ch < chunks; ++ch) {
-        tmp_cell[gr_off] = c;
-        tmp_first[gr_off] = c * cell_cap + f;
-        tmp_cnt[gr_off] = cnt | (ch << 8);
-        atomicAdd(&hist[klass(cnt, ch, c)], 1);
-        ++gr_off;
+  // Two sweeps over this thread's cells (cell c = tid, tid + 256, ...): count the entries per class,
+  // then emit them into their class's range.  Order inside a class is irrelevant.
+  auto sweep = [&](bool emit) {
+    for (int c = tid; c < C; c += 256) {
+      const int n = cell_count[c];
+      if (n == 0) continue;
+      const int nblk = blk_off[c + 1] - blk_off[c];
+      const int chunks = (nblk + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+      for (int f = 0; f < n; f += gsz) {
+        const int cnt = (n - f < gsz) ? n - f : gsz;
+        for (int ch = 0; ch < chunks; ++ch) {
+          int nb = nblk - ch * FUSED_UNIT_BLOCKS;
+          nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
+          const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
+          const int k = (FUSED_G - cnt) * 4 + (3 - rq);              // small class index = big entry
+          if (!emit) {
+            atomicAdd(&hist[k], 1);
+          } else {
+            const int slot = atomicAdd(&start[k], 1);
+            out_cell[slot] = c;
+            out_first[slot] = c * cell_cap + f;
+            out_cnt[slot] = cnt | (ch << 8);
+          }
+        }
       }
     }
-  }
+  };
+  sweep(false);
   __syncthreads();
   if (tid == 0) {
     int acc = 0;
     for (int b = 0; b < NB; ++b) { start[b] = acc; acc += hist[b]; }
+    n_groups[0] = acc;
   }
   __syncthreads();
-  for (int e = tid; e < total; e += 256) {
-    const int cnt = tmp_cnt[e] & 0xff, chunk = tmp_cnt[e] >> 8, c = tmp_cell[e];
-    const int slot = atomicAdd(&start[klass(cnt, chunk, c)], 1);
-    out_cell[slot] = c;
-    out_first[slot] = tmp_first[e];
-    out_cnt[slot] = tmp_cnt[e];
-  }
+  sweep(true);
 }
 
 struct FusedArgs {
