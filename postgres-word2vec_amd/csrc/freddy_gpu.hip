@@ -759,6 +759,8 @@ static int max_queries_per_chunk(const freddy_gpu_index* ix, int W) {
   const size_t surv_bytes = upi <= 8 ? sizeof(u64) * (size_t)W * upi * FUSED_NW * FUSED_RMAX * 64 : 0;
   const size_t per_query = std::max(lut_bytes, surv_bytes);
   size_t n = lut_budget_bytes() / std::max<size_t>(per_query, 1);
+  // the fused path's per-cell item buckets are [C][queries of the chunk]: keep them within 256 MiB
+  if (surv_bytes) n = std::min<size_t>(n, ((size_t)256 << 20) / (sizeof(int32_t) * (size_t)std::max(ix->C, 1)));
   if (n < 1) n = 1;
   if (n > (1u << 20)) n = 1u << 20;
   return (int)n;
