@@ -540,8 +540,15 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
 
   timed_launch(ix, s, "coarse_dist", [&] {
     if (tiled)
-      hipLaunchKernelGGL((coarse_tile_kernel<2>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
-                         ix->w_distT.as<float>(), Q, Cpad, d, za);
+      {
+        static const int cdk = getenv("FREDDY_GPU_COARSE_DK") ? atoi(getenv("FREDDY_GPU_COARSE_DK")) : 16;   // (32 measured slower: 30 vs 27 us)
+        if (cdk == 16)
+          hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
+                             ix->w_distT.as<float>(), Q, Cpad, d, za);
+        else
+          hipLaunchKernelGGL((coarse_tile_kernel<2, 32>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
+                             ix->w_distT.as<float>(), Q, Cpad, d, za);
+      }
     else
       hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, d_q,
                          ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);

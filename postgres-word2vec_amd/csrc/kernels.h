@@ -93,13 +93,12 @@ __global__ __launch_bounds__(WG) void coarse_dist_kernel(const float* __restrict
 }
 
 // Tiled form of the same computation for batches: a workgroup produces a 64-query x 64-cell tile,
-// every thread a 4x4 block of it.  Queries and centroids are staged through LDS CT_DK dimensions
-// at a time (double buffered, one barrier per chunk), so per dimension a thread issues two
+// every thread a 4x4 block of it.  Queries and centroids are staged through LDS DK dimensions
+// at a time (double buffered, one barrier per chunk of DK dimensions), so per dimension a thread issues two
 // ds_read_b128 for 24 packed VALU instructions (8 independent sub/mul/add chains) and the tables
 // cross the L2 once per tile.  Dimensions past d are staged as zeros: (0-0)^2 adds +0, which
 // leaves every partial sum bit-identical.  Order per (query, cell): dimensions ascending, as
 // squareDistance (index_utils.c:500-508).
-static constexpr int CT_DK = 16;
 // Scratch words the round's later kernels expect zeroed (probe bitmaps, counters): cleared by the
 // coarse kernel's threads on their way in instead of by four or five separate memset launches.
 struct ZeroArgs {
@@ -108,7 +107,7 @@ struct ZeroArgs {
 };
 // TCW = cells per thread (4: 64x64 tile, one workgroup per CU for Q = C = 1024; 2: 64x32 tile, twice
 // the workgroups -- two waves per SIMD issue packed ops ~25 % faster than one)
-template <int TCW>
+template <int TCW, int DK>
 __global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restrict__ queries,
                                                          const float* __restrict__ coarseT,
                                                          float* __restrict__ dist, int Q, int Cpad, int d, ZeroArgs z) {
@@ -120,35 +119,44 @@ __global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restric
       for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
   }
   constexpr int TCELLS = 16 * TCW;   // cells per tile
-  __shared__ __attribute__((aligned(16))) float As[2][CT_DK][64];
-  __shared__ __attribute__((aligned(16))) float Bs[2][CT_DK][TCELLS];
+  constexpr int APT = DK / 4;        // dimensions of one query each thread stages per chunk
+  constexpr int BPT = DK / 16;       // dimension rows (of TCW cells) each thread stages per chunk
+  static_assert(DK % 16 == 0, "staging roles");
+  __shared__ __attribute__((aligned(16))) float As[2][DK][64];
+  __shared__ __attribute__((aligned(16))) float Bs[2][DK][TCELLS];
   const int tid = threadIdx.x;
   const int tc = tid & 15, tq = tid >> 4;
   const int c0 = blockIdx.x * TCELLS, q0 = blockIdx.y * 64;
   // staging roles
-  const int aq = tid >> 2, adim = (tid & 3) * 4;      // query aq, dims adim..adim+3 of the chunk
-  const int bdim = tid >> 4, bc = (tid & 15) * TCW;   // dim bdim, cells bc..bc+TCW-1
+  const int aq = tid >> 2, adim = (tid & 3) * APT;    // query aq, dims adim..adim+APT-1 of the chunk
+  const int bdim = tid >> 4, bc = (tid & 15) * TCW;   // dims bdim, bdim+16, ..., cells bc..bc+TCW-1
   const int aqg = (q0 + aq < Q) ? q0 + aq : Q - 1;
   const float* arow = queries + (size_t)aqg * d;
-  float ra[4];
-  float rb[TCW];
+  float ra[APT];
+  float rb[BPT][TCW];
   auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) ra[u] = (k0 + adim + u < d) ? arow[k0 + adim + u] : 0.0f;
-    const float* brow = coarseT + (size_t)(k0 + bdim) * Cpad + c0 + bc;
-    if (k0 + bdim < d) {
-      if (TCW == 4) { const float4 v = *reinterpret_cast<const float4*>(brow); rb[0] = v.x; rb[1] = v.y; rb[2 % TCW] = v.z; rb[3 % TCW] = v.w; }
-      else { const float2 v = *reinterpret_cast<const float2*>(brow); rb[0] = v.x; rb[1] = v.y; }
-    } else {
+    for (int u = 0; u < APT; ++u) ra[u] = (k0 + adim + u < d) ? arow[k0 + adim + u] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < TCW; ++i) rb[i] = 0.0f;
+    for (int w = 0; w < BPT; ++w) {
+      const int dim = k0 + bdim + w * 16;
+      const float* brow = coarseT + (size_t)dim * Cpad + c0 + bc;
+      if (dim < d) {
+        if (TCW == 4) { const float4 v = *reinterpret_cast<const float4*>(brow); rb[w][0] = v.x; rb[w][1] = v.y; rb[w][2 % TCW] = v.z; rb[w][3 % TCW] = v.w; }
+        else { const float2 v = *reinterpret_cast<const float2*>(brow); rb[w][0] = v.x; rb[w][1] = v.y; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TCW; ++i) rb[w][i] = 0.0f;
+      }
     }
   };
   auto stash = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) As[buf][adim + u][aq] = ra[u];
+    for (int u = 0; u < APT; ++u) As[buf][adim + u][aq] = ra[u];
 #pragma unroll
-    for (int i = 0; i < TCW; ++i) Bs[buf][bdim][bc + i] = rb[i];
+    for (int w = 0; w < BPT; ++w)
+#pragma unroll
+      for (int i = 0; i < TCW; ++i) Bs[buf][bdim + w * 16][bc + i] = rb[w][i];
   };
   v2f acc[TCW][2];   // [cell i][query pair j]
 #pragma unroll
@@ -157,11 +165,11 @@ __global__ __launch_bounds__(256) void coarse_tile_kernel(const float* __restric
   stash(0);
   __syncthreads();
   int buf = 0;
-  for (int k0 = 0; k0 < d; k0 += CT_DK) {
-    const bool more = k0 + CT_DK < d;
-    if (more) fetch(k0 + CT_DK);
+  for (int k0 = 0; k0 < d; k0 += DK) {
+    const bool more = k0 + DK < d;
+    if (more) fetch(k0 + DK);
 #pragma unroll
-    for (int dd = 0; dd < CT_DK; ++dd) {
+    for (int dd = 0; dd < DK; ++dd) {
       const float4 a4 = *reinterpret_cast<const float4*>(&As[buf][dd][tq * 4]);
       float bv[TCW];
       if (TCW == 4) {
