@@ -2,8 +2,9 @@
 """bench.py -- batched IVFADC kNN throughput (BASELINE.json metric) on N MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic queries that are already
-resident in HBM: coarse distances -> probe plan -> residuals -> LUT build -> ADC scan with
-fused top-k -> merge/replay (+ the RCCL gather of the per-shard top-k when N > 1).
+resident in HBM: coarse distances -> probe plan (items bucketed by cell) -> work table -> the fused
+kernel (residuals, LUT slabs, ADC sums and survivor selection) -> merge/replay
+(+ the asynchronous RCCL gather of the per-shard top-k when N > 1).
 
 Workload (BASELINE.json configs[2]): 3,000,000 x 300-d synthetic GoogleNews-shaped corpus,
 C=1000 coarse cells, m=12, K=1024 residual PQ, nprobe W=10, k=5, 1024 queries per GPU
