@@ -140,6 +140,17 @@ int grouping_pq(freddy_session_t* s, const int32_t* input_ids, int32_t n_ids, co
 int analogy_3cosadd_pq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, int32_t* result);
 int analogy_3cosadd_ivfadc(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, int32_t* result);
 
+/* The plpgsql callers of the two single-query SRFs, keyed by row id; row.distance
+ * carries the SIMILARITY, *n_rows <= k (the joins drop the (-1, sentinel) filler rows).
+ * k_nearest_neighbour_pq / k_nearest_neighbour_ivfadc (bytea, int)        freddy--0.0.1.sql:610-622, 520-531
+ *   similarity = (1.0 - (distance / 2.0))::float4 of the distance as the SRF emits it ("%f")
+ * k_nearest_neighbour_pq_pv / k_nearest_neighbour_ivfadc_pv (bytea, int)  freddy--0.0.1.sql:625-641, 575-591
+ *   get_pvf() * k candidates, re-ranked by cosine_similarity_bytea(q, vector) DESC, first k */
+int k_nearest_neighbour_pq(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+int k_nearest_neighbour_ivfadc(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+int k_nearest_neighbour_pq_pv(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+int k_nearest_neighbour_ivfadc_pv(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
+
 /* per-call row emit: snprintf("%d") / snprintf("%f") into 16-byte buffers   freddy.c:154-169,1001-1023 */
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]);
 void freddy_emit_row3(const freddy_row3* row, char values[3][16]);

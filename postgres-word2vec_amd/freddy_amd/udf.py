@@ -171,6 +171,18 @@ class Session:
         self._check(self.lib.knn_in_exact(self.h, _p(q), q.size, k, _p(ids), ids.size, _p(out), C.byref(n)))
         return out[:n.value]
 
+    def _knn2(self, fn, query, k):
+        q = _f32(query)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(fn(self.h, _p(q), q.size, k, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def k_nearest_neighbour_pq(self, query, k): return self._knn2(self.lib.k_nearest_neighbour_pq, query, k)
+    def k_nearest_neighbour_ivfadc(self, query, k): return self._knn2(self.lib.k_nearest_neighbour_ivfadc, query, k)
+    def k_nearest_neighbour_pq_pv(self, query, k): return self._knn2(self.lib.k_nearest_neighbour_pq_pv, query, k)
+    def k_nearest_neighbour_ivfadc_pv(self, query, k): return self._knn2(self.lib.k_nearest_neighbour_ivfadc_pv, query, k)
+
     def grouping_pq(self, input_ids, group_ids):
         """freddy.c:1176-1401: rows (id, group_id)."""
         ids, groups = _i32(input_ids), _i32(group_ids)

@@ -614,6 +614,74 @@ int analogy_3cosadd_ivfadc(freddy_session_t* s, int32_t id1, int32_t id2, int32_
   return analogy_common(s, true, id1, id2, id3, result);
 }
 
+// ---- the plpgsql callers of pq_search / ivfadc_search, keyed by row id ------------------
+// SRF text round trip of a distance: snprintf("%f") into the tuple, float4in on the way out (freddy.c:164)
+static float emitted(float distance) {
+  char buf[16];
+  snprintf(buf, sizeof buf, "%f", distance);
+  return strtof(buf, nullptr);
+}
+// (1.0 - (distance / 2.0))::float4 -- float4 / numeric is evaluated in float8   freddy--0.0.1.sql:527,617
+static float similarity_of(float distance) { return (float)(1.0 - (double)emitted(distance) / 2.0); }
+
+static int knn_plain(freddy_session_t* s, bool ivf, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  if (!s || (ivf ? !s->ivf : !s->pq)) return fail(-1, ivf ? "coarse_quantization / residual_codebook / fine_quantization are not loaded"
+                                                          : "pq_quantization / pq_codebook are not loaded");
+  if (dim != (ivf ? s->ivf_d : s->pq_d)) return fail(-1, "query has %d dimensions, index has %d", dim, ivf ? s->ivf_d : s->pq_d);
+  if (k <= 0 || !query || !out) return fail(-1, "bad argument");
+  std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+  const int rc = ivf ? freddy_gpu_ivfadc_search(s->ivf, query, 1, k, s->w, 1000.0f, FREDDY_FOUND_ROWS, ids.data(), dist.data())
+                     : freddy_gpu_pq_search(s->pq, query, 1, k, 100.0f, nullptr, 0, ids.data(), dist.data());
+  if (rc) return gpu_fail(rc);
+  int n = 0;   // INNER JOIN ... ON idx = id drops the (-1, sentinel) rows
+  for (int i = 0; i < k; ++i)
+    if (ids[i] >= 0) { out[n].id = ids[i]; out[n].distance = similarity_of(dist[i]); ++n; }
+  if (n_rows) *n_rows = n;
+  return 0;
+}
+int k_nearest_neighbour_pq(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  return knn_plain(s, false, query, dim, k, out, n_rows);
+}
+int k_nearest_neighbour_ivfadc(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  return knn_plain(s, true, query, dim, k, out, n_rows);
+}
+
+// ... with post verification: get_pvf() * k candidates, ORDER BY cosine_similarity_bytea(q, v.vector) DESC
+// FETCH FIRST k ROWS ONLY (equal similarities: ascending id)            freddy--0.0.1.sql:575-591, 625-641
+static int knn_pv(freddy_session_t* s, bool ivf, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  if (!s || (ivf ? !s->ivf : !s->pq)) return fail(-1, ivf ? "coarse_quantization / residual_codebook / fine_quantization are not loaded"
+                                                          : "pq_quantization / pq_codebook are not loaded");
+  if (s->norm_ids.empty() || s->d != dim) return fail(-1, "google_vecs_norm is not loaded");
+  if (dim != (ivf ? s->ivf_d : s->pq_d)) return fail(-1, "query has %d dimensions, index has %d", dim, ivf ? s->ivf_d : s->pq_d);
+  if (k <= 0 || !query || !out) return fail(-1, "bad argument");
+  const int64_t kc = (int64_t)k * std::max(s->pvf, 1);
+  if (kc > 512) return fail(-1, "pvf * k = %lld exceeds this build's limit of 512 candidates", (long long)kc);
+  std::vector<int32_t> ids((size_t)kc); std::vector<float> dist((size_t)kc);
+  const int rc = ivf ? freddy_gpu_ivfadc_search(s->ivf, query, 1, (int)kc, s->w, 1000.0f, FREDDY_FOUND_ROWS, ids.data(), dist.data())
+                     : freddy_gpu_pq_search(s->pq, query, 1, (int)kc, 100.0f, nullptr, 0, ids.data(), dist.data());
+  if (rc) return gpu_fail(rc);
+  std::vector<freddy_row2> cand;
+  for (int64_t i = 0; i < kc; ++i) {
+    if (ids[i] < 0) continue;
+    const float* v = norm_vec_of(s, ids[i]);
+    if (!v) continue;
+    cand.push_back({ids[i], cos_sim_bytea(query, v, dim)});
+  }
+  std::sort(cand.begin(), cand.end(), [](const freddy_row2& a, const freddy_row2& b) {
+    return a.distance != b.distance ? a.distance > b.distance : a.id < b.id;
+  });
+  const int n = (int)std::min<size_t>(cand.size(), (size_t)k);
+  for (int i = 0; i < n; ++i) out[i] = cand[i];
+  if (n_rows) *n_rows = n;
+  return 0;
+}
+int k_nearest_neighbour_pq_pv(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  return knn_pv(s, false, query, dim, k, out, n_rows);
+}
+int k_nearest_neighbour_ivfadc_pv(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows) {
+  return knn_pv(s, true, query, dim, k, out, n_rows);
+}
+
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]) {
   snprintf(values[0], 16, "%d", row->id);
   snprintf(values[1], 16, "%f", row->distance);

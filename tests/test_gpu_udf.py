@@ -186,3 +186,27 @@ def test_index_file_import(db, oracle, tmp_path):
     rows = s2.ivfadc_batch_search([17, 900], 5)
     same(rows, oracle.ivfadc_batch_search(t["ivf"], t["x"][[16, 899]], 5))
     s2.close()
+
+
+@pytest.mark.parametrize("which", ["pq", "ivfadc"])
+def test_k_nearest_neighbour_callers(db, oracle, which):
+    """The plpgsql callers of pq_search / ivfadc_search (freddy--0.0.1.sql:520-531, 575-591, 610-641):
+    similarity from the emitted distance, and post verification by exact cosine similarity."""
+    s, t = db
+    s.set_w(3); s.set_pvf(4)
+    q = t["x"][2468]
+    ids_all = t["x"]
+    cand = (lambda k: oracle.pq_search(t["pq"], q, k)) if which == "pq" else (lambda k: oracle.ivfadc_search(t["ivf"], q, k, 3))
+    plain = s.k_nearest_neighbour_pq(q, 6) if which == "pq" else s.k_nearest_neighbour_ivfadc(q, 6)
+    exp = [e for e in cand(6) if e["id"] >= 0]
+    assert plain["id"].tolist() == [int(e["id"]) for e in exp]
+    sims = [np.float32(1.0 - np.float64(oracle.emit_roundtrip(e["dist"])) / 2.0) for e in exp]
+    assert np.array_equal(plain["distance"].view(np.uint32), np.array(sims, np.float32).view(np.uint32))
+    pv = s.k_nearest_neighbour_pq_pv(q, 5) if which == "pq" else s.k_nearest_neighbour_ivfadc_pv(q, 5)
+    c = [int(e["id"]) for e in cand(20) if e["id"] >= 0]
+    scored = sorted(((-float(oracle.cosine_similarity_bytea(q, ids_all[i - 1])), i) for i in c))[:5]
+    assert pv["id"].tolist() == [i for _, i in scored]
+    assert np.array_equal(pv["distance"].view(np.uint32),
+                          np.array([oracle.cosine_similarity_bytea(q, ids_all[i - 1]) for _, i in scored], np.float32).view(np.uint32))
+    assert pv["id"][0] == 2469                                   # the query's own row wins the exact re-ranking
+    s.set_pvf(20)
