@@ -151,6 +151,13 @@ int k_nearest_neighbour_ivfadc(freddy_session_t* s, const float* query, int32_t 
 int k_nearest_neighbour_pq_pv(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
 int k_nearest_neighbour_ivfadc_pv(freddy_session_t* s, const float* query, int32_t dim, int32_t k, freddy_row2* out, int32_t* n_rows);
 
+/* knn_in_pq(anyarray, int, int[]) and k_nearest_neighbour_ivfadc_batch(varchar[], int) (by query ids):
+ * pq_search_in / ivfadc_batch_search with the same similarity mapping     freddy--0.0.1.sql:830-843, 535-553 */
+int knn_in_pq(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
+              freddy_row2* out, int32_t* n_rows);
+int k_nearest_neighbour_ivfadc_batch(freddy_session_t* s, const int32_t* query_ids, int32_t n_query_ids, int32_t k,
+                                     freddy_row3* out, int32_t* n_rows);
+
 /* per-call row emit: snprintf("%d") / snprintf("%f") into 16-byte buffers   freddy.c:154-169,1001-1023 */
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]);
 void freddy_emit_row3(const freddy_row3* row, char values[3][16]);

@@ -183,6 +183,20 @@ class Session:
     def k_nearest_neighbour_pq_pv(self, query, k): return self._knn2(self.lib.k_nearest_neighbour_pq_pv, query, k)
     def k_nearest_neighbour_ivfadc_pv(self, query, k): return self._knn2(self.lib.k_nearest_neighbour_ivfadc_pv, query, k)
 
+    def knn_in_pq(self, query, k, input_ids):
+        q, ids = _f32(query), _i32(input_ids)
+        out = np.empty(k, ROW2)
+        n = C.c_int32(0)
+        self._check(self.lib.knn_in_pq(self.h, _p(q), q.size, k, _p(ids), ids.size, _p(out), C.byref(n)))
+        return out[:n.value]
+
+    def k_nearest_neighbour_ivfadc_batch(self, query_ids, k):
+        qid = _i32(query_ids)
+        out = np.empty(max(qid.size, 1) * k, ROW3)
+        n = C.c_int32(0)
+        self._check(self.lib.k_nearest_neighbour_ivfadc_batch(self.h, _p(qid), qid.size, k, _p(out), C.byref(n)))
+        return out[:n.value]
+
     def grouping_pq(self, input_ids, group_ids):
         """freddy.c:1176-1401: rows (id, group_id)."""
         ids, groups = _i32(input_ids), _i32(group_ids)

@@ -682,6 +682,34 @@ int k_nearest_neighbour_ivfadc_pv(freddy_session_t* s, const float* query, int32
   return knn_pv(s, true, query, dim, k, out, n_rows);
 }
 
+// knn_in_pq(anyarray, int, int[])                                          freddy--0.0.1.sql:830-843
+int knn_in_pq(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids, int32_t n_ids,
+              freddy_row2* out, int32_t* n_rows) {
+  if (k <= 0 || !out) return fail(-1, "bad argument");
+  std::vector<freddy_row2> rows((size_t)k);
+  int32_t n = 0;
+  if (int rc = pq_search_in(s, query, dim, k, input_ids, n_ids, rows.data(), &n)) return rc;
+  int m = 0;
+  for (int i = 0; i < n; ++i)
+    if (rows[i].id >= 0) { out[m].id = rows[i].id; out[m].distance = similarity_of(rows[i].distance); ++m; }
+  if (n_rows) *n_rows = m;
+  return 0;
+}
+
+// k_nearest_neighbour_ivfadc_batch(varchar[], int), by query ids            freddy--0.0.1.sql:535-553
+int k_nearest_neighbour_ivfadc_batch(freddy_session_t* s, const int32_t* query_ids, int32_t n_query_ids, int32_t k,
+                                     freddy_row3* out, int32_t* n_rows) {
+  if (k <= 0 || !out || n_query_ids < 0) return fail(-1, "bad argument");
+  std::vector<freddy_row3> rows((size_t)std::max(n_query_ids, 1) * k);
+  int32_t n = 0;
+  if (int rc = ivfadc_batch_search(s, query_ids, n_query_ids, k, rows.data(), &n)) return rc;
+  int m = 0;
+  for (int i = 0; i < n; ++i)
+    if (rows[i].id >= 0) { out[m] = rows[i]; out[m].distance = similarity_of(rows[i].distance); ++m; }
+  if (n_rows) *n_rows = m;
+  return 0;
+}
+
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]) {
   snprintf(values[0], 16, "%d", row->id);
   snprintf(values[1], 16, "%f", row->distance);

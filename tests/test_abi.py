@@ -59,7 +59,8 @@ def test_host_mirror_exports_every_declared_symbol():
     assert {"pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search",
             "ivpq_search_in", "knn_join", "k_nearest_neighbour", "knn_in_exact", "grouping_pq",
             "analogy_3cosadd_pq", "analogy_3cosadd_ivfadc", "k_nearest_neighbour_pq", "k_nearest_neighbour_ivfadc",
-            "k_nearest_neighbour_pq_pv", "k_nearest_neighbour_ivfadc_pv"} <= set(flat)
+            "k_nearest_neighbour_pq_pv", "k_nearest_neighbour_ivfadc_pv", "knn_in_pq",
+            "k_nearest_neighbour_ivfadc_batch"} <= set(flat)
     for n in flat:
         assert hasattr(lib, n), f"{n} declared in include/freddy_udf.h but not exported"
 

@@ -210,3 +210,24 @@ def test_k_nearest_neighbour_callers(db, oracle, which):
                           np.array([oracle.cosine_similarity_bytea(q, ids_all[i - 1]) for _, i in scored], np.float32).view(np.uint32))
     assert pv["id"][0] == 2469                                   # the query's own row wins the exact re-ranking
     s.set_pvf(20)
+
+
+def test_knn_in_pq_and_ivfadc_batch_callers(db, oracle):
+    """knn_in_pq / k_nearest_neighbour_ivfadc_batch (freddy--0.0.1.sql:830-843, 535-553): the SRF rows with
+    similarity = (1.0 - (emitted distance / 2.0))::float4, filler rows dropped by the joins."""
+    s, t = db
+    sim = lambda d: np.float32(1.0 - np.float64(oracle.emit_roundtrip(d)) / 2.0)
+    q = t["x"][55]
+    ids = [5, 17, 900, 19999, 20001]
+    rows = s.knn_in_pq(q, 6, ids)
+    exp = [e for e in oracle.pq_search_in(t["pq"], q, 6, ids) if e["id"] >= 0]
+    assert len(rows) == 4 and rows["id"].tolist() == [int(e["id"]) for e in exp]
+    assert np.array_equal(rows["distance"].view(np.uint32), np.array([sim(e["dist"]) for e in exp], np.float32).view(np.uint32))
+    rows = s.k_nearest_neighbour_ivfadc_batch([900, 3, 17], 4)
+    found = np.array([3, 17, 900], np.int32)
+    exp = oracle.ivfadc_batch_search(t["ivf"], t["x"][found - 1], 4)
+    keep = exp["id"].ravel() >= 0
+    assert rows["query_id"].tolist() == np.repeat(found, 4)[keep].tolist()
+    assert rows["id"].tolist() == exp["id"].ravel()[keep].tolist()
+    assert np.array_equal(rows["distance"].view(np.uint32),
+                          np.array([sim(d) for d in exp["dist"].ravel()[keep]], np.float32).view(np.uint32))
