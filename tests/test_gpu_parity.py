@@ -365,3 +365,40 @@ def test_ivfadc_many_probes(gpu, oracle, fused, monkeypatch):
         exp = oracle.ivfadc_search_many(ot, qs, 4, W, sentinel=1000.0, found_rule=0)
         util.assert_same_lists(gi, gd, exp, f"W={W}")
     idx.close()
+
+
+def test_hip_path_reproduces_committed_golden_vectors(gpu, monkeypatch):
+    """The HIP path against the committed vectors of tests/golden/ (no oracle involved on this side)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "freddy_small.npz"))
+    x, ids, qs = g["x"], g["ids"], g["queries"]
+
+    def same(gi, gd, exp, what):
+        assert np.array_equal(gi, exp["id"]), what
+        assert np.array_equal(gd.view(np.uint32), exp["dist"].view(np.uint32)), what
+
+    _, codes = gpu.encode(g["pq_codebook"], x)
+    assert np.array_equal(codes, g["pq_codes"])
+    pq = gpu.PQIndex(g["pq_codebook"], ids, g["pq_codes"])
+    same(*pq.search(qs, 5, sentinel=100.0), g["pq_search"], "pq_search")
+    same(*pq.search(qs, 4, sentinel=1000.0, subset_ids=g["subset"]), g["pq_search_in"], "pq_search_in")
+    gi, gg = pq.grouping(x[[9, 199, 349]], g["grouping_input"])
+    assert np.array_equal(gi, g["grouping_ids"]) and np.array_equal(gg, g["grouping_group"])
+    pq.close()
+    ivf = gpu.IVFIndex(g["coarse"], g["codebook"], g["list_off"], g["ivf_ids"], g["ivf_codes"])
+    for fused in ("1", "0"):
+        monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
+        same(*ivf.search(qs, 5, 3, sentinel=1000.0, found_rule=gpu.FOUND_ROWS), g["ivfadc_w3_k5"], f"ivfadc fused={fused}")
+        same(*ivf.search(qs, 7, 1, sentinel=100.0, found_rule=gpu.FOUND_ACCEPTED), g["ivfadc_w1_k7_accepted"], f"batch rule fused={fused}")
+        same(*ivf.search(qs, 20, 8, sentinel=1000.0, found_rule=gpu.FOUND_ROWS), g["ivfadc_w8_k20"], f"W=8 fused={fused}")
+    ivf.close()
+    iv = gpu.IVPQIndex(g["ivpq_codebook"], g["ivpq_coarse"], ids, g["ivpq_coarse_id"], g["ivpq_codes"], x, g["ivpq_stats"])
+    for method in (0, 1, 2):
+        gi, gd, it = iv.knn_join(qs, 5, g["targets"], 3, 4, method)
+        same(gi, gd, g[f"knn_join_m{method}"], f"knn_join method {method}")
+        assert it == int(g[f"knn_join_m{method}_iterations"])
+    iv.close()
+    vi = gpu.VectorIndex(ids, x)
+    gi, gs = vi.search(qs, 6)
+    same(gi, gs, g["exact_knn"], "exact kNN")
+    vi.close()

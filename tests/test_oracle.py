@@ -485,3 +485,31 @@ def test_encode_oracle(oracle):
     for i in range(50):
         ds = np.array([py_sqdist(v[i], coarse[c]) for c in range(9)], f32)
         assert cell[i] == int(np.argmin(ds)) and cell[i] != 6
+
+
+def golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "freddy_small.npz"))
+
+
+def test_oracle_reproduces_committed_golden_vectors(oracle):
+    """tests/golden/freddy_small.npz (inputs + the oracle's outputs when it was written; see
+    make_golden.py for what it does and does not pin): the oracle built here gives the same bits."""
+    g = golden()
+    x, ids, qs = g["x"], g["ids"], g["queries"]
+    same = lambda a, b: np.array_equal(a["id"], b["id"]) and np.array_equal(a["dist"].view(np.uint32), b["dist"].view(np.uint32))
+    assert np.array_equal(oracle.encode_pq(g["pq_codebook"], x), g["pq_codes"])
+    pq = oracle.pq_table(g["pq_codebook"], ids, g["pq_codes"])
+    assert same(np.stack([oracle.pq_search(pq, q, 5) for q in qs]), g["pq_search"])
+    assert same(np.stack([oracle.pq_search_in(pq, q, 4, g["subset"]) for q in qs]), g["pq_search_in"])
+    ivf = oracle.ivf_table(g["coarse"], g["codebook"], g["list_off"], g["ivf_ids"], g["ivf_codes"])
+    assert same(oracle.ivfadc_search_many(ivf, qs, 5, 3, sentinel=1000.0, found_rule=0), g["ivfadc_w3_k5"])
+    assert same(oracle.ivfadc_search_many(ivf, qs, 7, 1, sentinel=100.0, found_rule=1), g["ivfadc_w1_k7_accepted"])
+    assert same(oracle.ivfadc_search_many(ivf, qs, 20, 8, sentinel=1000.0, found_rule=0), g["ivfadc_w8_k20"])
+    ivpq = oracle.ivpq_table(g["ivpq_codebook"], g["ivpq_coarse"], ids, g["ivpq_coarse_id"], g["ivpq_codes"], x, g["ivpq_stats"])
+    for method in (0, 1, 2):
+        exp, it = oracle.ivpq_search_in(ivpq, qs, 5, g["targets"], 3, 4, method)
+        assert same(exp, g[f"knn_join_m{method}"]) and it == int(g[f"knn_join_m{method}_iterations"])
+    assert same(np.stack([oracle.exact_knn(x, ids, q, 6) for q in qs]), g["exact_knn"])
+    gi, gg = oracle.grouping_pq(pq, x[[9, 199, 349]], g["grouping_input"])
+    assert np.array_equal(gi, g["grouping_ids"]) and np.array_equal(gg, g["grouping_group"])
