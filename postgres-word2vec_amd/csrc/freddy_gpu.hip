@@ -23,6 +23,7 @@
 #include "fused.h"
 #include "fused2.h"
 #include "fused3.h"
+#include "fused4.h"
 #include "exact.h"
 #include "join.h"
 
@@ -96,6 +97,10 @@ struct freddy_gpu_index {
   int Cpad = 0;
   float* cbT = nullptr;         // [m][S][K]
   float* cbP = nullptr;         // fused kernel layout [m][SP/4][512 slots][4 dims][2 codes] (NULL unless K <= 1024)
+  // filter + refine path (fused4.h); NULL unless the shape is the fused one and the table fits the budget
+  float* cbR = nullptr;         // [m][K][S] row-major codebook for the exact stage
+  float* dtab = nullptr;        // [C][m][K]  |c|^2 + 2 co_p . c
+  float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
   uint32_t* packed = nullptr;   // [blocks][M2][64]
@@ -110,11 +115,17 @@ struct freddy_gpu_index {
   // workspaces
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
 };
+
+static size_t filter_table_budget_bytes() {
+  const char* e = getenv("FREDDY_GPU_FILTER_TABLE_MB");   // 0 disables the filter + refine path at pin time
+  size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 8192;
+  return mb << 20;
+}
 
 static size_t lut_budget_bytes() {
   const char* e = getenv("FREDDY_GPU_LUT_BUDGET_MB");
@@ -151,7 +162,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->dtab, ix->pmax, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -159,7 +170,7 @@ static void free_index(freddy_gpu_index* ix) {
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
                     &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
-                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof};
+                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof, &ix->w_qc, &ix->w_qn};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
     for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -312,6 +323,36 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
                   cbP[((((size_t)p * SPq + jb) * FUSED_T + tl) * 4 + u) * 2 + e] = t->codebook[((size_t)p * ix->K + c) * ix->S + j];
               }
       if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    }
+    // filter + refine tables (fused4.h): dt is C*m*K floats (49 MB for C=1000, m=12, K=1024)
+    const size_t dt_bytes = sizeof(float) * (size_t)t->C * ix->m * ix->K;
+    if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && dt_bytes <= filter_table_budget_bytes()) {
+      std::vector<float> pmax((size_t)ix->m);
+      for (int p = 0; p < ix->m; ++p) {
+        double comax = 0.0, cmax = 0.0;
+        for (int c = 0; c < t->C; ++c) {
+          double n2 = 0.0;
+          for (int j = 0; j < ix->S; ++j) { const double v = t->coarse[(size_t)c * t->d + p * ix->S + j]; n2 += v * v; }
+          comax = std::max(comax, std::sqrt(n2));
+        }
+        for (int c = 0; c < ix->K; ++c) {
+          double n2 = 0.0;
+          for (int j = 0; j < ix->S; ++j) { const double v = t->codebook[((size_t)p * ix->K + c) * ix->S + j]; n2 += v * v; }
+          cmax = std::max(cmax, std::sqrt(n2));
+        }
+        pmax[p] = (float)((comax + cmax) * (1.0 + 1e-6));
+      }
+      if (upload(&ix->cbR, t->codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
+          upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
+          hipMalloc((void**)&ix->dtab, dt_bytes) != hipSuccess)
+        rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+      if (!rc) {
+        ix->bytes += (int64_t)dt_bytes;
+        hipLaunchKernelGGL(cell_codebook_kernel, dim3(t->C, ix->m), dim3(256), 0, ix->stream, ix->coarse, ix->cbT, ix->dtab,
+                           t->d, ix->m, ix->K, ix->S);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
+          rc = fail(FREDDY_E_HIP, "building the cell x codebook table failed");
+      }
     }
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
@@ -510,6 +551,16 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
       ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  // FREDDY_GPU_FUSED_KERNEL: 1 = symmetric exact kernel (fused.h), 2 = one builder wave per SIMD (fused2.h),
+  // 3 = two builder waves per SIMD, 12 items per entry (fused3.h), default 4 = filter + refine (fused4.h:
+  // cheap bounded distances in the scan, the reference's arithmetic only for the rows that can matter)
+  const char* fvenv = getenv("FREDDY_GPU_FUSED_KERNEL");   // read per call: the tests switch it
+  int fvariant = (fvenv && fvenv[0] >= '1' && fvenv[0] <= '4') ? fvenv[0] - '0' : 4;
+  if (fvariant == 4 && !ix->dtab) fvariant = 3;
+  if (fused && fvariant == 4) {
+    if (ix->w_qc.ensure(sizeof(float) * (size_t)Q * m * K) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  }
   if (fused) {
     // cell_count[C]; cell_items[C][Q]; group table: 2 x 3 arrays of (items/G + C) * upi entries
     if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
@@ -555,6 +606,14 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   });
   HIP_TRY(hipGetLastError());
 
+  if (fused && fvariant == 4) {
+    timed_launch(ix, s, "query_codebook", [&] {
+      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3((K + 255) / 256, m, (Q + 31) / 32), dim3(256), 0, s, d_q, ix->cbT,
+                         ix->w_qc.as<float>(), ix->w_qn.as<float>(), Q, d, m, K);
+    });
+    HIP_TRY(hipGetLastError());
+  }
+
   ix->last_Q = Q;
   int n_active = Q;
   const int32_t* active = nullptr;
@@ -592,10 +651,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     // forms the residuals itself
     // FREDDY_GPU_FUSED_KERNEL: 1 = symmetric kernel (fused.h), 2 = one builder wave per SIMD (fused2.h),
     // default 3 = two builder waves per SIMD, 12 items per entry (fused3.h)
-    const char* fvenv = getenv("FREDDY_GPU_FUSED_KERNEL");   // read per call: the tests switch it
-    const int fvariant = (fvenv && fvenv[0] >= '1' && fvenv[0] <= '2') ? fvenv[0] - '0' : 3;
     const bool symmetric = fvariant == 1;
-    const int gsz = (fvariant == 3) ? SPEC2_G : FUSED_G;
+    const int gsz = (fvariant >= 3) ? SPEC2_G : FUSED_G;
     if (!fused || symmetric) {
       timed_launch(ix, s, "residual", [&] {
         hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
@@ -674,6 +731,32 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
           else
             hipLaunchKernelGGL((ivf_spec_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
         });
+      } else if (fvariant == 4) {
+        FilterArgs fl;
+        fl.qc = ix->w_qc.as<float>(); fl.qn = ix->w_qn.as<float>(); fl.dt = ix->dtab; fl.pmax = ix->pmax;
+        fl.dist = ix->w_distT.as<float>(); fl.Cpad = Cpad;
+        fl.item_query = fa.item_query; fl.sorted_item = fa.sorted_item; fl.group_cell = fa.group_cell;
+        fl.group_first = fa.group_first; fl.group_cnt = fa.group_cnt; fl.n_groups = fa.n_groups; fl.work_counter = fa.work_counter;
+        fl.blk_off = fa.blk_off; fl.packed = fa.packed; fl.pos = fa.pos; fl.surv = fa.surv; fl.surv_count = fa.surv_count;
+        fl.cand_count = fa.cand_count; fl.K = K; fl.L = L; fl.upi = upi; fl.sentinel = sentinel;
+        fl.ablate = fa.ablate; fl.prof = fa.prof;
+        const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
+        const size_t flds = desc_off + 4096 + 64 + 512 + (2 * 5 * 16 + 16) * sizeof(float);
+        fl.desc_offset = (uint32_t)desc_off;
+        static bool f4attr = false;
+        if (!f4attr) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_filter_kernel<12, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_filter_kernel<12, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          f4attr = true;
+        }
+        timed_launch(ix, s, "ivf_fused", [&] {
+          if (K == 1024)
+            hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+          else
+            hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+        });
       } else {
         const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
         const size_t flds = desc_off + 4096 + 64 + 512 + (size_t)SPEC2_G * 12 * 28 * sizeof(float);
@@ -704,6 +787,21 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
           fprintf(stderr, "[spec prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f | workgroups ran dry over %.1f us\n",
                   n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent, (mx_end - mn_end) / 100.0);
       }
+      if (fvariant == 4) {
+        MergeRefineArgs mr;
+        mr.surv = fa.surv; mr.surv_count = fa.surv_count; mr.active = active; mr.round_rows = pa.round_rows;
+        mr.item_cell = pa.item_cell; mr.queries = d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
+        mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos;
+        mr.cand_count = fa.cand_count; mr.out_ids = d_out_ids; mr.out_dist = d_out_dist;
+        mr.found = ix->w_found.as<int32_t>(); mr.next_active = next; mr.n_next = ix->w_cnt.as<int32_t>();
+        mr.status = d_status;
+        mr.n_active = n_active; mr.W = W; mr.upi = upi; mr.L = L; mr.k = k; mr.found_rule = found_rule;
+        mr.first_round = first ? 1 : 0; mr.K = K; mr.d = d; mr.sentinel = sentinel;
+        timed_launch(ix, s, "merge_replay", [&] {
+          hipLaunchKernelGGL((merge_refine_kernel<25, 12>), dim3(n_active), dim3(64), 0, s, mr);
+        });
+        HIP_TRY(hipGetLastError());
+      } else {
       MergeSurvArgs ms;
       ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = active; ms.round_rows = pa.round_rows;
       ms.cand_count = fa.cand_count; ms.out_ids = d_out_ids; ms.out_dist = d_out_dist;
@@ -715,6 +813,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         hipLaunchKernelGGL(merge_surv_kernel, dim3(n_active), dim3(64), 0, s, ms);
       });
       HIP_TRY(hipGetLastError());
+      }
     } else {
       if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
       ScanArgs sa;

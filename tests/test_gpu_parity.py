@@ -74,7 +74,7 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
     idx.close()
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3"])
+@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("K", [256, 1024])
 def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
     """The three fused kernels (FREDDY_GPU_FUSED_KERNEL: 1 symmetric fused.h, 2 one builder wave per SIMD
