@@ -101,6 +101,8 @@ struct freddy_gpu_index {
   float* cbR = nullptr;         // [m][K][S] row-major codebook for the exact stage
   float* dtab = nullptr;        // [C][m][K]  |c|^2 + 2 co_p . c
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
+  float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
+  int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
   uint32_t* packed = nullptr;   // [blocks][M2][64]
@@ -115,7 +117,7 @@ struct freddy_gpu_index {
   // workspaces
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -162,7 +164,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->dtab, ix->pmax, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->dtab, ix->pmax, ix->cmaxp, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -170,7 +172,7 @@ static void free_index(freddy_gpu_index* ix) {
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
                     &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
-                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof, &ix->w_qc, &ix->w_qn};
+                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof, &ix->w_qc, &ix->w_qn, &ix->w_records};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
     for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -223,6 +225,11 @@ static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off
       pos[(size_t)b * 64 + lane] = row_pos ? row_pos[r] : (int32_t)r;
     }
   }
+  std::vector<int32_t> blk_cell((size_t)std::max<int64_t>(n_blocks, 1), 0);
+  for (int c = 0; c < n_lists; ++c)
+    for (int b = blk_off[c]; b < blk_off[c + 1]; ++b) blk_cell[(size_t)b] = c;
+  if (upload(&ix->blk_cell, blk_cell.data(), blk_cell.size(), &ix->bytes))
+    return fail(FREDDY_E_NOMEM, "device allocation/copy failed while pinning the lists");
   ix->n_blocks = n_blocks;
   ix->max_list_blocks = max_blocks;
   ix->h_list_off.assign(list_off, list_off + n_lists + 1);
@@ -327,7 +334,7 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
     // filter + refine tables (fused4.h): dt is C*m*K floats (49 MB for C=1000, m=12, K=1024)
     const size_t dt_bytes = sizeof(float) * (size_t)t->C * ix->m * ix->K;
     if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && dt_bytes <= filter_table_budget_bytes()) {
-      std::vector<float> pmax((size_t)ix->m);
+      std::vector<float> pmax((size_t)ix->m), cmaxp((size_t)ix->m);
       for (int p = 0; p < ix->m; ++p) {
         double comax = 0.0, cmax = 0.0;
         for (int c = 0; c < t->C; ++c) {
@@ -341,9 +348,11 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
           cmax = std::max(cmax, std::sqrt(n2));
         }
         pmax[p] = (float)((comax + cmax) * (1.0 + 1e-6));
+        cmaxp[p] = (float)(cmax * (1.0 + 1e-6));
       }
       if (upload(&ix->cbR, t->codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
           upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
+          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes) ||
           hipMalloc((void**)&ix->dtab, dt_bytes) != hipSuccess)
         rc = fail(FREDDY_E_NOMEM, "device allocation failed");
       if (!rc) {
@@ -558,7 +567,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   int fvariant = (fvenv && fvenv[0] >= '1' && fvenv[0] <= '4') ? fvenv[0] - '0' : 4;
   if (fvariant == 4 && !ix->dtab) fvariant = 3;
   if (fused && fvariant == 4) {
-    if (ix->w_qc.ensure(sizeof(float) * (size_t)Q * m * K) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m))
+    if (ix->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   }
   if (fused) {
@@ -608,8 +617,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
 
   if (fused && fvariant == 4) {
     timed_launch(ix, s, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3((K + 255) / 256, m, (Q + 31) / 32), dim3(256), 0, s, d_q, ix->cbT,
-                         ix->w_qc.as<float>(), ix->w_qn.as<float>(), Q, d, m, K);
+      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3(2, m, (Q + 31) / 32), dim3(256), 0, s, d_q, ix->cbT, ix->cmaxp,
+                         ix->w_qc.as<uint32_t>(), ix->w_qn.as<float>(), ix->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
     });
     HIP_TRY(hipGetLastError());
   }
@@ -732,16 +741,24 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
             hipLaunchKernelGGL((ivf_spec_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
         });
       } else if (fvariant == 4) {
+        const size_t max_rec = max_groups;
+        if (ix->w_records.ensure(sizeof(int32_t) * REC_DW * max_rec)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+        RecordArgs ra;
+        ra.group_cell = fa.group_cell; ra.group_first = fa.group_first; ra.group_cnt = fa.group_cnt; ra.n_groups = fa.n_groups;
+        ra.sorted_item = fa.sorted_item; ra.item_query = fa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
+        ra.dist = ix->w_distT.as<float>(); ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
+        ra.records = ix->w_records.as<int32_t>(); ra.Cpad = Cpad; ra.sentinel = sentinel;
+        timed_launch(ix, s, "entry_records", [&] {
+          hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((max_rec + 3) / 4)), dim3(256), 0, s, ra);
+        });
+        HIP_TRY(hipGetLastError());
         FilterArgs fl;
-        fl.qc = ix->w_qc.as<float>(); fl.qn = ix->w_qn.as<float>(); fl.dt = ix->dtab; fl.pmax = ix->pmax;
-        fl.dist = ix->w_distT.as<float>(); fl.Cpad = Cpad;
-        fl.item_query = fa.item_query; fl.sorted_item = fa.sorted_item; fl.group_cell = fa.group_cell;
-        fl.group_first = fa.group_first; fl.group_cnt = fa.group_cnt; fl.n_groups = fa.n_groups; fl.work_counter = fa.work_counter;
-        fl.blk_off = fa.blk_off; fl.packed = fa.packed; fl.pos = fa.pos; fl.surv = fa.surv; fl.surv_count = fa.surv_count;
+        fl.qc = ix->w_qc.as<uint32_t>(); fl.dt = ix->dtab; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = fa.n_groups;
+        fl.packed = fa.packed; fl.surv = fa.surv; fl.surv_count = fa.surv_count;
         fl.cand_count = fa.cand_count; fl.K = K; fl.L = L; fl.upi = upi; fl.sentinel = sentinel;
         fl.ablate = fa.ablate; fl.prof = fa.prof;
         const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + 512 + (2 * 5 * 16 + 16) * sizeof(float);
+        const size_t flds = desc_off + 4096 + 64 + 2 * REC_DW * sizeof(int32_t);
         fl.desc_offset = (uint32_t)desc_off;
         static bool f4attr = false;
         if (!f4attr) {
@@ -791,14 +808,33 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         MergeRefineArgs mr;
         mr.surv = fa.surv; mr.surv_count = fa.surv_count; mr.active = active; mr.round_rows = pa.round_rows;
         mr.item_cell = pa.item_cell; mr.queries = d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
-        mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos;
+        mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
         mr.cand_count = fa.cand_count; mr.out_ids = d_out_ids; mr.out_dist = d_out_dist;
         mr.found = ix->w_found.as<int32_t>(); mr.next_active = next; mr.n_next = ix->w_cnt.as<int32_t>();
         mr.status = d_status;
         mr.n_active = n_active; mr.W = W; mr.upi = upi; mr.L = L; mr.k = k; mr.found_rule = found_rule;
         mr.first_round = first ? 1 : 0; mr.K = K; mr.d = d; mr.sentinel = sentinel;
+        { const char* ab = getenv("FREDDY_GPU_MERGE_ABLATE"); mr.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
+        static const bool dbg_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;   // debugging aid: survivor statistics
+        if (dbg_surv) {
+          const size_t nreg = (size_t)n_items * upi * FUSED_NW;
+          std::vector<int32_t> h(nreg);
+          std::vector<float> hq((size_t)Q * m * 2);
+          HIP_TRY(hipStreamSynchronize(s));
+          HIP_TRY(hipMemcpy(h.data(), fa.surv_count, sizeof(int32_t) * nreg, hipMemcpyDeviceToHost));
+          HIP_TRY(hipMemcpy(hq.data(), ix->w_qn.p, sizeof(float) * hq.size(), hipMemcpyDeviceToHost));
+          long long tot = 0; int mx = 0; long long item_mx = 0;
+          for (size_t it = 0; it < (size_t)n_items; ++it) {
+            long long si = 0;
+            for (size_t r = 0; r < (size_t)upi * FUSED_NW; ++r) { const int c = h[it * upi * FUSED_NW + r]; si += c; mx = std::max(mx, c); }
+            tot += si; item_mx = std::max(item_mx, si);
+          }
+          double qnm = 0; for (int p = 0; p < m; ++p) qnm += hq[p];
+          fprintf(stderr, "[surv] items=%d survivors=%lld (%.2f per item, max %lld), largest region %d; sum_p |q_p| of query 0 = %.4f, scale[0][0]=%g\n",
+                  n_items, tot, (double)tot / n_items, item_mx, mx, qnm, hq[(size_t)Q * m]);
+        }
         timed_launch(ix, s, "merge_replay", [&] {
-          hipLaunchKernelGGL((merge_refine_kernel<25, 12>), dim3(n_active), dim3(64), 0, s, mr);
+          hipLaunchKernelGGL((merge_refine_kernel<25, 12>), dim3(n_active), dim3(256), 0, s, mr);
         });
         HIP_TRY(hipGetLastError());
       } else {

@@ -34,22 +34,11 @@
 namespace freddy {
 
 struct FilterArgs {
-  const float* qc;             // [Q][M][K]   -2 q_p . c            (query_codebook_kernel)
-  const float* qn;             // [Q][M]      |q_p|, rounded up
+  const uint32_t* qc;          // [Q][M][512] -2 q_p . c as int16 pairs (codes b, b+512)   (query_codebook_kernel)
   const float* dt;             // [C][M][K]   |c|^2 + 2 co_p . c    (pinned)
-  const float* pmax;           // [M]         max_cell |co_p| + max_code |c_p|, rounded up (pinned)
-  const float* dist;           // [Q][Cpad]   coarse distances |q - co|^2 of the probe plan
-  int Cpad;
-  const int32_t* item_query;   // [items]
-  const int32_t* sorted_item;  // items in cell order
-  const int32_t* group_cell;   // [groups]
-  const int32_t* group_first;
-  const int32_t* group_cnt;
-  const int32_t* n_groups;
-  int32_t* work_counter;
-  const int32_t* blk_off;      // [C+1]
+  const int32_t* records;      // [entries][REC_DW] (entry_record_kernel)
+  const int32_t* n_groups;     // [1] number of work entries
   const uint32_t* packed;      // [blocks][M2][64]
-  const int32_t* pos;          // [blocks*64]
   u64* surv;                   // [items][upi][8 waves][512]: (bits(d_lo) << 32) | flag << 31 | row location
   int32_t* surv_count;
   int32_t* cand_count;         // [Q] or NULL: rows certainly below the sentinel (the flagged ones are added by the merge)
@@ -111,42 +100,64 @@ __device__ __forceinline__ uint32_t widen_threshold(uint32_t tau_bits, float E) 
 }
 
 // ---------------------------------------------------------------------------------------
-// qc[q][p][code] = -2 q_p . c_{p,code} and qn[q][p] = |q_p| (rounded up).  Thread <-> code (its S
-// codebook values in registers), QT queries per workgroup through LDS.
+// qc[q][p][code] = -2 q_p . c_{p,code}, stored as 16-bit fixed point with one scale per (query,
+// position): |value| <= 2 |q_p| max|c_p| = 32767 * scale, so the quantisation error is <= scale / 2
+// -- an ABSOLUTE bound that fits the budget E (a 16-bit float's relative error would not).  The table
+// is what the scan streams per (query, cell) item, so its width is the scan's memory traffic.
+// Layout [q][p][512] dwords: low half = code b, high half = code b + 512 (the builder lane's two codes).
+// Also writes qn[q][p] = |q_p| (rounded up) and qscale[q][p].  Thread <-> code pair, QT queries per
+// workgroup through LDS.
 // ---------------------------------------------------------------------------------------
 template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
-                                                            float* __restrict__ qc, float* __restrict__ qn, int Q, int d, int m, int K) {
+                                                            const float* __restrict__ cmax, uint32_t* __restrict__ qc,
+                                                            float* __restrict__ qn, float* __restrict__ qscale, int Q, int d, int m, int K) {
   constexpr int SP = (S + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float qs[QT][SP];
+  __shared__ float inv_s[QT];
   const int tid = threadIdx.x, p = blockIdx.y, q0 = blockIdx.z * QT;
-  const int c = blockIdx.x * 256 + tid;
+  const int b = blockIdx.x * 256 + tid;   // codes b and b + 512
   for (int i = tid; i < QT * SP; i += 256) {
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
   }
-  float cb[S];
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f cb[S];   // (codes b, b+512): one packed fma per dimension
 #pragma unroll
-  for (int j = 0; j < S; ++j) cb[j] = c < K ? cbT[((size_t)p * S + j) * K + c] : 0.0f;
+  for (int j = 0; j < S; ++j) {
+    cb[j].x = b < K ? cbT[((size_t)p * S + j) * K + b] : 0.0f;
+    cb[j].y = b + 512 < K ? cbT[((size_t)p * S + j) * K + b + 512] : 0.0f;
+  }
   __syncthreads();
-  if (blockIdx.x == 0 && tid < QT && q0 + tid < Q) {
+  if (tid < QT) {
     float n2 = 0.0f;
 #pragma unroll
     for (int j = 0; j < S; ++j) n2 = __builtin_fmaf(qs[tid][j], qs[tid][j], n2);
-    qn[(size_t)(q0 + tid) * m + p] = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+    const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+    const float sc = 2.0f * nrm * cmax[p] * (1.0f / 32767.0f) * (1.0f + 1e-6f);
+    inv_s[tid] = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
+    if (blockIdx.x == 0 && q0 + tid < Q) {
+      qn[(size_t)(q0 + tid) * m + p] = nrm;
+      qscale[(size_t)(q0 + tid) * m + p] = sc;
+    }
   }
+  __syncthreads();
   const int nq = (Q - q0 < QT) ? Q - q0 : QT;
   for (int qi = 0; qi < nq; ++qi) {
-    float acc = 0.0f;
+    v2f acc = v2f{0.0f, 0.0f};
 #pragma unroll
     for (int jb = 0; jb < SP / 4; ++jb) {
       const float4 v = *reinterpret_cast<const float4*>(&qs[qi][jb * 4]);
-      if (jb * 4 + 0 < S) acc = __builtin_fmaf(v.x, cb[jb * 4 + 0 < S ? jb * 4 + 0 : 0], acc);
-      if (jb * 4 + 1 < S) acc = __builtin_fmaf(v.y, cb[jb * 4 + 1 < S ? jb * 4 + 1 : 0], acc);
-      if (jb * 4 + 2 < S) acc = __builtin_fmaf(v.z, cb[jb * 4 + 2 < S ? jb * 4 + 2 : 0], acc);
-      if (jb * 4 + 3 < S) acc = __builtin_fmaf(v.w, cb[jb * 4 + 3 < S ? jb * 4 + 3 : 0], acc);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (jb * 4 + u < S) acc = __builtin_elementwise_fma(v2f{vv[u], vv[u]}, cb[jb * 4 + u < S ? jb * 4 + u : 0], acc);
     }
-    if (c < K) qc[((size_t)(q0 + qi) * m + p) * K + c] = -2.0f * acc;
+    const float a0 = acc.x, a1 = acc.y;
+    const float inv = inv_s[qi];
+    const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * a0 * inv), -32767.0f), 32767.0f);
+    const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * a1 * inv), -32767.0f), 32767.0f);
+    if (b < 512) qc[((size_t)(q0 + qi) * m + p) * 512 + b] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
   }
 }
 
@@ -166,62 +177,102 @@ __global__ __launch_bounds__(256) void cell_codebook_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------
-// The scan.  Same roles, slab layout, barrier schedule, work entries and survivor regions as
-// ivf_spec2_kernel; the builders only add two streamed tables now (prefetched two positions ahead).
+// Work-entry records: everything the scan needs to know about an entry in one 512-byte row, so that the
+// persistent workgroups fetch the next entry with ONE load instead of a chain of dependent ones
+// (cell -> items -> queries -> bounds), which the short phases of this kernel can no longer hide.
+//   [0] cell  [1] items  [2] chunk  [3] first row block  [4] row blocks  [5] rows
+//   [8+g] item  [24+g] query (slots past the last item repeat item 0: always loadable)
+//   [40+g] OFF  [56+g] E  [72+g] SHIFT  [88+g] lo bits  [104+g] hi bits        (item_bounds)
+// ---------------------------------------------------------------------------------------
+static constexpr int REC_DW = 272;   // + [128 + p*12 + g] fixed-point scale of item g at position p
+
+struct RecordArgs {
+  const int32_t* group_cell;
+  const int32_t* group_first;
+  const int32_t* group_cnt;
+  const int32_t* n_groups;
+  const int32_t* sorted_item;
+  const int32_t* item_query;
+  const int32_t* blk_off;
+  const int32_t* list_off;
+  const float* dist;
+  const float* qn;
+  const float* qscale;
+  const float* pmax;
+  int32_t* records;
+  int Cpad;
+  float sentinel;
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void entry_record_kernel(RecordArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= a.n_groups[0]) return;
+  const int cell = a.group_cell[e], first = a.group_first[e], gc = a.group_cnt[e];
+  const int cnt = gc & 0xff, chunk = gc >> 8;
+  int32_t* rec = a.records + (size_t)e * REC_DW;
+  if (lane == 0) {
+    const int b0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
+    int nb = a.blk_off[cell + 1] - b0;
+    if (nb > FUSED_UNIT_BLOCKS) nb = FUSED_UNIT_BLOCKS;
+    int rows = a.list_off[cell + 1] - a.list_off[cell] - chunk * (FUSED_UNIT_BLOCKS * 64);
+    if (rows > FUSED_UNIT_BLOCKS * 64) rows = FUSED_UNIT_BLOCKS * 64;
+    rec[0] = cell; rec[1] = cnt; rec[2] = chunk; rec[3] = b0; rec[4] = nb; rec[5] = rows;
+  }
+  int q = 0;
+  if (lane < 16) {
+    const int it = lane < cnt ? a.sorted_item[first + lane] : -1;
+    q = a.item_query[it >= 0 ? it : a.sorted_item[first]];
+    ItemBounds ib = item_bounds(0.0f, 0.0f, a.sentinel);
+    if (it >= 0) ib = item_bounds(a.dist[(size_t)q * a.Cpad + cell], filter_width<M>(a.qn + (size_t)q * M, a.pmax), a.sentinel);
+    rec[8 + lane] = it;
+    rec[24 + lane] = q;
+    rec[40 + lane] = (int32_t)__float_as_uint(ib.off);
+    rec[56 + lane] = (int32_t)__float_as_uint(ib.e);
+    rec[72 + lane] = (int32_t)__float_as_uint(ib.shift);
+    rec[88 + lane] = (int32_t)ib.lo_bits;
+    rec[104 + lane] = (int32_t)ib.hi_bits;
+  }
+  for (int i0 = 0; i0 < M * 12; i0 += 64) {
+    const int i = i0 + lane;
+    const int p = i / 12, g = i - p * 12;
+    const int qg = __shfl(q, g, 64);   // (every lane takes part; g < 12 always names a lane that holds a query)
+    if (i < M * 12) rec[128 + i] = (int32_t)__float_as_uint(a.qscale[(size_t)qg * M + p]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The scan.  Same roles, slab layout, barrier schedule and survivor regions as ivf_spec2_kernel.  The
+// builders only add two streamed tables (requested one phase ahead, consumed at the start of a phase so
+// that the wait is for loads that are a whole phase old); entries are assigned statically (entry i of
+// workgroup w = the w-th of the i-th stripe of the largest-first table, stripes alternating direction).
 // ---------------------------------------------------------------------------------------
 template <int M, bool FULLK>
 __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
   constexpr int G = SPEC2_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
   constexpr int M2 = M / 2;
-  static_assert(M % 2 == 0 && G % 4 == 0 && G <= 16 && M >= 10, "layout");
+  static_assert(M % 2 == 0 && G == 12 && M >= 6, "layout");
   typedef float v2f __attribute__((ext_vector_type(2)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* slab = reinterpret_cast<float*>(smem);                                   // [2][K][G]
   uint32_t* colmin = reinterpret_cast<uint32_t*>(smem + a.desc_offset);           // [16][64]
   uint32_t* thr_s = colmin + 16 * 64;                                             // [16]
-  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // as in fused3.h
-  float* bnd = reinterpret_cast<float*>(smem + a.desc_offset + 4096 + 64 + 512);  // [2][5][16] item bounds
-  float* pmax_s = bnd + 2 * 5 * 16;                                               // [16]
+  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // [2][REC_DW] entry records
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool builder = wave < SPEC2_NB;
-  const int K = a.K;
+  const int K = FULLK ? 1024 : a.K;
   const int n_work = a.n_groups[0];
+  const int nwg = (int)gridDim.x;
+  auto entry_of = [&](int i) { return i * nwg + ((i & 1) ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x); };
 
-  // bounds of the items of descriptor buffer b (lane g < cnt of one wave)
-  auto stage_bounds = [&](int b, int g, float A, float E) {
-    const ItemBounds ib = item_bounds(A, E, a.sentinel);
-    float* o = bnd + b * 80;
-    o[g] = ib.off; o[16 + g] = ib.e; o[32 + g] = ib.shift;
-    o[48 + g] = __uint_as_float(ib.lo_bits); o[64 + g] = __uint_as_float(ib.hi_bits);
-  };
-
-  // ---- first entry: fetched serially by everybody ----
-  int cur = 0;
-  if (tid == 0) dsc[32] = atomicAdd(a.work_counter, 1);
+  int cur = 0, ei = 0;
+  if (entry_of(0) >= n_work) return;
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
-  if (tid < 16) pmax_s[tid] = tid < M ? a.pmax[tid] : 0.0f;
-  __syncthreads();
-  {
-    const int gid0 = dsc[32];
-    if (gid0 >= n_work) return;
-    if (wave == 0) {
-      const int cell = a.group_cell[gid0], first = a.group_first[gid0], gc = a.group_cnt[gid0];
-      const int cnt0 = gc & 0xff, chunk0 = gc >> 8;
-      const int b0 = a.blk_off[cell] + chunk0 * FUSED_UNIT_BLOCKS;
-      int nb0 = a.blk_off[cell + 1] - b0;
-      if (nb0 > FUSED_UNIT_BLOCKS) nb0 = FUSED_UNIT_BLOCKS;
-      if (lane < G) {
-        const int it = (lane < cnt0) ? a.sorted_item[first + lane] : -1;
-        const int q = it >= 0 ? a.item_query[it] : 0;
-        dsc[lane] = it;
-        dsc[64 + lane] = q;
-        if (it >= 0) stage_bounds(0, lane, a.dist[(size_t)q * a.Cpad + cell], filter_width<M>(a.qn + (size_t)q * M, pmax_s));
-      }
-      if (lane == 0) { dsc[33] = cnt0; dsc[34] = b0; dsc[35] = nb0; dsc[36] = chunk0; dsc[37] = cell; }
-    }
-  }
+  if (tid < REC_DW) dsc[tid] = a.records[(size_t)entry_of(0) * REC_DW + tid];
+  static_assert(REC_DW <= 5 * 64, "record prefetch by builder waves 0-4");
   __syncthreads();
 
   if (builder) {
@@ -229,41 +280,51 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     // BUILDERS: lane <-> codes b and b+512
     // =====================================================================================
     const int b = tid;
-    float dtv[2][2], qv[2][G][2];
+    const bool ok0 = FULLK || b < K, ok1 = FULLK || b + 512 < K;
+    const uint32_t vo0 = ok0 ? (uint32_t)b * 4u : 0u, vo1 = ok1 ? (uint32_t)(b + 512) * 4u : 0u;
+    const size_t prow = (size_t)K * 4;   // bytes of one [K] row of dt
+    const uint32_t vq = (uint32_t)b * 4u;   // this lane's dword of a [512] row of qc
+    float dtv[2][2];
+    uint32_t qw[2][G];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int g = 0; g < G; ++g) qv[u][g][0] = qv[u][g][1] = 0.0f;
-    const bool ok0 = FULLK || b < K, ok1 = FULLK || b + 512 < K;
-    // request the table values of position p for an entry (cell, cnt items, their queries in LDS)
-    auto issue = [&](int buf, int p, int cell, int cnt, const int (&qids)[G]) {
-      if (cnt > 0) {
-        const float* dp = a.dt + ((size_t)cell * M + p) * K;
-        dtv[buf][0] = ok0 ? dp[b] : 0.0f;
-        dtv[buf][1] = ok1 ? dp[b + 512] : 0.0f;
-      }
+      for (int g = 0; g < G; ++g) qw[u][g] = 0u;
+    auto ldf = [&](const char* base, uint32_t off) { return *reinterpret_cast<const float*>(base + off); };
+    // request the table values of position p of an entry (cell, nq item quads, query ids)
+    auto issue = [&](int buf, int p, int cell, int nq, const int (&qids)[G]) {
+      const char* dp = reinterpret_cast<const char*>(a.dt) + ((size_t)cell * M + p) * prow;
+      dtv[buf][0] = ldf(dp, vo0);
+      dtv[buf][1] = ldf(dp, vo1);
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (g < cnt) {
-          const float* qp = a.qc + ((size_t)qids[g] * M + p) * K;
-          qv[buf][g][0] = ok0 ? qp[b] : 0.0f;
-          qv[buf][g][1] = ok1 ? qp[b + 512] : 0.0f;
+      for (int gq = 0; gq < G / 4; ++gq) {
+        if (gq < nq) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int g = gq * 4 + u;
+            const char* qp = reinterpret_cast<const char*>(a.qc) + ((size_t)qids[g] * M + p) * 2048;
+            qw[buf][g] = *reinterpret_cast<const uint32_t*>(qp + vq);
+          }
         }
       }
     };
-    // slab rows are [code][12 items]: one aligned 16-byte store per item quad and code
-    auto emit = [&](int buf, float* dst, int cnt) {
+    // slab rows are [code][12 items]: one aligned 16-byte store per item quad and code; value = dt +
+    // scale * fixed-point qc (one fma).  sc = the entry record's scales of this position.
+    auto emit = [&](int buf, float* dst, int nq, const int32_t* sc) {
 #pragma unroll
       for (int gq = 0; gq < G / 4; ++gq) {
-        if (gq * 4 < cnt) {
-          if (ok0)
-            *reinterpret_cast<float4*>(dst + b * G + gq * 4) =
-                float4{dtv[buf][0] + qv[buf][gq * 4 + 0][0], dtv[buf][0] + qv[buf][gq * 4 + 1][0],
-                       dtv[buf][0] + qv[buf][gq * 4 + 2][0], dtv[buf][0] + qv[buf][gq * 4 + 3][0]};
-          if (ok1)
-            *reinterpret_cast<float4*>(dst + (b + 512) * G + gq * 4) =
-                float4{dtv[buf][1] + qv[buf][gq * 4 + 0][1], dtv[buf][1] + qv[buf][gq * 4 + 1][1],
-                       dtv[buf][1] + qv[buf][gq * 4 + 2][1], dtv[buf][1] + qv[buf][gq * 4 + 3][1]};
+        if (gq < nq) {
+          const float4 s4 = *reinterpret_cast<const float4*>(sc + gq * 4);
+          const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
+          float lo[4], hi[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t w = qw[buf][gq * 4 + u];
+            lo[u] = __builtin_fmaf((float)((int32_t)(w << 16) >> 16), ss[u], dtv[buf][0]);
+            hi[u] = __builtin_fmaf((float)((int32_t)w >> 16), ss[u], dtv[buf][1]);
+          }
+          if (ok0) *reinterpret_cast<float4*>(dst + b * G + gq * 4) = float4{lo[0], lo[1], lo[2], lo[3]};
+          if (ok1) *reinterpret_cast<float4*>(dst + (b + 512) * G + gq * 4) = float4{hi[0], hi[1], hi[2], hi[3]};
         }
       }
     };
@@ -271,82 +332,45 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
     auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
     if (a.prof) pc = clock64();
-    int cnt = __builtin_amdgcn_readfirstlane(dsc[33]);
-    int cell = __builtin_amdgcn_readfirstlane(dsc[37]);
+    int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 3) >> 2;
+    int cell = __builtin_amdgcn_readfirstlane(dsc[0]);
     int qid[G], nqid[G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { qid[g] = __builtin_amdgcn_readfirstlane(dsc[64 + g]); nqid[g] = 0; }
-    issue(0, 0, cell, cnt, qid);
-    issue(1, 1, cell, cnt, qid);
-    emit(0, slab, cnt);
+    for (int g = 0; g < G; ++g) { qid[g] = __builtin_amdgcn_readfirstlane(dsc[24 + g]); nqid[g] = qid[g]; }
+    issue(0, 0, cell, nq, qid);
+    issue(1, 1, cell, nq, qid);
+    emit(0, slab, nq, dsc + 128);
     lds_barrier();
     for (;;) {
-      int ngid = 0;
-      int n_cell = 0, n_first = 0, n_gc = 0, n_item = -1, n_b0 = 0, n_b1 = 0, n_q = 0;
-      float n_A = 0.0f, n_E = 0.0f;
-      int next_gid = -1, next_cnt = 0, next_cell = 0;
       const int nb = cur ^ 1;
-      if (tid == 0) ngid = atomicAdd(a.work_counter, 1);
+      const int ngid = entry_of(ei + 1);
+      const bool have_next = ngid < n_work;
+      int next_nq = 0, next_cell = 0;
+      int32_t rr0 = 0, rr1 = 0;   // wave 0/1: the next entry's record on its way to LDS
 #pragma unroll
       for (int p = 0; p < M; ++p) {
-        tick(5);
-        // slab(p+1) of this entry -- or slab(0) of the next one -- from the registers filled two phases ago
-        if (p + 1 < M) emit((p + 1) & 1, slab + (size_t)((p + 1) & 1) * G * K, cnt);
-        else emit(0, slab, next_cnt);
+        // the next entry's record: requested in P(0), stored in P(2), first read in P(M-2)
+        if (p == 2 && tid < REC_DW) {
+          dsc[nb * REC_DW + tid] = rr0;
+          if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
+        }
+        // slab(p+1) of this entry -- or slab(0) of the next one -- from the registers requested a phase ago
+        if (p + 1 < M) emit((p + 1) & 1, slab + (size_t)((p + 1) & 1) * G * K, nq, dsc + cur * REC_DW + 128 + (p + 1) * 12);
+        else emit(0, slab, next_nq, dsc + nb * REC_DW + 128);
         // request position p+2
         if (p + 2 < M) {
-          issue(p & 1, p + 2, cell, cnt, qid);
+          issue(p & 1, p + 2, cell, nq, qid);
         } else {
           if (p + 2 == M) {
-            next_gid = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
-            next_cnt = next_gid >= 0 ? __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8 + 1]) : 0;
-            next_cell = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8 + 5]);
+            next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 3) >> 2 : 0;
+            next_cell = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 0]) : cell;
 #pragma unroll
-            for (int g = 0; g < G; ++g) nqid[g] = __builtin_amdgcn_readfirstlane(dsc[64 + nb * 16 + g]);
+            for (int g = 0; g < G; ++g) nqid[g] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g]) : qid[g];
           }
-          issue(p & 1, p + 2 - M, next_cell, next_cnt, nqid);
+          issue(p & 1, p + 2 - M, next_cell, next_nq, nqid);
         }
+        if (p == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
         tick(0);
-        // next entry's descriptor and bounds, one dependent global round trip per position (wave 0 only)
-        if (wave == 0) {
-          if (p == 1) {
-            ngid = __builtin_amdgcn_readfirstlane(ngid);
-            if (ngid < n_work) {
-              n_cell = a.group_cell[ngid];
-              n_first = a.group_first[ngid];
-              n_gc = a.group_cnt[ngid];
-            }
-          } else if (p == 3) {
-            if (ngid < n_work) {
-              if (lane < (n_gc & 0xff)) n_item = a.sorted_item[n_first + lane];
-              n_b0 = a.blk_off[n_cell];
-              n_b1 = a.blk_off[n_cell + 1];
-            }
-          } else if (p == 5) {
-            if (ngid < n_work) {
-              const int cntn = n_gc & 0xff, chn = n_gc >> 8;
-              const int b0 = n_b0 + chn * FUSED_UNIT_BLOCKS;
-              int nbn = n_b1 - b0;
-              if (nbn > FUSED_UNIT_BLOCKS) nbn = FUSED_UNIT_BLOCKS;
-              if (n_item >= 0) n_q = a.item_query[n_item];
-              if (lane < G) dsc[nb * 16 + lane] = n_item;
-              if (lane == 0) {
-                dsc[32 + nb * 8 + 1] = cntn; dsc[32 + nb * 8 + 2] = b0;
-                dsc[32 + nb * 8 + 3] = nbn; dsc[32 + nb * 8 + 4] = chn; dsc[32 + nb * 8 + 5] = n_cell;
-              }
-            }
-          } else if (p == 6) {
-            if (ngid < n_work && n_item >= 0) {
-              n_A = a.dist[(size_t)n_q * a.Cpad + n_cell];
-              n_E = filter_width<M>(a.qn + (size_t)n_q * M, pmax_s);
-            }
-          } else if (p == 7) {
-            if (ngid < n_work && n_item >= 0) stage_bounds(nb, lane, n_A, n_E);
-            if (lane < G) dsc[64 + nb * 16 + lane] = n_q;
-            if (lane == 0) dsc[32 + nb * 8 + 0] = (ngid < n_work) ? ngid : -1;
-          }
-        }
-        tick(5);
         lds_barrier();
         tick(1);
       }
@@ -354,9 +378,11 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       lds_barrier();   // S2
       tick(3);
       pt[7] += 1;
-      if (next_gid < 0) break;
+      (void)rr1;
+      if (!have_next) break;
       cur = nb;
-      cnt = next_cnt;
+      ++ei;
+      nq = next_nq;
       cell = next_cell;
 #pragma unroll
       for (int g = 0; g < G; ++g) qid[g] = nqid[g];
@@ -375,12 +401,13 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     auto bits = [&](int g, int r) { return __float_as_uint((g & 1) ? acc[g >> 1][r].y : acc[g >> 1][r].x); };
     lds_barrier();   // (pairs with the builders' barrier after the first slab)
     for (;;) {
-      const int32_t* desc = dsc + cur * 16;
-      const float* bn = bnd + cur * 80;
-      const int cnt = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 1]);
-      const int blk0 = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 2]);
-      const int nblk = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 3]);
-      const int chunk = __builtin_amdgcn_readfirstlane(dsc[32 + cur * 8 + 4]);
+      const int32_t* rec = dsc + cur * REC_DW;
+      const int cnt = __builtin_amdgcn_readfirstlane(rec[1]);
+      const int chunk = __builtin_amdgcn_readfirstlane(rec[2]);
+      const int blk0 = __builtin_amdgcn_readfirstlane(rec[3]);
+      const int nblk = __builtin_amdgcn_readfirstlane(rec[4]);
+      const int nrows = __builtin_amdgcn_readfirstlane(rec[5]);
+      const int nq = (cnt + 3) >> 2;
       const int nb = cur ^ 1;
       auto row_block = [&](int r) {
         const int bl = r * NG + gw;
@@ -390,7 +417,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) cw[r] = a.packed[(row_block(r) * M2 + (uint32_t)pair) * 64u + (uint32_t)lane];
       };
-      auto gather = [&](int p, const float* curs) {
+      // one row at a time: three ds_read_b128 fetch a row's 12 item values
+      auto gather_any = [&](int p) {
+        const float* curs = slab + (size_t)(p & 1) * G * K;
         const int sh = (p & 1) * 16;
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
@@ -408,32 +437,26 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       };
 #pragma unroll
       for (int h = 0; h < G / 2; ++h) {
-        const v2f o = v2f{bn[2 * h], bn[2 * h + 1]};
+        const v2f o = v2f{__int_as_float(rec[40 + 2 * h]), __int_as_float(rec[40 + 2 * h + 1])};
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) acc[h][r] = o;
       }
       load_codes(0);
       for (int p = 0; p + 1 < M; ++p) {
-        if (!(a.ablate & 2)) gather(p, slab + (size_t)(p & 1) * G * K);
+        if (!(a.ablate & 2)) gather_any(p);
         __builtin_amdgcn_sched_barrier(0);
         if (p & 1) load_codes((p + 1) >> 1);
         lds_barrier();
       }
-      if (!(a.ablate & 2)) gather(M - 1, slab + (size_t)((M - 1) & 1) * G * K);
-      int32_t pid[RMAX];
+      if (!(a.ablate & 2)) gather_any(M - 1);
+      // rows past the end of the list (last block of the last chunk): park them above everything
+      if (nrows < FUSED_UNIT_BLOCKS * 64) {
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
-      {
-        bool dead[RMAX];
-        bool some = false;
+        for (int r = 0; r < RMAX; ++r) {
+          const bool dead = ((r * NG + gw) * 64 + lane) >= nrows;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) { dead[r] = !(((r * NG + gw) < nblk) && pid[r] >= 0); some |= dead[r]; }
-        if (__ballot(some) != 0ull) {
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r)
-#pragma unroll
-            for (int h = 0; h < G / 2; ++h)
-              if (dead[r]) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+          for (int h = 0; h < G / 2; ++h)
+            if (dead) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
         }
       }
       if (!(a.ablate & 4)) {
@@ -456,8 +479,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         wave_sort32_x2(c0, c1);
         const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
         if (lane == 0) {
-          thr_s[g0] = widen_threshold(t0, bn[16 + g0]);
-          thr_s[g1] = widen_threshold(t1, bn[16 + g1]);
+          thr_s[g0] = widen_threshold(t0, __int_as_float(rec[56 + g0]));
+          thr_s[g1] = widen_threshold(t1, __int_as_float(rec[56 + g1]));
         }
         colmin[g0 * 64 + lane] = 0xffffffffu;
         colmin[g1 * 64 + lane] = 0xffffffffu;
@@ -469,18 +492,18 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
             const uint32_t thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)thr_s[g]);
-            const int it = __builtin_amdgcn_readfirstlane(desc[g]);
-            const float shift = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bn[32 + g])));
+            const int it = __builtin_amdgcn_readfirstlane(rec[8 + g]);
+            const float shift = __int_as_float(__builtin_amdgcn_readfirstlane(rec[72 + g]));
             const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
             u64* dst = a.surv + region * (size_t)(RMAX * 64);
             uint32_t lo_b = 0xffffffffu, hi_b = 0u;   // (no flagged rows unless the accepted rows are counted)
             if (a.cand_count) {
-              lo_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bn[48 + g]));
-              hi_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(bn[64 + g]));
+              lo_b = (uint32_t)__builtin_amdgcn_readfirstlane(rec[88 + g]);
+              hi_b = (uint32_t)__builtin_amdgcn_readfirstlane(rec[104 + g]);
               int accepted = 0;
 #pragma unroll
               for (int r = 0; r < RMAX; ++r) accepted += __popcll(__ballot(bits(g, r) < lo_b));
-              if (lane == 0 && accepted) atomicAdd(a.cand_count + a.item_query[it], accepted);
+              if (lane == 0 && accepted) atomicAdd(a.cand_count + __builtin_amdgcn_readfirstlane(rec[24 + g]), accepted);
             }
             int run = 0;
 #pragma unroll
@@ -502,9 +525,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
           }
         }
       }
-      const int next_gid = __builtin_amdgcn_readfirstlane(dsc[32 + nb * 8]);
+      const int next_ok = __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 6]);
       lds_barrier();
-      if (next_gid < 0) break;
+      if (next_ok < 0) break;
       cur = nb;
     }
   }
@@ -526,6 +549,7 @@ struct MergeRefineArgs {
   const float* pmax;           // [M]
   const uint32_t* packed;
   const int32_t* pos;
+  const int32_t* blk_cell;     // [blocks] list (cell) of every row block
   int32_t* cand_count;
   int32_t* out_ids;
   float* out_dist;
@@ -535,33 +559,103 @@ struct MergeRefineArgs {
   int32_t* status;
   int n_active, W, upi, L, k, found_rule, first_round, K, d;
   float sentinel;
+  uint32_t ablate;   // timing experiments only (FREDDY_GPU_MERGE_ABLATE): 1 = skip the exact stage
 };
 
 template <int S, int M>
-__global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
-  constexpr int NC = 16;            // candidates refined together
-  constexpr int SQ = S + 1;         // row pitch of the squared differences
+__global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a) {
+  // Four waves per query.  Wave 0 selects and replays; the exact stage of the normal case (<= NC rows)
+  // is spread over all four -- one tile of 64 (row, position) chains each -- because a wave spends it
+  // waiting for two dependent round trips per tile.
+  constexpr int NT = 4;                     // tiles of 64 chains refined together
+  constexpr int NC = NT * 64 / M;           // = 21 candidates
+  constexpr int SQ = S + 1;                 // row pitch of the squared differences
   constexpr int M2 = M / 2;
   __shared__ u64 stage[64];
   __shared__ float qs[M * S];
-  __shared__ float sq[64 * SQ];
-  __shared__ float lutv[NC * M];
-  __shared__ int32_t cbo[64], coo[64];
+  __shared__ float sq[NT * 64 * SQ];
+  __shared__ float lutv[NT * 64];
+  __shared__ int32_t cbo[NT * 64], coo[NT * 64];
   __shared__ u64 cq_key[64 + NC];
   __shared__ int32_t cq_cell[64 + NC];
-  const int x = blockIdx.x, lane = threadIdx.x;
+  __shared__ int sh_n;
+  const int x = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = a.active ? a.active[x] : x;
   const int k = a.k;
   const int per_item = a.upi * FUSED_NW;
   const int R = a.W * per_item;
   constexpr int NBATCH = 4;
 
-  for (int j = lane; j < M * S; j += 64) qs[j] = a.queries[(size_t)q * a.d + j];
-  const float E = filter_width<M>(a.qn + (size_t)q * M, a.pmax);
+  if (!(a.ablate & 2)) for (int j = threadIdx.x; j < M * S; j += 256) qs[j] = a.queries[(size_t)q * a.d + j];
+  const float E = (a.ablate & 2) ? 0.0f : filter_width<M>(a.qn + (size_t)q * M, a.pmax);
+
+  // one tile of the exact stage: chains [t*64, t*64+64) of the first n queue entries -> lutv
+  auto tile_work = [&](int t, float* sqb, int n) {
+    const int chains = n * M;
+    const int ch = t * 64 + lane;
+    if (ch < chains) {   // round trip 1: the chain's code
+      const int c = ch / M, p = ch - c * M;
+      const uint32_t loc = (uint32_t)cq_key[c] & 0x7fffffffu;
+      const uint32_t word = a.packed[((size_t)(loc >> 6) * M2 + (uint32_t)(p >> 1)) * 64u + (loc & 63u)];
+      const int code = (int)((word >> ((p & 1) * 16)) & 0xffffu);
+      cbo[ch] = (p * a.K + code) * S;
+      coo[ch] = cq_cell[c] * a.d + p * S;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // round trips 2 and 3: every element (chain, dimension) -- consecutive lanes read consecutive floats
+    // of a codeword / centroid; two halves of H steps each, the loads of a half go out together (all S
+    // at once would need more than the 128 registers four resident workgroups per CU leave a wave)
+    constexpr int H = (S + 1) / 2;
+#pragma unroll 1
+    for (int h0 = 0; h0 < S; h0 += H) {
+      float cv[H], cov[H];
+#pragma unroll
+      for (int u = 0; u < H; ++u) {
+        const int e = (h0 + u) * 64 + lane;
+        const int cl = t * 64 + e / S, j = e % S;
+        const bool live = (h0 + u < S) && cl < chains;
+        const uint32_t off = ((uint32_t)cbo[live ? cl : t * 64] + (uint32_t)j) * 4u;
+        const uint32_t offc = ((uint32_t)coo[live ? cl : t * 64] + (uint32_t)j) * 4u;   // (C*d*4 < 2^32)
+        cv[u] = live ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.cbR) + off) : 0.0f;
+        cov[u] = live ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.coarse) + offc) : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < H; ++u) {
+        const int e = (h0 + u) * 64 + lane;
+        const int cl = e / S, j = e % S;
+        const int p = (t * 64 + cl) % M;
+        if ((h0 + u < S) && t * 64 + cl < chains) {
+          const float r = qs[p * S + j] - cov[u];                        // freddy.c:296-303
+          const float tt = r - cv[u];
+          sqb[cl * SQ + j] = tt * tt;                                    // index_utils.c:500-508
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (ch < chains) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int j = 0; j < S; ++j) acc = acc + sqb[lane * SQ + j];
+      lutv[ch] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  if (wave != 0) {
+    __syncthreads();                       // wave 0 has queued the rows to refine
+    const int n1 = sh_n;
+    if (n1 > 0 && wave * 64 < n1 * M) tile_work(wave, sq + wave * 64 * SQ, n1);
+    __syncthreads();
+    return;
+  }
 
   // ---- pass 1: the L smallest lower bounds ----
+  // (a few more than L are kept: the rows to refine are normally all among them)
+  const int LW = (a.ablate & 4) ? a.L : (a.L + 22 < 64 ? a.L + 22 : 64);
   WaveSelect<1> sel;
-  sel.init(stage, KEY_INF, a.L);
+  sel.init(stage, KEY_INF, LW);
+  uint32_t flag_seen = 0u;
   for (int jb = 0; jb < R; jb += 64 * NBATCH) {
     int c[NBATCH];
     size_t region[NBATCH];
@@ -577,6 +671,8 @@ __global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
       const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
       k0[u] = (c[u] > 0) ? src[0] : KEY_INF;
       k1[u] = (c[u] > 1) ? src[1] : KEY_INF;
+      if (c[u] > 0) flag_seen |= (uint32_t)k0[u];
+      if (c[u] > 1) flag_seen |= (uint32_t)k1[u];
     }
 #pragma unroll
     for (int u = 0; u < NBATCH; ++u) {
@@ -588,11 +684,20 @@ __global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
       if (maxc > 1) sel.push(k1[u], c[u] > 1);
       for (int t = 2; t < maxc; ++t) {
         const bool valid = t < c[u];
-        sel.push(valid ? src[t] : KEY_INF, valid);
+        const u64 kk = valid ? src[t] : KEY_INF;
+        if (valid) flag_seen |= (uint32_t)kk;
+        sel.push(kk, valid);
       }
     }
   }
   sel.finish();
+  if (a.ablate & 8) {
+    if (lane < k) a.out_ids[(size_t)q * k + lane] = (int32_t)sel.acc[0];
+    if (lane == 0) sh_n = 0;
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   // T = (L-th smallest d_lo) + E, rounded up; every key of the query if there are fewer than L or E is not finite
   uint32_t T_bits;
   {
@@ -606,40 +711,8 @@ __global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
   sel2.init(stage, KEY_INF, a.L);
   int queued = 0;        // wave-uniform
   int amb_accepted = 0;  // lane 0..NC-1 partial counts
-  auto refine = [&](int n) {   // the first n <= NC queue entries -> exact keys into sel2
-    __builtin_amdgcn_wave_barrier();
+  auto finalize = [&](int n) {   // chain sums of the first n queue entries -> exact keys into sel2; drops them
     u64 out_key = KEY_INF;
-    const int chains = n * M;
-    for (int t0 = 0; t0 < chains; t0 += 64) {
-      const int ch = t0 + lane;
-      if (ch < chains) {
-        const int c = ch / M, p = ch - c * M;
-        const uint32_t loc = (uint32_t)cq_key[c] & 0x7fffffffu;
-        const uint32_t word = a.packed[((size_t)(loc >> 6) * M2 + (uint32_t)(p >> 1)) * 64u + (loc & 63u)];
-        const int code = (int)((word >> ((p & 1) * 16)) & 0xffffu);
-        cbo[lane] = (p * a.K + code) * S;
-        coo[lane] = cq_cell[c] * a.d + p * S;
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int nch = (chains - t0 < 64) ? chains - t0 : 64;
-      // element e = (chain, dimension): consecutive lanes read consecutive floats of a codeword
-      for (int e = lane; e < nch * S; e += 64) {
-        const int cl = e / S, j = e - cl * S;
-        const int p = (t0 + cl) % M;
-        const float cv = a.cbR[(size_t)cbo[cl] + j];
-        const float r = qs[p * S + j] - a.coarse[(size_t)coo[cl] + j];   // freddy.c:296-303
-        const float t = r - cv;
-        sq[cl * SQ + j] = t * t;                                          // index_utils.c:500-508
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (lane < nch) {
-        float acc = 0.0f;
-#pragma unroll
-        for (int j = 0; j < S; ++j) acc = acc + sq[lane * SQ + j];
-        lutv[t0 + lane] = acc;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
     if (lane < n) {
       float dsum = 0.0f;
 #pragma unroll
@@ -661,6 +734,11 @@ __global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
     queued -= n;
     __builtin_amdgcn_wave_barrier();
   };
+  auto refine = [&](int n) {     // (wave 0 alone: the rare cases)
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t * 64 < n * M; ++t) tile_work(t, sq, n);
+    finalize(n);
+  };
   auto offer = [&](u64 key, bool valid, int cell) {
     const bool need = valid && (((uint32_t)(key >> 32) <= T_bits) || ((uint32_t)key & 0x80000000u));
     const u64 mask = __ballot(need);
@@ -675,7 +753,38 @@ __global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
       __builtin_amdgcn_wave_barrier();
     }
   };
-  for (int jb = 0; jb < R; jb += 64) {
+  // Normal case: the rows to refine (d_lo <= T) are a proper prefix of the LW keys pass 1 kept and no
+  // flagged row exists -- they go to the queue straight from the registers.  Otherwise (more such rows
+  // than were kept, e.g. many duplicates of one vector, or a sentinel decision pending) every key is revisited.
+  bool revisit = true;
+  {
+    const u64 mine = sel.acc[0];
+    const bool in = lane < LW && mine != KEY_INF && (uint32_t)(mine >> 32) <= T_bits;
+    const u64 in_mask = __ballot(in);
+    const bool any_flag = __ballot((flag_seen & 0x80000000u) != 0u) != 0ull;
+    const bool all_in = __popcll(in_mask) >= LW;   // every kept key qualifies: there may be more outside
+    if (a.ablate & 16) {   // debugging aid: what the exact stage would be asked to do
+      if (lane == 0) {
+        float* o = a.out_dist + (size_t)q * k;
+        o[0] = (float)__popcll(in_mask); o[1] = all_in ? 1.0f : 0.0f; o[2] = E; o[3] = __uint_as_float(T_bits);
+        o[4] = __uint_as_float((uint32_t)(wave_topk_at<1>(sel.acc, a.L - 1) >> 32));
+        sh_n = 0;
+      }
+      __syncthreads();
+      __syncthreads();
+      return;
+    }
+    if (!all_in && !any_flag) {
+      revisit = false;
+      if (in) {
+        cq_key[lanes_below(in_mask)] = mine;
+        cq_cell[lanes_below(in_mask)] = a.blk_cell[((uint32_t)mine & 0x7fffffffu) >> 6];
+      }
+      queued = __popcll(in_mask);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  for (int jb = 0; revisit && jb < R; jb += 64) {
     const int j = jb + lane;
     const size_t region = (size_t)x * R + (size_t)(j < R ? j : 0);
     const int c = (j < R) ? a.surv_count[region] : 0;
@@ -688,6 +797,16 @@ __global__ __launch_bounds__(64) void merge_refine_kernel(MergeRefineArgs a) {
       const bool valid = t < c;
       offer(valid ? src[t] : KEY_INF, valid, cell);
     }
+  }
+  if (a.ablate & 1) queued = 0;
+  // the normal case's rows (at most NC of them) are refined by the four waves together
+  {
+    const int n1 = revisit ? 0 : (queued < NC ? queued : NC);
+    if (lane == 0) sh_n = n1;
+    __syncthreads();
+    if (n1 > 0) tile_work(0, sq, n1);
+    __syncthreads();
+    if (n1 > 0) finalize(n1);
   }
   while (queued > 0) refine(queued < NC ? queued : NC);
   sel2.finish();
