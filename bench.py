@@ -176,7 +176,7 @@ def main():
             traffic = None
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-                kname = {"ivf_fused": "ivf_spec2_kernel", "adc_scan": "adc_scan_kernel", "lut_build": "lut_build_kernel",
+                kname = {"ivf_fused": "ivf_filter_kernel", "adc_scan": "adc_scan_kernel", "lut_build": "lut_build_kernel",
                          "coarse_dist": "coarse_tile_kernel", "probe_plan": "probe_plan_kernel"}.get(dom, dom)
                 if kname not in pmc and dom == "ivf_fused":   # FREDDY_GPU_FUSED_KERNEL=2 / 1
                     kname = "ivf_spec_kernel" if "ivf_spec_kernel" in pmc else "ivf_fused_kernel"
