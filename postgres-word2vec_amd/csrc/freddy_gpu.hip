@@ -84,6 +84,8 @@ struct freddy_gpu_index {
   int kind = 0;
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
+  hipEvent_t ev_q = nullptr, ev_qc = nullptr;
   int d = 0, m = 0, K = 0, C = 0, S = 0, M2 = 0;
   int64_t N = 0;
   int64_t n_blocks = 0;
@@ -164,6 +166,9 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
+  if (ix->ev_q) (void)hipEventDestroy(ix->ev_q);
+  if (ix->ev_qc) (void)hipEventDestroy(ix->ev_qc);
   void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->dtab, ix->pmax, ix->cmaxp, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
@@ -598,6 +603,32 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
   za.p[4] = fused ? ix->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = fused ? (int)(items * upi * FUSED_NW) : 0;
 
+  bool qc_pending = false;
+  if (fused && fvariant == 4) {
+    // independent of the coarse distances / probe plan / work table: built on the side stream, joined
+    // before the entry records need it
+    if (!ix->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ix->ev_q, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ix->ev_qc, hipEventDisableTiming));
+    }
+    static const bool side = !(getenv("FREDDY_GPU_SIDE_STREAM") && getenv("FREDDY_GPU_SIDE_STREAM")[0] == '0');
+    hipStream_t sq = side ? ix->stream2 : s;
+    if (side) {
+      HIP_TRY(hipEventRecord(ix->ev_q, s));
+      HIP_TRY(hipStreamWaitEvent(ix->stream2, ix->ev_q, 0));
+    }
+    timed_launch(ix, sq, "query_codebook", [&] {
+      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3(2, m, (Q + 31) / 32), dim3(256), 0, sq, d_q, ix->cbT, ix->cmaxp,
+                         ix->w_qc.as<uint32_t>(), ix->w_qn.as<float>(), ix->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
+    });
+    HIP_TRY(hipGetLastError());
+    if (side) {
+      HIP_TRY(hipEventRecord(ix->ev_qc, ix->stream2));
+      qc_pending = true;
+    }
+  }
+
   timed_launch(ix, s, "coarse_dist", [&] {
     if (tiled)
       {
@@ -614,14 +645,6 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
                          ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);
   });
   HIP_TRY(hipGetLastError());
-
-  if (fused && fvariant == 4) {
-    timed_launch(ix, s, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3(2, m, (Q + 31) / 32), dim3(256), 0, s, d_q, ix->cbT, ix->cmaxp,
-                         ix->w_qc.as<uint32_t>(), ix->w_qn.as<float>(), ix->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
-    });
-    HIP_TRY(hipGetLastError());
-  }
 
   ix->last_Q = Q;
   int n_active = Q;
@@ -679,7 +702,8 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
       timed_launch(ix, s, "group_items", [&] {
         hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(256), 0, s, cell_count, C, n_active, gsz, ix->blk_off,
-                           group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups);
+                           group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups,
+                           fvariant == 4 ? 1 : 0);
       });
       HIP_TRY(hipGetLastError());
       FusedArgs fa;
@@ -748,17 +772,18 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         ra.sorted_item = fa.sorted_item; ra.item_query = fa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
         ra.dist = ix->w_distT.as<float>(); ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
         ra.records = ix->w_records.as<int32_t>(); ra.Cpad = Cpad; ra.sentinel = sentinel;
+        if (qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ix->ev_qc, 0)); qc_pending = false; }
         timed_launch(ix, s, "entry_records", [&] {
           hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((max_rec + 3) / 4)), dim3(256), 0, s, ra);
         });
         HIP_TRY(hipGetLastError());
         FilterArgs fl;
-        fl.qc = ix->w_qc.as<uint32_t>(); fl.dt = ix->dtab; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = fa.n_groups;
+        fl.qc = ix->w_qc.as<uint32_t>(); fl.dt = ix->dtab; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = fa.n_groups; fl.work_counter = fa.work_counter;
         fl.packed = fa.packed; fl.surv = fa.surv; fl.surv_count = fa.surv_count;
         fl.cand_count = fa.cand_count; fl.K = K; fl.L = L; fl.upi = upi; fl.sentinel = sentinel;
         fl.ablate = fa.ablate; fl.prof = fa.prof;
         const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + 2 * REC_DW * sizeof(int32_t);
+        const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t);
         fl.desc_offset = (uint32_t)desc_off;
         static bool f4attr = false;
         if (!f4attr) {

@@ -53,8 +53,8 @@ static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row bloc
 __global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
                                                         const int32_t* __restrict__ blk_off, int32_t* __restrict__ out_cell,
                                                         int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
-                                                        int32_t* __restrict__ n_groups) {
-  constexpr int NB = FUSED_G * 4 + 4;   // class = (items, quarter of a full chunk), descending
+                                                        int32_t* __restrict__ n_groups, int cost_mode) {
+  constexpr int NB = 128;   // cost classes, descending (cost_mode 0 uses FUSED_G * 4 + 4 of them: (items, quarter of a full chunk))
   __shared__ int hist[NB];
   __shared__ int start[NB];
   const int tid = threadIdx.x;
@@ -74,7 +74,14 @@ __global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restri
           int nb = nblk - ch * FUSED_UNIT_BLOCKS;
           nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
           const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
-          const int k = (FUSED_G - cnt) * 4 + (3 - rq);              // small class index = big entry
+          // small class index = big entry.  cost_mode 0 (exact kernels): slab arithmetic grows with the items;
+          // cost_mode 1 (filter kernel, LDS-bound): item quads x row-slot quarters = its LDS reads
+          int k = (FUSED_G - cnt) * 4 + (3 - rq);
+          if (cost_mode) {   // measured model in units of 100 cycles: selection tail + 12 x max(builder phase, gather phase)
+            const int gp = 4 + (26 * (rq + 1) * ((cnt + 3) >> 2) + 5) / 10;
+            const int cost = 50 + 7 * cnt + 12 * (gp > 15 ? gp : 15);   // 237 .. 554
+            k = (560 - cost) / 3;
+          }
           if (!emit) {
             atomicAdd(&hist[k], 1);
           } else {

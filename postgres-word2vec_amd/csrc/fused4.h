@@ -38,6 +38,7 @@ struct FilterArgs {
   const float* dt;             // [C][M][K]   |c|^2 + 2 co_p . c    (pinned)
   const int32_t* records;      // [entries][REC_DW] (entry_record_kernel)
   const int32_t* n_groups;     // [1] number of work entries
+  int32_t* work_counter;       // [1] zeroed before the launch
   const uint32_t* packed;      // [blocks][M2][64]
   u64* surv;                   // [items][upi][8 waves][512]: (bits(d_lo) << 32) | flag << 31 | row location
   int32_t* surv_count;
@@ -143,21 +144,33 @@ __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __rest
   }
   __syncthreads();
   const int nq = (Q - q0 < QT) ? Q - q0 : QT;
-  for (int qi = 0; qi < nq; ++qi) {
-    v2f acc = v2f{0.0f, 0.0f};
+  static_assert(QT % 4 == 0, "four queries per step");
+  // four queries per step = four independent fma chains (a dependent packed op issues only every ~19 cycles)
+  for (int qi = 0; qi < nq; qi += 4) {
+    v2f acc[4] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
 #pragma unroll
     for (int jb = 0; jb < SP / 4; ++jb) {
-      const float4 v = *reinterpret_cast<const float4*>(&qs[qi][jb * 4]);
-      const float vv[4] = {v.x, v.y, v.z, v.w};
+      float vv[4][4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&qs[qi + w][jb * 4]);
+        vv[w][0] = v.x; vv[w][1] = v.y; vv[w][2] = v.z; vv[w][3] = v.w;
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (jb * 4 + u < S) acc = __builtin_elementwise_fma(v2f{vv[u], vv[u]}, cb[jb * 4 + u < S ? jb * 4 + u : 0], acc);
+        if (jb * 4 + u < S) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            acc[w] = __builtin_elementwise_fma(v2f{vv[w][u], vv[w][u]}, cb[jb * 4 + u < S ? jb * 4 + u : 0], acc[w]);
+        }
     }
-    const float a0 = acc.x, a1 = acc.y;
-    const float inv = inv_s[qi];
-    const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * a0 * inv), -32767.0f), 32767.0f);
-    const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * a1 * inv), -32767.0f), 32767.0f);
-    if (b < 512) qc[((size_t)(q0 + qi) * m + p) * 512 + b] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float inv = inv_s[qi + w];
+      const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w].x * inv), -32767.0f), 32767.0f);
+      const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w].y * inv), -32767.0f), 32767.0f);
+      if (qi + w < nq && b < 512) qc[((size_t)(q0 + qi + w) * m + p) * 512 + b] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+    }
   }
 }
 
@@ -259,19 +272,23 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
   uint32_t* colmin = reinterpret_cast<uint32_t*>(smem + a.desc_offset);           // [16][64]
   uint32_t* thr_s = colmin + 16 * 64;                                             // [16]
   int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // [2][REC_DW] entry records
+  int32_t* gidq = dsc + 2 * REC_DW;                                                // [2] entry numbers: slot i & 1 = the workgroup's i-th
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool builder = wave < SPEC2_NB;
   const int K = FULLK ? 1024 : a.K;
   const int n_work = a.n_groups[0];
-  const int nwg = (int)gridDim.x;
-  auto entry_of = [&](int i) { return i * nwg + ((i & 1) ? nwg - 1 - (int)blockIdx.x : (int)blockIdx.x); };
 
+  // Entries are pulled from a device counter in largest-first order, TWO ahead: the number of the entry
+  // after the next is requested while the current one runs, so neither the atomic nor the record load
+  // that depends on it is ever waited for.
   int cur = 0, ei = 0;
-  if (entry_of(0) >= n_work) return;
+  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = atomicAdd(a.work_counter, 1); }
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
-  if (tid < REC_DW) dsc[tid] = a.records[(size_t)entry_of(0) * REC_DW + tid];
+  __syncthreads();
+  if (gidq[0] >= n_work) return;
+  if (tid < REC_DW) dsc[tid] = a.records[(size_t)gidq[0] * REC_DW + tid];
   static_assert(REC_DW <= 5 * 64, "record prefetch by builder waves 0-4");
   __syncthreads();
 
@@ -343,14 +360,16 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     lds_barrier();
     for (;;) {
       const int nb = cur ^ 1;
-      const int ngid = entry_of(ei + 1);
+      const int ngid = __builtin_amdgcn_readfirstlane(gidq[(ei + 1) & 1]);
       const bool have_next = ngid < n_work;
+      int gid2 = 0;   // (thread 0) the entry after the next
       int next_nq = 0, next_cell = 0;
       int32_t rr0 = 0, rr1 = 0;   // wave 0/1: the next entry's record on its way to LDS
 #pragma unroll
       for (int p = 0; p < M; ++p) {
         // the next entry's record: requested in P(0), stored in P(2), first read in P(M-2)
         if (p == 2 && tid < REC_DW) {
+          if (tid == 0) gidq[ei & 1] = gid2;   // (slot of the current entry: read by everybody before P(0))
           dsc[nb * REC_DW + tid] = rr0;
           if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
         }
@@ -370,6 +389,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
           issue(p & 1, p + 2 - M, next_cell, next_nq, nqid);
         }
         if (p == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
+        if (p == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
         tick(0);
         lds_barrier();
         tick(1);
@@ -409,31 +429,47 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       const int nrows = __builtin_amdgcn_readfirstlane(rec[5]);
       const int nq = (cnt + 3) >> 2;
       const int nb = cur ^ 1;
+      const int rl_wave = (nblk - gw + NG - 1) / NG < 0 ? 0 : (nblk - gw + NG - 1) / NG;   // row slots of this wave that hold rows
       auto row_block = [&](int r) {
         const int bl = r * NG + gw;
         return (uint32_t)(blk0 + (bl < nblk - 1 ? bl : nblk - 1));
       };
-      auto load_codes = [&](int pair) {
+      // The main loop, instantiated per (item quads NQ the entry has, row slots RL this wave has rows in):
+      // LDS bandwidth bounds it, so the reads of unused item slots and of row slots past the end of the
+      // list are not issued.  (Selected OUTSIDE the position loop: conditional updates inside it make
+      // hipcc copy the whole register tile.)  Every variant passes the same barriers.
+      auto main_loop = [&](auto nqc, auto rlc) {
+        constexpr int NQ = decltype(nqc)::value, RL = decltype(rlc)::value;
+        auto load_codes = [&](int pair) {
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) cw[r] = a.packed[(row_block(r) * M2 + (uint32_t)pair) * 64u + (uint32_t)lane];
-      };
-      // one row at a time: three ds_read_b128 fetch a row's 12 item values
-      auto gather_any = [&](int p) {
-        const float* curs = slab + (size_t)(p & 1) * G * K;
-        const int sh = (p & 1) * 16;
+          for (int r = 0; r < RL; ++r) cw[r] = a.packed[(row_block(r) * M2 + (uint32_t)pair) * 64u + (uint32_t)lane];
+        };
+        // one row at a time: NQ ds_read_b128 fetch a row's item values
+        auto gather = [&](int p) {
+          const float* curs = slab + (size_t)(p & 1) * G * K;
+          const int sh = (p & 1) * 16;
 #pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const int code = (int)((cw[r] >> sh) & 0xffffu);
-          const float* row = curs + code * G;
-          float4 v[G / 4];
+          for (int r = 0; r < RL; ++r) {
+            const int code = (int)((cw[r] >> sh) & 0xffffu);
+            const float* row = curs + code * G;
+            float4 v[NQ];
 #pragma unroll
-          for (int q = 0; q < G / 4; ++q) v[q] = *reinterpret_cast<const float4*>(row + q * 4);
+            for (int q = 0; q < NQ; ++q) v[q] = *reinterpret_cast<const float4*>(row + q * 4);
 #pragma unroll
-          for (int q = 0; q < G / 4; ++q) {
-            acc[q * 2 + 0][r] = acc[q * 2 + 0][r] + v2f{v[q].x, v[q].y};
-            acc[q * 2 + 1][r] = acc[q * 2 + 1][r] + v2f{v[q].z, v[q].w};
+            for (int q = 0; q < NQ; ++q) {
+              acc[q * 2 + 0][r] = acc[q * 2 + 0][r] + v2f{v[q].x, v[q].y};
+              acc[q * 2 + 1][r] = acc[q * 2 + 1][r] + v2f{v[q].z, v[q].w};
+            }
           }
+        };
+        load_codes(0);
+        for (int p = 0; p + 1 < M; ++p) {
+          if (!(a.ablate & 2)) gather(p);
+          __builtin_amdgcn_sched_barrier(0);
+          if (p & 1) load_codes((p + 1) >> 1);
+          lds_barrier();
         }
+        if (!(a.ablate & 2)) gather(M - 1);
       };
 #pragma unroll
       for (int h = 0; h < G / 2; ++h) {
@@ -441,14 +477,28 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) acc[h][r] = o;
       }
-      load_codes(0);
-      for (int p = 0; p + 1 < M; ++p) {
-        if (!(a.ablate & 2)) gather_any(p);
-        __builtin_amdgcn_sched_barrier(0);
-        if (p & 1) load_codes((p + 1) >> 1);
-        lds_barrier();
+      {
+        int rl = rl_wave;
+        rl = rl < 1 ? 1 : rl;
+        const int rc = (rl + 1) >> 1;         // 1..4 -> RL = 2, 4, 6, 8
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>;
+        using I6 = std::integral_constant<int, 6>; using I8 = std::integral_constant<int, 8>;
+        switch (nq * 4 + rc) {
+          case 1 * 4 + 1: main_loop(I1{}, I2{}); break;
+          case 1 * 4 + 2: main_loop(I1{}, I4{}); break;
+          case 1 * 4 + 3: main_loop(I1{}, I6{}); break;
+          case 1 * 4 + 4: main_loop(I1{}, I8{}); break;
+          case 2 * 4 + 1: main_loop(I2{}, I2{}); break;
+          case 2 * 4 + 2: main_loop(I2{}, I4{}); break;
+          case 2 * 4 + 3: main_loop(I2{}, I6{}); break;
+          case 2 * 4 + 4: main_loop(I2{}, I8{}); break;
+          case 3 * 4 + 1: main_loop(I3{}, I2{}); break;
+          case 3 * 4 + 2: main_loop(I3{}, I4{}); break;
+          case 3 * 4 + 3: main_loop(I3{}, I6{}); break;
+          default: main_loop(I3{}, I8{}); break;
+        }
       }
-      if (!(a.ablate & 2)) gather_any(M - 1);
       // rows past the end of the list (last block of the last chunk): park them above everything
       if (nrows < FUSED_UNIT_BLOCKS * 64) {
 #pragma unroll
@@ -466,7 +516,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
             uint32_t best = bits(g, 0);
 #pragma unroll
             for (int r = 1; r < RMAX; ++r) best = min(best, bits(g, r));
-            atomicMin(colmin + g * 64 + lane, best);
+            if (rl_wave > 0) atomicMin(colmin + g * 64 + lane, best);
           }
         }
       }
@@ -475,15 +525,17 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       if (!(a.ablate & 4)) {
         static_assert(G <= 2 * NG, "at most two items per gatherer wave");
         const int g0 = gw, g1 = gw + NG;
-        uint32_t c0 = colmin[g0 * 64 + lane], c1 = colmin[g1 * 64 + lane];
-        wave_sort32_x2(c0, c1);
-        const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
-        if (lane == 0) {
-          thr_s[g0] = widen_threshold(t0, __int_as_float(rec[56 + g0]));
-          thr_s[g1] = widen_threshold(t1, __int_as_float(rec[56 + g1]));
+        if (g0 < cnt) {   // (items gw and gw + 8; nothing to do for a wave whose items the entry does not have)
+          uint32_t c0 = colmin[g0 * 64 + lane], c1 = colmin[g1 * 64 + lane];
+          wave_sort32_x2(c0, c1);
+          const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
+          if (lane == 0) {
+            thr_s[g0] = widen_threshold(t0, __int_as_float(rec[56 + g0]));
+            thr_s[g1] = widen_threshold(t1, __int_as_float(rec[56 + g1]));
+          }
+          colmin[g0 * 64 + lane] = 0xffffffffu;
+          colmin[g1 * 64 + lane] = 0xffffffffu;
         }
-        colmin[g0 * 64 + lane] = 0xffffffffu;
-        colmin[g1 * 64 + lane] = 0xffffffffu;
       }
       lds_barrier();
       // S2: survivors -> this wave's region of each item's buffer
@@ -506,8 +558,25 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
               if (lane == 0 && accepted) atomicAdd(a.cand_count + __builtin_amdgcn_readfirstlane(rec[24 + g]), accepted);
             }
             int run = 0;
+            if (!a.cand_count) {   // the common case (freddy.c:366 counts retrieved rows): nothing but the threshold test
+#pragma unroll
+              for (int r = 0; r < RMAX; ++r) {
+                if (r >= rl_wave) break;   // (uniform: the wave's remaining row slots are past the end of the list)
+                const uint32_t sb = bits(g, r);
+                const u64 mask = __ballot(sb <= thr);
+                if (mask != 0ull) {
+                  if (sb <= thr) {
+                    const float dlo = fmaxf(0.0f, __uint_as_float(sb) - shift);
+                    const uint32_t loc = (uint32_t)(blk0 + r * NG + gw) * 64u + (uint32_t)lane;
+                    dst[run + lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+                  }
+                  run += __popcll(mask);
+                }
+              }
+            } else
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) {
+              if (r >= rl_wave) break;
               const uint32_t sb = bits(g, r);
               const bool amb = sb >= lo_b && sb < hi_b;
               const bool pass = sb <= thr || amb;
