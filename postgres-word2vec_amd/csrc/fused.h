@@ -50,56 +50,73 @@ static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row bloc
 // cell x 4096-row chunk; first = index into cell_items), so the fused kernels' grids have no holes, in
 // longest-processing-time-first order: entries with more items (more slab arithmetic) are pulled first,
 // the tail of the launch is made of small entries (counting sort on (items, rows) classes).
-__global__ __launch_bounds__(256) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
-                                                        const int32_t* __restrict__ blk_off, int32_t* __restrict__ out_cell,
-                                                        int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
-                                                        int32_t* __restrict__ n_groups, int cost_mode) {
+__global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
+                                                         const int32_t* __restrict__ blk_off, int32_t* __restrict__ out_cell,
+                                                         int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
+                                                         int32_t* __restrict__ n_groups, int cost_mode) {
   constexpr int NB = 128;   // cost classes, descending (cost_mode 0 uses FUSED_G * 4 + 4 of them: (items, quarter of a full chunk))
+  constexpr int T = 1024, CPT = 4;   // the first T * CPT cells are read once and kept in registers for both sweeps
   __shared__ int hist[NB];
   __shared__ int start[NB];
   const int tid = threadIdx.x;
-  for (int i = tid; i < NB; i += 256) hist[i] = 0;
+  for (int i = tid; i < NB; i += T) hist[i] = 0;
+  int cn[CPT], cb[CPT];
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const int c = tid + i * T;
+    cn[i] = c < C ? cell_count[c] : 0;
+    cb[i] = c < C ? blk_off[c + 1] - blk_off[c] : 0;
+  }
   __syncthreads();
-  // Two sweeps over this thread's cells (cell c = tid, tid + 256, ...): count the entries per class,
-  // then emit them into their class's range.  Order inside a class is irrelevant.
-  auto sweep = [&](bool emit) {
-    for (int c = tid; c < C; c += 256) {
-      const int n = cell_count[c];
-      if (n == 0) continue;
-      const int nblk = blk_off[c + 1] - blk_off[c];
-      const int chunks = (nblk + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
-      for (int f = 0; f < n; f += gsz) {
-        const int cnt = (n - f < gsz) ? n - f : gsz;
-        for (int ch = 0; ch < chunks; ++ch) {
-          int nb = nblk - ch * FUSED_UNIT_BLOCKS;
-          nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
-          const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
-          // small class index = big entry.  cost_mode 0 (exact kernels): slab arithmetic grows with the items;
-          // cost_mode 1 (filter kernel, LDS-bound): item quads x row-slot quarters = its LDS reads
-          int k = (FUSED_G - cnt) * 4 + (3 - rq);
-          if (cost_mode) {   // measured model in units of 100 cycles: selection tail + 12 x max(builder phase, gather phase)
-            const int gp = 4 + (26 * (rq + 1) * ((cnt + 3) >> 2) + 5) / 10;
-            const int cost = 50 + 7 * cnt + 12 * (gp > 15 ? gp : 15);   // 237 .. 554
-            k = (560 - cost) / 3;
-          }
-          if (!emit) {
-            atomicAdd(&hist[k], 1);
-          } else {
-            const int slot = atomicAdd(&start[k], 1);
-            out_cell[slot] = c;
-            out_first[slot] = c * cell_cap + f;
-            out_cnt[slot] = cnt | (ch << 8);
-          }
+  // Two sweeps over this thread's cells: count the entries per class, then emit them into their class's
+  // range.  Order inside a class is irrelevant.
+  auto cell = [&](bool emit, int c, int n, int nblk) {
+    if (n == 0) return;
+    const int chunks = (nblk + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+    for (int f = 0; f < n; f += gsz) {
+      const int cnt = (n - f < gsz) ? n - f : gsz;
+      for (int ch = 0; ch < chunks; ++ch) {
+        int nb = nblk - ch * FUSED_UNIT_BLOCKS;
+        nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
+        const int rq = (nb * 4 - 1) / FUSED_UNIT_BLOCKS;          // 0..3
+        // small class index = big entry.  cost_mode 0 (exact kernels): slab arithmetic grows with the items;
+        // cost_mode 1 (filter kernel, LDS-bound): measured model in units of 100 cycles, selection tail +
+        // 12 x max(builder phase, gather phase)
+        int k = (FUSED_G - cnt) * 4 + (3 - rq);
+        if (cost_mode) {
+          const int gp = 4 + (26 * (rq + 1) * ((cnt + 3) >> 2) + 5) / 10;
+          const int cost = 50 + 7 * cnt + 12 * (gp > 15 ? gp : 15);   // 237 .. 554
+          k = (560 - cost) / 3;
+        }
+        if (!emit) {
+          atomicAdd(&hist[k], 1);
+        } else {
+          const int slot = atomicAdd(&start[k], 1);
+          out_cell[slot] = c;
+          out_first[slot] = c * cell_cap + f;
+          out_cnt[slot] = cnt | (ch << 8);
         }
       }
     }
   };
+  auto sweep = [&](bool emit) {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) cell(emit, tid + i * T, cn[i], cb[i]);
+    for (int c = tid + CPT * T; c < C; c += T) cell(emit, c, cell_count[c], blk_off[c + 1] - blk_off[c]);
+  };
   sweep(false);
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    for (int b = 0; b < NB; ++b) { start[b] = acc; acc += hist[b]; }
-    n_groups[0] = acc;
+  if (tid < 64) {   // exclusive prefix over the NB = 128 classes, two per lane
+    const int h0 = hist[2 * tid], h1 = hist[2 * tid + 1];
+    int inc = h0 + h1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (tid >= o) inc += up;
+    }
+    start[2 * tid] = inc - h0 - h1;
+    start[2 * tid + 1] = inc - h1;
+    if (tid == 63) n_groups[0] = inc;
   }
   __syncthreads();
   sweep(true);
