@@ -402,3 +402,79 @@ def test_hip_path_reproduces_committed_golden_vectors(gpu, monkeypatch):
     gi, gs = vi.search(qs, 6)
     same(gi, gs, g["exact_knn"], "exact kNN")
     vi.close()
+
+
+# ---------------------------------------------------------------------------------------
+# filter + refine scan (fused4.h, the default for batches): the cases its bounds have to survive
+# ---------------------------------------------------------------------------------------
+def _fr_setup(gpu, oracle, K=256, scale=1.0, dup_rows=0):
+    t = dict(util.ivf_tables(N=20000, C=32, K=K))
+    if scale != 1.0:
+        t["coarse"] = (t["coarse"] * np.float32(scale)).astype(np.float32)
+        t["codebook"] = (t["codebook"] * np.float32(scale)).astype(np.float32)
+    if dup_rows:
+        # the first dup_rows rows of every list get the list's first code row: that many exactly equal distances
+        codes = t["codes"].copy()
+        lo = t["list_off"]
+        for c in range(len(lo) - 1):
+            n = min(dup_rows, int(lo[c + 1] - lo[c]))
+            codes[lo[c]:lo[c] + n] = codes[lo[c]]
+        t["codes"] = codes
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(20000, 120)
+    return t, ot, idx, (qs * np.float32(scale)).astype(np.float32)
+
+
+def test_filter_refine_many_equal_distances(gpu, oracle, monkeypatch):
+    """Hundreds of rows with the SAME exact distance around the k-th place: more rows inside the error
+    margin than the merge keeps in registers (every key is revisited), order decided by id."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, dup_rows=300)
+    for k, W, rule, sent in ((5, 3, 0, 1000.0), (32, 2, 0, 1000.0), (10, 4, 1, 100.0)):
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"equal distances k={k} W={W} rule={rule}")
+    idx.close()
+
+
+def test_filter_refine_sentinel_inside_the_data(gpu, oracle, monkeypatch):
+    """The guard dist < sentinel (freddy.c:128-131) with the sentinel in the middle of the distances and
+    exactly ON a row's distance: rows whose bound straddles it are decided by the exact stage, and with
+    the batch rule the number of accepted rows decides whether a query goes to another round."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle)
+    base = oracle.ivfadc_search_many(ot, qs, 8, 2, sentinel=1000.0, found_rule=0)
+    d = base["dist"].reshape(len(qs), 8)
+    for sent in (float(d[0, 3]), float(d[5, 0]), float(np.median(d[:, 7])), float(np.nextafter(d[9, 2], np.float32(0)))):
+        for rule in (0, 1):
+            gi, gd = idx.search(qs, 8, 2, sentinel=sent, found_rule=rule)
+            exp = oracle.ivfadc_search_many(ot, qs, 8, 2, sentinel=sent, found_rule=rule)
+            util.assert_same_lists(gi, gd, exp, f"sentinel {sent!r} rule={rule}")
+    idx.close()
+
+
+@pytest.mark.parametrize("scale", [1e-12, 30.0, 1e4])
+def test_filter_refine_scaled_data(gpu, oracle, scale, monkeypatch):
+    """Tiny magnitudes (squares near the denormals), distances above the sentinels (x30: around 100 and
+    1000; x1e4: everything rejected): the bounds scale with the data."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, scale=scale)
+    for k, W, rule, sent in ((5, 3, 0, 1000.0), (5, 2, 1, 100.0)):
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"scale {scale} k={k} W={W} rule={rule}")
+    idx.close()
+
+
+def test_filter_refine_overflowing_bound(gpu, oracle, monkeypatch):
+    """Queries so large that the error bound itself overflows: every row goes to the exact stage (and
+    is rejected there, its distance being +inf) -- same lists as the reference arithmetic gives."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle)
+    qs = qs[:40].copy()
+    qs[::4] *= np.float32(3e19)
+    gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
+    exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
+    util.assert_same_lists(gi, gd, exp, "overflowing bound")
+    idx.close()
