@@ -2,9 +2,12 @@
 """bench.py -- batched IVFADC kNN throughput (BASELINE.json metric) on N MI355X.
 
 One "step" = one pass of the hot path over one batch of synthetic queries that are already
-resident in HBM: coarse distances -> probe plan (items bucketed by cell) -> work table -> the fused
-kernel (residuals, LUT slabs, ADC sums and survivor selection) -> merge/replay
-(+ the asynchronous RCCL gather of the per-shard top-k when N > 1).
+resident in HBM: coarse distances (+ the query x codebook table on a side stream) -> probe plan (items
+bucketed by cell) -> work table -> entry records -> the filter kernel (bounded cheap distances from two
+streamed tables, LDS slabs, sums and survivor selection) -> merge with the exact stage
+(the reference's arithmetic for the rows that can matter) and the updateTopK replay
+(+ the asynchronous RCCL gather of the per-shard top-k when N > 1).  Results are checked bit for bit
+against the CPU oracle on the bench queries (cpu_baseline.parity_with_gpu_on_sample).
 
 Workload (BASELINE.json configs[2]): 3,000,000 x 300-d synthetic GoogleNews-shaped corpus,
 C=1000 coarse cells, m=12, K=1024 residual PQ, nprobe W=10, k=5, 1024 queries per GPU
