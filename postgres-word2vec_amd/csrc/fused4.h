@@ -301,28 +301,34 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     const uint32_t vo0 = ok0 ? (uint32_t)b * 4u : 0u, vo1 = ok1 ? (uint32_t)(b + 512) * 4u : 0u;
     const size_t prow = (size_t)K * 4;   // bytes of one [K] row of dt
     const uint32_t vq = (uint32_t)b * 4u;   // this lane's dword of a [512] row of qc
-    float dtv[2][2];
-    uint32_t qw[2][G];
+    // three register sets: position p+3 is requested while p+1 is written -- with one phase of lead the
+    // 26 KB a CU has in flight bound the table streams to ~3.4 TB/s chip-wide (latency ~2 us)
+    static_assert(M % 3 == 0, "register sets rotate with the position, also across entries");
+    float dtv[3][2];
+    uint32_t qw[3][G];
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int g = 0; g < G; ++g) qw[u][g] = 0u;
     auto ldf = [&](const char* base, uint32_t off) { return *reinterpret_cast<const float*>(base + off); };
     // request the table values of position p of an entry (cell, nq item quads, query ids)
+    // (scalar base of the item's [M][512] block + one 32-bit lane offset per position: one instruction per
+    // load; the 64-bit multiply-adds hipcc otherwise emits per load are quarter rate)
+    typedef const char __attribute__((address_space(1))) * gptrc;
+    typedef const uint32_t __attribute__((address_space(1))) * gptru;
     auto issue = [&](int buf, int p, int cell, int nq, const int (&qids)[G]) {
       const char* dp = reinterpret_cast<const char*>(a.dt) + ((size_t)cell * M + p) * prow;
       dtv[buf][0] = ldf(dp, vo0);
       dtv[buf][1] = ldf(dp, vo1);
+      uint32_t voff = vq + (uint32_t)p * 2048u;
+      asm volatile("" : "+v"(voff));   // opaque: keeps per-load 64-bit addresses from being materialised
+      // (all 12 slots, also the unused ones -- they repeat item 0 and hit the L1: a STATIC number of loads
+      // lets the compiler wait for the set that is two phases old and no younger one)
+      (void)nq;
 #pragma unroll
-      for (int gq = 0; gq < G / 4; ++gq) {
-        if (gq < nq) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int g = gq * 4 + u;
-            const char* qp = reinterpret_cast<const char*>(a.qc) + ((size_t)qids[g] * M + p) * 2048;
-            qw[buf][g] = *reinterpret_cast<const uint32_t*>(qp + vq);
-          }
-        }
+      for (int g = 0; g < G; ++g) {
+        const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[g] * (size_t)(M * 2048);
+        qw[buf][g] = *(gptru)(qb + voff);
       }
     };
     // slab rows are [code][12 items]: one aligned 16-byte store per item quad and code; value = dt +
@@ -356,6 +362,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     for (int g = 0; g < G; ++g) { qid[g] = __builtin_amdgcn_readfirstlane(dsc[24 + g]); nqid[g] = qid[g]; }
     issue(0, 0, cell, nq, qid);
     issue(1, 1, cell, nq, qid);
+    issue(2, 2, cell, nq, qid);
     emit(0, slab, nq, dsc + 128);
     lds_barrier();
     for (;;) {
@@ -367,26 +374,26 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       int32_t rr0 = 0, rr1 = 0;   // wave 0/1: the next entry's record on its way to LDS
 #pragma unroll
       for (int p = 0; p < M; ++p) {
-        // the next entry's record: requested in P(0), stored in P(2), first read in P(M-2)
+        // the next entry's record: requested in P(0), stored in P(2), first read in P(M-3)
         if (p == 2 && tid < REC_DW) {
           if (tid == 0) gidq[ei & 1] = gid2;   // (slot of the current entry: read by everybody before P(0))
           dsc[nb * REC_DW + tid] = rr0;
           if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
         }
-        // slab(p+1) of this entry -- or slab(0) of the next one -- from the registers requested a phase ago
-        if (p + 1 < M) emit((p + 1) & 1, slab + (size_t)((p + 1) & 1) * G * K, nq, dsc + cur * REC_DW + 128 + (p + 1) * 12);
+        // slab(p+1) of this entry -- or slab(0) of the next one -- from the registers requested two phases ago
+        if (p + 1 < M) emit((p + 1) % 3, slab + (size_t)((p + 1) & 1) * G * K, nq, dsc + cur * REC_DW + 128 + (p + 1) * 12);
         else emit(0, slab, next_nq, dsc + nb * REC_DW + 128);
-        // request position p+2
-        if (p + 2 < M) {
-          issue(p & 1, p + 2, cell, nq, qid);
+        // request position p+3
+        if (p + 3 < M) {
+          issue(p % 3, p + 3, cell, nq, qid);
         } else {
-          if (p + 2 == M) {
+          if (p + 3 == M) {
             next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 3) >> 2 : 0;
             next_cell = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 0]) : cell;
 #pragma unroll
             for (int g = 0; g < G; ++g) nqid[g] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g]) : qid[g];
           }
-          issue(p & 1, p + 2 - M, next_cell, next_nq, nqid);
+          issue(p % 3, p + 3 - M, next_cell, next_nq, nqid);
         }
         if (p == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
         if (p == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
