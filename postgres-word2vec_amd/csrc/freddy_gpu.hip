@@ -101,7 +101,7 @@ struct freddy_gpu_index {
   float* cbP = nullptr;         // fused kernel layout [m][SP/4][512 slots][4 dims][2 codes] (NULL unless K <= 1024)
   // filter + refine path (fused4.h); NULL unless the shape is the fused one and the table fits the budget
   float* cbR = nullptr;         // [m][K][S] row-major codebook for the exact stage
-  float* dtab = nullptr;        // [C][m][K]  |c|^2 + 2 co_p . c
+  float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
@@ -126,7 +126,7 @@ struct freddy_gpu_index {
 };
 
 static size_t filter_table_budget_bytes() {
-  const char* e = getenv("FREDDY_GPU_FILTER_TABLE_MB");   // 0 disables the filter + refine path at pin time
+  const char* e = getenv("FREDDY_GPU_FILTER_TABLE_MB");   // 0: no filter + refine tables at pin time (4 bytes per row)
   size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 8192;
   return mb << 20;
 }
@@ -169,7 +169,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
   if (ix->ev_q) (void)hipEventDestroy(ix->ev_q);
   if (ix->ev_qc) (void)hipEventDestroy(ix->ev_qc);
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->dtab, ix->pmax, ix->cmaxp, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -336,9 +336,8 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
               }
       if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     }
-    // filter + refine tables (fused4.h): dt is C*m*K floats (49 MB for C=1000, m=12, K=1024)
-    const size_t dt_bytes = sizeof(float) * (size_t)t->C * ix->m * ix->K;
-    if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && dt_bytes <= filter_table_budget_bytes()) {
+    // filter + refine tables (fused4.h)
+    if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && filter_table_budget_bytes() > 0) {
       std::vector<float> pmax((size_t)ix->m), cmaxp((size_t)ix->m);
       for (int p = 0; p < ix->m; ++p) {
         double comax = 0.0, cmax = 0.0;
@@ -357,19 +356,22 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
       }
       if (upload(&ix->cbR, t->codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
           upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
-          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes) ||
-          hipMalloc((void**)&ix->dtab, dt_bytes) != hipSuccess)
+          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
         rc = fail(FREDDY_E_NOMEM, "device allocation failed");
-      if (!rc) {
-        ix->bytes += (int64_t)dt_bytes;
-        hipLaunchKernelGGL(cell_codebook_kernel, dim3(t->C, ix->m), dim3(256), 0, ix->stream, ix->coarse, ix->cbT, ix->dtab,
-                           t->d, ix->m, ix->K, ix->S);
-        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
-          rc = fail(FREDDY_E_HIP, "building the cell x codebook table failed");
-      }
     }
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
+  if (!rc && ix->cbR) {   // one float per row slot: the (cell, row) part of the filter's cheap distance
+    const int64_t n_slots = std::max<int64_t>(ix->n_blocks, 1) * 64;
+    if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    if (!rc && ix->n_blocks > 0) {
+      ix->bytes += (int64_t)sizeof(float) * n_slots;
+      hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((ix->n_blocks * 64 + 255) / 256)), dim3(256), 0, ix->stream, ix->packed,
+                         ix->blk_cell, ix->coarse, ix->cbR, ix->rterm, ix->n_blocks * 64, ix->M2, ix->d, ix->m, ix->K, ix->S);
+      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
+        rc = fail(FREDDY_E_HIP, "building the row terms failed");
+    }
+  }
   if (rc) { free_index(ix); return rc; }
   *out = ix;
   return FREDDY_OK;
@@ -570,7 +572,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   // cheap bounded distances in the scan, the reference's arithmetic only for the rows that can matter)
   const char* fvenv = getenv("FREDDY_GPU_FUSED_KERNEL");   // read per call: the tests switch it
   int fvariant = (fvenv && fvenv[0] >= '1' && fvenv[0] <= '4') ? fvenv[0] - '0' : 4;
-  if (fvariant == 4 && !ix->dtab) fvariant = 3;
+  if (fvariant == 4 && !ix->rterm) fvariant = 3;
   if (fused && fvariant == 4) {
     if (ix->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
@@ -779,12 +781,12 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         });
         HIP_TRY(hipGetLastError());
         FilterArgs fl;
-        fl.qc = ix->w_qc.as<uint32_t>(); fl.dt = ix->dtab; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = fa.n_groups; fl.work_counter = fa.work_counter;
+        fl.qc = ix->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = fa.n_groups; fl.work_counter = fa.work_counter;
         fl.packed = fa.packed; fl.surv = fa.surv; fl.surv_count = fa.surv_count;
         fl.cand_count = fa.cand_count; fl.K = K; fl.L = L; fl.upi = upi; fl.sentinel = sentinel;
         fl.ablate = fa.ablate; fl.prof = fa.prof;
         const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t);
+        const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
         fl.desc_offset = (uint32_t)desc_off;
         static bool f4attr = false;
         if (!f4attr) {

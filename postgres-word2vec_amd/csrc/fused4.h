@@ -35,7 +35,7 @@ namespace freddy {
 
 struct FilterArgs {
   const uint32_t* qc;          // [Q][M][512] -2 q_p . c as int16 pairs (codes b, b+512)   (query_codebook_kernel)
-  const float* dt;             // [C][M][K]   |c|^2 + 2 co_p . c    (pinned)
+  const float* rterm;          // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row (pinned)
   const int32_t* records;      // [entries][REC_DW] (entry_record_kernel)
   const int32_t* n_groups;     // [1] number of work entries
   int32_t* work_counter;       // [1] zeroed before the launch
@@ -174,19 +174,26 @@ __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __rest
   }
 }
 
-// dt[cell][p][code] = |c|^2 + 2 co_p . c in fp64, rounded once (pin time)
-__global__ __launch_bounds__(256) void cell_codebook_kernel(const float* __restrict__ coarse, const float* __restrict__ cbT,
-                                                           float* __restrict__ dt, int d, int m, int K, int S) {
-  const int cell = blockIdx.x, p = blockIdx.y;
-  for (int c = threadIdx.x; c < K; c += 256) {
-    double acc = 0.0;
-    for (int j = 0; j < S; ++j) {
-      const double cv = (double)cbT[((size_t)p * S + j) * K + c];
-      const double co = (double)coarse[(size_t)cell * d + p * S + j];
-      acc += cv * cv + 2.0 * co * cv;
-    }
-    dt[((size_t)cell * m + p) * K + c] = (float)acc;
+// rterm[row] = sum_p (|c|^2 + 2 co_p . c) over the row's 12 codewords c and its cell's centroid co, in fp64,
+// rounded once (pin time).  The part of the cheap distance that depends on (cell, row) only: it is the
+// initial value of the row's running sum, so the scan streams nothing per cell.
+__global__ __launch_bounds__(256) void row_term_kernel(const uint32_t* __restrict__ packed, const int32_t* __restrict__ blk_cell,
+                                                      const float* __restrict__ coarse, const float* __restrict__ cbR,
+                                                      float* __restrict__ rterm, int64_t n_slots, int M2, int d, int m, int K, int S) {
+  const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (slot >= n_slots) return;
+  const int64_t block = slot >> 6;
+  const int lane = (int)(slot & 63);
+  const int cell = blk_cell[block];
+  double acc = 0.0;
+  for (int p = 0; p < m; ++p) {
+    const uint32_t word = packed[((size_t)block * M2 + (p >> 1)) * 64 + lane];
+    const int code = (int)((word >> ((p & 1) * 16)) & 0xffffu);
+    const float* cv = cbR + ((size_t)p * K + (code < K ? code : 0)) * S;
+    const float* co = coarse + (size_t)cell * d + (size_t)p * S;
+    for (int j = 0; j < S; ++j) acc += (double)cv[j] * (double)cv[j] + 2.0 * (double)co[j] * (double)cv[j];
   }
+  rterm[slot] = (float)acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
   uint32_t* thr_s = colmin + 16 * 64;                                             // [16]
   int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // [2][REC_DW] entry records
   int32_t* gidq = dsc + 2 * REC_DW;                                                // [2] entry numbers: slot i & 1 = the workgroup's i-th
+  float* rt_s = reinterpret_cast<float*>(gidq + 4);                                // [4096] row terms of the entry about to start
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,28 +306,22 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     // =====================================================================================
     const int b = tid;
     const bool ok0 = FULLK || b < K, ok1 = FULLK || b + 512 < K;
-    const uint32_t vo0 = ok0 ? (uint32_t)b * 4u : 0u, vo1 = ok1 ? (uint32_t)(b + 512) * 4u : 0u;
-    const size_t prow = (size_t)K * 4;   // bytes of one [K] row of dt
     const uint32_t vq = (uint32_t)b * 4u;   // this lane's dword of a [512] row of qc
     // three register sets: position p+3 is requested while p+1 is written -- with one phase of lead the
     // 26 KB a CU has in flight bound the table streams to ~3.4 TB/s chip-wide (latency ~2 us)
     static_assert(M % 3 == 0, "register sets rotate with the position, also across entries");
-    float dtv[3][2];
     uint32_t qw[3][G];
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int g = 0; g < G; ++g) qw[u][g] = 0u;
-    auto ldf = [&](const char* base, uint32_t off) { return *reinterpret_cast<const float*>(base + off); };
     // request the table values of position p of an entry (cell, nq item quads, query ids)
     // (scalar base of the item's [M][512] block + one 32-bit lane offset per position: one instruction per
     // load; the 64-bit multiply-adds hipcc otherwise emits per load are quarter rate)
     typedef const char __attribute__((address_space(1))) * gptrc;
     typedef const uint32_t __attribute__((address_space(1))) * gptru;
     auto issue = [&](int buf, int p, int cell, int nq, const int (&qids)[G]) {
-      const char* dp = reinterpret_cast<const char*>(a.dt) + ((size_t)cell * M + p) * prow;
-      dtv[buf][0] = ldf(dp, vo0);
-      dtv[buf][1] = ldf(dp, vo1);
+      (void)cell;
       uint32_t voff = vq + (uint32_t)p * 2048u;
       asm volatile("" : "+v"(voff));   // opaque: keeps per-load 64-bit addresses from being materialised
       // (all 12 slots, also the unused ones -- they repeat item 0 and hit the L1: a STATIC number of loads
@@ -343,8 +345,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const uint32_t w = qw[buf][gq * 4 + u];
-            lo[u] = __builtin_fmaf((float)((int32_t)(w << 16) >> 16), ss[u], dtv[buf][0]);
-            hi[u] = __builtin_fmaf((float)((int32_t)w >> 16), ss[u], dtv[buf][1]);
+            lo[u] = (float)((int32_t)(w << 16) >> 16) * ss[u];
+            hi[u] = (float)((int32_t)w >> 16) * ss[u];
           }
           if (ok0) *reinterpret_cast<float4*>(dst + b * G + gq * 4) = float4{lo[0], lo[1], lo[2], lo[3]};
           if (ok1) *reinterpret_cast<float4*>(dst + (b + 512) * G + gq * 4) = float4{hi[0], hi[1], hi[2], hi[3]};
@@ -360,6 +362,22 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     int qid[G], nqid[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { qid[g] = __builtin_amdgcn_readfirstlane(dsc[24 + g]); nqid[g] = qid[g]; }
+    // row terms of an entry (record rc): builder wave w fetches what gatherer wave w's lanes start from
+    float rtv[RMAX];
+    auto fetch_row_terms = [&](const int32_t* rc) {
+      const int b0 = __builtin_amdgcn_readfirstlane(rc[3]), nbk = __builtin_amdgcn_readfirstlane(rc[4]);
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const int bl = r * NG + wave;
+        rtv[r] = a.rterm[(size_t)(uint32_t)(b0 + (bl < nbk - 1 ? bl : nbk - 1)) * 64u + (uint32_t)lane];
+      }
+    };
+    auto stash_row_terms = [&]() {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) rt_s[(r * NG + wave) * 64 + lane] = rtv[r];
+    };
+    fetch_row_terms(dsc);
+    stash_row_terms();
     issue(0, 0, cell, nq, qid);
     issue(1, 1, cell, nq, qid);
     issue(2, 2, cell, nq, qid);
@@ -395,6 +413,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
           }
           issue(p % 3, p + 3 - M, next_cell, next_nq, nqid);
         }
+        // the next entry's row terms: requested in P(4) (its record is in LDS since P(2)), staged in P(7) --
+        // the gatherers read the current entry's before P(0)
+        if (p == 4) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
+        if (p == 7) stash_row_terms();
         if (p == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
         if (p == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
         tick(0);
@@ -469,6 +491,18 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
             }
           }
         };
+        // sums start at OFF + the row's own term (staged in LDS by the builders during the previous entry).
+        // Row slots >= RL hold no rows: parked.
+#pragma unroll
+        for (int r = 0; r < RL; ++r) cw[r] = __float_as_uint(rt_s[(r * NG + gw) * 64 + lane]);
+#pragma unroll
+        for (int h = 0; h < G / 2; ++h) {
+          const v2f o = v2f{__int_as_float(rec[40 + 2 * h]), __int_as_float(rec[40 + 2 * h + 1])};
+#pragma unroll
+          for (int r = 0; r < RL; ++r) acc[h][r] = o + v2f{__uint_as_float(cw[r]), __uint_as_float(cw[r])};
+#pragma unroll
+          for (int r = RL; r < RMAX; ++r) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+        }
         load_codes(0);
         for (int p = 0; p + 1 < M; ++p) {
           if (!(a.ablate & 2)) gather(p);
@@ -478,12 +512,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         }
         if (!(a.ablate & 2)) gather(M - 1);
       };
-#pragma unroll
-      for (int h = 0; h < G / 2; ++h) {
-        const v2f o = v2f{__int_as_float(rec[40 + 2 * h]), __int_as_float(rec[40 + 2 * h + 1])};
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) acc[h][r] = o;
-      }
       {
         int rl = rl_wave;
         rl = rl < 1 ? 1 : rl;
