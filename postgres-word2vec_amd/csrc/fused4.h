@@ -6,18 +6,19 @@
 // replayed only for the rows that can still matter:
 //
 //   |r - c|^2 = |r|^2 + (|c|^2 + 2 co.c) - 2 q.c          r = q - co  (co = coarse centroid, c = codeword)
-//                       `----- dt[cell][p][code]           pinned once (fp64 -> fp32)
+//                       `----- summed over the row's codewords: rterm[row], pinned once (fp64 -> fp32)
 //                                        `---- qc[query][p][code] = -2 q_p.c   one small kernel per batch
 //
-// so the slab of a position is ONE addition per (code, item): slab = dt + qc.  The |r|^2 term is the
-// same for all rows of an item and is only needed as a bound (the coarse distance the probe plan
+// so a row's running sum starts at rterm[row] and the slab of a position is ONE multiplication per
+// (code, item): slab = scale * qc16.  The |r|^2 term is the same for all rows of an item and is only
+// needed as a bound (the coarse distance the probe plan
 // already has).  With u = 2^-24, B = sum_p (|q_p| + max|co_p| + max|c_p|)^2 and E = 2048 u B:
-//   * stored sum  s = OFF + sum_p slab_p  (OFF = A_up + E >= what keeps s positive)
-//   * | (s - OFF + |r|^2) - d | <= 117 u B  for the reference's binary32 result d  (derivation: DESIGN.md 5.3b)
+//   * stored sum  s = OFF + rterm + sum_p slab_p  (OFF = A_up + E >= what keeps s positive)
+//   * | (s - OFF + |r|^2) - d | <= 248 u B  for the reference's binary32 result d  (derivation: DESIGN.md 5.3b)
 //   * d_lo = max(0, s - SHIFT) <= d <= d_lo + E
 // Selection keeps every row with s <= tau + E (tau = the L-th column minimum, as in fused3.h): that
 // set contains every row whose exact distance is <= the L-th smallest exact distance of the item,
-// ties included.  Survivors carry (d_lo, row location); merge_refine_kernel (one wave per query)
+// ties included.  Survivors carry (d_lo, row location); merge_refine_kernel (four waves per query)
 // finds T = (L-th smallest d_lo) + E, recomputes the reference's distance -- sequential binary32
 // squareDistance per position, positions added in order (index_utils.c:500-508, :1126-1133) -- for
 // the rows with d_lo <= T only (typically L + 1 of ~130 survivors), and runs the same 2k-smallest
