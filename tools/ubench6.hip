@@ -67,7 +67,16 @@ __global__ __launch_bounds__(1024) void gather_kernel(const uint32_t* codes, flo
 int main() {
   const int nb = 256, iters = 1200;
   uint32_t* h = (uint32_t*)malloc(nb * 1024 * 8 * 4);
-  for (int i = 0; i < nb * 1024 * 8; ++i) h[i] = (uint32_t)rand() ^ ((uint32_t)rand() << 16);
+  const int arrange = getenv("ARRANGE") ? atoi(getenv("ARRANGE")) : 0;   // g: lanes of every g-lane group get distinct (code mod 16)... residues
+  for (int i = 0; i < nb * 1024 * 8; ++i) {
+    uint32_t lo = rand() & 1023, hi = rand() & 1023;
+    if (arrange) {
+      const int lane = (i / 8) & 63;
+      const int res = (lane % arrange) % 16;
+      lo = (lo & ~15u) | res; hi = (hi & ~15u) | res;
+    }
+    h[i] = lo | (hi << 16);
+  }
   uint32_t* d; float* o; long long* c;
   hipMalloc(&d, nb * 1024 * 8 * 4); hipMalloc(&o, nb * 1024 * 4); hipMalloc(&c, nb * 8);
   hipMemcpy(d, h, nb * 1024 * 8 * 4, hipMemcpyHostToDevice);
