@@ -316,18 +316,16 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int g = 0; g < G; ++g) qw[u][g] = 0u;
-    // request the table values of position p of an entry (cell, nq item quads, query ids)
+    // request the query-table values of position p for an entry's 12 item slots (their query ids)
     // (scalar base of the item's [M][512] block + one 32-bit lane offset per position: one instruction per
     // load; the 64-bit multiply-adds hipcc otherwise emits per load are quarter rate)
     typedef const char __attribute__((address_space(1))) * gptrc;
     typedef const uint32_t __attribute__((address_space(1))) * gptru;
-    auto issue = [&](int buf, int p, int cell, int nq, const int (&qids)[G]) {
-      (void)cell;
+    auto issue = [&](int buf, int p, const int (&qids)[G]) {
       uint32_t voff = vq + (uint32_t)p * 2048u;
       asm volatile("" : "+v"(voff));   // opaque: keeps per-load 64-bit addresses from being materialised
       // (all 12 slots, also the unused ones -- they repeat item 0 and hit the L1: a STATIC number of loads
       // lets the compiler wait for the set that is two phases old and no younger one)
-      (void)nq;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[g] * (size_t)(M * 2048);
@@ -359,7 +357,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
     if (a.prof) pc = clock64();
     int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 3) >> 2;
-    int cell = __builtin_amdgcn_readfirstlane(dsc[0]);
     int qid[G], nqid[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { qid[g] = __builtin_amdgcn_readfirstlane(dsc[24 + g]); nqid[g] = qid[g]; }
@@ -379,9 +376,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     };
     fetch_row_terms(dsc);
     stash_row_terms();
-    issue(0, 0, cell, nq, qid);
-    issue(1, 1, cell, nq, qid);
-    issue(2, 2, cell, nq, qid);
+    issue(0, 0, qid);
+    issue(1, 1, qid);
+    issue(2, 2, qid);
     emit(0, slab, nq, dsc + 128);
     lds_barrier();
     for (;;) {
@@ -389,8 +386,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       const int ngid = __builtin_amdgcn_readfirstlane(gidq[(ei + 1) & 1]);
       const bool have_next = ngid < n_work;
       int gid2 = 0;   // (thread 0) the entry after the next
-      int next_nq = 0, next_cell = 0;
-      int32_t rr0 = 0, rr1 = 0;   // wave 0/1: the next entry's record on its way to LDS
+      int next_nq = 0;
+      int32_t rr0 = 0;   // (threads < REC_DW) the next entry's record on its way to LDS
 #pragma unroll
       for (int p = 0; p < M; ++p) {
         // the next entry's record: requested in P(0), stored in P(2), first read in P(M-3)
@@ -404,15 +401,14 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         else emit(0, slab, next_nq, dsc + nb * REC_DW + 128);
         // request position p+3
         if (p + 3 < M) {
-          issue(p % 3, p + 3, cell, nq, qid);
+          issue(p % 3, p + 3, qid);
         } else {
           if (p + 3 == M) {
             next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 3) >> 2 : 0;
-            next_cell = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 0]) : cell;
 #pragma unroll
             for (int g = 0; g < G; ++g) nqid[g] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g]) : qid[g];
           }
-          issue(p % 3, p + 3 - M, next_cell, next_nq, nqid);
+          issue(p % 3, p + 3 - M, nqid);
         }
         // the next entry's row terms: requested in P(4) (its record is in LDS since P(2)), staged in P(7) --
         // the gatherers read the current entry's before P(0)
@@ -428,12 +424,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       lds_barrier();   // S2
       tick(3);
       pt[7] += 1;
-      (void)rr1;
       if (!have_next) break;
       cur = nb;
       ++ei;
       nq = next_nq;
-      cell = next_cell;
 #pragma unroll
       for (int g = 0; g < G; ++g) qid[g] = nqid[g];
     }
