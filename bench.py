@@ -190,7 +190,10 @@ def main():
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "avg_launch_us": round(avg_s * 1e6, 2)}
+                    "avg_launch_us": round(avg_s * 1e6, 2),
+                    "note": "achieved = SURVEY 8d algorithmic bytes (every probed row's 28 B once per QUERY) / the scan "
+                            "kernel's duration; the kernel reads a list once per CELL entry (traffic = 2*FETCH_SIZE + "
+                            "WRITE_SIZE of the committed PMC passes), so achieved can exceed what crosses HBM"}
 
         # ---- recall@5 vs exact search, and parity of a sample against the oracle ---------------
         recall = None
