@@ -14,7 +14,7 @@
 // needed as a bound (the coarse distance the probe plan
 // already has).  With u = 2^-24, B = sum_p (|q_p| + max|co_p| + max|c_p|)^2 and E = 2048 u B:
 //   * stored sum  s = OFF + rterm + sum_p slab_p  (OFF = A_up + E >= what keeps s positive)
-//   * | (s - OFF + |r|^2) - d | <= 248 u B  for the reference's binary32 result d  (derivation: DESIGN.md 5.3b)
+//   * | (s - OFF + |r|^2) - d | <= 264 u B  for the reference's binary32 result d  (derivation: DESIGN.md 5.3b)
 //   * d_lo = max(0, s - SHIFT) <= d <= d_lo + E
 // Selection keeps every row with s <= tau + E (tau = the L-th column minimum, as in fused3.h): that
 // set contains every row whose exact distance is <= the L-th smallest exact distance of the item,
