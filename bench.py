@@ -150,6 +150,7 @@ def main():
     step()      # leave this rank's final results in d_res2[0] (= d_ids / d_dist below)
     barrier()
     scanned_rows = index.last_scanned_rows()
+    bound_violations = index.bound_violations()   # self-check of the filter + refine scan (must be 0)
     straggler = int(d_status[0].item())
 
     # ---- the same batch through the synchronous host-buffer ABI (H2D of queries, D2H of results,
@@ -238,6 +239,7 @@ def main():
                        "batch_per_gpu": a.Q, "parallelism": f"dp{world}"},
             "recall_at_5": None if recall is None else round(recall, 4),
             "queries_needing_extra_round": straggler,
+            "filter_bound_violations": bound_violations,
             "host_buffer_abi_queries_per_s": None if host_qps is None else round(host_qps, 1),
             "roofline": roof, "kernels": kern, "cpu_baseline": cpu,
         }

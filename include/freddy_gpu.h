@@ -206,6 +206,11 @@ int freddy_gpu_profile_read(freddy_gpu_index_t* index, int32_t cap, char (*names
 int64_t freddy_gpu_index_bytes(const freddy_gpu_index_t* index);   /* HBM footprint of the pinned index */
 /* Sum of list lengths the last ivfadc call scanned (all queries, all probes). */
 int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* index);
+/* Self-check of the filter + refine IVFADC scan: every row that reaches the exact stage
+ * has both its proven bracket [d_lo, d_lo + E] and the reference's distance d in hand; this returns how
+ * many such rows had d outside the bracket since the index was pinned (0 unless the error analysis is
+ * wrong for some input; <0 on a HIP error).  Synchronises the device. */
+int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* index);
 
 #ifdef __cplusplus
 }

@@ -106,6 +106,7 @@ struct freddy_gpu_index {
   float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
+  int32_t* viol = nullptr;      // [2] self-check counters of the exact stage
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
@@ -171,7 +172,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
   if (ix->ev_q) (void)hipEventDestroy(ix->ev_q);
   if (ix->ev_qc) (void)hipEventDestroy(ix->ev_qc);
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -418,7 +419,9 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
   if (!rc && ix->cbR) {   // one float per row slot: the (cell, row) part of the filter's cheap distance
     const int64_t n_slots = std::max<int64_t>(ix->n_blocks, 1) * 64;
-    if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess ||
+        hipMalloc((void**)&ix->viol, 2 * sizeof(int32_t)) != hipSuccess || hipMemset(ix->viol, 0, 2 * sizeof(int32_t)) != hipSuccess)
+      rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     if (!rc && ix->n_blocks > 0) {
       ix->bytes += (int64_t)sizeof(float) * n_slots;
       hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((ix->n_blocks * 64 + 255) / 256)), dim3(256), 0, ix->stream, ix->packed,
@@ -466,6 +469,15 @@ extern "C" int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* ix) {
   int64_t sum = 0;
   for (int32_t r : rows) if (r > 0) sum += r;
   return sum;
+}
+
+extern "C" int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* ix) {
+  if (!ix || !ix->viol) return 0;
+  int32_t h[2] = {0, 0};
+  if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(h, ix->viol, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+    return -1;
+  return h[0];
 }
 
 extern "C" int freddy_gpu_profile_enable(freddy_gpu_index_t* ix, int32_t enable) {
@@ -892,7 +904,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
         mr.surv = fa.surv; mr.surv_count = fa.surv_count; mr.active = active; mr.round_rows = pa.round_rows;
         mr.item_cell = pa.item_cell; mr.queries = d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
         mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
-        mr.cand_count = fa.cand_count; mr.out_ids = d_out_ids; mr.out_dist = d_out_dist;
+        mr.cand_count = fa.cand_count; mr.violations = ix->viol; mr.out_ids = d_out_ids; mr.out_dist = d_out_dist;
         mr.found = ix->w_found.as<int32_t>(); mr.next_active = next; mr.n_next = ix->w_cnt.as<int32_t>();
         mr.status = d_status;
         mr.n_active = n_active; mr.W = W; mr.upi = upi; mr.L = L; mr.k = k; mr.found_rule = found_rule;

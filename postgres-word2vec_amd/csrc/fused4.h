@@ -650,6 +650,7 @@ struct MergeRefineArgs {
   const int32_t* pos;
   const int32_t* blk_cell;     // [blocks] list (cell) of every row block
   int32_t* cand_count;
+  int32_t* violations;         // [2] rows of the exact stage whose distance left the bracket [d_lo, d_lo + E] / rows checked
   int32_t* out_ids;
   float* out_dist;
   int32_t* found;
@@ -818,6 +819,10 @@ __global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a)
       for (int p = 0; p < M; ++p) dsum = dsum + lutv[lane * M + p];       // index_utils.c:1126-1133
       const uint32_t lo = (uint32_t)cq_key[lane];
       const int32_t pid = a.pos[lo & 0x7fffffffu];
+      {   // self-check of the bound (freddy_gpu_filter_bound_violations)
+        const float dlo = __uint_as_float((uint32_t)(cq_key[lane] >> 32));
+        if (E < 1e20f && (dsum < dlo || dsum > dlo + E)) atomicAdd(a.violations, 1);
+      }
       if (dsum < a.sentinel) {
         out_key = ((u64)__float_as_uint(dsum) << 32) | (u64)(uint32_t)pid;
         if (lo & 0x80000000u) amb_accepted += 1;

@@ -435,6 +435,7 @@ def test_filter_refine_many_equal_distances(gpu, oracle, monkeypatch):
         gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"equal distances k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0, "a refined row's distance left its proven bracket"
     idx.close()
 
 
@@ -451,6 +452,7 @@ def test_filter_refine_sentinel_inside_the_data(gpu, oracle, monkeypatch):
             gi, gd = idx.search(qs, 8, 2, sentinel=sent, found_rule=rule)
             exp = oracle.ivfadc_search_many(ot, qs, 8, 2, sentinel=sent, found_rule=rule)
             util.assert_same_lists(gi, gd, exp, f"sentinel {sent!r} rule={rule}")
+    assert idx.bound_violations() == 0, "a refined row's distance left its proven bracket"
     idx.close()
 
 
@@ -464,6 +466,7 @@ def test_filter_refine_scaled_data(gpu, oracle, scale, monkeypatch):
         gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"scale {scale} k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0, "a refined row's distance left its proven bracket"
     idx.close()
 
 
@@ -477,4 +480,5 @@ def test_filter_refine_overflowing_bound(gpu, oracle, monkeypatch):
     gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
     exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
     util.assert_same_lists(gi, gd, exp, "overflowing bound")
+    assert idx.bound_violations() == 0, "a refined row's distance left its proven bracket"
     idx.close()
