@@ -211,6 +211,9 @@ int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* index);
  * many such rows had d outside the bracket since the index was pinned (0 unless the error analysis is
  * wrong for some input; <0 on a HIP error).  Synchronises the device. */
 int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* index);
+/* How many rows that check has seen -- counted only in the tests' refine-every-row mode
+ * (FREDDY_GPU_MERGE_ABLATE=32), where it is the number of probed rows; 0 otherwise. */
+int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* index);
 
 #ifdef __cplusplus
 }

@@ -471,14 +471,16 @@ extern "C" int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* ix) {
   return sum;
 }
 
-extern "C" int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* ix) {
+static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
   if (!ix || !ix->viol) return 0;
   int32_t h[2] = {0, 0};
   if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(h, ix->viol, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
-  return h[0];
+  return h[which];
 }
+extern "C" int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* ix) { return read_viol(ix, 0); }
+extern "C" int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* ix) { return read_viol(ix, 1); }
 
 extern "C" int freddy_gpu_profile_enable(freddy_gpu_index_t* ix, int32_t enable) {
   if (!ix) return fail(FREDDY_E_ARG, "NULL index");

@@ -560,8 +560,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
           wave_sort32_x2(c0, c1);
           const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
           if (lane == 0) {
-            thr_s[g0] = widen_threshold(t0, __int_as_float(rec[56 + g0]));
-            thr_s[g1] = widen_threshold(t1, __int_as_float(rec[56 + g1]));
+            // (ablate & 8, tests only: keep EVERY row, so that the exact stage -- and its self-check of the
+            // bracket -- sees all of them)
+            thr_s[g0] = (a.ablate & 8) ? 0xfffffffeu : widen_threshold(t0, __int_as_float(rec[56 + g0]));
+            thr_s[g1] = (a.ablate & 8) ? 0xfffffffeu : widen_threshold(t1, __int_as_float(rec[56 + g1]));
           }
           colmin[g0 * 64 + lane] = 0xffffffffu;
           colmin[g1 * 64 + lane] = 0xffffffffu;
@@ -802,7 +804,7 @@ __global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a)
   uint32_t T_bits;
   {
     const u64 kth = wave_topk_at<1>(sel.acc, a.L - 1);
-    T_bits = (kth == KEY_INF) ? 0xfffffffeu : widen_threshold((uint32_t)(kth >> 32), E);
+    T_bits = (kth == KEY_INF || (a.ablate & 32)) ? 0xfffffffeu : widen_threshold((uint32_t)(kth >> 32), E);   // (32: tests, every row)
   }
   __builtin_amdgcn_wave_barrier();
 
@@ -822,6 +824,7 @@ __global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a)
       {   // self-check of the bound (freddy_gpu_filter_bound_violations)
         const float dlo = __uint_as_float((uint32_t)(cq_key[lane] >> 32));
         if (E < 1e20f && (dsum < dlo || dsum > dlo + E)) atomicAdd(a.violations, 1);
+        if (a.ablate & 32) atomicAdd(a.violations + 1, 1);
       }
       if (dsum < a.sentinel) {
         out_key = ((u64)__float_as_uint(dsum) << 32) | (u64)(uint32_t)pid;

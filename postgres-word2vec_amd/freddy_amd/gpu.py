@@ -21,7 +21,7 @@ EXPORTS = [
     "freddy_gpu_pq_search", "freddy_gpu_ivfadc_search", "freddy_gpu_knn_join",
     "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
-    "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
+    "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_filter_bound_checked", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
     "freddy_gpu_encode",
 ]
 
@@ -81,6 +81,8 @@ def load():
     lib.freddy_gpu_last_scanned_rows.argtypes = [C.c_void_p]
     lib.freddy_gpu_filter_bound_violations.restype = C.c_int64
     lib.freddy_gpu_filter_bound_violations.argtypes = [C.c_void_p]
+    lib.freddy_gpu_filter_bound_checked.restype = C.c_int64
+    lib.freddy_gpu_filter_bound_checked.argtypes = [C.c_void_p]
     lib.freddy_gpu_pin_pq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivpq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -262,6 +264,9 @@ class IVFIndex(_Index):
     def bound_violations(self):
         """Rows of the filter + refine scan's exact stage whose distance left the proven bracket (must be 0)."""
         return int(self.lib.freddy_gpu_filter_bound_violations(self.h))
+
+    def bound_checked(self):
+        return int(self.lib.freddy_gpu_filter_bound_checked(self.h))
 
 
 class IVPQIndex(_Index):

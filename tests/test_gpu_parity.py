@@ -482,3 +482,21 @@ def test_filter_refine_overflowing_bound(gpu, oracle, monkeypatch):
     util.assert_same_lists(gi, gd, exp, "overflowing bound")
     assert idx.bound_violations() == 0, "a refined row's distance left its proven bracket"
     idx.close()
+
+
+def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
+    """Debug switches make the scan keep EVERY probed row and the merge refine every one of them, so the
+    kernel's self-check compares the proven bracket [d_lo, d_lo + E] with the reference's distance for all
+    rows, not only for the few a normal run refines.  Results must not change either."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    monkeypatch.setenv("FREDDY_GPU_FUSED_ABLATE", "8")
+    monkeypatch.setenv("FREDDY_GPU_MERGE_ABLATE", "32")
+    for scale in (1.0, 1e-12, 8.0):   # (x8: coarse distances stay below the probe plan's limit of 100)
+        t, ot, idx, qs = _fr_setup(gpu, oracle, scale=scale)
+        qs = qs[:48]
+        gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
+        exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"every row refined, scale {scale}")
+        assert idx.bound_checked() > 20000, f"scale {scale}: {idx.bound_checked()} brackets checked"   # every probed row ...
+        assert idx.bound_violations() == 0             # ... and none was violated
+        idx.close()
