@@ -106,7 +106,8 @@ __device__ __forceinline__ uint32_t widen_threshold(uint32_t tau_bits, float E) 
 // position): |value| <= 2 |q_p| max|c_p| = 32767 * scale, so the quantisation error is <= scale / 2
 // -- an ABSOLUTE bound that fits the budget E (a 16-bit float's relative error would not).  The table
 // is what the scan streams per (query, cell) item, so its width is the scan's memory traffic.
-// Layout [q][p][512] dwords: low half = code b, high half = code b + 512 (the builder lane's two codes).
+// Layout [q][p][512] dwords: low half = code b, high half = code b + 512, pair b at dword 4 (b mod 128) + b / 128
+// (a builder lane's four code pairs are one 16-byte load).
 // Also writes qn[q][p] = |q_p| (rounded up) and qscale[q][p].  Thread <-> code pair, QT queries per
 // workgroup through LDS.
 // ---------------------------------------------------------------------------------------
@@ -170,7 +171,9 @@ __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __rest
       const float inv = inv_s[qi + w];
       const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w].x * inv), -32767.0f), 32767.0f);
       const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w].y * inv), -32767.0f), 32767.0f);
-      if (qi + w < nq && b < 512) qc[((size_t)(q0 + qi + w) * m + p) * 512 + b] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+      // (dword 4 * (b mod 128) + b / 128: the scan's builder lane li loads pairs li, li+128, li+256, li+384 at once)
+      if (qi + w < nq && b < 512)
+        qc[((size_t)(q0 + qi + w) * m + p) * 512 + 4 * (b & 127) + (b >> 7)] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
     }
   }
 }
@@ -303,53 +306,60 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
 
   if (builder) {
     // =====================================================================================
-    // BUILDERS: lane <-> codes b and b+512
+    // BUILDERS: a pair of waves per item quad (waves 6-7 only stage records and row terms); lane li of
+    // the pair <-> the code pairs li, li+128, li+256, li+384 (a pair = codes b and b+512) -- the qc table
+    // is laid out so that these are the four dwords of ONE 16-byte load: a dword load moves 256 bytes per
+    // wave-level instruction and the CU's address unit takes about as long for it as for 1 KB, which is
+    // what bounded the builders (12 dword loads per lane and phase: ~1.4 k cycles per phase for the CU)
     // =====================================================================================
-    const int b = tid;
-    const bool ok0 = FULLK || b < K, ok1 = FULLK || b + 512 < K;
-    const uint32_t vq = (uint32_t)b * 4u;   // this lane's dword of a [512] row of qc
+    const int grp = wave >> 1;                          // item quad of this wave pair
+    const bool has_quad = grp < G / 4;
+    const int li = (wave & 1) * 64 + lane;              // 0..127
+    const uint32_t vq = (uint32_t)li * 16u;             // this lane's 16 bytes of a [512]-dword row of qc
     // three register sets: position p+3 is requested while p+1 is written -- with one phase of lead the
-    // 26 KB a CU has in flight bound the table streams to ~3.4 TB/s chip-wide (latency ~2 us)
+    // bytes a CU has in flight bound the table stream to ~3.4 TB/s chip-wide (latency ~2 us)
     static_assert(M % 3 == 0, "register sets rotate with the position, also across entries");
-    uint32_t qw[3][G];
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    u4 qw[3][4];
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
-      for (int g = 0; g < G; ++g) qw[u][g] = 0u;
-    // request the query-table values of position p for an entry's 12 item slots (their query ids)
-    // (scalar base of the item's [M][512] block + one 32-bit lane offset per position: one instruction per
-    // load; the 64-bit multiply-adds hipcc otherwise emits per load are quarter rate)
+      for (int g = 0; g < 4; ++g) qw[u][g] = u4{0u, 0u, 0u, 0u};
+    // request the query-table values of position p for the quad's 4 item slots (their query ids): scalar
+    // base of the item's [M][512] block + one 32-bit lane offset per position.  Always all 4 slots (unused
+    // ones repeat item 0 and hit the L1): a STATIC number of loads lets the compiler wait for the set that
+    // is two phases old and no younger one.
     typedef const char __attribute__((address_space(1))) * gptrc;
-    typedef const uint32_t __attribute__((address_space(1))) * gptru;
-    auto issue = [&](int buf, int p, const int (&qids)[G]) {
+    typedef const u4 __attribute__((address_space(1))) * gptr4u;
+    auto issue = [&](int buf, int p, const int (&qids)[4]) {
+      if (!has_quad) return;
       uint32_t voff = vq + (uint32_t)p * 2048u;
       asm volatile("" : "+v"(voff));   // opaque: keeps per-load 64-bit addresses from being materialised
-      // (all 12 slots, also the unused ones -- they repeat item 0 and hit the L1: a STATIC number of loads
-      // lets the compiler wait for the set that is two phases old and no younger one)
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[g] * (size_t)(M * 2048);
-        qw[buf][g] = *(gptru)(qb + voff);
+      for (int u = 0; u < 4; ++u) {
+        const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[u] * (size_t)(M * 2048);
+        qw[buf][u] = *(gptr4u)(qb + voff);
       }
     };
-    // slab rows are [code][12 items]: one aligned 16-byte store per item quad and code; value = dt +
-    // scale * fixed-point qc (one fma).  sc = the entry record's scales of this position.
+    // slab rows are [code][12 items]: one aligned 16-byte store per item quad and code; value =
+    // scale * fixed-point qc.  sc = the entry record's scales of this position.  Store k of a lane goes to
+    // code li + 128 k: consecutive lanes, consecutive 48-byte rows (conflict-free).
     auto emit = [&](int buf, float* dst, int nq, const int32_t* sc) {
+      if (!has_quad || grp >= nq) return;
+      const float4 s4 = *reinterpret_cast<const float4*>(sc + grp * 4);
+      const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-      for (int gq = 0; gq < G / 4; ++gq) {
-        if (gq < nq) {
-          const float4 s4 = *reinterpret_cast<const float4*>(sc + gq * 4);
-          const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
-          float lo[4], hi[4];
+      for (int k = 0; k < 4; ++k) {
+        float lo[4], hi[4];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const uint32_t w = qw[buf][gq * 4 + u];
-            lo[u] = (float)((int32_t)(w << 16) >> 16) * ss[u];
-            hi[u] = (float)((int32_t)w >> 16) * ss[u];
-          }
-          if (ok0) *reinterpret_cast<float4*>(dst + b * G + gq * 4) = float4{lo[0], lo[1], lo[2], lo[3]};
-          if (ok1) *reinterpret_cast<float4*>(dst + (b + 512) * G + gq * 4) = float4{hi[0], hi[1], hi[2], hi[3]};
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t w = k == 0 ? qw[buf][u].x : k == 1 ? qw[buf][u].y : k == 2 ? qw[buf][u].z : qw[buf][u].w;
+          lo[u] = (float)((int32_t)(w << 16) >> 16) * ss[u];
+          hi[u] = (float)((int32_t)w >> 16) * ss[u];
         }
+        const int b = li + 128 * k;
+        if (FULLK || b < K) *reinterpret_cast<float4*>(dst + b * G + grp * 4) = float4{lo[0], lo[1], lo[2], lo[3]};
+        if (FULLK || b + 512 < K) *reinterpret_cast<float4*>(dst + (b + 512) * G + grp * 4) = float4{hi[0], hi[1], hi[2], hi[3]};
       }
     };
 
@@ -357,9 +367,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
     if (a.prof) pc = clock64();
     int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 3) >> 2;
-    int qid[G], nqid[G];
+    const int g0 = has_quad ? grp * 4 : 0;   // first item slot of this wave pair's quad
+    int qid[4], nqid[4];
 #pragma unroll
-    for (int g = 0; g < G; ++g) { qid[g] = __builtin_amdgcn_readfirstlane(dsc[24 + g]); nqid[g] = qid[g]; }
+    for (int u = 0; u < 4; ++u) { qid[u] = __builtin_amdgcn_readfirstlane(dsc[24 + g0 + u]); nqid[u] = qid[u]; }
     // row terms of an entry (record rc): builder wave w fetches what gatherer wave w's lanes start from
     float rtv[RMAX];
     auto fetch_row_terms = [&](const int32_t* rc) {
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
           if (p + 3 == M) {
             next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 3) >> 2 : 0;
 #pragma unroll
-            for (int g = 0; g < G; ++g) nqid[g] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g]) : qid[g];
+            for (int u = 0; u < 4; ++u) nqid[u] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g0 + u]) : qid[u];
           }
           issue(p % 3, p + 3 - M, nqid);
         }
@@ -429,7 +440,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
       ++ei;
       nq = next_nq;
 #pragma unroll
-      for (int g = 0; g < G; ++g) qid[g] = nqid[g];
+      for (int u = 0; u < 4; ++u) qid[u] = nqid[u];
     }
     if (a.prof && tid == 0) {
       for (int i = 0; i < 8; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];
