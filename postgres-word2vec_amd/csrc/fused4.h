@@ -332,7 +332,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     typedef const char __attribute__((address_space(1))) * gptrc;
     typedef const u4 __attribute__((address_space(1))) * gptr4u;
     auto issue = [&](int buf, int p, const int (&qids)[4]) {
-      if (!has_quad) return;
+      if (!has_quad || (a.ablate & 32)) return;
       uint32_t voff = vq + (uint32_t)p * 2048u;
       asm volatile("" : "+v"(voff));   // opaque: keeps per-load 64-bit addresses from being materialised
 #pragma unroll
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
     // scale * fixed-point qc.  sc = the entry record's scales of this position.  Store k of a lane goes to
     // code li + 128 k: consecutive lanes, consecutive 48-byte rows (conflict-free).
     auto emit = [&](int buf, float* dst, int nq, const int32_t* sc) {
-      if (!has_quad || grp >= nq) return;
+      if (!has_quad || grp >= nq || (a.ablate & 16)) return;
       const float4 s4 = *reinterpret_cast<const float4*>(sc + grp * 4);
       const float ss[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
