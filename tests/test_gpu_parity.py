@@ -500,3 +500,21 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
         assert idx.bound_checked() > 20000, f"scale {scale}: {idx.bound_checked()} brackets checked"   # every probed row ...
         assert idx.bound_violations() == 0             # ... and none was violated
         idx.close()
+
+
+@pytest.mark.parametrize("arrange", ["0", "1"])
+def test_row_order_inside_a_list_is_free(gpu, oracle, arrange, monkeypatch):
+    """The pin-time arrangement of the rows inside a list (against LDS bank conflicts in the scans) must
+    not be observable: same lists with it and without, on every scan path."""
+    monkeypatch.setenv("FREDDY_GPU_ARRANGE_ROWS", arrange)
+    t = util.ivf_tables(N=20000, C=32, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(20000, 150)
+    exp = oracle.ivfadc_search_many(ot, qs, 10, 3, sentinel=1000.0, found_rule=0)
+    for fused, variant in (("1", "4"), ("1", "3"), ("0", "4")):
+        monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
+        monkeypatch.setenv("FREDDY_GPU_FUSED_KERNEL", variant)
+        gi, gd = idx.search(qs, 10, 3, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"arrange={arrange} fused={fused} kernel={variant}")
+    idx.close()
