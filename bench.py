@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- batched IVFADC kNN throughput (BASELINE.json metric) on N MI355X.
 
-One "step" = one pass of the hot path over one batch of synthetic queries that are already
-resident in HBM: coarse distances (+ the query x codebook table on a side stream) -> probe plan (items
-bucketed by cell) -> work table -> entry records -> the filter kernel (bounded cheap distances from two
-streamed tables, LDS slabs, sums and survivor selection) -> merge with the exact stage
-(the reference's arithmetic for the rows that can matter) and the updateTopK replay
-(+ the asynchronous RCCL gather of the per-shard top-k when N > 1).  Results are checked bit for bit
-against the CPU oracle on the bench queries (cpu_baseline.parity_with_gpu_on_sample).
+One "step" = one pass of the hot path over one batch of synthetic queries that are already resident in
+HBM: coarse distances (+ the query x codebook table on a side stream) -> probe plan (items bucketed by
+cell) -> work table -> entry records -> the filter kernel (bounded cheap distances, LDS slabs, sums and
+survivor selection) -> merge with the exact stage (the reference's arithmetic for the rows
+that can matter) and the updateTopK replay (+ the asynchronous RCCL gather of the per-shard top-k when
+N > 1).  Results are checked bit for bit against the CPU oracle on the bench queries
+(cpu_baseline.parity_with_gpu_on_sample).
 
-Workload (BASELINE.json configs[2]): 3,000,000 x 300-d synthetic GoogleNews-shaped corpus,
-C=1000 coarse cells, m=12, K=1024 residual PQ, nprobe W=10, k=5, 1024 queries per GPU
-(replicated index, queries sharded by rank -> "weak" scaling).
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 3,000,000 x 300-d synthetic
+GoogleNews-shaped corpus, C=1000 coarse cells, m=12, K=1024 residual PQ, nprobe W=10, k=5, 1024 queries per
+GPU (replicated index, queries sharded by rank -> "weak" scaling; --scaling strong splits ONE batch of --Q
+queries over the ranks).  --config pq / join time BASELINE configs[1] / configs[3] with the same JSON shape.
+
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts N ranks itself (a child
+`python -m torch.distributed.run`, before anything touches the GPU).  `--dry-run --backend gloo` runs the
+sharded step -- double-buffered asynchronous gather included -- on CPU tensors with a stand-in search, which
+is how the CPU test suite covers this file's N > 1 path.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
-  "roofline":     dominant kernel, algorithmic bytes / its HIP-event duration vs 8 TB/s HBM
+  "roofline":     the dominant kernel against the HBM roofline + the ceilings that actually bind (LDS gather)
   "cpu_baseline": the CPU oracle (oracle/, a port of the reference loops) on a bounded sample.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,16 +37,22 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "postgres-word2vec_amd")]
 
-HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+LDS_PEAK_GBS = 150000.0    # ibid. (LDS): ~150 TB/s aggregate for ds_read_b64 / b128 with every CU streaming
+METRIC = "batched IVFADC kNN queries/sec (k=5) + recall@5, 3Mx300d"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--N", type=int, default=3_000_000)
-    ap.add_argument("--Q", type=int, default=1024, help="queries per GPU per step")
+    ap.add_argument("--config", default="ivfadc", choices=["ivfadc", "pq", "join"],
+                    help="ivfadc = BASELINE configs[2] (the metric's), pq = configs[1], join = configs[3]")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --Q queries per GPU per step; strong: --Q queries per step in total")
+    ap.add_argument("--N", type=int, default=None)
+    ap.add_argument("--Q", type=int, default=None, help="queries per step (per GPU with weak scaling)")
     ap.add_argument("--C", type=int, default=1000)
     ap.add_argument("--m", type=int, default=12)
     ap.add_argument("--K", type=int, default=1024)
@@ -46,155 +60,262 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
-    return ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
+    ap.add_argument("--dry-run", action="store_true", help="CPU tensors + stand-in search: exercises the sharded step / gather only")
+    return ap.parse_args(argv)
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in single-GPU dry runs
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(a.backend, rank=rank, world_size=world)
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    from freddy_amd import gpu, index_build as ib
 
-    def log(*x):
-        if rank == 0:
-            print("[bench]", *x, file=sys.stderr, flush=True)
+def launch_ranks(a):
+    """--gpus N without a torchrun environment: start N ranks as children.  This process has not touched the
+    GPU (importing torch does not); it only waits and passes the children's exit code on."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
-    # ---- synthetic corpus + index (every rank builds the identical replica) -----------------
-    t0 = time.time()
-    x = ib.make_corpus(a.N, d=300, seed=20260101, device=dev)
-    tab = ib.build_ivf_index(x, C=a.C, m=a.m, K=a.K, train_size=100000, iters=10, seed=2)
-    log(f"corpus+index built in {time.time() - t0:.1f}s")
-    t0 = time.time()
-    index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=dev_index)
-    log(f"pinned {index.nbytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
 
-    # queries = indexed vectors themselves (ivfadc_batch_search takes ids), distinct per rank
-    rng = np.random.default_rng(7 + rank)
-    qids = np.sort(rng.choice(np.arange(1, a.N + 1), size=a.Q, replace=False)).astype(np.int64)
-    d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
-    # ids and distances of the shard live in ONE buffer so that the per-shard top-k crosses xGMI
-    # in a single RCCL all_gather (the payload is 40 KB per rank: pure latency).  Two such buffers
-    # alternate: the gather of step i is asynchronous and only has to be finished before its buffers are
-    # reused by step i+2, so its latency hides under the next step's kernels instead of adding to them.
-    d_res2 = [torch.empty((2, a.Q, a.k), dtype=torch.int32, device=dev) for _ in range(2)]
-    d_res = d_res2[0]
-    d_ids = d_res[0]
-    d_dist = d_res[1].view(torch.float32)
-    d_status = torch.zeros(4, dtype=torch.int32, device=dev)
-    g_res2 = [torch.empty((world, 2, a.Q, a.k), dtype=torch.int32, device=dev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
-    step_no = [0]
+def log(rank, *x):
+    if rank == 0:
+        print("[bench]", *x, file=sys.stderr, flush=True)
 
-    stream = torch.cuda.current_stream(dev)
 
-    def step():
-        b = step_no[0] & 1
-        step_no[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()
-            pending[b] = None
-        res = d_res2[b]
-        index.search_dev(d_q.data_ptr(), a.Q, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
-                         res[1].data_ptr(), d_status.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            pending[b] = dist.all_gather_into_tensor(g_res2[b].view(-1), res.view(-1), async_op=True)
+def fill_pattern(res, rank, step):
+    """Stand-in search of the dry run: a (rank, step) dependent pattern in the [2][q][k] result buffer."""
+    n = res[0].numel()
+    base = torch.arange(n, dtype=torch.int32, device=res.device).view(res[0].shape)
+    res[0].copy_(base + (rank * 1_000_003 + step * 7919))
+    res[1].copy_(base * 3 + (rank * 17 + step))
+
+
+def sharded_steps(step_fn, pg, steps, warmup, sync, world):
+    """warmup + exactly `steps` timed steps, bracketed by drain + barrier + device sync on both sides;
+    returns the MAX over ranks of the elapsed seconds."""
+    import torch.distributed as dist
 
     def barrier():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
-        torch.cuda.synchronize(dev)
+        pg.drain()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        sync()
 
-    for _ in range(a.warmup):
-        step()
+    for _ in range(warmup):
+        step_fn()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    for _ in range(steps):
+        step_fn()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
+        dev = pg.res[0].device
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    qps = world * a.Q * a.steps / dt
+    return dt, barrier
 
-    # ---- per-kernel durations with HIP events on the launch stream (instrumented re-run) ----
-    index.profile_enable(True)
-    for _ in range(a.steps):
+
+def verify_gather(pg, rank, world):
+    """The gathered buffer of the last step must hold every rank's own result: slot `rank` equals the local
+    buffer, and every slot's checksum equals the checksum its owner reports."""
+    import torch.distributed as dist
+    if world == 1:
+        return True
+    local, gathered = pg.last()
+    ok = bool(torch.equal(gathered[rank], local))
+    mine = local.to(torch.int64).sum().view(1)
+    sums = torch.zeros(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(sums, mine)
+    got = gathered.to(torch.int64).sum(dim=(1, 2, 3))
+    ok = ok and bool(torch.equal(got, sums))
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=local.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+def run_dry(a, rank, world):
+    """The N > 1 path of this file on CPU tensors (gloo): sharding, the double-buffered asynchronous gather,
+    the timing brackets and the JSON line -- with fill_pattern() where the HIP search would be."""
+    import torch.distributed as dist
+    from freddy_amd import shard
+    Q = a.Q or 1024
+    q_local = Q if a.scaling == "weak" else shard.shard_bounds(Q, rank, world)[1] - shard.shard_bounds(Q, rank, world)[0]
+    if a.scaling == "strong" and Q % world:
+        raise SystemExit("--scaling strong needs --Q divisible by the number of ranks")
+    pg = shard.PipelinedGather(q_local, a.k, torch.device("cpu"))
+    n = [0]
+
+    def step():
+        res = pg.next_buffer()
+        fill_pattern(res, rank, n[0])
+        n[0] += 1
+        pg.submit()
+
+    dt, _ = sharded_steps(step, pg, a.steps, a.warmup, lambda: None, world)
+    ok = verify_gather(pg, rank, world)
+    if world > 1:   # every slot must hold ITS rank's pattern of the last step
+        _, gathered = pg.last()
+        for r in range(world):
+            exp = torch.empty_like(gathered[r])
+            fill_pattern(exp, r, n[0] - 1)
+            ok = ok and bool(torch.equal(gathered[r], exp))
+    total_q = q_local * world if a.scaling == "weak" else Q
+    out = {"metric": METRIC, "value": round(total_q * a.steps / dt, 1), "unit": "queries/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
+           "scaling": a.scaling, "vs_baseline": None, "dtype": "none (dry run)", "data": "synthetic",
+           "config": {"workload": "DRY RUN: stand-in search on CPU tensors, gloo", "batch_per_gpu": q_local,
+                      "parallelism": f"dp{world}"},
+           "dry_run": True, "gather_verified": ok, "roofline": None, "cpu_baseline": None}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0 if ok else 1
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/latest_pmc.json, written by tools/profile_round.sh): 2 x FETCH_SIZE (gfx950 reports half of
+    wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  None if there is no such record."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        if kernel in pmc:
+            return int((2 * pmc[kernel].get("fetch_kib", 0) + pmc[kernel].get("write_kib", 0)) * 1024)
+    except Exception:
+        pass
+    return None
+
+
+def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
+    ach = algorithmic_bytes / avg_s / 1e9
+    r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+         "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc passes of this command, 2*FETCH_SIZE + WRITE_SIZE)",
+         "algorithmic_bytes_per_launch": int(algorithmic_bytes), "algorithmic_model": model,
+         "avg_launch_us": round(avg_s * 1e6, 2)}
+    if traffic:
+        r["hbm_counter"] = {"achieved": round(traffic / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 5),
+                            "note": "counter traffic / kernel time; the counters include Infinity-Cache hits"}
+    if extra:
+        r.update(extra)
+    return r
+
+
+# ---------------------------------------------------------------------------------------------------
+# config ivfadc (BASELINE configs[2]; with --gpus N: configs[4])
+# ---------------------------------------------------------------------------------------------------
+def run_ivfadc(a, rank, world, dev, dev_index):
+    import torch.distributed as dist
+    from freddy_amd import gpu, shard, index_build as ib
+    N = a.N or 3_000_000
+    Q = a.Q or 1024
+    if a.scaling == "strong":
+        if Q % world:
+            raise SystemExit("--scaling strong needs --Q divisible by the number of ranks")
+        q_local = Q // world
+    else:
+        q_local = Q
+    t0 = time.time()
+    x = ib.make_corpus(N, d=300, seed=20260101, device=dev)
+    tab = ib.build_ivf_index(x, C=a.C, m=a.m, K=a.K, train_size=100000, iters=10, seed=2)
+    log(rank, f"corpus+index built in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=dev_index)
+    log(rank, f"pinned {index.nbytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
+
+    # queries = indexed vectors themselves (ivfadc_batch_search takes ids), distinct per rank
+    rng = np.random.default_rng(7 + rank)
+    qids = np.sort(rng.choice(np.arange(1, N + 1), size=q_local, replace=False)).astype(np.int64)
+    d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
+    d_status = torch.zeros(4, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize(dev)
+    # Everything of a step -- the search kernels (through the C ABI, on this stream's handle) and the RCCL
+    # gather -- is ordered on ONE explicit non-default stream, so the collective reads a shard's results
+    # only after the search wrote them and the buffer is rewritten only after the collective read it.
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        pg = shard.PipelinedGather(q_local, a.k, dev)
+
+        def step():
+            res = pg.next_buffer()
+            index.search_dev(d_q.data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
+                             res[1].data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+            pg.submit()
+
+        dt, barrier = sharded_steps(step, pg, a.steps, a.warmup, lambda: torch.cuda.synchronize(dev), world)
+        qps = world * q_local * a.steps / dt
+        gather_ok = verify_gather(pg, rank, world)
+
+        # ---- per-kernel durations with HIP events on the launch stream (instrumented re-run) ----
+        index.profile_enable(True)
+        for _ in range(a.steps):
+            step()
+        barrier()
+        prof = index.profile_read()
+        index.profile_enable(False)
         step()
-    barrier()
-    prof = index.profile_read()
-    index.profile_enable(False)
-    step_no[0] = 0
-    step()      # leave this rank's final results in d_res2[0] (= d_ids / d_dist below)
-    barrier()
+        barrier()
+        res_last, _ = pg.last()
+        d_ids, d_dist = res_last[0], res_last[1].view(torch.float32)
     scanned_rows = index.last_scanned_rows()
+    n_cells, cell_rows = index.last_probed_cells()
     bound_violations = index.bound_violations()   # self-check of the filter + refine scan (must be 0)
     straggler = int(d_status[0].item())
 
-    # ---- the same batch through the synchronous host-buffer ABI (H2D of queries, D2H of results,
-    # one stream sync per call): reported beside `value`, never as `value`
-    host_qps = None
-    if rank == 0:
-        h_q = d_q.cpu().numpy()
-        index.search(h_q, a.k, a.nprobe)
-        t0 = time.perf_counter()
-        for _ in range(10):
-            index.search(h_q, a.k, a.nprobe)
-        host_qps = 10 * a.Q / (time.perf_counter() - t0)
-
     out = None
     if rank == 0:
-        # algorithmic bytes per query: sum of probed list lengths * (m*2 + 4) + query + result
-        bytes_per_launch = scanned_rows * (a.m * 2 + 4) + a.Q * (300 * 4 + a.k * 8)
+        # ---- the same batch through the synchronous host-buffer ABI (H2D of queries, D2H of results, one
+        # stream sync per call, stragglers re-run): reported beside `value`, never as `value`
+        h_q = d_q.cpu().numpy()
+        hi, hd = index.search(h_q, a.k, a.nprobe)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            hi, hd = index.search(h_q, a.k, a.nprobe)
+        host_qps = 10 * q_local / (time.perf_counter() - t0)
+        host_same = bool(np.array_equal(hi, d_ids.cpu().numpy()) and
+                         np.array_equal(hd.view(np.uint32), d_dist.cpu().numpy().view(np.uint32)))
+
+        row_bytes = a.m * 2 + 4
+        per_query_bytes = scanned_rows * row_bytes + q_local * (300 * 4 + a.k * 8)          # SURVEY 8d, per query
+        shared = a.C * 300 * 4 + a.m * a.K * (300 // a.m) * 4                                # coarse + codebook, once
+        cell_bytes = cell_rows * row_bytes + q_local * (300 * 4 + a.k * 8) + shared           # every probed list ONCE
         kern = {n: {"launches": l, "avg_us": round(1e3 * ms / max(l, 1), 2)} for n, (l, ms) in prof.items()}
         dom = max(prof.items(), key=lambda kv: kv[1][1])[0] if prof else None
         roof = None
         if dom:
             avg_s = prof[dom][1] / max(prof[dom][0], 1) / 1e3
-            ach = bytes_per_launch / avg_s / 1e9
-            # HBM bytes of the dominant kernel from the committed rocprofv3 PMC passes of this same
-            # command (profiles/latest_pmc.json, written by tools/profile_round.sh): 2 x FETCH_SIZE
-            # (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KiB -> bytes.
-            traffic = None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
-                kname = {"ivf_fused": "ivf_filter_kernel", "adc_scan": "adc_scan_kernel", "lut_build": "lut_build_kernel",
-                         "coarse_dist": "coarse_tile_kernel", "probe_plan": "probe_plan_kernel"}.get(dom, dom)
-                if kname not in pmc and dom == "ivf_fused":   # FREDDY_GPU_FUSED_KERNEL=2 / 1
-                    kname = "ivf_spec_kernel" if "ivf_spec_kernel" in pmc else "ivf_fused_kernel"
-                if kname in pmc:
-                    traffic = int((2 * pmc[kname].get("fetch_kib", 0) + pmc[kname].get("write_kib", 0)) * 1024)
-            except Exception:
-                traffic = None
-            roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                    "avg_launch_us": round(avg_s * 1e6, 2),
-                    "note": "achieved = SURVEY 8d algorithmic bytes (every probed row's 28 B once per QUERY) / the scan "
-                            "kernel's duration; the kernel reads a list once per CELL entry (traffic = 2*FETCH_SIZE + "
-                            "WRITE_SIZE of the committed PMC passes), so achieved can exceed what crosses HBM"}
+            kname = {"ivf_filter": "ivf_filter_kernel", "ivf_exact_scan": "ivf_spec2_kernel", "adc_scan": "adc_scan_kernel",
+                     "lut_build": "lut_build_kernel", "coarse_dist": "coarse_tile_kernel",
+                     "probe_plan": "probe_plan_kernel"}.get(dom, dom)
+            lds_bytes = scanned_rows * a.m * 4   # one 4-byte table value per (query, probed row, position)
+            lds = lds_bytes / avg_s / 1e9
+            pq_ach = per_query_bytes / avg_s / 1e9
+            ceiling_qps = HBM_PEAK_GBS * 1e9 / (per_query_bytes / q_local)
+            roof = roofline(
+                kname, avg_s, cell_bytes,
+                "cell-grouped, as the reference's own loop (freddy.c:939-974 reads a probed cell's rows once per round and "
+                "offers each to every query of the cell): 28 B per row of every DISTINCT probed list + queries + results + "
+                "coarse and codebook tables once",
+                pmc_traffic(kname),
+                {"lds_gather": {"achieved": round(lds, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBS, 5),
+                                "bytes_per_launch": int(lds_bytes),
+                                "note": "the resource that binds this kernel: 4 B of slab per (query, probed row, position) "
+                                        "gathered from LDS at random 48-byte rows (~3-way bank conflicts, DESIGN.md 5.3b)"},
+                 "per_query_model": {"bytes_per_launch": int(per_query_bytes), "achieved": round(pq_ach, 1), "unit": "GB/s",
+                                     "note": "SURVEY 8d's per-QUERY bytes (every probed row once per query) / kernel time: an "
+                                             "equivalent rate, not traffic -- the kernel reads a list once per work entry",
+                                     "step_qps_ceiling_at_8TBs": round(ceiling_qps, 1),
+                                     "step_frac_of_ceiling": round(qps / world / ceiling_qps, 5)},
+                 "distinct_probed_cells": int(n_cells), "index_bytes": int(index.nbytes),
+                 "note": f"the {index.nbytes / 1e6:.0f} MB index is Infinity-Cache (256 MiB) resident after first touch; a "
+                         "non-resident corpus (N = 40 M) is measured in profiles/ (DESIGN.md 5.6)"})
 
         # ---- recall@5 vs exact search, and parity of a sample against the oracle ---------------
         recall = None
@@ -207,7 +328,7 @@ def main():
             from oracle.oracle import Oracle
             o = Oracle()
             ot = o.ivf_table(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"])
-            ns = min(a.cpu_sample, a.Q)
+            ns = min(a.cpu_sample, q_local)
             cores = os.cpu_count() or 1
             qs = d_q[:ns].cpu().numpy()
             t0 = time.perf_counter()
@@ -223,26 +344,208 @@ def main():
             one_core = n1 / (time.perf_counter() - t0)
             cpu = {"value": round(ns / cdt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
                    "value_1_core": round(one_core, 2),
-                   "sample": f"first {ns} of the {a.Q} bench queries, same index, nprobe={a.nprobe}, k={a.k}; "
-                             f"oracle/ (C port of freddy.c:174-393 loops, gcc -O2, OpenMP over queries)",
+                   "sample": f"first {ns} of the {q_local} bench queries, same index, nprobe={a.nprobe}, k={a.k}",
+                   "loop": "oracle/fo_ivfadc_search_many: per query the W-probe loop of ivfadc_search (freddy.c:174-393: W best "
+                           "cells, W LUTs, rows of the W lists merged by id, updateTopK), OpenMP over queries = one backend per "
+                           "core; gcc -O2 without -march=native (PGXS defaults).  SPI / tuple / per-call table reload cost of the "
+                           "real UDF is NOT included (README: ~0.01 s per query end to end)",
                    "parity_with_gpu_on_sample": parity}
 
         out = {
-            "metric": "batched IVFADC kNN queries/sec (k=5) + recall@5, 3Mx300d",
+            "metric": METRIC,
             "value": round(qps, 1), "unit": "queries/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": a.scaling,
+            "vs_baseline": None,
+            "dtype": "f32 (results: the reference's binary32 sub/mul/add chains; filter stage: int16 fixed-point table x f32 scale, f32 sums)",
+            "data": "synthetic",
             "config": {"workload": "IVFADC batch (ivfadc_batch_search generalised to nprobe), "
-                                   f"{a.N}x300d, C={a.C}, m={a.m}, K={a.K}, nprobe={a.nprobe}, k={a.k}, "
-                                   f"batch={a.Q} queries per GPU, replicated index, queries sharded by rank",
-                       "N": a.N, "d": 300, "C": a.C, "m": a.m, "K": a.K, "nprobe": a.nprobe, "k": a.k,
-                       "batch_per_gpu": a.Q, "parallelism": f"dp{world}"},
+                                   f"{N}x300d, C={a.C}, m={a.m}, K={a.K}, nprobe={a.nprobe}, k={a.k}, "
+                                   f"batch={q_local} queries per GPU, replicated index, queries sharded by rank",
+                       "N": N, "d": 300, "C": a.C, "m": a.m, "K": a.K, "nprobe": a.nprobe, "k": a.k,
+                       "batch_per_gpu": q_local, "parallelism": f"dp{world}"},
             "recall_at_5": None if recall is None else round(recall, 4),
             "queries_needing_extra_round": straggler,
             "filter_bound_violations": bound_violations,
-            "host_buffer_abi_queries_per_s": None if host_qps is None else round(host_qps, 1),
+            "gather_verified": gather_ok,
+            "host_buffer_abi": {"queries_per_s": round(host_qps, 1), "same_results_as_device_path": host_same,
+                                "note": "freddy_gpu_ivfadc_search: H2D of the queries, D2H of the results, one stream sync, "
+                                        "extra probing rounds for stragglers -- per call"},
             "roofline": roof, "kernels": kern, "cpu_baseline": cpu,
         }
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# config pq (BASELINE configs[1]): pq_search, 1M x 300d, m=12, K=1024, k=5
+# ---------------------------------------------------------------------------------------------------
+def run_pq(a, rank, world, dev, dev_index):
+    from freddy_amd import gpu, index_build as ib
+    N = a.N or 1_000_000
+    Q = a.Q or 64
+    x = ib.make_corpus(N, d=300, seed=11, device=dev)
+    tab = ib.build_pq_index(x, m=a.m, K=a.K, train_size=100000, iters=6, seed=1)
+    index = gpu.PQIndex(tab["codebook"], tab["ids"], tab["codes"], device=dev_index)
+    rng = np.random.default_rng(7 + rank)
+    qids = np.sort(rng.choice(np.arange(1, N + 1), size=Q, replace=False)).astype(np.int64)
+    d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
+    d_ids = torch.empty((Q, a.k), dtype=torch.int32, device=dev)
+    d_dist = torch.empty((Q, a.k), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize(dev)
+    stream = torch.cuda.Stream(dev)
+
+    def step():
+        index.search_dev(d_q.data_ptr(), Q, a.k, 100.0, d_ids.data_ptr(), d_dist.data_ptr(), stream.cuda_stream)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    index.profile_enable(True)
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    prof = index.profile_read()
+    index.profile_enable(False)
+    kern = {n: {"launches": l, "avg_us": round(1e3 * ms / max(l, 1), 2)} for n, (l, ms) in prof.items()}
+    avg_s = prof["adc_scan"][1] / max(prof["adc_scan"][0], 1) / 1e3
+    row_bytes = a.m * 2 + 4
+    once = N * row_bytes + Q * (a.m * a.K * 4 + 300 * 4 + a.k * 8)   # the table once + every query's LUT
+    per_query = Q * (N * row_bytes + a.m * a.K * 4)
+    roof = roofline("adc_scan_kernel", avg_s, once,
+                    "the code table once per batch (28 B per row) + one 48 KiB LUT, query and result per query",
+                    pmc_traffic("adc_scan_kernel"),
+                    {"per_query_model": {"bytes_per_launch": int(per_query), "achieved": round(per_query / avg_s / 1e9, 1), "unit": "GB/s",
+                                         "note": "SURVEY 8d: N*(m*2+4) = 28 MB per QUERY / kernel time; one workgroup per (query, "
+                                                 "chunk) re-reads the table from the caches for every query"},
+                     "lds_gather": {"achieved": round(Q * N * a.m * 4 / avg_s / 1e9, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(Q * N * a.m * 4 / avg_s / 1e9 / LDS_PEAK_GBS, 5)}})
+    from oracle.oracle import Oracle
+    o = Oracle()
+    ot = o.pq_table(tab["codebook"], tab["ids"], tab["codes"])
+    qs = d_q.cpu().numpy()
+    ns = min(Q, 32)
+    t0 = time.perf_counter()
+    exp = np.stack([o.pq_search(ot, q, a.k) for q in qs[:ns]])
+    cdt = time.perf_counter() - t0
+    parity = bool(np.array_equal(exp["id"], d_ids[:ns].cpu().numpy()) and
+                  np.array_equal(exp["dist"].view(np.uint32), d_dist[:ns].cpu().numpy().view(np.uint32)))
+    h_q = qs[:1]
+    index.search(h_q, a.k, sentinel=100.0)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        index.search(h_q, a.k, sentinel=100.0)
+    one_ms = (time.perf_counter() - t0) / 20 * 1e3
+    return {
+        "metric": "PQ search queries/sec (pq_search, k=5), 1Mx300d", "value": round(Q * a.steps / dt, 1), "unit": "queries/s",
+        "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PQ search (pq_search / knn_in_pq), {N}x300d, m={a.m}, K={a.K}, k={a.k}, batch={Q} queries",
+                   "N": N, "m": a.m, "K": a.K, "k": a.k, "batch": Q},
+        "single_query_host_abi_ms": round(one_ms, 4),
+        "roofline": roof, "kernels": kern,
+        "cpu_baseline": {"value": round(ns / cdt, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                         "sample": f"first {ns} bench queries, same table",
+                         "loop": "oracle/fo_pq_search (freddy.c:28-152: LUT, ADC over all rows, updateTopK), one thread; SPI excluded",
+                         "parity_with_gpu_on_sample": parity}}
+
+
+# ---------------------------------------------------------------------------------------------------
+# config join (BASELINE configs[3]): knn_join 5,000 x 100,000, k=5, alpha=100, pvf=20, method 2
+# ---------------------------------------------------------------------------------------------------
+def run_join(a, rank, world, dev, dev_index):
+    from freddy_amd import gpu, index_build as ib
+    N = a.N or 1_000_000
+    Q = a.Q or 5000
+    T = 100_000
+    x = ib.make_corpus(N, d=300, seed=5, device=dev)
+    t = ib.build_ivpq_index(x, m=30, K=32, k_coarse=32, train_size=100000, iters=6, seed=3)
+    index = gpu.IVPQIndex(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"], device=dev_index)
+    rng = np.random.default_rng(4)
+    qid = rng.choice(np.arange(1, N + 1), Q, replace=False)
+    targets = rng.choice(np.arange(1, N + 1), T, replace=False).astype(np.int32)
+    qs = t["vectors"][qid - 1]
+    alpha, pvf, method = 100, 20, 2
+    for _ in range(max(a.warmup, 1)):
+        gi, gd, it = index.knn_join(qs, a.k, targets, alpha, pvf, method)
+    track = None
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        gi, gd, it = index.knn_join(qs, a.k, targets, alpha, pvf, method)
+        tr = index.last_track()
+        track = tr if track is None else {n: track[n] + tr[n] for n in tr}
+    dt = time.perf_counter() - t0
+    track = {n: (v / a.steps) for n, v in track.items()}
+    kernel_s = track["join_kernel_time"]
+    rows = track["candidate_rows"]
+    alg = rows * (30 * 2 + 4) + Q * (a.k * pvf * 300 * 4 + 300 * 4 + a.k * 8)   # codes + ids, PV vectors, query, result
+    roof = roofline("join_query_kernel", kernel_s, alg,
+                    "SURVEY 8d: sum over queries of the target rows in their cells x (m*2+4) B + k*pvf PV vectors (1200 B each) + query + result",
+                    pmc_traffic("join_query_kernel"),
+                    {"candidate_rows_per_call": int(rows), "iterations": track["iterations"],
+                     "note": "the call is a host loop (alpha doubling, multi-index traversal in libm on the host cores): "
+                             "the kernel is " + f"{100 * kernel_s / (dt / a.steps):.0f} % of a call"})
+    from oracle.oracle import Oracle
+    o = Oracle()
+    ot = o.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    t0 = time.perf_counter()
+    exp, eit = o.ivpq_search_in(ot, qs, a.k, targets, alpha, pvf, method)
+    cdt = time.perf_counter() - t0
+    parity = bool(np.array_equal(exp["id"].reshape(gi.shape), gi) and
+                  np.array_equal(exp["dist"].reshape(gd.shape).view(np.uint32), gd.view(np.uint32)) and eit == it)
+    return {
+        "metric": "kNN-join queries/sec (ivpq_search_in, 5000 x 100000, k=5, alpha=100, pvf=20, method 2)",
+        "value": round(Q * a.steps / dt, 1), "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"knn_join (ivpq_search_in): {Q} queries x {T} targets of {N} rows, k={a.k}, alpha={alpha}, "
+                               f"pvf={pvf}, method=2, host-buffer ABI (one synchronous call per step)",
+                   "N": N, "Q": Q, "targets": T, "m": 30, "K": 32, "coarse": "2 x 32"},
+        "track": {n: (round(v, 6) if isinstance(v, float) else v) for n, v in track.items()},
+        "roofline": roof,
+        "cpu_baseline": {"value": round(Q / cdt, 2), "unit": "queries/s", "cores": 1, "kind": "port",
+                         "sample": f"the same call ({Q} queries, {T} targets), once",
+                         "loop": "oracle/fo_ivpq_search_in (ivpq_search_in.c:61-699), one thread; SPI / SQL string building excluded "
+                                 "(README: 2.7-20 s for this join end to end)",
+                         "parity_with_gpu_on_sample": parity}}
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if a.dry_run:
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU tensors: always gloo
+        sys.exit(run_dry(a, rank, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback); --dry-run --backend gloo exercises the "
+                         "sharded step on CPU")
+    dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in single-GPU dry runs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        if a.config != "ivfadc":
+            raise SystemExit("--config pq / join are single-GPU measurements")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
+    if a.config == "ivfadc":
+        out = run_ivfadc(a, rank, world, dev, dev_index)
+    elif a.config == "pq":
+        out = run_pq(a, rank, world, dev, dev_index)
+    else:
+        out = run_join(a, rank, world, dev, dev_index)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

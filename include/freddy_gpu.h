@@ -36,7 +36,10 @@ extern "C" {
 
 /* found_rule for freddy_gpu_ivfadc_search */
 #define FREDDY_FOUND_ROWS 0      /* ivfadc_search:       found += rows retrieved  (freddy.c:377) */
-#define FREDDY_FOUND_ACCEPTED 1  /* ivfadc_batch_search: found += insertions      (freddy.c:971) */
+#define FREDDY_FOUND_ACCEPTED 1  /* found += insertions (freddy.c:971) over ivfadc_search's cell choice */
+#define FREDDY_FOUND_BATCH_UDF 2 /* ivfadc_batch_search itself: found += insertions (freddy.c:971) AND its cell choice --
+                                  * argmin by strict "<" from minDist = 1000 (freddy.c:853-866), where ivfadc_search's cell
+                                  * list never admits a cell at distance >= 100 (freddy.c:266-283).  W must be 1. */
 
 /* calculationMethod, index_utils.h:111 */
 #define FREDDY_METHOD_PQ 0
@@ -112,7 +115,7 @@ int freddy_gpu_pq_search(freddy_gpu_index_t* pq, const float* queries, int32_t Q
                          int32_t* out_ids, float* out_dist);
 
 /* Body of ivfadc_search (freddy.c:174-393) for Q independent queries; with W == 1,
- * sentinel 100.0 and FREDDY_FOUND_ACCEPTED it is the body of ivfadc_batch_search
+ * sentinel 100.0 and FREDDY_FOUND_BATCH_UDF it is the body of ivfadc_batch_search
  * (freddy.c:679-999).  Each round probes the W nearest not-yet-used cells; rounds repeat
  * while found < k (found_rule).  out_*: [Q][k]. */
 int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ivf, const float* queries, int32_t Q, int32_t k,
@@ -191,6 +194,32 @@ int freddy_gpu_pq_search_dev(freddy_gpu_index_t* pq, const float* d_queries, int
 
 /* ---- diagnostics ------------------------------------------------------------------------ */
 
+/* Stage timers of the most recent freddy_gpu_knn_join call on this handle, in seconds, under the names the
+ * reference reports with elog(INFO, "TRACK <stage> %f") (ivpq_search_in.c:234-697; scraped off the
+ * connection by evaluation/tracking.py).  The PostgreSQL host re-emits them with the same elog lines. */
+typedef struct freddy_track {
+  double precomputation_time;                /* :294  here: coarse sub-distances + side sorts (the LUTs are built inside the join kernel) */
+  double determine_coarse_quantization_time; /* :341  multi-index traversal, summed over the alpha rounds */
+  double query_construction_time;            /* :397  per-query cell lists */
+  double data_retrieval_time;                /* :403  "fq.id IN (targets)": ids resolved and bucketed by cell on the device */
+  double computation_time;                   /* :632  the join kernel: ADC / exact distances, selection, replay */
+  double pv_computation_time;                /* :627  0: post verification happens inside the join kernel */
+  double recalculate_query_indices_time;     /* :671 */
+  double total_time;                         /* :697 */
+  double join_kernel_time;                   /* HIP-event time of the join kernel launches alone (inside computation_time) */
+  int64_t candidate_rows;                    /* sum over queries of the target rows in their selected cells (what the kernel scans) */
+  int32_t iterations;                        /* alpha-doubling rounds */
+  int32_t reserved;
+} freddy_track;
+int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
+
+/* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
+ * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (4 filter +
+ * refine, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
+ * row, used by the tests' exhaustive bound check), "side_stream", "fused_prof", "debug_surv",
+ * "lut_budget_mb".  No setting changes a result. */
+int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);
+
 /* Thread-local message of the last failing call; valid until the next call. */
 const char* freddy_gpu_last_error(void);
 
@@ -206,13 +235,16 @@ int freddy_gpu_profile_read(freddy_gpu_index_t* index, int32_t cap, char (*names
 int64_t freddy_gpu_index_bytes(const freddy_gpu_index_t* index);   /* HBM footprint of the pinned index */
 /* Sum of list lengths the last ivfadc call scanned (all queries, all probes). */
 int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* index);
+/* Distinct cells the last probing round touched (cell-grouped scans) and the rows of their lists: the bytes a
+ * scan that reads every probed list once per batch must move, as the reference's loop does (freddy.c:939-974). */
+int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* index, int64_t* n_cells, int64_t* rows);
 /* Self-check of the filter + refine IVFADC scan: every row that reaches the exact stage
  * has both its proven bracket [d_lo, d_lo + E] and the reference's distance d in hand; this returns how
  * many such rows had d outside the bracket since the index was pinned (0 unless the error analysis is
  * wrong for some input; <0 on a HIP error).  Synchronises the device. */
 int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* index);
 /* How many rows that check has seen -- counted only in the tests' refine-every-row mode
- * (FREDDY_GPU_MERGE_ABLATE=32), where it is the number of probed rows; 0 otherwise. */
+ * (option merge_ablate = 32), where it is the number of probed rows; 0 otherwise. */
 int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* index);
 
 #ifdef __cplusplus

@@ -18,12 +18,12 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "kernels.h"
-#include "fused.h"
-#include "fused2.h"
+#include "scan_common.h"
 #include "fused3.h"
 #include "fused4.h"
 #include "exact.h"
@@ -59,6 +59,40 @@ extern "C" const char* freddy_gpu_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------
 enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3, KIND_VEC = 4 };
 
+// Tuning / debug switches.  Read from the environment ONCE, when an index is pinned (never on the search
+// path); freddy_gpu_set_option changes them on a pinned index (tests and tools).  None of them is needed
+// for results: every setting gives the same lists.
+struct Tuning {
+  int fused = -1;              // FREDDY_GPU_FUSED: -1 auto (cell-grouped scans for >= 256 items), 0 generic kernels, 1 always
+  int scan_kernel = 4;         // FREDDY_GPU_FUSED_KERNEL: 4 filter + refine (fused4.h), 3 exact fused scan (fused3.h)
+  uint32_t scan_ablate = 0;    // FREDDY_GPU_FUSED_ABLATE: timing experiments / 8 = keep every row (tests)
+  uint32_t merge_ablate = 0;   // FREDDY_GPU_MERGE_ABLATE: timing experiments / 32 = refine every row (tests)
+  int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
+  int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
+  int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
+  int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
+  int64_t lut_budget_mb = 1024;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit)
+  int64_t filter_table_mb = 8192;    // FREDDY_GPU_FILTER_TABLE_MB (pin time): 0 = no filter + refine tables
+};
+static int64_t env_int(const char* name, int64_t dflt) {
+  const char* e = getenv(name);
+  return (e && *e) ? (int64_t)strtoll(e, nullptr, 10) : dflt;
+}
+static Tuning read_tuning() {
+  Tuning t;
+  t.fused = (int)env_int("FREDDY_GPU_FUSED", t.fused);
+  t.scan_kernel = (int)env_int("FREDDY_GPU_FUSED_KERNEL", t.scan_kernel);
+  t.scan_ablate = (uint32_t)env_int("FREDDY_GPU_FUSED_ABLATE", 0);
+  t.merge_ablate = (uint32_t)env_int("FREDDY_GPU_MERGE_ABLATE", 0);
+  t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
+  t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
+  t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
+  t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
+  t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
+  t.filter_table_mb = env_int("FREDDY_GPU_FILTER_TABLE_MB", t.filter_table_mb);
+  return t;
+}
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
@@ -85,6 +119,7 @@ struct ProfRec {
 struct freddy_gpu_index {
   int kind = 0;
   int device = 0;
+  Tuning tune;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
   hipEvent_t ev_q = nullptr, ev_qc = nullptr;
@@ -127,19 +162,6 @@ struct freddy_gpu_index {
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
 };
-
-static size_t filter_table_budget_bytes() {
-  const char* e = getenv("FREDDY_GPU_FILTER_TABLE_MB");   // 0: no filter + refine tables at pin time (4 bytes per row)
-  size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 8192;
-  return mb << 20;
-}
-
-static size_t lut_budget_bytes() {
-  const char* e = getenv("FREDDY_GPU_LUT_BUDGET_MB");
-  size_t mb = e ? (size_t)strtoull(e, nullptr, 10) : 1024;
-  if (mb < 1) mb = 1;
-  return mb << 20;
-}
 
 template <class F>
 static inline void timed_launch(freddy_gpu_index* ix, hipStream_t s, const char* name, F&& f) {
@@ -252,8 +274,7 @@ static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off
   std::vector<uint32_t> packed((size_t)std::max<int64_t>(n_blocks, 1) * M2 * 64, 0u);
   std::vector<int32_t> pos((size_t)std::max<int64_t>(n_blocks, 1) * 64, -1);
   // (inverted lists only: the flat PQ table is addressed by row index)
-  const char* arr_env = getenv("FREDDY_GPU_ARRANGE_ROWS");
-  const bool arrange = row_pos != nullptr && !(arr_env && arr_env[0] == '0');
+  const bool arrange = row_pos != nullptr && ix->tune.arrange_rows != 0;
   std::vector<std::vector<int64_t>> orders(arrange ? (size_t)n_lists : 0);
   if (arrange) {
     std::atomic<int> next_list{0};
@@ -302,12 +323,37 @@ static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off
   return 0;
 }
 
+// Kernels that want more than the default 64 KiB of dynamic LDS: the limit is a per-device function
+// attribute, so it is raised once for every device an index is pinned on.
+static int raise_lds_limits(int device) {
+  static std::mutex mu;
+  static std::vector<char> done;
+  std::lock_guard<std::mutex> g(mu);
+  if ((size_t)device < done.size() && done[(size_t)device]) return 0;
+  const void* kernels[] = {
+      (const void*)&adc_scan_kernel<12, 1>, (const void*)&adc_scan_kernel<12, 2>, (const void*)&adc_scan_kernel<12, 4>,
+      (const void*)&adc_scan_kernel<12, 8>, (const void*)&adc_scan_kernel<12, 16>, (const void*)&adc_scan_kernel<0, 1>,
+      (const void*)&adc_scan_kernel<0, 2>, (const void*)&adc_scan_kernel<0, 4>, (const void*)&adc_scan_kernel<0, 8>,
+      (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
+      (const void*)&ivf_spec2_kernel<25, 12, false>, (const void*)&ivf_filter_kernel<12, true>,
+      (const void*)&ivf_filter_kernel<12, false>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
+      (const void*)&grouping_kernel<0>, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
+      (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>};
+  for (const void* k : kernels)
+    HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);
+  done[(size_t)device] = 1;
+  return 0;
+}
+
 static int open_device(freddy_gpu_index* ix, int device) {
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));
   if (device < 0 || device >= n) return fail(FREDDY_E_ARG, "device %d out of range (%d visible)", device, n);
   HIP_TRY(hipSetDevice(device));
   ix->device = device;
+  ix->tune = read_tuning();
+  if (int rc = raise_lds_limits(device)) return rc;
   HIP_TRY(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ix->n_cus = prop.multiProcessorCount;
@@ -355,12 +401,22 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
   if (int rc = check_pq_shape(t->d, t->m, t->K, t->N)) return rc;
   if (t->C <= 0) return fail(FREDDY_E_ARG, "C must be positive");
   if (t->list_off[0] != 0 || t->list_off[t->C] != t->N) return fail(FREDDY_E_ARG, "list_off must span [0, N]");
+  for (int c = 0; c < t->C; ++c)   // every offset is checked BEFORE any row is touched through it
+    if (t->list_off[c] < 0 || t->list_off[c] > t->list_off[c + 1] || (int64_t)t->list_off[c + 1] > t->N)
+      return fail(FREDDY_E_ARG, "list_off is not non-decreasing inside [0, N] at list %d", c);
   for (int c = 0; c < t->C; ++c)
     for (int64_t r = t->list_off[c]; r < t->list_off[c + 1]; ++r) {
       if (t->ids[r] < 0) return fail(FREDDY_E_ARG, "negative id at row %lld", (long long)r);
       if (r > t->list_off[c] && t->ids[r] <= t->ids[r - 1])
         return fail(FREDDY_E_ARG, "ids must be strictly ascending inside list %d (row %lld)", c, (long long)r);
     }
+  {   // "unique overall": a row id may sit in one list only (the merge orders a query's candidates by id)
+    std::vector<int32_t> sorted_ids(t->ids, t->ids + t->N);
+    std::sort(sorted_ids.begin(), sorted_ids.end());
+    for (int64_t r = 1; r < t->N; ++r)
+      if (sorted_ids[(size_t)r] == sorted_ids[(size_t)r - 1])
+        return fail(FREDDY_E_ARG, "id %d occurs in more than one list", (int)sorted_ids[(size_t)r]);
+  }
   freddy_gpu_index* ix = new freddy_gpu_index();
   ix->kind = KIND_IVF;
   ix->d = t->d; ix->m = t->m; ix->K = t->K; ix->S = t->d / t->m; ix->M2 = (t->m + 1) / 2; ix->N = t->N; ix->C = t->C;
@@ -393,7 +449,7 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
       if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     }
     // filter + refine tables (fused4.h)
-    if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && filter_table_budget_bytes() > 0) {
+    if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && ix->tune.filter_table_mb > 0) {
       std::vector<float> pmax((size_t)ix->m), cmaxp((size_t)ix->m);
       for (int p = 0; p < ix->m; ++p) {
         double comax = 0.0, cmax = 0.0;
@@ -471,6 +527,22 @@ extern "C" int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* ix) {
   return sum;
 }
 
+extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_t* n_cells, int64_t* rows) {
+  // distinct cells the most recent probing round (cell-grouped scans only) touched, and the rows of their
+  // lists: what a scan that reads every probed list ONCE per batch has to move (freddy.c:939-974)
+  if (!ix || !n_cells || !rows) return fail(FREDDY_E_ARG, "NULL argument");
+  *n_cells = 0; *rows = 0;
+  if (ix->kind != KIND_IVF) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  if (ix->last_Q <= 0 || !ix->w_cellcnt.p) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipDeviceSynchronize());
+  std::vector<int32_t> cnt((size_t)ix->C);
+  HIP_TRY(hipMemcpy(cnt.data(), ix->w_cellcnt.p, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));
+  for (int c = 0; c < ix->C; ++c)
+    if (cnt[(size_t)c] > 0) { *n_cells += 1; *rows += ix->h_list_off[(size_t)c + 1] - ix->h_list_off[(size_t)c]; }
+  return FREDDY_OK;
+}
+
 static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
   if (!ix || !ix->viol) return 0;
   int32_t h[2] = {0, 0};
@@ -516,6 +588,22 @@ extern "C" int freddy_gpu_profile_read(freddy_gpu_index_t* ix, int32_t cap, char
   return n;
 }
 
+extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, int64_t value) {
+  if (!ix || !name) return fail(FREDDY_E_ARG, "NULL argument");
+  Tuning& t = ix->tune;
+  const std::string n(name);
+  if (n == "fused") t.fused = (int)value;
+  else if (n == "fused_kernel") t.scan_kernel = (int)value;
+  else if (n == "fused_ablate") t.scan_ablate = (uint32_t)value;
+  else if (n == "merge_ablate") t.merge_ablate = (uint32_t)value;
+  else if (n == "side_stream") t.side_stream = (int)value;
+  else if (n == "fused_prof") t.scan_prof = (int)value;
+  else if (n == "debug_surv") t.debug_surv = (int)value;
+  else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
+  else return fail(FREDDY_E_ARG, "unknown option '%s'", name);
+  return FREDDY_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // kernel dispatch helpers
 // ---------------------------------------------------------------------------------------
@@ -530,12 +618,6 @@ static int pick_V(int L) {
 
 template <int M, int V>
 static int launch_scan_mv(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, dim3 grid, size_t lds) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&adc_scan_kernel<M, V>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
   timed_launch(ix, s, "adc_scan", [&] { hipLaunchKernelGGL((adc_scan_kernel<M, V>), grid, dim3(SCAN_WG), lds, s, a); });
   HIP_TRY(hipGetLastError());
   return 0;
@@ -603,79 +685,51 @@ static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, co
 // ---------------------------------------------------------------------------------------
 // IVFADC
 // ---------------------------------------------------------------------------------------
-// One chunk of queries (device pointers).  sync_rounds: run the extra rounds with a host
-// sync per round; otherwise only round one is enqueued and d_status reports stragglers.
-static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, int W,
-                        float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
-                        int32_t* d_status, bool sync_rounds) {
-  const int d = ix->d, C = ix->C, m = ix->m, K = ix->K;
-  const int L = std::min(2 * k, 64 * 16);
-  const int Cpad = ix->Cpad;
+// State of one chunk of queries while its probing rounds are enqueued.
+struct IvfRun {
+  freddy_gpu_index* ix;
+  hipStream_t s;
+  const float* d_q;
+  int Q, k, W, L, found_rule, upi;
+  float sentinel, cell_limit;
+  int32_t *d_out_ids, *d_status;
+  float* d_out_dist;
+  bool fused;          // cell-grouped scans (fused3.h / fused4.h) instead of lut_build + adc_scan
+  int scan_kernel;     // 4: filter + refine, 3: exact fused scan
+  bool tiled;          // the batch coarse kernel also clears the round-one scratch
+  bool qc_pending;     // the query x codebook table is being built on the side stream
+  // per round
+  int n_active, round;
+  const int32_t* active;
+  int32_t* next;
+  bool first() const { return round == 0; }
+};
+
+// coarse distances (a6/a7) of every query of the chunk, and -- for the filter + refine scan -- the
+// per-batch query x codebook table beside them on the side stream
+static int ivf_coarse(IvfRun& r) {
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int Q = r.Q, d = ix->d, C = ix->C, m = ix->m, K = ix->K, Cpad = ix->Cpad;
   const int used_words = (C + 31) / 32;
-  const size_t lutN = (size_t)m * K;
-  const int chunk_blocks = 256;   // one workgroup per (query, probed cell) unless the list is huge
-  const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
-  const size_t items = (size_t)Q * W;
-  if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
-
-  // Fused LUT+scan path: residual PQ with m=12, S=25, K<=1024 and a selection width that one
-  // wave holds (2k <= 64).  Everything else takes the generic lut_build + adc_scan kernels.
-  // FREDDY_GPU_FUSED=0 forces the generic lut_build + adc_scan kernels (tests run both).  The
-  // fused kernel pays off once several (query, cell) items share a cell, i.e. for batches.
-  const char* fenv = getenv("FREDDY_GPU_FUSED");
-  const bool force_fused = fenv && fenv[0] == '1';
-  // (lists longer than 8 chunks of 4096 rows would need survivor buffers out of proportion: generic path)
-  const int upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
-  const bool fused = !(fenv && fenv[0] == '0') && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && L <= 64 && upi <= 8 &&
-                     (force_fused || items >= 256);
-  if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
-      ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
-      ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
-      ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_resid.ensure(sizeof(float) * items * (size_t)m * ((ix->S + 3) & ~3)) ||
-      ix->w_cand.ensure(sizeof(int32_t) * Q) ||
-      ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
-      ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
-    return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-  // FREDDY_GPU_FUSED_KERNEL: 1 = symmetric exact kernel (fused.h), 2 = one builder wave per SIMD (fused2.h),
-  // 3 = two builder waves per SIMD, 12 items per entry (fused3.h), default 4 = filter + refine (fused4.h:
-  // cheap bounded distances in the scan, the reference's arithmetic only for the rows that can matter)
-  const char* fvenv = getenv("FREDDY_GPU_FUSED_KERNEL");   // read per call: the tests switch it
-  int fvariant = (fvenv && fvenv[0] >= '1' && fvenv[0] <= '4') ? fvenv[0] - '0' : 4;
-  if (fvariant == 4 && !ix->rterm) fvariant = 3;
-  if (fused && fvariant == 4) {
-    if (ix->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
-      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-  }
-  if (fused) {
-    // cell_count[C]; cell_items[C][Q]; group table: 2 x 3 arrays of (items/G + C) * upi entries
-    if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
-        ix->w_groups.ensure(sizeof(int32_t) * 6 * (items / SPEC2_G + (size_t)C + 1) * upi) ||
-        ix->w_surv.ensure(sizeof(u64) * items * upi * FUSED_NW * FUSED_RMAX * 64) ||
-        ix->w_surv_cnt.ensure(sizeof(int32_t) * items * upi * FUSED_NW))
-      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-  } else {
-    if (ix->w_lut.ensure(sizeof(float) * items * lutN) || ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * L))
-      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-  }
-
+  const size_t items = (size_t)Q * r.W;
   // round-one scratch that must start at zero: the probe bitmaps, the counters (n_next, n_groups, work
   // counter), the per-cell item counts and the accepted-candidate counts.  The tiled coarse kernel clears
   // them itself; the small-batch kernel gets memsets.
-  const bool tiled = Q >= 32;
-  if (!tiled) {
+  if (!r.tiled) {
     HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
     HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
   }
   ZeroArgs za;
   za.p[0] = ix->w_used.as<uint32_t>(); za.n[0] = Q * used_words;
   za.p[1] = ix->w_cnt.as<uint32_t>(); za.n[1] = 4;
-  za.p[2] = fused ? ix->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = fused ? C * 2 : 0;
+  za.p[2] = r.fused ? ix->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = r.fused ? C * 2 : 0;
   za.p[3] = ix->w_cand.as<uint32_t>(); za.n[3] = Q;
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
-  za.p[4] = fused ? ix->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = fused ? (int)(items * upi * FUSED_NW) : 0;
+  za.p[4] = r.fused ? ix->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = r.fused ? (int)(items * r.upi * FUSED_NW) : 0;
 
-  bool qc_pending = false;
-  if (fused && fvariant == 4) {
+  r.qc_pending = false;
+  if (r.fused && r.scan_kernel == 4) {
     // independent of the coarse distances / probe plan / work table: built beside them on the side
     // stream, joined before the entry records need it (starting it only after the coarse kernel, so that
     // it overlaps the latency-bound plan / work-table kernels alone, measured 2 % slower)
@@ -684,299 +738,326 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
       HIP_TRY(hipEventCreateWithFlags(&ix->ev_q, hipEventDisableTiming));
       HIP_TRY(hipEventCreateWithFlags(&ix->ev_qc, hipEventDisableTiming));
     }
-    static const bool side = !(getenv("FREDDY_GPU_SIDE_STREAM") && getenv("FREDDY_GPU_SIDE_STREAM")[0] == '0');
+    const bool side = ix->tune.side_stream != 0;
     hipStream_t sq = side ? ix->stream2 : s;
     if (side) {
       HIP_TRY(hipEventRecord(ix->ev_q, s));
       HIP_TRY(hipStreamWaitEvent(ix->stream2, ix->ev_q, 0));
     }
     timed_launch(ix, sq, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3(2, m, (Q + 31) / 32), dim3(256), 0, sq, d_q, ix->cbT, ix->cmaxp,
+      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3(2, m, (Q + 31) / 32), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
                          ix->w_qc.as<uint32_t>(), ix->w_qn.as<float>(), ix->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
     });
     HIP_TRY(hipGetLastError());
     if (side) {
       HIP_TRY(hipEventRecord(ix->ev_qc, ix->stream2));
-      qc_pending = true;
+      r.qc_pending = true;
     }
   }
-
-
   timed_launch(ix, s, "coarse_dist", [&] {
-    if (tiled)
-      {
-        static const int cdk = getenv("FREDDY_GPU_COARSE_DK") ? atoi(getenv("FREDDY_GPU_COARSE_DK")) : 16;   // (32 measured slower: 30 vs 27 us)
-        if (cdk == 16)
-          hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
-                             ix->w_distT.as<float>(), Q, Cpad, d, za);
-        else
-          hipLaunchKernelGGL((coarse_tile_kernel<2, 32>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, d_q, ix->coarseT,
-                             ix->w_distT.as<float>(), Q, Cpad, d, za);
-      }
+    if (r.tiled)
+      hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
+                         ix->w_distT.as<float>(), Q, Cpad, d, za);
     else
-      hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, d_q,
+      hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, r.d_q,
                          ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);
   });
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// a7: the W nearest not-yet-used cells of every active query (+ their items appended to the cells' buckets)
+static int ivf_plan(IvfRun& r, PlanArgs& pa) {
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int C = ix->C, W = r.W;
+  pa.dist = ix->w_distT.as<float>(); pa.active = r.active; pa.list_off = ix->list_off;
+  pa.used = ix->w_used.as<uint32_t>();
+  pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
+  pa.round_rows = ix->w_rows.as<int32_t>();
+  pa.n_active = r.n_active; pa.Cpad = ix->Cpad; pa.C = C; pa.W = W; pa.used_words = (C + 31) / 32;
+  pa.cell_count = r.fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
+  pa.cell_items = r.fused ? ix->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = r.n_active;
+  pa.cell_limit = r.cell_limit;
+  const int n_items = r.n_active * W;
+  if (r.fused && !(r.tiled && r.first())) {
+    HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
+    HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * (size_t)n_items * r.upi * FUSED_NW, s));
+  }
+  const int PV = pick_V(2 * W);
+  const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
+  timed_launch(ix, s, "probe_plan", [&] {
+    switch (PV) {
+      case 1: hipLaunchKernelGGL((probe_plan_kernel<1>), dim3(r.n_active), dim3(64), plan_lds, s, pa); break;
+      case 2: hipLaunchKernelGGL((probe_plan_kernel<2>), dim3(r.n_active), dim3(64), plan_lds, s, pa); break;
+      case 4: hipLaunchKernelGGL((probe_plan_kernel<4>), dim3(r.n_active), dim3(64), plan_lds, s, pa); break;
+      case 8: hipLaunchKernelGGL((probe_plan_kernel<8>), dim3(r.n_active), dim3(64), plan_lds, s, pa); break;
+      default: hipLaunchKernelGGL((probe_plan_kernel<16>), dim3(r.n_active), dim3(64), plan_lds, s, pa); break;
+    }
+  });
+  HIP_TRY(hipGetLastError());
+  if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * r.Q, s));
+  return 0;
+}
+
+// The work table shared by both cell-grouped scans: per-cell item counts -> (<= 12 items of a cell, 4096-row
+// chunk) entries, largest first.
+struct WorkTable {
+  size_t max_groups;
+  int32_t *group_cell, *group_first, *group_cnt, *n_groups, *work_counter;
+};
+static int ivf_work_table(IvfRun& r, WorkTable& wt) {
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int n_items = r.n_active * r.W;
+  wt.max_groups = ((size_t)n_items / SPEC2_G + (size_t)ix->C + 1) * r.upi;   // (group, chunk) work entries
+  int32_t* base = ix->w_groups.as<int32_t>();
+  wt.group_cell = base; wt.group_first = base + wt.max_groups; wt.group_cnt = base + 2 * wt.max_groups;
+  wt.n_groups = ix->w_cnt.as<int32_t>() + 1;
+  wt.work_counter = ix->w_cnt.as<int32_t>() + 2;
+  timed_launch(ix, s, "work_table", [&] {
+    hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ix->w_cellcnt.as<int32_t>(), ix->C, r.n_active, SPEC2_G, ix->blk_off,
+                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 4 ? 1 : 0);
+  });
+  HIP_TRY(hipGetLastError());
+  if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, sizeof(int32_t), s));
+  return 0;
+}
+
+static int scan_prof_buffer(freddy_gpu_index* ix, long long** prof) {
+  *prof = nullptr;
+  if (!ix->tune.scan_prof) return 0;
+  if (ix->w_prof.ensure(sizeof(long long) * 8 * 1024)) return fail(FREDDY_E_NOMEM, "profile buffer");
+  *prof = ix->w_prof.as<long long>();
+  return 0;
+}
+
+// debugging aid (option fused_prof): per-phase shader-clock sums of every persistent workgroup's builder wave 0
+static int scan_prof_print(freddy_gpu_index* ix, hipStream_t s, const long long* prof, unsigned n_persist) {
+  std::vector<long long> h(8 * (size_t)n_persist);
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipMemcpy(h.data(), prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+  double sum[8] = {0}; long long mx_end = 0, mn_end = -1; double ent = 0;
+  for (unsigned b = 0; b < n_persist; ++b) {
+    for (int i = 0; i < 6; ++i) sum[i] += (double)h[b * 8 + i];
+    ent += (double)h[b * 8 + 7];
+    mx_end = std::max(mx_end, h[b * 8 + 6]);
+    mn_end = mn_end < 0 ? h[b * 8 + 6] : std::min(mn_end, h[b * 8 + 6]);
+  }
+  fprintf(stderr, "[scan prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f | workgroups ran dry over %.1f us\n",
+          n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent, (mx_end - mn_end) / 100.0);
+  (void)ix;
+  return 0;
+}
+
+// Default scan: filter + refine (fused4.h).  entry records -> ivf_filter_kernel -> merge_refine_kernel.
+static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int Q = r.Q, m = ix->m, K = ix->K;
+  if (ix->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  RecordArgs ra;
+  ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
+  ra.sorted_item = ix->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
+  ra.dist = ix->w_distT.as<float>(); ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
+  ra.records = ix->w_records.as<int32_t>(); ra.Cpad = ix->Cpad; ra.sentinel = r.sentinel;
+  if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ix->ev_qc, 0)); r.qc_pending = false; }
+  timed_launch(ix, s, "entry_records", [&] {
+    hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
+  });
+  HIP_TRY(hipGetLastError());
+  FilterArgs fl;
+  fl.qc = ix->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
+  fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ix->w_surv.as<u64>(); fl.surv_count = ix->w_surv_cnt.as<int32_t>();
+  fl.cand_count = (r.found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
+  fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.ablate = ix->tune.scan_ablate;
+  if (int rc = scan_prof_buffer(ix, &fl.prof)) return rc;
+  const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
+  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
+  fl.desc_offset = (uint32_t)desc_off;
+  // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
+  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)ix->n_cus);
+  timed_launch(ix, s, "ivf_filter", [&] {
+    if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+  });
+  HIP_TRY(hipGetLastError());
+  if (fl.prof) if (int rc = scan_prof_print(ix, s, fl.prof, n_persist)) return rc;
+
+  MergeRefineArgs mr;
+  mr.surv = fl.surv; mr.surv_count = fl.surv_count; mr.active = r.active; mr.round_rows = pa.round_rows;
+  mr.item_cell = pa.item_cell; mr.queries = r.d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
+  mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
+  mr.cand_count = fl.cand_count; mr.violations = ix->viol; mr.out_ids = r.d_out_ids; mr.out_dist = r.d_out_dist;
+  mr.found = ix->w_found.as<int32_t>(); mr.next_active = r.next; mr.n_next = ix->w_cnt.as<int32_t>();
+  mr.status = r.d_status;
+  mr.n_active = r.n_active; mr.W = r.W; mr.upi = r.upi; mr.L = r.L; mr.k = r.k; mr.found_rule = r.found_rule;
+  mr.first_round = r.first() ? 1 : 0; mr.K = K; mr.d = ix->d; mr.sentinel = r.sentinel;
+  mr.ablate = ix->tune.merge_ablate;
+  if (ix->tune.debug_surv) {   // debugging aid: survivor statistics of the round
+    const int n_items = r.n_active * r.W;
+    const size_t nreg = (size_t)n_items * r.upi * FUSED_NW;
+    std::vector<int32_t> h(nreg);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(h.data(), fl.surv_count, sizeof(int32_t) * nreg, hipMemcpyDeviceToHost));
+    long long tot = 0; int mx = 0; long long item_mx = 0;
+    for (size_t it = 0; it < (size_t)n_items; ++it) {
+      long long si = 0;
+      for (size_t g = 0; g < (size_t)r.upi * FUSED_NW; ++g) { const int c = h[it * r.upi * FUSED_NW + g]; si += c; mx = std::max(mx, c); }
+      tot += si; item_mx = std::max(item_mx, si);
+    }
+    fprintf(stderr, "[surv] items=%d survivors=%lld (%.2f per item, max %lld), largest region %d\n", n_items, tot,
+            (double)tot / std::max(n_items, 1), item_mx, mx);
+  }
+  timed_launch(ix, s, "merge_refine", [&] {
+    hipLaunchKernelGGL((merge_refine_kernel<25, 12>), dim3(r.n_active), dim3(256), 0, s, mr);
+  });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// The yardstick: the reference's arithmetic for every probed row (fused3.h).  ivf_spec2_kernel -> merge_surv_kernel.
+static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int K = ix->K;
+  FusedArgs fa;
+  fa.resid = nullptr; fa.item_query = pa.item_query; fa.queries = r.d_q; fa.coarse = ix->coarse;
+  fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = wt.group_cell; fa.group_first = wt.group_first;
+  fa.group_cnt = wt.group_cnt; fa.n_groups = wt.n_groups; fa.work_counter = wt.work_counter;
+  fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
+  fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
+  fa.cand_count = (r.found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
+  fa.d = ix->d; fa.K = K; fa.L = r.L; fa.upi = r.upi;
+  memcpy(&fa.sentinel_bits, &r.sentinel, 4);
+  fa.ablate = ix->tune.scan_ablate;
+  if (int rc = scan_prof_buffer(ix, &fa.prof)) return rc;
+  const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
+  const size_t flds = desc_off + 4096 + 64 + 512 + (size_t)SPEC2_G * 12 * 28 * sizeof(float);
+  fa.desc_offset = (uint32_t)desc_off;
+  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)ix->n_cus);
+  timed_launch(ix, s, "ivf_exact_scan", [&] {
+    if (K == 1024) hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
+    else hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
+  });
+  HIP_TRY(hipGetLastError());
+  if (fa.prof) if (int rc = scan_prof_print(ix, s, fa.prof, n_persist)) return rc;
+  MergeSurvArgs ms;
+  ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = r.active; ms.round_rows = pa.round_rows;
+  ms.cand_count = fa.cand_count; ms.out_ids = r.d_out_ids; ms.out_dist = r.d_out_dist;
+  ms.found = ix->w_found.as<int32_t>(); ms.next_active = r.next; ms.n_next = ix->w_cnt.as<int32_t>();
+  ms.status = r.d_status;
+  ms.n_active = r.n_active; ms.W = r.W; ms.upi = r.upi; ms.L = r.L; ms.k = r.k; ms.found_rule = r.found_rule;
+  ms.first_round = r.first() ? 1 : 0; ms.sentinel = r.sentinel;
+  timed_launch(ix, s, "merge_surv", [&] { hipLaunchKernelGGL(merge_surv_kernel, dim3(r.n_active), dim3(64), 0, s, ms); });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// Generic path (small batches, other m / S / K, k > 32): residual -> lut_build -> adc_scan -> merge_replay;
+// the LUTs round-trip through memory.
+static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int n_items = r.n_active * r.W;
+  const int chunk_blocks = 256;   // one workgroup per (query, probed cell) unless the list is huge
+  const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
+  timed_launch(ix, s, "residual", [&] {
+    hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, r.d_q, ix->coarse, pa.item_cell, pa.item_query,
+                       ix->w_resid.as<float>(), ix->d, ix->S, ix->S);
+  });
+  HIP_TRY(hipGetLastError());
+  if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
+  ScanArgs sa;
+  sa.lut = ix->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
+  sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ix->w_part.as<u64>();
+  sa.cand_count = ix->w_cand.as<int32_t>();
+  sa.m = ix->m; sa.K = ix->K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = r.L;
+  memcpy(&sa.sentinel_bits, &r.sentinel, 4);
+  if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
+  MergeArgs ma;
+  ma.part = sa.part; ma.active = r.active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
+  ma.cand_count = sa.cand_count; ma.out_ids = r.d_out_ids; ma.out_dist = r.d_out_dist;
+  ma.found = ix->w_found.as<int32_t>(); ma.next_active = r.next; ma.n_next = ix->w_cnt.as<int32_t>();
+  ma.status = r.d_status;
+  ma.n_active = r.n_active; ma.parts_per_query = r.W * nchunk; ma.L = r.L; ma.k = r.k;
+  ma.found_rule = r.found_rule; ma.first_round = r.first() ? 1 : 0; ma.sentinel = r.sentinel;
+  return launch_merge(ix, s, ma);
+}
+
+// One chunk of queries (device pointers).  sync_rounds: run the extra rounds of the reference's
+// "while (foundInstances < k)" loop with a host sync per round; otherwise only round one is enqueued and
+// d_status reports stragglers.
+static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, int W,
+                        float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
+                        int32_t* d_status, bool sync_rounds) {
+  const int C = ix->C, m = ix->m, K = ix->K;
+  if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
+  IvfRun r;
+  r.ix = ix; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
+  r.sentinel = sentinel; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = d_status;
+  // FREDDY_FOUND_BATCH_UDF = the accepted-rows rule + the batch UDF's cell limit (argmin from minDist = 1000,
+  // freddy.c:853-866); ivfadc_search's cell list starts at 100.0 (freddy.c:266-283)
+  r.found_rule = found_rule == FREDDY_FOUND_ROWS ? 0 : 1;
+  r.cell_limit = found_rule == FREDDY_FOUND_BATCH_UDF ? 1000.0f : 100.0f;
+  const size_t items = (size_t)Q * W;
+  // Cell-grouped scans: residual PQ with m=12, S=25, K<=1024 and a selection width that one wave holds
+  // (2k <= 64); lists longer than 8 chunks of 4096 rows would need survivor buffers out of proportion.  They
+  // pay off once several (query, cell) items share a cell, i.e. for batches; option fused = 1 / 0 forces
+  // them / the generic lut_build + adc_scan kernels (the tests run both).
+  r.upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  r.fused = ix->tune.fused != 0 && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && r.L <= 64 && r.upi <= 8 &&
+            (ix->tune.fused == 1 || items >= 256);
+  r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : 4;
+  r.tiled = Q >= 32;
+  const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
+  if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
+      ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
+      ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
+      ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
+      ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  if (r.fused) {
+    // cell_count[C] + cursors; cell_items[C][Q]; work table: 3 arrays of (items/G + C + 1) * upi entries
+    if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
+        ix->w_groups.ensure(sizeof(int32_t) * 3 * (items / SPEC2_G + (size_t)C + 1) * r.upi) ||
+        ix->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
+        ix->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+    if (r.scan_kernel == 4 &&
+        (ix->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  } else {
+    const int nchunk = std::max(1, (ix->max_list_blocks + 255) / 256);
+    if (ix->w_resid.ensure(sizeof(float) * items * (size_t)ix->d) || ix->w_lut.ensure(sizeof(float) * items * (size_t)m * K) ||
+        ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * r.L))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  }
+
+  if (int rc = ivf_coarse(r)) return rc;
   ix->last_Q = Q;
-  int n_active = Q;
-  const int32_t* active = nullptr;
-  int32_t* next = ix->w_act0.as<int32_t>();
-  bool first = true;
+  r.n_active = Q; r.active = nullptr; r.next = ix->w_act0.as<int32_t>();
   const int max_rounds = (C + W - 1) / W + 1;
-  for (int round = 0; round < max_rounds && n_active > 0; ++round) {
-    const int n_items = n_active * W;
+  for (r.round = 0; r.round < max_rounds && r.n_active > 0; ++r.round) {
     PlanArgs pa;
-    pa.dist = ix->w_distT.as<float>(); pa.active = active; pa.list_off = ix->list_off;
-    pa.used = ix->w_used.as<uint32_t>();
-    pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
-    pa.round_rows = ix->w_rows.as<int32_t>();
-    pa.n_active = n_active; pa.Cpad = Cpad; pa.C = C; pa.W = W; pa.used_words = used_words;
-    pa.cell_count = fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
-    pa.cell_items = fused ? ix->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = n_active;
-    if (fused && !(tiled && first)) {
-      HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
-      HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * (size_t)n_items * upi * FUSED_NW, s));
-    }
-    {
-      const int PV = pick_V(2 * W);
-      const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
-      timed_launch(ix, s, "probe_plan", [&] {
-        switch (PV) {
-          case 1: hipLaunchKernelGGL((probe_plan_kernel<1>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
-          case 2: hipLaunchKernelGGL((probe_plan_kernel<2>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
-          case 4: hipLaunchKernelGGL((probe_plan_kernel<4>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
-          case 8: hipLaunchKernelGGL((probe_plan_kernel<8>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
-          default: hipLaunchKernelGGL((probe_plan_kernel<16>), dim3(n_active), dim3(64), plan_lds, s, pa); break;
-        }
-      });
-    }
-    // FREDDY_GPU_FUSED_KERNEL=1: the symmetric kernel of fused.h; default: the role-specialised one, which
-    // forms the residuals itself
-    // FREDDY_GPU_FUSED_KERNEL: 1 = symmetric kernel (fused.h), 2 = one builder wave per SIMD (fused2.h),
-    // default 3 = two builder waves per SIMD, 12 items per entry (fused3.h)
-    const bool symmetric = fvariant == 1;
-    const int gsz = (fvariant >= 3) ? SPEC2_G : FUSED_G;
-    if (!fused || symmetric) {
-      timed_launch(ix, s, "residual", [&] {
-        hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, d_q, ix->coarse, pa.item_cell, pa.item_query,
-                           ix->w_resid.as<float>(), d, ix->S, fused ? ((ix->S + 3) & ~3) : ix->S);
-      });
-      HIP_TRY(hipGetLastError());
-    }
-    if (!(tiled && first)) HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * Q, s));
-    if (fused) {
-      const size_t max_groups = ((size_t)n_items / gsz + (size_t)C + 1) * upi;   // (group, chunk) work entries
-      int32_t* cell_count = ix->w_cellcnt.as<int32_t>();
-      int32_t* group_cell = ix->w_groups.as<int32_t>();
-      int32_t* group_first = group_cell + max_groups;
-      int32_t* group_cnt = group_first + max_groups;
-      int32_t* n_groups = ix->w_cnt.as<int32_t>() + 1;
-      timed_launch(ix, s, "group_items", [&] {
-        hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, cell_count, C, n_active, gsz, ix->blk_off,
-                           group_cnt + max_groups, group_cnt + 2 * max_groups, group_cnt + 3 * max_groups, n_groups,
-                           fvariant == 4 ? 1 : 0);
-      });
-      HIP_TRY(hipGetLastError());
-      FusedArgs fa;
-      fa.resid = ix->w_resid.as<float>(); fa.item_query = pa.item_query; fa.queries = d_q; fa.coarse = ix->coarse;
-      fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = group_cnt + max_groups;
-      fa.group_first = group_cnt + 2 * max_groups; fa.group_cnt = group_cnt + 3 * max_groups; fa.n_groups = n_groups; fa.work_counter = ix->w_cnt.as<int32_t>() + 2;
-      if (!(tiled && first)) HIP_TRY(hipMemsetAsync(ix->w_cnt.as<int32_t>() + 2, 0, sizeof(int32_t), s));
-      fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
-      fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
-      fa.cand_count = (found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
-      fa.d = d; fa.K = K; fa.L = L; fa.upi = upi;
-      memcpy(&fa.sentinel_bits, &sentinel, 4);
-      const size_t slab_bytes = (size_t)2 * FUSED_G * K * sizeof(float);
-      const size_t exch_bytes = (size_t)FUSED_G * FUSED_T * sizeof(uint32_t) + 64 * sizeof(uint32_t);
-      const size_t res_bytes = (size_t)FUSED_G * 12 * 28 * sizeof(float);   // padded residuals of one entry
-      { const char* ab = getenv("FREDDY_GPU_FUSED_ABLATE"); fa.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
-      fa.prof = nullptr;
-      static const bool want_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
-      if (want_prof) {
-        if (ix->w_prof.ensure(sizeof(long long) * 8 * 1024)) return fail(FREDDY_E_NOMEM, "profile buffer");
-        fa.prof = ix->w_prof.as<long long>();
-      }
-      static bool fattr = false;
-      if (!fattr) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_fused_kernel<25, 12, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_fused_kernel<25, 12, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec_kernel<25, 12, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec_kernel<25, 12, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec2_kernel<25, 12, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_spec2_kernel<25, 12, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        fattr = true;
-      }
-      // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
-      const unsigned n_persist = (unsigned)std::min<size_t>(max_groups, (size_t)ix->n_cus);
-      if (symmetric) {
-        const size_t desc_off = (std::max(slab_bytes, exch_bytes) + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 256 + res_bytes;   // + entry descriptors + padded residuals
-        fa.desc_offset = (uint32_t)desc_off;
-        timed_launch(ix, s, "ivf_fused", [&] {
-          if (K == FUSED_T * FUSED_E)
-            hipLaunchKernelGGL((ivf_fused_kernel<25, 12, true>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
-          else
-            hipLaunchKernelGGL((ivf_fused_kernel<25, 12, false>), dim3(n_persist), dim3(FUSED_T), flds, s, fa);
-        });
-      } else if (fvariant == 2) {
-        const size_t desc_off = (slab_bytes + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + 512 + res_bytes;   // + column minima, thresholds, descriptors, residuals
-        fa.desc_offset = (uint32_t)desc_off;
-        timed_launch(ix, s, "ivf_fused", [&] {
-          if (K == 1024)
-            hipLaunchKernelGGL((ivf_spec_kernel<25, 12, true>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
-          else
-            hipLaunchKernelGGL((ivf_spec_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC_T), flds, s, fa);
-        });
-      } else if (fvariant == 4) {
-        const size_t max_rec = max_groups;
-        if (ix->w_records.ensure(sizeof(int32_t) * REC_DW * max_rec)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-        RecordArgs ra;
-        ra.group_cell = fa.group_cell; ra.group_first = fa.group_first; ra.group_cnt = fa.group_cnt; ra.n_groups = fa.n_groups;
-        ra.sorted_item = fa.sorted_item; ra.item_query = fa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
-        ra.dist = ix->w_distT.as<float>(); ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
-        ra.records = ix->w_records.as<int32_t>(); ra.Cpad = Cpad; ra.sentinel = sentinel;
-        if (qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ix->ev_qc, 0)); qc_pending = false; }
-        timed_launch(ix, s, "entry_records", [&] {
-          hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((max_rec + 3) / 4)), dim3(256), 0, s, ra);
-        });
-        HIP_TRY(hipGetLastError());
-        FilterArgs fl;
-        fl.qc = ix->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = fa.n_groups; fl.work_counter = fa.work_counter;
-        fl.packed = fa.packed; fl.surv = fa.surv; fl.surv_count = fa.surv_count;
-        fl.cand_count = fa.cand_count; fl.K = K; fl.L = L; fl.upi = upi; fl.sentinel = sentinel;
-        fl.ablate = fa.ablate; fl.prof = fa.prof;
-        const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
-        fl.desc_offset = (uint32_t)desc_off;
-        static bool f4attr = false;
-        if (!f4attr) {
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_filter_kernel<12, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&ivf_filter_kernel<12, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          f4attr = true;
-        }
-        timed_launch(ix, s, "ivf_fused", [&] {
-          if (K == 1024)
-            hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-          else
-            hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-        });
-      } else {
-        const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
-        const size_t flds = desc_off + 4096 + 64 + 512 + (size_t)SPEC2_G * 12 * 28 * sizeof(float);
-        fa.desc_offset = (uint32_t)desc_off;
-        timed_launch(ix, s, "ivf_fused", [&] {
-          if (K == 1024)
-            hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
-          else
-            hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
-        });
-      }
-      HIP_TRY(hipGetLastError());
-      if (fa.prof) {   // debugging aid: per-phase shader-clock sums of every persistent workgroup
-        std::vector<long long> h(8 * (size_t)n_persist);
-        HIP_TRY(hipStreamSynchronize(s));
-        HIP_TRY(hipMemcpy(h.data(), fa.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
-        double sum[8] = {0}; long long mx_end = 0, mn_end = -1; double ent = 0;
-        for (unsigned b = 0; b < n_persist; ++b) {
-          for (int i = 0; i < 6; ++i) sum[i] += (double)h[b * 8 + i];
-          ent += (double)h[b * 8 + 7];
-          mx_end = std::max(mx_end, h[b * 8 + 6]);
-          mn_end = mn_end < 0 ? h[b * 8 + 6] : std::min(mn_end, h[b * 8 + 6]);
-        }
-        if (symmetric)
-          fprintf(stderr, "[fused prof] wgs=%u entries=%.0f  cycles/entry: stage=%.0f slab0=%.0f loop=%.0f lastgather=%.0f select=%.0f\n",
-                  n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[4] / ent);
-        else
-          fprintf(stderr, "[spec prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f | workgroups ran dry over %.1f us\n",
-                  n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent, (mx_end - mn_end) / 100.0);
-      }
-      if (fvariant == 4) {
-        MergeRefineArgs mr;
-        mr.surv = fa.surv; mr.surv_count = fa.surv_count; mr.active = active; mr.round_rows = pa.round_rows;
-        mr.item_cell = pa.item_cell; mr.queries = d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
-        mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
-        mr.cand_count = fa.cand_count; mr.violations = ix->viol; mr.out_ids = d_out_ids; mr.out_dist = d_out_dist;
-        mr.found = ix->w_found.as<int32_t>(); mr.next_active = next; mr.n_next = ix->w_cnt.as<int32_t>();
-        mr.status = d_status;
-        mr.n_active = n_active; mr.W = W; mr.upi = upi; mr.L = L; mr.k = k; mr.found_rule = found_rule;
-        mr.first_round = first ? 1 : 0; mr.K = K; mr.d = d; mr.sentinel = sentinel;
-        { const char* ab = getenv("FREDDY_GPU_MERGE_ABLATE"); mr.ablate = ab ? (uint32_t)atoi(ab) : 0u; }
-        static const bool dbg_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;   // debugging aid: survivor statistics
-        if (dbg_surv) {
-          const size_t nreg = (size_t)n_items * upi * FUSED_NW;
-          std::vector<int32_t> h(nreg);
-          std::vector<float> hq((size_t)Q * m * 2);
-          HIP_TRY(hipStreamSynchronize(s));
-          HIP_TRY(hipMemcpy(h.data(), fa.surv_count, sizeof(int32_t) * nreg, hipMemcpyDeviceToHost));
-          HIP_TRY(hipMemcpy(hq.data(), ix->w_qn.p, sizeof(float) * hq.size(), hipMemcpyDeviceToHost));
-          long long tot = 0; int mx = 0; long long item_mx = 0;
-          for (size_t it = 0; it < (size_t)n_items; ++it) {
-            long long si = 0;
-            for (size_t r = 0; r < (size_t)upi * FUSED_NW; ++r) { const int c = h[it * upi * FUSED_NW + r]; si += c; mx = std::max(mx, c); }
-            tot += si; item_mx = std::max(item_mx, si);
-          }
-          double qnm = 0; for (int p = 0; p < m; ++p) qnm += hq[p];
-          fprintf(stderr, "[surv] items=%d survivors=%lld (%.2f per item, max %lld), largest region %d; sum_p |q_p| of query 0 = %.4f, scale[0][0]=%g\n",
-                  n_items, tot, (double)tot / n_items, item_mx, mx, qnm, hq[(size_t)Q * m]);
-        }
-        timed_launch(ix, s, "merge_replay", [&] {
-          hipLaunchKernelGGL((merge_refine_kernel<25, 12>), dim3(n_active), dim3(256), 0, s, mr);
-        });
-        HIP_TRY(hipGetLastError());
-      } else {
-      MergeSurvArgs ms;
-      ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = active; ms.round_rows = pa.round_rows;
-      ms.cand_count = fa.cand_count; ms.out_ids = d_out_ids; ms.out_dist = d_out_dist;
-      ms.found = ix->w_found.as<int32_t>(); ms.next_active = next; ms.n_next = ix->w_cnt.as<int32_t>();
-      ms.status = d_status;
-      ms.n_active = n_active; ms.W = W; ms.upi = upi; ms.L = L; ms.k = k; ms.found_rule = found_rule;
-      ms.first_round = first ? 1 : 0; ms.sentinel = sentinel;
-      timed_launch(ix, s, "merge_replay", [&] {
-        hipLaunchKernelGGL(merge_surv_kernel, dim3(n_active), dim3(64), 0, s, ms);
-      });
-      HIP_TRY(hipGetLastError());
-      }
+    if (int rc = ivf_plan(r, pa)) return rc;
+    if (r.fused) {
+      WorkTable wt;
+      if (int rc = ivf_work_table(r, wt)) return rc;
+      if (int rc = (r.scan_kernel == 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt)) return rc;
     } else {
-      if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
-      ScanArgs sa;
-      sa.lut = ix->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
-      sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ix->w_part.as<u64>();
-      sa.cand_count = ix->w_cand.as<int32_t>();
-      sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
-      memcpy(&sa.sentinel_bits, &sentinel, 4);
-      if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
-
-      MergeArgs ma;
-      ma.part = sa.part; ma.active = active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
-      ma.cand_count = sa.cand_count; ma.out_ids = d_out_ids; ma.out_dist = d_out_dist;
-      ma.found = ix->w_found.as<int32_t>(); ma.next_active = next; ma.n_next = ix->w_cnt.as<int32_t>();
-      ma.status = d_status;
-      ma.n_active = n_active; ma.parts_per_query = W * nchunk; ma.L = L; ma.k = k;
-      ma.found_rule = found_rule; ma.first_round = first ? 1 : 0; ma.sentinel = sentinel;
-      if (int rc = launch_merge(ix, s, ma)) return rc;
+      if (int rc = ivf_scan_generic(r, pa)) return rc;
     }
-    first = false;
     if (!sync_rounds) break;
-
     int32_t n_next = 0;
     HIP_TRY(hipMemcpyAsync(&n_next, ix->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (n_next <= 0) break;
     HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t), s));
-    active = next;
-    next = (next == ix->w_act0.as<int32_t>()) ? ix->w_act1.as<int32_t>() : ix->w_act0.as<int32_t>();
-    n_active = n_next;
+    r.active = r.next;
+    r.next = (r.next == ix->w_act0.as<int32_t>()) ? ix->w_act1.as<int32_t>() : ix->w_act0.as<int32_t>();
+    r.n_active = n_next;
   }
   return 0;
 }
@@ -997,7 +1078,7 @@ static int max_queries_per_chunk(const freddy_gpu_index* ix, int W) {
   const size_t lut_bytes = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
   const size_t surv_bytes = upi <= 8 ? sizeof(u64) * (size_t)W * upi * FUSED_NW * FUSED_RMAX * 64 : 0;
   const size_t per_query = std::max(lut_bytes, surv_bytes);
-  size_t n = lut_budget_bytes() / std::max<size_t>(per_query, 1);
+  size_t n = ((size_t)ix->tune.lut_budget_mb << 20) / std::max<size_t>(per_query, 1);
   // the fused path's per-cell item buckets are [C][queries of the chunk]: keep them within 256 MiB
   if (surv_bytes) n = std::min<size_t>(n, ((size_t)256 << 20) / (sizeof(int32_t) * (size_t)std::max(ix->C, 1)));
   if (n < 1) n = 1;
@@ -1010,6 +1091,8 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
                                             float* d_out_dist, int32_t* d_status, void* hip_stream) {
   if (int rc = check_search_args(ix, KIND_IVF, d_queries, Q, k, d_out_ids, d_out_dist)) return rc;
   if (W <= 0) return fail(FREDDY_E_ARG, "W must be positive");
+  if (found_rule < 0 || found_rule > 2 || (found_rule == FREDDY_FOUND_BATCH_UDF && W != 1))
+    return fail(FREDDY_E_ARG, "bad found_rule (FREDDY_FOUND_BATCH_UDF needs W == 1)");
   if (W > ix->C) W = ix->C;
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ix->stream;
@@ -1027,6 +1110,8 @@ extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* que
                                         float sentinel, int32_t found_rule, int32_t* out_ids, float* out_dist) {
   if (int rc = check_search_args(ix, KIND_IVF, queries, Q, k, out_ids, out_dist)) return rc;
   if (W <= 0) return fail(FREDDY_E_ARG, "W must be positive");
+  if (found_rule < 0 || found_rule > 2 || (found_rule == FREDDY_FOUND_BATCH_UDF && W != 1))
+    return fail(FREDDY_E_ARG, "bad found_rule (FREDDY_FOUND_BATCH_UDF needs W == 1)");
   if (W > ix->C) W = ix->C;
   if (Q == 0) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
@@ -1195,13 +1280,6 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   HIP_TRY(hipMemcpyAsync(ix->w_q.p, group_vectors, sizeof(float) * (size_t)G * d, hipMemcpyHostToDevice, s));
   if (int rc = launch_lut(ix, s, ix->w_q.as<float>(), nullptr, ix->w_lut.as<float>(), G)) return rc;   // freddy.c:1288-1299
-  static bool gattr = false;
-  if (!gattr) {
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grouping_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grouping_kernel<15>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&grouping_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    gattr = true;
-  }
   const dim3 grid((unsigned)((n_blocks + GROUP_BLOCKS - 1) / GROUP_BLOCKS));
   timed_launch(ix, s, "grouping", [&] {
     if (ix->M2 == 6)
@@ -1317,6 +1395,13 @@ extern "C" int freddy_gpu_knn_join(freddy_gpu_index_t* ix, const float* queries,
   int rc = join_run(&ix->join, ix->stream, queries, Q, k, target_ids, n_targets, alpha, pvf, method,
                     use_target_lists, confidence, double_threshold, out_ids, out_dist, iterations_out);
   if (rc) return fail(rc, "%s", join_error());
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_last_track(const freddy_gpu_index_t* ix, freddy_track* out) {
+  if (!ix || !out) return fail(FREDDY_E_ARG, "NULL argument");
+  if (ix->kind != KIND_IVPQ) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  *out = ix->join.track;
   return FREDDY_OK;
 }
 

@@ -16,7 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "fused.h"
+#include "scan_common.h"
 
 namespace freddy {
 

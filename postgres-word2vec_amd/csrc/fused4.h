@@ -29,7 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "fused.h"
+#include "scan_common.h"
 #include "fused3.h"
 
 namespace freddy {

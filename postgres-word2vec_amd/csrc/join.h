@@ -86,6 +86,9 @@ struct JoinIndex {
   // workspaces
   void* w[16] = {nullptr};
   size_t wcap[16] = {0};
+  // stage timers of the last call under the reference's TRACK names (ivpq_search_in.c:234-697)
+  freddy_track track;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
 
 static inline int join_buf(JoinIndex* j, int slot, size_t bytes, void** out) {
@@ -105,6 +108,8 @@ static inline void join_free(JoinIndex* j) {
   void* ptrs[] = {j->cbT, j->coarseT, j->ids, j->codes, j->vectors, j->cell, j->markbits};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (int i = 0; i < 16; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
+  if (j->ev0) (void)hipEventDestroy(j->ev0);
+  if (j->ev1) (void)hipEventDestroy(j->ev1);
   *j = JoinIndex();
 }
 
@@ -635,15 +640,7 @@ static inline int join_pick_V(int L) {
 static inline int join_launch(hipStream_t s, const JoinArgs& a, int n_scan, int V, size_t lds) {
   dim3 grid((unsigned)n_scan), block(JOIN_WG);
 #define JOIN_CASE(v)                                                                                         \
-  case v: {                                                                                                  \
-    static bool attr = false;                                                                                \
-    if (!attr) {                                                                                             \
-      JOIN_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&join_query_kernel<v>),                     \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                 \
-      attr = true;                                                                                           \
-    }                                                                                                        \
-    hipLaunchKernelGGL((join_query_kernel<v>), grid, block, lds, s, a);                                      \
-  } break;
+  case v: hipLaunchKernelGGL((join_query_kernel<v>), grid, block, lds, s, a); break;
   switch (V) {
     JOIN_CASE(1) JOIN_CASE(2) JOIN_CASE(4) JOIN_CASE(8) JOIN_CASE(16)
     default: return join_fail(FREDDY_E_LIMIT, "unsupported selection width");
@@ -661,14 +658,14 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   if (n_targets > INT32_MAX) return join_fail(FREDDY_E_LIMIT, "too many targets");
   const int d = j->d, m = j->m, K = j->K, Kc = j->Kc, cells = j->cells;
   const int alpha_original = alpha;
-  // stage timers in the spirit of the reference's elog(INFO, "TRACK ...") lines (FREDDY_GPU_JOIN_TRACE=1)
-  const bool trace = getenv("FREDDY_GPU_JOIN_TRACE") != nullptr;
+  // stage timers under the names of the reference's elog(INFO, "TRACK <stage> %f") lines (freddy_gpu_last_track)
+  j->track = freddy_track();
   auto now = [] { return std::chrono::steady_clock::now(); };
-  auto t_last = now();
-  auto track = [&](const char* what) {
-    if (!trace) return;
-    auto t = now();
-    fprintf(stderr, "TRACK %s %f\n", what, std::chrono::duration<double>(t - t_last).count());
+  const auto t_start = now();
+  auto t_last = t_start;
+  auto track = [&](double freddy_track::*stage) {
+    const auto t = now();
+    j->track.*stage += std::chrono::duration<double>(t - t_last).count();
     t_last = t;
   };
   if (pvf < 1) pvf = 1;                                                                       // :207-209
@@ -721,7 +718,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     JOIN_HIP(hipGetLastError());
     JOIN_HIP(hipMemcpyAsync(tcell_off.data(), d_tcell, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToHost, s));
   }
-  track("target_resolution_time");   // (enqueue only: the device work overlaps what follows)
+  track(&freddy_track::data_retrieval_time);   // "fq.id IN (targets)" (enqueue only: the device work overlaps what follows)
   JOIN_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc);
   JOIN_HIP(hipGetLastError());
@@ -742,8 +739,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   JOIN_HIP(hipMemcpyAsync(sides.data(), d_sorted, sizeof(JoinSide) * sides.size(), hipMemcpyDeviceToHost, s));
   JOIN_HIP(hipStreamSynchronize(s));
 
-  track("sub_distance_time");
-  track("side_sort_time");
+  track(&freddy_track::precomputation_time);   // sub-distances, side sorts and their way back to the host
   std::vector<int32_t> active(Q), target_count(Q, 0);
   for (int i = 0; i < Q; ++i) active[i] = i;
   std::vector<std::vector<int32_t>> qcells(Q);
@@ -768,7 +764,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       if (any_open) all_last.store(0);
     });
     const bool last = all_last.load() != 0;
-    track("determine_coarse_quantization_time");
+    track(&freddy_track::determine_coarse_quantization_time);
     // targetCounts (:459) and the target-list skip rule (:553-557)
     scan.clear(); qoff.assign(1, 0); flat.clear();
     for (int x = 0; x < n_active; ++x) {
@@ -782,7 +778,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       qoff.push_back((int32_t)flat.size());
     }
     const int n_scan = (int)scan.size();
-    track("query_construction_time");
+    track(&freddy_track::query_construction_time);
     if (n_scan > 0) {
       if (join_buf(j, 6, sizeof(int32_t) * std::max<size_t>(flat.size(), 1), &d_qcells)) return FREDDY_E_NOMEM;
       JOIN_HIP(hipMemcpyAsync(d_scan, scan.data(), sizeof(int32_t) * n_scan, hipMemcpyHostToDevice, s));
@@ -794,18 +790,24 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       a.ids = j->ids; a.codes = j->codes; a.vectors = j->vectors; a.cbT = j->cbT;
       a.out_ids = (int32_t*)d_oi; a.out_dist = (float*)d_od;
       a.d = d; a.m = m; a.K = K; a.S = j->S; a.k = k; a.L = L; a.method = method; a.double_codes = double_codes ? 1 : 0;
+      for (int x = 0; x < n_scan; ++x)
+        for (int i = qoff[(size_t)x]; i < qoff[(size_t)x + 1]; ++i) j->track.candidate_rows += tcell_off[(size_t)flat[(size_t)i] + 1] - tcell_off[(size_t)flat[(size_t)i]];
+      if (!j->ev0) { JOIN_HIP(hipEventCreate(&j->ev0)); JOIN_HIP(hipEventCreate(&j->ev1)); }
+      JOIN_HIP(hipEventRecord(j->ev0, s));
       if (int rc = join_launch(s, a, n_scan, V, lds)) return rc;
+      JOIN_HIP(hipEventRecord(j->ev1, s));
       h_oi.resize((size_t)n_scan * k);
       h_od.resize((size_t)n_scan * k);
       JOIN_HIP(hipMemcpyAsync(h_oi.data(), d_oi, sizeof(int32_t) * h_oi.size(), hipMemcpyDeviceToHost, s));
       JOIN_HIP(hipMemcpyAsync(h_od.data(), d_od, sizeof(float) * h_od.size(), hipMemcpyDeviceToHost, s));
       JOIN_HIP(hipStreamSynchronize(s));
+      { float ms = 0.0f; if (hipEventElapsedTime(&ms, j->ev0, j->ev1) == hipSuccess) j->track.join_kernel_time += 1e-3 * ms; }
       for (int x = 0; x < n_scan; ++x) {
         memcpy(out_ids + (size_t)scan[x] * k, h_oi.data() + (size_t)x * k, sizeof(int32_t) * k);
         memcpy(out_dist + (size_t)scan[x] * k, h_od.data() + (size_t)x * k, sizeof(float) * k);
       }
     }
-    track("computation_time");
+    track(&freddy_track::computation_time);   // LUTs, ADC / exact distances, post verification: one kernel
     if (!last) {                                                                            // :639-669
       std::vector<int32_t> next;
       for (int q : active) {
@@ -819,7 +821,10 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       active.clear();
     }
     alpha += alpha;                                                                         // :680
+    track(&freddy_track::recalculate_query_indices_time);
   }
+  j->track.iterations = iterations;
+  j->track.total_time = std::chrono::duration<double>(now() - t_start).count();
   if (iterations_out) *iterations_out = iterations;
   return 0;
 }

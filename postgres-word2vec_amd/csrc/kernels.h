@@ -227,6 +227,8 @@ struct PlanArgs {
   int32_t* cell_items;      // [C][cell_cap] fused path: the items of each cell, in arrival order (any order is fine)
   int cell_cap;             // >= number of active queries (a query probes a cell at most once)
   int n_active, Cpad, C, W, used_words;
+  float cell_limit;         // a cell at this distance or beyond is never probed: 100.0 (ivfadc_search, the cell list's
+                            // sentinel, freddy.c:266-283), 1000.0 (ivfadc_batch_search, minDist of its argmin, freddy.c:855)
 };
 
 template <int V>
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
   uint32_t* used = a.used + (size_t)q * a.used_words;
   const float* drow = a.dist + (size_t)q * a.Cpad;
 
-  const u64 limit = (u64)__float_as_uint(100.0f) << 32;
+  const u64 limit = (u64)__float_as_uint(a.cell_limit) << 32;
   // Cells are read in batches of PB x 64: distance and used-bitmap word of every slot are independent
   // loads issued together (one wave per query: nothing else would hide their latency).
   constexpr int PB = 8;
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
   wave_sort_full<V>(byp);
   if (V == 1 && W <= 64) {
     // lane i = slot i of the W-entry list; candidates replayed in cell order
-    float d_slot = 100.0f;
+    float d_slot = a.cell_limit;
     int32_t c_slot = -1;
     wave_list_replay(d_slot, c_slot, W, byp[0], L, [](uint32_t hi) { return (int32_t)hi; });
     const bool have = lane < W && c_slot >= 0;
@@ -324,10 +326,10 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
   }
 #pragma unroll
   for (int v = 0; v < V; ++v) cand[v * 64 + lane] = byp[v];
-  for (int i = lane; i < W; i += 64) { sd[i] = 100.0f; sc[i] = -1; }
+  for (int i = lane; i < W; i += 64) { sd[i] = a.cell_limit; sc[i] = -1; }
   __syncthreads();
   if (lane == 0) {
-    float maxd = 100.0f;
+    float maxd = a.cell_limit;
     for (int e = 0; e < L; ++e) {
       const u64 c = cand[e];
       if (c == KEY_INF) break;

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_PKG, "libfreddy_gpu.so")
 
 FOUND_ROWS = 0
 FOUND_ACCEPTED = 1
+FOUND_BATCH_UDF = 2   # ivfadc_batch_search itself (W == 1): accepted-rows rule + its argmin cell limit of 1000
 METHOD_PQ, METHOD_EXACT, METHOD_PQ_PV = 0, 1, 2
 
 EXPORTS = [
@@ -22,7 +23,7 @@ EXPORTS = [
     "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
     "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_filter_bound_checked", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
-    "freddy_gpu_encode",
+    "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells",
 ]
 
 
@@ -102,6 +103,9 @@ def load():
                                                  C.c_void_p]
     lib.freddy_gpu_pq_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_last_probed_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.freddy_gpu_last_track.argtypes = [C.c_void_p, C.c_void_p]
     lib.freddy_gpu_profile_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.freddy_gpu_profile_read.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
@@ -150,6 +154,10 @@ class _Index:
     @property
     def nbytes(self):
         return int(self.lib.freddy_gpu_index_bytes(self.h))
+
+    def set_option(self, name, value):
+        """Tuning / debug switch of this pinned index (include/freddy_gpu.h: freddy_gpu_set_option)."""
+        _check(self.lib.freddy_gpu_set_option(self.h, name.encode(), int(value)))
 
     def profile_enable(self, on=True):
         _check(self.lib.freddy_gpu_profile_enable(self.h, 1 if on else 0))
@@ -261,6 +269,12 @@ class IVFIndex(_Index):
     def last_scanned_rows(self):
         return int(self.lib.freddy_gpu_last_scanned_rows(self.h))
 
+    def last_probed_cells(self):
+        """(distinct cells, rows of their lists) of the last probing round (cell-grouped scans)."""
+        n, r = C.c_int64(0), C.c_int64(0)
+        _check(self.lib.freddy_gpu_last_probed_cells(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
     def bound_violations(self):
         """Rows of the filter + refine scan's exact stage whose distance left the proven bracket (must be 0)."""
         return int(self.lib.freddy_gpu_filter_bound_violations(self.h))
@@ -297,6 +311,22 @@ class IVPQIndex(_Index):
                                             1 if use_target_lists else 0, C.c_float(confidence),
                                             double_threshold, _p(out_i), _p(out_d), C.byref(iters)))
         return out_i, out_d, iters.value
+
+    def last_track(self):
+        """{stage name: seconds} of the most recent knn_join call (the reference's TRACK lines)."""
+        t = Track()
+        _check(self.lib.freddy_gpu_last_track(self.h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in Track._fields_ if n != "reserved"}
+
+
+class Track(C.Structure):
+    """freddy_track: stage timers under the reference's TRACK names (ivpq_search_in.c:234-697)."""
+    _fields_ = [("precomputation_time", C.c_double), ("determine_coarse_quantization_time", C.c_double),
+                ("query_construction_time", C.c_double), ("data_retrieval_time", C.c_double),
+                ("computation_time", C.c_double), ("pv_computation_time", C.c_double),
+                ("recalculate_query_indices_time", C.c_double), ("total_time", C.c_double),
+                ("join_kernel_time", C.c_double), ("candidate_rows", C.c_int64),
+                ("iterations", C.c_int32), ("reserved", C.c_int32)]
 
 
 class EncodeDesc(C.Structure):

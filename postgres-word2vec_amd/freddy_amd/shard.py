@@ -49,3 +49,53 @@ def sharded_search(search_fn, queries, k, group=None):
     lo, hi = shard_bounds(Q, rank, world)
     ids, dd = search_fn(queries[lo:hi])
     return gather_topk(ids, dd, Q, group)
+
+
+class PipelinedGather:
+    """Double-buffered, asynchronous gather of the per-shard top-k (what bench.py times).
+
+    ids and distances of a shard live in ONE [2][q_local][k] int32 buffer (row 0 = ids, row 1 = the
+    distances' bits), so a step's results cross xGMI in a single all_gather (40 KB per rank at Q=1024, k=5:
+    pure latency).  `depth` such buffers alternate: the gather of step i only has to be finished before its
+    buffers are reused by step i+depth, so its latency hides under the next step's kernels.
+
+    Ordering contract: the search of a step must be enqueued on torch's CURRENT stream (pass its handle to
+    the C ABI) between next_buffer() and submit().  The collective is enqueued behind that stream's work,
+    and wait() makes the current stream wait for it before the buffer is written again."""
+
+    def __init__(self, q_local, k, device, group=None, depth=2):
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.group, self.depth = group, depth
+        self.res = [torch.zeros((2, q_local, k), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.gathered = ([torch.zeros((self.world, 2, q_local, k), dtype=torch.int32, device=device) for _ in range(depth)]
+                         if self.world > 1 else None)
+        self.pending = [None] * depth
+        self.steps = 0
+        self.cur = 0
+
+    def next_buffer(self):
+        """The [2][q_local][k] buffer of the coming step (its previous gather is waited for first)."""
+        b = self.steps % self.depth
+        self.steps += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self.cur = b
+        return self.res[b]
+
+    def submit(self):
+        """Start the gather of the buffer handed out last."""
+        if self.world > 1:
+            b = self.cur
+            self.pending[b] = dist.all_gather_into_tensor(self.gathered[b].view(-1), self.res[b].view(-1),
+                                                          group=self.group, async_op=True)
+
+    def drain(self):
+        for b in range(self.depth):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def last(self):
+        """(local buffer, gathered [world][2][q_local][k] or None) of the most recent step; drain() first."""
+        return self.res[self.cur], (self.gathered[self.cur] if self.gathered is not None else None)

@@ -328,7 +328,7 @@ int ivfadc_batch_search(freddy_session_t* s, const int32_t* query_ids, int32_t n
   }
   std::vector<int32_t> ids((size_t)Q * k); std::vector<float> dist((size_t)Q * k);
   if (Q > 0)
-    if (int rc = freddy_gpu_ivfadc_search(s->ivf, qv.data(), Q, k, 1, 100.0f, FREDDY_FOUND_ACCEPTED, ids.data(), dist.data()))
+    if (int rc = freddy_gpu_ivfadc_search(s->ivf, qv.data(), Q, k, 1, 100.0f, FREDDY_FOUND_BATCH_UDF, ids.data(), dist.data()))
       return gpu_fail(rc);
   return emit3(qid.data(), Q, k, ids, dist, out, n_rows);
 }

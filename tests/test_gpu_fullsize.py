@@ -54,6 +54,25 @@ def test_config3_ivfadc_batch_3m(oracle):
         util.assert_same_lists(gi, gd, exp, f"config 3 W={W}")
     # the query is an indexed vector: its own id must be in its result (at ADC distance rank 1 up to ties)
     assert (gi == qid[:, None]).any(axis=1).mean() > 0.99
+    # The benchmarked instantiation in the every-row mode (ivf_filter_kernel<12, true>, all ~31 M probed rows
+    # kept by the scan and refined by the merge): the proven bracket [d_lo, d_lo + E] is compared with the
+    # reference's distance for EVERY probed row of this batch, and the lists must not change.
+    gi0, gd0 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
+    idx.set_option("fused_ablate", 8)
+    idx.set_option("merge_ablate", 32)
+    before = idx.bound_checked()
+    gi1, gd1 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
+    rows = idx.last_scanned_rows()
+    assert rows > 25_000_000
+    assert idx.bound_checked() - before == rows, f"{idx.bound_checked() - before} brackets checked, {rows} rows probed"
+    assert idx.bound_violations() == 0
+    assert np.array_equal(gi0, gi1) and np.array_equal(gd0.view(np.uint32), gd1.view(np.uint32))
+    idx.set_option("fused_ablate", 0)
+    idx.set_option("merge_ablate", 0)
+    # ... and the exact scan (the reference's arithmetic for every row, fused3.h) on the same batch
+    idx.set_option("fused_kernel", 3)
+    gi3, gd3 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
+    assert np.array_equal(gi0, gi3) and np.array_equal(gd0.view(np.uint32), gd3.view(np.uint32))
     idx.close()
 
 

@@ -74,12 +74,12 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
     idx.close()
 
 
-@pytest.mark.parametrize("variant", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("variant", ["3", "4"])
 @pytest.mark.parametrize("K", [256, 1024])
 def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
-    """The three fused kernels (FREDDY_GPU_FUSED_KERNEL: 1 symmetric fused.h, 2 one builder wave per SIMD
-    fused2.h, 3 = default, two builder waves per SIMD and 12-item entries fused3.h) against the oracle:
-    many queries per cell (entries of every size incl. split cells), both found rules, k up to 32."""
+    """The two cell-grouped scans (FREDDY_GPU_FUSED_KERNEL: 3 = the reference's arithmetic for every row,
+    fused3.h; 4 = default, filter + refine, fused4.h) against the oracle: many queries per cell (entries of
+    every size incl. split cells), both found rules, k up to 32."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     monkeypatch.setenv("FREDDY_GPU_FUSED_KERNEL", variant)
     N = 20000
@@ -104,9 +104,36 @@ def test_ivfadc_batch_udf_semantics(gpu, oracle, fused, monkeypatch):
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     _, qs = util.queries_from_corpus(N, 100)
-    gi, gd = idx.search(qs, 5, 1, sentinel=100.0, found_rule=gpu.FOUND_ACCEPTED)
+    gi, gd = idx.search(qs, 5, 1, sentinel=100.0, found_rule=gpu.FOUND_BATCH_UDF)
     exp = oracle.ivfadc_batch_search(ot, qs, 5)
     util.assert_same_lists(gi, gd, exp, "ivfadc_batch_search")
+    idx.close()
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("scale", [14.0, 20.0])
+def test_ivfadc_batch_udf_cell_limit(gpu, oracle, fused, scale, monkeypatch):
+    """Non-normalised data: ivfadc_batch_search picks its cell by argmin from minDist = 1000 (freddy.c:853-866),
+    ivfadc_search's cell list never admits a cell at distance >= 100 (freddy.c:266-283).  With every coarse
+    distance in [100, 1000) the batch UDF keeps probing where the W-probe search retires the query."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
+    N = 20000
+    t = dict(util.ivf_tables(N=N, C=32, K=256))
+    t["coarse"] = (t["coarse"] * np.float32(scale)).astype(np.float32)
+    t["codebook"] = (t["codebook"] * np.float32(scale)).astype(np.float32)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 80)
+    qs = (qs * np.float32(scale)).astype(np.float32)
+    qs[::2] += np.float32(0.04 * scale)        # pushed further out: every row beyond the sentinel, all 32 cells get probed
+    gi, gd = idx.search(qs, 5, 1, sentinel=100.0, found_rule=gpu.FOUND_BATCH_UDF)
+    exp = oracle.ivfadc_batch_search(ot, qs, 5)
+    util.assert_same_lists(gi, gd, exp, f"ivfadc_batch_search, data x{scale}")
+    # the same queries under ivfadc_search's rule (cell list sentinel 100.0)
+    gi2, gd2 = idx.search(qs, 5, 1, sentinel=100.0, found_rule=gpu.FOUND_ACCEPTED)
+    exp2 = oracle.ivfadc_search_many(ot, qs, 5, 1, sentinel=100.0, found_rule=1)
+    util.assert_same_lists(gi2, gd2, exp2, f"ivfadc_search W=1, data x{scale}")
+    assert not np.array_equal(exp["id"].reshape(gi.shape), exp2["id"].reshape(gi.shape)), "the two cell limits must be told apart by this test"
     idx.close()
 
 
@@ -489,10 +516,10 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
     kernel's self-check compares the proven bracket [d_lo, d_lo + E] with the reference's distance for all
     rows, not only for the few a normal run refines.  Results must not change either."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
-    monkeypatch.setenv("FREDDY_GPU_FUSED_ABLATE", "8")
-    monkeypatch.setenv("FREDDY_GPU_MERGE_ABLATE", "32")
     for scale in (1.0, 1e-12, 8.0):   # (x8: coarse distances stay below the probe plan's limit of 100)
         t, ot, idx, qs = _fr_setup(gpu, oracle, scale=scale)
+        idx.set_option("fused_ablate", 8)
+        idx.set_option("merge_ablate", 32)
         qs = qs[:48]
         gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
         exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
@@ -500,6 +527,90 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
         assert idx.bound_checked() > 20000, f"scale {scale}: {idx.bound_checked()} brackets checked"   # every probed row ...
         assert idx.bound_violations() == 0             # ... and none was violated
         idx.close()
+
+
+def _every_row_check(idx, oracle, ot, qs, k, W, what):
+    """Every probed row kept by the scan and refined by the merge: the kernel's self-check then compares the
+    proven bracket with the reference's distance for ALL of them.  Returns the lists."""
+    idx.set_option("fused", 1)
+    idx.set_option("fused_kernel", 4)
+    idx.set_option("fused_ablate", 8)
+    idx.set_option("merge_ablate", 32)
+    before = idx.bound_checked()
+    gi, gd = idx.search(qs, k, W, sentinel=1000.0, found_rule=0)
+    checked = idx.bound_checked() - before
+    rows = idx.last_scanned_rows()
+    assert checked == rows, f"{what}: {checked} brackets checked, {rows} rows probed"
+    assert idx.bound_violations() == 0, f"{what}: a row's distance left its proven bracket"
+    idx.set_option("fused_ablate", 0)
+    idx.set_option("merge_ablate", 0)
+    exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0, found_rule=0)
+    util.assert_same_lists(gi, gd, exp, what)
+    return gi, gd
+
+
+def test_filter_refine_bracket_every_row_K1024(gpu, oracle, monkeypatch):
+    """The instantiation the benchmark runs -- ivf_filter_kernel<12, true>, K = 1024 -- in the every-row mode:
+    brackets checked == rows probed, none violated, lists equal to the oracle's, to the exact scan's
+    (fused3.h) and to the normal filter + refine run."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    for scale in (1.0, 1e-12, 8.0):
+        t, ot, idx, qs = _fr_setup(gpu, oracle, K=1024, scale=scale)
+        qs = qs[:96]
+        gi, gd = _every_row_check(idx, oracle, ot, qs, 5, 3, f"K=1024 every row, scale {scale}")
+        idx.set_option("fused_kernel", 3)
+        ei, ed = idx.search(qs, 5, 3, sentinel=1000.0, found_rule=0)
+        idx.set_option("fused_kernel", 4)
+        ni, nd = idx.search(qs, 5, 3, sentinel=1000.0, found_rule=0)
+        assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32)), "exact scan differs"
+        assert np.array_equal(gi, ni) and np.array_equal(gd.view(np.uint32), nd.view(np.uint32)), "normal run differs"
+        idx.close()
+
+
+def _adversarial_tables(kind, K):
+    """Index tables that stress the FIXED-POINT term of the filter's cheap distance (16-bit query x codeword
+    table with one scale per (query, position), scale = 2 |q_p| max|c_p| / 32767)."""
+    t = dict(util.ivf_tables(N=20000, C=32, K=K))
+    cb = t["codebook"].copy()
+    if kind == "huge_codeword":
+        # one codeword per position 200x longer than the others: max|c_p| -- and with it the scale of every
+        # table entry of that position -- grows 200x, i.e. typical entries keep ~7 bits
+        for p in range(cb.shape[0]):
+            cb[p, (7 * p + 3) % K] *= np.float32(200.0)
+    elif kind == "huge_codeword_used":
+        # ... and rows that actually carry such a codeword (their distances are huge, the others' are not)
+        for p in range(cb.shape[0]):
+            cb[p, (7 * p + 3) % K] *= np.float32(50.0)
+        codes = t["codes"].copy()
+        codes[::97, 5] = (7 * 5 + 3) % K
+        t["codes"] = codes
+    t["codebook"] = cb
+    return t
+
+
+@pytest.mark.parametrize("kind", ["huge_codeword", "huge_codeword_used", "dominant_subvector", "K300", "K40"])
+def test_filter_refine_adversarial_fixed_point(gpu, oracle, kind, monkeypatch):
+    """Inputs chosen against the fixed-point table: coarse scales (one huge codeword per position), queries
+    whose norm sits in ONE sub-vector (one position's scale dwarfs the rest), and K < 512 / K not a
+    multiple of anything (padding slots of the [512]-pair table layout).  Normal run and every-row run."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    K = {"K300": 300, "K40": 40}.get(kind, 1024 if kind != "dominant_subvector" else 256)
+    t = _adversarial_tables(kind, K)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(20000, 72)
+    if kind == "dominant_subvector":
+        qs = qs.copy()
+        for i in range(len(qs)):
+            p = i % 12
+            qs[i, p * 25:(p + 1) * 25] *= np.float32(40.0 if i % 2 else 6.0)
+    for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 2, 1, 100.0)):
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"{kind} k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0
+    _every_row_check(idx, oracle, ot, qs[:40], 5, 2, f"{kind}, every row")
+    idx.close()
 
 
 @pytest.mark.parametrize("arrange", ["0", "1"])
@@ -512,9 +623,9 @@ def test_row_order_inside_a_list_is_free(gpu, oracle, arrange, monkeypatch):
     idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     _, qs = util.queries_from_corpus(20000, 150)
     exp = oracle.ivfadc_search_many(ot, qs, 10, 3, sentinel=1000.0, found_rule=0)
-    for fused, variant in (("1", "4"), ("1", "3"), ("0", "4")):
-        monkeypatch.setenv("FREDDY_GPU_FUSED", fused)
-        monkeypatch.setenv("FREDDY_GPU_FUSED_KERNEL", variant)
+    for fused, variant in ((1, 4), (1, 3), (0, 4)):
+        idx.set_option("fused", fused)
+        idx.set_option("fused_kernel", variant)
         gi, gd = idx.search(qs, 10, 3, sentinel=1000.0, found_rule=0)
         util.assert_same_lists(gi, gd, exp, f"arrange={arrange} fused={fused} kernel={variant}")
     idx.close()

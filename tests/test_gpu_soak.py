@@ -1,20 +1,24 @@
-"""GPU-box helper: long randomised soak of the fused IVFADC kernels against the oracle (the shapes of
-tests/test_gpu_parity.py::test_ivfadc_randomised_small_indexes, many more seeds, both cell-grouped scans; the fixed-seed version runs in tests/test_gpu_soak.py)."""
-import os, sys, time
+"""-m gpu: randomised soak of the IVFADC scans against the oracle with a FIXED seed budget (the long version
+is tools/soak_fused.py): random shapes -- K from 4 to 1024, 1 to 40 cells incl. empty ones, 50 to 30 000
+rows, 1 to 5000 distinct code rows (i.e. from "every distance equal" to "all different"), 1 to 700 queries
+-- both cell-grouped scans and the generic kernels, both found rules."""
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "postgres-word2vec_amd"), os.path.join(ROOT, "tests")]
-import torch  # noqa: F401
-from freddy_amd import gpu
-from oracle.oracle import Oracle
+import pytest
+
 import util
 
-oracle = Oracle()
-os.environ["FREDDY_GPU_FUSED"] = "1"
-seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-t0 = time.time()
-n = 0
-for seed in range(seeds):
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from freddy_amd import gpu as g
+    g.load()
+    return g
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_soak_random_index(gpu, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     d, m = 300, 12
     K = int(rng.choice([4, 16, 64, 256, 1024]))
@@ -24,7 +28,7 @@ for seed in range(seeds):
     codebook = (rng.standard_normal((m, K, 25)) * 0.3).astype(np.float32)
     cell = rng.integers(0, C, size=N) if seed % 3 else np.zeros(N, np.int64)
     if C > 2:
-        cell[cell == 1] = 0
+        cell[cell == 1] = 0          # an empty list
     order = np.argsort(cell, kind="stable")
     ids = (np.arange(N) * 3 + 7).astype(np.int32)[order]
     n_distinct = int(rng.choice([1, 3, 50, 5000]))
@@ -37,13 +41,14 @@ for seed in range(seeds):
     idx = gpu.IVFIndex(coarse, codebook, list_off, ids_sorted, codes)
     Q = int(rng.choice([1, 40, 300, 700]))
     qs = (coarse[rng.integers(0, C, size=Q)] + 0.2 * rng.standard_normal((Q, d))).astype(np.float32)
-    for variant in (4, 3):
+    for fused, variant in ((1, 4), (1, 3), (0, 4)):
+        idx.set_option("fused", fused)
         idx.set_option("fused_kernel", variant)
         for k, W in [(1, 1), (5, min(3, C)), (32, min(C, 12))]:
             for rule, sent in [(0, 1000.0), (1, 100.0)]:
                 gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
                 exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-                util.assert_same_lists(gi, gd, exp, f"seed={seed} variant={variant} K={K} C={C} N={N} Q={Q} k={k} W={W} rule={rule}")
-                n += 1
+                util.assert_same_lists(gi, gd, exp, f"seed={seed} fused={fused} kernel={variant} K={K} C={C} N={N} Q={Q} "
+                                                    f"k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0
     idx.close()
-print(f"soak ok: {n} searches over {seeds} random indexes in {time.time() - t0:.1f}s")

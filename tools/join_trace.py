@@ -12,5 +12,6 @@ qid = rng.choice(np.arange(1, N + 1), 5000, replace=False)
 targets = rng.choice(np.arange(1, N + 1), 100000, replace=False).astype(np.int32)
 qs = t["vectors"][qid - 1]
 idx.knn_join(qs, 5, targets, 100, 20, 2)
-os.environ["FREDDY_GPU_JOIN_TRACE"] = "1"
 t0 = time.perf_counter(); idx.knn_join(qs, 5, targets, 100, 20, 2); print("total", time.perf_counter() - t0)
+for name, v in idx.last_track().items():   # the reference's TRACK stage names (freddy_gpu_last_track)
+    print("TRACK", name, v)
