@@ -216,7 +216,8 @@ int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
 /* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
  * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (4 filter +
  * refine, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
- * row, used by the tests' exhaustive bound check), "side_stream", "fused_prof", "debug_surv",
+ * row, used by the tests' exhaustive bound check), "side_stream", "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
+ * "coarse_refine_all", "fused_prof", "debug_surv",
  * "lut_budget_mb".  No setting changes a result. */
 int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);
 
@@ -246,6 +247,11 @@ int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* index);
 /* How many rows that check has seen -- counted only in the tests' refine-every-row mode
  * (option merge_ablate = 32), where it is the number of probed rows; 0 otherwise. */
 int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* index);
+/* The coarse-cell selection is a filter + refine too (MFMA distances with a proven bracket, the reference's
+ * squareDistance for the candidate cells): refined cells whose distance left the bracket are
+ * INCLUDED in freddy_gpu_filter_bound_violations; this returns how many cells the tests' refine-every-cell mode
+ * (option coarse_refine_all = 1) has checked. */
+int64_t freddy_gpu_coarse_bound_checked(const freddy_gpu_index_t* index);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@
 #include "scan_common.h"
 #include "fused3.h"
 #include "fused4.h"
+#include "coarse.h"
 #include "exact.h"
 #include "join.h"
 
@@ -67,6 +68,8 @@ struct Tuning {
   int scan_kernel = 4;         // FREDDY_GPU_FUSED_KERNEL: 4 filter + refine (fused4.h), 3 exact fused scan (fused3.h)
   uint32_t scan_ablate = 0;    // FREDDY_GPU_FUSED_ABLATE: timing experiments / 8 = keep every row (tests)
   uint32_t merge_ablate = 0;   // FREDDY_GPU_MERGE_ABLATE: timing experiments / 32 = refine every row (tests)
+  int coarse_approx = 1;       // FREDDY_GPU_COARSE_APPROX: cell selection as filter + refine (coarse.h); 0 = every distance exact
+  int coarse_refine_all = 0;   // tests: refine every cell (exhaustive check of the coarse bracket)
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
@@ -85,6 +88,7 @@ static Tuning read_tuning() {
   t.scan_ablate = (uint32_t)env_int("FREDDY_GPU_FUSED_ABLATE", 0);
   t.merge_ablate = (uint32_t)env_int("FREDDY_GPU_MERGE_ABLATE", 0);
   t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
+  t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
@@ -133,6 +137,10 @@ struct freddy_gpu_index {
   // pinned tables
   float* coarse = nullptr;      // [C][d]
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
+  float* coarseP = nullptr;     // [Cpad][dp] zero-padded rows for the MFMA coarse kernel (coarse.h)
+  float* cn2 = nullptr;         // [Cpad] |c_j|^2
+  float cmax = 0.0f;            // max_j |c_j|, rounded up
+  int dp = 0;
   int Cpad = 0;
   float* cbT = nullptr;         // [m][S][K]
   float* cbP = nullptr;         // fused kernel layout [m][SP/4][512 slots][4 dims][2 codes] (NULL unless K <= 1024)
@@ -141,7 +149,7 @@ struct freddy_gpu_index {
   float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
-  int32_t* viol = nullptr;      // [2] self-check counters of the exact stage
+  int32_t* viol = nullptr;      // [4] self-check counters: scan bracket violations / rows checked, coarse bracket violations / cells checked
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
@@ -157,7 +165,7 @@ struct freddy_gpu_index {
   // workspaces
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -194,7 +202,7 @@ static void free_index(freddy_gpu_index* ix) {
   if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
   if (ix->ev_q) (void)hipEventDestroy(ix->ev_q);
   if (ix->ev_qc) (void)hipEventDestroy(ix->ev_qc);
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
@@ -202,7 +210,7 @@ static void free_index(freddy_gpu_index* ix) {
                     &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
                     &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
                     &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
-                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof, &ix->w_qc, &ix->w_qn, &ix->w_records};
+                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof, &ix->w_qc, &ix->w_qn, &ix->w_records, &ix->w_qn2, &ix->w_item_dist};
   for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
     for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -431,6 +439,25 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
         upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes) ||
         upload(&ix->coarseT, cT.data(), cT.size(), &ix->bytes))
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    if (!rc) {   // MFMA coarse kernel (coarse.h): zero-padded rows, squared norms (fp64, rounded once), largest norm
+      ix->dp = (t->d + COARSE_DP_ALIGN - 1) / COARSE_DP_ALIGN * COARSE_DP_ALIGN;
+      std::vector<float> cP((size_t)ix->Cpad * ix->dp, 0.0f), cn2((size_t)ix->Cpad, 0.0f);
+      double cmax2 = 0.0;
+      for (int c = 0; c < t->C; ++c) {
+        double n2 = 0.0;
+        for (int i = 0; i < t->d; ++i) {
+          const float v = t->coarse[(size_t)c * t->d + i];
+          cP[(size_t)c * ix->dp + i] = v;
+          n2 += (double)v * (double)v;
+        }
+        cn2[(size_t)c] = (float)n2;
+        cmax2 = std::max(cmax2, n2);
+      }
+      ix->cmax = (float)(std::sqrt(cmax2) * (1.0 + 1e-6));
+      if (upload(&ix->coarseP, cP.data(), cP.size(), &ix->bytes) || upload(&ix->cn2, cn2.data(), cn2.size(), &ix->bytes) ||
+          hipMalloc((void**)&ix->viol, 4 * sizeof(int32_t)) != hipSuccess || hipMemset(ix->viol, 0, 4 * sizeof(int32_t)) != hipSuccess)
+        rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    }
     if (!rc && ix->K <= FUSED_T * FUSED_E) {
       // paired layout of the fused kernels: slot t holds codes (t, t+512); 4 dims x 2 codes per 32 bytes.
       // (Splitting the two 16-byte halves of a slot into separate contiguous arrays measured SLOWER: the
@@ -475,8 +502,7 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
   if (!rc && ix->cbR) {   // one float per row slot: the (cell, row) part of the filter's cheap distance
     const int64_t n_slots = std::max<int64_t>(ix->n_blocks, 1) * 64;
-    if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess ||
-        hipMalloc((void**)&ix->viol, 2 * sizeof(int32_t)) != hipSuccess || hipMemset(ix->viol, 0, 2 * sizeof(int32_t)) != hipSuccess)
+    if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess)
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     if (!rc && ix->n_blocks > 0) {
       ix->bytes += (int64_t)sizeof(float) * n_slots;
@@ -545,14 +571,15 @@ extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_
 
 static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
   if (!ix || !ix->viol) return 0;
-  int32_t h[2] = {0, 0};
+  int32_t h[4] = {0, 0, 0, 0};
   if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
       hipMemcpy(h, ix->viol, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
-  return h[which];
+  return which == 0 ? (int64_t)h[0] + h[2] : h[which];
 }
 extern "C" int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* ix) { return read_viol(ix, 0); }
 extern "C" int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* ix) { return read_viol(ix, 1); }
+extern "C" int64_t freddy_gpu_coarse_bound_checked(const freddy_gpu_index_t* ix) { return read_viol(ix, 3); }
 
 extern "C" int freddy_gpu_profile_enable(freddy_gpu_index_t* ix, int32_t enable) {
   if (!ix) return fail(FREDDY_E_ARG, "NULL index");
@@ -597,6 +624,8 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "fused_ablate") t.scan_ablate = (uint32_t)value;
   else if (n == "merge_ablate") t.merge_ablate = (uint32_t)value;
   else if (n == "side_stream") t.side_stream = (int)value;
+  else if (n == "coarse_approx") t.coarse_approx = (int)value;
+  else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
   else if (n == "debug_surv") t.debug_surv = (int)value;
   else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
@@ -697,6 +726,7 @@ struct IvfRun {
   bool fused;          // cell-grouped scans (fused3.h / fused4.h) instead of lut_build + adc_scan
   int scan_kernel;     // 4: filter + refine, 3: exact fused scan
   bool tiled;          // the batch coarse kernel also clears the round-one scratch
+  bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
   bool qc_pending;     // the query x codebook table is being built on the side stream
   // per round
   int n_active, round;
@@ -755,7 +785,10 @@ static int ivf_coarse(IvfRun& r) {
     }
   }
   timed_launch(ix, s, "coarse_dist", [&] {
-    if (r.tiled)
+    if (r.approx)
+      hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseP, ix->cn2,
+                         ix->w_distT.as<float>(), ix->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
+    else if (r.tiled)
       hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
                          ix->w_distT.as<float>(), Q, Cpad, d, za);
     else
@@ -774,6 +807,7 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
   pa.dist = ix->w_distT.as<float>(); pa.active = r.active; pa.list_off = ix->list_off;
   pa.used = ix->w_used.as<uint32_t>();
   pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
+  pa.item_dist = ix->w_item_dist.as<float>();
   pa.round_rows = ix->w_rows.as<int32_t>();
   pa.n_active = r.n_active; pa.Cpad = ix->Cpad; pa.C = C; pa.W = W; pa.used_words = (C + 31) / 32;
   pa.cell_count = r.fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
@@ -786,6 +820,12 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
   }
   const int PV = pick_V(2 * W);
   const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
+  if (r.approx) {
+    Plan2Args g;
+    g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ix->w_qn2.as<float>(); g.item_dist = pa.item_dist;
+    g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all;
+    timed_launch(ix, s, "probe_plan", [&] { hipLaunchKernelGGL(probe_plan2_kernel, dim3(r.n_active), dim3(64), 0, s, g); });
+  } else
   timed_launch(ix, s, "probe_plan", [&] {
     switch (PV) {
       case 1: hipLaunchKernelGGL((probe_plan_kernel<1>), dim3(r.n_active), dim3(64), plan_lds, s, pa); break;
@@ -859,8 +899,8 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
   ra.sorted_item = ix->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
-  ra.dist = ix->w_distT.as<float>(); ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
-  ra.records = ix->w_records.as<int32_t>(); ra.Cpad = ix->Cpad; ra.sentinel = r.sentinel;
+  ra.item_dist = pa.item_dist; ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
+  ra.records = ix->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
   if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ix->ev_qc, 0)); r.qc_pending = false; }
   timed_launch(ix, s, "entry_records", [&] {
     hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
@@ -1010,11 +1050,14 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
             (ix->tune.fused == 1 || items >= 256);
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : 4;
   r.tiled = Q >= 32;
+  // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
+  r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->coarseP;
   const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
       ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ix->w_qn2.ensure(sizeof(float) * Q) || ix->w_item_dist.ensure(sizeof(float) * items) ||
       ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
       ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);

@@ -219,12 +219,11 @@ struct RecordArgs {
   const int32_t* item_query;
   const int32_t* blk_off;
   const int32_t* list_off;
-  const float* dist;
+  const float* item_dist;   // [items] exact coarse distance of every item (probe plan)
   const float* qn;
   const float* qscale;
   const float* pmax;
   int32_t* records;
-  int Cpad;
   float sentinel;
 };
 
@@ -249,7 +248,7 @@ __global__ __launch_bounds__(256) void entry_record_kernel(RecordArgs a) {
     const int it = lane < cnt ? a.sorted_item[first + lane] : -1;
     q = a.item_query[it >= 0 ? it : a.sorted_item[first]];
     ItemBounds ib = item_bounds(0.0f, 0.0f, a.sentinel);
-    if (it >= 0) ib = item_bounds(a.dist[(size_t)q * a.Cpad + cell], filter_width<M>(a.qn + (size_t)q * M, a.pmax), a.sentinel);
+    if (it >= 0) ib = item_bounds(a.item_dist[it], filter_width<M>(a.qn + (size_t)q * M, a.pmax), a.sentinel);
     rec[8 + lane] = it;
     rec[24 + lane] = q;
     rec[40 + lane] = (int32_t)__float_as_uint(ib.off);

@@ -222,6 +222,7 @@ struct PlanArgs {
   uint32_t* used;           // [Q][used_words] bitmap of cells already probed
   int32_t* item_cell;       // [n_active*W]
   int32_t* item_query;      // [n_active*W]
+  float* item_dist;         // [n_active*W] or NULL: the item's coarse distance (the scan's bound on |r|^2)
   int32_t* round_rows;      // [n_active] rows retrieved this round, -1 = no cell was left
   int32_t* cell_count;      // [C] fused path only (NULL otherwise): += items probing each cell
   int32_t* cell_items;      // [C][cell_cap] fused path: the items of each cell, in arrival order (any order is fine)
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
     if (lane < W) {
       a.item_cell[(size_t)x * W + lane] = c_slot;
       a.item_query[(size_t)x * W + lane] = q;
+      if (a.item_dist) a.item_dist[(size_t)x * W + lane] = d_slot;
     }
     return;
   }
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
   for (int i = lane; i < W; i += 64) {
     a.item_cell[(size_t)x * W + i] = sc[i];
     a.item_query[(size_t)x * W + i] = q;
+    if (a.item_dist) a.item_dist[(size_t)x * W + i] = sd[i];
   }
 }
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "freddy_gpu_ivfadc_search_dev", "freddy_gpu_pq_search_dev", "freddy_gpu_last_error",
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
     "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_filter_bound_checked", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
-    "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells",
+    "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells", "freddy_gpu_coarse_bound_checked",
 ]
 
 
@@ -84,6 +84,8 @@ def load():
     lib.freddy_gpu_filter_bound_violations.argtypes = [C.c_void_p]
     lib.freddy_gpu_filter_bound_checked.restype = C.c_int64
     lib.freddy_gpu_filter_bound_checked.argtypes = [C.c_void_p]
+    lib.freddy_gpu_coarse_bound_checked.restype = C.c_int64
+    lib.freddy_gpu_coarse_bound_checked.argtypes = [C.c_void_p]
     lib.freddy_gpu_pin_pq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivpq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -278,6 +280,9 @@ class IVFIndex(_Index):
     def bound_violations(self):
         """Rows of the filter + refine scan's exact stage whose distance left the proven bracket (must be 0)."""
         return int(self.lib.freddy_gpu_filter_bound_violations(self.h))
+
+    def coarse_bound_checked(self):
+        return int(self.lib.freddy_gpu_coarse_bound_checked(self.h))
 
     def bound_checked(self):
         return int(self.lib.freddy_gpu_filter_bound_checked(self.h))

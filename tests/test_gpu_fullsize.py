@@ -69,6 +69,18 @@ def test_config3_ivfadc_batch_3m(oracle):
     assert np.array_equal(gi0, gi1) and np.array_equal(gd0.view(np.uint32), gd1.view(np.uint32))
     idx.set_option("fused_ablate", 0)
     idx.set_option("merge_ablate", 0)
+    # the coarse filter + refine's bracket for EVERY (query, cell) pair of the batch (1024 x 1000)
+    idx.set_option("coarse_refine_all", 1)
+    before = idx.coarse_bound_checked()
+    gi2, gd2 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
+    assert idx.coarse_bound_checked() - before == 1024 * 1000
+    assert idx.bound_violations() == 0
+    assert np.array_equal(gi0, gi2) and np.array_equal(gd0.view(np.uint32), gd2.view(np.uint32))
+    idx.set_option("coarse_refine_all", 0)
+    idx.set_option("coarse_approx", 0)     # every coarse distance exact (coarse_tile_kernel)
+    gi2, gd2 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
+    assert np.array_equal(gi0, gi2) and np.array_equal(gd0.view(np.uint32), gd2.view(np.uint32))
+    idx.set_option("coarse_approx", 1)
     # ... and the exact scan (the reference's arithmetic for every row, fused3.h) on the same batch
     idx.set_option("fused_kernel", 3)
     gi3, gd3 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)

@@ -529,6 +529,77 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
         idx.close()
 
 
+# ---------------------------------------------------------------------------------------
+# coarse-cell selection as filter + refine (coarse.h): MFMA distances with a proven bracket, the reference's
+# squareDistance for the candidate cells only
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scale", [1.0, 1e-12, 8.0, 1e4])
+def test_coarse_filter_refine_every_cell(gpu, oracle, scale, monkeypatch):
+    """Debug switch coarse_refine_all: EVERY (query, cell) pair gets both the MFMA value and the reference's
+    distance, the kernel counts the pairs outside the bracket; the lists equal the oracle's and the ones of
+    the all-exact coarse kernel (option coarse_approx = 0)."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, K=256, scale=scale)
+    C = len(t["list_off"]) - 1
+    for k, W, rule, sent in ((5, 3, 0, 1000.0), (3, 1, 1, 100.0), (8, 10, 0, 1000.0)):
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        idx.set_option("coarse_approx", 1)
+        idx.set_option("coarse_refine_all", 1)
+        before = idx.coarse_bound_checked()
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"coarse refine all, scale {scale} k={k} W={W}")
+        assert idx.coarse_bound_checked() - before >= len(qs) * C      # first round: every cell of every query
+        idx.set_option("coarse_refine_all", 0)
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"coarse filter + refine, scale {scale} k={k} W={W}")
+        idx.set_option("coarse_approx", 0)
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"coarse all exact, scale {scale} k={k} W={W}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+@pytest.mark.parametrize("kind", ["duplicate_centroids", "one_huge_centroid", "far_queries", "tiny_cells_many_rounds"])
+def test_coarse_filter_refine_adversarial(gpu, oracle, kind, monkeypatch):
+    """Equal coarse distances (identical centroids: the lowest cell index has to win exactly as in the
+    reference's strict '<' / updateTopK), a centroid whose norm dwarfs the others (the bracket's width follows
+    the LARGEST centroid norm: many candidates), queries far from everything (distances beyond the cell
+    limit of 100), and extra probing rounds (cells already used are masked)."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    rng = np.random.default_rng(11)
+    if kind == "tiny_cells_many_rounds":
+        N = 900
+        x = util.corpus(N)
+        from freddy_amd import index_build as ib
+        t = dict(ib.build_ivf_index(x, C=200, m=12, K=64, train_size=N, iters=3, seed=9))
+        qs = np.repeat(x.numpy()[::9].astype(np.float32), 1, axis=0)
+    else:
+        t = dict(util.ivf_tables(N=20000, C=32, K=256))
+        _, qs = util.queries_from_corpus(20000, 90)
+    coarse = t["coarse"].copy()
+    if kind == "duplicate_centroids":
+        coarse[5] = coarse[17]
+        coarse[30] = coarse[2]
+        coarse[3] = coarse[2]
+    elif kind == "one_huge_centroid":
+        coarse[9] *= np.float32(300.0)
+    elif kind == "far_queries":
+        qs = qs.copy()
+        qs[::3] += np.float32(0.5)     # coarse distances ~75 + : some beyond the limit of 100, some just below
+        qs[1::3] *= np.float32(9.5)
+    t["coarse"] = coarse
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 1, 1, 100.0), (12, 4, 0, 1000.0)):
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        for approx in (1, 0):
+            idx.set_option("coarse_approx", approx)
+            gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+            util.assert_same_lists(gi, gd, exp, f"{kind} approx={approx} k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
 def _every_row_check(idx, oracle, ot, qs, k, W, what):
     """Every probed row kept by the scan and refined by the merge: the kernel's self-check then compares the
     proven bracket with the reference's distance for ALL of them.  Returns the lists."""
