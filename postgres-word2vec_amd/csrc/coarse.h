@@ -15,11 +15,11 @@
 //
 // The bracket (u = 2^-24, D = exact real |q - c|^2 <= (|q| + |c|)^2):
 //   reference      |d - D| <= ((1+u)^(d+3) - 1) D                      <= 1.82e-5 (|q| + |c|)^2   for d <= 300
-//   dot product    fmaf chain of <= 304 terms (any order):  <= 304 u |q||c|, doubled by the factor 2,
+//   dot product    fmaf chain of <= 320 terms (any order):  <= 320 u |q||c|, doubled by the factor 2,
 //                  |q||c| <= (|q| + |c|)^2 / 4                          <= 0.91e-5 (|q| + |c|)^2
-//   |q|^2, |c|^2   fp32 fma sums of 8 / 38 partial terms, one rounding  <= 0.3e-5  (|q| + |c|)^2
+//   |q|^2, |c|^2   |q|^2: two fp32 fma chains of 152 terms, added; |c|^2: fp64, rounded once  <= 0.92e-5 (|q| + |c|)^2
 //   final add/fma  2 u (|q| + |c|)^2
-//   sum < 3.1e-5 (|q| + |c|)^2;   eps(q) = COARSE_EPS (|q| + max_j |c_j|)^2 with COARSE_EPS = 1.2e-4 (4x margin,
+//   sum < 3.7e-5 (|q| + |c|)^2;   eps(q) = COARSE_EPS (|q| + max_j |c_j|)^2 with COARSE_EPS = 1.2e-4 (3x margin,
 //   and it would still hold if the matrix core TRUNCATED every accumulation step instead of rounding it).
 // Every refined cell has both numbers in hand: the kernel counts the cells whose d left [a - eps, a + eps]
 // (freddy_gpu_filter_bound_violations; the tests also run with EVERY cell refined).
@@ -33,80 +33,110 @@
 namespace freddy {
 
 static constexpr float COARSE_EPS = 1.2e-4f;
-static constexpr int COARSE_DP_ALIGN = 8;     // the padded dimension count is a multiple of 8 (two float4 per MFMA quad)
+static constexpr int COARSE_DP_ALIGN = 64;    // padded dimension count: whole blocks of 8 iterations x 8 dimensions (zeros)
 static constexpr int COARSE_MAX_CPAD = 1024;  // the plan keeps a query's approximate distances in registers: 16 per lane
 
 // ---------------------------------------------------------------------------------------
 // a[q][j] for a 64-query x 64-cell tile per workgroup; wave w owns the 32 x 32 quadrant (w >> 1, w & 1).
-// No LDS staging: a lane's operands for FOUR consecutive MFMAs are one 16-byte load from its query row and
-// one from its centroid row (the k index of an MFMA step may be any permutation as long as A and B agree:
-// step t of iteration i pairs elements 8 i + t (lanes 0-31) and 8 i + 4 + t (lanes 32-63)).
-//   queries [Q][d] (d need not be a multiple of 8: the tail is guarded), coarseP [Cpad][dp] zero padded,
+// The k index of an MFMA step may be any permutation as long as A and B agree: step t of iteration i pairs
+// elements 8 i + t (lanes 0-31) and 8 i + 4 + t (lanes 32-63), so a lane's operands for FOUR consecutive MFMAs
+// are 16 contiguous bytes of its row.
+//   B (centroids): pinned in FRAGMENT order coarseF[Cpad / 32][dp / 8][64 lanes][4] -- a wave's operand load is
+//     one fully coalesced 1 KB read, several iterations in flight (a first version read row-major centroids
+//     and queries directly, 64 different cache lines per wave-level load: 28 us, latency-bound);
+//   A (queries, row-major from the caller): the tile's 64 rows are staged ONCE in LDS by coalesced 16-byte
+//     loads, all in flight together (row pitch dp + 4 floats: the ds_read_b128 of 16 consecutive rows at one
+//     column hit 16 different 4-bank groups).
 //   cn2 [Cpad] = |c_j|^2 (fp64 sum rounded once, pin time), out [Q][Cpad], qn2 [Q] = |q|^2.
 // Also clears the round-one scratch (ZeroArgs), as coarse_tile_kernel does.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseP,
+__global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
                                                            const float* __restrict__ cn2, float* __restrict__ out,
                                                            float* __restrict__ qn2, int Q, int Cpad, int d, int dp, ZeroArgs z) {
+  // (host guarantees: d % 4 == 0, dp % 64 == 0 -- whole blocks of UN = 8 iterations, zero padded on both sides,
+  // so that the loops below carry no guards: guarded loads made hipcc emit a branch per element)
   typedef float f16v __attribute__((ext_vector_type(16)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
     const int gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, gsz = gridDim.x * gridDim.y * 256;
 #pragma unroll
     for (int a = 0; a < 5; ++a)
       for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
   }
-  __shared__ float rown[4][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int PA = dp + 4;
+  float* As = reinterpret_cast<float*>(smem);        // [64][PA]
+  float* rown = As + 64 * PA;                         // [4][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = blockIdx.y * 64 + (wave >> 1) * 32, c0 = blockIdx.x * 64 + (wave & 1) * 32;
-  const int qrow = (q0 + r < Q) ? q0 + r : Q - 1;
-  const float* ap = queries + (size_t)qrow * d + 4 * h;
-  const float* bp = coarseP + (size_t)(c0 + r) * dp + 4 * h;
-  const bool d4 = (d & 3) == 0;   // 16-byte alignment of the query rows
+  const int q0w = (wave >> 1) * 32;
+  const int q0 = blockIdx.y * 64, c0 = blockIdx.x * 64 + (wave & 1) * 32;
+  const int nit = dp >> 3;
+  const float4* bp = reinterpret_cast<const float4*>(coarseF) + ((size_t)(c0 >> 5) * nit) * 64 + lane;
+  constexpr int UN = 8;   // B operands in flight per wave
+  float4 bv[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) bv[u] = bp[(size_t)u * 64];
+  // Stage the query tile: its rows are ONE contiguous span of the row-major query matrix, copied flat with
+  // every load of a thread in flight together (a per-row formulation with clamped indices measured 13 us for
+  // this step alone, the flat copy 2); columns d..dp-1 are zeroed, rows beyond Q hold junk that is never stored.
+  {
+    const int d4n = d >> 2;
+    const int rows = Q - q0 < 64 ? Q - q0 : 64;
+    const int n4 = rows * d4n;
+    const float4* src = reinterpret_cast<const float4*>(queries + (size_t)q0 * d);
+    constexpr int SB = 19;   // 64 rows x 300 floats = 4800 float4 = 18.75 per thread
+    for (int base = 0; base < 64 * d4n; base += 256 * SB) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int i = base + u * 256 + tid;
+        v[u] = src[i < n4 ? i : n4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        const int i = base + u * 256 + tid;
+        if (i < 64 * d4n) {
+          const int row = i / d4n, c4 = i - row * d4n;
+          *reinterpret_cast<float4*>(As + row * PA + c4 * 4) = v[u];
+        }
+      }
+    }
+    const int p4n = (dp - d) >> 2;   // zero columns
+    for (int i = tid; i < 64 * p4n; i += 256) {
+      const int row = i / p4n, c4 = i - row * p4n;
+      *reinterpret_cast<float4*>(As + row * PA + d + c4 * 4) = float4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __syncthreads();
   f16v acc;
 #pragma unroll
   for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
   float nrm = 0.0f;
-  auto load_a = [&](int k) -> float4 {
-    const int kk = k + 4 * h;
-    if (d4 && kk + 4 <= d) return *reinterpret_cast<const float4*>(ap + k);
-    float4 v;
-    v.x = kk + 0 < d ? ap[k + 0] : 0.0f;
-    v.y = kk + 1 < d ? ap[k + 1] : 0.0f;
-    v.z = kk + 2 < d ? ap[k + 2] : 0.0f;
-    v.w = kk + 3 < d ? ap[k + 3] : 0.0f;
-    return v;
-  };
-  constexpr int UN = 4;   // iterations whose loads are in flight together
-  for (int k0 = 0; k0 < dp; k0 += 8 * UN) {
-    float4 av[UN], bv[UN];
+  const float* arow = As + (q0w + r) * PA + 4 * h;
+  for (int i0 = 0; i0 < nit; i0 += UN) {
+    float4 cur[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) cur[u] = bv[u];
+    const int inb = i0 + UN < nit ? i0 + UN : i0;   // (last block: re-request the current one, unused)
+#pragma unroll
+    for (int u = 0; u < UN; ++u) bv[u] = bp[(size_t)(inb + u) * 64];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const int k = k0 + 8 * u;
-      if (k < dp) {
-        av[u] = load_a(k);
-        bv[u] = *reinterpret_cast<const float4*>(bp + k);
-      } else {
-        av[u] = float4{0.f, 0.f, 0.f, 0.f};
-        bv[u] = float4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].x, bv[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].y, bv[u].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].z, bv[u].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u].w, bv[u].w, acc, 0, 0, 0);
-      nrm = __builtin_fmaf(av[u].x, av[u].x, nrm);
-      nrm = __builtin_fmaf(av[u].y, av[u].y, nrm);
-      nrm = __builtin_fmaf(av[u].z, av[u].z, nrm);
-      nrm = __builtin_fmaf(av[u].w, av[u].w, nrm);
+      const float4 av = *reinterpret_cast<const float4*>(arow + (i0 + u) * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cur[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cur[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cur[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cur[u].w, acc, 0, 0, 0);
+      nrm = __builtin_fmaf(av.x, av.x, nrm);
+      nrm = __builtin_fmaf(av.y, av.y, nrm);
+      nrm = __builtin_fmaf(av.z, av.z, nrm);
+      nrm = __builtin_fmaf(av.w, av.w, nrm);
     }
   }
   nrm += __shfl_xor(nrm, 32, 64);
   if (h == 0) {
-    rown[wave][r] = nrm;
-    if ((wave & 1) == 0 && blockIdx.x == 0 && q0 + r < Q) qn2[q0 + r] = nrm;
+    rown[wave * 32 + r] = nrm;
+    if ((wave & 1) == 0 && blockIdx.x == 0 && q0 + q0w + r < Q) qn2[q0 + q0w + r] = nrm;
   }
   __syncthreads();
   const float cn = cn2[c0 + r];
@@ -114,19 +144,22 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
     const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-    if (q0 + i < Q) out[(size_t)(q0 + i) * Cpad + c0 + r] = __builtin_fmaf(-2.0f, acc[v], rown[wave][i] + cn);
+    if (q0 + q0w + i < Q) out[(size_t)(q0 + q0w + i) * Cpad + c0 + r] = __builtin_fmaf(-2.0f, acc[v], rown[wave * 32 + i] + cn);
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// a7 probe plan on the approximate distances: one wave per active query.
-//   1. the query's <= 1024 approximate distances into registers (16 per lane), cells already probed masked;
-//   2. tau = the 2W-th smallest of the 64 lane minima (>= the 2W-th smallest overall); candidates =
-//      cells with a <= tau + 2 eps: every cell among the 2W smallest EXACT keys is one of them
-//      (at least 2W cells have d <= a + eps <= tau + eps, so such a cell has a - eps <= d <= tau + eps);
-//   3. the reference's squareDistance for the candidates: lanes <-> dimensions for the separately rounded
-//      (q_i - c_i)^2 (coalesced centroid rows), staged in LDS, then lane <-> candidate for the sequential sum;
-//   4. the 2W smallest exact keys, ordered by cell id, replayed through updateTopK: identical to
+// a7 probe plan on the approximate distances: FOUR waves per active query (a single wave per query spends its
+// time waiting on its own dependent instructions: 41 us for the batch, tools/ubench_plan).
+//   1. wave w takes cells [256 w, 256 w + 256): approximate distances into registers (4 per lane), cells
+//      already probed masked;
+//   2. tau = the 2W-th smallest of the 64 per-lane minima over all four waves (>= the 2W-th smallest
+//      overall); candidates = cells with a <= tau + 2 eps: every cell among the 2W smallest EXACT keys is one
+//      of them (at least 2W cells have d <= a + eps <= tau + eps, so such a cell has a - eps <= d <= tau + eps);
+//   3. every wave refines ITS candidates with the reference's squareDistance, PLAN2_NCB at a time: lanes <->
+//      dimensions for the separately rounded (q_i - c_i)^2 (coalesced centroid rows, all loads of a batch in
+//      flight), staged in LDS, then lane <-> candidate for the sequential sum;
+//   4. wave 0 keeps the 2W smallest exact keys, orders them by cell id and replays updateTopK: identical to
 //      probe_plan_kernel from here on (same outputs, plus the exact distance of every item).
 // ---------------------------------------------------------------------------------------
 struct Plan2Args {
@@ -139,136 +172,253 @@ struct Plan2Args {
   float cmax;               // max_j |c_j|, rounded up
   int d;
   int refine_all;           // tests: every unused cell is refined (exhaustive check of the bracket)
+  long long* prof;          // NULL, or [queries][16] cycle sums per phase of wave 0 (tools/ubench_plan)
 };
 
-static constexpr int PLAN2_NCB = 24;     // candidates refined per batch
-static constexpr int PLAN2_PITCH = 301;  // floats per candidate row in LDS (odd: the per-candidate sums read conflict-free)
+static constexpr int PLAN2_NW = 4;       // waves per query
+static constexpr int PLAN2_NCB = 7;      // candidates a wave loads per round: 28 per round and query
+static constexpr int PLAN2_PITCH = 308;  // floats per candidate row in LDS (16-byte aligned rows)
+static constexpr int PLAN2_PASS = 128;   // candidates per pass (more than one pass only in degenerate cases / the tests' refine-all mode)
+// LDS per workgroup: 4 x 7 x 308 x 4 = 34.5 KB + lists: 4 workgroups per CU = a whole 1024-query batch resident.
+// The kernel is bound by instruction ISSUE (16 waves per CU, 4 per SIMD, mostly serial work): everything that
+// one wave can do for the query is done by wave 0 alone, the others only fetch and square.
 
 __device__ __forceinline__ uint32_t float_order_bits(float f) {   // monotone map float -> u32 (negative values included)
   const uint32_t b = __float_as_uint(f);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-__global__ __launch_bounds__(64) void probe_plan2_kernel(Plan2Args g) {
+template <int ABL>   // 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
+__global__ __launch_bounds__(64 * PLAN2_NW) void probe_plan2_kernel(Plan2Args g) {
   const PlanArgs& a = g.p;
+  constexpr int NW = PLAN2_NW, NCB = PLAN2_NCB, RC = NW * NCB;   // RC candidates per round
+  constexpr int NV = COARSE_MAX_CPAD / 64 / NW;                  // cells per lane
   __shared__ u64 stage[64];
-  __shared__ int32_t cl[COARSE_MAX_CPAD];   // candidate cells
-  __shared__ float ca[COARSE_MAX_CPAD];     // their approximate distances
-  __shared__ float sq[PLAN2_NCB * PLAN2_PITCH];
-  const int x = blockIdx.x, lane = threadIdx.x;
+  __shared__ float mins[NW][64];
+  __shared__ int nws[NW];
+  __shared__ float thr_s;
+  __shared__ uint16_t clw[NW][64 * NV];   // candidate cells of each wave's cell range, ascending
+  __shared__ float cdist[PLAN2_PASS];     // exact distances of the pass's candidates
+  __shared__ __attribute__((aligned(16))) float sq[RC * PLAN2_PITCH];   // row i % RC: candidate i of the round
+  __shared__ __attribute__((aligned(16))) float qs[320];
+  const int x = blockIdx.x, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = a.active ? a.active[x] : x;
   const int W = a.W, L = 2 * W, d = g.d;
   uint32_t* used = a.used + (size_t)q * a.used_words;
   const float* drow = a.dist + (size_t)q * a.Cpad;
-  constexpr int NV = COARSE_MAX_CPAD / 64;
   const float INF = __uint_as_float(0x7f800000u);
+  long long pc = g.prof ? clock64() : 0;
+  auto tick = [&](int slot) {
+    if (g.prof && threadIdx.x == 0) { const long long t = clock64(); g.prof[(size_t)blockIdx.x * 16 + slot] += t - pc; pc = t; }
+  };
 
+  // ---- A (all waves): this wave's 256 cells, masked; per-lane minimum; the query into LDS ----
   float av[NV];
   uint32_t uw[NV];
 #pragma unroll
   for (int u = 0; u < NV; ++u) {
-    const int j = u * 64 + lane;
+    const int j = (wave * NV + u) * 64 + lane;
     const int jc = j < a.C ? j : a.C - 1;
     av[u] = drow[jc];
     uw[u] = used[jc >> 5];
   }
-  // the query itself: dimension i = lane + 64 u
-  constexpr int QV = 5;   // d <= 320
-  float qv[QV];
-#pragma unroll
-  for (int u = 0; u < QV; ++u) qv[u] = (lane + 64 * u < d) ? g.queries[(size_t)q * d + lane + 64 * u] : 0.0f;
-  float eps;
+  const int d4n = d >> 2;   // (d % 4 == 0, d <= 320)
   {
-    const float s = __builtin_sqrtf(g.qn2[q]) * (1.0f + 1e-6f) + g.cmax;
-    eps = s * s * COARSE_EPS;
+    const int tq = (int)threadIdx.x < d4n ? (int)threadIdx.x : d4n - 1;
+    const float4 qreg = *reinterpret_cast<const float4*>(g.queries + (size_t)q * d + 4 * tq);
+    if ((int)threadIdx.x < d4n) *reinterpret_cast<float4*>(qs + 4 * threadIdx.x) = qreg;
   }
-  const bool finite = eps < 1e30f;   // (false for NaN too)
   float mn = INF;
 #pragma unroll
   for (int u = 0; u < NV; ++u) {
-    const int j = u * 64 + lane;
+    const int j = (wave * NV + u) * 64 + lane;
     const bool valid = j < a.C && !((uw[u] >> (j & 31)) & 1u);
     if (!valid) av[u] = INF;
     if (av[u] == av[u]) mn = fminf(mn, av[u]);
     else av[u] = -INF;                          // NaN (non-finite table entries): always a candidate, never a threshold
   }
-  float thr = INF;
-  if (finite && !g.refine_all) {
-    const u64 sorted = wave_sort64((u64)float_order_bits(mn));
-    const uint32_t tb = (uint32_t)__shfl(sorted, L - 1 < 63 ? L - 1 : 63, 64);
-    const float tau = __uint_as_float((tb & 0x80000000u) ? (tb & 0x7fffffffu) : ~tb);
-    if (tau < 1e30f) thr = (tau + 2.0f * eps) * (1.0f + 1e-6f) + 1e-37f;
+  mins[wave][lane] = mn;
+  tick(0);
+  __syncthreads();
+  if (ABL == 2) { if (mn == 12345.0f) g.item_dist[0] = mn; return; }
+  // ---- B (wave 0): tau = the 2W-th smallest of the 64 per-lane minima; thr = tau + 2 eps ----
+  float eps = 0.0f;
+  bool finite = true;
+  if (wave == 0) {
+    const float s = __builtin_sqrtf(g.qn2[q]) * (1.0f + 1e-6f) + g.cmax;
+    eps = s * s * COARSE_EPS;
+    finite = eps < 1e30f;   // (false for NaN too)
+    float thr = INF;
+    if (finite && !g.refine_all) {
+      float m4 = mins[0][lane];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) m4 = fminf(m4, mins[w][lane]);
+      // (a lone wave issues about one instruction per 10 cycles whether it depends on the previous one or not:
+      // what counts in wave 0 is the NUMBER of instructions -- counting ranks with 64 independent compares
+      // measured twice the time of this 21-stage sort)
+      const uint32_t k0 = wave_sort32(float_order_bits(m4));
+      const uint32_t tb = (uint32_t)__shfl((int)k0, L - 1 < 63 ? L - 1 : 63, 64);
+      const float tau = __uint_as_float((tb & 0x80000000u) ? (tb & 0x7fffffffu) : ~tb);
+      if (tau < 1e30f) thr = (tau + 2.0f * eps) * (1.0f + 1e-6f) + 1e-37f;
+    }
+    if (lane == 0) thr_s = thr;
   }
-  // candidates -> LDS
-  int n_cand = 0;
+  tick(1);
+  __syncthreads();
+  // ---- C (all waves): this wave's candidates, ascending, into its own list ----
+  const float thr = thr_s;
+  int n_mine = 0;
 #pragma unroll
   for (int u = 0; u < NV; ++u) {
     const bool c = av[u] <= thr && av[u] < INF;
     const u64 mask = __ballot(c);
     if (mask != 0ull) {
-      if (c) {
-        const int slot = n_cand + lanes_below(mask);
-        cl[slot] = u * 64 + lane;
-        ca[slot] = av[u];
-      }
-      n_cand += __popcll(mask);
+      if (c) clw[wave][n_mine + lanes_below(mask)] = (uint16_t)((wave * NV + u) * 64 + lane);
+      n_mine += __popcll(mask);
     }
   }
-  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) nws[wave] = n_mine;
+  tick(2);
+  __syncthreads();
+  // the query's candidate list = the four lists one after the other: candidate i lives in list wi(i) at i - off[wi]
+  int off[NW + 1];
+  off[0] = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) off[w + 1] = off[w] + nws[w];
+  const int n_all = off[NW];
+  auto cell_of = [&](int i) -> int {
+    int w = 0;
+#pragma unroll
+    for (int t = 1; t < NW; ++t) w += i >= off[t] ? 1 : 0;
+    int o = off[0];
+#pragma unroll
+    for (int t = 1; t < NW; ++t) o = i >= off[t] ? off[t] : o;
+    return (int)clw[w][i - o];
+  };
+  if (ABL == 3) { if (n_all == 12345) g.item_dist[0] = thr; return; }
 
+  // flat view of a wave's NCB candidate rows as 16-byte elements: element 64 k + lane = float4 fc[k] of slot ft[k]
+  constexpr int NK = (NCB * 80 + 63) / 64;
+  int ft[NK], fc[NK];
+  {
+    int t = 0, c = lane;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      while (c >= d4n) { c -= d4n; ++t; }
+      ft[k] = t; fc[k] = c;
+      c += 64;
+    }
+  }
   const u64 limit = (u64)__float_as_uint(a.cell_limit) << 32;
-  WaveSelect<1> sel;
-  sel.init(stage, limit, L);
+  WaveSelect<1> sel;   // (more candidates than lanes only)
+  if (wave == 0 && n_all > 64) sel.init(stage, limit, L);
   int viol = 0;
-  for (int b0 = 0; b0 < n_cand; b0 += PLAN2_NCB) {
-    const int nb = n_cand - b0 < PLAN2_NCB ? n_cand - b0 : PLAN2_NCB;
-    // (q_i - c_i)^2, separately rounded: four candidates' rows in flight at a time
-    for (int b = 0; b < nb; b += 4) {
-      float cv[4][QV];
+  for (int p0 = 0; p0 < n_all; p0 += PLAN2_PASS) {
+    const int np = n_all - p0 < PLAN2_PASS ? n_all - p0 : PLAN2_PASS;
+    for (int r0 = 0; r0 < np; r0 += RC) {
+      // ---- D (all waves): candidates r0 + wave * NCB + t (t < NCB) of the pass: rows fetched, (q_i - c_i)^2 into LDS ----
+      int nb = np - r0 - wave * NCB;
+      nb = nb < 0 ? 0 : (nb > NCB ? NCB : nb);
+      if (nb > 0) {
+        // (NO conditions around the loads: a guarded load becomes a basic block of its own with a full wait at
+        // its end; elements past the wave's last candidate re-read its last element and are not stored)
+        const int nf = nb * d4n;
+        const int mycell = cell_of(p0 + r0 + wave * NCB + (lane < nb ? lane : nb - 1));   // lane t: candidate slot t
+        float4 cv[NK];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int cell = cl[b0 + (b + t < nb ? b + t : nb - 1)];
-        const float* crow = g.coarse + (size_t)cell * d;
+        for (int k = 0; k < NK; ++k) {
+          const bool in = 64 * k + lane < nf;
+          const int t = in ? ft[k] : nb - 1, c4 = in ? fc[k] : d4n - 1;
+          const int cell = __shfl(mycell, t, 64);
+          cv[k] = *reinterpret_cast<const float4*>(g.coarse + (size_t)cell * d + 4 * c4);
+        }
+        float* sqw = sq + wave * NCB * PLAN2_PITCH;
 #pragma unroll
-        for (int u = 0; u < QV; ++u) cv[t][u] = (lane + 64 * u < d) ? crow[lane + 64 * u] : 0.0f;
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (b + t < nb) {
-#pragma unroll
-          for (int u = 0; u < QV; ++u) {
-            const float df = qv[u] - cv[t][u];          // index_utils.c:500-508: sub, mul, add rounded one by one
-            const float pr = df * df;
-            if (lane + 64 * u < d) sq[(b + t) * PLAN2_PITCH + lane + 64 * u] = pr;
-          }
+        for (int k = 0; k < NK; ++k) {
+          const float4 qq = *reinterpret_cast<const float4*>(qs + 4 * fc[k]);
+          float4 pr;                                      // index_utils.c:500-508: sub, mul, add rounded one by one
+          pr.x = qq.x - cv[k].x; pr.y = qq.y - cv[k].y; pr.z = qq.z - cv[k].z; pr.w = qq.w - cv[k].w;
+          pr.x = pr.x * pr.x; pr.y = pr.y * pr.y; pr.z = pr.z * pr.z; pr.w = pr.w * pr.w;
+          if (64 * k + lane < nf) *reinterpret_cast<float4*>(sqw + ft[k] * PLAN2_PITCH + 4 * fc[k]) = pr;
         }
       }
+      tick(3);
+      __syncthreads();
+      // ---- E (wave 0): lane <-> candidate, the sequential sum ----
+      if (wave == 0) {
+        const int nr = np - r0 < RC ? np - r0 : RC;
+        if (lane < nr) {
+          const int cell = cell_of(p0 + r0 + lane);
+          const float ap = drow[cell];   // the approximate value again (bracket check; L1 / L2 hit, used after the sum)
+          float acc = 0.0f;
+          const float* row = sq + lane * PLAN2_PITCH;
+          int e = 0;
+          // (25 LDS reads in flight per block: a read per step would expose its latency 75 times)
+          for (; e + 100 <= d; e += 100) {
+            float4 v[25];
+#pragma unroll
+            for (int t = 0; t < 25; ++t) v[t] = *reinterpret_cast<const float4*>(row + e + 4 * t);
+#pragma unroll
+            for (int t = 0; t < 25; ++t) { acc = acc + v[t].x; acc = acc + v[t].y; acc = acc + v[t].z; acc = acc + v[t].w; }
+          }
+          for (; e < d; ++e) acc = acc + row[e];
+          cdist[r0 + lane] = acc;
+          if (finite && ap == ap && !(__builtin_fabsf(acc - ap) <= eps)) ++viol;
+        }
+      }
+      tick(4);
+      if (r0 + RC < np || p0 + PLAN2_PASS < n_all) __syncthreads();   // (sq is rewritten by the next round)
     }
-    __builtin_amdgcn_wave_barrier();
-    u64 key = KEY_INF;
-    if (lane < nb) {
-      float acc = 0.0f;
-      const float* row = sq + lane * PLAN2_PITCH;
-#pragma unroll 10
-      for (int i = 0; i < d; ++i) acc = acc + row[i];
-      key = make_key(acc, (uint32_t)cl[b0 + lane]);
-      const float ap = ca[b0 + lane];
-      if (finite && !(__builtin_fabsf(acc - ap) <= eps) && ap > -INF) ++viol;
+    if (wave == 0 && n_all > 64) {   // streaming selection of the 2W smallest keys
+      __builtin_amdgcn_wave_barrier();
+      for (int c0 = 0; c0 < np; c0 += 64) {
+        const bool v = c0 + lane < np;
+        const u64 key = v ? make_key(cdist[c0 + lane], (uint32_t)cell_of(p0 + c0 + (v ? lane : 0))) : KEY_INF;
+        sel.push(key, v);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
-    sel.push(key, lane < nb);
   }
-  sel.finish();
+  if (wave != 0) return;
+  if (g.violations && viol) atomicAdd(g.violations + 2, viol);
+  if (ABL == 4) { if (n_all == 12345) g.item_dist[0] = 1.0f; return; }
   if (g.violations) {
-    if (viol) atomicAdd(g.violations + 2, viol);
-    if (g.refine_all && lane == 0) atomicAdd(g.violations + 3, n_cand);
+#ifdef FREDDY_PLAN2_STATS   // (tools/ubench_plan: candidates per query)
+    if (lane == 0) atomicAdd(g.violations + 3, n_all);
+#else
+    if (g.refine_all && lane == 0) atomicAdd(g.violations + 3, n_all);
+#endif
   }
-  u64 byp = (sel.acc[0] == KEY_INF || lane >= L) ? KEY_INF : ((sel.acc[0] << 32) | (sel.acc[0] >> 32));
-  byp = wave_sort64(byp);
-  // lane i = slot i of the W-entry list; candidates replayed in cell order (freddy.c:266-283)
+  // ---- F (wave 0): lane i = slot i of the W-entry list (freddy.c:266-283: cells offered in ascending id, updateTopK) ----
   float d_slot = a.cell_limit;
   int32_t c_slot = -1;
-  wave_list_replay(d_slot, c_slot, W, byp, L, [](uint32_t hi) { return (int32_t)hi; });
+  bool done = false;
+  u64 byc = KEY_INF;   // candidates in cell order: (cell << 32) | distance bits
+  if (n_all <= 64) {
+    // The candidates ARE in ascending cell order already (lane i = candidate i), and replaying a superset of the
+    // 2W smallest keys gives the same list as replaying exactly those.  Without equal distances among the W + 1
+    // smallest the list is simply the W smallest below the limit, ascending: one sort instead of the replay.
+    __builtin_amdgcn_wave_barrier();
+    const bool v = lane < n_all;
+    const uint32_t db = v ? __float_as_uint(cdist[lane]) : 0xffffffffu;
+    const uint32_t cb = v ? (uint32_t)cell_of(v ? lane : 0) : 0xffffffffu;
+    byc = v ? (((u64)cb << 32) | (u64)db) : KEY_INF;
+    const u64 byd = wave_sort64(v ? (((u64)db << 32) | (u64)cb) : KEY_INF);
+    const uint32_t dn = (uint32_t)(__shfl_down(byd, 1, 64) >> 32);
+    const bool tie = lane < W && lane + 1 < n_all && (uint32_t)(byd >> 32) == dn;
+    if (__ballot(tie) == 0ull) {
+      if (lane < W && byd < limit) { d_slot = __uint_as_float((uint32_t)(byd >> 32)); c_slot = (int32_t)(uint32_t)byd; }
+      done = true;
+    }
+  } else {
+    sel.finish();
+    byc = (sel.acc[0] == KEY_INF || lane >= L) ? KEY_INF : ((sel.acc[0] << 32) | (sel.acc[0] >> 32));
+    byc = wave_sort64(byc);
+  }
+  if (!done) wave_list_replay(d_slot, c_slot, W, byc, n_all <= 64 ? n_all : L, [](uint32_t hi) { return (int32_t)hi; });
+  if (ABL == 5) { if (c_slot == 12345) g.item_dist[0] = d_slot; return; }
+  tick(5);
   const bool have = lane < W && c_slot >= 0;
   int rows = have ? (a.list_off[c_slot + 1] - a.list_off[c_slot]) : 0;
 #pragma unroll
@@ -287,6 +437,7 @@ __global__ __launch_bounds__(64) void probe_plan2_kernel(Plan2Args g) {
     a.item_query[(size_t)x * W + lane] = q;
     g.item_dist[(size_t)x * W + lane] = d_slot;
   }
+  tick(6);
 }
 
 }  // namespace freddy

@@ -70,6 +70,7 @@ struct Tuning {
   uint32_t merge_ablate = 0;   // FREDDY_GPU_MERGE_ABLATE: timing experiments / 32 = refine every row (tests)
   int coarse_approx = 1;       // FREDDY_GPU_COARSE_APPROX: cell selection as filter + refine (coarse.h); 0 = every distance exact
   int coarse_refine_all = 0;   // tests: refine every cell (exhaustive check of the coarse bracket)
+  int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
@@ -89,6 +90,7 @@ static Tuning read_tuning() {
   t.merge_ablate = (uint32_t)env_int("FREDDY_GPU_MERGE_ABLATE", 0);
   t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
+  t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
@@ -137,7 +139,7 @@ struct freddy_gpu_index {
   // pinned tables
   float* coarse = nullptr;      // [C][d]
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
-  float* coarseP = nullptr;     // [Cpad][dp] zero-padded rows for the MFMA coarse kernel (coarse.h)
+  float* coarseP = nullptr;     // centroids in MFMA fragment order [Cpad/32][dp/8][64][4], zero padded (coarse.h)
   float* cn2 = nullptr;         // [Cpad] |c_j|^2
   float cmax = 0.0f;            // max_j |c_j|, rounded up
   int dp = 0;
@@ -345,7 +347,7 @@ static int raise_lds_limits(int device) {
       (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
       (const void*)&ivf_spec2_kernel<25, 12, false>, (const void*)&ivf_filter_kernel<12, true>,
       (const void*)&ivf_filter_kernel<12, false>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
-      (const void*)&grouping_kernel<0>, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
+      (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>};
   for (const void* k : kernels)
     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -441,13 +443,16 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     if (!rc) {   // MFMA coarse kernel (coarse.h): zero-padded rows, squared norms (fp64, rounded once), largest norm
       ix->dp = (t->d + COARSE_DP_ALIGN - 1) / COARSE_DP_ALIGN * COARSE_DP_ALIGN;
+      // fragment order [Cpad / 32][dp / 8][lane = 32 h + r][4]: element t = c[32 g + r][8 i + 4 h + t]
       std::vector<float> cP((size_t)ix->Cpad * ix->dp, 0.0f), cn2((size_t)ix->Cpad, 0.0f);
+      const int nit = ix->dp / 8;
       double cmax2 = 0.0;
       for (int c = 0; c < t->C; ++c) {
         double n2 = 0.0;
         for (int i = 0; i < t->d; ++i) {
           const float v = t->coarse[(size_t)c * t->d + i];
-          cP[(size_t)c * ix->dp + i] = v;
+          const int it = i >> 3, hh = (i >> 2) & 1, tt = i & 3;
+          cP[((((size_t)(c >> 5) * nit + it) * 64) + (size_t)hh * 32 + (c & 31)) * 4 + tt] = v;
           n2 += (double)v * (double)v;
         }
         cn2[(size_t)c] = (float)n2;
@@ -758,11 +763,31 @@ static int ivf_coarse(IvfRun& r) {
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
   za.p[4] = r.fused ? ix->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = r.fused ? (int)(items * r.upi * FUSED_NW) : 0;
 
+  auto launch_coarse = [&]() -> int {
+    timed_launch(ix, s, "coarse_dist", [&] {
+      if (r.approx)
+        hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256),
+                           (size_t)(64 * (ix->dp + 4) + 128) * sizeof(float), s, r.d_q, ix->coarseP, ix->cn2,
+                           ix->w_distT.as<float>(), ix->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
+      else if (r.tiled)
+        hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
+                           ix->w_distT.as<float>(), Q, Cpad, d, za);
+      else
+        hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, r.d_q,
+                           ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);
+    });
+    HIP_TRY(hipGetLastError());
+    return 0;
+  };
+  // The query x codebook table is independent of the coarse distances / probe plan / work table: it is built on
+  // the side stream and joined before the entry records need it.  Beside the MFMA coarse kernel (a few us) it
+  // would only delay it -- the kernel launched first gets the CUs -- so there it is forked AFTER the coarse
+  // kernel and runs beside the latency-bound plan / work-table kernels; the all-exact coarse kernel is long
+  // and VALU-bound like the table kernel, and the table beside it measured 2 % faster than after it.
+  const bool coarse_first = r.approx && !ix->tune.qc_first;
+  if (coarse_first) if (int rc = launch_coarse()) return rc;
   r.qc_pending = false;
   if (r.fused && r.scan_kernel == 4) {
-    // independent of the coarse distances / probe plan / work table: built beside them on the side
-    // stream, joined before the entry records need it (starting it only after the coarse kernel, so that
-    // it overlaps the latency-bound plan / work-table kernels alone, measured 2 % slower)
     if (!ix->stream2) {
       HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
       HIP_TRY(hipEventCreateWithFlags(&ix->ev_q, hipEventDisableTiming));
@@ -775,7 +800,7 @@ static int ivf_coarse(IvfRun& r) {
       HIP_TRY(hipStreamWaitEvent(ix->stream2, ix->ev_q, 0));
     }
     timed_launch(ix, sq, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook_kernel<25, 32>), dim3(2, m, (Q + 31) / 32), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
+      hipLaunchKernelGGL((query_codebook_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
                          ix->w_qc.as<uint32_t>(), ix->w_qn.as<float>(), ix->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
     });
     HIP_TRY(hipGetLastError());
@@ -784,18 +809,7 @@ static int ivf_coarse(IvfRun& r) {
       r.qc_pending = true;
     }
   }
-  timed_launch(ix, s, "coarse_dist", [&] {
-    if (r.approx)
-      hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseP, ix->cn2,
-                         ix->w_distT.as<float>(), ix->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
-    else if (r.tiled)
-      hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
-                         ix->w_distT.as<float>(), Q, Cpad, d, za);
-    else
-      hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, r.d_q,
-                         ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);
-  });
-  HIP_TRY(hipGetLastError());
+  if (!coarse_first) if (int rc = launch_coarse()) return rc;
   return 0;
 }
 
@@ -823,8 +837,8 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
   if (r.approx) {
     Plan2Args g;
     g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ix->w_qn2.as<float>(); g.item_dist = pa.item_dist;
-    g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all;
-    timed_launch(ix, s, "probe_plan", [&] { hipLaunchKernelGGL(probe_plan2_kernel, dim3(r.n_active), dim3(64), 0, s, g); });
+    g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all; g.prof = nullptr;
+    timed_launch(ix, s, "probe_plan", [&] { hipLaunchKernelGGL(probe_plan2_kernel<0>, dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g); });
   } else
   timed_launch(ix, s, "probe_plan", [&] {
     switch (PV) {
@@ -1051,7 +1065,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : 4;
   r.tiled = Q >= 32;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
-  r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->coarseP;
+  r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
   const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
   if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||

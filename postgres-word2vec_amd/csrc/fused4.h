@@ -115,21 +115,30 @@ template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
                                                             const float* __restrict__ cmax, uint32_t* __restrict__ qc,
                                                             float* __restrict__ qn, float* __restrict__ qscale, int Q, int d, int m, int K) {
+  // One workgroup = QT queries x ALL 512 code pairs of one position: thread t owns pairs t and t + 256, so the
+  // workgroup produces whole 2 KB rows of the table.  The values of four queries at a time are laid out in LDS
+  // exactly as the rows will sit in memory and leave as 16 bytes per lane, 1 KB per wave-level store (the
+  // first version stored one dword per lane at a stride of 16 bytes, every cache line being completed by four
+  // waves of two workgroups: 27 us alone, bound by those partial-line writes).
   constexpr int SP = (S + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float qs[QT][SP];
   __shared__ float inv_s[QT];
-  const int tid = threadIdx.x, p = blockIdx.y, q0 = blockIdx.z * QT;
-  const int b = blockIdx.x * 256 + tid;   // codes b and b + 512
+  __shared__ __attribute__((aligned(16))) uint32_t ob[2][4][512];   // [buffer][query of the group][dword of the row]
+  const int tid = threadIdx.x, p = blockIdx.x, q0 = blockIdx.y * QT;
   for (int i = tid; i < QT * SP; i += 256) {
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
   }
   typedef float v2f __attribute__((ext_vector_type(2)));
-  v2f cb[S];   // (codes b, b+512): one packed fma per dimension
+  v2f cb[2][S];   // [pair t / t + 256][dimension] = (code b, code b + 512): one packed fma per dimension
 #pragma unroll
-  for (int j = 0; j < S; ++j) {
-    cb[j].x = b < K ? cbT[((size_t)p * S + j) * K + b] : 0.0f;
-    cb[j].y = b + 512 < K ? cbT[((size_t)p * S + j) * K + b + 512] : 0.0f;
+  for (int e = 0; e < 2; ++e) {
+    const int b = tid + 256 * e;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      cb[e][j].x = b < K ? cbT[((size_t)p * S + j) * K + b] : 0.0f;
+      cb[e][j].y = b + 512 < K ? cbT[((size_t)p * S + j) * K + b + 512] : 0.0f;
+    }
   }
   __syncthreads();
   if (tid < QT) {
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __rest
     const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
     const float sc = 2.0f * nrm * cmax[p] * (1.0f / 32767.0f) * (1.0f + 1e-6f);
     inv_s[tid] = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
-    if (blockIdx.x == 0 && q0 + tid < Q) {
+    if (q0 + tid < Q) {
       qn[(size_t)(q0 + tid) * m + p] = nrm;
       qscale[(size_t)(q0 + tid) * m + p] = sc;
     }
@@ -147,9 +156,11 @@ __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __rest
   __syncthreads();
   const int nq = (Q - q0 < QT) ? Q - q0 : QT;
   static_assert(QT % 4 == 0, "four queries per step");
-  // four queries per step = four independent fma chains (a dependent packed op issues only every ~19 cycles)
+  // four queries per step = eight independent fma chains
   for (int qi = 0; qi < nq; qi += 4) {
-    v2f acc[4] = {v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}, v2f{0.0f, 0.0f}};
+    v2f acc[4][2];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc[w][0] = acc[w][1] = v2f{0.0f, 0.0f};
 #pragma unroll
     for (int jb = 0; jb < SP / 4; ++jb) {
       float vv[4][4];
@@ -162,18 +173,33 @@ __global__ __launch_bounds__(256) void query_codebook_kernel(const float* __rest
       for (int u = 0; u < 4; ++u)
         if (jb * 4 + u < S) {
 #pragma unroll
-          for (int w = 0; w < 4; ++w)
-            acc[w] = __builtin_elementwise_fma(v2f{vv[w][u], vv[w][u]}, cb[jb * 4 + u < S ? jb * 4 + u : 0], acc[w]);
+          for (int w = 0; w < 4; ++w) {
+            const v2f qq = v2f{vv[w][u], vv[w][u]};
+            acc[w][0] = __builtin_elementwise_fma(qq, cb[0][jb * 4 + u < S ? jb * 4 + u : 0], acc[w][0]);
+            acc[w][1] = __builtin_elementwise_fma(qq, cb[1][jb * 4 + u < S ? jb * 4 + u : 0], acc[w][1]);
+          }
         }
     }
+    const int buf = (qi >> 2) & 1;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float inv = inv_s[qi + w];
-      const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w].x * inv), -32767.0f), 32767.0f);
-      const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w].y * inv), -32767.0f), 32767.0f);
-      // (dword 4 * (b mod 128) + b / 128: the scan's builder lane li loads pairs li, li+128, li+256, li+384 at once)
-      if (qi + w < nq && b < 512)
-        qc[((size_t)(q0 + qi + w) * m + p) * 512 + 4 * (b & 127) + (b >> 7)] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int b = tid + 256 * e;
+        const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].x * inv), -32767.0f), 32767.0f);
+        const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].y * inv), -32767.0f), 32767.0f);
+        // (dword 4 * (b mod 128) + b / 128: the scan's builder lane li loads pairs li, li+128, li+256, li+384 at once)
+        ob[buf][w][4 * (b & 127) + (b >> 7)] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+      }
+    }
+    __syncthreads();   // (two buffers: the next group's stores go to the other one, so one barrier per group is enough)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = tid + 256 * h;   // 16-byte element of the group's 4 x 2 KB
+      const int w = i >> 7, e4 = i & 127;
+      if (qi + w < nq)
+        *reinterpret_cast<uint4*>(qc + ((size_t)(q0 + qi + w) * m + p) * 512 + 4 * e4) = *reinterpret_cast<const uint4*>(&ob[buf][w][4 * e4]);
     }
   }
 }

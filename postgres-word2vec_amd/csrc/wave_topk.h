@@ -81,6 +81,21 @@ __device__ __forceinline__ u64 wave_sort64(u64 key) {
   return key;
 }
 
+// Ascending bitonic sort of 64 32-bit keys, one per lane.
+__device__ __forceinline__ uint32_t wave_sort32(uint32_t x) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t ox = (uint32_t)lane_xor((int)x, j);
+      const bool take_min = (((lane & k) == 0) == ((lane & j) == 0));
+      x = take_min ? min(x, ox) : max(x, ox);
+    }
+  }
+  return x;
+}
+
 // Two independent ascending bitonic sorts of 64 32-bit keys (one key of each per lane), interleaved
 // so that the cross-lane moves of one hide behind the other's.
 __device__ __forceinline__ void wave_sort32_x2(uint32_t& x, uint32_t& y) {

@@ -1,0 +1,225 @@
+// GPU-box micro-benchmark: the MFMA coarse-distance kernel (csrc/coarse.h) in isolation, plus ablations of
+// a local copy of it (MODE 1: no query staging, 2: no MFMAs, 3: no centroid loads, 4: no epilogue).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_coarse.hip -o tools/ubench_coarse
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../postgres-word2vec_amd/csrc/coarse.h"
+using namespace freddy;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void abl_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
+                                                 const float* __restrict__ cn2, float* __restrict__ out,
+                                                 float* __restrict__ qn2, int Q, int Cpad, int d, int dp) {
+  typedef float f16v __attribute__((ext_vector_type(16)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int PA = dp + 4;
+  float* As = reinterpret_cast<float*>(smem);
+  float* rown = As + 64 * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0w = (wave >> 1) * 32;
+  const int q0 = blockIdx.y * 64, c0 = blockIdx.x * 64 + (wave & 1) * 32;
+  const int nit = dp >> 3;
+  const float4* bp = reinterpret_cast<const float4*>(coarseF) + ((size_t)(c0 >> 5) * nit) * 64 + lane;
+  constexpr int UN = 8;
+  float4 bv[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) bv[u] = bp[(size_t)u * 64];
+  if (MODE != 1) {
+    const int c4n = dp >> 2, d4n = d >> 2;
+    constexpr int SB = 10;
+    const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < 64 * c4n; base += 256 * SB) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        int idx = base + u * 256 + tid;
+        idx = idx < 64 * c4n ? idx : 64 * c4n - 1;
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        const int qrow = q0 + row < Q ? q0 + row : Q - 1;
+        const int c4c = c4 < d4n ? c4 : d4n - 1;
+        v[u] = *reinterpret_cast<const float4*>(queries + (size_t)qrow * d + c4c * 4);
+        v[u] = c4 < d4n ? v[u] : zero4;
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        int idx = base + u * 256 + tid;
+        idx = idx < 64 * c4n ? idx : 64 * c4n - 1;
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        *reinterpret_cast<float4*>(As + row * PA + c4 * 4) = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  f16v acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  float nrm = 0.0f;
+  const float* arow = As + (q0w + r) * PA + 4 * h;
+  for (int i0 = 0; i0 < nit; i0 += UN) {
+    float4 cur[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) cur[u] = bv[u];
+    const int inb = i0 + UN < nit ? i0 + UN : i0;
+    if (MODE != 3) {
+#pragma unroll
+      for (int u = 0; u < UN; ++u) bv[u] = bp[(size_t)(inb + u) * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float4 av = *reinterpret_cast<const float4*>(arow + (i0 + u) * 8);
+      if (MODE != 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, cur[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, cur[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, cur[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, cur[u].w, acc, 0, 0, 0);
+      } else {
+        acc[0] += av.x * cur[u].x + av.y * cur[u].y + av.z * cur[u].z + av.w * cur[u].w;
+      }
+      nrm = __builtin_fmaf(av.x, av.x, nrm);
+    }
+  }
+  nrm += __shfl_xor(nrm, 32, 64);
+  if (h == 0) rown[wave * 32 + r] = nrm;
+  __syncthreads();
+  const float cn = cn2[c0 + r];
+  if (MODE == 4) {
+    float t = 0; for (int v = 0; v < 16; ++v) t += acc[v];
+    if (t == 12345.f) out[0] = t;
+    return;
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+    if (q0 + q0w + i < Q) out[(size_t)(q0 + q0w + i) * Cpad + c0 + r] = __builtin_fmaf(-2.0f, acc[v], rown[wave * 32 + i] + cn);
+  }
+  (void)qn2;
+}
+
+template <int VAR>
+__global__ __launch_bounds__(256) void stage_kernel(const float* __restrict__ queries, float* __restrict__ out, int Q, int d, int dp) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int PA = dp + 4;
+  float* As = reinterpret_cast<float*>(smem);
+  const int tid = threadIdx.x;
+  const int q0 = blockIdx.y * 64;
+  if (VAR == 0) {          // as in the kernel
+    const int c4n = dp >> 2, d4n = d >> 2;
+    constexpr int SB = 10;
+    const float4 zero4 = float4{0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < 64 * c4n; base += 256 * SB) {
+      float4 v[SB];
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        int idx = base + u * 256 + tid;
+        idx = idx < 64 * c4n ? idx : 64 * c4n - 1;
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        const int qrow = q0 + row < Q ? q0 + row : Q - 1;
+        const int c4c = c4 < d4n ? c4 : d4n - 1;
+        v[u] = *reinterpret_cast<const float4*>(queries + (size_t)qrow * d + c4c * 4);
+        v[u] = c4 < d4n ? v[u] : zero4;
+      }
+#pragma unroll
+      for (int u = 0; u < SB; ++u) {
+        int idx = base + u * 256 + tid;
+        idx = idx < 64 * c4n ? idx : 64 * c4n - 1;
+        const int row = idx / c4n, c4 = idx - row * c4n;
+        *reinterpret_cast<float4*>(As + row * PA + c4 * 4) = v[u];
+      }
+    }
+  } else if (VAR == 1) {   // the tile's rows are one contiguous span of 64 * d floats: flat copy, all loads in flight
+    const float4* src = reinterpret_cast<const float4*>(queries + (size_t)q0 * d);
+    const int n4 = 64 * d / 4;      // 4800
+    constexpr int SB = 19;
+    float4 v[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) { const int i = u * 256 + tid; v[u] = src[i < n4 ? i : n4 - 1]; }
+    const int d4n = d >> 2;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int i = u * 256 + tid;
+      if (i < n4) { const int row = i / d4n, c4 = i - row * d4n; *reinterpret_cast<float4*>(As + row * PA + c4 * 4) = v[u]; }
+    }
+  } else if (VAR == 2) {   // flat copy without the LDS stores
+    const float4* src = reinterpret_cast<const float4*>(queries + (size_t)q0 * d);
+    const int n4 = 64 * d / 4;
+    constexpr int SB = 19;
+    float4 v[SB];
+#pragma unroll
+    for (int u = 0; u < SB; ++u) { const int i = u * 256 + tid; v[u] = src[i < n4 ? i : n4 - 1]; }
+    float t = 0;
+#pragma unroll
+    for (int u = 0; u < SB; ++u) t += v[u].x + v[u].y + v[u].z + v[u].w;
+    if (t == 1234.5f) out[0] = t;
+    return;
+  }
+  __syncthreads();
+  if (As[tid] == 1234.5f) out[0] = As[tid + 1];
+}
+template <int VAR>
+static void run_stage(const char* what, float* dq, float* out, int Q, int d, int dp, int gx) {
+  hipFuncSetAttribute((const void*)&stage_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const size_t lds = (size_t)(64 * (dp + 4) + 128) * 4;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  float best = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL(stage_kernel<VAR>, dim3(gx, (Q + 63) / 64), dim3(256), lds, 0, dq, out, Q, d, dp);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    best = ms < best ? ms : best;
+  }
+  printf("%-40s %.2f us per launch (%s)\n", what, best * 1000 / 50, hipGetErrorString(hipGetLastError()));
+}
+
+template <int MODE>
+static void run(const char* what, float* dq, float* dc, float* dn, float* out, float* qn, int Q, int Cpad, int d, int dp) {
+  hipFuncSetAttribute((const void*)&abl_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const size_t lds = (size_t)(64 * (dp + 4) + 128) * 4;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  float best = 1e9;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(a, 0);
+    for (int i = 0; i < 50; ++i)
+      hipLaunchKernelGGL(abl_kernel<MODE>, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), lds, 0, dq, dc, dn, out, qn, Q, Cpad, d, dp);
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    best = ms < best ? ms : best;
+  }
+  printf("%-28s %.2f us per launch (%s)\n", what, best * 1000 / 50, hipGetErrorString(hipGetLastError()));
+}
+
+int main() {
+  const int Q = 1024, Cpad = 1024, d = 300, dp = 320;
+  std::vector<float> q((size_t)Q * d), cf((size_t)Cpad * dp), cn(Cpad, 1.0f);
+  for (auto& v : q) v = (float)rand() / RAND_MAX - 0.5f;
+  for (auto& v : cf) v = (float)rand() / RAND_MAX - 0.5f;
+  float *dq, *dc, *dn, *out, *qn;
+  (void)hipMalloc(&dq, q.size() * 4); (void)hipMalloc(&dc, cf.size() * 4); (void)hipMalloc(&dn, Cpad * 4);
+  (void)hipMalloc(&out, (size_t)Q * Cpad * 4); (void)hipMalloc(&qn, Q * 4);
+  (void)hipMemcpy(dq, q.data(), q.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dc, cf.data(), cf.size() * 4, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dn, cn.data(), Cpad * 4, hipMemcpyHostToDevice);
+  run_stage<0>("stage only, as in the kernel", dq, out, Q, d, dp, 16);
+  run_stage<1>("stage only, flat copy 19 in flight", dq, out, Q, d, dp, 16);
+  run_stage<2>("loads only, flat, no LDS stores", dq, out, Q, d, dp, 16);
+  run_stage<2>("loads only, 1 WG per q-tile (16 WGs)", dq, out, Q, d, dp, 1);
+  run<0>("full", dq, dc, dn, out, qn, Q, Cpad, d, dp);
+  run<1>("no query staging", dq, dc, dn, out, qn, Q, Cpad, d, dp);
+  run<2>("no MFMA", dq, dc, dn, out, qn, Q, Cpad, d, dp);
+  run<3>("no centroid loads in loop", dq, dc, dn, out, qn, Q, Cpad, d, dp);
+  run<4>("no epilogue stores", dq, dc, dn, out, qn, Q, Cpad, d, dp);
+  ZeroArgs z; for (int i = 0; i < 5; ++i) { z.p[i] = nullptr; z.n[i] = 0; }
+  hipFuncSetAttribute((const void*)&coarse_approx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  const size_t lds = (size_t)(64 * (dp + 4) + 128) * 4;
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipEventRecord(a, 0);
+  for (int i = 0; i < 50; ++i)
+    hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), lds, 0, dq, dc, dn, out, qn, Q, Cpad, d, dp, z);
+  hipEventRecord(b, 0); hipEventSynchronize(b);
+  float ms; hipEventElapsedTime(&ms, a, b);
+  printf("%-28s %.2f us per launch\n", "coarse_approx_kernel", ms * 1000 / 50);
+  return 0;
+}
