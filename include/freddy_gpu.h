@@ -177,6 +177,35 @@ typedef struct freddy_encode_desc {
 int freddy_gpu_encode(const freddy_encode_desc* desc, int device, const float* vectors, int64_t N, int32_t* out_cell,
                       int16_t* out_codes);
 
+/* ---- next row: insert_batch --------------------------------------------------------------
+ * Quantisation of NEW vectors as insert_batch does it (freddy.c:1557-1623): per vector the PQ code, the coarse
+ * cell (argmin from minDistCoarse = 100, :1568-1575) with the code of the residual, the ivpq code, and the
+ * two multi-index coarse codes (argmin from MAX_DIST = 1000, :1588-1597); codes = exact 1-NN by squareDistance
+ * from minDist = 100 with the first entry winning ties (updateCodebook, index_utils.c:925-939).  A codebook
+ * pointer that is NULL skips its part.  FREDDY_E_ARG if some (vector, position) has no centroid nearer than
+ * 100 (undefined behaviour in the reference).  The codebook update itself (index_utils.c:940-956: a few
+ * sequential float / double operations per new vector) and the table rows stay with the host. */
+typedef struct freddy_insert_desc {
+  int32_t d;
+  int32_t pq_m, pq_K;       const float* pq_codebook;         /* [pq_m][pq_K][d/pq_m]   pq_codebook */
+  int32_t res_m, res_K;     const float* residual_codebook;   /* residual_codebook */
+  int32_t C;                const float* coarse;              /* [C][d] coarse_quantization */
+  int32_t ivpq_m, ivpq_K;   const float* ivpq_codebook;       /* codebook_ivpq */
+  int32_t multi_positions, multi_codes; const float* coarse_multi;   /* [positions][codes][d/positions] coarse_quantization_ivpq */
+} freddy_insert_desc;
+int freddy_gpu_insert_quantize(const freddy_insert_desc* desc, int device, const float* vectors, int64_t n,
+                               int16_t* pq_codes /*[n][pq_m]*/, int32_t* coarse_id /*[n]*/, int16_t* residual_codes /*[n][res_m]*/,
+                               int16_t* ivpq_codes /*[n][ivpq_m]*/, int16_t* coarse_multi_codes /*[n][multi_positions]*/);
+/* Append rows to a pinned index in HBM (the INSERTs of updateProductQuantizationRelation /
+ * updateWordVectorsRelation, index_utils.c:993-1074): ids must be larger than every id already pinned and
+ * ascending.  pq: (ids, codes); ivf: (ids, coarse_id, codes) -- each row joins the end of its cell's inverted
+ * list, the block layout is rebuilt on the device; ivpq: (ids, coarse_id, codes[, vectors]); vectors: (ids, vectors). */
+int freddy_gpu_append_rows(freddy_gpu_index_t* index, int64_t n, const int32_t* ids, const int32_t* coarse_id,
+                           const int16_t* codes, const float* vectors);
+/* Replace the codebook of a pinned pq / ivf / ivpq index (updateCodebookRelation, index_utils.c:959-991) and
+ * re-derive everything on the device that depends on it. */
+int freddy_gpu_update_codebook(freddy_gpu_index_t* index, const float* codebook /*[m][K][d/m]*/);
+
 /* ---- device-resident variant used for throughput measurement ----------------------------
  * Same as freddy_gpu_ivfadc_search, but queries / outputs are DEVICE pointers on the
  * index's device and all work is enqueued on `hip_stream` (a hipStream_t; NULL = the

@@ -921,3 +921,115 @@ void fo_assign_coarse(const float* coarse, int C, int d, const float* vecs, int6
     cell[i] = best;
   }
 }
+
+/* ------------------------------------------------------------------------------------
+ * f4  insert_batch                                   freddy.c:1403-1658, index_utils.c:908-1074
+ * The reference quantises the NEW vectors against the coarse quantizer, the multi-index coarse
+ * quantizer and the three codebooks, nudges the codebook entries that received vectors, and INSERTs
+ * the rows; every float goes to the tables as "%f" text.  Restated statement by statement, slips
+ * included (they decide what ends up in the tables):
+ *   - the nearest centroid of a position is searched from minDist = 100 by strict "<" over the entries in
+ *     table order (index_utils.c:925-939); a sub-vector farther than 100 from every entry leaves the code
+ *     uninitialised in the reference -> here: return -2;
+ *   - `nearestCentroidRaw` is ONE pointer for all positions: after the scan it is the vector of the LAST entry
+ *     (in table order) that improved its position's minimum, and that vector -- not the difference to the new
+ *     sub-vector -- is what every position of this row adds to its bucket (:940-946);
+ *   - the recalculation reads the bucket `differences[pos + code]` (not pos * codes + code) and adds
+ *     (1.0 / count) * bucket in double (:949-956);
+ *   - only entries with a count increment are written back (updateCodebookRelation :959-991), through
+ *     sprintf("%f") and float4 input (:972-983);
+ *   - the multi-index cell id is built with factor *= POSITIONS (freddy.c:1599), not codes.
+ * Table order = position-major, code-minor (what index_creation/database_export.py inserts).
+ * ------------------------------------------------------------------------------------ */
+float fo_text_roundtrip(float v) {                      /* sprintf("%f") -> '{...}'::float4[] : index_utils.c:976, :1053 */
+  char buf[64];
+  snprintf(buf, sizeof buf, "%f", v);
+  return strtof(buf, NULL);
+}
+
+/* updateCodebook + updateCodebookRelation.  codebook [m][K][s] and counts [m*K] are updated in place (what the
+ * table holds afterwards); codes [n][m] = nearestCentroids; count_incs [m*K]. */
+int fo_update_codebook(float* codebook, int32_t* counts, int m, int K, int s, const float* vecs, int n,
+                       int16_t* codes, int32_t* count_incs) {
+  const int d = m * s, E = m * K;
+  float* differences = (float*)calloc((size_t)E * s, sizeof(float));        /* :913-921 */
+  float* min_dist = (float*)xmalloc(sizeof(float) * (size_t)m);
+  float* work = (float*)xmalloc(sizeof(float) * (size_t)E * s);             /* the in-memory CodebookWithCounts */
+  int32_t* wcount = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)E);
+  int* nearest = (int*)xmalloc(sizeof(int) * (size_t)m);
+  memcpy(work, codebook, sizeof(float) * (size_t)E * s);
+  memcpy(wcount, counts, sizeof(int32_t) * (size_t)E);
+  for (int i = 0; i < E; ++i) count_incs[i] = 0;
+  int rc = 0;
+  for (int i = 0; i < n && !rc; ++i) {                                      /* :923 */
+    const float* nearest_raw = NULL;
+    for (int j = 0; j < m; ++j) { min_dist[j] = 100; nearest[j] = -1; }     /* :925-927 */
+    for (int j = 0; j < E; ++j) {                                           /* :928-939 */
+      const int pos = j / K, code = j % K;
+      const float dist = fo_sqdist(vecs + (size_t)i * d + (size_t)pos * s, work + (size_t)j * s, s);
+      if (dist < min_dist[pos]) {
+        nearest[pos] = code;
+        min_dist[pos] = dist;
+        nearest_raw = work + (size_t)j * s;
+      }
+    }
+    for (int j = 0; j < m; ++j) {                                           /* :940-946 */
+      if (nearest[j] < 0) { rc = -2; break; }
+      codes[(size_t)i * m + j] = (int16_t)nearest[j];
+      count_incs[j * K + nearest[j]] += 1;
+      for (int k = 0; k < s; ++k) differences[((size_t)j * K + nearest[j]) * s + k] += nearest_raw[k];
+    }
+  }
+  if (!rc) {
+    for (int i = 0; i < E; ++i) {                                           /* :949-956 */
+      const int pos = i / K, code = i % K;
+      wcount[i] += count_incs[pos * K + code];
+      for (int j = 0; j < s; ++j)
+        work[(size_t)i * s + j] += (1.0 / wcount[i]) * differences[(size_t)(pos + code) * s + j];
+    }
+    for (int i = 0; i < E; ++i) {                                           /* :959-991 */
+      if (count_incs[i] > 0) {
+        for (int j = 0; j < s; ++j) codebook[(size_t)i * s + j] = fo_text_roundtrip(work[(size_t)i * s + j]);
+        counts[i] = wcount[i];
+      }
+    }
+  }
+  free(nearest); free(wcount); free(work); free(min_dist); free(differences);
+  return rc;
+}
+
+/* coarse quantisation + residuals                                          freddy.c:1566-1582 */
+int fo_insert_coarse(const float* coarse, int C, int d, const float* vecs, int n, int32_t* cq, float* residuals) {
+  for (int i = 0; i < n; ++i) {
+    float min_dist = 100;
+    int best = -1;
+    for (int j = 0; j < C; ++j) {
+      const float dist = fo_sqdist(vecs + (size_t)i * d, coarse + (size_t)j * d, d);
+      if (dist < min_dist) { best = j; min_dist = dist; }
+    }
+    if (best < 0) return -2;   /* the reference would use a stale / NULL centroid pointer here */
+    cq[i] = best;
+    for (int j = 0; j < d; ++j) residuals[(size_t)i * d + j] = vecs[(size_t)i * d + j] - coarse[(size_t)best * d + j];
+  }
+  return 0;
+}
+
+/* multi-index coarse id                                                    freddy.c:1584-1604 */
+int fo_insert_coarse_multi(const float* cq_multi, int P, int Kc, int d, const float* vecs, int n, int32_t* out) {
+  const int subdim = d / P;
+  for (int i = 0; i < n; ++i) {
+    int factor = 1;
+    out[i] = 0;
+    for (int pos = 0; pos < P; ++pos) {
+      float min_dist = FO_MAX_DIST;
+      int coarse_id = 0;
+      for (int j = 0; j < Kc; ++j) {
+        const float dist = fo_sqdist(vecs + (size_t)i * d + (size_t)pos * subdim, cq_multi + ((size_t)pos * Kc + j) * subdim, subdim);
+        if (dist < min_dist) { coarse_id = j; min_dist = dist; }
+      }
+      out[i] += factor * coarse_id;
+      factor *= P;   /* sic: freddy.c:1599 multiplies by the number of POSITIONS */
+    }
+  }
+  return 0;
+}

@@ -202,6 +202,15 @@ void fo_encode_pq(const float* codebook, int m, int K, int s, const float* vecs,
  * by squareDistance over all d dimensions, lowest index on ties. */
 void fo_assign_coarse(const float* coarse, int C, int d, const float* vecs, int64_t n, int32_t* cell);
 
+/* ---- f4: insert_batch (freddy.c:1403-1658, index_utils.c:908-1074) ------------------------------------- */
+float fo_text_roundtrip(float v);   /* sprintf("%f") -> float4 input, as every float the reference INSERTs / UPDATEs */
+/* updateCodebook + updateCodebookRelation: codebook [m][K][s] / counts [m*K] updated in place; codes [n][m];
+ * count_incs [m*K].  -2: a sub-vector is >= 100 away from every entry (undefined in the reference). */
+int fo_update_codebook(float* codebook, int32_t* counts, int m, int K, int s, const float* vecs, int n,
+                       int16_t* codes, int32_t* count_incs);
+int fo_insert_coarse(const float* coarse, int C, int d, const float* vecs, int n, int32_t* cq, float* residuals);
+int fo_insert_coarse_multi(const float* cq_multi, int P, int Kc, int d, const float* vecs, int n, int32_t* out);
+
 /* SRF emit text round trip               freddy.c:164 ("%f" into a 16-byte buffer) */
 float fo_emit_roundtrip(float dist);
 

@@ -180,6 +180,40 @@ class Oracle:
         self.lib.fo_assign_coarse(_p(c), c.shape[0], c.shape[1], _p(v), v.shape[0], _p(out))
         return out
 
+    # ---- insert_batch (freddy.c:1403-1658) ----------------------------------------------------
+    def text_roundtrip(self, a):
+        a = _f32(a)
+        self.lib.fo_text_roundtrip.restype = C.c_float
+        return np.array([self.lib.fo_text_roundtrip(C.c_float(float(v))) for v in a.ravel()], np.float32).reshape(a.shape)
+
+    def update_codebook(self, codebook, counts, vecs):
+        """-> (new codebook, new counts, codes[n, m], count_incs[m*K]); raises on the reference's undefined case."""
+        cb, cnt, v = _f32(codebook).copy(), _i32(counts).copy(), _f32(vecs)
+        m, K, s_ = cb.shape
+        codes = np.empty((v.shape[0], m), np.int16)
+        incs = np.empty(m * K, np.int32)
+        rc = self.lib.fo_update_codebook(_p(cb), _p(cnt), m, K, s_, _p(v), v.shape[0], _p(codes), _p(incs))
+        if rc:
+            raise ValueError(f"fo_update_codebook: {rc}")
+        return cb, cnt, codes, incs
+
+    def insert_coarse(self, coarse, vecs):
+        c, v = _f32(coarse), _f32(vecs)
+        cq = np.empty(v.shape[0], np.int32)
+        res = np.empty_like(v)
+        rc = self.lib.fo_insert_coarse(_p(c), c.shape[0], c.shape[1], _p(v), v.shape[0], _p(cq), _p(res))
+        if rc:
+            raise ValueError(f"fo_insert_coarse: {rc}")
+        return cq, res
+
+    def insert_coarse_multi(self, cq_multi, vecs):
+        c, v = _f32(cq_multi), _f32(vecs)
+        P, Kc, sub = c.shape
+        out = np.empty(v.shape[0], np.int32)
+        rc = self.lib.fo_insert_coarse_multi(_p(c), P, Kc, P * sub, _p(v), v.shape[0], _p(out))
+        assert rc == 0
+        return out
+
     def confidence_hyp(self, expect, size, p, stat_size):
         return np.float32(self.lib.fo_confidence_hyp(int(expect), int(size), C.c_float(float(p)), int(stat_size)))
 

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <string>
@@ -160,6 +161,8 @@ struct freddy_gpu_index {
   int32_t* ids = nullptr;       // PQ: [N] position -> id
   std::vector<int32_t> h_ids;   // PQ: ascending ids for "id IN (...)" resolution
   std::vector<int32_t> h_list_off;
+  std::vector<float> h_coarse;  // IVF: [C][d], kept for the norm bounds of a replaced codebook
+  int32_t max_id = -1;          // largest row id pinned (appended rows must be larger)
   // raw vectors (exact kNN): 64-row blocks [block][d][64]
   float* xb = nullptr;
   // ivpq extras
@@ -356,6 +359,76 @@ static int raise_lds_limits(int device) {
   return 0;
 }
 
+// Everything on the device that is a function of the (residual) codebook: the transposed copy of the generic
+// LUT kernel, the paired layout of the exact fused scan, and -- for the filter + refine scan -- the row-major
+// copy and the norm bounds.  (Re)built at pin time and by freddy_gpu_update_codebook; the row terms follow
+// in refresh_row_terms once the rows are in place.
+static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
+  void* old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
+  for (void* p : old) if (p) (void)hipFree(p);
+  ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = nullptr;
+  std::vector<float> cbT = transpose_codebook(codebook, ix->m, ix->K, ix->S);
+  if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
+  if (ix->kind != KIND_IVF) return 0;
+  const int C = ix->C, d = ix->d;
+  if (ix->K <= FUSED_T * FUSED_E) {
+    // paired layout of the fused kernels: slot t holds codes (t, t+512); 4 dims x 2 codes per 32 bytes.
+    // (Splitting the two 16-byte halves of a slot into separate contiguous arrays measured SLOWER: the
+    // second load of a slot then no longer hits the lines the first one brought in.)
+    const int SP = (ix->S + 3) & ~3, SPq = SP / 4;
+    std::vector<float> cbP((size_t)ix->m * SPq * FUSED_T * 8, 0.0f);
+    for (int p = 0; p < ix->m; ++p)
+      for (int jb = 0; jb < SPq; ++jb)
+        for (int tl = 0; tl < FUSED_T; ++tl)
+          for (int u = 0; u < 4; ++u)
+            for (int e = 0; e < 2; ++e) {
+              const int j = jb * 4 + u, c = tl + e * FUSED_T;
+              if (j < ix->S && c < ix->K)
+                cbP[((((size_t)p * SPq + jb) * FUSED_T + tl) * 4 + u) * 2 + e] = codebook[((size_t)p * ix->K + c) * ix->S + j];
+            }
+    if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
+  }
+  // filter + refine tables (fused4.h)
+  if (ix->cbP && ix->m == 12 && ix->S == 25 && ix->tune.filter_table_mb > 0) {
+    std::vector<float> pmax((size_t)ix->m), cmaxp((size_t)ix->m);
+    for (int p = 0; p < ix->m; ++p) {
+      double comax = 0.0, cmax = 0.0;
+      for (int c = 0; c < C; ++c) {
+        double n2 = 0.0;
+        for (int j = 0; j < ix->S; ++j) { const double v = ix->h_coarse[(size_t)c * d + p * ix->S + j]; n2 += v * v; }
+        comax = std::max(comax, std::sqrt(n2));
+      }
+      for (int c = 0; c < ix->K; ++c) {
+        double n2 = 0.0;
+        for (int j = 0; j < ix->S; ++j) { const double v = codebook[((size_t)p * ix->K + c) * ix->S + j]; n2 += v * v; }
+        cmax = std::max(cmax, std::sqrt(n2));
+      }
+      pmax[p] = (float)((comax + cmax) * (1.0 + 1e-6));
+      cmaxp[p] = (float)(cmax * (1.0 + 1e-6));
+    }
+    if (upload(&ix->cbR, codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
+        upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
+        upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
+      return fail(FREDDY_E_NOMEM, "device allocation failed");
+  }
+  return 0;
+}
+
+// rterm[slot] for every row slot of the pinned lists (the (cell, row) part of the filter's cheap distance)
+static int refresh_row_terms(freddy_gpu_index* ix) {
+  if (ix->rterm) { (void)hipFree(ix->rterm); ix->rterm = nullptr; }
+  if (!ix->cbR) return 0;
+  const int64_t n_slots = std::max<int64_t>(ix->n_blocks, 1) * 64;
+  if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess) return fail(FREDDY_E_NOMEM, "device allocation failed");
+  if (ix->n_blocks > 0) {
+    hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((ix->n_blocks * 64 + 255) / 256)), dim3(256), 0, ix->stream, ix->packed,
+                       ix->blk_cell, ix->coarse, ix->cbR, ix->rterm, ix->n_blocks * 64, ix->M2, ix->d, ix->m, ix->K, ix->S);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
+      return fail(FREDDY_E_HIP, "building the row terms failed");
+  }
+  return 0;
+}
+
 static int open_device(freddy_gpu_index* ix, int device) {
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));
@@ -390,16 +463,13 @@ extern "C" int freddy_gpu_pin_pq(const freddy_pq_desc* t, int device, freddy_gpu
   ix->kind = KIND_PQ;
   ix->d = t->d; ix->m = t->m; ix->K = t->K; ix->S = t->d / t->m; ix->M2 = (t->m + 1) / 2; ix->N = t->N;
   int rc = open_device(ix, device);
-  if (!rc) {
-    std::vector<float> cbT = transpose_codebook(t->codebook, ix->m, ix->K, ix->S);
-    if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes) || upload(&ix->ids, t->ids, (size_t)t->N, &ix->bytes))
-      rc = fail(FREDDY_E_NOMEM, "device allocation failed");
-  }
+  if (!rc) rc = derive_codebook_tables(ix, t->codebook);
+  if (!rc && upload(&ix->ids, t->ids, (size_t)t->N, &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
   if (!rc) {
     const int32_t off[2] = {0, (int32_t)t->N};
     rc = pack_lists(ix, 1, off, t->codes, nullptr);
   }
-  if (!rc) ix->h_ids.assign(t->ids, t->ids + t->N);
+  if (!rc) { ix->h_ids.assign(t->ids, t->ids + t->N); ix->max_id = t->N ? t->ids[t->N - 1] : -1; }
   if (rc) { free_index(ix); return rc; }
   *out = ix;
   return FREDDY_OK;
@@ -432,13 +502,11 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
   ix->d = t->d; ix->m = t->m; ix->K = t->K; ix->S = t->d / t->m; ix->M2 = (t->m + 1) / 2; ix->N = t->N; ix->C = t->C;
   int rc = open_device(ix, device);
   if (!rc) {
-    std::vector<float> cbT = transpose_codebook(t->codebook, ix->m, ix->K, ix->S);
     ix->Cpad = (t->C + WG - 1) / WG * WG;
     std::vector<float> cT((size_t)t->d * ix->Cpad, 0.0f);
     for (int c = 0; c < t->C; ++c)
       for (int i = 0; i < t->d; ++i) cT[(size_t)i * ix->Cpad + c] = t->coarse[(size_t)c * t->d + i];
-    if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes) ||
-        upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes) ||
+    if (upload(&ix->coarse, t->coarse, (size_t)t->C * t->d, &ix->bytes) ||
         upload(&ix->coarseT, cT.data(), cT.size(), &ix->bytes))
       rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     if (!rc) {   // MFMA coarse kernel (coarse.h): zero-padded rows, squared norms (fp64, rounded once), largest norm
@@ -463,59 +531,13 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
           hipMalloc((void**)&ix->viol, 4 * sizeof(int32_t)) != hipSuccess || hipMemset(ix->viol, 0, 4 * sizeof(int32_t)) != hipSuccess)
         rc = fail(FREDDY_E_NOMEM, "device allocation failed");
     }
-    if (!rc && ix->K <= FUSED_T * FUSED_E) {
-      // paired layout of the fused kernels: slot t holds codes (t, t+512); 4 dims x 2 codes per 32 bytes.
-      // (Splitting the two 16-byte halves of a slot into separate contiguous arrays measured SLOWER: the
-      // second load of a slot then no longer hits the lines the first one brought in.)
-      const int SP = (ix->S + 3) & ~3, SPq = SP / 4;
-      std::vector<float> cbP((size_t)ix->m * SPq * FUSED_T * 8, 0.0f);
-      for (int p = 0; p < ix->m; ++p)
-        for (int jb = 0; jb < SPq; ++jb)
-          for (int tl = 0; tl < FUSED_T; ++tl)
-            for (int u = 0; u < 4; ++u)
-              for (int e = 0; e < 2; ++e) {
-                const int j = jb * 4 + u, c = tl + e * FUSED_T;
-                if (j < ix->S && c < ix->K)
-                  cbP[((((size_t)p * SPq + jb) * FUSED_T + tl) * 4 + u) * 2 + e] = t->codebook[((size_t)p * ix->K + c) * ix->S + j];
-              }
-      if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
-    }
-    // filter + refine tables (fused4.h)
-    if (!rc && ix->cbP && ix->m == 12 && ix->S == 25 && ix->tune.filter_table_mb > 0) {
-      std::vector<float> pmax((size_t)ix->m), cmaxp((size_t)ix->m);
-      for (int p = 0; p < ix->m; ++p) {
-        double comax = 0.0, cmax = 0.0;
-        for (int c = 0; c < t->C; ++c) {
-          double n2 = 0.0;
-          for (int j = 0; j < ix->S; ++j) { const double v = t->coarse[(size_t)c * t->d + p * ix->S + j]; n2 += v * v; }
-          comax = std::max(comax, std::sqrt(n2));
-        }
-        for (int c = 0; c < ix->K; ++c) {
-          double n2 = 0.0;
-          for (int j = 0; j < ix->S; ++j) { const double v = t->codebook[((size_t)p * ix->K + c) * ix->S + j]; n2 += v * v; }
-          cmax = std::max(cmax, std::sqrt(n2));
-        }
-        pmax[p] = (float)((comax + cmax) * (1.0 + 1e-6));
-        cmaxp[p] = (float)(cmax * (1.0 + 1e-6));
-      }
-      if (upload(&ix->cbR, t->codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
-          upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
-          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
-        rc = fail(FREDDY_E_NOMEM, "device allocation failed");
-    }
+    if (!rc) { ix->h_coarse.assign(t->coarse, t->coarse + (size_t)t->C * t->d); rc = derive_codebook_tables(ix, t->codebook); }
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
-  if (!rc && ix->cbR) {   // one float per row slot: the (cell, row) part of the filter's cheap distance
-    const int64_t n_slots = std::max<int64_t>(ix->n_blocks, 1) * 64;
-    if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess)
-      rc = fail(FREDDY_E_NOMEM, "device allocation failed");
-    if (!rc && ix->n_blocks > 0) {
-      ix->bytes += (int64_t)sizeof(float) * n_slots;
-      hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((ix->n_blocks * 64 + 255) / 256)), dim3(256), 0, ix->stream, ix->packed,
-                         ix->blk_cell, ix->coarse, ix->cbR, ix->rterm, ix->n_blocks * 64, ix->M2, ix->d, ix->m, ix->K, ix->S);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
-        rc = fail(FREDDY_E_HIP, "building the row terms failed");
-    }
+  if (!rc) rc = refresh_row_terms(ix);   // one float per row slot: the (cell, row) part of the filter's cheap distance
+  if (!rc) {
+    if (ix->rterm) ix->bytes += (int64_t)sizeof(float) * std::max<int64_t>(ix->n_blocks, 1) * 64;
+    for (int64_t r = 0; r < t->N; ++r) ix->max_id = std::max(ix->max_id, t->ids[r]);
   }
   if (rc) { free_index(ix); return rc; }
   *out = ix;
@@ -1361,8 +1383,10 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
 // ---------------------------------------------------------------------------------------
 // index build: encoding
 // ---------------------------------------------------------------------------------------
-extern "C" int freddy_gpu_encode(const freddy_encode_desc* t, int device, const float* vectors, int64_t N, int32_t* out_cell,
-                                 int16_t* out_codes) {
+// limit_coarse / limit_code < +inf: insert_batch's searches start from that distance (strict "<"); *n_too_far
+// counts the (vector[, position]) pairs with no centroid nearer than the limit.
+static int encode_impl(const freddy_encode_desc* t, int device, const float* vectors, int64_t N, int32_t* out_cell,
+                       int16_t* out_codes, float limit_coarse, float limit_code, int32_t* n_too_far) {
   if (!t || !t->codebook || !out_codes || N < 0 || (N > 0 && !vectors)) return fail(FREDDY_E_ARG, "NULL argument");
   if (t->d <= 0 || t->m <= 0 || t->K <= 0 || t->d % t->m) return fail(FREDDY_E_ARG, "bad shape d=%d m=%d K=%d", t->d, t->m, t->K);
   if (t->K > 32767) return fail(FREDDY_E_LIMIT, "K=%d does not fit an int16 code", t->K);
@@ -1384,12 +1408,12 @@ extern "C" int freddy_gpu_encode(const freddy_encode_desc* t, int device, const 
   }
   const int64_t chunk = std::min<int64_t>(N, 1 << 16);
   float *d_cbT = nullptr, *d_cT = nullptr, *d_coarse = nullptr, *d_vec = nullptr, *d_res = nullptr;
-  int32_t* d_cell = nullptr;
+  int32_t *d_cell = nullptr, *d_far = nullptr;
   int16_t* d_codes = nullptr;
   int rc = FREDDY_OK;
   hipStream_t s = nullptr;
   auto cleanup = [&] {
-    void* ptrs[] = {d_cbT, d_cT, d_coarse, d_vec, d_res, d_cell, d_codes};
+    void* ptrs[] = {d_cbT, d_cT, d_coarse, d_vec, d_res, d_cell, d_codes, d_far};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     if (s) (void)hipStreamDestroy(s);
   };
@@ -1403,6 +1427,10 @@ extern "C" int freddy_gpu_encode(const freddy_encode_desc* t, int device, const 
   ENC_TRY(hipMalloc((void**)&d_vec, sizeof(float) * (size_t)chunk * d));
   ENC_TRY(hipMalloc((void**)&d_codes, sizeof(int16_t) * (size_t)chunk * m));
   ENC_TRY(hipMemcpyAsync(d_cbT, cbT.data(), sizeof(float) * cbT.size(), hipMemcpyHostToDevice, s));
+  if (n_too_far) {
+    ENC_TRY(hipMalloc((void**)&d_far, sizeof(int32_t)));
+    ENC_TRY(hipMemsetAsync(d_far, 0, sizeof(int32_t), s));
+  }
   if (C) {
     ENC_TRY(hipMalloc((void**)&d_cT, sizeof(float) * cT.size()));
     ENC_TRY(hipMalloc((void**)&d_coarse, sizeof(float) * (size_t)C * d));
@@ -1416,24 +1444,293 @@ extern "C" int freddy_gpu_encode(const freddy_encode_desc* t, int device, const 
     ENC_TRY(hipMemcpyAsync(d_vec, vectors + (size_t)i0 * d, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice, s));
     const float* src = d_vec;
     if (C) {
-      hipLaunchKernelGGL(assign_coarse_kernel, dim3((unsigned)n), dim3(64), 0, s, (const float*)d_vec, (const float*)d_cT, d_cell, n, C, Cpad, d);
+      hipLaunchKernelGGL(assign_coarse_kernel, dim3((unsigned)n), dim3(64), 0, s, (const float*)d_vec, (const float*)d_cT, d_cell, n, C, Cpad, d, limit_coarse, d_far);
       hipLaunchKernelGGL(residual_kernel, dim3((unsigned)n), dim3(WG), 0, s, (const float*)d_vec, (const float*)d_coarse,
                          (const int32_t*)d_cell, (const int32_t*)nullptr, d_res, d, S, S);
       src = d_res;
     }
     const int ipw = 64;
     const dim3 grid((unsigned)m, (unsigned)((n + ipw - 1) / ipw));
-    if (S == 25) hipLaunchKernelGGL((encode_pq_kernel<25, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S);
-    else if (S == 10) hipLaunchKernelGGL((encode_pq_kernel<10, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S);
-    else hipLaunchKernelGGL((encode_pq_kernel<0, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S);
+    if (S == 25) hipLaunchKernelGGL((encode_pq_kernel<25, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S, limit_code, d_far);
+    else if (S == 10) hipLaunchKernelGGL((encode_pq_kernel<10, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S, limit_code, d_far);
+    else hipLaunchKernelGGL((encode_pq_kernel<0, 4>), grid, dim3(WG), 0, s, src, (const float*)d_cbT, d_codes, n, ipw, m, K, d, S, limit_code, d_far);
     ENC_TRY(hipGetLastError());
     ENC_TRY(hipMemcpyAsync(out_codes + (size_t)i0 * m, d_codes, sizeof(int16_t) * (size_t)n * m, hipMemcpyDeviceToHost, s));
     if (C) ENC_TRY(hipMemcpyAsync(out_cell + i0, d_cell, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
     ENC_TRY(hipStreamSynchronize(s));
   }
+  if (n_too_far) ENC_TRY(hipMemcpy(n_too_far, d_far, sizeof(int32_t), hipMemcpyDeviceToHost));
 #undef ENC_TRY
   cleanup();
   return rc;
+}
+
+extern "C" int freddy_gpu_encode(const freddy_encode_desc* t, int device, const float* vectors, int64_t N, int32_t* out_cell,
+                                 int16_t* out_codes) {
+  const float inf = std::numeric_limits<float>::infinity();
+  return encode_impl(t, device, vectors, N, out_cell, out_codes, inf, inf, nullptr);
+}
+
+// insert_batch, quantisation of the new vectors (freddy.c:1557-1623): codes against the PQ codebook, coarse
+// cell (from minDistCoarse = 100) + codes of the residual against the residual codebook, codes against the ivpq
+// codebook, and the two coarse codes of the multi index (from MAX_DIST = 1000).  Every search is the exact
+// 1-NN by squareDistance with the first entry winning ties, as updateCodebook's strict "<" scan.
+extern "C" int freddy_gpu_insert_quantize(const freddy_insert_desc* t, int device, const float* vectors, int64_t n,
+                                          int16_t* pq_codes, int32_t* coarse_id, int16_t* residual_codes, int16_t* ivpq_codes,
+                                          int16_t* coarse_multi_codes) {
+  if (!t || n < 0 || (n > 0 && !vectors)) return fail(FREDDY_E_ARG, "NULL argument");
+  const float inf = std::numeric_limits<float>::infinity();
+  int32_t far = 0, far_total = 0;
+  if (t->pq_codebook) {
+    if (!pq_codes) return fail(FREDDY_E_ARG, "pq_codes is required with a PQ codebook");
+    freddy_encode_desc e = {t->d, t->pq_m, t->pq_K, t->pq_codebook, 0, nullptr};
+    if (int rc = encode_impl(&e, device, vectors, n, nullptr, pq_codes, inf, 100.0f, &far)) return rc;
+    far_total += far;
+  }
+  if (t->residual_codebook) {
+    if (!t->coarse || !coarse_id || !residual_codes) return fail(FREDDY_E_ARG, "the residual codebook needs the coarse quantizer and both outputs");
+    freddy_encode_desc e = {t->d, t->res_m, t->res_K, t->residual_codebook, t->C, t->coarse};
+    if (int rc = encode_impl(&e, device, vectors, n, coarse_id, residual_codes, 100.0f, 100.0f, &far)) return rc;
+    far_total += far;
+  }
+  if (t->ivpq_codebook) {
+    if (!ivpq_codes) return fail(FREDDY_E_ARG, "ivpq_codes is required with an ivpq codebook");
+    freddy_encode_desc e = {t->d, t->ivpq_m, t->ivpq_K, t->ivpq_codebook, 0, nullptr};
+    if (int rc = encode_impl(&e, device, vectors, n, nullptr, ivpq_codes, inf, 100.0f, &far)) return rc;
+    far_total += far;
+  }
+  if (t->coarse_multi) {
+    if (!coarse_multi_codes) return fail(FREDDY_E_ARG, "coarse_multi_codes is required with a multi-index coarse quantizer");
+    freddy_encode_desc e = {t->d, t->multi_positions, t->multi_codes, t->coarse_multi, 0, nullptr};
+    if (int rc = encode_impl(&e, device, vectors, n, nullptr, coarse_multi_codes, inf, inf, nullptr)) return rc;
+  }
+  if (far_total)
+    return fail(FREDDY_E_ARG, "%d (vector, position) pairs are 100 or farther from every centroid: insert_batch is undefined for them "
+                "(index_utils.c:925-939 leaves the code uninitialised)", far_total);
+  return FREDDY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// insert_batch: HBM index mutation
+// ---------------------------------------------------------------------------------------
+// new block j of list blk_cell[b] <- old block j of that list (or empty)
+__global__ __launch_bounds__(256) void repack_blocks_kernel(const uint32_t* __restrict__ old_packed, const int32_t* __restrict__ old_pos,
+                                                           const int32_t* __restrict__ old_blk_off, const int32_t* __restrict__ new_blk_off,
+                                                           const int32_t* __restrict__ new_blk_cell, uint32_t* __restrict__ packed,
+                                                           int32_t* __restrict__ pos, int64_t n_new_blocks, int M2) {
+  const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (b >= n_new_blocks) return;
+  const int c = new_blk_cell[b];
+  const int j = (int)(b - new_blk_off[c]);
+  const bool have = j < old_blk_off[c + 1] - old_blk_off[c];
+  const int64_t ob = (int64_t)old_blk_off[c] + j;
+  for (int w = 0; w < M2; ++w) packed[((size_t)b * M2 + w) * 64 + lane] = have ? old_packed[((size_t)ob * M2 + w) * 64 + lane] : 0u;
+  pos[(size_t)b * 64 + lane] = have ? old_pos[(size_t)ob * 64 + lane] : -1;
+}
+// new rows into their slots: slot[i] = row slot (block * 64 + lane) of new row i
+__global__ __launch_bounds__(256) void place_rows_kernel(const int64_t* __restrict__ slot, const int32_t* __restrict__ row_pos,
+                                                        const int16_t* __restrict__ codes, int64_t n, uint32_t* __restrict__ packed,
+                                                        int32_t* __restrict__ pos, int m, int M2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t sl = slot[i], b = sl >> 6;
+  const int lane = (int)(sl & 63);
+  for (int w = 0; w < M2; ++w) {
+    const uint32_t lo = (uint16_t)codes[(size_t)i * m + 2 * w];
+    const uint32_t hi = (2 * w + 1 < m) ? (uint16_t)codes[(size_t)i * m + 2 * w + 1] : 0u;
+    packed[((size_t)b * M2 + w) * 64 + lane] = lo | (hi << 16);
+  }
+  pos[(size_t)sl] = row_pos[i];
+}
+// raw vectors into the 64-row blocked layout: row r -> xb[r / 64][dim][r % 64]
+__global__ __launch_bounds__(256) void place_vectors_kernel(const float* __restrict__ src, int64_t first_row, int64_t n, float* __restrict__ xb, int d) {
+  const int64_t i = (int64_t)blockIdx.x;
+  if (i >= n) return;
+  const int64_t r = first_row + i;
+  for (int dim = threadIdx.x; dim < d; dim += 256) xb[((r >> 6) * d + dim) * 64 + (r & 63)] = src[(size_t)i * d + dim];
+}
+
+template <class T>
+static int grow_device_array(T** arr, size_t old_n, size_t new_n, const T* append_host, size_t append_n) {
+  T* fresh = nullptr;
+  if (hipMalloc((void**)&fresh, sizeof(T) * std::max<size_t>(new_n, 1)) != hipSuccess) return -1;
+  if (old_n && hipMemcpy(fresh, *arr, sizeof(T) * old_n, hipMemcpyDeviceToDevice) != hipSuccess) { (void)hipFree(fresh); return -2; }
+  if (append_n && hipMemcpy(fresh + old_n, append_host, sizeof(T) * append_n, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(fresh); return -2; }
+  if (*arr) (void)hipFree(*arr);
+  *arr = fresh;
+  return 0;
+}
+
+// rows of a pq / ivf index: each new row goes to the end of its list; the 64-row block layout is rebuilt on
+// the device (old blocks copied to their new places, new rows written into the free slots behind them)
+static int append_packed_rows(freddy_gpu_index* ix, int n_lists, int64_t n, const int32_t* cell, const int32_t* row_pos, const int16_t* codes) {
+  const int m = ix->m, M2 = ix->M2;
+  std::vector<int32_t> new_list_off((size_t)n_lists + 1, 0), add((size_t)n_lists, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const int c = cell ? cell[i] : 0;
+    if (c < 0 || c >= n_lists) return fail(FREDDY_E_ARG, "coarse_id %d of new row %lld is outside [0, %d)", c, (long long)i, n_lists);
+    for (int l = 0; l < m; ++l)
+      if (codes[(size_t)i * m + l] < 0 || codes[(size_t)i * m + l] >= ix->K)
+        return fail(FREDDY_E_ARG, "code %d of new row %lld is outside [0, %d)", (int)codes[(size_t)i * m + l], (long long)i, ix->K);
+    add[(size_t)c]++;
+  }
+  std::vector<int32_t> old_blk((size_t)n_lists + 1, 0), new_blk((size_t)n_lists + 1, 0);
+  int max_blocks = 0;
+  for (int c = 0; c < n_lists; ++c) {
+    const int64_t old_len = ix->h_list_off[(size_t)c + 1] - ix->h_list_off[(size_t)c];
+    old_blk[(size_t)c + 1] = old_blk[(size_t)c] + (int32_t)((old_len + 63) / 64);
+    const int64_t len = old_len + add[(size_t)c];
+    if ((int64_t)new_list_off[(size_t)c] + len > INT32_MAX - 64) return fail(FREDDY_E_LIMIT, "N too large for 32-bit row positions");
+    new_list_off[(size_t)c + 1] = new_list_off[(size_t)c] + (int32_t)len;
+    const int nb = (int)((len + 63) / 64);
+    new_blk[(size_t)c + 1] = new_blk[(size_t)c] + nb;
+    max_blocks = std::max(max_blocks, nb);
+  }
+  const int64_t n_new_blocks = new_blk[(size_t)n_lists];
+  std::vector<int32_t> blk_cell((size_t)std::max<int64_t>(n_new_blocks, 1), 0);
+  for (int c = 0; c < n_lists; ++c)
+    for (int b = new_blk[(size_t)c]; b < new_blk[(size_t)c + 1]; ++b) blk_cell[(size_t)b] = c;
+  std::vector<int64_t> slot((size_t)n);
+  std::vector<int32_t> cursor((size_t)n_lists, 0);
+  for (int64_t i = 0; i < n; ++i) {
+    const int c = cell ? cell[i] : 0;
+    const int64_t old_len = ix->h_list_off[(size_t)c + 1] - ix->h_list_off[(size_t)c];
+    slot[(size_t)i] = (int64_t)new_blk[(size_t)c] * 64 + old_len + cursor[(size_t)c]++;
+  }
+  uint32_t* packed = nullptr;
+  int32_t *pos = nullptr, *d_blk_cell = nullptr, *d_new_blk = nullptr, *d_list_off = nullptr, *d_row_pos = nullptr;
+  int64_t* d_slot = nullptr;
+  int16_t* d_codes = nullptr;
+  int64_t junk = 0;
+  int rc = 0;
+  if (hipMalloc((void**)&packed, sizeof(uint32_t) * (size_t)std::max<int64_t>(n_new_blocks, 1) * M2 * 64) != hipSuccess ||
+      hipMalloc((void**)&pos, sizeof(int32_t) * (size_t)std::max<int64_t>(n_new_blocks, 1) * 64) != hipSuccess ||
+      upload(&d_blk_cell, blk_cell.data(), blk_cell.size(), &junk) || upload(&d_new_blk, new_blk.data(), new_blk.size(), &junk) ||
+      upload(&d_list_off, new_list_off.data(), new_list_off.size(), &junk) || upload(&d_slot, slot.data(), slot.size(), &junk) ||
+      upload(&d_row_pos, row_pos, (size_t)n, &junk) || upload(&d_codes, codes, (size_t)n * m, &junk))
+    rc = fail(FREDDY_E_NOMEM, "device allocation failed while appending rows");
+  if (!rc && n_new_blocks > 0) {
+    hipLaunchKernelGGL(repack_blocks_kernel, dim3((unsigned)((n_new_blocks + 3) / 4)), dim3(256), 0, ix->stream, ix->packed, ix->pos, ix->blk_off,
+                       d_new_blk, d_blk_cell, packed, pos, n_new_blocks, M2);
+    if (n > 0)
+      hipLaunchKernelGGL(place_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ix->stream, d_slot, d_row_pos, d_codes, n, packed, pos, m, M2);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess) rc = fail(FREDDY_E_HIP, "re-blocking the lists failed");
+  }
+  void* tmp[] = {d_slot, d_row_pos, d_codes};
+  for (void* p : tmp) if (p) (void)hipFree(p);
+  if (rc) {
+    void* fresh[] = {packed, pos, d_blk_cell, d_new_blk, d_list_off};
+    for (void* p : fresh) if (p) (void)hipFree(p);
+    return rc;
+  }
+  void* old[] = {ix->packed, ix->pos, ix->blk_cell, ix->blk_off, ix->list_off};
+  for (void* p : old) if (p) (void)hipFree(p);
+  ix->packed = packed; ix->pos = pos; ix->blk_cell = d_blk_cell; ix->blk_off = d_new_blk; ix->list_off = d_list_off;
+  ix->n_blocks = n_new_blocks;
+  ix->max_list_blocks = max_blocks;
+  ix->h_list_off = new_list_off;
+  ix->N += n;
+  return 0;
+}
+
+extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const int32_t* ids, const int32_t* coarse_id,
+                                      const int16_t* codes, const float* vectors) {
+  if (!ix) return fail(FREDDY_E_ARG, "NULL index");
+  if (n < 0 || (n > 0 && !ids)) return fail(FREDDY_E_ARG, "bad argument");
+  if (n == 0) return FREDDY_OK;
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  const int32_t last_id = ix->kind == KIND_IVPQ ? (ix->join.h_ids.empty() ? -1 : ix->join.h_ids.back())
+                          : ix->kind == KIND_IVF ? ix->max_id : (ix->h_ids.empty() ? -1 : ix->h_ids.back());
+  for (int64_t i = 0; i < n; ++i)
+    if (ids[i] <= (i ? ids[i - 1] : last_id))
+      return fail(FREDDY_E_ARG, "appended ids must ascend beyond the largest pinned id %d (row %lld has %d)", last_id, (long long)i, ids[i]);
+  if (ix->N + n > (int64_t)INT32_MAX - 64) return fail(FREDDY_E_LIMIT, "N too large for 32-bit row positions");
+  switch (ix->kind) {
+    case KIND_PQ: {
+      if (!codes) return fail(FREDDY_E_ARG, "codes are required");
+      std::vector<int32_t> row_pos((size_t)n);
+      for (int64_t i = 0; i < n; ++i) row_pos[(size_t)i] = (int32_t)(ix->N + i);   // flat table: position = row index
+      const int64_t old_n = ix->N;
+      if (int rc = append_packed_rows(ix, 1, n, nullptr, row_pos.data(), codes)) return rc;
+      if (grow_device_array(&ix->ids, (size_t)old_n, (size_t)(old_n + n), ids, (size_t)n)) return fail(FREDDY_E_NOMEM, "device allocation failed");
+      ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);
+      ix->max_id = ids[n - 1];
+      return FREDDY_OK;
+    }
+    case KIND_IVF: {
+      if (!codes || !coarse_id) return fail(FREDDY_E_ARG, "coarse_id and codes are required");
+      if (int rc = append_packed_rows(ix, ix->C, n, coarse_id, ids, codes)) return rc;
+      ix->max_id = ids[n - 1];
+      return refresh_row_terms(ix);
+    }
+    case KIND_IVPQ: {
+      JoinIndex& j = ix->join;
+      if (!codes || !coarse_id || (j.has_vectors && !vectors)) return fail(FREDDY_E_ARG, "coarse_id, codes (and vectors, if pinned) are required");
+      for (int64_t i = 0; i < n; ++i) {
+        if (coarse_id[i] < 0 || coarse_id[i] >= j.cells) return fail(FREDDY_E_ARG, "coarse_id %d out of range", coarse_id[i]);
+        for (int l = 0; l < j.m; ++l)
+          if (codes[(size_t)i * j.m + l] < 0 || codes[(size_t)i * j.m + l] >= j.K) return fail(FREDDY_E_ARG, "code out of range at new row %lld", (long long)i);
+      }
+      const size_t o = (size_t)j.N, nn = (size_t)(j.N + n);
+      if (grow_device_array(&j.ids, o, nn, ids, (size_t)n) || grow_device_array(&j.cell, o, nn, coarse_id, (size_t)n) ||
+          grow_device_array(&j.codes, o * j.m, nn * j.m, codes, (size_t)n * j.m) ||
+          (j.has_vectors && grow_device_array(&j.vectors, o * j.d, nn * j.d, vectors, (size_t)n * j.d)))
+        return fail(FREDDY_E_NOMEM, "device allocation failed");
+      if (j.markbits) (void)hipFree(j.markbits);
+      j.markbits = nullptr;
+      HIP_TRY(hipMalloc((void**)&j.markbits, sizeof(uint32_t) * ((nn + 31) / 32 + 1)));
+      j.h_ids.insert(j.h_ids.end(), ids, ids + n);
+      j.h_cell.insert(j.h_cell.end(), coarse_id, coarse_id + n);
+      j.N += n; ix->N = j.N;
+      j.ids_affine = (int64_t)j.h_ids.back() - j.h_ids.front() == j.N - 1;
+      return FREDDY_OK;
+    }
+    case KIND_VEC: {
+      if (!vectors) return fail(FREDDY_E_ARG, "vectors are required");
+      const int d = ix->d;
+      const size_t o = (size_t)ix->N, nn = (size_t)(ix->N + n);
+      const int64_t new_blocks = (int64_t)((nn + 63) / 64);
+      float* xb = nullptr;
+      HIP_TRY(hipMalloc((void**)&xb, sizeof(float) * (size_t)new_blocks * d * 64));
+      HIP_TRY(hipMemset(xb, 0, sizeof(float) * (size_t)new_blocks * d * 64));
+      if (ix->n_blocks) HIP_TRY(hipMemcpy(xb, ix->xb, sizeof(float) * (size_t)ix->n_blocks * d * 64, hipMemcpyDeviceToDevice));
+      if (grow_device_array(&ix->coarse, o * d, nn * d, vectors, (size_t)n * d) || grow_device_array(&ix->ids, o, nn, ids, (size_t)n)) {
+        (void)hipFree(xb);
+        return fail(FREDDY_E_NOMEM, "device allocation failed");
+      }
+      hipLaunchKernelGGL(place_vectors_kernel, dim3((unsigned)n), dim3(256), 0, ix->stream, ix->coarse + o * d, (int64_t)o, n, xb, d);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(ix->stream));
+      if (ix->xb) (void)hipFree(ix->xb);
+      ix->xb = xb; ix->n_blocks = new_blocks; ix->N += n;
+      ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);
+      return FREDDY_OK;
+    }
+  }
+  return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+}
+
+extern "C" int freddy_gpu_update_codebook(freddy_gpu_index_t* ix, const float* codebook) {
+  if (!ix || !codebook) return fail(FREDDY_E_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(ix->device));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (ix->kind == KIND_PQ) return derive_codebook_tables(ix, codebook);
+  if (ix->kind == KIND_IVF) {
+    if (int rc = derive_codebook_tables(ix, codebook)) return rc;
+    return refresh_row_terms(ix);
+  }
+  if (ix->kind == KIND_IVPQ) {
+    JoinIndex& j = ix->join;
+    std::vector<float> cbT((size_t)j.m * j.S * j.K);
+    for (int p = 0; p < j.m; ++p)
+      for (int c = 0; c < j.K; ++c)
+        for (int i = 0; i < j.S; ++i) cbT[((size_t)p * j.S + i) * j.K + c] = codebook[((size_t)p * j.K + c) * j.S + i];
+    HIP_TRY(hipMemcpy(j.cbT, cbT.data(), sizeof(float) * cbT.size(), hipMemcpyHostToDevice));
+    return FREDDY_OK;
+  }
+  return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
 }
 
 // ---------------------------------------------------------------------------------------

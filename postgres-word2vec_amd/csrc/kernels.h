@@ -453,7 +453,7 @@ __global__ __launch_bounds__(WG) void lut_build_kernel(const float* __restrict__
 template <int S, int E>
 __global__ __launch_bounds__(WG) void encode_pq_kernel(const float* __restrict__ vecs, const float* __restrict__ cbT,
                                                       int16_t* __restrict__ codes, int n_items, int items_per_wg, int m,
-                                                      int K, int d, int S_rt) {
+                                                      int K, int d, int S_rt, float limit, int32_t* __restrict__ too_far) {
   __shared__ u64 wmin[WG / 64];
   const int p = blockIdx.x;
   const int it0 = blockIdx.y * items_per_wg;
@@ -511,6 +511,9 @@ __global__ __launch_bounds__(WG) void encode_pq_kernel(const float* __restrict__
 #pragma unroll
       for (int w = 1; w < WG / 64; ++w) b = umin64(b, wmin[w]);
       codes[(size_t)it * m + p] = (int16_t)key_pos(b);
+      // insert_batch searches from minDist = 100 by strict "<" (index_utils.c:925-939): the same code unless NO
+      // entry is nearer than the limit, which the reference leaves undefined -- reported
+      if (too_far && !(key_dist(b) < limit)) atomicAdd(too_far, 1);
     }
   }
 }
@@ -518,7 +521,8 @@ __global__ __launch_bounds__(WG) void encode_pq_kernel(const float* __restrict__
 // Coarse assignment: nearest of C centroids by squareDistance over all d dimensions, lowest index on
 // ties (faiss IndexFlatL2 search k=1 / ivfadc.py); one wave per vector, lane <-> centroid.
 __global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restrict__ vecs, const float* __restrict__ coarseT,
-                                                          int32_t* __restrict__ cell, int n, int C, int Cpad, int d) {
+                                                          int32_t* __restrict__ cell, int n, int C, int Cpad, int d,
+                                                          float limit, int32_t* __restrict__ too_far) {
   const int it = blockIdx.x, lane = threadIdx.x;
   if (it >= n) return;
   const float* v = vecs + (size_t)it * d;
@@ -534,7 +538,10 @@ __global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restri
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) best = umin64(best, __shfl_xor(best, o, 64));
-  if (lane == 0) cell[it] = (int32_t)key_pos(best);
+  if (lane == 0) {
+    cell[it] = (int32_t)key_pos(best);
+    if (too_far && !(key_dist(best) < limit)) atomicAdd(too_far, 1);   // (freddy.c:1568-1575: minDistCoarse = 100)
+  }
 }
 
 // generic sub-vector size (runtime S): no register cache, codebook streamed from L2

@@ -24,6 +24,7 @@ EXPORTS = [
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
     "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_filter_bound_checked", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
     "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells", "freddy_gpu_coarse_bound_checked",
+    "freddy_gpu_insert_quantize", "freddy_gpu_append_rows", "freddy_gpu_update_codebook",
 ]
 
 
@@ -106,6 +107,10 @@ def load():
     lib.freddy_gpu_pq_search_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
     lib.freddy_gpu_last_probed_cells.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_insert_quantize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_append_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_update_codebook.argtypes = [C.c_void_p, C.c_void_p]
     lib.freddy_gpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.freddy_gpu_last_track.argtypes = [C.c_void_p, C.c_void_p]
     lib.freddy_gpu_profile_enable.argtypes = [C.c_void_p, C.c_int32]
@@ -156,6 +161,18 @@ class _Index:
     @property
     def nbytes(self):
         return int(self.lib.freddy_gpu_index_bytes(self.h))
+
+    def append_rows(self, ids, coarse_id=None, codes=None, vectors=None):
+        """INSERT of new rows into the pinned tables (freddy_gpu_append_rows): ids ascending beyond the pinned ones."""
+        ids = _i32(ids)
+        cid = None if coarse_id is None else _i32(coarse_id)
+        cd = None if codes is None else _i16(codes)
+        v = None if vectors is None else _f32(vectors)
+        _check(self.lib.freddy_gpu_append_rows(self.h, ids.size, _p(ids), _p(cid), _p(cd), _p(v)))
+
+    def update_codebook(self, codebook):
+        cb = _f32(codebook)
+        _check(self.lib.freddy_gpu_update_codebook(self.h, _p(cb)))
 
     def set_option(self, name, value):
         """Tuning / debug switch of this pinned index (include/freddy_gpu.h: freddy_gpu_set_option)."""
@@ -353,3 +370,45 @@ def encode(codebook, vectors, coarse=None, device=0):
     cell = None if co is None else np.empty(v.shape[0], np.int32)
     _check(lib.freddy_gpu_encode(C.byref(desc), device, _p(v), C.c_int64(v.shape[0]), _p(cell), _p(codes)))
     return cell, codes
+
+
+class InsertDesc(C.Structure):
+    _fields_ = [("d", C.c_int32), ("pq_m", C.c_int32), ("pq_K", C.c_int32), ("pq_codebook", C.c_void_p),
+                ("res_m", C.c_int32), ("res_K", C.c_int32), ("residual_codebook", C.c_void_p),
+                ("C", C.c_int32), ("coarse", C.c_void_p),
+                ("ivpq_m", C.c_int32), ("ivpq_K", C.c_int32), ("ivpq_codebook", C.c_void_p),
+                ("multi_positions", C.c_int32), ("multi_codes", C.c_int32), ("coarse_multi", C.c_void_p)]
+
+
+def insert_quantize(vectors, pq_codebook=None, residual_codebook=None, coarse=None, ivpq_codebook=None, coarse_multi=None,
+                    device=0):
+    """insert_batch's quantisation of new vectors (freddy.c:1557-1623) on the device.  Returns a dict with the
+    arrays of the parts that were given: pq_codes, coarse_id, residual_codes, ivpq_codes, coarse_multi_codes."""
+    lib = load()
+    v = _f32(vectors)
+    n, d = v.shape
+    keep = []
+
+    def cb(a):
+        if a is None:
+            return 0, 0, None
+        a = _f32(a)
+        keep.append(a)
+        return a.shape[0], a.shape[1], _p(a)
+
+    pm, pk, pp = cb(pq_codebook)
+    rm, rk, rp = cb(residual_codebook)
+    im, ik, ip = cb(ivpq_codebook)
+    mp, mk, mpp = cb(coarse_multi)
+    co = None if coarse is None else _f32(coarse)
+    desc = InsertDesc(d, pm, pk, pp, rm, rk, rp, 0 if co is None else co.shape[0], _p(co), im, ik, ip, mp, mk, mpp)
+    out = {}
+    if pp: out["pq_codes"] = np.empty((n, pm), np.int16)
+    if rp:
+        out["coarse_id"] = np.empty(n, np.int32)
+        out["residual_codes"] = np.empty((n, rm), np.int16)
+    if ip: out["ivpq_codes"] = np.empty((n, im), np.int16)
+    if mpp: out["coarse_multi_codes"] = np.empty((n, mp), np.int16)
+    _check(lib.freddy_gpu_insert_quantize(C.byref(desc), device, _p(v), C.c_int64(n), _p(out.get("pq_codes")), _p(out.get("coarse_id")),
+                                          _p(out.get("residual_codes")), _p(out.get("ivpq_codes")), _p(out.get("coarse_multi_codes"))))
+    return out

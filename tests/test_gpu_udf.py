@@ -231,3 +231,133 @@ def test_knn_in_pq_and_ivfadc_batch_callers(db, oracle):
     assert rows["id"].tolist() == exp["id"].ravel()[keep].tolist()
     assert np.array_equal(rows["distance"].view(np.uint32),
                           np.array([sim(d) for d in exp["dist"].ravel()[keep]], np.float32).view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------
+# insert_batch: quantisation on the device, HBM index mutation
+# ---------------------------------------------------------------------------------------
+def _new_vectors(n, seed=5):
+    x = util.corpus(20000).numpy()
+    rng = np.random.default_rng(seed)
+    v = x[rng.choice(20000, n, replace=False)] + 0.05 * rng.standard_normal((n, 300)).astype(np.float32)
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+def test_insert_quantize_matches_oracle(oracle):
+    """Codes / coarse ids of new vectors exactly as the reference's insert_batch finds them (freddy.c:1557-1623,
+    index_utils.c:925-939): PQ, coarse + residual, ivpq, multi-index coarse codes -- bit for bit."""
+    from freddy_amd import gpu
+    pq, ivf, ivpq = util.pq_tables(), util.ivf_tables(), util.ivpq_tables()
+    v = _new_vectors(37)
+    got = gpu.insert_quantize(v, pq_codebook=pq["codebook"], residual_codebook=ivf["codebook"], coarse=ivf["coarse"],
+                              ivpq_codebook=ivpq["codebook"], coarse_multi=ivpq["coarse"])
+    m, K, s_ = pq["codebook"].shape
+    _, _, codes, _ = oracle.update_codebook(pq["codebook"], np.ones(m * K, np.int32), v)
+    assert np.array_equal(codes, got["pq_codes"])
+    cq, res = oracle.insert_coarse(ivf["coarse"], v)
+    assert np.array_equal(cq, got["coarse_id"])
+    m, K, s_ = ivf["codebook"].shape
+    _, _, codes, _ = oracle.update_codebook(ivf["codebook"], np.ones(m * K, np.int32), res)
+    assert np.array_equal(codes, got["residual_codes"])
+    m, K, s_ = ivpq["codebook"].shape
+    _, _, codes, _ = oracle.update_codebook(ivpq["codebook"], np.ones(m * K, np.int32), v)
+    assert np.array_equal(codes, got["ivpq_codes"])
+    multi = oracle.insert_coarse_multi(ivpq["coarse"], v)
+    P = ivpq["coarse"].shape[0]
+    assert np.array_equal(multi, got["coarse_multi_codes"][:, 0].astype(np.int32) + P * got["coarse_multi_codes"][:, 1].astype(np.int32))
+    # a vector 100 or farther from every centroid: undefined in the reference, an error here
+    with pytest.raises(gpu.FreddyGpuError):
+        gpu.insert_quantize(v * np.float32(40.0), pq_codebook=pq["codebook"])
+
+
+def test_append_rows_and_update_codebook_equal_a_fresh_pin(oracle):
+    """HBM mutation: rows appended to pinned pq / ivf / ivpq / vector indexes and a replaced codebook give
+    the same results as pinning the final tables from scratch (and as the oracle on those tables)."""
+    from freddy_amd import gpu
+    N, n_new = 20000, 333
+    pq, ivf, ivpq = util.pq_tables(), util.ivf_tables(), util.ivpq_tables()
+    x = util.corpus(N).numpy()
+    v = _new_vectors(n_new, seed=9)
+    new_ids = np.arange(N + 5, N + 5 + 2 * n_new, 2, dtype=np.int32)
+    q = gpu.insert_quantize(v, pq_codebook=pq["codebook"], residual_codebook=ivf["codebook"], coarse=ivf["coarse"],
+                            ivpq_codebook=ivpq["codebook"], coarse_multi=ivpq["coarse"])
+    _, qs = util.queries_from_corpus(N, 40)
+    qs = np.concatenate([qs, v[:24]])
+    rng = np.random.default_rng(2)
+
+    def nudged(cb):   # a "running mean" style change of some entries
+        out = cb.copy()
+        out[:, ::3] += np.float32(0.01) * rng.standard_normal(out[:, ::3].shape).astype(np.float32)
+        return out
+
+    # pq
+    idx = gpu.PQIndex(pq["codebook"], pq["ids"], pq["codes"])
+    idx.append_rows(new_ids, codes=q["pq_codes"])
+    cb2 = nudged(pq["codebook"])
+    idx.update_codebook(cb2)
+    ids2, codes2 = np.concatenate([pq["ids"], new_ids]), np.concatenate([pq["codes"], q["pq_codes"]])
+    ot = oracle.pq_table(cb2, ids2, codes2)
+    gi, gd = idx.search(qs, 7, sentinel=100.0)
+    util.assert_same_lists(gi, gd, np.stack([oracle.pq_search(ot, qq, 7) for qq in qs]), "pq after append")
+    gi, gd = idx.search(qs, 5, sentinel=1000.0, subset_ids=new_ids[::2])
+    util.assert_same_lists(gi, gd, oracle.pq_search_in_batch(ot, qs, 5, new_ids[::2]), "pq_search_in on appended ids")
+    idx.close()
+    # ivf: appended rows join the END of their cell's list (two batches: the second finds partially filled blocks)
+    idx = gpu.IVFIndex(ivf["coarse"], ivf["codebook"], ivf["list_off"], ivf["ids"], ivf["codes"])
+    h = n_new // 2
+    idx.append_rows(new_ids[:h], coarse_id=q["coarse_id"][:h], codes=q["residual_codes"][:h])
+    idx.append_rows(new_ids[h:], coarse_id=q["coarse_id"][h:], codes=q["residual_codes"][h:])
+    cb2 = nudged(ivf["codebook"])
+    idx.update_codebook(cb2)
+    C = len(ivf["list_off"]) - 1
+    cell_old = np.repeat(np.arange(C), np.diff(ivf["list_off"]))
+    cell_all = np.concatenate([cell_old, q["coarse_id"]])
+    ids_all, codes_all = np.concatenate([ivf["ids"], new_ids]), np.concatenate([ivf["codes"], q["residual_codes"]])
+    order = np.lexsort((ids_all, cell_all))
+    lo = np.zeros(C + 1, np.int32)
+    lo[1:] = np.cumsum(np.bincount(cell_all, minlength=C))
+    ot = oracle.ivf_table(ivf["coarse"], cb2, lo, ids_all[order], codes_all[order])
+    fresh = gpu.IVFIndex(ivf["coarse"], cb2, lo, ids_all[order], codes_all[order])
+    for fused in (1, 0):
+        idx.set_option("fused", fused)
+        fresh.set_option("fused", fused)
+        for k, W in ((5, 3), (10, 1)):
+            gi, gd = idx.search(qs, k, W)
+            fi, fd = fresh.search(qs, k, W)
+            util.assert_same_lists(gi, gd, oracle.ivfadc_search_many(ot, qs, k, W), f"ivf after append fused={fused} W={W}")
+            assert np.array_equal(gi, fi) and np.array_equal(gd.view(np.uint32), fd.view(np.uint32))
+    assert idx.bound_violations() == 0
+    assert (gi >= N + 5).any(), "appended rows must be reachable"
+    idx.close(); fresh.close()
+    # ivpq (kNN-join) with vectors
+    P = ivpq["coarse"].shape[0]
+    multi = q["coarse_multi_codes"][:, 0].astype(np.int32) + ivpq["coarse"].shape[1] * q["coarse_multi_codes"][:, 1].astype(np.int32)
+    idx = gpu.IVPQIndex(ivpq["codebook"], ivpq["coarse"], ivpq["ids"], ivpq["coarse_id"], ivpq["codes"], ivpq["vectors"], ivpq["stats"])
+    idx.append_rows(new_ids, coarse_id=multi, codes=q["ivpq_codes"], vectors=v)
+    ot = oracle.ivpq_table(ivpq["codebook"], ivpq["coarse"], np.concatenate([ivpq["ids"], new_ids]),
+                           np.concatenate([ivpq["coarse_id"], multi]), np.concatenate([ivpq["codes"], q["ivpq_codes"]]),
+                           np.concatenate([ivpq["vectors"], v]), ivpq["stats"])
+    targets = np.concatenate([rng.choice(ivpq["ids"], 600, replace=False), new_ids[::3]]).astype(np.int32)
+    for method in (0, 2):
+        gi, gd, it = idx.knn_join(qs, 5, targets, 3, 4, method)
+        exp, eit = oracle.ivpq_search_in(ot, qs, 5, targets, 3, 4, method)
+        assert it == eit
+        util.assert_same_lists(gi, gd, exp, f"knn_join after append, method {method}")
+    idx.close()
+    # raw vectors (exact kNN)
+    base_ids = np.arange(1, N + 1, dtype=np.int32)
+    idx = gpu.VectorIndex(base_ids, x)
+    idx.append_rows(new_ids, vectors=v)
+    fresh = gpu.VectorIndex(np.concatenate([base_ids, new_ids]), np.concatenate([x, v]))
+    gi, gs = idx.search(qs, 6)
+    fi, fs = fresh.search(qs, 6)
+    assert np.array_equal(gi, fi) and np.array_equal(gs.view(np.uint32), fs.view(np.uint32))
+    gi, gs = idx.search(qs, 4, subset_ids=new_ids[:50])
+    fi, fs = fresh.search(qs, 4, subset_ids=new_ids[:50])
+    assert np.array_equal(gi, fi) and np.array_equal(gs.view(np.uint32), fs.view(np.uint32))
+    idx.close(); fresh.close()
+    # ids must ascend beyond what is pinned
+    idx = gpu.PQIndex(pq["codebook"], pq["ids"], pq["codes"])
+    with pytest.raises(gpu.FreddyGpuError):
+        idx.append_rows(np.array([5], np.int32), codes=q["pq_codes"][:1])
+    idx.close()
