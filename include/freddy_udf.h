@@ -158,6 +158,35 @@ int knn_in_pq(freddy_session_t* s, const float* query, int32_t dim, int32_t k, c
 int k_nearest_neighbour_ivfadc_batch(freddy_session_t* s, const int32_t* query_ids, int32_t n_query_ids, int32_t k,
                                      freddy_row3* out, int32_t* n_rows);
 
+/* Next row (remainder): analogy over an input set and the clustering functions, by row id.
+ * analogy_3cosadd_in_pq / analogy_3cosadd_in_ivpq                        freddy--0.0.1.sql:1348-1426
+ *   as analogy_3cosadd_pq, candidates from pq_search_in(q, get_pvf() + 3, input ids) resp.
+ *   ivpq_search_in(ARRAY[q], '{0}', 4, input ids, get_alpha(), get_pvf(), get_method_flag(), ...) (k is the literal 4 there).
+ * cluster_exact / cluster_pq / cluster_ivpq = generic_cluster             freddy--0.0.1.sql:1086-1209
+ *   k-means in the reference's plpgsql: k random tokens as initial centroids, 10 rounds of "every token goes to the
+ *   centroid that lists it with the highest similarity" (rows of knn_search_in_batch / knn_in_pq_batch /
+ *   knn_in_ivpq_batch with k = all tokens, ORDER BY similarity DESC; ties: centroid, then token position), centroids
+ *   re-estimated by centroid_bytea over 10 random members -- empty clusters draw their samples and keep their
+ *   centroid, as the reference does.  `draws` are the values random() returns, in call order (k, then 10 per
+ *   cluster and round): a caller-supplied sequence makes a run reproducible; once it is used up (or NULL) an
+ *   internal generator continues.  cluster_out[i] = 1..k for token i (0: no centroid listed it). */
+int analogy_3cosadd_in_pq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, const int32_t* input_ids, int32_t n_ids, int32_t* result);
+int analogy_3cosadd_in_ivpq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, const int32_t* input_ids, int32_t n_ids, int32_t* result);
+int cluster_exact(freddy_session_t* s, const int32_t* token_ids, int32_t n, int32_t k, const double* draws, int32_t n_draws, int32_t* cluster_out);
+int cluster_pq(freddy_session_t* s, const int32_t* token_ids, int32_t n, int32_t k, const double* draws, int32_t n_draws, int32_t* cluster_out);
+int cluster_ivpq(freddy_session_t* s, const int32_t* token_ids, int32_t n, int32_t k, const double* draws, int32_t n_draws, int32_t* cluster_out);
+
+/* Next row: insert_batch(varchar[]) -> int4                  freddy.c:1403-1658
+ * The tokenisation sub-query (:1503-1519: tokenize(term) for the terms NOT yet in the vocabulary) stays with SQL;
+ * the caller passes its result, the normalised vectors of the new terms.  Per vector: PQ code, coarse cell +
+ * residual code, ivpq code + multi-index cell (device); the three codebooks' running update exactly as
+ * updateCodebook / updateCodebookRelation compute and store it (index_utils.c:908-991, "%f" text included);
+ * one row per table with id = max(id) + 1 of THAT table (index_utils.c:993-1074); every pinned index is extended in
+ * HBM.  new_ids (may be NULL) receives the ids given in google_vecs_norm.  The count column of a codebook is 1
+ * unless freddy_set_codebook_counts (table: 0 pq_codebook, 1 residual_codebook, 2 codebook_ivpq) has set it. */
+int freddy_set_codebook_counts(freddy_session_t* s, int32_t table, const int32_t* pos, const int32_t* code, const int32_t* count, int32_t n);
+int insert_batch(freddy_session_t* s, const float* norm_vectors, int32_t n, int32_t dim, int32_t* new_ids);
+
 /* per-call row emit: snprintf("%d") / snprintf("%f") into 16-byte buffers   freddy.c:154-169,1001-1023 */
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]);
 void freddy_emit_row3(const freddy_row3* row, char values[3][16]);

@@ -215,6 +215,41 @@ class Session:
         self._check(self.lib.analogy_3cosadd_ivfadc(self.h, int(id1), int(id2), int(id3), C.byref(r)))
         return r.value
 
+    def analogy_3cosadd_in_pq(self, id1, id2, id3, input_ids):
+        r, ids = C.c_int32(-1), _i32(input_ids)
+        self._check(self.lib.analogy_3cosadd_in_pq(self.h, int(id1), int(id2), int(id3), _p(ids), ids.size, C.byref(r)))
+        return r.value
+
+    def analogy_3cosadd_in_ivpq(self, id1, id2, id3, input_ids):
+        r, ids = C.c_int32(-1), _i32(input_ids)
+        self._check(self.lib.analogy_3cosadd_in_ivpq(self.h, int(id1), int(id2), int(id3), _p(ids), ids.size, C.byref(r)))
+        return r.value
+
+    def _cluster(self, fn, token_ids, k, draws):
+        ids = _i32(token_ids)
+        dr = None if draws is None else np.ascontiguousarray(draws, dtype=np.float64)
+        out = np.zeros(ids.size, np.int32)
+        self._check(fn(self.h, _p(ids), ids.size, int(k), _p(dr), 0 if dr is None else dr.size, _p(out)))
+        return out
+
+    def cluster_exact(self, token_ids, k, draws=None): return self._cluster(self.lib.cluster_exact, token_ids, k, draws)
+    def cluster_pq(self, token_ids, k, draws=None): return self._cluster(self.lib.cluster_pq, token_ids, k, draws)
+    def cluster_ivpq(self, token_ids, k, draws=None): return self._cluster(self.lib.cluster_ivpq, token_ids, k, draws)
+
+    def set_codebook_counts(self, table, counts):
+        """count column of pq_codebook (0) / residual_codebook (1) / codebook_ivpq (2): counts[m, K]."""
+        c = _i32(counts)
+        m, K = c.shape
+        pos, code = np.divmod(np.arange(m * K, dtype=np.int32), K)
+        self._check(self.lib.freddy_set_codebook_counts(self.h, int(table), _p(_i32(pos)), _p(_i32(code)), _p(c.reshape(-1)), m * K))
+
+    def insert_batch(self, norm_vectors):
+        """freddy.c:1403-1658 for the normalised vectors of NEW terms; returns the ids given in google_vecs_norm."""
+        v = _f32(norm_vectors)
+        out = np.empty(v.shape[0], np.int32)
+        self._check(self.lib.insert_batch(self.h, _p(v), v.shape[0], v.shape[1], _p(out)))
+        return out
+
     def pq_search_in_batch(self, queries, query_ids, k, input_ids, use_targetlist=True):
         qs, qid, ids = _f32(queries), _i32(query_ids), _i32(input_ids)
         out = np.empty(max(qs.shape[0], 1) * k, ROW3)

@@ -79,6 +79,13 @@ struct freddy_session {
   freddy_gpu_index_t* ivpq = nullptr;
   freddy_gpu_index_t* vecs = nullptr;  // google_vecs_norm pinned for the exact kNN functions (lazily)
   int pq_d = 0, ivf_d = 0, ivpq_d = 0;
+  // what insert_batch reads and writes besides the rows (freddy.c:1545-1560): the codebooks with their
+  // count column, the coarse quantizers, and the largest id of each table ("SELECT max(id) + 1")
+  Codebook pq_cb, res_cb, ivpq_cb, cq_multi;
+  std::vector<int32_t> pq_counts, res_counts, ivpq_counts;   // count column; 1 unless freddy_set_codebook_counts was called
+  std::vector<float> coarse;                                 // [C][d]
+  int C = 0;
+  int32_t pq_max_id = 0, fine_max_id = 0, ivpq_max_id = 0;
 };
 
 extern "C" {
@@ -133,6 +140,9 @@ int freddy_load_pq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* cb
   if (s->pq) { freddy_gpu_unpin(s->pq); s->pq = nullptr; }
   if (int rc = freddy_gpu_pin_pq(&desc, s->device, &s->pq)) return gpu_fail(rc);
   s->pq_d = cb.m * cb.s;
+  s->pq_cb = cb;
+  s->pq_counts.assign((size_t)cb.m * cb.K, 1);
+  s->pq_max_id = N ? sid[(size_t)N - 1] : 0;
   return 0;
 }
 
@@ -172,6 +182,12 @@ int freddy_load_ivfadc(freddy_session_t* s, const int32_t* coarse_ids_tbl, const
   if (s->ivf) { freddy_gpu_unpin(s->ivf); s->ivf = nullptr; }
   if (int rc = freddy_gpu_pin_ivf(&desc, s->device, &s->ivf)) return gpu_fail(rc);
   s->ivf_d = d;
+  s->res_cb = cb;
+  s->res_counts.assign((size_t)cb.m * cb.K, 1);
+  s->coarse = coarse;
+  s->C = C;
+  s->fine_max_id = 0;
+  for (int64_t i = 0; i < N; ++i) s->fine_max_id = std::max(s->fine_max_id, ids[i]);
   return 0;
 }
 
@@ -219,6 +235,10 @@ int freddy_load_ivpq(freddy_session_t* s, const int32_t* cb_pos, const int32_t* 
   if (s->ivpq) { freddy_gpu_unpin(s->ivpq); s->ivpq = nullptr; }
   if (int rc = freddy_gpu_pin_ivpq(&desc, s->device, &s->ivpq)) return gpu_fail(rc);
   s->ivpq_d = d;
+  s->ivpq_cb = cb;
+  s->ivpq_counts.assign((size_t)cb.m * cb.K, 1);
+  s->cq_multi = cq;
+  s->ivpq_max_id = N ? sid[(size_t)N - 1] : 0;
   return 0;
 }
 
@@ -357,15 +377,20 @@ int knn_join(freddy_session_t* s, const float* queries, int32_t n_queries, int32
 }
 
 // ---- exact brute force -------------------------------------------------------------
+// google_vecs_norm pinned as raw vectors, on first use
+static int ensure_vecs(freddy_session_t* s) {
+  if (s->vecs) return 0;
+  freddy_vec_desc desc = {s->d, (int64_t)s->norm_ids.size(), s->norm_ids.data(), s->norm_vecs.data()};
+  if (int rc = freddy_gpu_pin_vectors(&desc, s->device, &s->vecs)) return gpu_fail(rc);
+  return 0;
+}
+
 static int exact_common(freddy_session_t* s, const float* query, int32_t dim, int32_t k, const int32_t* input_ids,
                         int32_t n_ids, bool subset, freddy_row2* out, int32_t* n_rows) {
   if (!s || s->norm_ids.empty()) return fail(-1, "google_vecs_norm is not loaded");
   if (dim != s->d) return fail(-1, "query has %d dimensions, table has %d", dim, s->d);
   if (k <= 0 || !query || !out || n_ids < 0) return fail(-1, "bad argument");
-  if (!s->vecs) {
-    freddy_vec_desc desc = {s->d, (int64_t)s->norm_ids.size(), s->norm_ids.data(), s->norm_vecs.data()};
-    if (int rc = freddy_gpu_pin_vectors(&desc, s->device, &s->vecs)) return gpu_fail(rc);
-  }
+  if (int rc = ensure_vecs(s)) return rc;
   std::vector<int32_t> ids((size_t)k); std::vector<float> sim((size_t)k);
   const int32_t none = -1;
   const int32_t* sub = subset ? (n_ids ? input_ids : &none) : nullptr;
@@ -708,6 +733,263 @@ int k_nearest_neighbour_ivfadc_batch(freddy_session_t* s, const int32_t* query_i
     if (rows[i].id >= 0) { out[m] = rows[i]; out[m].distance = similarity_of(rows[i].distance); ++m; }
   if (n_rows) *n_rows = m;
   return 0;
+}
+
+// ---- insert_batch --------------------------------------------------------------------
+int freddy_set_codebook_counts(freddy_session_t* s, int32_t table, const int32_t* pos, const int32_t* code, const int32_t* count, int32_t n) {
+  if (!s || !pos || !code || !count) return fail(-1, "bad argument");
+  Codebook* cb = table == 0 ? &s->pq_cb : table == 1 ? &s->res_cb : table == 2 ? &s->ivpq_cb : nullptr;
+  std::vector<int32_t>* cnt = table == 0 ? &s->pq_counts : table == 1 ? &s->res_counts : table == 2 ? &s->ivpq_counts : nullptr;
+  if (!cb || cb->m == 0) return fail(-1, "that codebook is not loaded");
+  for (int i = 0; i < n; ++i) {
+    if (pos[i] < 0 || pos[i] >= cb->m || code[i] < 0 || code[i] >= cb->K) return fail(-1, "(pos, code) out of range");
+    (*cnt)[(size_t)pos[i] * cb->K + code[i]] = count[i];
+  }
+  return 0;
+}
+
+// sprintf("%f") -> '{...}'::float4[]: how every float reaches the tables (index_utils.c:976, :1053)
+static float text_roundtrip(float v) {
+  char buf[64];
+  snprintf(buf, sizeof buf, "%f", v);
+  return strtof(buf, nullptr);
+}
+
+// updateCodebook's bookkeeping + updateCodebookRelation (index_utils.c:940-991) for codes found on the device.
+// Statement by statement, slips included: `nearestCentroidRaw` is ONE pointer for all positions -- after the
+// scan in table order (position-major) it is the nearest entry of the LAST position --, that vector is what
+// every position of the row adds to its bucket, the recalculation reads bucket [pos + code] and adds
+// (1.0 / count) * bucket in double, only entries with an increment are written back, as "%f" text.
+static void update_codebook_host(Codebook& cb, std::vector<int32_t>& counts, const int16_t* codes, int n) {
+  const int m = cb.m, K = cb.K, sdim = cb.s, E = m * K;
+  std::vector<float> differences((size_t)E * sdim, 0.0f), work(cb.dense);
+  std::vector<int32_t> incs((size_t)E, 0), wcount(counts);
+  for (int i = 0; i < n; ++i) {
+    const float* nearest_raw = &work[((size_t)(m - 1) * K + codes[(size_t)i * m + (m - 1)]) * sdim];
+    for (int j = 0; j < m; ++j) {
+      const int code = codes[(size_t)i * m + j];
+      incs[(size_t)j * K + code] += 1;
+      for (int k = 0; k < sdim; ++k) differences[((size_t)j * K + code) * sdim + k] += nearest_raw[k];
+    }
+  }
+  for (int i = 0; i < E; ++i) {
+    const int pos = i / K, code = i % K;
+    wcount[(size_t)i] += incs[(size_t)pos * K + code];
+    for (int j = 0; j < sdim; ++j)
+      work[(size_t)i * sdim + j] += (1.0 / wcount[(size_t)i]) * differences[(size_t)(pos + code) * sdim + j];
+  }
+  for (int i = 0; i < E; ++i)
+    if (incs[(size_t)i] > 0) {
+      for (int j = 0; j < sdim; ++j) cb.dense[(size_t)i * sdim + j] = text_roundtrip(work[(size_t)i * sdim + j]);
+      counts[(size_t)i] = wcount[(size_t)i];
+    }
+}
+
+int insert_batch(freddy_session_t* s, const float* norm_vectors, int32_t n, int32_t dim, int32_t* new_ids) {
+  if (!s || n < 0 || (n > 0 && !norm_vectors)) return fail(-1, "bad argument");
+  if (!s->pq || !s->ivf || !s->ivpq || s->norm_ids.empty())
+    return fail(-1, "insert_batch needs google_vecs_norm, the pq, ivfadc and ivpq tables (freddy.c:1467-1481)");
+  if (dim != s->d || dim != s->pq_d || dim != s->ivf_d || dim != s->ivpq_d) return fail(-1, "vectors have %d dimensions, the tables %d", dim, s->d);
+  if (n == 0) return 0;
+  // quantisation of the new vectors on the device (freddy.c:1557-1623)
+  freddy_insert_desc desc = {dim, s->pq_cb.m, s->pq_cb.K, s->pq_cb.dense.data(), s->res_cb.m, s->res_cb.K, s->res_cb.dense.data(),
+                             s->C, s->coarse.data(), s->ivpq_cb.m, s->ivpq_cb.K, s->ivpq_cb.dense.data(),
+                             s->cq_multi.m, s->cq_multi.K, s->cq_multi.dense.data()};
+  std::vector<int16_t> pq_codes((size_t)n * s->pq_cb.m), res_codes((size_t)n * s->res_cb.m), iv_codes((size_t)n * s->ivpq_cb.m),
+      multi((size_t)n * s->cq_multi.m);
+  std::vector<int32_t> cq((size_t)n);
+  if (int rc = freddy_gpu_insert_quantize(&desc, s->device, norm_vectors, n, pq_codes.data(), cq.data(), res_codes.data(),
+                                          iv_codes.data(), multi.data()))
+    return gpu_fail(rc);
+  // multi-index cell: factor *= POSITIONS (freddy.c:1599, sic)
+  std::vector<int32_t> cq_multi_id((size_t)n, 0);
+  for (int i = 0; i < n; ++i) {
+    int factor = 1;
+    for (int p = 0; p < s->cq_multi.m; ++p) { cq_multi_id[(size_t)i] += factor * multi[(size_t)i * s->cq_multi.m + p]; factor *= s->cq_multi.m; }
+  }
+  // the three codebooks (index_utils.c:940-991)
+  update_codebook_host(s->pq_cb, s->pq_counts, pq_codes.data(), n);
+  update_codebook_host(s->res_cb, s->res_counts, res_codes.data(), n);
+  update_codebook_host(s->ivpq_cb, s->ivpq_counts, iv_codes.data(), n);
+  // the rows: every INSERT takes (SELECT max(id) + 1 FROM <its table>)   index_utils.c:1003-1021, 1046-1058
+  std::vector<int32_t> id_pq((size_t)n), id_fine((size_t)n), id_iv((size_t)n), id_norm((size_t)n);
+  std::vector<float> stored((size_t)n * dim);
+  for (size_t i = 0; i < stored.size(); ++i) stored[i] = text_roundtrip(norm_vectors[i]);
+  for (int i = 0; i < n; ++i) {
+    id_pq[(size_t)i] = ++s->pq_max_id;
+    id_fine[(size_t)i] = ++s->fine_max_id;
+    id_iv[(size_t)i] = ++s->ivpq_max_id;
+    id_norm[(size_t)i] = s->norm_ids.back() + 1 + i;
+  }
+  if (int rc = freddy_gpu_append_rows(s->pq, n, id_pq.data(), nullptr, pq_codes.data(), nullptr)) return gpu_fail(rc);
+  if (int rc = freddy_gpu_append_rows(s->ivf, n, id_fine.data(), cq.data(), res_codes.data(), nullptr)) return gpu_fail(rc);
+  // (a cell id built with factor = positions can exceed codes^2 only if positions > codes; it is stored as the reference stores it)
+  if (int rc = freddy_gpu_append_rows(s->ivpq, n, id_iv.data(), cq_multi_id.data(), iv_codes.data(), stored.data())) return gpu_fail(rc);
+  if (int rc = freddy_gpu_update_codebook(s->pq, s->pq_cb.dense.data())) return gpu_fail(rc);
+  if (int rc = freddy_gpu_update_codebook(s->ivf, s->res_cb.dense.data())) return gpu_fail(rc);
+  if (int rc = freddy_gpu_update_codebook(s->ivpq, s->ivpq_cb.dense.data())) return gpu_fail(rc);
+  if (s->vecs) if (int rc = freddy_gpu_append_rows(s->vecs, n, id_norm.data(), nullptr, nullptr, stored.data())) return gpu_fail(rc);
+  s->norm_ids.insert(s->norm_ids.end(), id_norm.begin(), id_norm.end());
+  s->norm_vecs.insert(s->norm_vecs.end(), stored.begin(), stored.end());
+  if (new_ids) memcpy(new_ids, id_norm.data(), sizeof(int32_t) * (size_t)n);
+  return 0;
+}
+
+// ---- analogy_3cosadd_in_pq / analogy_3cosadd_in_ivpq      freddy--0.0.1.sql:1348-1426 --------------------
+static int analogy_in_common(freddy_session_t* s, bool ivpq, int32_t id1, int32_t id2, int32_t id3, const int32_t* input_ids,
+                             int32_t n_ids, int32_t* result) {
+  if (!s || !result || n_ids < 0 || (n_ids > 0 && !input_ids)) return fail(-1, "bad argument");
+  if (ivpq ? !s->ivpq : !s->pq) return fail(-1, ivpq ? "the ivpq tables are not loaded" : "pq_quantization / pq_codebook are not loaded");
+  if (s->norm_ids.empty() || s->d != (ivpq ? s->ivpq_d : s->pq_d)) return fail(-1, "google_vecs_norm is not loaded");
+  *result = -1;
+  const float *v1 = norm_vec_of(s, id1), *v2 = norm_vec_of(s, id2), *v3 = norm_vec_of(s, id3);
+  if (!v1 || !v2 || !v3) return 0;
+  std::vector<float> raw, unit;
+  vec3cosadd(v1, v2, v3, s->d, raw, unit);
+  // pq: pq_search_in(q, get_pvf() + 3, ids of the input set); ivpq: ivpq_search_in(ARRAY[q], '{0}', 4, ids, alpha, pvf,
+  // method_flag, use_targetlist, confidence, long_codes_threshold) -- k is the literal 4 there (:1414)
+  const int k = ivpq ? 4 : s->pvf + 3;
+  std::vector<int32_t> ids((size_t)k); std::vector<float> dist((size_t)k);
+  const int32_t none = -1;
+  const int rc = ivpq ? freddy_gpu_knn_join(s->ivpq, unit.data(), 1, k, input_ids, n_ids, s->alpha, s->pvf, s->method_flag,
+                                            s->use_targetlist, s->confidence, s->long_codes_threshold, ids.data(), dist.data(), nullptr)
+                      : freddy_gpu_pq_search(s->pq, unit.data(), 1, k, 1000.0f, n_ids ? input_ids : &none, n_ids ? n_ids : 1,
+                                             ids.data(), dist.data());
+  if (rc) return gpu_fail(rc);
+  bool have = false;
+  float best = 0;
+  for (int i = 0; i < k; ++i) {
+    const int32_t id = ids[i];
+    if (id < 0 || id == id1 || id == id2 || id == id3) continue;
+    const float* v4 = norm_vec_of(s, id);
+    if (!v4) continue;
+    const float sim = cos_sim_bytea(raw.data(), v4, s->d);
+    if (!have || sim > best || (sim == best && id < *result)) { have = true; best = sim; *result = id; }
+  }
+  return 0;
+}
+int analogy_3cosadd_in_pq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, const int32_t* input_ids, int32_t n_ids, int32_t* result) {
+  return analogy_in_common(s, false, id1, id2, id3, input_ids, n_ids, result);
+}
+int analogy_3cosadd_in_ivpq(freddy_session_t* s, int32_t id1, int32_t id2, int32_t id3, const int32_t* input_ids, int32_t n_ids, int32_t* result) {
+  return analogy_in_common(s, true, id1, id2, id3, input_ids, n_ids, result);
+}
+
+// ---- cluster_exact / cluster_pq / cluster_ivpq = generic_cluster      freddy--0.0.1.sql:1086-1209 --------------
+namespace {
+struct SimRow { float sim; int qid; int tid; };
+}
+
+// (query, target, similarity) rows of knn_search_in_batch / knn_in_pq_batch / knn_in_ivpq_batch (bytea[] overloads:
+// query = 1-based centroid index) for k = all tokens; target as 1-based token index
+static int cluster_knn(freddy_session_t* s, int method, const std::vector<float>& centroids, int kc, const int32_t* token_ids, int n,
+                       std::vector<SimRow>& rows) {
+  const int d = s->d;
+  rows.clear();
+  std::vector<int32_t> ids((size_t)kc * n); std::vector<float> val((size_t)kc * n);
+  if (method == 0) {          // knn_in_exact per centroid: cosine_similarity_bytea DESC (freddy--0.0.1.sql:456-476, 1041-1054)
+    if (int rc = ensure_vecs(s)) return rc;
+    if (int rc = freddy_gpu_exact_search(s->vecs, centroids.data(), kc, n, token_ids, n, ids.data(), val.data())) return gpu_fail(rc);
+  } else if (method == 1) {   // pq_search_in_batch (:880-902)
+    if (!s->pq) return fail(-1, "pq_quantization / pq_codebook are not loaded");
+    if (int rc = freddy_gpu_pq_search(s->pq, centroids.data(), kc, n, 1000.0f, token_ids, n, ids.data(), val.data())) return gpu_fail(rc);
+  } else {                    // ivpq_search_in through knn_in_iv_batch (:754-795)
+    if (!s->ivpq) return fail(-1, "the ivpq tables are not loaded");
+    if (int rc = freddy_gpu_knn_join(s->ivpq, centroids.data(), kc, n, token_ids, n, s->alpha, s->pvf, s->method_flag, s->use_targetlist,
+                                     s->confidence, s->long_codes_threshold, ids.data(), val.data(), nullptr))
+      return gpu_fail(rc);
+  }
+  // token id -> 1-based token index (INNER JOIN unnest(token_ids, tokens) ON token = target; duplicates: every index)
+  std::vector<std::pair<int32_t, int>> by_id((size_t)n);
+  for (int i = 0; i < n; ++i) by_id[(size_t)i] = {token_ids[i], i + 1};
+  std::sort(by_id.begin(), by_id.end());
+  for (int qi = 0; qi < kc; ++qi)
+    for (int r = 0; r < n; ++r) {
+      const int32_t id = ids[(size_t)qi * n + r];
+      if (id < 0) continue;   // the joins drop the (-1, sentinel) filler rows
+      const float sim = method == 0 ? val[(size_t)qi * n + r] : similarity_of(val[(size_t)qi * n + r]);
+      auto it = std::lower_bound(by_id.begin(), by_id.end(), std::make_pair(id, 0));
+      for (; it != by_id.end() && it->first == id; ++it) rows.push_back({sim, qi + 1, it->second});
+    }
+  // ORDER BY similarity DESC (ties are unspecified in SQL: query, then token position)
+  std::stable_sort(rows.begin(), rows.end(), [](const SimRow& a, const SimRow& b) {
+    if (a.sim != b.sim) return a.sim > b.sim;
+    if (a.qid != b.qid) return a.qid < b.qid;
+    return a.tid < b.tid;
+  });
+  return 0;
+}
+
+static int generic_cluster(freddy_session_t* s, int method, const int32_t* token_ids, int32_t n, int32_t k, const double* draws,
+                           int32_t n_draws, int32_t* cluster_out) {
+  if (!s || !token_ids || n <= 0 || k <= 0 || !cluster_out) return fail(-1, "bad argument");
+  if (s->norm_ids.empty()) return fail(-1, "google_vecs_norm is not loaded");
+  const int d = s->d;
+  int used = 0;
+  uint64_t state = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() -> double {   // random(): the caller's sequence first (reproducible runs), then an xorshift
+    if (draws && used < n_draws) return draws[used++];
+    state ^= state << 13; state ^= state >> 7; state ^= state << 17;
+    return (double)(state >> 11) / 9007199254740992.0;
+  };
+  auto pick = [&](int upper) -> int {   // round(random() * upper + 0.5): 1..upper
+    const int v = (int)std::nearbyint(rnd() * upper + 0.5);   // float8 round() is rint()
+    return v < 1 ? 1 : (v > upper ? upper : v);
+  };
+  std::vector<const float*> tok((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    tok[(size_t)i] = norm_vec_of(s, token_ids[i]);
+    if (!tok[(size_t)i]) return fail(-1, "token id %d has no vector", token_ids[i]);
+  }
+  std::vector<float> centroids((size_t)k * d);
+  std::vector<int> clusters((size_t)n, 0), lens((size_t)k, 0);
+  std::vector<char> processed((size_t)n, 0);
+  for (int I = 0; I < k; ++I) memcpy(&centroids[(size_t)I * d], tok[(size_t)pick(n) - 1], sizeof(float) * d);   // :1107-1112
+  std::vector<SimRow> rows;
+  for (int J = 1; J <= 10; ++J) {                                                                                  // :1114
+    if (int rc = cluster_knn(s, method, centroids, k, token_ids, n, rows)) return rc;
+    for (const SimRow& r : rows)                                                                                   // :1122-1128
+      if (!processed[(size_t)r.tid - 1]) {
+        clusters[(size_t)r.tid - 1] = r.qid;
+        lens[(size_t)r.qid - 1] += 1;
+        processed[(size_t)r.tid - 1] = 1;
+      }
+    if (J < 10) {
+      for (int I = 1; I <= k; ++I) {                                                                               // :1131-1156
+        if (lens[(size_t)I - 1] == 0) {
+          for (int t = 0; t < 10; ++t) (void)pick(n);   // ten samples are drawn and thrown away: the centroid keeps its value (:1133-1142)
+        } else {
+          std::vector<int> members;   // tokens of cluster I, in token order
+          for (int i = 0; i < n; ++i) if (clusters[(size_t)i] == I) members.push_back(i);
+          const int len = lens[(size_t)I - 1];
+          std::vector<const float*> samples;
+          for (int t = 0; t < 10; ++t) {   // r.x INNER JOIN x.id: ten draws with replacement (draws beyond the members vanish)
+            const int x = pick(len);
+            if (x <= (int)members.size()) samples.push_back(tok[(size_t)members[(size_t)x - 1]]);
+          }
+          if (!samples.empty()) {   // centroid_bytea: output[j] += data[i][j] / (float) n   core_functions.c:371-379
+            float* c = &centroids[(size_t)(I - 1) * d];
+            for (int j = 0; j < d; ++j) c[j] = 0;
+            for (size_t i = 0; i < samples.size(); ++i)
+              for (int j = 0; j < d; ++j) c[j] += samples[i][j] / (float)samples.size();
+          }
+          lens[(size_t)I - 1] = 0;
+        }
+      }
+      std::fill(processed.begin(), processed.end(), 0);                                                            // :1158-1160
+    }
+  }
+  for (int i = 0; i < n; ++i) cluster_out[i] = clusters[(size_t)i];
+  return 0;
+}
+int cluster_exact(freddy_session_t* s, const int32_t* token_ids, int32_t n, int32_t k, const double* draws, int32_t n_draws, int32_t* cluster_out) {
+  return generic_cluster(s, 0, token_ids, n, k, draws, n_draws, cluster_out);
+}
+int cluster_pq(freddy_session_t* s, const int32_t* token_ids, int32_t n, int32_t k, const double* draws, int32_t n_draws, int32_t* cluster_out) {
+  return generic_cluster(s, 1, token_ids, n, k, draws, n_draws, cluster_out);
+}
+int cluster_ivpq(freddy_session_t* s, const int32_t* token_ids, int32_t n, int32_t k, const double* draws, int32_t n_draws, int32_t* cluster_out) {
+  return generic_cluster(s, 2, token_ids, n, k, draws, n_draws, cluster_out);
 }
 
 void freddy_emit_row2(const freddy_row2* row, char values[2][16]) {

@@ -361,3 +361,173 @@ def test_append_rows_and_update_codebook_equal_a_fresh_pin(oracle):
     with pytest.raises(gpu.FreddyGpuError):
         idx.append_rows(np.array([5], np.int32), codes=q["pq_codes"][:1])
     idx.close()
+
+
+def _fresh_session():
+    from freddy_amd import udf
+    x = util.corpus(N).numpy()
+    ids_all = np.arange(1, N + 1, dtype=np.int32)
+    s = udf.Session()
+    s.load_vecs_norm(ids_all, x)
+    pq, ivf, iv = util.pq_tables(N=N, K=256), util.ivf_tables(N=N, C=32, K=256), util.ivpq_tables(N=N)
+    cell_of = np.repeat(np.arange(32), np.diff(ivf["list_off"])).astype(np.int32)
+    s.load_pq(pq["codebook"], pq["ids"], pq["codes"])
+    s.load_ivfadc(ivf["coarse"], ivf["codebook"], ivf["ids"], cell_of, ivf["codes"])
+    s.load_ivpq(iv["codebook"], iv["coarse"], iv["ids"], iv["coarse_id"], iv["codes"], iv["stats"])
+    return s, x, pq, ivf, iv, cell_of
+
+
+def test_insert_batch_udf(oracle):
+    """insert_batch (freddy.c:1403-1658) through the host mirror: afterwards every search answers as the oracle
+    does on the tables the reference would hold -- new rows with max(id) + 1, codebook entries nudged by
+    updateCodebook's own arithmetic (index_utils.c:908-991), every float stored through "%f"."""
+    s, x, pq, ivf, iv, cell_of = _fresh_session()
+    rng = np.random.default_rng(3)
+    counts = {name: rng.integers(1, 400, size=t["codebook"].shape[:2]).astype(np.int32) for name, t in (("pq", pq), ("ivf", ivf), ("iv", iv))}
+    s.set_codebook_counts(0, counts["pq"]); s.set_codebook_counts(1, counts["ivf"]); s.set_codebook_counts(2, counts["iv"])
+    v = _new_vectors(29, seed=13)
+    new_ids = s.insert_batch(v)
+    assert new_ids.tolist() == list(range(N + 1, N + 30))
+    stored = oracle.text_roundtrip(v)
+    # --- the tables after the reference's insert_batch ---
+    pq_cb, _, pq_codes, pq_incs = oracle.update_codebook(pq["codebook"], counts["pq"].reshape(-1), v)
+    cq, res = oracle.insert_coarse(ivf["coarse"], v)
+    res_cb, _, res_codes, _ = oracle.update_codebook(ivf["codebook"], counts["ivf"].reshape(-1), res)
+    iv_cb, _, iv_codes, _ = oracle.update_codebook(iv["codebook"], counts["iv"].reshape(-1), v)
+    multi = oracle.insert_coarse_multi(iv["coarse"], v)
+    assert pq_incs.sum() == 29 * pq["codebook"].shape[0] and (pq_cb != pq["codebook"]).any()
+    ot_pq = oracle.pq_table(pq_cb, np.concatenate([pq["ids"], new_ids]), np.concatenate([pq["codes"], pq_codes]))
+    cell_all = np.concatenate([cell_of, cq])
+    ids_all, codes_all = np.concatenate([ivf["ids"], new_ids]), np.concatenate([ivf["codes"], res_codes])
+    order = np.lexsort((ids_all, cell_all))
+    lo = np.zeros(33, np.int32); lo[1:] = np.cumsum(np.bincount(cell_all, minlength=32))
+    ot_ivf = oracle.ivf_table(ivf["coarse"], res_cb, lo, ids_all[order], codes_all[order])
+    ot_iv = oracle.ivpq_table(iv_cb, iv["coarse"], np.concatenate([iv["ids"], new_ids]), np.concatenate([iv["coarse_id"], multi]),
+                              np.concatenate([iv["codes"], iv_codes]), np.concatenate([x, stored]), iv["stats"])
+    # --- searches ---
+    for q in list(v[:6]) + [x[77], x[4000]]:
+        same(s.pq_search(q, 6), oracle.pq_search(ot_pq, q, 6))
+        same(s.ivfadc_search(q, 6), oracle.ivfadc_search(ot_ivf, q, 6, 3))
+    qs = np.concatenate([v[:10], x[100:110]])
+    qids = np.arange(1, 21, dtype=np.int32)
+    targets = np.concatenate([np.arange(1, N + 1, 23), new_ids]).astype(np.int32)
+    for method in (0, 2):
+        rows = s.ivpq_search_in(qs, qids, 4, targets, 3, 5, method, True, 0.8, 10000000)
+        exp, _ = oracle.ivpq_search_in(ot_iv, qs, 4, targets, 3, 5, method)
+        same(rows, exp)
+    hit = s.pq_search(v[0], 6)["id"]
+    assert (hit > N).any(), "an inserted vector must find its own row"
+    # exact kNN sees the rows as stored ("%f" text, six decimals)
+    got = s.k_nearest_neighbour(stored[3], 3)
+    exp = oracle.exact_knn(np.concatenate([x, stored]), np.arange(1, N + 30, dtype=np.int32), stored[3], 3)
+    assert np.array_equal(got["id"], exp["id"]) and np.array_equal(got["distance"].view(np.uint32), exp["dist"].view(np.uint32))
+    # a second batch continues the id sequences and meets the updated codebooks
+    new2 = s.insert_batch(v[:3] * np.float32(0.999))
+    assert new2.tolist() == [N + 30, N + 31, N + 32]
+    s.close()
+
+
+def _sim_of(oracle, dist):
+    return np.float32(1.0 - float(oracle.emit_roundtrip(dist)) / 2.0)
+
+
+def _cluster_reference(knn_rows, vectors, n, k, draws):
+    """generic_cluster (freddy--0.0.1.sql:1086-1209) restated; knn_rows(centroids) -> [(similarity, qid, tid)]."""
+    it = iter(draws)
+    pick = lambda upper: int(min(max(np.rint(next(it) * upper + 0.5), 1), upper))
+    d = vectors.shape[1]
+    centroids = np.stack([vectors[pick(n) - 1] for _ in range(k)]).astype(np.float32)
+    clusters, lens = np.zeros(n, np.int32), np.zeros(k, np.int64)
+    for J in range(1, 11):
+        processed = np.zeros(n, bool)
+        rows = sorted(knn_rows(centroids), key=lambda r: (-r[0], r[1], r[2]))
+        for sim, qid, tid in rows:
+            if not processed[tid - 1]:
+                clusters[tid - 1] = qid; lens[qid - 1] += 1; processed[tid - 1] = True
+        if J < 10:
+            for I in range(1, k + 1):
+                if lens[I - 1] == 0:
+                    for _ in range(10):
+                        pick(n)
+                else:
+                    members = np.flatnonzero(clusters == I)
+                    samples = []
+                    for _ in range(10):
+                        xx = pick(int(lens[I - 1]))
+                        if xx <= len(members):
+                            samples.append(vectors[members[xx - 1]])
+                    if samples:
+                        c = np.zeros(d, np.float32)
+                        for smp in samples:
+                            c = (c + smp / np.float32(len(samples))).astype(np.float32)
+                        centroids[I - 1] = c
+                    lens[I - 1] = 0
+    return clusters
+
+
+@pytest.mark.parametrize("which", ["exact", "pq", "ivpq"])
+def test_cluster_functions(db, oracle, which):
+    """cluster_exact / cluster_pq / cluster_ivpq = generic_cluster with the three batch kNN functions; the random()
+    draws are supplied, so the whole 10-round k-means must reproduce the restatement built from the oracle."""
+    s, t = db
+    x = t["x"]
+    rng = np.random.default_rng(31)
+    tokens = np.sort(rng.choice(np.arange(1, N + 1), 90, replace=False)).astype(np.int32)
+    vecs = x[tokens - 1]
+    k = 5
+    draws = rng.random(k + 9 * k * 10)
+    n = len(tokens)
+    s.set_alpha(3); s.set_pvf(4); s.set_method_flag(0)
+
+    def rows_exact(cent):
+        out = []
+        for qi, c in enumerate(cent):
+            e = oracle.exact_knn(x, np.arange(1, N + 1, dtype=np.int32), c, n, tokens)
+            out += [(np.float32(e["dist"][r]), qi + 1, int(np.searchsorted(tokens, e["id"][r])) + 1) for r in range(len(e))]
+        return out
+
+    def rows_pq(cent):
+        e = oracle.pq_search_in_batch(t["pq"], cent, n, tokens)
+        return [(_sim_of(oracle, e["dist"][qi, r]), qi + 1, int(np.searchsorted(tokens, e["id"][qi, r])) + 1)
+                for qi in range(len(cent)) for r in range(n) if e["id"][qi, r] >= 0]
+
+    def rows_ivpq(cent):
+        e, _ = oracle.ivpq_search_in(t["ivpq"], cent, n, tokens, 3, 4, 0)
+        e = e.reshape(len(cent), n)
+        return [(_sim_of(oracle, e["dist"][qi, r]), qi + 1, int(np.searchsorted(tokens, e["id"][qi, r])) + 1)
+                for qi in range(len(cent)) for r in range(n) if e["id"][qi, r] >= 0]
+
+    exp = _cluster_reference({"exact": rows_exact, "pq": rows_pq, "ivpq": rows_ivpq}[which], vecs, n, k, draws)
+    got = getattr(s, "cluster_" + which)(tokens, k, draws)
+    assert np.array_equal(got, exp), f"cluster_{which}: {np.flatnonzero(got != exp)[:10]}"
+    assert set(np.unique(got)) <= set(range(0, k + 1)) and (got > 0).mean() > 0.9
+    s.set_pvf(20)
+
+
+@pytest.mark.parametrize("which", ["pq", "ivpq"])
+def test_analogy_3cosadd_in(db, oracle, which):
+    """analogy_3cosadd_in_pq / _in_ivpq (freddy--0.0.1.sql:1348-1426): candidates from pq_search_in(q, pvf + 3, ids)
+    resp. ivpq_search_in(ARRAY[q], '{0}', 4, ids, ...), exact re-ranking, the three inputs excluded."""
+    s, t = db
+    x = t["x"]
+    s.set_pvf(6); s.set_alpha(3); s.set_method_flag(0)
+    rng = np.random.default_rng(8)
+    input_ids = np.sort(rng.choice(np.arange(1, N + 1), 400, replace=False)).astype(np.int32)
+    for (i1, i2, i3) in ((10, 200, 3000), (4321, 4322, 77)):
+        raw = oracle.vec_plus(oracle.vec_minus(x[i3 - 1], x[i1 - 1]), x[i2 - 1])
+        unit = oracle.vec_normalize(raw)
+        if which == "pq":
+            cands = oracle.pq_search_in(t["pq"], unit, 9, input_ids)["id"].tolist()
+        else:
+            e, _ = oracle.ivpq_search_in(t["ivpq"], unit[None, :], 4, input_ids, 3, 6, 0)
+            cands = e["id"].ravel().tolist()
+        best, bid = None, -1
+        for cid in cands:
+            if cid < 0 or cid in (i1, i2, i3):
+                continue
+            sim = oracle.cosine_similarity_bytea(raw, x[cid - 1])
+            if best is None or sim > best or (sim == best and cid < bid):
+                best, bid = sim, cid
+        got = getattr(s, "analogy_3cosadd_in_" + which)(i1, i2, i3, input_ids)
+        assert got == bid
+    s.set_pvf(20)
