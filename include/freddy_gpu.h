@@ -177,6 +177,16 @@ typedef struct freddy_encode_desc {
 int freddy_gpu_encode(const freddy_encode_desc* desc, int device, const float* vectors, int64_t N, int32_t* out_cell,
                       int16_t* out_codes);
 
+/* Quantizer training (index_creation/quantizer_creation.py:13-52: scipy k-means for the coarse quantizer, per
+ * sub-vector position for the PQ codebooks): Lloyd's algorithm on the device.  Initial centroids =
+ * vectors[init_rows[c]] (NULL: vectors[c mod n]); every iteration assigns each vector to its nearest centroid by
+ * squareDistance (lowest index on ties) and replaces each centroid by the binary32 mean of its members, summed
+ * in index order; an empty cluster keeps its centroid.  centroids [k][d]; assign_out [n] (may be NULL) = the
+ * assignment under the final centroids.  Deterministic: equals oracle/fo_kmeans bit for bit.  (The reference
+ * seeds scipy randomly, so its own output is not reproducible; d <= 1024.) */
+int freddy_gpu_kmeans(int device, const float* vectors, int64_t n, int32_t d, int32_t k, int32_t iters,
+                      const int32_t* init_rows, float* centroids, int32_t* assign_out);
+
 /* ---- next row: insert_batch --------------------------------------------------------------
  * Quantisation of NEW vectors as insert_batch does it (freddy.c:1557-1623): per vector the PQ code, the coarse
  * cell (argmin from minDistCoarse = 100, :1568-1575) with the code of the residual, the ivpq code, and the

@@ -1033,3 +1033,37 @@ int fo_insert_coarse_multi(const float* cq_multi, int P, int Kc, int d, const fl
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------
+ * f2  quantizer training: Lloyd's k-means                  index_creation/quantizer_creation.py:13-52
+ * The reference calls scipy.cluster.vq.kmeans (random initial centroids, no seed): there is no result of
+ * the reference to be identical to.  What is pinned here is the algorithm the device runs, so that the HIP
+ * path and this restatement agree bit for bit: centroids start at the given vectors; per iteration every
+ * vector goes to its nearest centroid by squareDistance (strict "<": lowest index on ties), a centroid
+ * becomes sum(members in index order) / count in binary32, an empty cluster keeps its centroid.
+ * ------------------------------------------------------------------------------------ */
+int fo_kmeans(const float* vecs, int64_t n, int d, int k, int iters, const int32_t* init_rows, float* centroids,
+              int32_t* assign_out) {
+  if (!vecs || !centroids || n <= 0 || d <= 0 || k <= 0 || iters < 0) return -1;
+  for (int c = 0; c < k; ++c) memcpy(centroids + (size_t)c * d, vecs + (size_t)(init_rows ? init_rows[c] : c % n) * d, sizeof(float) * (size_t)d);
+  int32_t* a = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)n);
+  float* sum = (float*)xmalloc(sizeof(float) * (size_t)d);
+  for (int it = 0; it <= iters; ++it) {
+    fo_assign_coarse(centroids, k, d, vecs, n, a);
+    if (it == iters) break;
+    for (int c = 0; c < k; ++c) {
+      int64_t cnt = 0;
+      for (int j = 0; j < d; ++j) sum[j] = 0.0f;
+      for (int64_t i = 0; i < n; ++i)
+        if (a[i] == c) {
+          ++cnt;
+          for (int j = 0; j < d; ++j) sum[j] = sum[j] + vecs[(size_t)i * d + j];
+        }
+      if (cnt > 0)
+        for (int j = 0; j < d; ++j) centroids[(size_t)c * d + j] = sum[j] / (float)cnt;
+    }
+  }
+  if (assign_out) memcpy(assign_out, a, sizeof(int32_t) * (size_t)n);
+  free(sum); free(a);
+  return 0;
+}

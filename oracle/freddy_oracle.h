@@ -202,6 +202,11 @@ void fo_encode_pq(const float* codebook, int m, int K, int s, const float* vecs,
  * by squareDistance over all d dimensions, lowest index on ties. */
 void fo_assign_coarse(const float* coarse, int C, int d, const float* vecs, int64_t n, int32_t* cell);
 
+/* ---- f2: quantizer training (quantizer_creation.py:13-52): Lloyd's k-means as the device runs it.  Initial
+ * centroids = vecs[init_rows[c]] (NULL: vecs[c mod n]); assign_out [n] (may be NULL) = the final assignment. */
+int fo_kmeans(const float* vecs, int64_t n, int d, int k, int iters, const int32_t* init_rows, float* centroids,
+              int32_t* assign_out);
+
 /* ---- f4: insert_batch (freddy.c:1403-1658, index_utils.c:908-1074) ------------------------------------- */
 float fo_text_roundtrip(float v);   /* sprintf("%f") -> float4 input, as every float the reference INSERTs / UPDATEs */
 /* updateCodebook + updateCodebookRelation: codebook [m][K][s] / counts [m*K] updated in place; codes [n][m];

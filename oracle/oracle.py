@@ -180,6 +180,15 @@ class Oracle:
         self.lib.fo_assign_coarse(_p(c), c.shape[0], c.shape[1], _p(v), v.shape[0], _p(out))
         return out
 
+    def kmeans(self, vecs, k, iters, init_rows=None):
+        v = _f32(vecs)
+        cent = np.empty((k, v.shape[1]), np.float32)
+        a = np.empty(v.shape[0], np.int32)
+        ir = None if init_rows is None else _i32(init_rows)
+        rc = self.lib.fo_kmeans(_p(v), C.c_int64(v.shape[0]), v.shape[1], k, iters, _p(ir), _p(cent), _p(a))
+        assert rc == 0, rc
+        return cent, a
+
     # ---- insert_batch (freddy.c:1403-1658) ----------------------------------------------------
     def text_roundtrip(self, a):
         a = _f32(a)

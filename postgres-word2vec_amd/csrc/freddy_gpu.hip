@@ -1511,6 +1511,61 @@ extern "C" int freddy_gpu_insert_quantize(const freddy_insert_desc* t, int devic
 }
 
 // ---------------------------------------------------------------------------------------
+// index build: quantizer training
+// ---------------------------------------------------------------------------------------
+extern "C" int freddy_gpu_kmeans(int device, const float* vectors, int64_t n, int32_t d, int32_t k, int32_t iters,
+                                 const int32_t* init_rows, float* centroids, int32_t* assign_out) {
+  if (!vectors || !centroids || n <= 0 || d <= 0 || k <= 0 || iters < 0) return fail(FREDDY_E_ARG, "bad argument");
+  if (d > 1024) return fail(FREDDY_E_LIMIT, "d=%d exceeds this build's limit of 1024 dimensions", d);
+  if (n > INT32_MAX) return fail(FREDDY_E_LIMIT, "too many training vectors");
+  HIP_TRY(hipSetDevice(device));
+  const int kpad = (k + 63) / 64 * 64;
+  std::vector<float> init((size_t)k * d);
+  for (int c = 0; c < k; ++c) {
+    const int64_t r = init_rows ? init_rows[c] : c % n;
+    if (r < 0 || r >= n) return fail(FREDDY_E_ARG, "init_rows[%d] = %lld is not a training row", c, (long long)r);
+    memcpy(&init[(size_t)c * d], vectors + (size_t)r * d, sizeof(float) * (size_t)d);
+  }
+  float *d_vec = nullptr, *d_cent = nullptr, *d_centT = nullptr;
+  int32_t* d_assign = nullptr;
+  hipStream_t s = nullptr;
+  int rc = FREDDY_OK;
+  auto cleanup = [&] {
+    void* ptrs[] = {d_vec, d_cent, d_centT, d_assign};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (s) (void)hipStreamDestroy(s);
+  };
+#define KM_TRY(expr)                                                                           \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) { cleanup(); return fail(FREDDY_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } \
+  } while (0)
+  KM_TRY(hipStreamCreate(&s));
+  KM_TRY(hipMalloc((void**)&d_vec, sizeof(float) * (size_t)n * d));
+  KM_TRY(hipMalloc((void**)&d_cent, sizeof(float) * (size_t)k * d));
+  KM_TRY(hipMalloc((void**)&d_centT, sizeof(float) * (size_t)kpad * d));
+  KM_TRY(hipMalloc((void**)&d_assign, sizeof(int32_t) * (size_t)n));
+  KM_TRY(hipMemcpyAsync(d_vec, vectors, sizeof(float) * (size_t)n * d, hipMemcpyHostToDevice, s));
+  KM_TRY(hipMemcpyAsync(d_cent, init.data(), sizeof(float) * init.size(), hipMemcpyHostToDevice, s));
+  const float inf = std::numeric_limits<float>::infinity();
+  for (int it = 0; it <= iters; ++it) {
+    hipLaunchKernelGGL(kmeans_transpose_kernel, dim3((unsigned)(((size_t)d * kpad + 255) / 256)), dim3(256), 0, s, (const float*)d_cent, d_centT, k, kpad, d);
+    hipLaunchKernelGGL(assign_coarse_kernel, dim3((unsigned)n), dim3(64), 0, s, (const float*)d_vec, (const float*)d_centT, d_assign, (int)n, k, kpad, d,
+                       inf, (int32_t*)nullptr);
+    if (it == iters) break;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3((unsigned)k), dim3(256), 0, s, (const float*)d_vec, (const int32_t*)d_assign, n, d, d_cent);
+    KM_TRY(hipGetLastError());
+  }
+  KM_TRY(hipGetLastError());
+  KM_TRY(hipMemcpyAsync(centroids, d_cent, sizeof(float) * (size_t)k * d, hipMemcpyDeviceToHost, s));
+  if (assign_out) KM_TRY(hipMemcpyAsync(assign_out, d_assign, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s));
+  KM_TRY(hipStreamSynchronize(s));
+#undef KM_TRY
+  cleanup();
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------
 // insert_batch: HBM index mutation
 // ---------------------------------------------------------------------------------------
 // new block j of list blk_cell[b] <- old block j of that list (or empty)

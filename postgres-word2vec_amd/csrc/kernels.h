@@ -544,6 +544,57 @@ __global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Quantizer training (quantizer_creation.py:13-52): Lloyd's k-means.  Assignment =
+// assign_coarse_kernel on the transposed centroids; update = kmeans_update_kernel: one workgroup per
+// cluster walks the assignment array in index order, compacts its members chunk by chunk into LDS
+// (ballot + prefix counts: the order of the members is their index order) and adds their vectors
+// dimension-parallel, member-sequential -- a binary32 sum in a fixed order, so the result does not depend on
+// the launch and equals the restatement in oracle/ bit for bit.  An empty cluster keeps its centroid.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kmeans_transpose_kernel(const float* __restrict__ cent, float* __restrict__ centT, int k, int kpad, int d) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= d * kpad) return;
+  const int dim = i / kpad, c = i - dim * kpad;
+  centT[i] = c < k ? cent[(size_t)c * d + dim] : 0.0f;
+}
+__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ vecs, const int32_t* __restrict__ assign, int64_t n,
+                                                           int d, float* __restrict__ cent) {
+  __shared__ int32_t members[256];
+  __shared__ int wcount[4];
+  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int DV = 4;   // dimensions per thread: d <= 1024
+  float sum[DV];
+#pragma unroll
+  for (int u = 0; u < DV; ++u) sum[u] = 0.0f;
+  int64_t cnt = 0;
+  for (int64_t base = 0; base < n; base += 256) {
+    const int64_t i = base + tid;
+    const bool mine = i < n && assign[i] == c;
+    const u64 mask = __ballot(mine);
+    if (lane == 0) wcount[wave] = __popcll(mask);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) off += wcount[w]; total += wcount[w]; }
+    if (mine) members[off + lanes_below(mask)] = (int32_t)(i - base);
+    __syncthreads();
+    for (int t = 0; t < total; ++t) {
+      const float* v = vecs + (size_t)(base + members[t]) * d;
+#pragma unroll
+      for (int u = 0; u < DV; ++u)
+        if (tid + 256 * u < d) sum[u] = sum[u] + v[tid + 256 * u];
+    }
+    cnt += total;
+    __syncthreads();
+  }
+  if (cnt > 0) {
+#pragma unroll
+    for (int u = 0; u < DV; ++u)
+      if (tid + 256 * u < d) cent[(size_t)c * d + tid + 256 * u] = sum[u] / (float)cnt;
+  }
+}
+
 // generic sub-vector size (runtime S): no register cache, codebook streamed from L2
 __global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __restrict__ vecs,
                                                               const int32_t* __restrict__ item_cell,

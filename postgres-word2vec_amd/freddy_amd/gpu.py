@@ -24,7 +24,7 @@ EXPORTS = [
     "freddy_gpu_profile_enable", "freddy_gpu_profile_read", "freddy_gpu_index_bytes",
     "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_filter_bound_checked", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
     "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells", "freddy_gpu_coarse_bound_checked",
-    "freddy_gpu_insert_quantize", "freddy_gpu_append_rows", "freddy_gpu_update_codebook",
+    "freddy_gpu_insert_quantize", "freddy_gpu_append_rows", "freddy_gpu_update_codebook", "freddy_gpu_kmeans",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
                                                C.c_void_p, C.c_void_p]
     lib.freddy_gpu_append_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.freddy_gpu_update_codebook.argtypes = [C.c_void_p, C.c_void_p]
+    lib.freddy_gpu_kmeans.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.freddy_gpu_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     lib.freddy_gpu_last_track.argtypes = [C.c_void_p, C.c_void_p]
     lib.freddy_gpu_profile_enable.argtypes = [C.c_void_p, C.c_int32]
@@ -411,4 +412,27 @@ def insert_quantize(vectors, pq_codebook=None, residual_codebook=None, coarse=No
     if mpp: out["coarse_multi_codes"] = np.empty((n, mp), np.int16)
     _check(lib.freddy_gpu_insert_quantize(C.byref(desc), device, _p(v), C.c_int64(n), _p(out.get("pq_codes")), _p(out.get("coarse_id")),
                                           _p(out.get("residual_codes")), _p(out.get("ivpq_codes")), _p(out.get("coarse_multi_codes"))))
+    return out
+
+
+def kmeans(vectors, k, iters=10, init_rows=None, device=0):
+    """Quantizer training on the device (quantizer_creation.py:13-52): (centroids[k, d], assignment[n])."""
+    lib = load()
+    v = _f32(vectors)
+    cent = np.empty((int(k), v.shape[1]), np.float32)
+    assign = np.empty(v.shape[0], np.int32)
+    ir = None if init_rows is None else _i32(init_rows)
+    _check(lib.freddy_gpu_kmeans(device, _p(v), C.c_int64(v.shape[0]), v.shape[1], int(k), int(iters), _p(ir), _p(cent), _p(assign)))
+    return cent, assign
+
+
+def train_pq_codebook(vectors, m, K, iters=10, seed=0, device=0):
+    """create_quantizer (quantizer_creation.py:13-30): one k-means per sub-vector position -> [m][K][d/m]."""
+    v = _f32(vectors)
+    s_ = v.shape[1] // m
+    rng = np.random.default_rng(seed)
+    out = np.empty((m, K, s_), np.float32)
+    for p in range(m):
+        init = rng.choice(v.shape[0], K, replace=v.shape[0] < K).astype(np.int32)
+        out[p], _ = kmeans(np.ascontiguousarray(v[:, p * s_:(p + 1) * s_]), K, iters, init, device)
     return out

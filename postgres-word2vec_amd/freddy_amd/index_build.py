@@ -173,3 +173,22 @@ def recall_at_k(approx_ids, exact_ids):
     for a, e in zip(approx_ids, exact_ids):
         hits += len(set(int(v) for v in a if v >= 0) & set(int(v) for v in e))
     return hits / float(exact_ids.size)
+
+
+def build_ivf_index_native(x, C=1000, m=12, K=256, train_size=100000, iters=10, seed=2, device=0):
+    """ivfadc.py on the native index-build ABI only (no torch): quantizer training = freddy_gpu_kmeans
+    (quantizer_creation.py:13-52), coarse assignment + residual codes = freddy_gpu_encode (ivfadc.py:36-96).
+    x: numpy [N][d] float32.  Same dictionary as build_ivf_index."""
+    from . import gpu
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    N = x.shape[0]
+    train = x[:train_size]
+    rng = np.random.default_rng(seed)
+    coarse, a = gpu.kmeans(train, C, iters, rng.choice(len(train), C, replace=len(train) < C).astype(np.int32), device)
+    cb = gpu.train_pq_codebook(train - coarse[a], m, K, iters, seed + 1000, device)
+    cid, codes = gpu.encode(cb, x, coarse=coarse, device=device)
+    order = np.argsort(cid, kind="stable")            # ids stay ascending inside each list
+    list_off = np.zeros(C + 1, np.int32)
+    list_off[1:] = np.cumsum(np.bincount(cid, minlength=C))
+    return dict(coarse=coarse, codebook=cb, list_off=list_off, ids=(order + 1).astype(np.int32),
+                codes=np.ascontiguousarray(codes[order]), coarse_id=cid.astype(np.int32))

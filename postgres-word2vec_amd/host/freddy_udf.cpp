@@ -517,6 +517,10 @@ int freddy_import_index(freddy_session_t* s, const char* path) {
       return fail(-1, "index file %s: pq tables have columns of different lengths", path);
     if (int rc = freddy_load_pq(s, I32(pos), I32(code), F32(vec), (int32_t)pos->rows(), (int32_t)vec->cols(), I32(id), I16(q), id->rows()))
       return rc;
+    if (has({"pq_codebook.count"})) {   // the count column insert_batch updates (index_utils.c:949-956)
+      ARR(cnt, "pq_codebook.count", 1, 1)
+      if (cnt->rows() == pos->rows()) if (int rc = freddy_set_codebook_counts(s, 0, I32(pos), I32(code), I32(cnt), (int32_t)pos->rows())) return rc;
+    }
     ++loaded;
   }
   if (has({"coarse_quantization.id", "coarse_quantization.vector", "residual_codebook.pos", "residual_codebook.code",
@@ -530,6 +534,10 @@ int freddy_import_index(freddy_session_t* s, const char* path) {
     if (int rc = freddy_load_ivfadc(s, I32(cid), F32(cv), (int32_t)cid->rows(), I32(pos), I32(code), F32(vec), (int32_t)pos->rows(),
                                     (int32_t)vec->cols(), I32(id), I32(co), I16(q), id->rows()))
       return rc;
+    if (has({"residual_codebook.count"})) {
+      ARR(cnt, "residual_codebook.count", 1, 1)
+      if (cnt->rows() == pos->rows()) if (int rc = freddy_set_codebook_counts(s, 1, I32(pos), I32(code), I32(cnt), (int32_t)pos->rows())) return rc;
+    }
     ++loaded;
   }
   if (has({"codebook_ivpq.pos", "codebook_ivpq.code", "codebook_ivpq.vector", "coarse_quantization_ivpq.pos",
@@ -547,6 +555,10 @@ int freddy_import_index(freddy_session_t* s, const char* path) {
                                   F32(qvec), (int32_t)qpos->rows(), I32(id), I32(co), I16(q), id->rows(), I32(sid), F32(sf),
                                   (int32_t)sid->rows()))
       return rc;
+    if (has({"codebook_ivpq.count"})) {
+      ARR(cnt, "codebook_ivpq.count", 1, 1)
+      if (cnt->rows() == pos->rows()) if (int rc = freddy_set_codebook_counts(s, 2, I32(pos), I32(code), I32(cnt), (int32_t)pos->rows())) return rc;
+    }
     ++loaded;
   }
 #undef ARR

@@ -700,3 +700,29 @@ def test_row_order_inside_a_list_is_free(gpu, oracle, arrange, monkeypatch):
         gi, gd = idx.search(qs, 10, 3, sentinel=1000.0, found_rule=0)
         util.assert_same_lists(gi, gd, exp, f"arrange={arrange} fused={fused} kernel={variant}")
     idx.close()
+
+
+def test_kmeans_matches_oracle(gpu, oracle):
+    """Quantizer training (quantizer_creation.py:13-52) as a native Lloyd k-means: centroids and assignment equal
+    the restatement bit for bit (fixed summation order), for the coarse quantizer shape and a PQ sub-codebook."""
+    x = util.corpus(20000).numpy()
+    rng = np.random.default_rng(21)
+    for vecs, k, iters in ((x[:6000], 40, 4), (np.ascontiguousarray(x[:5000, 50:75]), 256, 3), (x[:300], 7, 6)):
+        init = rng.choice(len(vecs), k, replace=False).astype(np.int32)
+        gc, ga = gpu.kmeans(vecs, k, iters, init)
+        oc, oa = oracle.kmeans(vecs, k, iters, init)
+        assert np.array_equal(ga, oa)
+        assert np.array_equal(gc.view(np.uint32), oc.view(np.uint32))
+        assert len(np.unique(ga)) > k // 2
+    # duplicated initial rows: the second copy of a centroid loses every tie (strict "<") and, empty, keeps its value
+    init = np.array([5, 5, 9], np.int32)
+    gc, ga = gpu.kmeans(x[:200], 3, 0, init)
+    assert (ga != 1).all()
+    for iters in (1, 2):
+        gc, ga = gpu.kmeans(x[:200], 3, iters, init)
+        oc, oa = oracle.kmeans(x[:200], 3, iters, init)
+        assert np.array_equal(ga, oa) and np.array_equal(gc.view(np.uint32), oc.view(np.uint32))
+    # a trained PQ codebook encodes its own training vectors (end to end through the index build ABI)
+    cb = gpu.train_pq_codebook(x[:4000], 12, 64, iters=3, seed=4)
+    _, codes = gpu.encode(cb, x[:500])
+    assert np.array_equal(codes, oracle.encode_pq(cb, x[:500]))
