@@ -121,3 +121,21 @@ def test_index_file_format_roundtrip(tmp_path):
     with pytest.raises(udf.FreddyError, match="bad magic"):
         s.import_index(bad)
     s.close()
+
+
+def test_pg_hosts_bind_the_declared_abi():
+    """pg/*.c cannot be compiled in this image (no PostgreSQL headers): at least every freddy_gpu_* entry point
+    they call must be declared in include/freddy_gpu.h, and the SRF symbols the SQL script binds must be there."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "freddy_gpu.h")).read()
+    declared = set(re.findall(r"\b(freddy_gpu_\w+)\s*\(", hdr))
+    srcs = {f: open(os.path.join(ROOT, "pg", f)).read() for f in ("freddy_srf.c", "ivpq_search_in.c", "freddy_gpu_glue.c")}
+    called = set()
+    for text in srcs.values():
+        called |= set(re.findall(r"\b(freddy_gpu_\w+)\s*\(", text))
+    assert called and called <= declared, called - declared
+    v1 = set(re.findall(r"PG_FUNCTION_INFO_V1\((\w+)\)", srcs["freddy_srf.c"] + srcs["ivpq_search_in.c"]))
+    assert v1 == {"pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search", "ivpq_search_in"}
+    mk = open(os.path.join(ROOT, "pg", "Makefile")).read()
+    for fn in ("pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search"):
+        assert f"-D{fn}=freddy_cpu_{fn}" in mk      # the reference's own copies step aside
