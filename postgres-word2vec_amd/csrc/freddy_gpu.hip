@@ -76,7 +76,7 @@ struct Tuning {
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
-  int64_t lut_budget_mb = 1024;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit)
+  int64_t lut_budget_mb = 8192;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit); 288 GB of HBM: 8 GiB = 12 800 queries at nprobe 10
   int64_t filter_table_mb = 8192;    // FREDDY_GPU_FILTER_TABLE_MB (pin time): 0 = no filter + refine tables
 };
 static int64_t env_int(const char* name, int64_t dflt) {

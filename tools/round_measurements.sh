@@ -1,0 +1,33 @@
+#!/bin/bash
+# GPU-box helper: everything profiles/<tag>_* holds for one round.
+#   tools/round_measurements.sh <tag>
+set -u
+TAG=${1:-rXX}
+mkdir -p gpurun_out/prof
+tools/profile_round.sh $TAG > gpurun_out/prof/${TAG}_profile.log 2>&1
+cp gpurun_out/prof/${TAG}_pmc.json profiles/latest_pmc.json
+python3 bench.py --steps 30 --warmup 5 > gpurun_out/prof/${TAG}_bench.json 2> gpurun_out/prof/${TAG}_bench.err
+# configs 2 and 4 (BASELINE configs[1], configs[3]) with their own kernel stats + PMC passes
+for cfg in pq join; do
+  tools/profile_round.sh ${TAG}_${cfg} --config $cfg > gpurun_out/prof/${TAG}_${cfg}_profile.log 2>&1
+  cp gpurun_out/prof/${TAG}_${cfg}_pmc.json profiles/latest_pmc_${cfg}.json 2>/dev/null
+  python3 - <<PY
+import json
+a = json.load(open("profiles/latest_pmc.json")) if __import__("os").path.exists("profiles/latest_pmc.json") else {}
+try:
+    b = json.load(open("gpurun_out/prof/${TAG}_${cfg}_pmc.json"))
+    for k, v in b.items():
+        a.setdefault(k, v)
+    json.dump(a, open("profiles/latest_pmc.json", "w"), indent=1)
+except Exception as e:
+    print("pmc merge:", e)
+PY
+  python3 bench.py --config $cfg --steps 20 --warmup 3 > gpurun_out/prof/${TAG}_config_${cfg}.json 2> gpurun_out/prof/${TAG}_config_${cfg}.err
+done
+cp profiles/latest_pmc.json gpurun_out/prof/${TAG}_latest_pmc.json
+# larger batches on one GPU (SURVEY 8e asks for a Q >= 8192 variant)
+python3 bench.py --steps 20 --warmup 3 --Q 8192 --cpu-sample 0 --no-recall > gpurun_out/prof/${TAG}_bench_Q8192.json 2> /dev/null
+# a corpus that does NOT fit the 256 MiB Infinity Cache: N = 40 M rows (1.1 GB of lists), same list length
+timeout 1500 python3 bench.py --steps 20 --warmup 3 --N 40000000 --C 13000 --cpu-sample 64 --no-recall > gpurun_out/prof/${TAG}_bench_N40M.json 2> gpurun_out/prof/${TAG}_bench_N40M.err
+tail -2 gpurun_out/prof/${TAG}_bench_N40M.err
+ls -la gpurun_out/prof | tail -30
