@@ -456,6 +456,27 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         lds_barrier();
         tick(1);
       }
+      // S1 (thresholds tau + E) is done HERE, by the builder waves, which have nothing else to do in the tail
+      // phases: the gatherers' tail (column minima, survivor passes) is what the SIMDs' issue slots go to, and
+      // the two 64-key sorts per wave were a fifth of it.  Builder wave w takes items w and w + 8.
+      if (!(a.ablate & 4)) {
+        const int32_t* rec = dsc + cur * REC_DW;
+        const int cnt = __builtin_amdgcn_readfirstlane(rec[1]);
+        const int g0 = wave, g1 = wave + NG;
+        if (g0 < cnt) {
+          uint32_t c0 = colmin[g0 * 64 + lane], c1 = colmin[g1 * 64 + lane];
+          wave_sort32_x2(c0, c1);
+          const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
+          if (lane == 0) {
+            // (ablate & 8, tests only: keep EVERY row, so that the exact stage -- and its self-check of the
+            // bracket -- sees all of them)
+            thr_s[g0] = (a.ablate & 8) ? 0xfffffffeu : widen_threshold(t0, __int_as_float(rec[56 + g0]));
+            thr_s[g1] = (a.ablate & 8) ? 0xfffffffeu : widen_threshold(t1, __int_as_float(rec[56 + g1]));
+          }
+          colmin[g0 * 64 + lane] = 0xffffffffu;
+          colmin[g1 * 64 + lane] = 0xffffffffu;
+        }
+      }
       lds_barrier();   // S1
       lds_barrier();   // S2
       tick(3);
@@ -538,7 +559,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         for (int p = 0; p + 1 < M; ++p) {
           if (!(a.ablate & 2)) gather(p);
           __builtin_amdgcn_sched_barrier(0);
-          if (p & 1) load_codes((p + 1) >> 1);
+          if ((p & 1) && !(a.ablate & 64)) load_codes((p + 1) >> 1);   // (64: timing experiment, the first pair's codes for all positions)
           lds_barrier();
         }
         if (!(a.ablate & 2)) gather(M - 1);
@@ -565,14 +586,24 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
           default: main_loop(I3{}, I8{}); break;
         }
       }
-      // rows past the end of the list (last block of the last chunk): park them above everything
-      if (nrows < FUSED_UNIT_BLOCKS * 64) {
+      // Rows past the end of the list are parked above everything.  Row slots of this wave beyond its last block
+      // (the gather variants round the slot count up to an even number and re-read the last block there) are
+      // parked whole -- a uniform test per slot --, and only the LAST row block of the chunk can be partial: one
+      // slot of one wave gets the per-lane test.  (Testing every slot of every wave per lane was a tenth of the tail.)
+      {
+        const int last_blk = nrows > 0 ? (nrows - 1) >> 6 : -1;     // chunk-relative block holding the last row
+        const int rs = (last_blk >= 0 && (last_blk % NG) == gw && (nrows & 63)) ? last_blk / NG : -1;
+        const bool dead = lane >= (nrows & 63);
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
-          const bool dead = ((r * NG + gw) * 64 + lane) >= nrows;
+          if (r >= rl_wave) {
 #pragma unroll
-          for (int h = 0; h < G / 2; ++h)
-            if (dead) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+            for (int h = 0; h < G / 2; ++h) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+          } else if (r == rs) {
+#pragma unroll
+            for (int h = 0; h < G / 2; ++h)
+              if (dead) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
+          }
         }
       }
       if (!(a.ablate & 4)) {
@@ -587,24 +618,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter_kernel(FilterArgs a) {
         }
       }
       lds_barrier();
-      // S1: thresholds tau + E, two items per gatherer wave
-      if (!(a.ablate & 4)) {
-        static_assert(G <= 2 * NG, "at most two items per gatherer wave");
-        const int g0 = gw, g1 = gw + NG;
-        if (g0 < cnt) {   // (items gw and gw + 8; nothing to do for a wave whose items the entry does not have)
-          uint32_t c0 = colmin[g0 * 64 + lane], c1 = colmin[g1 * 64 + lane];
-          wave_sort32_x2(c0, c1);
-          const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
-          if (lane == 0) {
-            // (ablate & 8, tests only: keep EVERY row, so that the exact stage -- and its self-check of the
-            // bracket -- sees all of them)
-            thr_s[g0] = (a.ablate & 8) ? 0xfffffffeu : widen_threshold(t0, __int_as_float(rec[56 + g0]));
-            thr_s[g1] = (a.ablate & 8) ? 0xfffffffeu : widen_threshold(t1, __int_as_float(rec[56 + g1]));
-          }
-          colmin[g0 * 64 + lane] = 0xffffffffu;
-          colmin[g1 * 64 + lane] = 0xffffffffu;
-        }
-      }
+      // (S1, the thresholds tau + E, is computed by the builder waves between these two barriers)
       lds_barrier();
       // S2: survivors -> this wave's region of each item's buffer
       if (!(a.ablate & 4)) {
