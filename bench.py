@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU (config ivfadc): consecutive steps alternate between this many HIP streams, "
+                         "so the front end of batch i+1 runs beside the merge of batch i; 1 = strictly one batch at a time")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="CPU tensors + stand-in search: exercises the sharded step / gather only")
     return ap.parse_args(argv)
@@ -239,28 +242,45 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     # Everything of a step -- the search kernels (through the C ABI, on this stream's handle) and the RCCL
     # gather -- is ordered on ONE explicit non-default stream, so the collective reads a shard's results
     # only after the search wrote them and the buffer is rewritten only after the collective read it.
-    stream = torch.cuda.Stream(dev)
-    with torch.cuda.stream(stream):
-        pg = shard.PipelinedGather(q_local, a.k, dev)
+    # Consecutive steps alternate between `in_flight` streams (each with its own result buffer and, inside the
+    # library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of two
+    # batches -- merge of batch i, cell selection of batch i+1 -- overlap.  --in-flight 1 is the strict sequence.
+    n_fl = max(1, min(a.in_flight, 3))
+    streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
+    with torch.cuda.stream(streams[0]):
+        pg = shard.PipelinedGather(q_local, a.k, dev, depth=max(2, n_fl))
+    torch.cuda.synchronize(dev)
+    counter = [0]
 
+    def step_on(n_streams):
         def step():
-            res = pg.next_buffer()
-            index.search_dev(d_q.data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
-                             res[1].data_ptr(), d_status.data_ptr(), stream.cuda_stream)
-            pg.submit()
+            st = streams[counter[0] % n_streams]
+            counter[0] += 1
+            with torch.cuda.stream(st):
+                res = pg.next_buffer()
+                index.search_dev(d_q.data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
+                                 res[1].data_ptr(), d_status.data_ptr(), st.cuda_stream)
+                pg.submit()
+        return step
 
+    if True:
+        step = step_on(n_fl)
         dt, barrier = sharded_steps(step, pg, a.steps, a.warmup, lambda: torch.cuda.synchronize(dev), world)
         qps = world * q_local * a.steps / dt
         gather_ok = verify_gather(pg, rank, world)
+        # the same steps strictly one after the other (one stream): the latency of a batch
+        counter[0] = 0
+        step1 = step_on(1)
+        dt1, _ = sharded_steps(step1, pg, a.steps, 2, lambda: torch.cuda.synchronize(dev), world)
 
-        # ---- per-kernel durations with HIP events on the launch stream (instrumented re-run) ----
+        # ---- per-kernel durations with HIP events on the launch stream (instrumented re-run, one batch at a time) ----
         index.profile_enable(True)
         for _ in range(a.steps):
-            step()
+            step1()
         barrier()
         prof = index.profile_read()
         index.profile_enable(False)
-        step()
+        step1()
         barrier()
         res_last, _ = pg.last()
         d_ids, d_dist = res_last[0], res_last[1].view(torch.float32)
@@ -367,6 +387,10 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             "queries_needing_extra_round": straggler,
             "filter_bound_violations": bound_violations,
             "gather_verified": gather_ok,
+            "pipelining": {"batches_in_flight": n_fl, "serial_ms_per_step": round(1e3 * dt1 / a.steps, 4),
+                           "serial_queries_per_s": round(world * q_local * a.steps / dt1, 1),
+                           "note": "value = throughput with consecutive batches on alternating HIP streams (separate "
+                                   "workspaces); serial_* = the same steps strictly one after the other"},
             "host_buffer_abi": {"queries_per_s": round(host_qps, 1), "same_results_as_device_path": host_same,
                                 "note": "freddy_gpu_ivfadc_search: H2D of the queries, D2H of the results, one stream sync, "
                                         "extra probing rounds for stragglers -- per call"},

@@ -26,7 +26,7 @@
 #include "kernels.h"
 #include "scan_common.h"
 #include "fused3.h"
-#include "fused4.h"
+#include "fused5.h"
 #include "coarse.h"
 #include "exact.h"
 #include "join.h"
@@ -73,6 +73,7 @@ struct Tuning {
   int coarse_refine_all = 0;   // tests: refine every cell (exhaustive check of the coarse bracket)
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
+  int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
@@ -90,6 +91,7 @@ static Tuning read_tuning() {
   t.scan_ablate = (uint32_t)env_int("FREDDY_GPU_FUSED_ABLATE", 0);
   t.merge_ablate = (uint32_t)env_int("FREDDY_GPU_MERGE_ABLATE", 0);
   t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
+  t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -117,6 +119,31 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Everything a search writes besides its outputs.  Keyed by the stream the search is enqueued on, so that two
+// batches in flight on two streams (the front end of batch i+1 beside the merge of batch i) never share scratch.
+struct Workspace {
+  bool used = false;
+  hipStream_t owner = nullptr;
+  hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
+  hipEvent_t ev_q = nullptr, ev_qc = nullptr;
+  DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
+      w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist;
+  void release() {
+    if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); stream2 = nullptr; }
+    if (ev_q) { (void)hipEventDestroy(ev_q); ev_q = nullptr; }
+    if (ev_qc) { (void)hipEventDestroy(ev_qc); ev_qc = nullptr; }
+    DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
+                      &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
+                      &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
+                      &w_qn, &w_records, &w_qn2, &w_item_dist};
+    for (DevBuf* b : bufs) b->release();
+    used = false;
+    owner = nullptr;
+  }
+};
+static constexpr int FREDDY_MAX_WS = 4;
+
 struct ProfRec {
   int64_t launches = 0;
   double ms = 0.0;
@@ -128,8 +155,6 @@ struct freddy_gpu_index {
   int device = 0;
   Tuning tune;
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
-  hipEvent_t ev_q = nullptr, ev_qc = nullptr;
   int d = 0, m = 0, K = 0, C = 0, S = 0, M2 = 0;
   int64_t N = 0;
   int64_t n_blocks = 0;
@@ -167,10 +192,9 @@ struct freddy_gpu_index {
   float* xb = nullptr;
   // ivpq extras
   JoinIndex join;
-  // workspaces
-  DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
-      w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist;
+  // workspaces: one per stream the caller searches on (searches on different streams may overlap)
+  Workspace ws[FREDDY_MAX_WS];
+  Workspace* last_ws = nullptr;   // of the most recent search (freddy_gpu_last_* read its counters)
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -190,6 +214,21 @@ static inline void timed_launch(freddy_gpu_index* ix, hipStream_t s, const char*
   r.open.emplace_back(a, b);
 }
 
+// The workspace of the stream a search is enqueued on.  A fifth stream takes over the least recently claimed slot
+// after that slot's stream has drained.
+static Workspace* workspace_for(freddy_gpu_index* ix, hipStream_t s) {
+  for (Workspace& w : ix->ws)
+    if (w.used && w.owner == s) { ix->last_ws = &w; return &w; }
+  for (Workspace& w : ix->ws)
+    if (!w.used) { w.used = true; w.owner = s; ix->last_ws = &w; return &w; }
+  Workspace& w = ix->ws[FREDDY_MAX_WS - 1];
+  (void)hipStreamSynchronize(w.owner);
+  if (w.stream2) (void)hipStreamSynchronize(w.stream2);
+  w.owner = s;
+  ix->last_ws = &w;
+  return &w;
+}
+
 template <class T>
 static int upload(T** dst, const T* src, size_t n, int64_t* bytes) {
   *dst = nullptr;
@@ -204,19 +243,10 @@ static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  if (ix->stream2) { (void)hipStreamSynchronize(ix->stream2); (void)hipStreamDestroy(ix->stream2); }
-  if (ix->ev_q) (void)hipEventDestroy(ix->ev_q);
-  if (ix->ev_qc) (void)hipEventDestroy(ix->ev_qc);
+  for (Workspace& w : ix->ws) { if (w.used && w.owner) (void)hipStreamSynchronize(w.owner); w.release(); }
   void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
-  DevBuf* bufs[] = {&ix->w_q, &ix->w_distT, &ix->w_used, &ix->w_item_cell,
-                    &ix->w_item_query, &ix->w_rows, &ix->w_resid, &ix->w_lut, &ix->w_part,
-                    &ix->w_cand, &ix->w_found, &ix->w_act0, &ix->w_act1, &ix->w_cnt,
-                    &ix->w_out_ids, &ix->w_out_dist, &ix->w_sub_rows, &ix->w_sub_packed,
-                    &ix->w_sub_pos, &ix->w_sub_blk, &ix->w_cellcnt, &ix->w_sorted, &ix->w_groups,
-                    &ix->w_surv, &ix->w_surv_cnt, &ix->w_prof, &ix->w_qc, &ix->w_qn, &ix->w_records, &ix->w_qn2, &ix->w_item_dist};
-  for (DevBuf* b : bufs) b->release();
   for (auto& kv : ix->prof)
     for (auto& ev : kv.second.open) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   if (ix->stream) (void)hipStreamDestroy(ix->stream);
@@ -361,7 +391,8 @@ static int raise_lds_limits(int device) {
       (const void*)&adc_scan_kernel<0, 2>, (const void*)&adc_scan_kernel<0, 4>, (const void*)&adc_scan_kernel<0, 8>,
       (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
       (const void*)&ivf_spec2_kernel<25, 12, false>, (const void*)&ivf_filter_kernel<12, true>,
-      (const void*)&ivf_filter_kernel<12, false>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
+      (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true>,
+      (const void*)&ivf_filter5_kernel<12, false>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>};
   for (const void* k : kernels)
@@ -583,10 +614,11 @@ extern "C" int freddy_gpu_unpin(freddy_gpu_index_t* ix) {
 extern "C" int64_t freddy_gpu_index_bytes(const freddy_gpu_index_t* ix) { return ix ? ix->bytes : 0; }
 extern "C" int64_t freddy_gpu_last_scanned_rows(const freddy_gpu_index_t* ix) {
   // rows retrieved in the most recent probing round (last query chunk): read back on demand
-  if (!ix || ix->kind != KIND_IVF || ix->last_Q <= 0 || !ix->w_rows.p) return 0;
+  const Workspace* ws = ix ? (ix->last_ws ? ix->last_ws : &ix->ws[0]) : nullptr;
+  if (!ix || ix->kind != KIND_IVF || ix->last_Q <= 0 || !ws->w_rows.p) return 0;
   if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
   std::vector<int32_t> rows((size_t)ix->last_Q);
-  if (hipMemcpy(rows.data(), ix->w_rows.p, sizeof(int32_t) * rows.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (hipMemcpy(rows.data(), ws->w_rows.p, sizeof(int32_t) * rows.size(), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   int64_t sum = 0;
   for (int32_t r : rows) if (r > 0) sum += r;
   return sum;
@@ -598,11 +630,12 @@ extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_
   if (!ix || !n_cells || !rows) return fail(FREDDY_E_ARG, "NULL argument");
   *n_cells = 0; *rows = 0;
   if (ix->kind != KIND_IVF) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
-  if (ix->last_Q <= 0 || !ix->w_cellcnt.p) return FREDDY_OK;
+  const Workspace* ws = ix->last_ws ? ix->last_ws : &ix->ws[0];
+  if (ix->last_Q <= 0 || !ws->w_cellcnt.p) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipDeviceSynchronize());
   std::vector<int32_t> cnt((size_t)ix->C);
-  HIP_TRY(hipMemcpy(cnt.data(), ix->w_cellcnt.p, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(cnt.data(), ws->w_cellcnt.p, sizeof(int32_t) * cnt.size(), hipMemcpyDeviceToHost));
   for (int c = 0; c < ix->C; ++c)
     if (cnt[(size_t)c] > 0) { *n_cells += 1; *rows += ix->h_list_off[(size_t)c + 1] - ix->h_list_off[(size_t)c]; }
   return FREDDY_OK;
@@ -663,6 +696,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "fused_ablate") t.scan_ablate = (uint32_t)value;
   else if (n == "merge_ablate") t.merge_ablate = (uint32_t)value;
   else if (n == "side_stream") t.side_stream = (int)value;
+  else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -756,6 +790,7 @@ static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, co
 // State of one chunk of queries while its probing rounds are enqueued.
 struct IvfRun {
   freddy_gpu_index* ix;
+  Workspace* ws;
   hipStream_t s;
   const float* d_q;
   int Q, k, W, L, found_rule, upi;
@@ -777,6 +812,7 @@ struct IvfRun {
 // coarse distances (a6/a7) of every query of the chunk, and -- for the filter + refine scan -- the
 // per-batch query x codebook table beside them on the side stream
 static int ivf_coarse(IvfRun& r) {
+  Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int Q = r.Q, d = ix->d, C = ix->C, m = ix->m, K = ix->K, Cpad = ix->Cpad;
@@ -786,29 +822,29 @@ static int ivf_coarse(IvfRun& r) {
   // counter), the per-cell item counts and the accepted-candidate counts.  The tiled coarse kernel clears
   // them itself; the small-batch kernel gets memsets.
   if (!r.tiled) {
-    HIP_TRY(hipMemsetAsync(ix->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
-    HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t) * 4, s));
+    HIP_TRY(hipMemsetAsync(ws->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
+    HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 4, s));
   }
   ZeroArgs za;
-  za.p[0] = ix->w_used.as<uint32_t>(); za.n[0] = Q * used_words;
-  za.p[1] = ix->w_cnt.as<uint32_t>(); za.n[1] = 4;
-  za.p[2] = r.fused ? ix->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = r.fused ? C * 2 : 0;
-  za.p[3] = ix->w_cand.as<uint32_t>(); za.n[3] = Q;
+  za.p[0] = ws->w_used.as<uint32_t>(); za.n[0] = Q * used_words;
+  za.p[1] = ws->w_cnt.as<uint32_t>(); za.n[1] = 4;
+  za.p[2] = r.fused ? ws->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = r.fused ? C * 2 : 0;
+  za.p[3] = ws->w_cand.as<uint32_t>(); za.n[3] = Q;
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
-  za.p[4] = r.fused ? ix->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = r.fused ? (int)(items * r.upi * FUSED_NW) : 0;
+  za.p[4] = r.fused ? ws->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = r.fused ? (int)(items * r.upi * FUSED_NW) : 0;
 
   auto launch_coarse = [&]() -> int {
     timed_launch(ix, s, "coarse_dist", [&] {
       if (r.approx)
         hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256),
                            (size_t)(64 * (ix->dp + 4) + 128) * sizeof(float), s, r.d_q, ix->coarseP, ix->cn2,
-                           ix->w_distT.as<float>(), ix->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
+                           ws->w_distT.as<float>(), ws->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
       else if (r.tiled)
         hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
-                           ix->w_distT.as<float>(), Q, Cpad, d, za);
+                           ws->w_distT.as<float>(), Q, Cpad, d, za);
       else
         hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, r.d_q,
-                           ix->coarseT, ix->w_distT.as<float>(), Q, Cpad, d);
+                           ix->coarseT, ws->w_distT.as<float>(), Q, Cpad, d);
     });
     HIP_TRY(hipGetLastError());
     return 0;
@@ -821,25 +857,39 @@ static int ivf_coarse(IvfRun& r) {
   const bool coarse_first = r.approx && !ix->tune.qc_first;
   if (coarse_first) if (int rc = launch_coarse()) return rc;
   r.qc_pending = false;
-  if (r.fused && r.scan_kernel == 4) {
-    if (!ix->stream2) {
-      HIP_TRY(hipStreamCreateWithFlags(&ix->stream2, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&ix->ev_q, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&ix->ev_qc, hipEventDisableTiming));
+  if (r.fused && r.scan_kernel >= 4) {
+    if (!ws->stream2) {
+      HIP_TRY(hipStreamCreateWithFlags(&ws->stream2, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ws->ev_q, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&ws->ev_qc, hipEventDisableTiming));
     }
-    const bool side = ix->tune.side_stream != 0;
-    hipStream_t sq = side ? ix->stream2 : s;
+    // (only while ONE stream searches: the runtime maps streams onto four hardware queues, and a side stream per
+    // workspace ends up sharing an in-order queue with another batch's main stream -- measured: no overlap at all)
+    int n_ws = 0;
+    for (const Workspace& w : ix->ws) n_ws += w.used ? 1 : 0;
+    const bool side = ix->tune.side_stream != 0 && n_ws == 1;
+    hipStream_t sq = side ? ws->stream2 : s;
     if (side) {
-      HIP_TRY(hipEventRecord(ix->ev_q, s));
-      HIP_TRY(hipStreamWaitEvent(ix->stream2, ix->ev_q, 0));
+      HIP_TRY(hipEventRecord(ws->ev_q, s));
+      HIP_TRY(hipStreamWaitEvent(ws->stream2, ws->ev_q, 0));
     }
+    if (r.scan_kernel == 5) {
+      timed_launch(ix, sq, "query_scale", [&] {
+        hipLaunchKernelGGL((query_scale5_kernel<25>), dim3(Q), dim3(64), 0, sq, r.d_q, ix->cmaxp, ws->w_qn.as<float>(),
+                           ws->w_qn.as<float>() + (size_t)Q * m, Q, d, m);
+      });
+      timed_launch(ix, sq, "query_codebook", [&] {
+        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT,
+                           ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
+      });
+    } else
     timed_launch(ix, sq, "query_codebook", [&] {
       hipLaunchKernelGGL((query_codebook_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
-                         ix->w_qc.as<uint32_t>(), ix->w_qn.as<float>(), ix->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
+                         ws->w_qc.as<uint32_t>(), ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
     });
     HIP_TRY(hipGetLastError());
     if (side) {
-      HIP_TRY(hipEventRecord(ix->ev_qc, ix->stream2));
+      HIP_TRY(hipEventRecord(ws->ev_qc, ws->stream2));
       r.qc_pending = true;
     }
   }
@@ -849,28 +899,29 @@ static int ivf_coarse(IvfRun& r) {
 
 // a7: the W nearest not-yet-used cells of every active query (+ their items appended to the cells' buckets)
 static int ivf_plan(IvfRun& r, PlanArgs& pa) {
+  Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int C = ix->C, W = r.W;
-  pa.dist = ix->w_distT.as<float>(); pa.active = r.active; pa.list_off = ix->list_off;
-  pa.used = ix->w_used.as<uint32_t>();
-  pa.item_cell = ix->w_item_cell.as<int32_t>(); pa.item_query = ix->w_item_query.as<int32_t>();
-  pa.item_dist = ix->w_item_dist.as<float>();
-  pa.round_rows = ix->w_rows.as<int32_t>();
+  pa.dist = ws->w_distT.as<float>(); pa.active = r.active; pa.list_off = ix->list_off;
+  pa.used = ws->w_used.as<uint32_t>();
+  pa.item_cell = ws->w_item_cell.as<int32_t>(); pa.item_query = ws->w_item_query.as<int32_t>();
+  pa.item_dist = ws->w_item_dist.as<float>();
+  pa.round_rows = ws->w_rows.as<int32_t>();
   pa.n_active = r.n_active; pa.Cpad = ix->Cpad; pa.C = C; pa.W = W; pa.used_words = (C + 31) / 32;
-  pa.cell_count = r.fused ? ix->w_cellcnt.as<int32_t>() : nullptr;
-  pa.cell_items = r.fused ? ix->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = r.n_active;
+  pa.cell_count = r.fused ? ws->w_cellcnt.as<int32_t>() : nullptr;
+  pa.cell_items = r.fused ? ws->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = r.n_active;
   pa.cell_limit = r.cell_limit;
   const int n_items = r.n_active * W;
   if (r.fused && !(r.tiled && r.first())) {
-    HIP_TRY(hipMemsetAsync(ix->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
-    HIP_TRY(hipMemsetAsync(ix->w_surv_cnt.p, 0, sizeof(int32_t) * (size_t)n_items * r.upi * FUSED_NW, s));
+    HIP_TRY(hipMemsetAsync(ws->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
+    HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * (size_t)n_items * r.upi * FUSED_NW, s));
   }
   const int PV = pick_V(2 * W);
   const size_t plan_lds = (size_t)(64 + 64 * PV) * sizeof(u64) + (size_t)W * 8;
   if (r.approx) {
     Plan2Args g;
-    g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ix->w_qn2.as<float>(); g.item_dist = pa.item_dist;
+    g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ws->w_qn2.as<float>(); g.item_dist = pa.item_dist;
     g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all; g.prof = nullptr;
     timed_launch(ix, s, "probe_plan", [&] { hipLaunchKernelGGL(probe_plan2_kernel<0>, dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g); });
   } else
@@ -884,7 +935,7 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
     }
   });
   HIP_TRY(hipGetLastError());
-  if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(ix->w_cand.p, 0, sizeof(int32_t) * r.Q, s));
+  if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(ws->w_cand.p, 0, sizeof(int32_t) * r.Q, s));
   return 0;
 }
 
@@ -895,28 +946,29 @@ struct WorkTable {
   int32_t *group_cell, *group_first, *group_cnt, *n_groups, *work_counter;
 };
 static int ivf_work_table(IvfRun& r, WorkTable& wt) {
+  Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int n_items = r.n_active * r.W;
   wt.max_groups = ((size_t)n_items / SPEC2_G + (size_t)ix->C + 1) * r.upi;   // (group, chunk) work entries
-  int32_t* base = ix->w_groups.as<int32_t>();
+  int32_t* base = ws->w_groups.as<int32_t>();
   wt.group_cell = base; wt.group_first = base + wt.max_groups; wt.group_cnt = base + 2 * wt.max_groups;
-  wt.n_groups = ix->w_cnt.as<int32_t>() + 1;
-  wt.work_counter = ix->w_cnt.as<int32_t>() + 2;
+  wt.n_groups = ws->w_cnt.as<int32_t>() + 1;
+  wt.work_counter = ws->w_cnt.as<int32_t>() + 2;
   timed_launch(ix, s, "work_table", [&] {
-    hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ix->w_cellcnt.as<int32_t>(), ix->C, r.n_active, SPEC2_G, ix->blk_off,
-                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 4 ? 1 : 0);
+    hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ws->w_cellcnt.as<int32_t>(), ix->C, r.n_active, r.scan_kernel == 5 ? SCAN5_G : SPEC2_G, ix->blk_off,
+                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : r.scan_kernel == 4 ? 1 : 0);
   });
   HIP_TRY(hipGetLastError());
   if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, sizeof(int32_t), s));
   return 0;
 }
 
-static int scan_prof_buffer(freddy_gpu_index* ix, long long** prof) {
+static int scan_prof_buffer(freddy_gpu_index* ix, Workspace* ws, long long** prof) {
   *prof = nullptr;
   if (!ix->tune.scan_prof) return 0;
-  if (ix->w_prof.ensure(sizeof(long long) * 8 * 1024)) return fail(FREDDY_E_NOMEM, "profile buffer");
-  *prof = ix->w_prof.as<long long>();
+  if (ws->w_prof.ensure(sizeof(long long) * 8 * 1024)) return fail(FREDDY_E_NOMEM, "profile buffer");
+  *prof = ws->w_prof.as<long long>();
   return 0;
 }
 
@@ -932,41 +984,48 @@ static int scan_prof_print(freddy_gpu_index* ix, hipStream_t s, const long long*
     mx_end = std::max(mx_end, h[b * 8 + 6]);
     mn_end = mn_end < 0 ? h[b * 8 + 6] : std::min(mn_end, h[b * 8 + 6]);
   }
-  fprintf(stderr, "[scan prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f P(M-1)=%.0f S1+S2=%.0f other=%.0f | workgroups ran dry over %.1f us\n",
-          n_persist, ent, sum[0] / ent, sum[1] / ent, sum[2] / ent, sum[3] / ent, sum[5] / ent, (mx_end - mn_end) / 100.0);
+  fprintf(stderr, "[scan prof] wgs=%u entries=%.0f  builder cycles/entry: builds=%.0f barrier-wait=%.0f tail=%.0f | gatherer wave 0 (fused5.h): main=%.0f colmin=%.0f S2=%.0f | workgroups ran dry over %.1f us\n",
+          n_persist, ent, sum[0] / ent, sum[1] / ent, sum[3] / ent, sum[2] / ent, sum[4] / ent, sum[5] / ent, (mx_end - mn_end) / 100.0);
   (void)ix;
   return 0;
 }
 
 // Default scan: filter + refine (fused4.h).  entry records -> ivf_filter_kernel -> merge_refine_kernel.
 static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
+  Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int Q = r.Q, m = ix->m, K = ix->K;
-  if (ix->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  const bool v5 = r.scan_kernel == 5;
+  if (ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
-  ra.sorted_item = ix->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
-  ra.item_dist = pa.item_dist; ra.qn = ix->w_qn.as<float>(); ra.qscale = ix->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
-  ra.records = ix->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
-  if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ix->ev_qc, 0)); r.qc_pending = false; }
+  ra.sorted_item = ws->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
+  ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
+  ra.records = ws->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
+  if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ws->ev_qc, 0)); r.qc_pending = false; }
   timed_launch(ix, s, "entry_records", [&] {
-    hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
+    if (v5) hipLaunchKernelGGL((entry_record5_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
+    else hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
   });
   HIP_TRY(hipGetLastError());
   FilterArgs fl;
-  fl.qc = ix->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ix->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
-  fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ix->w_surv.as<u64>(); fl.surv_count = ix->w_surv_cnt.as<int32_t>();
-  fl.cand_count = (r.found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
+  fl.qc = ws->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ws->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
+  fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
+  fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.ablate = ix->tune.scan_ablate;
-  if (int rc = scan_prof_buffer(ix, &fl.prof)) return rc;
-  const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
+  if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
+  // slabs: [2 buffers][K][12 items] fp32, or [2 buffers][2 positions][K][16 items] int16 (fused5.h)
+  const size_t desc_off = v5 ? (size_t)4 * SCAN5_G * 2 * K : (((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15);
   const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
   fl.desc_offset = (uint32_t)desc_off;
   // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
-  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)ix->n_cus);
+  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, ix->n_cus - ix->tune.reserve_cus));
   timed_launch(ix, s, "ivf_filter", [&] {
-    if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    if (v5) {
+      if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    } else if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
     else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
   });
   HIP_TRY(hipGetLastError());
@@ -975,9 +1034,9 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   MergeRefineArgs mr;
   mr.surv = fl.surv; mr.surv_count = fl.surv_count; mr.active = r.active; mr.round_rows = pa.round_rows;
   mr.item_cell = pa.item_cell; mr.queries = r.d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
-  mr.qn = ix->w_qn.as<float>(); mr.pmax = ix->pmax; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
+  mr.qn = ws->w_qn.as<float>(); mr.pmax = ix->pmax; mr.qscale5 = v5 ? ws->w_qn.as<float>() + (size_t)Q * m : nullptr; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
   mr.cand_count = fl.cand_count; mr.violations = ix->viol; mr.out_ids = r.d_out_ids; mr.out_dist = r.d_out_dist;
-  mr.found = ix->w_found.as<int32_t>(); mr.next_active = r.next; mr.n_next = ix->w_cnt.as<int32_t>();
+  mr.found = ws->w_found.as<int32_t>(); mr.next_active = r.next; mr.n_next = ws->w_cnt.as<int32_t>();
   mr.status = r.d_status;
   mr.n_active = r.n_active; mr.W = r.W; mr.upi = r.upi; mr.L = r.L; mr.k = r.k; mr.found_rule = r.found_rule;
   mr.first_round = r.first() ? 1 : 0; mr.K = K; mr.d = ix->d; mr.sentinel = r.sentinel;
@@ -1006,20 +1065,21 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
 
 // The yardstick: the reference's arithmetic for every probed row (fused3.h).  ivf_spec2_kernel -> merge_surv_kernel.
 static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
+  Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int K = ix->K;
   FusedArgs fa;
   fa.resid = nullptr; fa.item_query = pa.item_query; fa.queries = r.d_q; fa.coarse = ix->coarse;
-  fa.sorted_item = ix->w_sorted.as<int32_t>(); fa.group_cell = wt.group_cell; fa.group_first = wt.group_first;
+  fa.sorted_item = ws->w_sorted.as<int32_t>(); fa.group_cell = wt.group_cell; fa.group_first = wt.group_first;
   fa.group_cnt = wt.group_cnt; fa.n_groups = wt.n_groups; fa.work_counter = wt.work_counter;
   fa.cbP = ix->cbP; fa.blk_off = ix->blk_off; fa.packed = ix->packed; fa.pos = ix->pos;
-  fa.surv = ix->w_surv.as<u64>(); fa.surv_count = ix->w_surv_cnt.as<int32_t>();
-  fa.cand_count = (r.found_rule == 1) ? ix->w_cand.as<int32_t>() : nullptr;
+  fa.surv = ws->w_surv.as<u64>(); fa.surv_count = ws->w_surv_cnt.as<int32_t>();
+  fa.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fa.d = ix->d; fa.K = K; fa.L = r.L; fa.upi = r.upi;
   memcpy(&fa.sentinel_bits, &r.sentinel, 4);
   fa.ablate = ix->tune.scan_ablate;
-  if (int rc = scan_prof_buffer(ix, &fa.prof)) return rc;
+  if (int rc = scan_prof_buffer(ix, ws, &fa.prof)) return rc;
   const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
   const size_t flds = desc_off + 4096 + 64 + 512 + (size_t)SPEC2_G * 12 * 28 * sizeof(float);
   fa.desc_offset = (uint32_t)desc_off;
@@ -1033,7 +1093,7 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   MergeSurvArgs ms;
   ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = r.active; ms.round_rows = pa.round_rows;
   ms.cand_count = fa.cand_count; ms.out_ids = r.d_out_ids; ms.out_dist = r.d_out_dist;
-  ms.found = ix->w_found.as<int32_t>(); ms.next_active = r.next; ms.n_next = ix->w_cnt.as<int32_t>();
+  ms.found = ws->w_found.as<int32_t>(); ms.next_active = r.next; ms.n_next = ws->w_cnt.as<int32_t>();
   ms.status = r.d_status;
   ms.n_active = r.n_active; ms.W = r.W; ms.upi = r.upi; ms.L = r.L; ms.k = r.k; ms.found_rule = r.found_rule;
   ms.first_round = r.first() ? 1 : 0; ms.sentinel = r.sentinel;
@@ -1045,6 +1105,7 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
 // Generic path (small batches, other m / S / K, k > 32): residual -> lut_build -> adc_scan -> merge_replay;
 // the LUTs round-trip through memory.
 static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
+  Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int n_items = r.n_active * r.W;
@@ -1052,21 +1113,21 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
   timed_launch(ix, s, "residual", [&] {
     hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, r.d_q, ix->coarse, pa.item_cell, pa.item_query,
-                       ix->w_resid.as<float>(), ix->d, ix->S, ix->S);
+                       ws->w_resid.as<float>(), ix->d, ix->S, ix->S);
   });
   HIP_TRY(hipGetLastError());
-  if (int rc = launch_lut(ix, s, ix->w_resid.as<float>(), pa.item_cell, ix->w_lut.as<float>(), n_items)) return rc;
+  if (int rc = launch_lut(ix, s, ws->w_resid.as<float>(), pa.item_cell, ws->w_lut.as<float>(), n_items)) return rc;
   ScanArgs sa;
-  sa.lut = ix->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
-  sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ix->w_part.as<u64>();
-  sa.cand_count = ix->w_cand.as<int32_t>();
+  sa.lut = ws->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
+  sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ws->w_part.as<u64>();
+  sa.cand_count = ws->w_cand.as<int32_t>();
   sa.m = ix->m; sa.K = ix->K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = r.L;
   memcpy(&sa.sentinel_bits, &r.sentinel, 4);
   if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
   MergeArgs ma;
   ma.part = sa.part; ma.active = r.active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
   ma.cand_count = sa.cand_count; ma.out_ids = r.d_out_ids; ma.out_dist = r.d_out_dist;
-  ma.found = ix->w_found.as<int32_t>(); ma.next_active = r.next; ma.n_next = ix->w_cnt.as<int32_t>();
+  ma.found = ws->w_found.as<int32_t>(); ma.next_active = r.next; ma.n_next = ws->w_cnt.as<int32_t>();
   ma.status = r.d_status;
   ma.n_active = r.n_active; ma.parts_per_query = r.W * nchunk; ma.L = r.L; ma.k = r.k;
   ma.found_rule = r.found_rule; ma.first_round = r.first() ? 1 : 0; ma.sentinel = r.sentinel;
@@ -1079,10 +1140,11 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
 static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, int W,
                         float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
                         int32_t* d_status, bool sync_rounds) {
+  Workspace* ws = workspace_for(ix, s);
   const int C = ix->C, m = ix->m, K = ix->K;
   if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
   IvfRun r;
-  r.ix = ix; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
+  r.ix = ix; r.ws = ws; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
   r.sentinel = sentinel; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = d_status;
   // FREDDY_FOUND_BATCH_UDF = the accepted-rows rule + the batch UDF's cell limit (argmin from minDist = 1000,
   // freddy.c:853-866); ivfadc_search's cell list starts at 100.0 (freddy.c:266-283)
@@ -1096,39 +1158,39 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   r.upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   r.fused = ix->tune.fused != 0 && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && r.L <= 64 && r.upi <= 8 &&
             (ix->tune.fused == 1 || items >= 256);
-  r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : 4;
+  r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : ix->tune.scan_kernel == 5 ? 5 : 4;
   r.tiled = Q >= 32;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
   const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
-  if (ix->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
-      ix->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
-      ix->w_item_cell.ensure(sizeof(int32_t) * items) || ix->w_item_query.ensure(sizeof(int32_t) * items) ||
-      ix->w_rows.ensure(sizeof(int32_t) * Q) || ix->w_cand.ensure(sizeof(int32_t) * Q) ||
-      ix->w_qn2.ensure(sizeof(float) * Q) || ix->w_item_dist.ensure(sizeof(float) * items) ||
-      ix->w_found.ensure(sizeof(int32_t) * Q) || ix->w_act0.ensure(sizeof(int32_t) * Q) ||
-      ix->w_act1.ensure(sizeof(int32_t) * Q) || ix->w_cnt.ensure(sizeof(int32_t) * 4))
+  if (ws->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
+      ws->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
+      ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
+      ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ws->w_qn2.ensure(sizeof(float) * Q) || ws->w_item_dist.ensure(sizeof(float) * items) ||
+      ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) ||
+      ws->w_act1.ensure(sizeof(int32_t) * Q) || ws->w_cnt.ensure(sizeof(int32_t) * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   if (r.fused) {
     // cell_count[C] + cursors; cell_items[C][Q]; work table: 3 arrays of (items/G + C + 1) * upi entries
-    if (ix->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ix->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
-        ix->w_groups.ensure(sizeof(int32_t) * 3 * (items / SPEC2_G + (size_t)C + 1) * r.upi) ||
-        ix->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
-        ix->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW))
+    if (ws->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ws->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
+        ws->w_groups.ensure(sizeof(int32_t) * 3 * (items / SPEC2_G + (size_t)C + 1) * r.upi) ||
+        ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
+        ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-    if (r.scan_kernel == 4 &&
-        (ix->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ix->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
+    if (r.scan_kernel >= 4 &&
+        (ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
     const int nchunk = std::max(1, (ix->max_list_blocks + 255) / 256);
-    if (ix->w_resid.ensure(sizeof(float) * items * (size_t)ix->d) || ix->w_lut.ensure(sizeof(float) * items * (size_t)m * K) ||
-        ix->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * r.L))
+    if (ws->w_resid.ensure(sizeof(float) * items * (size_t)ix->d) || ws->w_lut.ensure(sizeof(float) * items * (size_t)m * K) ||
+        ws->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * r.L))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   }
 
   if (int rc = ivf_coarse(r)) return rc;
   ix->last_Q = Q;
-  r.n_active = Q; r.active = nullptr; r.next = ix->w_act0.as<int32_t>();
+  r.n_active = Q; r.active = nullptr; r.next = ws->w_act0.as<int32_t>();
   const int max_rounds = (C + W - 1) / W + 1;
   for (r.round = 0; r.round < max_rounds && r.n_active > 0; ++r.round) {
     PlanArgs pa;
@@ -1136,18 +1198,18 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     if (r.fused) {
       WorkTable wt;
       if (int rc = ivf_work_table(r, wt)) return rc;
-      if (int rc = (r.scan_kernel == 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt)) return rc;
+      if (int rc = (r.scan_kernel >= 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt)) return rc;
     } else {
       if (int rc = ivf_scan_generic(r, pa)) return rc;
     }
     if (!sync_rounds) break;
     int32_t n_next = 0;
-    HIP_TRY(hipMemcpyAsync(&n_next, ix->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(&n_next, ws->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (n_next <= 0) break;
-    HIP_TRY(hipMemsetAsync(ix->w_cnt.p, 0, sizeof(int32_t), s));
+    HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t), s));
     r.active = r.next;
-    r.next = (r.next == ix->w_act0.as<int32_t>()) ? ix->w_act1.as<int32_t>() : ix->w_act0.as<int32_t>();
+    r.next = (r.next == ws->w_act0.as<int32_t>()) ? ws->w_act1.as<int32_t>() : ws->w_act0.as<int32_t>();
     r.n_active = n_next;
   }
   return 0;
@@ -1206,21 +1268,22 @@ extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* que
   if (W > ix->C) W = ix->C;
   if (Q == 0) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
+  Workspace* ws = workspace_for(ix, ix->stream);
   hipStream_t s = ix->stream;
-  if (ix->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
-      ix->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+  if (ws->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
   const int qc = max_queries_per_chunk(ix, W);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
-    if (int rc = ivfadc_chunk(ix, s, ix->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
-                              ix->w_out_ids.as<int32_t>() + (size_t)q0 * k, ix->w_out_dist.as<float>() + (size_t)q0 * k,
+    if (int rc = ivfadc_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+                              ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k,
                               nullptr, true))
       return rc;
   }
-  HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(out_dist, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_dist, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FREDDY_OK;
 }
@@ -1231,6 +1294,7 @@ extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* que
 static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
                     const int32_t* blk_off, const uint32_t* packed, const int32_t* pos, int64_t n_blocks,
                     int32_t* d_out_ids, float* d_out_dist) {
+  Workspace* ws = workspace_for(ix, s);
   const int m = ix->m, K = ix->K;
   const int L = std::min(2 * k, 64 * 16);
   const size_t lutN = (size_t)m * K;
@@ -1239,13 +1303,13 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   int chunk_blocks = 64;   // 4096 rows; longer chunks once there are enough (query, chunk) workgroups
   while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)Q > 4096 && chunk_blocks < 8192) chunk_blocks *= 2;
   const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
-  if (ix->w_lut.ensure(sizeof(float) * (size_t)Q * lutN) ||
-      ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * SCAN_WAVES * L))
+  if (ws->w_lut.ensure(sizeof(float) * (size_t)Q * lutN) ||
+      ws->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * SCAN_WAVES * L))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (int rc = launch_lut(ix, s, d_q, nullptr, ix->w_lut.as<float>(), Q)) return rc;
+  if (int rc = launch_lut(ix, s, d_q, nullptr, ws->w_lut.as<float>(), Q)) return rc;
   ScanArgs sa;
-  sa.lut = ix->w_lut.as<float>(); sa.item_list = nullptr; sa.item_query = nullptr;
-  sa.blk_off = blk_off; sa.packed = packed; sa.pos = pos; sa.part = ix->w_part.as<u64>();
+  sa.lut = ws->w_lut.as<float>(); sa.item_list = nullptr; sa.item_query = nullptr;
+  sa.blk_off = blk_off; sa.packed = packed; sa.pos = pos; sa.part = ws->w_part.as<u64>();
   sa.cand_count = nullptr;
   sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
   memcpy(&sa.sentinel_bits, &sentinel, 4);
@@ -1279,6 +1343,7 @@ extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_q
 // order; the rows' packed codes are gathered into a temporary one-list table (synchronises the stream).
 static int pq_subset(freddy_gpu_index* ix, hipStream_t s, const int32_t* subset_ids, int64_t n_subset, const int32_t** blk_off,
                      const uint32_t** packed, const int32_t** pos, int64_t* n_blocks) {
+  Workspace* ws = workspace_for(ix, s);
   std::vector<int32_t> rows;
   rows.reserve((size_t)n_subset);
   for (int64_t i = 0; i < n_subset; ++i) {
@@ -1291,23 +1356,23 @@ static int pq_subset(freddy_gpu_index* ix, hipStream_t s, const int32_t* subset_
   const int nb = (n_rows + 63) / 64;
   const int n_pad = nb * 64;
   const int32_t h_blk[2] = {0, nb};
-  if (ix->w_sub_rows.ensure(sizeof(int32_t) * std::max(n_rows, 1)) ||
-      ix->w_sub_packed.ensure(sizeof(uint32_t) * (size_t)std::max(nb, 1) * ix->M2 * 64) ||
-      ix->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max(n_pad, 1)) || ix->w_sub_blk.ensure(sizeof(int32_t) * 2))
+  if (ws->w_sub_rows.ensure(sizeof(int32_t) * std::max(n_rows, 1)) ||
+      ws->w_sub_packed.ensure(sizeof(uint32_t) * (size_t)std::max(nb, 1) * ix->M2 * 64) ||
+      ws->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max(n_pad, 1)) || ws->w_sub_blk.ensure(sizeof(int32_t) * 2))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (n_rows) HIP_TRY(hipMemcpyAsync(ix->w_sub_rows.p, rows.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
-  HIP_TRY(hipMemcpyAsync(ix->w_sub_blk.p, h_blk, sizeof(h_blk), hipMemcpyHostToDevice, s));
+  if (n_rows) HIP_TRY(hipMemcpyAsync(ws->w_sub_rows.p, rows.data(), sizeof(int32_t) * n_rows, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ws->w_sub_blk.p, h_blk, sizeof(h_blk), hipMemcpyHostToDevice, s));
   if (n_pad) {
     timed_launch(ix, s, "gather_rows", [&] {
-      hipLaunchKernelGGL(gather_rows_kernel, dim3((n_pad + WG - 1) / WG), dim3(WG), 0, s, ix->w_sub_rows.as<int32_t>(),
-                         n_rows, ix->packed, ix->w_sub_packed.as<uint32_t>(), ix->w_sub_pos.as<int32_t>(), ix->M2, n_pad);
+      hipLaunchKernelGGL(gather_rows_kernel, dim3((n_pad + WG - 1) / WG), dim3(WG), 0, s, ws->w_sub_rows.as<int32_t>(),
+                         n_rows, ix->packed, ws->w_sub_packed.as<uint32_t>(), ws->w_sub_pos.as<int32_t>(), ix->M2, n_pad);
     });
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(s));  // rows / h_blk are stack/heap temporaries
-  *blk_off = ix->w_sub_blk.as<int32_t>();
-  *packed = ix->w_sub_packed.as<uint32_t>();
-  *pos = ix->w_sub_pos.as<int32_t>();
+  *blk_off = ws->w_sub_blk.as<int32_t>();
+  *packed = ws->w_sub_packed.as<uint32_t>();
+  *pos = ws->w_sub_pos.as<int32_t>();
   *n_blocks = nb;
   return 0;
 }
@@ -1318,11 +1383,12 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   if (n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FREDDY_E_ARG, "bad subset");
   if (Q == 0) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
+  Workspace* ws = workspace_for(ix, ix->stream);
   hipStream_t s = ix->stream;
-  if (ix->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
-      ix->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+  if (ws->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
 
   const int32_t* blk_off = ix->blk_off;
   const uint32_t* packed = ix->packed;
@@ -1333,12 +1399,12 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   const int qc = max_queries_per_chunk(ix, 1);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
-    if (int rc = pq_chunk(ix, s, ix->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel, blk_off, packed, pos, n_blocks,
-                          ix->w_out_ids.as<int32_t>() + (size_t)q0 * k, ix->w_out_dist.as<float>() + (size_t)q0 * k))
+    if (int rc = pq_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel, blk_off, packed, pos, n_blocks,
+                          ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k))
       return rc;
   }
-  HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(out_dist, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_dist, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FREDDY_OK;
 }
@@ -1354,6 +1420,7 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
   if (n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FREDDY_E_ARG, "bad subset");
   *n_out = 0;
   HIP_TRY(hipSetDevice(ix->device));
+  Workspace* ws = workspace_for(ix, ix->stream);
   hipStream_t s = ix->stream;
   const int m = ix->m, K = ix->K, d = ix->d;
   const size_t lutN = (size_t)m * K;
@@ -1366,23 +1433,23 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
     if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
   (void)blk_off;
   if (n_blocks == 0) return FREDDY_OK;
-  if (ix->w_q.ensure(sizeof(float) * (size_t)G * d) || ix->w_lut.ensure(sizeof(float) * (size_t)G * lutN) ||
-      ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)n_blocks * 64))
+  if (ws->w_q.ensure(sizeof(float) * (size_t)G * d) || ws->w_lut.ensure(sizeof(float) * (size_t)G * lutN) ||
+      ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)n_blocks * 64))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  HIP_TRY(hipMemcpyAsync(ix->w_q.p, group_vectors, sizeof(float) * (size_t)G * d, hipMemcpyHostToDevice, s));
-  if (int rc = launch_lut(ix, s, ix->w_q.as<float>(), nullptr, ix->w_lut.as<float>(), G)) return rc;   // freddy.c:1288-1299
+  HIP_TRY(hipMemcpyAsync(ws->w_q.p, group_vectors, sizeof(float) * (size_t)G * d, hipMemcpyHostToDevice, s));
+  if (int rc = launch_lut(ix, s, ws->w_q.as<float>(), nullptr, ws->w_lut.as<float>(), G)) return rc;   // freddy.c:1288-1299
   const dim3 grid((unsigned)((n_blocks + GROUP_BLOCKS - 1) / GROUP_BLOCKS));
   timed_launch(ix, s, "grouping", [&] {
     if (ix->M2 == 6)
-      hipLaunchKernelGGL((grouping_kernel<6>), grid, dim3(WG), lutN * sizeof(float), s, ix->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ix->w_out_ids.as<int32_t>());
+      hipLaunchKernelGGL((grouping_kernel<6>), grid, dim3(WG), lutN * sizeof(float), s, ws->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ws->w_out_ids.as<int32_t>());
     else if (ix->M2 == 15)
-      hipLaunchKernelGGL((grouping_kernel<15>), grid, dim3(WG), lutN * sizeof(float), s, ix->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ix->w_out_ids.as<int32_t>());
+      hipLaunchKernelGGL((grouping_kernel<15>), grid, dim3(WG), lutN * sizeof(float), s, ws->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ws->w_out_ids.as<int32_t>());
     else
-      hipLaunchKernelGGL((grouping_kernel<0>), grid, dim3(WG), lutN * sizeof(float), s, ix->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ix->w_out_ids.as<int32_t>());
+      hipLaunchKernelGGL((grouping_kernel<0>), grid, dim3(WG), lutN * sizeof(float), s, ws->w_lut.as<float>(), G, m, K, packed, (int)n_blocks, ws->w_out_ids.as<int32_t>());
   });
   HIP_TRY(hipGetLastError());
   std::vector<int32_t> h_grp((size_t)n_blocks * 64), h_pos((size_t)n_blocks * 64);
-  HIP_TRY(hipMemcpyAsync(h_grp.data(), ix->w_out_ids.p, sizeof(int32_t) * h_grp.size(), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_grp.data(), ws->w_out_ids.p, sizeof(int32_t) * h_grp.size(), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(h_pos.data(), pos, sizeof(int32_t) * h_pos.size(), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   int64_t n = 0;
@@ -1878,6 +1945,7 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
   if (k > 1024) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 1024", k);
   if (Q == 0) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
+  Workspace* ws = workspace_for(ix, ix->stream);
   hipStream_t s = ix->stream;
   const int d = ix->d, L = k, V = pick_V(L);
   const float* xb = ix->xb;
@@ -1894,32 +1962,32 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
     rows.erase(std::unique(rows.begin(), rows.end()), rows.end());
     n_rows = (int64_t)rows.size();
     n_blocks = (n_rows + 63) / 64;
-    if (ix->w_sub_rows.ensure(sizeof(int32_t) * std::max<size_t>(rows.size(), 1)) ||
-        ix->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(n_blocks, 1) * 64) ||
-        ix->w_resid.ensure(sizeof(float) * (size_t)std::max<int64_t>(n_blocks, 1) * d * 64))
+    if (ws->w_sub_rows.ensure(sizeof(int32_t) * std::max<size_t>(rows.size(), 1)) ||
+        ws->w_sub_pos.ensure(sizeof(int32_t) * (size_t)std::max<int64_t>(n_blocks, 1) * 64) ||
+        ws->w_resid.ensure(sizeof(float) * (size_t)std::max<int64_t>(n_blocks, 1) * d * 64))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed");
     if (n_rows) {
-      HIP_TRY(hipMemcpyAsync(ix->w_sub_rows.p, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, ix->coarse, ix->w_sub_rows.as<int32_t>(), n_rows,
-                         ix->w_resid.as<float>(), ix->w_sub_pos.as<int32_t>(), d);
+      HIP_TRY(hipMemcpyAsync(ws->w_sub_rows.p, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(block_rows_kernel, dim3((unsigned)n_blocks), dim3(256), 0, s, ix->coarse, ws->w_sub_rows.as<int32_t>(), n_rows,
+                         ws->w_resid.as<float>(), ws->w_sub_pos.as<int32_t>(), d);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipStreamSynchronize(s));   // `rows` is a host temporary
     }
-    xb = ix->w_resid.as<float>();
-    pos = ix->w_sub_pos.as<int32_t>();
+    xb = ws->w_resid.as<float>();
+    pos = ws->w_sub_pos.as<int32_t>();
   }
   int chunk_blocks = 8;   // 512 rows per workgroup-chunk; longer chunks once the grid is large enough
   const int EX_QT = ex_qt(V, Q);
   const int qgroups = (Q + EX_QT - 1) / EX_QT;
   while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)qgroups > 8192 && chunk_blocks < 1024) chunk_blocks *= 2;
   const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
-  if (ix->w_q.ensure(sizeof(float) * (size_t)Q * d) || ix->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
-      ix->w_out_dist.ensure(sizeof(float) * (size_t)Q * k) ||
-      ix->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * EX_WAVES * L))
+  if (ws->w_q.ensure(sizeof(float) * (size_t)Q * d) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k) ||
+      ws->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * EX_WAVES * L))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  HIP_TRY(hipMemcpyAsync(ix->w_q.p, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
   ExactArgs ea;
-  ea.xb = xb; ea.pos = pos; ea.queries = ix->w_q.as<float>(); ea.part = ix->w_part.as<u64>();
+  ea.xb = xb; ea.pos = pos; ea.queries = ws->w_q.as<float>(); ea.part = ws->w_part.as<u64>();
   ea.n_rows = n_rows; ea.n_blocks = (int)n_blocks; ea.chunk_blocks = chunk_blocks; ea.nchunk = nchunk; ea.Q = Q; ea.d = d; ea.L = L;
   const size_t lds = (((size_t)d * EX_QT * 4 + 15) & ~(size_t)15) + (size_t)EX_WAVES * EX_QT * 64 * sizeof(u64);
   dim3 grid((unsigned)nchunk, (unsigned)qgroups);
@@ -1942,16 +2010,16 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
   const int ppq = nchunk * EX_WAVES;
   timed_launch(ix, s, "exact_merge", [&] {
     switch (V) {
-      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (1 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (2 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (4 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(8 * 64), (size_t)8 * 64 * (8 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
-      default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (16 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ix->w_out_ids.as<int32_t>(), ix->w_out_dist.as<float>()); break;
+      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (1 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+      case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (2 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+      case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (4 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+      case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(8 * 64), (size_t)8 * 64 * (8 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+      default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (16 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
     }
   });
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(out_ids, ix->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(out_sim, ix->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_sim, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return FREDDY_OK;
 }

@@ -65,6 +65,20 @@ __device__ __forceinline__ float filter_width(const float* __restrict__ qn, cons
   return __builtin_fmaf(sb, FILT_EPS, 1e-30f);
 }
 
+// The integer-slab scan (fused5.h) quantises the table with one scale per query; its margin (derivation there):
+static constexpr int FILT5_VMAX = 2730;   // 12 positions x 2730 = 32760 < 2^15
+static constexpr float FILT5_EPS = 512.0f * 5.9604644775390625e-8f * 1.0001f;
+template <int M>
+__device__ __forceinline__ float filter_width5(const float* __restrict__ qn, const float* __restrict__ pmax, float scale) {
+  float sb = 0.0f;
+#pragma unroll
+  for (int p = 0; p < M; ++p) {
+    const float t = qn[p] + pmax[p];
+    sb = __builtin_fmaf(t, t, sb);
+  }
+  return __builtin_fmaf(sb, FILT5_EPS, __builtin_fmaf(28.0f, scale, 1e-30f));
+}
+
 struct ItemBounds {
   float off;          // initial value of the running sums
   float e;            // selection margin E (+inf: keep every row)
@@ -698,6 +712,7 @@ struct MergeRefineArgs {
   const float* cbR;            // [m][K][S]
   const float* qn;             // [Q][M]
   const float* pmax;           // [M]
+  const float* qscale5;        // [Q] or NULL: the integer-slab scan's per-query table scale (selects its margin E)
   const uint32_t* packed;
   const int32_t* pos;
   const int32_t* blk_cell;     // [blocks] list (cell) of every row block
@@ -740,7 +755,9 @@ __global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a)
   constexpr int NBATCH = 4;
 
   if (!(a.ablate & 2)) for (int j = threadIdx.x; j < M * S; j += 256) qs[j] = a.queries[(size_t)q * a.d + j];
-  const float E = (a.ablate & 2) ? 0.0f : filter_width<M>(a.qn + (size_t)q * M, a.pmax);
+  const float E = (a.ablate & 2) ? 0.0f
+                  : a.qscale5 ? filter_width5<M>(a.qn + (size_t)q * M, a.pmax, a.qscale5[q])
+                              : filter_width<M>(a.qn + (size_t)q * M, a.pmax);
 
   // one tile of the exact stage: chains [t*64, t*64+64) of the first n queue entries -> lutv
   auto tile_work = [&](int t, float* sqb, int n) {

@@ -1,0 +1,607 @@
+// fused5.h -- the filter + refine scan of fused4.h with INTEGER slabs: half the LDS traffic, half the phases.
+//
+// What bounds ivf_filter_kernel (fused4.h) in its main loop is the LDS pipe: per position 48 KB of fp32 slab are
+// written (48 wave-level ds_write_b128 at ~13 cycles) and gathered (8 waves x 8 rows x 3 ds_read_b128 at ~7.8
+// cycles under ~40 % bank conflicts), 87 % of the phase (rocprofv3 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT),
+// with a workgroup barrier per position.  Here a slab entry is the table's own 16-bit integer:
+//
+//   * the query x codebook table is quantised with ONE scale per query (not per (query, position)) to
+//     |v| <= 2730, so that the sum over the 12 positions fits 16 bits and is EXACT: the gatherers add rows
+//     with v_pk_add_i16 (two items per instruction, as v_pk_add_f32 did) and a (row, item) sum is one 16-bit
+//     half of a register -- 48 sum registers instead of 96;
+//   * a slab row is 12 items x 2 B = 24 B: three ds_read_b64 per row and position instead of three
+//     ds_read_b128, half the bytes written by the builders, who only interleave the items' table words
+//     (v_perm_b32) -- no conversion, no multiplication;
+//   * two positions fit one buffer (2 x 24 KB): SIX phases -- barriers -- per entry instead of twelve, and the
+//     rows' code dword of a phase is exactly the two codes it needs;
+//   * the floating-point value s = (OFF[item] + rterm[row]) + scale[item] * V is formed once per (row, item) in the
+//     tail (one conversion + one fma), where the selection needs its bits.
+//
+// The bound (u = 2^-24, B and the reference's error as in fused4.h; D exact, d the reference's binary32 value):
+//   reference                                   |d - D|        <= 39 u B
+//   rterm (fp64, rounded once)                                  <=  1 u B
+//   per position: dot product (fmaf chain of 25)  25 u 2|q_p||c| ; quotient and rint: <= 0.5 scale (+ 2 u 2|q_p||c|)
+//                 no clamping: 2 |q_p| max|c_p| <= 2730 scale by construction
+//       summed over 12 positions                                <= 27 u B + 6 scale
+//   the sum V itself: exact (integers below 2^15)
+//   s = fma(scale, V, OFF + rterm) (OFF the item's own, as in fused4.h): two roundings of values <= 3 B + E      <=  7 u B
+//   residual's own rounding (as fused4.h)                                    <=  2 u B
+//   =>  |(s - OFF + |r|^2) - d| <= e = 76 u B + 6 scale;  the construction needs e <= E / 4.2:
+//   E = 512 u B + 28 scale   (typical: 2.0e-3 against 1.2e-3 of fused4.h -- 13.7 instead of 11.8 survivors per item).
+// Everything downstream (thresholds tau + E, survivor regions, merge_refine_kernel with the same E, the self-check
+// of the bracket on every refined row) is fused4.h's.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fused4.h"
+
+namespace freddy {
+
+// (FILT5_VMAX, filter_width5: fused4.h, next to the merge that shares them)
+
+static constexpr int SCAN5_G = 16;   // items per work entry
+
+// order-preserving 32-bit key of a float (NaNs sort above +inf or below -inf: only met with non-finite inputs)
+__device__ __forceinline__ uint32_t float_key(float x) {
+  const uint32_t b = __float_as_uint(x);
+  return b ^ ((b >> 31) ? 0xffffffffu : 0x80000000u);
+}
+// selection threshold of the integer scan from the KEY of tau': tau' + E rounded up, as a float; +inf = keep every row
+__device__ __forceinline__ uint32_t widen_threshold5(uint32_t tau_key, float E) {
+  const uint32_t b = (tau_key & 0x80000000u) ? (tau_key ^ 0x80000000u) : ~tau_key;
+  const float tau = __uint_as_float(b);
+  if (!(tau < 3e38f) || !(tau > -3e38f) || !(E < 1e30f)) return 0x7f800000u;
+  const float t = tau + E;
+  return __float_as_uint(t + __builtin_fabsf(t) * 2.4e-7f + 1e-37f);
+}
+
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_pk_add_u16 (wrap-around: never reached)
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, x) + __builtin_bit_cast(s2v, y));
+}
+
+// qn[q][p] = |q_p| (rounded up) and the query's ONE table scale: max_p 2 |q_p| max|c_p| / 2730.  One wave per query.
+template <int S>
+__global__ __launch_bounds__(64) void query_scale5_kernel(const float* __restrict__ queries, const float* __restrict__ cmax,
+                                                         float* __restrict__ qn, float* __restrict__ qscale, int Q, int d, int m) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  if (q >= Q) return;
+  float best = 0.0f;
+  if (lane < m) {
+    float n2 = 0.0f;
+    for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + lane * S + j]; n2 = __builtin_fmaf(v, v, n2); }
+    const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+    qn[(size_t)q * m + lane] = nrm;
+    best = 2.0f * nrm * cmax[lane];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+  if (lane == 0) qscale[q] = best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
+}
+
+// The table itself: as query_codebook_kernel (whole 2 KB rows through an LDS transpose), values
+// rint(-2 q_p . c / scale[q]) clamped to +-2730.
+template <int S, int QT>
+__global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
+                                                             const float* __restrict__ qscale, uint32_t* __restrict__ qc,
+                                                             int Q, int d, int m, int K) {
+  constexpr int SP = (S + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float qs[QT][SP];
+  __shared__ float inv_s[QT];
+  __shared__ __attribute__((aligned(16))) uint32_t ob[2][4][512];
+  const int tid = threadIdx.x, p = blockIdx.x, q0 = blockIdx.y * QT;
+  for (int i = tid; i < QT * SP; i += 256) {
+    const int qi = i / SP, j = i - qi * SP;
+    qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
+  }
+  if (tid < QT) {
+    const float sc = q0 + tid < Q ? qscale[q0 + tid] : 0.0f;
+    inv_s[tid] = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
+  }
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f cb[2][S];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int b = tid + 256 * e;
+#pragma unroll
+    for (int j = 0; j < S; ++j) {
+      cb[e][j].x = b < K ? cbT[((size_t)p * S + j) * K + b] : 0.0f;
+      cb[e][j].y = b + 512 < K ? cbT[((size_t)p * S + j) * K + b + 512] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const int nq = (Q - q0 < QT) ? Q - q0 : QT;
+  for (int qi = 0; qi < nq; qi += 4) {
+    v2f acc[4][2];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc[w][0] = acc[w][1] = v2f{0.0f, 0.0f};
+#pragma unroll
+    for (int jb = 0; jb < SP / 4; ++jb) {
+      float vv[4][4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&qs[qi + w][jb * 4]);
+        vv[w][0] = v.x; vv[w][1] = v.y; vv[w][2] = v.z; vv[w][3] = v.w;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (jb * 4 + u < S) {
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const v2f qq = v2f{vv[w][u], vv[w][u]};
+            acc[w][0] = __builtin_elementwise_fma(qq, cb[0][jb * 4 + u < S ? jb * 4 + u : 0], acc[w][0]);
+            acc[w][1] = __builtin_elementwise_fma(qq, cb[1][jb * 4 + u < S ? jb * 4 + u : 0], acc[w][1]);
+          }
+        }
+    }
+    const int buf = (qi >> 2) & 1;
+    const float vmax = (float)FILT5_VMAX;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float inv = inv_s[qi + w];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int b = tid + 256 * e;
+        const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].x * inv), -vmax), vmax);
+        const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].y * inv), -vmax), vmax);
+        ob[buf][w][4 * (b & 127) + (b >> 7)] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = tid + 256 * h;
+      const int w = i >> 7, e4 = i & 127;
+      if (qi + w < nq)
+        *reinterpret_cast<uint4*>(qc + ((size_t)(q0 + qi + w) * m + p) * 512 + 4 * e4) = *reinterpret_cast<const uint4*>(&ob[buf][w][4 * e4]);
+    }
+  }
+}
+
+// Entry records as entry_record_kernel; [128 + g] = the table scale of item g's query.
+template <int M>
+__global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= a.n_groups[0]) return;
+  const int cell = a.group_cell[e], first = a.group_first[e], gc = a.group_cnt[e];
+  const int cnt = gc & 0xff, chunk = gc >> 8;
+  int32_t* rec = a.records + (size_t)e * REC_DW;
+  if (lane == 0) {
+    const int b0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
+    int nb = a.blk_off[cell + 1] - b0;
+    if (nb > FUSED_UNIT_BLOCKS) nb = FUSED_UNIT_BLOCKS;
+    int rows = a.list_off[cell + 1] - a.list_off[cell] - chunk * (FUSED_UNIT_BLOCKS * 64);
+    if (rows > FUSED_UNIT_BLOCKS * 64) rows = FUSED_UNIT_BLOCKS * 64;
+    rec[0] = cell; rec[1] = cnt; rec[2] = chunk; rec[3] = b0; rec[4] = nb; rec[5] = rows;
+  }
+  if (lane < 16) {
+    const int it = lane < cnt ? a.sorted_item[first + lane] : -1;
+    const int q = a.item_query[it >= 0 ? it : a.sorted_item[first]];
+    const float sc = a.qscale[q];
+    ItemBounds ib = item_bounds(0.0f, 0.0f, a.sentinel);
+    if (it >= 0) ib = item_bounds(a.item_dist[it], filter_width5<M>(a.qn + (size_t)q * M, a.pmax, sc), a.sentinel);
+    rec[8 + lane] = it;
+    rec[24 + lane] = q;
+    rec[40 + lane] = (int32_t)__float_as_uint(ib.off);
+    rec[56 + lane] = (int32_t)__float_as_uint(ib.e);
+    rec[72 + lane] = (int32_t)__float_as_uint(ib.shift);
+    rec[88 + lane] = (int32_t)ib.lo_bits;
+    rec[104 + lane] = (int32_t)ib.hi_bits;
+    rec[128 + lane] = (int32_t)__float_as_uint((it >= 0 && sc < 1e30f) ? sc : 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The scan.  Roles, entry queue, records, row terms, thresholds and survivor regions as ivf_filter_kernel;
+// phases j = 0 .. M/2 - 1 cover positions 2j and 2j + 1.
+//   LDS: slab[2 buffers][2 positions][K][12] int16 = 96 KB, then colmin / thresholds / records / row terms.
+// ---------------------------------------------------------------------------------------
+template <int M, bool FULLK>
+__global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
+  constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
+  constexpr int NP = M / 2;             // phases per entry
+  constexpr int ROWB = G * 2;           // bytes of a slab row: two 16-byte halves of 8 items
+  static_assert(M % 4 == 0 && G == 16 && SPEC2_NB == 8, "layout");
+  typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* slab = smem;                                                      // [2][2][K][ROWB]
+  uint32_t* colmin = reinterpret_cast<uint32_t*>(smem + a.desc_offset);           // [16][64]
+  uint32_t* thr_s = colmin + 16 * 64;                                             // [16]
+  int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // [2][REC_DW] entry records
+  int32_t* gidq = dsc + 2 * REC_DW;
+  float* rt_s = reinterpret_cast<float*>(gidq + 4);                                // [4096] row terms of the entry about to start
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool builder = wave < SPEC2_NB;
+  const int K = FULLK ? 1024 : a.K;
+  const uint32_t POSB = (uint32_t)K * ROWB;          // bytes of one position's slab
+  const uint32_t BUFB = 2u * POSB;                   // bytes of one buffer
+  const int n_work = a.n_groups[0];
+
+  int cur = 0, ei = 0;
+  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = atomicAdd(a.work_counter, 1); }
+  for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
+  __syncthreads();
+  if (gidq[0] >= n_work) return;
+  if (tid < REC_DW) dsc[tid] = a.records[(size_t)gidq[0] * REC_DW + tid];
+  __syncthreads();
+
+  if (builder) {
+    // =====================================================================================
+    // BUILDERS: a pair of waves per item quad; lane li of the pair <-> code pairs li + 128 k (k < 4), one 16-byte
+    // load per item and position.  Two register sets of one PHASE each (2 positions x 4 items): the set that
+    // phase j + 1 is written from at the start of phase j is refilled at once with phase j + 3.
+    // =====================================================================================
+    const int grp = wave >> 1;
+    constexpr bool has_quad = true;      // (four quads, four wave pairs)
+    const int li = (wave & 1) * 64 + lane;
+    // byte offset of this quad inside a slab row: half (grp >> 1), swizzled with bit 3 of the code -- the same for all
+    // codes li + 128 k (+ 512) of this lane
+    const uint32_t qoff = (uint32_t)((((grp >> 1) ^ ((li >> 3) & 1)) << 4) + ((grp & 1) << 3));
+    const uint32_t vq = (uint32_t)li * 16u;
+    u4 qw[2][2][4];   // [set][position of the phase][item]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) qw[s][h][g] = u4{0u, 0u, 0u, 0u};
+    typedef const char __attribute__((address_space(1))) * gptrc;
+    typedef const u4 __attribute__((address_space(1))) * gptr4u;
+    auto issue = [&](int set, int phase, const int (&qids)[4]) {   // positions 2 phase, 2 phase + 1 of the quad's 4 items
+      if (!has_quad || (a.ablate & 32)) return;
+      uint32_t voff = vq + (uint32_t)phase * 4096u;
+      asm volatile("" : "+v"(voff));
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[u] * (size_t)(M * 2048);
+          qw[set][h][u] = *(gptr4u)(qb + voff + (uint32_t)h * 2048u);
+        }
+    };
+    // slab rows are [code][12 items] int16: 8 bytes per item quad and code -- the quad's four table words of
+    // code pair b = li + 128 k interleaved: low halves -> row b, high halves -> row b + 512
+    auto emit = [&](int set, unsigned char* dst, int nq) {
+      if (!has_quad || grp >= nq || (a.ablate & 16)) return;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned char* dp = dst + (uint32_t)h * POSB + qoff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          uint32_t w[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            w[u] = k == 0 ? qw[set][h][u].x : k == 1 ? qw[set][h][u].y : k == 2 ? qw[set][h][u].z : qw[set][h][u].w;
+          // v_perm_b32: bytes 0-3 come from the second operand, 4-7 from the first
+          const u2 lo = u2{__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u)};
+          const u2 hi = u2{__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u)};
+          const int b = li + 128 * k;
+          if (FULLK || b < K) *reinterpret_cast<u2*>(dp + (uint32_t)b * ROWB) = lo;
+          if (FULLK || b + 512 < K) *reinterpret_cast<u2*>(dp + (uint32_t)(b + 512) * ROWB) = hi;
+        }
+      }
+    };
+
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
+    auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
+    if (a.prof) pc = clock64();
+    int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 3) >> 2;
+    const int g0 = has_quad ? grp * 4 : 0;
+    int qid[4], nqid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { qid[u] = __builtin_amdgcn_readfirstlane(dsc[24 + g0 + u]); nqid[u] = qid[u]; }
+    float rtv[RMAX];
+    auto fetch_row_terms = [&](const int32_t* rc) {
+      const int b0 = __builtin_amdgcn_readfirstlane(rc[3]), nbk = __builtin_amdgcn_readfirstlane(rc[4]);
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        const int bl = r * NG + wave;
+        rtv[r] = a.rterm[(size_t)(uint32_t)(b0 + (bl < nbk - 1 ? bl : nbk - 1)) * 64u + (uint32_t)lane];
+      }
+    };
+    auto stash_row_terms = [&]() {
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) rt_s[(r * NG + wave) * 64 + lane] = rtv[r];
+    };
+    fetch_row_terms(dsc);
+    stash_row_terms();
+    issue(0, 0, qid);
+    issue(1, 1, qid);
+    emit(0, slab, nq);          // phase 0 -> buffer 0 (waits for set 0)
+    issue(0, 2, qid);
+    lds_barrier();
+    for (;;) {
+      const int nb = cur ^ 1;
+      const int ngid = __builtin_amdgcn_readfirstlane(gidq[(ei + 1) & 1]);
+      const bool have_next = ngid < n_work;
+      int gid2 = 0;
+      int next_nq = 0;
+      int32_t rr0 = 0;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        // the next entry's record: requested in phase 0, stored in phase 1, first read in phase 2
+        if (j == 1 && tid < REC_DW) {
+          if (tid == 0) gidq[ei & 1] = gid2;
+          dsc[nb * REC_DW + tid] = rr0;
+          if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
+        }
+        if (j == NP - 3) {   // (the next entry's record is in LDS since the barrier of phase 1)
+          next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 3) >> 2 : 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) nqid[u] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g0 + u]) : qid[u];
+        }
+        // slab of phase j + 1 of this entry -- or phase 0 of the next one -- from the set requested two phases ago,
+        // then the same set again for phase j + 3
+        const int set = (j + 1) & 1;
+        if (j + 1 < NP) emit(set, slab + (uint32_t)((j + 1) & 1) * BUFB, nq);
+        else emit(set, slab, next_nq);
+        if (j + 3 < NP) issue(set, j + 3, qid);
+        else issue(set, j + 3 - NP, nqid);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
+        if (j == 2) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
+        if (j == 4) stash_row_terms();
+        if (j == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
+        if (j == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
+        tick(0);
+        lds_barrier();
+        tick(1);
+      }
+      // S1: thresholds tau + E (builder wave w: items w and w + 8), while the gatherers are in their tail
+      if (!(a.ablate & 4)) {
+        const int32_t* rec = dsc + cur * REC_DW;
+        const int cnt = __builtin_amdgcn_readfirstlane(rec[1]);
+        const int i0 = wave, i1 = wave + NG;
+        if (i0 < cnt) {
+          uint32_t c0 = colmin[i0 * 64 + lane], c1 = colmin[i1 * 64 + lane];
+          wave_sort32_x2(c0, c1);   // (order-preserving keys of the float column minima)
+          const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
+          if (lane == 0) {
+            thr_s[i0] = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
+            thr_s[i1] = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
+          }
+          colmin[i0 * 64 + lane] = 0xffffffffu;
+          colmin[i1 * 64 + lane] = 0xffffffffu;
+        }
+      }
+      lds_barrier();   // S1
+      lds_barrier();   // S2
+      tick(3);
+      pt[7] += 1;
+      if (!have_next) break;
+      cur = nb;
+      ++ei;
+      nq = next_nq;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) qid[u] = nqid[u];
+    }
+    if (a.prof && tid == 0) {
+      for (int i = 0; i < 8; ++i) if (i != 2 && i != 4 && i != 5) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];   // (2, 4, 5: gatherer wave 0)
+      a.prof[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
+    }
+  } else {
+    // =====================================================================================
+    // GATHERERS: lane <-> 8 rows x 12 items, a (row, item) sum = one 16-bit half of a register
+    // =====================================================================================
+    const int gw = wave - SPEC2_NB;
+    uint32_t acc[G / 2][RMAX];     // [item pair][row]: low half = item 2i, high half = item 2i + 1
+    uint32_t cwa[RMAX], cwb[RMAX]; // code dwords of the even / odd phases (double buffered: requested a phase ahead)
+    lds_barrier();   // (pairs with the builders' barrier after the first slab)
+    long long gt[3] = {0, 0, 0}, gc = 0;
+    auto gtick = [&](int slot) { if (a.prof) { const long long t = clock64(); if (slot >= 0) gt[slot] += t - gc; gc = t; } };
+    for (;;) {
+      gtick(-1);
+      const int32_t* rec = dsc + cur * REC_DW;
+      const int cnt = __builtin_amdgcn_readfirstlane(rec[1]);
+      const int chunk = __builtin_amdgcn_readfirstlane(rec[2]);
+      const int blk0 = __builtin_amdgcn_readfirstlane(rec[3]);
+      const int nblk = __builtin_amdgcn_readfirstlane(rec[4]);
+      const int nrows = __builtin_amdgcn_readfirstlane(rec[5]);
+      const int nq = (cnt + 7) >> 3;     // 16-byte halves of a slab row in use
+      const int nb = cur ^ 1;
+      const int rl_wave = (nblk - gw + NG - 1) / NG < 0 ? 0 : (nblk - gw + NG - 1) / NG;
+      auto row_block = [&](int r) {
+        const int bl = r * NG + gw;
+        return (uint32_t)(blk0 + (bl < nblk - 1 ? bl : nblk - 1));
+      };
+      // base[r] = the row's own term (staged by the builders during the previous entry, overwritten during this one); +inf for the slots of this wave beyond its last block and for the lanes
+      // past the end of the list (s = +inf: above every finite threshold; S2 skips the former and masks the latter)
+      float base[RMAX];
+      const int last_blk = nrows > 0 ? (nrows - 1) >> 6 : -1;     // chunk-relative block holding the last row
+      const int rs2 = (last_blk >= 0 && (last_blk % NG) == gw && (nrows & 63)) ? last_blk / NG : -1;
+      const bool live_lane = lane < (nrows & 63);
+      {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          base[r] = rt_s[(r * NG + gw) * 64 + lane];
+          if (r >= rl_wave || (r == rs2 && !live_lane)) base[r] = __uint_as_float(0x7f800000u);
+        }
+      }
+      auto main_loop = [&](auto nqc, auto rlc) {
+        constexpr int NQ = decltype(nqc)::value, RL = decltype(rlc)::value;
+        auto load_codes = [&](uint32_t (&cw)[RMAX], int pair) {
+#pragma unroll
+          for (int r = 0; r < RL; ++r) cw[r] = a.packed[(row_block(r) * (uint32_t)(M / 2) + (uint32_t)pair) * 64u + (uint32_t)lane];
+        };
+        // both positions of a phase, one row at a time: NQ ds_read_b128 per position fetch the values of 8 items each.
+        // Half h of row c sits at byte 32 c + 16 (h ^ bit 3 of c): with the plain layout the first halves of all rows
+        // would share 8 of the 16 bank groups.
+        auto gather = [&](const uint32_t (&cw)[RMAX], int j) {
+          const unsigned char* bufp = slab + (uint32_t)(j & 1) * BUFB;
+#pragma unroll
+          for (int r = 0; r < RL; ++r) {
+            const uint32_t c0 = cw[r] & 0xffffu, c1 = cw[r] >> 16;
+            const uint32_t a0 = c0 * (uint32_t)ROWB + ((c0 & 8u) << 1);
+            const uint32_t a1 = c1 * (uint32_t)ROWB + ((c1 & 8u) << 1) + POSB;
+            u4 v0[NQ], v1[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v0[q] = *reinterpret_cast<const u4*>(bufp + (a0 ^ (uint32_t)(q * 16)));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) v1[q] = *reinterpret_cast<const u4*>(bufp + (a1 ^ (uint32_t)(q * 16)));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+              acc[q * 4 + 0][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 0][r], v0[q].x), v1[q].x);
+              acc[q * 4 + 1][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 1][r], v0[q].y), v1[q].y);
+              acc[q * 4 + 2][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 2][r], v0[q].z), v1[q].z);
+              acc[q * 4 + 3][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 3][r], v0[q].w), v1[q].w);
+            }
+          }
+        };
+#pragma unroll
+        for (int h = 0; h < G / 2; ++h)
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) acc[h][r] = 0u;
+        load_codes(cwa, 0);
+        load_codes(cwb, 1);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          if (!(a.ablate & 2)) {
+            if (j & 1) gather(cwb, j); else gather(cwa, j);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + 2 < NP && !(a.ablate & 64)) {   // the codes of phase j + 2 into the set phase j has just used
+            if (j & 1) load_codes(cwb, j + 2); else load_codes(cwa, j + 2);
+          }
+          if (j + 1 < NP) lds_barrier();
+        }
+      };
+      {
+        int rl = rl_wave;
+        rl = rl < 1 ? 1 : rl;
+        const int rc = (rl + 1) >> 1;
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
+        using I6 = std::integral_constant<int, 6>; using I8 = std::integral_constant<int, 8>;
+        switch (nq * 4 + rc) {
+          case 1 * 4 + 1: main_loop(I1{}, I2{}); break;
+          case 1 * 4 + 2: main_loop(I1{}, I4{}); break;
+          case 1 * 4 + 3: main_loop(I1{}, I6{}); break;
+          case 1 * 4 + 4: main_loop(I1{}, I8{}); break;
+          case 2 * 4 + 1: main_loop(I2{}, I2{}); break;
+          case 2 * 4 + 2: main_loop(I2{}, I4{}); break;
+          case 2 * 4 + 3: main_loop(I2{}, I6{}); break;
+          default: main_loop(I2{}, I8{}); break;
+        }
+      }
+      // ---- tail.  The selection works on s' = fma(scale[item], V, rterm[row]) -- the stored sum WITHOUT the item's
+      // constant OFF -- compared as floats: a constant shift changes neither the order nor tau' + E.  OFF (which keeps
+      // the stored bits positive for the merge) is added for the survivors only: s = s' + OFF.
+      gtick(0);
+      auto sval = [&](int g, int r, float sc) -> float {
+        const uint32_t w = acc[g >> 1][r];
+        const int v = (g & 1) ? ((int32_t)w >> 16) : ((int32_t)(w << 16) >> 16);
+        return __builtin_fmaf(sc, (float)v, base[r]);
+      };
+      // Per-item parameters: lane g holds item g's (one LDS read each, fetched with v_readlane below -- a chain of
+      // dependent LDS round trips per item was a quarter of the entry's time).
+      const int gi = lane & 15;
+      const float p_sc = __int_as_float(rec[128 + gi]);
+      // rows this lane really holds: bit r of live8
+      uint32_t live8 = 0u;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rl_wave && !(r == rs2 && !live_lane)) live8 |= 1u << r;
+      if (!(a.ablate & 4)) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g < cnt) {
+            const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));
+            float best = sval(g, 0, sc);
+#pragma unroll
+            for (int r = 1; r < RMAX; ++r) best = fminf(best, sval(g, r, sc));
+            if (rl_wave > 0) atomicMin(colmin + g * 64 + lane, float_key(best));
+          }
+        }
+      }
+      gtick(1);
+      lds_barrier();
+      // (S1, the thresholds tau' + E, is computed by the builder waves between these two barriers)
+      lds_barrier();
+      gtick(-1);
+      // S2: survivors -> this wave's region of each item's buffer.  First the pass bits of the lane's 8 rows, branch
+      // free; the per-row ballots and stores only run for the (item, wave) pairs that have a survivor at all.
+      if (!(a.ablate & 4)) {
+        const float p_thr = __uint_as_float(thr_s[gi]);
+        const int p_it = rec[8 + gi];
+        const float p_shift = __int_as_float(rec[72 + gi]);
+        const float p_off = __int_as_float(rec[40 + gi]);
+        const uint32_t p_lo = (uint32_t)rec[88 + gi], p_hi = (uint32_t)rec[104 + gi];
+        const int p_q = rec[24 + gi];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (g < cnt) {
+            const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_thr), g));
+            const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));
+            const float off = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_off), g));
+            const float shift = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_shift), g));
+            const int it = __builtin_amdgcn_readlane(p_it, g);
+            const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
+            u64* dst = a.surv + region * (size_t)(RMAX * 64);
+            int run = 0;
+            if (!a.cand_count) {   // the common case (freddy.c:366 counts retrieved rows): nothing but the threshold test
+              uint32_t m8 = 0u;
+#pragma unroll
+              for (int r = RMAX - 1; r >= 0; --r) m8 = m8 + m8 + (!(sval(g, r, sc) > thr) ? 1u : 0u);   // (a NaN passes: exact stage)
+              m8 &= live8;
+              if ((a.ablate & 128) == 0 && __ballot(m8 != 0u) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                  const bool pass = (m8 >> r) & 1u;
+                  const u64 mask = __ballot(pass);
+                  if (mask != 0ull) {
+                    if (pass) {
+                      const float dlo = fmaxf(0.0f, (sval(g, r, sc) + off) - shift);
+                      const uint32_t loc = (uint32_t)(blk0 + r * NG + gw) * 64u + (uint32_t)lane;
+                      dst[run + lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+                    }
+                    run += __popcll(mask);
+                  }
+                }
+              }
+            } else {   // rows below the sentinel are counted (freddy.c:971): bounds on the bits of s = s' + OFF > 0
+              const uint32_t lo_b = (uint32_t)__builtin_amdgcn_readlane((int)p_lo, g);
+              const uint32_t hi_b = (uint32_t)__builtin_amdgcn_readlane((int)p_hi, g);
+              int accepted = 0;
+#pragma unroll
+              for (int r = 0; r < RMAX; ++r) {
+                if (r >= rl_wave) break;
+                const float sv = sval(g, r, sc);
+                const uint32_t sb = __float_as_uint(sv + off);
+                const bool live = (live8 >> r) & 1u;
+                accepted += __popcll(__ballot(live && sb < lo_b));
+                const bool amb = sb >= lo_b && sb < hi_b;
+                const bool pass = live && (!(sv > thr) || amb);
+                const u64 mask = __ballot(pass);
+                if (mask != 0ull) {
+                  if (pass) {
+                    const float dlo = fmaxf(0.0f, __uint_as_float(sb) - shift);
+                    const uint32_t loc = ((uint32_t)(blk0 + r * NG + gw) * 64u + (uint32_t)lane) | (amb ? 0x80000000u : 0u);
+                    dst[run + lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+                  }
+                  run += __popcll(mask);
+                }
+              }
+              if (lane == 0 && accepted) atomicAdd(a.cand_count + __builtin_amdgcn_readlane(p_q, g), accepted);
+            }
+            if (lane == 0) a.surv_count[region] = run;
+          }
+        }
+      }
+      gtick(2);
+      const int next_ok = __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 6]);
+      lds_barrier();
+      if (next_ok < 0) break;
+      cur = nb;
+    }
+    if (a.prof && gw == 0 && lane == 0) {
+      a.prof[(size_t)blockIdx.x * 8 + 2] = gt[0];
+      a.prof[(size_t)blockIdx.x * 8 + 4] = gt[1];
+      a.prof[(size_t)blockIdx.x * 8 + 5] = gt[2];
+    }
+  }
+}
+
+}  // namespace freddy

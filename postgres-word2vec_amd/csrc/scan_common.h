@@ -67,11 +67,16 @@ __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restr
         // cost_mode 1 (filter kernel, LDS-bound): measured model in units of 100 cycles, selection tail +
         // 12 x max(builder phase, gather phase)
         int k = (FUSED_G - cnt) * 4 + (3 - rq);
-        if (cost_mode) {
+        if (cost_mode == 1) {
           const int gp = 4 + (26 * (rq + 1) * ((cnt + 3) >> 2) + 5) / 10;
           const int cost = 50 + 7 * cnt + 12 * (gp > 15 ? gp : 15);   // 237 .. 554
           k = (560 - cost) / 3;
+        } else if (cost_mode == 2) {   // integer-slab scan (fused5.h): 6 double phases, gathers per 8 items, <= 16 items
+          const int gp = 4 + 11 * (rq + 1) * ((cnt + 7) >> 3);
+          const int cost = 50 + 7 * cnt + 6 * (gp > 22 ? gp : 22);   // 189 .. 714
+          k = (720 - cost) / 5;
         }
+        k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
         if (!emit) {
           atomicAdd(&hist[k], 1);
         } else {
