@@ -66,7 +66,7 @@ enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3, KIND_VEC = 4 };
 // for results: every setting gives the same lists.
 struct Tuning {
   int fused = -1;              // FREDDY_GPU_FUSED: -1 auto (cell-grouped scans for >= 256 items), 0 generic kernels, 1 always
-  int scan_kernel = 4;         // FREDDY_GPU_FUSED_KERNEL: 4 filter + refine (fused4.h), 3 exact fused scan (fused3.h)
+  int scan_kernel = 5;         // FREDDY_GPU_FUSED_KERNEL: 5 filter + refine, int16 slabs (fused5.h), 4 the same with fp32 slabs (fused4.h), 3 exact fused scan (fused3.h)
   uint32_t scan_ablate = 0;    // FREDDY_GPU_FUSED_ABLATE: timing experiments / 8 = keep every row (tests)
   uint32_t merge_ablate = 0;   // FREDDY_GPU_MERGE_ABLATE: timing experiments / 32 = refine every row (tests)
   int coarse_approx = 1;       // FREDDY_GPU_COARSE_APPROX: cell selection as filter + refine (coarse.h); 0 = every distance exact

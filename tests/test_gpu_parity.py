@@ -74,11 +74,12 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
     idx.close()
 
 
-@pytest.mark.parametrize("variant", ["3", "4"])
+@pytest.mark.parametrize("variant", ["3", "4", "5"])
 @pytest.mark.parametrize("K", [256, 1024])
 def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
-    """The two cell-grouped scans (FREDDY_GPU_FUSED_KERNEL: 3 = the reference's arithmetic for every row,
-    fused3.h; 4 = default, filter + refine, fused4.h) against the oracle: many queries per cell (entries of
+    """The cell-grouped scans (FREDDY_GPU_FUSED_KERNEL: 3 = the reference's arithmetic for every row,
+    fused3.h; 4 = filter + refine with fp32 slabs, fused4.h; 5 = filter + refine with int16 slabs, fused5.h)
+    against the oracle: many queries per cell (entries of
     every size incl. split cells), both found rules, k up to 32."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     monkeypatch.setenv("FREDDY_GPU_FUSED_KERNEL", variant)
@@ -600,11 +601,11 @@ def test_coarse_filter_refine_adversarial(gpu, oracle, kind, monkeypatch):
     idx.close()
 
 
-def _every_row_check(idx, oracle, ot, qs, k, W, what):
+def _every_row_check(idx, oracle, ot, qs, k, W, what, kernel=5):
     """Every probed row kept by the scan and refined by the merge: the kernel's self-check then compares the
     proven bracket with the reference's distance for ALL of them.  Returns the lists."""
     idx.set_option("fused", 1)
-    idx.set_option("fused_kernel", 4)
+    idx.set_option("fused_kernel", kernel)
     idx.set_option("fused_ablate", 8)
     idx.set_option("merge_ablate", 32)
     before = idx.bound_checked()
@@ -620,18 +621,19 @@ def _every_row_check(idx, oracle, ot, qs, k, W, what):
     return gi, gd
 
 
-def test_filter_refine_bracket_every_row_K1024(gpu, oracle, monkeypatch):
-    """The instantiation the benchmark runs -- ivf_filter_kernel<12, true>, K = 1024 -- in the every-row mode:
-    brackets checked == rows probed, none violated, lists equal to the oracle's, to the exact scan's
-    (fused3.h) and to the normal filter + refine run."""
+@pytest.mark.parametrize("kernel", [4, 5])
+def test_filter_refine_bracket_every_row_K1024(gpu, oracle, kernel, monkeypatch):
+    """The instantiations the benchmark runs -- ivf_filter5_kernel<12, true> / ivf_filter_kernel<12, true>, K = 1024 --
+    in the every-row mode: brackets checked == rows probed, none violated, lists equal to the oracle's, to the exact
+    scan's (fused3.h) and to the normal filter + refine run."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     for scale in (1.0, 1e-12, 8.0):
         t, ot, idx, qs = _fr_setup(gpu, oracle, K=1024, scale=scale)
         qs = qs[:96]
-        gi, gd = _every_row_check(idx, oracle, ot, qs, 5, 3, f"K=1024 every row, scale {scale}")
+        gi, gd = _every_row_check(idx, oracle, ot, qs, 5, 3, f"K=1024 every row, scale {scale}, kernel {kernel}", kernel)
         idx.set_option("fused_kernel", 3)
         ei, ed = idx.search(qs, 5, 3, sentinel=1000.0, found_rule=0)
-        idx.set_option("fused_kernel", 4)
+        idx.set_option("fused_kernel", kernel)
         ni, nd = idx.search(qs, 5, 3, sentinel=1000.0, found_rule=0)
         assert np.array_equal(gi, ei) and np.array_equal(gd.view(np.uint32), ed.view(np.uint32)), "exact scan differs"
         assert np.array_equal(gi, ni) and np.array_equal(gd.view(np.uint32), nd.view(np.uint32)), "normal run differs"
@@ -676,11 +678,14 @@ def test_filter_refine_adversarial_fixed_point(gpu, oracle, kind, monkeypatch):
             p = i % 12
             qs[i, p * 25:(p + 1) * 25] *= np.float32(40.0 if i % 2 else 6.0)
     for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 2, 1, 100.0)):
-        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-        util.assert_same_lists(gi, gd, exp, f"{kind} k={k} W={W} rule={rule}")
+        for kernel in (5, 4):
+            idx.set_option("fused_kernel", kernel)
+            gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+            util.assert_same_lists(gi, gd, exp, f"{kind} kernel={kernel} k={k} W={W} rule={rule}")
     assert idx.bound_violations() == 0
-    _every_row_check(idx, oracle, ot, qs[:40], 5, 2, f"{kind}, every row")
+    for kernel in (5, 4):
+        _every_row_check(idx, oracle, ot, qs[:40], 5, 2, f"{kind}, every row, kernel {kernel}", kernel)
     idx.close()
 
 
@@ -694,7 +699,7 @@ def test_row_order_inside_a_list_is_free(gpu, oracle, arrange, monkeypatch):
     idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     _, qs = util.queries_from_corpus(20000, 150)
     exp = oracle.ivfadc_search_many(ot, qs, 10, 3, sentinel=1000.0, found_rule=0)
-    for fused, variant in ((1, 4), (1, 3), (0, 4)):
+    for fused, variant in ((1, 5), (1, 4), (1, 3), (0, 4)):
         idx.set_option("fused", fused)
         idx.set_option("fused_kernel", variant)
         gi, gd = idx.search(qs, 10, 3, sentinel=1000.0, found_rule=0)
@@ -726,3 +731,33 @@ def test_kmeans_matches_oracle(gpu, oracle):
     cb = gpu.train_pq_codebook(x[:4000], 12, 64, iters=3, seed=4)
     _, codes = gpu.encode(cb, x[:500])
     assert np.array_equal(codes, oracle.encode_pq(cb, x[:500]))
+
+
+def test_searches_on_two_streams_overlap_safely(gpu, oracle):
+    """Two batches in flight on two HIP streams (what bench.py does): every stream gets its own workspace inside
+    the library, so interleaved device-pointer searches give exactly the lists of the same searches run alone."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N = 60000
+    t = util.ivf_tables(N=N, C=64, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qa = util.queries_from_corpus(N, 300)
+    qb = np.ascontiguousarray(qa[::-1] * np.float32(1.01))
+    exp = [oracle.ivfadc_search_many(ot, q, 5, 4, sentinel=1000.0, found_rule=0) for q in (qa, qb)]
+    dq = [torch.from_numpy(q).to(dev) for q in (qa, qb)]
+    res = [torch.zeros((2, 300, 5), dtype=torch.int32, device=dev) for _ in range(2)]
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize(dev)
+    for rounds in range(6):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                res[i].zero_()
+                idx.search_dev(dq[i].data_ptr(), 300, 5, 4, 1000.0, gpu.FOUND_ROWS, res[i][0].data_ptr(), res[i][1].data_ptr(),
+                               st.data_ptr(), streams[i].cuda_stream)
+    torch.cuda.synchronize(dev)
+    for i in (0, 1):
+        util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i}")
+    assert idx.bound_violations() == 0
+    idx.close()
