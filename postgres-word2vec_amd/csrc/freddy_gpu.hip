@@ -391,8 +391,9 @@ static int raise_lds_limits(int device) {
       (const void*)&adc_scan_kernel<0, 2>, (const void*)&adc_scan_kernel<0, 4>, (const void*)&adc_scan_kernel<0, 8>,
       (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
       (const void*)&ivf_spec2_kernel<25, 12, false>, (const void*)&ivf_filter_kernel<12, true>,
-      (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true>,
-      (const void*)&ivf_filter5_kernel<12, false>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
+      (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true, false>,
+      (const void*)&ivf_filter5_kernel<12, false, false>, (const void*)&ivf_filter5_kernel<12, true, true>,
+      (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>};
   for (const void* k : kernels)
@@ -1023,8 +1024,13 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, ix->n_cus - ix->tune.reserve_cus));
   timed_launch(ix, s, "ivf_filter", [&] {
     if (v5) {
-      if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      // (four instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is
+      // larger than the instruction cache as it is)
+      if (fl.cand_count) {
+        if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+        else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
     } else if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
     else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
   });

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
 // phases j = 0 .. M/2 - 1 cover positions 2j and 2j + 1.
 //   LDS: slab[2 buffers][2 positions][K][12] int16 = 96 KB, then colmin / thresholds / records / row terms.
 // ---------------------------------------------------------------------------------------
-template <int M, bool FULLK>
+template <int M, bool FULLK, bool CAND>
 __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
   constexpr int NP = M / 2;             // phases per entry
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         if (j + 3 < NP) issue(set, j + 3, qid);
         else issue(set, j + 3 - NP, nqid);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
         if (j == 2) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
-        if (j == 4) stash_row_terms();
         if (j == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
         if (j == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
         tick(0);
@@ -368,6 +367,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         }
       }
       lds_barrier();   // S1
+      stash_row_terms();   // (the gatherers took the current entry's into registers before their S1 barrier)
       lds_barrier();   // S2
       tick(3);
       pt[7] += 1;
@@ -407,19 +407,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         const int bl = r * NG + gw;
         return (uint32_t)(blk0 + (bl < nblk - 1 ? bl : nblk - 1));
       };
-      // base[r] = the row's own term (staged by the builders during the previous entry, overwritten during this one); +inf for the slots of this wave beyond its last block and for the lanes
-      // past the end of the list (s = +inf: above every finite threshold; S2 skips the former and masks the latter)
-      float base[RMAX];
-      const int last_blk = nrows > 0 ? (nrows - 1) >> 6 : -1;     // chunk-relative block holding the last row
-      const int rs2 = (last_blk >= 0 && (last_blk % NG) == gw && (nrows & 63)) ? last_blk / NG : -1;
-      const bool live_lane = lane < (nrows & 63);
-      {
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          base[r] = rt_s[(r * NG + gw) * 64 + lane];
-          if (r >= rl_wave || (r == rs2 && !live_lane)) base[r] = __uint_as_float(0x7f800000u);
-        }
-      }
       auto main_loop = [&](auto nqc, auto rlc) {
         constexpr int NQ = decltype(nqc)::value, RL = decltype(rlc)::value;
         auto load_codes = [&](uint32_t (&cw)[RMAX], int pair) {
@@ -489,6 +476,19 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       // ---- tail.  The selection works on s' = fma(scale[item], V, rterm[row]) -- the stored sum WITHOUT the item's
       // constant OFF -- compared as floats: a constant shift changes neither the order nor tau' + E.  OFF (which keeps
       // the stored bits positive for the merge) is added for the survivors only: s = s' + OFF.
+      // base[r] = the row's own term (staged by the builders in the previous entry's tail, replaced in this one's after the S1 barrier); +inf for the slots of this wave beyond its last block and for the lanes
+      // past the end of the list (s = +inf: above every finite threshold; S2 skips the former and masks the latter)
+      float base[RMAX];
+      const int last_blk = nrows > 0 ? (nrows - 1) >> 6 : -1;     // chunk-relative block holding the last row
+      const int rs2 = (last_blk >= 0 && (last_blk % NG) == gw && (nrows & 63)) ? last_blk / NG : -1;
+      const bool live_lane = lane < (nrows & 63);
+      {
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          base[r] = rt_s[(r * NG + gw) * 64 + lane];
+          if (r >= rl_wave || (r == rs2 && !live_lane)) base[r] = __uint_as_float(0x7f800000u);
+        }
+      }
       gtick(0);
       auto sval = [&](int g, int r, float sc) -> float {
         const uint32_t w = acc[g >> 1][r];
@@ -504,15 +504,37 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
 #pragma unroll
       for (int r = 0; r < RMAX; ++r)
         if (r < rl_wave && !(r == rs2 && !live_lane)) live8 |= 1u << r;
+      float best[G];
+      uint32_t sec16[G / 2];           // second smallest, rounded DOWN to 16 bits (sign, exponent, 7 bits): two items per register
+      uint32_t apack[2] = {0u, 0u};
+#pragma unroll
+      for (int g = 0; g < G; ++g) best[g] = __uint_as_float(0x7f800000u);
+#pragma unroll
+      for (int i = 0; i < G / 2; ++i) sec16[i] = 0x7f807f80u;
       if (!(a.ablate & 4)) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
+            // the lane's smallest and second smallest s' of this item and the row of the smallest: a lane hardly ever
+            // holds two survivors, so S2 can emit (best, its row) without looking at the sums again
             const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));
-            float best = sval(g, 0, sc);
+            float b1 = __uint_as_float(0x7f800000u), b2 = __uint_as_float(0x7f800000u);
+            uint32_t ar = 0u;
 #pragma unroll
-            for (int r = 1; r < RMAX; ++r) best = fminf(best, sval(g, r, sc));
-            if (rl_wave > 0) atomicMin(colmin + g * 64 + lane, float_key(best));
+            for (int r = 0; r < RMAX; ++r) {
+              const float sv = sval(g, r, sc);
+              b2 = __builtin_amdgcn_fmed3f(b1, b2, sv);   // (b1 <= b2: the median is the new second smallest)
+              ar = sv < b1 ? (uint32_t)r : ar;
+              b1 = fminf(b1, sv);
+            }
+            best[g] = b1;
+            {
+              const uint32_t bb = __float_as_uint(b2);
+              const uint32_t dn = ((bb >> 31) ? bb + 0xffffu : bb) >> 16;   // toward -inf: the test below errs to the slow path
+              sec16[g >> 1] = (g & 1) ? ((sec16[g >> 1] & 0x0000ffffu) | (dn << 16)) : ((sec16[g >> 1] & 0xffff0000u) | dn);
+            }
+            apack[g >> 3] |= ar << (3 * (g & 7));
+            if (rl_wave > 0) atomicMin(colmin + g * 64 + lane, float_key(b1));
           }
         }
       }
@@ -521,8 +543,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       // (S1, the thresholds tau' + E, is computed by the builder waves between these two barriers)
       lds_barrier();
       gtick(-1);
-      // S2: survivors -> this wave's region of each item's buffer.  First the pass bits of the lane's 8 rows, branch
-      // free; the per-row ballots and stores only run for the (item, wave) pairs that have a survivor at all.
+      // S2: survivors -> this wave's region of each item's buffer.  Normally every lane has at most one (its smallest
+      // sum, kept from the pass above); otherwise the pass bits of the lane's 8 rows, branch free, then per-row ballots.
       if (!(a.ablate & 4)) {
         const float p_thr = __uint_as_float(thr_s[gi]);
         const int p_it = rec[8 + gi];
@@ -541,7 +563,22 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
             const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
             u64* dst = a.surv + region * (size_t)(RMAX * 64);
             int run = 0;
-            if (!a.cand_count) {   // the common case (freddy.c:366 counts retrieved rows): nothing but the threshold test
+            if constexpr (!CAND) {   // the common case (freddy.c:366 counts retrieved rows): nothing but the threshold test
+             const float second = __uint_as_float((g & 1) ? (sec16[g >> 1] & 0xffff0000u) : (sec16[g >> 1] << 16));
+             const u64 multi = __ballot(!(second > thr));   // lanes with two survivors (or: keep every row, NaNs)
+             if (__builtin_expect(multi == 0ull, 1)) {
+              const bool pass = !(best[g] > thr);
+              const u64 mask = __ballot(pass);
+              if (mask != 0ull) {
+                if (pass) {
+                  const uint32_t r = (apack[g >> 3] >> (3 * (g & 7))) & 7u;
+                  const float dlo = fmaxf(0.0f, (best[g] + off) - shift);
+                  const uint32_t loc = ((uint32_t)(blk0 + gw) + r * (uint32_t)NG) * 64u + (uint32_t)lane;
+                  dst[lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+                }
+                run = __popcll(mask);
+              }
+             } else {
               uint32_t m8 = 0u;
 #pragma unroll
               for (int r = RMAX - 1; r >= 0; --r) m8 = m8 + m8 + (!(sval(g, r, sc) > thr) ? 1u : 0u);   // (a NaN passes: exact stage)
@@ -561,6 +598,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
                   }
                 }
               }
+             }
             } else {   // rows below the sentinel are counted (freddy.c:971): bounds on the bits of s = s' + OFF > 0
               const uint32_t lo_b = (uint32_t)__builtin_amdgcn_readlane((int)p_lo, g);
               const uint32_t hi_b = (uint32_t)__builtin_amdgcn_readlane((int)p_hi, g);

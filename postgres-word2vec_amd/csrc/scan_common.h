@@ -72,9 +72,11 @@ __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restr
           const int cost = 50 + 7 * cnt + 12 * (gp > 15 ? gp : 15);   // 237 .. 554
           k = (560 - cost) / 3;
         } else if (cost_mode == 2) {   // integer-slab scan (fused5.h): 6 double phases, gathers per 8 items, <= 16 items
-          const int gp = 4 + 11 * (rq + 1) * ((cnt + 7) >> 3);
-          const int cost = 50 + 7 * cnt + 6 * (gp > 22 ? gp : 22);   // 189 .. 714
-          k = (720 - cost) / 5;
+          // measured (units of 100 cycles): tail 15 + 11 per item; a double phase = max(builders 25, gathers 4 + 6.5 per
+          // (quarter of a full chunk, 8 items))
+          const int gp = 4 + (13 * (rq + 1) * ((cnt + 7) >> 3)) / 2;
+          const int cost = 15 + 11 * cnt + 6 * (gp > 25 ? gp : 25);   // 176 .. 527
+          k = (530 - cost) / 3;
         }
         k = k < 0 ? 0 : (k > NB - 1 ? NB - 1 : k);
         if (!emit) {
