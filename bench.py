@@ -280,6 +280,14 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         barrier()
         prof = index.profile_read()
         index.profile_enable(False)
+        prof_ov = {}
+        if n_fl > 1:   # ... and with the batches in flight as in the timed region: durations under overlap
+            index.profile_enable(True)
+            for _ in range(a.steps):
+                step()
+            barrier()
+            prof_ov = index.profile_read()
+            index.profile_enable(False)
         step1()
         barrier()
         res_last, _ = pg.last()
@@ -311,10 +319,12 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         roof = None
         if dom:
             avg_s = prof[dom][1] / max(prof[dom][0], 1) / 1e3
-            kname = {"ivf_filter": "ivf_filter_kernel", "ivf_exact_scan": "ivf_spec2_kernel", "adc_scan": "adc_scan_kernel",
+            scan_variant = os.environ.get("FREDDY_GPU_FUSED_KERNEL", "5")
+            kname = {"ivf_filter": "ivf_filter5_kernel" if scan_variant == "5" else "ivf_filter_kernel", "ivf_exact_scan": "ivf_spec2_kernel", "adc_scan": "adc_scan_kernel",
                      "lut_build": "lut_build_kernel", "coarse_dist": "coarse_tile_kernel",
                      "probe_plan": "probe_plan_kernel"}.get(dom, dom)
-            lds_bytes = scanned_rows * a.m * 4   # one 4-byte table value per (query, probed row, position)
+            slab_b = 2 if scan_variant == "5" else 4
+            lds_bytes = scanned_rows * a.m * slab_b   # one table value per (query, probed row, position): int16 (fused5.h) / fp32
             lds = lds_bytes / avg_s / 1e9
             pq_ach = per_query_bytes / avg_s / 1e9
             ceiling_qps = HBM_PEAK_GBS * 1e9 / (per_query_bytes / q_local)
@@ -326,8 +336,10 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                 pmc_traffic(kname),
                 {"lds_gather": {"achieved": round(lds, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBS, 5),
                                 "bytes_per_launch": int(lds_bytes),
-                                "note": "the resource that binds this kernel: 4 B of slab per (query, probed row, position) "
-                                        "gathered from LDS at random 48-byte rows (~3-way bank conflicts, DESIGN.md 5.3b)"},
+                                "note": f"the resource that binds this kernel's main loop: {slab_b} B of slab per (query, probed row, "
+                                        "position) gathered from LDS with one 16-byte read per 8 items at random rows (~1.9 "
+                                        "conflict passes per read after the pin-time row arrangement; the cost is per access, "
+                                        "not per byte: DESIGN.md 5.3c)"},
                  "per_query_model": {"bytes_per_launch": int(per_query_bytes), "achieved": round(pq_ach, 1), "unit": "GB/s",
                                      "note": "SURVEY 8d's per-QUERY bytes (every probed row once per query) / kernel time: an "
                                              "equivalent rate, not traffic -- the kernel reads a list once per work entry",
@@ -394,7 +406,9 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             "host_buffer_abi": {"queries_per_s": round(host_qps, 1), "same_results_as_device_path": host_same,
                                 "note": "freddy_gpu_ivfadc_search: H2D of the queries, D2H of the results, one stream sync, "
                                         "extra probing rounds for stragglers -- per call"},
-            "roofline": roof, "kernels": kern, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": kern,
+            "kernels_overlapped": {n: {"launches": l, "avg_us": round(1e3 * ms / max(l, 1), 2)} for n, (l, ms) in prof_ov.items()},
+            "cpu_baseline": cpu,
         }
     return out
 

@@ -875,13 +875,9 @@ static int ivf_coarse(IvfRun& r) {
       HIP_TRY(hipStreamWaitEvent(ws->stream2, ws->ev_q, 0));
     }
     if (r.scan_kernel == 5) {
-      timed_launch(ix, sq, "query_scale", [&] {
-        hipLaunchKernelGGL((query_scale5_kernel<25>), dim3(Q), dim3(64), 0, sq, r.d_q, ix->cmaxp, ws->w_qn.as<float>(),
-                           ws->w_qn.as<float>() + (size_t)Q * m, Q, d, m);
-      });
       timed_launch(ix, sq, "query_codebook", [&] {
-        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT,
-                           ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
+        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
+                           ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
       });
     } else
     timed_launch(ix, sq, "query_codebook", [&] {

@@ -61,31 +61,17 @@ __device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, x) + __builtin_bit_cast(s2v, y));
 }
 
-// qn[q][p] = |q_p| (rounded up) and the query's ONE table scale: max_p 2 |q_p| max|c_p| / 2730.  One wave per query.
-template <int S>
-__global__ __launch_bounds__(64) void query_scale5_kernel(const float* __restrict__ queries, const float* __restrict__ cmax,
-                                                         float* __restrict__ qn, float* __restrict__ qscale, int Q, int d, int m) {
-  const int q = blockIdx.x, lane = threadIdx.x;
-  if (q >= Q) return;
-  float best = 0.0f;
-  if (lane < m) {
-    float n2 = 0.0f;
-    for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + lane * S + j]; n2 = __builtin_fmaf(v, v, n2); }
-    const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
-    qn[(size_t)q * m + lane] = nrm;
-    best = 2.0f * nrm * cmax[lane];
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
-  if (lane == 0) qscale[q] = best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
-}
-
-// The table itself: as query_codebook_kernel (whole 2 KB rows through an LDS transpose), values
-// rint(-2 q_p . c / scale[q]) clamped to +-2730.
+// The table: as query_codebook_kernel (whole 2 KB rows through an LDS transpose), values rint(-2 q_p . c / scale[q])
+// clamped to +-2730, scale[q] = max_p 2 |q_p| max|c_p| / 2730 -- ONE per query.  Every workgroup (position p, 16
+// queries) derives the scales of its queries itself (16 lanes per query, lane <-> position: the same fmaf chain and
+// the same maximum in every workgroup); the workgroups of position 0 also write qn[q][p] = |q_p| (rounded up) and
+// scale[q] for the record and merge kernels.
 template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
-                                                             const float* __restrict__ qscale, uint32_t* __restrict__ qc,
+                                                             const float* __restrict__ cmax, float* __restrict__ qn,
+                                                             float* __restrict__ qscale, uint32_t* __restrict__ qc,
                                                              int Q, int d, int m, int K) {
+  static_assert(QT == 16, "one 16-lane group per query");
   constexpr int SP = (S + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float qs[QT][SP];
   __shared__ float inv_s[QT];
@@ -95,9 +81,23 @@ __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __res
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
   }
-  if (tid < QT) {
-    const float sc = q0 + tid < Q ? qscale[q0 + tid] : 0.0f;
-    inv_s[tid] = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
+  {
+    const int qi = tid >> 4, pp = tid & 15, q = q0 + qi;
+    float best = 0.0f;
+    if (pp < m && q < Q) {
+      float n2 = 0.0f;
+      for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + pp * S + j]; n2 = __builtin_fmaf(v, v, n2); }
+      const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+      if (p == 0) qn[(size_t)q * m + pp] = nrm;
+      best = 2.0f * nrm * cmax[pp];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (pp == 0) {
+      const float sc = q < Q ? best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f) : 0.0f;
+      inv_s[qi] = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
+      if (p == 0 && q < Q) qscale[q] = sc;
+    }
   }
   typedef float v2f __attribute__((ext_vector_type(2)));
   v2f cb[2][S];

@@ -7,7 +7,10 @@ set -u
 TAG=${1:-rXX}; shift || true
 export TMPDIR=/tmp
 T=/tmp/prof_$TAG; rm -rf $T; mkdir -p $T gpurun_out/prof
-B="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall $*"
+# (--in-flight 1: one batch at a time, so that a kernel's duration in the trace is the kernel alone -- what bench.py's
+#  instrumented re-run and its roofline object report; the default command's overlapped timeline is the last pass)
+B="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall --in-flight 1 $*"
+B2="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -o r -- $B > gpurun_out/prof/${TAG}_bench_under_trace.json 2> $T/trace.err
 python3 tools/prof_summary.py stats $T/trace gpurun_out/prof/${TAG}_kernel_stats.txt > /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/fetch -o r -- $B > /dev/null 2> $T/fetch.err
@@ -28,4 +31,7 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
 json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(out))
 PY
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace2 -o r -- $B2 > gpurun_out/prof/${TAG}_bench_under_trace_inflight2.json 2> $T/trace2.err
+python3 tools/prof_summary.py stats $T/trace2 gpurun_out/prof/${TAG}_kernel_stats_inflight2.txt > /dev/null
+python3 tools/timeline.py $T/trace2 700 2>/dev/null | head -330 | tail -60 > gpurun_out/prof/${TAG}_timeline_inflight2.txt
 cat gpurun_out/prof/${TAG}_kernel_stats.txt
