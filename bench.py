@@ -60,7 +60,7 @@ def parse(argv=None):
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="batches in flight per GPU (config ivfadc): consecutive steps alternate between this many HIP streams, "
                          "so the front end of batch i+1 runs beside the merge of batch i; 1 = strictly one batch at a time")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
@@ -245,7 +245,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     # Consecutive steps alternate between `in_flight` streams (each with its own result buffer and, inside the
     # library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of two
     # batches -- merge of batch i, cell selection of batch i+1 -- overlap.  --in-flight 1 is the strict sequence.
-    n_fl = max(1, min(a.in_flight, 3))
+    n_fl = max(1, min(a.in_flight, 4))
     streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
     with torch.cuda.stream(streams[0]):
         pg = shard.PipelinedGather(q_local, a.k, dev, depth=max(2, n_fl))
