@@ -45,8 +45,8 @@ METRIC = "batched IVFADC kNN queries/sec (k=5) + recall@5, 3Mx300d"
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", default="ivfadc", choices=["ivfadc", "pq", "join"],
                     help="ivfadc = BASELINE configs[2] (the metric's), pq = configs[1], join = configs[3]")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],

@@ -222,7 +222,14 @@ int freddy_gpu_update_codebook(freddy_gpu_index_t* index, const float* codebook 
  * library's own stream) without synchronising.  d_status[0] is set non-zero by the
  * device if some query needs a further probing round (rare: its first W cells hold
  * fewer than k rows); such queries keep partial results and the caller should re-run
- * them through freddy_gpu_ivfadc_search.  Single round only. */
+ * them through freddy_gpu_ivfadc_search.  Single round only.
+ *
+ * Concurrency: everything a search writes besides its outputs lives in a workspace that belongs to the stream
+ * the search is enqueued on (up to four streams per handle; a fifth takes over a slot after its owner has
+ * drained).  Searches enqueued on DIFFERENT streams may therefore be in flight together on one handle --
+ * bench.py keeps three batches going that way, the front end of batch i+1 beside the merge of batch i --;
+ * searches on the same stream are ordered by it.  Calls from several host threads must not share a stream.
+ * The synchronous calls above use the library's own stream.  freddy_gpu_last_* report on the most recent call. */
 int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ivf, const float* d_queries, int32_t Q,
                                  int32_t k, int32_t W, float sentinel, int32_t found_rule,
                                  int32_t* d_out_ids, float* d_out_dist, int32_t* d_status,
@@ -253,9 +260,9 @@ typedef struct freddy_track {
 int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
 
 /* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
- * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (4 filter +
- * refine, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
- * row, used by the tests' exhaustive bound check), "side_stream", "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
+ * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (5 filter +
+ * refine with int16 slabs, 4 the same with fp32 slabs, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
+ * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
  * "coarse_refine_all", "fused_prof", "debug_surv",
  * "lut_budget_mb".  No setting changes a result. */
 int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);

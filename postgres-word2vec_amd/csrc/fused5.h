@@ -1,35 +1,40 @@
-// fused5.h -- the filter + refine scan of fused4.h with INTEGER slabs: half the LDS traffic, half the phases.
+// fused5.h -- the filter + refine scan of fused4.h with INTEGER slabs: one LDS access serves eight items, six
+// phases instead of twelve.  (DESIGN.md 5.3c has the measurements.)
 //
 // What bounds ivf_filter_kernel (fused4.h) in its main loop is the LDS pipe: per position 48 KB of fp32 slab are
-// written (48 wave-level ds_write_b128 at ~13 cycles) and gathered (8 waves x 8 rows x 3 ds_read_b128 at ~7.8
-// cycles under ~40 % bank conflicts), 87 % of the phase (rocprofv3 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT),
-// with a workgroup barrier per position.  Here a slab entry is the table's own 16-bit integer:
+// written (48 wave-level ds_write_b128) and gathered (8 waves x 8 rows x <= 3 ds_read_b128, a third of the read
+// cycles being bank conflicts), 87 % of the phase (rocprofv3 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT) -- and the
+// cost of a gather is per ACCESS, not per byte (tools/ubench6.hip).  Here a slab entry is the table's own 16-bit
+// integer:
 //
 //   * the query x codebook table is quantised with ONE scale per query (not per (query, position)) to
 //     |v| <= 2730, so that the sum over the 12 positions fits 16 bits and is EXACT: the gatherers add rows
-//     with v_pk_add_i16 (two items per instruction, as v_pk_add_f32 did) and a (row, item) sum is one 16-bit
-//     half of a register -- 48 sum registers instead of 96;
-//   * a slab row is 12 items x 2 B = 24 B: three ds_read_b64 per row and position instead of three
-//     ds_read_b128, half the bytes written by the builders, who only interleave the items' table words
-//     (v_perm_b32) -- no conversion, no multiplication;
-//   * two positions fit one buffer (2 x 24 KB): SIX phases -- barriers -- per entry instead of twelve, and the
+//     with v_pk_add_u16 and a (row, item) sum is one 16-bit half of a register -- 64 sum registers for
+//     16 items x 8 rows;
+//   * a slab row is 16 items x 2 B = 32 B = two 16-byte halves of 8 items: ONE ds_read_b128 per (row, position)
+//     for an entry of <= 8 items, two for 9..16 (fp32: one per 4 items).  Half h of row c sits at byte
+//     32 c + 16 (h ^ bit 3 of c), so that first halves do not all share 8 of the 16 bank groups; the builders only
+//     interleave the items' table words (v_perm_b32) -- no conversion, no multiplication;
+//   * two positions fit one buffer (2 x 32 KB): SIX phases -- barriers -- per entry instead of twelve, and the
 //     rows' code dword of a phase is exactly the two codes it needs;
-//   * the floating-point value s = (OFF[item] + rterm[row]) + scale[item] * V is formed once per (row, item) in the
-//     tail (one conversion + one fma), where the selection needs its bits.
+//   * work entries hold up to 16 items (scan_common.h work_table_kernel, cost_mode 2);
+//   * the floating-point value s' = fma(scale[item], V, rterm[row]) is formed in the tail, where the selection
+//     needs it -- WITHOUT the item's constant OFF: the selection compares floats (a constant shift changes neither
+//     the order nor tau' + E); OFF is added for the survivors only (s = s' + OFF > 0, the bits the merge expects).
 //
 // The bound (u = 2^-24, B and the reference's error as in fused4.h; D exact, d the reference's binary32 value):
 //   reference                                   |d - D|        <= 39 u B
 //   rterm (fp64, rounded once)                                  <=  1 u B
-//   per position: dot product (fmaf chain of 25)  25 u 2|q_p||c| ; quotient and rint: <= 0.5 scale (+ 2 u 2|q_p||c|)
+//   per position: dot product (fmaf chain of 25) and quotient  <= 28 u 2|q_p||c| ; rint: <= 0.5 scale
 //                 no clamping: 2 |q_p| max|c_p| <= 2730 scale by construction
-//       summed over 12 positions                                <= 27 u B + 6 scale
+//       summed over 12 positions                                <= 28 u B + 6 scale
 //   the sum V itself: exact (integers below 2^15)
-//   s = fma(scale, V, OFF + rterm) (OFF the item's own, as in fused4.h): two roundings of values <= 3 B + E      <=  7 u B
+//   s' = fma(scale, V, rterm), s = s' + OFF: two roundings of values <= 3 B + E      <=  7 u B
 //   residual's own rounding (as fused4.h)                                    <=  2 u B
-//   =>  |(s - OFF + |r|^2) - d| <= e = 76 u B + 6 scale;  the construction needs e <= E / 4.2:
+//   =>  |(s - OFF + |r|^2) - d| <= e = 77 u B + 6 scale;  the construction needs e <= E / 4.2:
 //   E = 512 u B + 28 scale   (typical: 2.0e-3 against 1.2e-3 of fused4.h -- 13.7 instead of 11.8 survivors per item).
-// Everything downstream (thresholds tau + E, survivor regions, merge_refine_kernel with the same E, the self-check
-// of the bracket on every refined row) is fused4.h's.
+// Everything downstream (survivor regions, merge_refine_kernel with the same E, the self-check of the bracket on
+// every refined row) is fused4.h's.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -39,7 +44,6 @@
 namespace freddy {
 
 // (FILT5_VMAX, filter_width5: fused4.h, next to the merge that shares them)
-
 static constexpr int SCAN5_G = 16;   // items per work entry
 
 // order-preserving 32-bit key of a float (NaNs sort above +inf or below -inf: only met with non-finite inputs)
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
   constexpr int NP = M / 2;             // phases per entry
   constexpr int ROWB = G * 2;           // bytes of a slab row: two 16-byte halves of 8 items
-  static_assert(M % 4 == 0 && G == 16 && SPEC2_NB == 8, "layout");
+  static_assert(M == 12 && G == 16 && SPEC2_NB == 8, "layout");
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -416,25 +420,36 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         // both positions of a phase, one row at a time: NQ ds_read_b128 per position fetch the values of 8 items each.
         // Half h of row c sits at byte 32 c + 16 (h ^ bit 3 of c): with the plain layout the first halves of all rows
         // would share 8 of the 16 bank groups.
+        // Software pipelined: the reads of row r + 1 are issued before the sums of row r -- with one row's 2 NQ reads in
+        // flight per wave the LDS pipe idled while the waves added (a closed loop: 8 waves x 4 reads, ~15 cycles of
+        // service each, then ~100 cycles of adds before the next batch).
         auto gather = [&](const uint32_t (&cw)[RMAX], int j) {
           const unsigned char* bufp = slab + (uint32_t)(j & 1) * BUFB;
-#pragma unroll
-          for (int r = 0; r < RL; ++r) {
+          constexpr int DEPTH = NQ == 1 ? 4 : 2;   // rows in flight (32 registers either way; 3 rows of two halves spill)
+          u4 va[DEPTH][2][NQ];   // [row slot][position of the phase][half]
+          auto issue_row = [&](int r) {
             const uint32_t c0 = cw[r] & 0xffffu, c1 = cw[r] >> 16;
             const uint32_t a0 = c0 * (uint32_t)ROWB + ((c0 & 8u) << 1);
             const uint32_t a1 = c1 * (uint32_t)ROWB + ((c1 & 8u) << 1) + POSB;
-            u4 v0[NQ], v1[NQ];
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v0[q] = *reinterpret_cast<const u4*>(bufp + (a0 ^ (uint32_t)(q * 16)));
+            for (int q = 0; q < NQ; ++q) va[r % DEPTH][0][q] = *reinterpret_cast<const u4*>(bufp + (a0 ^ (uint32_t)(q * 16)));
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) v1[q] = *reinterpret_cast<const u4*>(bufp + (a1 ^ (uint32_t)(q * 16)));
+            for (int q = 0; q < NQ; ++q) va[r % DEPTH][1][q] = *reinterpret_cast<const u4*>(bufp + (a1 ^ (uint32_t)(q * 16)));
+          };
+#pragma unroll
+          for (int r = 0; r < DEPTH - 1; ++r) if (r < RL) issue_row(r);
+#pragma unroll
+          for (int r = 0; r < RL; ++r) {
+            if (r + DEPTH - 1 < RL) issue_row(r + DEPTH - 1);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-              acc[q * 4 + 0][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 0][r], v0[q].x), v1[q].x);
-              acc[q * 4 + 1][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 1][r], v0[q].y), v1[q].y);
-              acc[q * 4 + 2][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 2][r], v0[q].z), v1[q].z);
-              acc[q * 4 + 3][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 3][r], v0[q].w), v1[q].w);
+              const u4 x = va[r % DEPTH][0][q], y = va[r % DEPTH][1][q];
+              acc[q * 4 + 0][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 0][r], x.x), y.x);
+              acc[q * 4 + 1][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 1][r], x.y), y.y);
+              acc[q * 4 + 2][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 2][r], x.z), y.z);
+              acc[q * 4 + 3][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 3][r], x.w), y.w);
             }
+            if (r + 1 < RL) __builtin_amdgcn_sched_barrier(0);
           }
         };
 #pragma unroll

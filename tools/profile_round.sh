@@ -31,7 +31,7 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
 json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(out))
 PY
-rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace2 -o r -- $B2 > gpurun_out/prof/${TAG}_bench_under_trace_inflight2.json 2> $T/trace2.err
-python3 tools/prof_summary.py stats $T/trace2 gpurun_out/prof/${TAG}_kernel_stats_inflight2.txt > /dev/null
-python3 tools/timeline.py $T/trace2 700 2>/dev/null | head -330 | tail -60 > gpurun_out/prof/${TAG}_timeline_inflight2.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace2 -o r -- $B2 > gpurun_out/prof/${TAG}_bench_under_trace_in_flight.json 2> $T/trace2.err
+python3 tools/prof_summary.py stats $T/trace2 gpurun_out/prof/${TAG}_kernel_stats_in_flight.txt > /dev/null
+python3 tools/timeline.py $T/trace2 60 --overlapped > gpurun_out/prof/${TAG}_timeline_in_flight.txt 2>/dev/null
 cat gpurun_out/prof/${TAG}_kernel_stats.txt
