@@ -31,6 +31,12 @@ import subprocess
 import sys
 import time
 
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the
+# runtime starts.  The batches in flight want a queue each, beside the queues the default stream, the library's
+# own streams and RCCL take; measured (tools/sweep_queues.sh): 4 queues / 3 batches 7.5 M q/s,
+# 6 queues / 4 batches 7.9 M, 8 queues 6.3-6.8 M (queues start sharing the four pipes of the command processor).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+
 import numpy as np
 import torch
 
@@ -60,7 +66,8 @@ def parse(argv=None):
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--stream-skip", type=int, default=0, help="experiment: create this many unused streams first")
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU (config ivfadc): consecutive steps alternate between this many HIP streams, "
                          "so the front end of batch i+1 runs beside the merge of batch i; 1 = strictly one batch at a time")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
@@ -245,7 +252,8 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     # Consecutive steps alternate between `in_flight` streams (each with its own result buffer and, inside the
     # library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of two
     # batches -- merge of batch i, cell selection of batch i+1 -- overlap.  --in-flight 1 is the strict sequence.
-    n_fl = max(1, min(a.in_flight, 4))
+    n_fl = max(1, min(a.in_flight, 8))
+    _skipped = [torch.cuda.Stream(dev) for _ in range(a.stream_skip)]   # (tools/sweep_queues.sh: shifts the streams' hardware queues)
     streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
     with torch.cuda.stream(streams[0]):
         pg = shard.PipelinedGather(q_local, a.k, dev, depth=max(2, n_fl))

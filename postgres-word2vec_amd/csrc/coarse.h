@@ -189,7 +189,7 @@ __device__ __forceinline__ uint32_t float_order_bits(float f) {   // monotone ma
 }
 
 template <int ABL>   // 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
-__global__ __launch_bounds__(64 * PLAN2_NW) void probe_plan2_kernel(Plan2Args g) {
+__global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args g) {   // (<= 128 registers: four workgroups per CU, what the LDS admits)
   const PlanArgs& a = g.p;
   constexpr int NW = PLAN2_NW, NCB = PLAN2_NCB, RC = NW * NCB;   // RC candidates per round
   constexpr int NV = COARSE_MAX_CPAD / 64 / NW;                  // cells per lane
@@ -354,13 +354,14 @@ __global__ __launch_bounds__(64 * PLAN2_NW) void probe_plan2_kernel(Plan2Args g)
           float acc = 0.0f;
           const float* row = sq + lane * PLAN2_PITCH;
           int e = 0;
-          // (25 LDS reads in flight per block: a read per step would expose its latency 75 times)
-          for (; e + 100 <= d; e += 100) {
-            float4 v[25];
+          // (15 LDS reads in flight per block: a read per step would expose its latency 75 times; 25 per block cost
+          // the kernel 171 registers, i.e. two resident workgroups per CU instead of four)
+          for (; e + 60 <= d; e += 60) {
+            float4 v[15];
 #pragma unroll
-            for (int t = 0; t < 25; ++t) v[t] = *reinterpret_cast<const float4*>(row + e + 4 * t);
+            for (int t = 0; t < 15; ++t) v[t] = *reinterpret_cast<const float4*>(row + e + 4 * t);
 #pragma unroll
-            for (int t = 0; t < 25; ++t) { acc = acc + v[t].x; acc = acc + v[t].y; acc = acc + v[t].z; acc = acc + v[t].w; }
+            for (int t = 0; t < 15; ++t) { acc = acc + v[t].x; acc = acc + v[t].y; acc = acc + v[t].z; acc = acc + v[t].w; }
           }
           for (; e < d; ++e) acc = acc + row[e];
           cdist[r0 + lane] = acc;

@@ -74,6 +74,8 @@ struct Tuning {
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
+  int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
+                               // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
@@ -92,6 +94,7 @@ static Tuning read_tuning() {
   t.merge_ablate = (uint32_t)env_int("FREDDY_GPU_MERGE_ABLATE", 0);
   t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
   t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
+  t.partition_cus = (int)env_int("FREDDY_GPU_PARTITION_CUS", t.partition_cus);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -126,13 +129,26 @@ struct Workspace {
   hipStream_t owner = nullptr;
   hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
   hipEvent_t ev_q = nullptr, ev_qc = nullptr;
+  // CU-partitioned mode (Tuning::partition_cus): the batch's small kernels on a stream masked to the reserved CUs, its
+  // scan on a stream masked to the rest; events chain caller stream -> fe -> scan -> fe -> caller stream
+  hipStream_t fe_stream = nullptr, scan_stream = nullptr;
+  int part_cus = 0;                // the R the two streams were created for
+  hipEvent_t ev_in = nullptr, ev_fe = nullptr, ev_scan = nullptr, ev_out = nullptr;
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
       w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist;
+  void release_partition() {
+    if (fe_stream) { (void)hipStreamSynchronize(fe_stream); (void)hipStreamDestroy(fe_stream); fe_stream = nullptr; }
+    if (scan_stream) { (void)hipStreamSynchronize(scan_stream); (void)hipStreamDestroy(scan_stream); scan_stream = nullptr; }
+    for (hipEvent_t* e : {&ev_in, &ev_fe, &ev_scan, &ev_out})
+      if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    part_cus = 0;
+  }
   void release() {
     if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); stream2 = nullptr; }
     if (ev_q) { (void)hipEventDestroy(ev_q); ev_q = nullptr; }
     if (ev_qc) { (void)hipEventDestroy(ev_qc); ev_qc = nullptr; }
+    release_partition();
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
@@ -142,7 +158,7 @@ struct Workspace {
     owner = nullptr;
   }
 };
-static constexpr int FREDDY_MAX_WS = 4;
+static constexpr int FREDDY_MAX_WS = 8;
 
 struct ProfRec {
   int64_t launches = 0;
@@ -224,6 +240,8 @@ static Workspace* workspace_for(freddy_gpu_index* ix, hipStream_t s) {
   Workspace& w = ix->ws[FREDDY_MAX_WS - 1];
   (void)hipStreamSynchronize(w.owner);
   if (w.stream2) (void)hipStreamSynchronize(w.stream2);
+  if (w.fe_stream) (void)hipStreamSynchronize(w.fe_stream);
+  if (w.scan_stream) (void)hipStreamSynchronize(w.scan_stream);
   w.owner = s;
   ix->last_ws = &w;
   return &w;
@@ -698,6 +716,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "merge_ablate") t.merge_ablate = (uint32_t)value;
   else if (n == "side_stream") t.side_stream = (int)value;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
+  else if (n == "partition_cus") t.partition_cus = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -792,7 +811,8 @@ static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, co
 struct IvfRun {
   freddy_gpu_index* ix;
   Workspace* ws;
-  hipStream_t s;
+  hipStream_t s;       // the stream the small kernels are enqueued on (the caller's, or the workspace's masked fe stream)
+  hipStream_t s_scan;  // the stream of the scan kernel (== s unless the CUs are partitioned)
   const float* d_q;
   int Q, k, W, L, found_rule, upi;
   float sentinel, cell_limit;
@@ -868,7 +888,7 @@ static int ivf_coarse(IvfRun& r) {
     // workspace ends up sharing an in-order queue with another batch's main stream -- measured: no overlap at all)
     int n_ws = 0;
     for (const Workspace& w : ix->ws) n_ws += w.used ? 1 : 0;
-    const bool side = ix->tune.side_stream != 0 && n_ws == 1;
+    const bool side = ix->tune.side_stream != 0 && n_ws == 1 && r.s_scan == r.s;
     hipStream_t sq = side ? ws->stream2 : s;
     if (side) {
       HIP_TRY(hipEventRecord(ws->ev_q, s));
@@ -1017,21 +1037,32 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
   fl.desc_offset = (uint32_t)desc_off;
   // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
-  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, ix->n_cus - ix->tune.reserve_cus));
-  timed_launch(ix, s, "ivf_filter", [&] {
+  const bool parted = r.s_scan != s;
+  const int scan_cus = parted ? ix->n_cus - ws->part_cus : ix->n_cus - ix->tune.reserve_cus;
+  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
+  hipStream_t ss = r.s_scan;
+  if (parted) {   // records (and everything before them) -> scan, on the stream masked to the scan's CUs
+    HIP_TRY(hipEventRecord(ws->ev_fe, s));
+    HIP_TRY(hipStreamWaitEvent(ss, ws->ev_fe, 0));
+  }
+  timed_launch(ix, ss, "ivf_filter", [&] {
     if (v5) {
       // (four instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is
       // larger than the instruction cache as it is)
       if (fl.cand_count) {
-        if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-        else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-      } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-    } else if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
-    else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+        if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+        else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+    } else if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+    else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
   });
   HIP_TRY(hipGetLastError());
-  if (fl.prof) if (int rc = scan_prof_print(ix, s, fl.prof, n_persist)) return rc;
+  if (parted) {
+    HIP_TRY(hipEventRecord(ws->ev_scan, ss));
+    HIP_TRY(hipStreamWaitEvent(s, ws->ev_scan, 0));
+  }
+  if (fl.prof) if (int rc = scan_prof_print(ix, ss, fl.prof, n_persist)) return rc;
 
   MergeRefineArgs mr;
   mr.surv = fl.surv; mr.surv_count = fl.surv_count; mr.active = r.active; mr.round_rows = pa.round_rows;
@@ -1136,6 +1167,24 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   return launch_merge(ix, s, ma);
 }
 
+// The workspace's two CU-masked streams.  Bit b of a mask is CU (b / 8) of XCD (b % 8) on this chip (tools/ubench_cumask:
+// bits 0..31 = 4 CUs of every XCD; a mask that leaves an XCD without CUs is ignored by the driver), so the reserved
+// partition is bits [0, R) and the scan's is [R, n_cus), R a multiple of 8.
+static int partition_streams(freddy_gpu_index* ix, Workspace* ws) {
+  int R = ix->tune.partition_cus < 0 ? -ix->tune.partition_cus : ix->tune.partition_cus;
+  R = std::max(8, std::min(R, ix->n_cus - 8)) & ~7;
+  if (ws->fe_stream && ws->part_cus == R) return 0;
+  ws->release_partition();
+  const int words = (ix->n_cus + 31) / 32;
+  std::vector<uint32_t> fe((size_t)words, 0u), sc((size_t)words, 0u);
+  for (int b = 0; b < ix->n_cus; ++b) (b < R ? fe : sc)[(size_t)b >> 5] |= 1u << (b & 31);
+  HIP_TRY(hipExtStreamCreateWithCUMask(&ws->fe_stream, (uint32_t)words, fe.data()));
+  HIP_TRY(hipExtStreamCreateWithCUMask(&ws->scan_stream, (uint32_t)words, sc.data()));
+  for (hipEvent_t* e : {&ws->ev_in, &ws->ev_fe, &ws->ev_scan, &ws->ev_out}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+  ws->part_cus = R;
+  return 0;
+}
+
 // One chunk of queries (device pointers).  sync_rounds: run the extra rounds of the reference's
 // "while (foundInstances < k)" loop with a host sync per round; otherwise only round one is enqueued and
 // d_status reports stragglers.
@@ -1164,6 +1213,26 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   r.tiled = Q >= 32;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
+  // CU partition: only for the filter + refine scan, whose persistent workgroups take whole CUs
+  hipStream_t s_caller = s;
+  r.s_scan = s;
+  if (ix->tune.partition_cus != 0 && r.fused && r.scan_kernel >= 4) {
+    if (int rc = partition_streams(ix, ws)) return rc;
+    if (ix->tune.partition_cus > 0) {
+      HIP_TRY(hipEventRecord(ws->ev_in, s_caller));
+      HIP_TRY(hipStreamWaitEvent(ws->fe_stream, ws->ev_in, 0));
+      r.s = s = ws->fe_stream;
+    }
+    // (negative: only the scan is masked -- the R CUs it never takes stay open to the small kernels of every stream)
+    r.s_scan = ws->scan_stream;
+  }
+  // (the caller's stream continues after everything enqueued on the internal streams)
+  auto rejoin = [&]() -> int {
+    if (s == s_caller) return 0;
+    HIP_TRY(hipEventRecord(ws->ev_out, s));
+    HIP_TRY(hipStreamWaitEvent(s_caller, ws->ev_out, 0));
+    return 0;
+  };
   const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
   if (ws->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ws->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
@@ -1214,7 +1283,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     r.next = (r.next == ws->w_act0.as<int32_t>()) ? ws->w_act1.as<int32_t>() : ws->w_act0.as<int32_t>();
     r.n_active = n_next;
   }
-  return 0;
+  return rejoin();
 }
 
 static int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q, int k, const void* oi,

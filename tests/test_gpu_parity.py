@@ -761,3 +761,39 @@ def test_searches_on_two_streams_overlap_safely(gpu, oracle):
         util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i}")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+@pytest.mark.parametrize("partition", [32, -16])
+def test_cu_partitioned_streams_give_the_same_lists(gpu, oracle, partition):
+    """Option partition_cus: the small kernels of a batch on a stream masked to R CUs and the scan on
+    a stream masked to the rest (R > 0), or only the scan masked (R < 0), chained by events to the caller's stream.
+    Five batches in flight on five streams (more than the runtime's four default hardware queues), host-buffer call
+    afterwards on the same handle: the lists are the oracle's in every mode."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N = 60000
+    t = util.ivf_tables(N=N, C=64, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx.set_option("partition_cus", partition)
+    _, qa = util.queries_from_corpus(N, 300)
+    qs = [np.ascontiguousarray(np.roll(qa, 7 * i, axis=0) * np.float32(1.0 + 0.01 * i)) for i in range(5)]
+    exp = [oracle.ivfadc_search_many(ot, q, 5, 4, sentinel=1000.0, found_rule=0) for q in qs]
+    dq = [torch.from_numpy(q).to(dev) for q in qs]
+    res = [torch.zeros((2, 300, 5), dtype=torch.int32, device=dev) for _ in qs]
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    streams = [torch.cuda.Stream(dev) for _ in qs]
+    torch.cuda.synchronize(dev)
+    for rounds in range(4):
+        for i in range(len(qs)):
+            with torch.cuda.stream(streams[i]):
+                res[i].zero_()
+                idx.search_dev(dq[i].data_ptr(), 300, 5, 4, 1000.0, gpu.FOUND_ROWS, res[i][0].data_ptr(), res[i][1].data_ptr(),
+                               st.data_ptr(), streams[i].cuda_stream)
+    torch.cuda.synchronize(dev)
+    for i in range(len(qs)):
+        util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i}")
+    got_i, got_d = idx.search(qs[1], 5, 4, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
+    util.assert_same_lists(got_i, got_d, exp[1], "host-buffer call")
+    assert idx.bound_violations() == 0
+    idx.close()
