@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -74,6 +75,8 @@ struct Tuning {
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
+  int scan_share = 0;          // FREDDY_GPU_SCAN_SHARE: the persistent scan takes n_cus / share CUs; 0 = auto: share = the streams that searched on
+                               // this handle within the last 2 ms (batches in flight), 1 = always the whole chip
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
@@ -95,6 +98,7 @@ static Tuning read_tuning() {
   t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
   t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
   t.partition_cus = (int)env_int("FREDDY_GPU_PARTITION_CUS", t.partition_cus);
+  t.scan_share = (int)env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -127,6 +131,7 @@ struct DevBuf {
 struct Workspace {
   bool used = false;
   hipStream_t owner = nullptr;
+  double last_use_ms = -1e30;      // host clock of the most recent search enqueued on this workspace (scan_share)
   hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
   hipEvent_t ev_q = nullptr, ev_qc = nullptr;
   // CU-partitioned mode (Tuning::partition_cus): the batch's small kernels on a stream masked to the reserved CUs, its
@@ -717,6 +722,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "side_stream") t.side_stream = (int)value;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "partition_cus") t.partition_cus = (int)value;
+  else if (n == "scan_share") t.scan_share = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -813,6 +819,7 @@ struct IvfRun {
   Workspace* ws;
   hipStream_t s;       // the stream the small kernels are enqueued on (the caller's, or the workspace's masked fe stream)
   hipStream_t s_scan;  // the stream of the scan kernel (== s unless the CUs are partitioned)
+  int share;           // batches in flight on this handle (the scan takes n_cus / share CUs)
   const float* d_q;
   int Q, k, W, L, found_rule, upi;
   float sentinel, cell_limit;
@@ -1038,7 +1045,12 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   fl.desc_offset = (uint32_t)desc_off;
   // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
   const bool parted = r.s_scan != s;
-  const int scan_cus = parted ? ix->n_cus - ws->part_cus : ix->n_cus - ix->tune.reserve_cus;
+  // Batches in flight share the chip: a persistent scan that took every CU would hold up the small kernels of the
+  // other batches until it drains, and their scans behind them; with n_cus / share workgroups each, the scans of
+  // `share` batches run side by side, the small kernels fit in between, and a scan's workgroups pull more entries
+  // each (a shorter tail).  Measured: 4 batches in flight, 256 / 192 / 128 / 64 workgroups: 7.86 / 8.0 / 8.26 / 8.6 M q/s.
+  const int scan_cus = parted ? ix->n_cus - ws->part_cus
+                              : std::max(ix->n_cus / std::max(1, r.share), std::min(ix->n_cus, 32)) - ix->tune.reserve_cus;
   const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
   hipStream_t ss = r.s_scan;
   if (parted) {   // records (and everything before them) -> scan, on the stream masked to the scan's CUs
@@ -1197,6 +1209,13 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   IvfRun r;
   r.ix = ix; r.ws = ws; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
   r.sentinel = sentinel; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = d_status;
+  {
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ws->last_use_ms = now;
+    int active = 0;
+    for (const Workspace& w : ix->ws) active += (w.used && now - w.last_use_ms < 2.0) ? 1 : 0;
+    r.share = ix->tune.scan_share > 0 ? ix->tune.scan_share : std::max(1, active);
+  }
   // FREDDY_FOUND_BATCH_UDF = the accepted-rows rule + the batch UDF's cell limit (argmin from minDist = 1000,
   // freddy.c:853-866); ivfadc_search's cell list starts at 100.0 (freddy.c:266-283)
   r.found_rule = found_rule == FREDDY_FOUND_ROWS ? 0 : 1;
