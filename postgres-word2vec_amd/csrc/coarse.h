@@ -34,17 +34,20 @@ namespace freddy {
 
 static constexpr float COARSE_EPS = 1.2e-4f;
 static constexpr int COARSE_DP_ALIGN = 64;    // padded dimension count: whole blocks of 8 iterations x 8 dimensions (zeros)
+static constexpr int COARSE_TQ = 32;          // queries per MFMA tile (a workgroup = 32 queries x 128 cells)
 static constexpr int COARSE_MAX_CPAD = 1024;  // the plan keeps a query's approximate distances in registers: 16 per lane
 
 // ---------------------------------------------------------------------------------------
-// a[q][j] for a 64-query x 64-cell tile per workgroup; wave w owns the 32 x 32 quadrant (w >> 1, w & 1).
+// a[q][j] for a 32-query x 128-cell tile per workgroup; wave w owns the 32 x 32 block of cells [32 w, 32 w + 32).
+// (Until round 2 the tile was 64 x 64 with 83 KB of LDS: one workgroup per CU, and with several batches in flight a
+// kernel of such workgroups waits for CUs the other batches' scans do not hold; 32 query rows are 41 KB.)
 // The k index of an MFMA step may be any permutation as long as A and B agree: step t of iteration i pairs
 // elements 8 i + t (lanes 0-31) and 8 i + 4 + t (lanes 32-63), so a lane's operands for FOUR consecutive MFMAs
 // are 16 contiguous bytes of its row.
 //   B (centroids): pinned in FRAGMENT order coarseF[Cpad / 32][dp / 8][64 lanes][4] -- a wave's operand load is
 //     one fully coalesced 1 KB read, several iterations in flight (a first version read row-major centroids
 //     and queries directly, 64 different cache lines per wave-level load: 28 us, latency-bound);
-//   A (queries, row-major from the caller): the tile's 64 rows are staged ONCE in LDS by coalesced 16-byte
+//   A (queries, row-major from the caller): the tile's 32 rows are staged ONCE in LDS by coalesced 16-byte
 //     loads, all in flight together (row pitch dp + 4 floats: the ds_read_b128 of 16 consecutive rows at one
 //     column hit 16 different 4-bank groups).
 //   cn2 [Cpad] = |c_j|^2 (fp64 sum rounded once, pin time), out [Q][Cpad], qn2 [Q] = |q|^2.
@@ -63,13 +66,14 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
     for (int a = 0; a < 5; ++a)
       for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
   }
+  constexpr int TQ = COARSE_TQ;                       // query rows of a tile
   const int PA = dp + 4;
-  float* As = reinterpret_cast<float*>(smem);        // [64][PA]
-  float* rown = As + 64 * PA;                         // [4][32]
+  float* As = reinterpret_cast<float*>(smem);        // [TQ][PA]
+  float* rown = As + TQ * PA;                         // [4][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int q0w = (wave >> 1) * 32;
-  const int q0 = blockIdx.y * 64, c0 = blockIdx.x * 64 + (wave & 1) * 32;
+  const int q0w = 0;
+  const int q0 = blockIdx.y * TQ, c0 = blockIdx.x * 128 + wave * 32;
   const int nit = dp >> 3;
   const float4* bp = reinterpret_cast<const float4*>(coarseF) + ((size_t)(c0 >> 5) * nit) * 64 + lane;
   constexpr int UN = 8;   // B operands in flight per wave
@@ -81,11 +85,11 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
   // this step alone, the flat copy 2); columns d..dp-1 are zeroed, rows beyond Q hold junk that is never stored.
   {
     const int d4n = d >> 2;
-    const int rows = Q - q0 < 64 ? Q - q0 : 64;
+    const int rows = Q - q0 < TQ ? Q - q0 : TQ;
     const int n4 = rows * d4n;
     const float4* src = reinterpret_cast<const float4*>(queries + (size_t)q0 * d);
-    constexpr int SB = 19;   // 64 rows x 300 floats = 4800 float4 = 18.75 per thread
-    for (int base = 0; base < 64 * d4n; base += 256 * SB) {
+    constexpr int SB = 10;   // 32 rows x 300 floats = 2400 float4 = 9.4 per thread
+    for (int base = 0; base < TQ * d4n; base += 256 * SB) {
       float4 v[SB];
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
@@ -95,14 +99,14 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
 #pragma unroll
       for (int u = 0; u < SB; ++u) {
         const int i = base + u * 256 + tid;
-        if (i < 64 * d4n) {
+        if (i < TQ * d4n) {
           const int row = i / d4n, c4 = i - row * d4n;
           *reinterpret_cast<float4*>(As + row * PA + c4 * 4) = v[u];
         }
       }
     }
     const int p4n = (dp - d) >> 2;   // zero columns
-    for (int i = tid; i < 64 * p4n; i += 256) {
+    for (int i = tid; i < TQ * p4n; i += 256) {
       const int row = i / p4n, c4 = i - row * p4n;
       *reinterpret_cast<float4*>(As + row * PA + d + c4 * 4) = float4{0.f, 0.f, 0.f, 0.f};
     }
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
   nrm += __shfl_xor(nrm, 32, 64);
   if (h == 0) {
     rown[wave * 32 + r] = nrm;
-    if ((wave & 1) == 0 && blockIdx.x == 0 && q0 + q0w + r < Q) qn2[q0 + q0w + r] = nrm;
+    if (wave == 0 && blockIdx.x == 0 && q0 + q0w + r < Q) qn2[q0 + q0w + r] = nrm;
   }
   __syncthreads();
   const float cn = cn2[c0 + r];

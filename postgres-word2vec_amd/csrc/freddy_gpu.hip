@@ -864,8 +864,8 @@ static int ivf_coarse(IvfRun& r) {
   auto launch_coarse = [&]() -> int {
     timed_launch(ix, s, "coarse_dist", [&] {
       if (r.approx)
-        hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256),
-                           (size_t)(64 * (ix->dp + 4) + 128) * sizeof(float), s, r.d_q, ix->coarseP, ix->cn2,
+        hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 128, (Q + COARSE_TQ - 1) / COARSE_TQ), dim3(256),
+                           (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), s, r.d_q, ix->coarseP, ix->cn2,
                            ws->w_distT.as<float>(), ws->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
       else if (r.tiled)
         hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,

@@ -217,7 +217,7 @@ int main() {
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
   hipEventRecord(a, 0);
   for (int i = 0; i < 50; ++i)
-    hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), lds, 0, dq, dc, dn, out, qn, Q, Cpad, d, dp, z);
+    hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 128, (Q + COARSE_TQ - 1) / COARSE_TQ), dim3(256), (size_t)(COARSE_TQ * (dp + 4) + 128) * 4, 0, dq, dc, dn, out, qn, Q, Cpad, d, dp, z);
   hipEventRecord(b, 0); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   printf("%-28s %.2f us per launch\n", "coarse_approx_kernel", ms * 1000 / 50);

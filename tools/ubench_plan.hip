@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
   float t_c = 0, t_p = 0;
   for (int it = 0; it < 40; ++it) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 64, (Q + 63) / 64), dim3(256), lds, 0, dq, dcf, dn, dist, qn, Q, Cpad, d, dp, z);
+    hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 128, (Q + COARSE_TQ - 1) / COARSE_TQ), dim3(256), (size_t)(COARSE_TQ * (dp + 4) + 128) * 4, 0, dq, dcf, dn, dist, qn, Q, Cpad, d, dp, z);
     hipEventRecord(e1, 0);
     if (abl == 0) hipLaunchKernelGGL(probe_plan2_kernel<0>, dim3(Q), dim3(64 * PLAN2_NW), 0, 0, g);
     else if (abl == 1) hipLaunchKernelGGL(probe_plan2_kernel<1>, dim3(Q), dim3(64 * PLAN2_NW), 0, 0, g);
