@@ -249,6 +249,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     # Everything of a step -- the search kernels (through the C ABI, on this stream's handle) and the RCCL
     # gather -- is ordered on ONE explicit non-default stream, so the collective reads a shard's results
     # only after the search wrote them and the buffer is rewritten only after the collective read it.
+    # (GPU_MAX_HW_QUEUES = 6 above: a hardware queue per stream plus spares for the default stream and RCCL.)
     # Consecutive steps alternate between `in_flight` streams (each with its own result buffer and, inside the
     # library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of two
     # batches -- merge of batch i, cell selection of batch i+1 -- overlap.  --in-flight 1 is the strict sequence.
@@ -410,8 +411,11 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             "gather_verified": gather_ok,
             "pipelining": {"batches_in_flight": n_fl, "serial_ms_per_step": round(1e3 * dt1 / a.steps, 4),
                            "serial_queries_per_s": round(world * q_local * a.steps / dt1, 1),
+                           "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                            "note": "value = throughput with consecutive batches on alternating HIP streams (separate "
-                                   "workspaces); serial_* = the same steps strictly one after the other"},
+                                   "workspaces; the library gives each batch's persistent scan n_cus / batches-in-flight "
+                                   "workgroups so the scans run side by side); serial_* = the same steps strictly one after "
+                                   "the other (the scan takes every CU)"},
             "host_buffer_abi": {"queries_per_s": round(host_qps, 1), "same_results_as_device_path": host_same,
                                 "note": "freddy_gpu_ivfadc_search: H2D of the queries, D2H of the results, one stream sync, "
                                         "extra probing rounds for stragglers -- per call"},

@@ -75,10 +75,11 @@ struct Tuning {
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
+  int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
   int scan_share = 0;          // FREDDY_GPU_SCAN_SHARE: the persistent scan takes n_cus / share CUs; 0 = auto: share = the streams that searched on
                                // this handle within the last 2 ms (batches in flight), 1 = always the whole chip
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
-                               // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R (DESIGN.md 5.2d); 0 = everything on the caller's stream
+                               // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R (DESIGN.md 5.2c); 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
@@ -99,6 +100,7 @@ static Tuning read_tuning() {
   t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
   t.partition_cus = (int)env_int("FREDDY_GPU_PARTITION_CUS", t.partition_cus);
   t.scan_share = (int)env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share);
+  t.merge_waves = (int)env_int("FREDDY_GPU_MERGE_WAVES", t.merge_waves);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -723,6 +725,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "partition_cus") t.partition_cus = (int)value;
   else if (n == "scan_share") t.scan_share = (int)value;
+  else if (n == "merge_waves") t.merge_waves = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -1102,7 +1105,11 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
             (double)tot / std::max(n_items, 1), item_mx, mx);
   }
   timed_launch(ix, s, "merge_refine", [&] {
-    hipLaunchKernelGGL((merge_refine_kernel<25, 12>), dim3(r.n_active), dim3(256), 0, s, mr);
+    // (one batch at a time: four waves per query, the shortest latency; batches in flight: one wave per query, the smallest footprint)
+    if (r.share > 1 ? ix->tune.merge_waves != 4 : ix->tune.merge_waves == 1)
+      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 1>), dim3(r.n_active), dim3(64), 0, s, mr);
+    else
+      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 4>), dim3(r.n_active), dim3(256), 0, s, mr);
   });
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1232,7 +1239,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   r.tiled = Q >= 32;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
-  // CU partition (DESIGN.md 5.2d): only for the filter + refine scan, whose persistent workgroups take whole CUs
+  // CU partition (DESIGN.md 5.2c): only for the filter + refine scan, whose persistent workgroups take whole CUs
   hipStream_t s_caller = s;
   r.s_scan = s;
   if (ix->tune.partition_cus != 0 && r.fused && r.scan_kernel >= 4) {

@@ -729,18 +729,21 @@ struct MergeRefineArgs {
   uint32_t ablate;   // timing experiments only (FREDDY_GPU_MERGE_ABLATE): 1 = skip the exact stage
 };
 
-template <int S, int M>
-__global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a) {
-  // Four waves per query.  Wave 0 selects and replays; the exact stage of the normal case (<= NC rows)
+template <int S, int M, int NWV>
+__global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineArgs a) {
+  // NWV = 4: four waves per query.  Wave 0 selects and replays; the exact stage of the normal case (<= NC rows)
   // is spread over all four -- one tile of 64 (row, position) chains each -- because a wave spends it
-  // waiting for two dependent round trips per tile.
+  // waiting for two dependent round trips per tile: the shortest latency for ONE batch.
+  // NWV = 1: one wave per query does everything, tile after tile -- a quarter of the wave slots and 12 instead of
+  // 30 KB of LDS per query: with several batches in flight, when this kernel has to fit into the CUs the scans of the
+  // other batches leave, the smaller footprint is worth more than the latency.
   constexpr int NT = 4;                     // tiles of 64 chains refined together
   constexpr int NC = NT * 64 / M;           // = 21 candidates
   constexpr int SQ = S + 1;                 // row pitch of the squared differences
   constexpr int M2 = M / 2;
   __shared__ u64 stage[64];
   __shared__ float qs[M * S];
-  __shared__ float sq[NT * 64 * SQ];
+  __shared__ float sq[(NWV == 1 ? 1 : NT) * 64 * SQ];
   __shared__ float lutv[NT * 64];
   __shared__ int32_t cbo[NT * 64], coo[NT * 64];
   __shared__ u64 cq_key[64 + NC];
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a)
   const int R = a.W * per_item;
   constexpr int NBATCH = 4;
 
-  if (!(a.ablate & 2)) for (int j = threadIdx.x; j < M * S; j += 256) qs[j] = a.queries[(size_t)q * a.d + j];
+  if (!(a.ablate & 2)) for (int j = threadIdx.x; j < M * S; j += 64 * NWV) qs[j] = a.queries[(size_t)q * a.d + j];
   const float E = (a.ablate & 2) ? 0.0f
                   : a.qscale5 ? filter_width5<M>(a.qn + (size_t)q * M, a.pmax, a.qscale5[q])
                               : filter_width<M>(a.qn + (size_t)q * M, a.pmax);
@@ -974,7 +977,7 @@ __global__ __launch_bounds__(256, 4) void merge_refine_kernel(MergeRefineArgs a)
   }
   if (a.ablate & 1) queued = 0;
   // the normal case's rows (at most NC of them) are refined by the four waves together
-  {
+  if (NWV > 1) {
     const int n1 = revisit ? 0 : (queued < NC ? queued : NC);
     if (lane == 0) sh_n = n1;
     __syncthreads();

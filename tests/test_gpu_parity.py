@@ -765,7 +765,7 @@ def test_searches_on_two_streams_overlap_safely(gpu, oracle):
 
 @pytest.mark.parametrize("partition", [32, -16])
 def test_cu_partitioned_streams_give_the_same_lists(gpu, oracle, partition):
-    """Option partition_cus (DESIGN.md 5.2d): the small kernels of a batch on a stream masked to R CUs and the scan on
+    """Option partition_cus (DESIGN.md 5.2c): the small kernels of a batch on a stream masked to R CUs and the scan on
     a stream masked to the rest (R > 0), or only the scan masked (R < 0), chained by events to the caller's stream.
     Five batches in flight on five streams (more than the runtime's four default hardware queues), host-buffer call
     afterwards on the same handle: the lists are the oracle's in every mode."""
@@ -795,5 +795,23 @@ def test_cu_partitioned_streams_give_the_same_lists(gpu, oracle, partition):
         util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i}")
     got_i, got_d = idx.search(qs[1], 5, 4, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
     util.assert_same_lists(got_i, got_d, exp[1], "host-buffer call")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+@pytest.mark.parametrize("share", [0, 3, 8])
+def test_scan_share_gives_the_same_lists(gpu, oracle, share):
+    """Option scan_share: the persistent scan on n_cus / share workgroups (0 = the streams that searched
+    within the last 2 ms).  The number of workgroups that pull work entries changes nothing in the lists."""
+    N = 60000
+    t = util.ivf_tables(N=N, C=64, K=1024)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx.set_option("scan_share", share)
+    _, qs = util.queries_from_corpus(N, 400)
+    exp = oracle.ivfadc_search_many(ot, qs, 5, 6, sentinel=1000.0, found_rule=0)
+    for _ in range(2):
+        got_i, got_d = idx.search(qs, 5, 6, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
+        util.assert_same_lists(got_i, got_d, exp, f"scan_share={share}")
     assert idx.bound_violations() == 0
     idx.close()
