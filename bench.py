@@ -355,6 +355,14 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                                              "equivalent rate, not traffic -- the kernel reads a list once per work entry",
                                      "step_qps_ceiling_at_8TBs": round(ceiling_qps, 1),
                                      "step_frac_of_ceiling": round(qps / world / ceiling_qps, 5)},
+                 "timed_region": (lambda ov: None if not ov else {
+                     "avg_launch_us": round(1e3 * ov[1] / max(ov[0], 1), 2), "batches_in_flight": n_fl,
+                     "share_of_chip": round(1.0 / n_fl, 4),
+                     "achieved": round(cell_bytes / (ov[1] / max(ov[0], 1) / 1e3) / 1e9, 2), "unit": "GB/s",
+                     "frac_of_share": round(cell_bytes / (ov[1] / max(ov[0], 1) / 1e3) / 1e9 / (HBM_PEAK_GBS / n_fl), 5),
+                     "note": "the same kernel inside the timed region: with n batches in flight a scan runs on n_cus / n "
+                             "workgroups beside the scans of the other batches (DESIGN.md 5.2c); frac_of_share prices it against "
+                             "that share of the HBM peak, the headline frac above prices the kernel alone on every CU"})(prof_ov.get(dom)),
                  "distinct_probed_cells": int(n_cells), "index_bytes": int(index.nbytes),
                  "note": f"the {index.nbytes / 1e6:.0f} MB index is Infinity-Cache (256 MiB) resident after first touch; a "
                          "non-resident corpus (N = 40 M) is measured in profiles/ (DESIGN.md 5.6)"})

@@ -6,7 +6,7 @@ TAG=${1:-rXX}
 mkdir -p gpurun_out/prof
 tools/profile_round.sh $TAG > gpurun_out/prof/${TAG}_profile.log 2>&1
 cp gpurun_out/prof/${TAG}_pmc.json profiles/latest_pmc.json
-python3 bench.py --steps 30 --warmup 5 > gpurun_out/prof/${TAG}_bench.json 2> gpurun_out/prof/${TAG}_bench.err
+python3 bench.py > gpurun_out/prof/${TAG}_bench.json 2> gpurun_out/prof/${TAG}_bench.err
 # configs 2 and 4 (BASELINE configs[1], configs[3]) with their own kernel stats + PMC passes
 for cfg in pq join; do
   tools/profile_round.sh ${TAG}_${cfg} --config $cfg > gpurun_out/prof/${TAG}_${cfg}_profile.log 2>&1
