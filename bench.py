@@ -470,18 +470,22 @@ def run_pq(a, rank, world, dev, dev_index):
     prof = index.profile_read()
     index.profile_enable(False)
     kern = {n: {"launches": l, "avg_us": round(1e3 * ms / max(l, 1), 2)} for n, (l, ms) in prof.items()}
-    avg_s = prof["adc_scan"][1] / max(prof["adc_scan"][0], 1) / 1e3
+    # batches of >= 16 queries take the cell-grouped filter + refine scan over pseudo-lists; smaller ones adc_scan_kernel
+    dom = "ivf_filter" if "ivf_filter" in prof else "adc_scan"
+    dom_kernel = "ivf_filter5_kernel" if dom == "ivf_filter" else "adc_scan_kernel"
+    avg_s = prof[dom][1] / max(prof[dom][0], 1) / 1e3
     row_bytes = a.m * 2 + 4
     once = N * row_bytes + Q * (a.m * a.K * 4 + 300 * 4 + a.k * 8)   # the table once + every query's LUT
     per_query = Q * (N * row_bytes + a.m * a.K * 4)
-    roof = roofline("adc_scan_kernel", avg_s, once,
+    roof = roofline(dom_kernel, avg_s, once,
                     "the code table once per batch (28 B per row) + one 48 KiB LUT, query and result per query",
-                    pmc_traffic("adc_scan_kernel"),
+                    pmc_traffic(dom_kernel) if dom == "adc_scan" else None,
                     {"per_query_model": {"bytes_per_launch": int(per_query), "achieved": round(per_query / avg_s / 1e9, 1), "unit": "GB/s",
-                                         "note": "SURVEY 8d: N*(m*2+4) = 28 MB per QUERY / kernel time; one workgroup per (query, "
-                                                 "chunk) re-reads the table from the caches for every query"},
-                     "lds_gather": {"achieved": round(Q * N * a.m * 4 / avg_s / 1e9, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                                    "frac": round(Q * N * a.m * 4 / avg_s / 1e9 / LDS_PEAK_GBS, 5)}})
+                                         "note": "SURVEY 8d: N*(m*2+4) = 28 MB per QUERY / kernel time (an equivalent rate: the "
+                                                 "cell-grouped scan reads a 4096-row pseudo-list once per 16 queries; adc_scan_kernel, "
+                                                 "for batches below 16 queries, re-reads the table from the caches for every query)"},
+                     "lds_gather": {"achieved": round(Q * N * a.m * (2 if dom == "ivf_filter" else 4) / avg_s / 1e9, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
+                                    "frac": round(Q * N * a.m * (2 if dom == "ivf_filter" else 4) / avg_s / 1e9 / LDS_PEAK_GBS, 5)}})
     from oracle.oracle import Oracle
     o = Oracle()
     ot = o.pq_table(tab["codebook"], tab["ids"], tab["codes"])

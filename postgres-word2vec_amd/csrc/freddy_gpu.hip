@@ -75,6 +75,7 @@ struct Tuning {
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
+  int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
   int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
   int scan_share = 0;          // FREDDY_GPU_SCAN_SHARE: the persistent scan takes n_cus / share CUs; 0 = auto: share = the streams that searched on
                                // this handle within the last 2 ms (batches in flight), 1 = always the whole chip
@@ -101,6 +102,7 @@ static Tuning read_tuning() {
   t.partition_cus = (int)env_int("FREDDY_GPU_PARTITION_CUS", t.partition_cus);
   t.scan_share = (int)env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share);
   t.merge_waves = (int)env_int("FREDDY_GPU_MERGE_WAVES", t.merge_waves);
+  t.pq_fused = (int)env_int("FREDDY_GPU_PQ_FUSED", t.pq_fused);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -215,6 +217,10 @@ struct freddy_gpu_index {
   float* xb = nullptr;
   // ivpq extras
   JoinIndex join;
+  // flat PQ table through the cell-grouped scan (pq_shadow_build): an IVF-shaped view of this table -- pseudo-lists of
+  // 4096 consecutive rows, zero centroids -- that shares packed / codebook tables with its owner
+  freddy_gpu_index* pq_shadow = nullptr;
+  freddy_gpu_index* shadow_of = nullptr;   // set in the shadow: profile records and shared arrays belong to this index
   // workspaces: one per stream the caller searches on (searches on different streams may overlap)
   Workspace ws[FREDDY_MAX_WS];
   Workspace* last_ws = nullptr;   // of the most recent search (freddy_gpu_last_* read its counters)
@@ -225,6 +231,7 @@ struct freddy_gpu_index {
 
 template <class F>
 static inline void timed_launch(freddy_gpu_index* ix, hipStream_t s, const char* name, F&& f) {
+  if (ix->shadow_of) ix = ix->shadow_of;
   if (!ix->profiling) { f(); return; }
   hipEvent_t a, b;
   (void)hipEventCreate(&a);
@@ -269,6 +276,13 @@ static void free_index(freddy_gpu_index* ix) {
   (void)hipSetDevice(ix->device);
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   for (Workspace& w : ix->ws) { if (w.used && w.owner) (void)hipStreamSynchronize(w.owner); w.release(); }
+  if (ix->shadow_of) {   // a PQ table's IVF-shaped view: its own arrays only (packed, codebook tables and the stream are the owner's)
+    void* own[] = {ix->coarse, ix->rterm, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->pos};
+    for (void* p : own) if (p) (void)hipFree(p);
+    delete ix;
+    return;
+  }
+  if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
@@ -438,6 +452,28 @@ static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
   ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = nullptr;
   std::vector<float> cbT = transpose_codebook(codebook, ix->m, ix->K, ix->S);
   if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
+  if (ix->kind == KIND_PQ) {
+    // batches over the flat table take the cell-grouped filter + refine scan (pq_shadow_build): its codebook-derived tables,
+    // with "centroids" that are zero
+    if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
+    if (ix->m == 12 && ix->S == 25 && ix->K <= FUSED_T * FUSED_E && ix->tune.filter_table_mb > 0) {
+      std::vector<float> cmaxp((size_t)ix->m);
+      for (int p = 0; p < ix->m; ++p) {
+        double cmax = 0.0;
+        for (int c = 0; c < ix->K; ++c) {
+          double n2 = 0.0;
+          for (int j = 0; j < ix->S; ++j) { const double v = codebook[((size_t)p * ix->K + c) * ix->S + j]; n2 += v * v; }
+          cmax = std::max(cmax, std::sqrt(n2));
+        }
+        cmaxp[p] = (float)(cmax * (1.0 + 1e-6));
+      }
+      if (upload(&ix->cbR, codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
+          upload(&ix->pmax, cmaxp.data(), cmaxp.size(), &ix->bytes) ||
+          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
+        return fail(FREDDY_E_NOMEM, "device allocation failed");
+    }
+    return 0;
+  }
   if (ix->kind != KIND_IVF) return 0;
   const int C = ix->C, d = ix->d;
   if (ix->K <= FUSED_T * FUSED_E) {
@@ -668,6 +704,7 @@ extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_
 }
 
 static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
+  if (ix && ix->pq_shadow) ix = ix->pq_shadow;
   if (!ix || !ix->viol) return 0;
   int32_t h[4] = {0, 0, 0, 0};
   if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
@@ -726,6 +763,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "partition_cus") t.partition_cus = (int)value;
   else if (n == "scan_share") t.scan_share = (int)value;
   else if (n == "merge_waves") t.merge_waves = (int)value;
+  else if (n == "pq_fused") t.pq_fused = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -1106,7 +1144,9 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   }
   timed_launch(ix, s, "merge_refine", [&] {
     // (one batch at a time: four waves per query, the shortest latency; batches in flight: one wave per query, the smallest footprint)
-    if (r.share > 1 ? ix->tune.merge_waves != 4 : ix->tune.merge_waves == 1)
+    // (hundreds of survivor regions per query -- a batch over the flat PQ table: four waves, which split the selection)
+    const bool many_regions = (size_t)r.W * r.upi * FUSED_NW > 256;
+    if (!many_regions && (r.share > 1 ? ix->tune.merge_waves != 4 : ix->tune.merge_waves == 1))
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 1>), dim3(r.n_active), dim3(64), 0, s, mr);
     else
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 4>), dim3(r.n_active), dim3(256), 0, s, mr);
@@ -1388,6 +1428,163 @@ extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* que
 // ---------------------------------------------------------------------------------------
 // exhaustive / subset PQ
 // ---------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------
+// Batches over the flat PQ table through the cell-grouped filter + refine scan (fused5.h).
+//
+// adc_scan_kernel runs one workgroup per (query, chunk): every query re-reads the code table from the caches and gathers
+// 4-byte LUT entries one (query, row, position) at a time.  The IVFADC scan shares a chunk's rows among 16 queries and
+// gathers eight 16-bit table values per LDS access -- and pq_search's distance is ivfadc_search's with a residual
+// r = q - 0: the flat table is pinned a second time only as METADATA -- pseudo-lists of 4096 consecutive rows
+// (FUSED_UNIT_BLOCKS blocks; the packed codes are shared), a zero centroid per list, the row terms sum_p |c|^2, the rows'
+// ids -- in a shadow index of kind IVF, and a batch "probes" every list: items (query, list) for all pairs, no coarse
+// distances, no plan.  The exact stage then evaluates (q_i - 0) - c_i: x - 0 = x exactly, so its squares, their
+// order of summation (index_utils.c:500-508, 1126-1133) and the guarded insertion in ascending id order are pq_search's
+// (freddy.c:28-152).  The item's bound on |r|^2 is squareDistance(q, 0) evaluated the reference's way.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pq_shadow_meta_kernel(const int32_t* __restrict__ pos, const int32_t* __restrict__ ids,
+                                                            int64_t n_blocks, int64_t n_rows, int lists, int32_t* __restrict__ list_off,
+                                                            int32_t* __restrict__ blk_off, int32_t* __restrict__ blk_cell,
+                                                            int32_t* __restrict__ pos_ids) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i <= lists) {
+    const int64_t r = i * (FUSED_UNIT_BLOCKS * 64), b = i * FUSED_UNIT_BLOCKS;
+    list_off[i] = (int32_t)(r < n_rows ? r : n_rows);
+    blk_off[i] = (int32_t)(b < n_blocks ? b : n_blocks);
+  }
+  if (i < n_blocks) blk_cell[i] = (int32_t)(i / FUSED_UNIT_BLOCKS);
+  if (i < n_blocks * 64) { const int32_t r = pos[i]; pos_ids[i] = r >= 0 ? ids[r] : -1; }
+}
+
+// One workgroup per query: A = squareDistance(q, 0) (sequential binary32, index_utils.c:500-508), the query's items --
+// one per pseudo-list -- and its slot in every list's bucket.
+__global__ __launch_bounds__(256) void pq_items_kernel(const float* __restrict__ queries, int Q, int d, int lists, int64_t n_rows,
+                                                      int32_t* __restrict__ item_cell, int32_t* __restrict__ item_query,
+                                                      float* __restrict__ item_dist, int32_t* __restrict__ cell_items,
+                                                      int32_t* __restrict__ cell_count, int32_t* __restrict__ round_rows) {
+  __shared__ float A_s;
+  const int q = blockIdx.x;
+  if (threadIdx.x == 0) {
+    float acc = 0.0f;
+    for (int i = 0; i < d; ++i) { const float t = queries[(size_t)q * d + i] - 0.0f; acc = acc + t * t; }
+    A_s = acc;
+    round_rows[q] = (int32_t)n_rows;
+  }
+  __syncthreads();
+  const float A = A_s;
+  for (int c = threadIdx.x; c < lists; c += 256) {
+    const int it = q * lists + c;
+    item_cell[it] = c; item_query[it] = q; item_dist[it] = A;
+    cell_items[(size_t)c * Q + q] = it;
+    if (q == 0) cell_count[c] = Q;
+  }
+}
+
+static bool pq_fused_shape(const freddy_gpu_index* ix) {
+  return ix->kind == KIND_PQ && ix->cbR && ix->m == 12 && ix->S == 25 && ix->K <= FUSED_T * FUSED_E && ix->n_blocks > 0 && ix->N > 0;
+}
+
+static bool pq_use_fused(const freddy_gpu_index* ix, int Q, int k) {
+  if (ix->tune.pq_fused == 0 || !pq_fused_shape(ix) || 2 * k > 64) return false;
+  return ix->tune.pq_fused > 0 || Q >= 16;
+}
+// survivor regions: 32 KiB per (query, pseudo-list) within the workspace budget; the buckets [lists][queries] within 256 MiB
+static int pq_fused_queries_per_chunk(const freddy_gpu_index* ix) {
+  const size_t lists = (size_t)((ix->n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  size_t n = ((size_t)ix->tune.lut_budget_mb << 20) / (sizeof(u64) * lists * FUSED_NW * FUSED_RMAX * 64);
+  n = std::min<size_t>(n, ((size_t)256 << 20) / (sizeof(int32_t) * lists));
+  return (int)std::max<size_t>(16, std::min<size_t>(n, 1u << 16));
+}
+
+static int pq_shadow_build(freddy_gpu_index* ix) {
+  if (ix->pq_shadow) return 0;
+  freddy_gpu_index* fx = new freddy_gpu_index();
+  fx->shadow_of = ix;
+  fx->kind = KIND_IVF; fx->device = ix->device; fx->tune = ix->tune; fx->stream = ix->stream; fx->n_cus = ix->n_cus;
+  fx->d = ix->d; fx->m = ix->m; fx->K = ix->K; fx->S = ix->S; fx->M2 = ix->M2; fx->N = ix->N;
+  fx->n_blocks = ix->n_blocks; fx->max_list_blocks = FUSED_UNIT_BLOCKS;
+  const int lists = (int)((ix->n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  fx->C = lists;
+  fx->packed = ix->packed; fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp;   // shared
+  const size_t slots = (size_t)ix->n_blocks * 64;
+  int rc = 0;
+  if (hipMalloc((void**)&fx->coarse, sizeof(float) * (size_t)lists * ix->d) != hipSuccess ||
+      hipMalloc((void**)&fx->list_off, sizeof(int32_t) * ((size_t)lists + 1)) != hipSuccess ||
+      hipMalloc((void**)&fx->blk_off, sizeof(int32_t) * ((size_t)lists + 1)) != hipSuccess ||
+      hipMalloc((void**)&fx->blk_cell, sizeof(int32_t) * (size_t)ix->n_blocks) != hipSuccess ||
+      hipMalloc((void**)&fx->pos, sizeof(int32_t) * slots) != hipSuccess ||
+      hipMalloc((void**)&fx->viol, 4 * sizeof(int32_t)) != hipSuccess)
+    rc = fail(FREDDY_E_NOMEM, "device allocation failed (PQ table as pseudo-lists)");
+  if (!rc) {
+    hipStream_t s = ix->stream;
+    (void)hipMemsetAsync(fx->coarse, 0, sizeof(float) * (size_t)lists * ix->d, s);
+    (void)hipMemsetAsync(fx->viol, 0, 4 * sizeof(int32_t), s);
+    hipLaunchKernelGGL(pq_shadow_meta_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ix->pos, ix->ids, ix->n_blocks,
+                       ix->N, lists, fx->list_off, fx->blk_off, fx->blk_cell, fx->pos);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = fail(FREDDY_E_HIP, "building the PQ pseudo-lists failed");
+  }
+  if (!rc) rc = refresh_row_terms(fx);
+  if (rc) { free_index(fx); return rc; }
+  fx->bytes = (int64_t)(sizeof(float) * (size_t)lists * ix->d + sizeof(int32_t) * (2 * ((size_t)lists + 1) + (size_t)ix->n_blocks + slots) + sizeof(float) * slots);
+  ix->bytes += fx->bytes;
+  ix->pq_shadow = fx;
+  return 0;
+}
+
+static int ivf_work_table(IvfRun& r, WorkTable& wt);
+static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt);
+
+static int pq_fused_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
+                          int32_t* d_out_ids, float* d_out_dist) {
+  freddy_gpu_index* fx = ix->pq_shadow;
+  fx->tune = ix->tune;
+  Workspace* ws = workspace_for(fx, s);
+  const int lists = fx->C, m = fx->m, K = fx->K;
+  IvfRun r;
+  r.ix = fx; r.ws = ws; r.s = s; r.s_scan = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = lists; r.L = 2 * k;
+  r.sentinel = sentinel; r.cell_limit = 0.0f; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = nullptr;
+  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.approx = false; r.qc_pending = false;
+  r.n_active = Q; r.round = 0; r.active = nullptr;
+  {
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    ws->last_use_ms = now;
+    int active = 0;
+    for (const Workspace& w : fx->ws) active += (w.used && now - w.last_use_ms < 2.0) ? 1 : 0;
+    r.share = ix->tune.scan_share > 0 ? ix->tune.scan_share : std::max(1, active);
+  }
+  const size_t items = (size_t)Q * lists;
+  if (ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
+      ws->w_item_dist.ensure(sizeof(float) * items) || ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) || ws->w_act1.ensure(sizeof(int32_t) * Q) ||
+      ws->w_cnt.ensure(sizeof(int32_t) * 8) || ws->w_cellcnt.ensure(sizeof(int32_t) * (size_t)lists * 3) ||
+      ws->w_sorted.ensure(sizeof(int32_t) * (size_t)lists * Q) ||
+      ws->w_groups.ensure(sizeof(int32_t) * 3 * (items / SPEC2_G + (size_t)lists + 1) * r.upi) ||
+      ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
+      ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW) ||
+      ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d over %d pseudo-lists)", Q, lists);
+  r.next = ws->w_act0.as<int32_t>();
+  HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 8, s));
+  HIP_TRY(hipMemsetAsync(ws->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)lists * 3, s));
+  HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * items * r.upi * FUSED_NW, s));
+  timed_launch(fx, s, "query_codebook", [&] {
+    hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, d_q, fx->cbT, fx->cmaxp,
+                       ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, fx->d, m, K);
+  });
+  HIP_TRY(hipGetLastError());
+  PlanArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.item_cell = ws->w_item_cell.as<int32_t>(); pa.item_query = ws->w_item_query.as<int32_t>(); pa.item_dist = ws->w_item_dist.as<float>();
+  pa.round_rows = ws->w_rows.as<int32_t>(); pa.n_active = Q; pa.C = lists; pa.W = lists;
+  timed_launch(fx, s, "pq_items", [&] {
+    hipLaunchKernelGGL(pq_items_kernel, dim3(Q), dim3(256), 0, s, d_q, Q, fx->d, lists, fx->N, pa.item_cell, pa.item_query, pa.item_dist,
+                       ws->w_sorted.as<int32_t>(), ws->w_cellcnt.as<int32_t>(), pa.round_rows);
+  });
+  HIP_TRY(hipGetLastError());
+  WorkTable wt;
+  if (int rc = ivf_work_table(r, wt)) return rc;
+  return ivf_scan_filter(r, pa, wt);
+}
+
 static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
                     const int32_t* blk_off, const uint32_t* packed, const int32_t* pos, int64_t n_blocks,
                     int32_t* d_out_ids, float* d_out_dist) {
@@ -1426,6 +1623,16 @@ extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_q
   if (Q == 0) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ix->stream;
+  if (pq_use_fused(ix, Q, k)) {
+    if (int rc = pq_shadow_build(ix)) return rc;
+    const int qf = pq_fused_queries_per_chunk(ix);
+    for (int q0 = 0; q0 < Q; q0 += qf) {
+      const int n = std::min(qf, Q - q0);
+      if (int rc = pq_fused_chunk(ix, s, d_queries + (size_t)q0 * ix->d, n, k, sentinel, d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k))
+        return rc;
+    }
+    return FREDDY_OK;
+  }
   const int qc = max_queries_per_chunk(ix, 1);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
@@ -1493,9 +1700,17 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   int64_t n_blocks = ix->n_blocks;
   if (subset_ids)
     if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
-  const int qc = max_queries_per_chunk(ix, 1);
+  const bool fused_path = !subset_ids && pq_use_fused(ix, Q, k);
+  if (fused_path) if (int rc = pq_shadow_build(ix)) return rc;
+  const int qc = fused_path ? pq_fused_queries_per_chunk(ix) : max_queries_per_chunk(ix, 1);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
+    if (fused_path) {
+      if (int rc = pq_fused_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel,
+                                  ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k))
+        return rc;
+      continue;
+    }
     if (int rc = pq_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel, blk_off, packed, pos, n_blocks,
                           ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k))
       return rc;
@@ -1884,6 +2099,7 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
       std::vector<int32_t> row_pos((size_t)n);
       for (int64_t i = 0; i < n; ++i) row_pos[(size_t)i] = (int32_t)(ix->N + i);   // flat table: position = row index
       const int64_t old_n = ix->N;
+      if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }   // (rebuilt by the next batch search)
       if (int rc = append_packed_rows(ix, 1, n, nullptr, row_pos.data(), codes)) return rc;
       if (grow_device_array(&ix->ids, (size_t)old_n, (size_t)(old_n + n), ids, (size_t)n)) return fail(FREDDY_E_NOMEM, "device allocation failed");
       ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);

@@ -741,7 +741,10 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   constexpr int NC = NT * 64 / M;           // = 21 candidates
   constexpr int SQ = S + 1;                 // row pitch of the squared differences
   constexpr int M2 = M / 2;
-  __shared__ u64 stage[64];
+  __shared__ u64 stage_all[NWV][64];
+  u64* const stage = stage_all[0];
+  __shared__ u64 part_key[NWV > 1 ? NWV : 1][64];        // pass 1 split over the waves (many survivor regions: the flat PQ table)
+  __shared__ uint32_t part_flag[NWV > 1 ? NWV : 1][64];
   __shared__ float qs[M * S];
   __shared__ float sq[(NWV == 1 ? 1 : NT) * 64 * SQ];
   __shared__ float lutv[NT * 64];
@@ -749,6 +752,10 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   __shared__ u64 cq_key[64 + NC];
   __shared__ int32_t cq_cell[64 + NC];
   __shared__ int sh_n;
+  constexpr int BQ = NWV > 1 ? 512 : 1;     // rows with d_lo <= T beyond the kept keys, collected by all waves (dense neighbourhoods)
+  __shared__ u64 bq_key[BQ];
+  __shared__ int bq_n;
+  __shared__ uint32_t sh_T;
   const int x = blockIdx.x, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int q = a.active ? a.active[x] : x;
@@ -814,59 +821,108 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     __builtin_amdgcn_wave_barrier();
   };
 
-  if (wave != 0) {
-    __syncthreads();                       // wave 0 has queued the rows to refine
-    const int n1 = sh_n;
-    if (n1 > 0 && wave * 64 < n1 * M) tile_work(wave, sq + wave * 64 * SQ, n1);
+  // ---- pass 1: the L smallest lower bounds ----
+  // (a few more than L are kept: the rows to refine are normally all among them)
+  const int LW = (a.ablate & 4) ? a.L : ((a.L + 22 < 64 && R <= 64 * NBATCH) ? a.L + 22 : 64);
+  // one sweep over survivor regions jb0, jb0 + jstep, ... (64 x NBATCH regions at a time: counts, then the first two keys
+  // of every region, in flight together); every key goes to sink(key, valid), called by the whole wave
+  auto sweep = [&](auto&& sink, int jb0, int jstep, uint32_t& flag_seen) {
+    for (int jb = jb0; jb < R; jb += jstep) {
+      int c[NBATCH];
+      size_t region[NBATCH];
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        const int j = jb + u * 64 + lane;
+        region[u] = (size_t)x * R + (size_t)(j < R ? j : 0);
+        c[u] = (j < R) ? a.surv_count[region[u]] : 0;
+      }
+      u64 k0[NBATCH], k1[NBATCH];
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
+        k0[u] = (c[u] > 0) ? src[0] : KEY_INF;
+        k1[u] = (c[u] > 1) ? src[1] : KEY_INF;
+        if (c[u] > 0) flag_seen |= (uint32_t)k0[u];
+        if (c[u] > 1) flag_seen |= (uint32_t)k1[u];
+      }
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
+        int maxc = c[u];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
+        if (maxc > 0) sink(k0[u], c[u] > 0);
+        if (maxc > 1) sink(k1[u], c[u] > 1);
+        for (int t = 2; t < maxc; ++t) {
+          const bool valid = t < c[u];
+          const u64 kk = valid ? src[t] : KEY_INF;
+          if (valid) flag_seen |= (uint32_t)kk;
+          sink(kk, valid);
+        }
+      }
+    }
+  };
+  // More regions than one sweep of a wave covers (W x chunks x 8 > 256: a batch over the flat PQ table "probes" hundreds of
+  // pseudo-lists): every wave selects from a quarter of them -- the sweeps are chains of dependent round trips -- and
+  // wave 0 merges the four selections.
+  const bool split1 = NWV > 1 && R > 64 * NBATCH;
+  if (split1) {
+    WaveSelect<1> sp;
+    sp.init(stage_all[wave], KEY_INF, LW);
+    uint32_t fs = 0u;
+    sweep([&](u64 kk, bool v) { sp.push(kk, v); }, wave * 64 * NBATCH, NWV * 64 * NBATCH, fs);
+    sp.finish();
+    part_key[wave][lane] = sp.acc[0];
+    part_flag[wave][lane] = fs;
     __syncthreads();
+  }
+
+  // every row with d_lo <= T (or a pending sentinel decision) of this wave's share of the regions -> bq_key
+  auto collect = [&]() {
+    const uint32_t Tb = sh_T;
+    uint32_t unused = 0u;
+    sweep([&](u64 kk, bool valid) {
+      const bool need = valid && (((uint32_t)(kk >> 32) <= Tb) || ((uint32_t)kk & 0x80000000u));
+      const u64 mask = __ballot(need);
+      if (mask != 0ull) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&bq_n, (int)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        const int slot = base + (int)lanes_below(mask);
+        if (need && slot < BQ) bq_key[slot] = kk;
+      }
+    }, wave * 64 * NBATCH, NWV * 64 * NBATCH, unused);
+  };
+
+  if (wave != 0) {
+    for (;;) {                               // rounds of <= NC rows until wave 0 announces none
+      __syncthreads();                       // wave 0 has queued the rows to refine
+      const int n1 = sh_n;
+      if (n1 < 0) { collect(); __syncthreads(); continue; }
+      if (n1 <= 0) break;
+      if (wave * 64 < n1 * M) tile_work(wave, sq + wave * 64 * SQ, n1);
+      __syncthreads();
+    }
     return;
   }
 
-  // ---- pass 1: the L smallest lower bounds ----
-  // (a few more than L are kept: the rows to refine are normally all among them)
-  const int LW = (a.ablate & 4) ? a.L : (a.L + 22 < 64 ? a.L + 22 : 64);
   WaveSelect<1> sel;
   sel.init(stage, KEY_INF, LW);
   uint32_t flag_seen = 0u;
-  for (int jb = 0; jb < R; jb += 64 * NBATCH) {
-    int c[NBATCH];
-    size_t region[NBATCH];
+  if (split1) {
 #pragma unroll
-    for (int u = 0; u < NBATCH; ++u) {
-      const int j = jb + u * 64 + lane;
-      region[u] = (size_t)x * R + (size_t)(j < R ? j : 0);
-      c[u] = (j < R) ? a.surv_count[region[u]] : 0;
+    for (int w = 0; w < NWV; ++w) {
+      const u64 kk = part_key[w][lane];
+      flag_seen |= part_flag[w][lane];
+      sel.push(kk, kk != KEY_INF);
     }
-    u64 k0[NBATCH], k1[NBATCH];
-#pragma unroll
-    for (int u = 0; u < NBATCH; ++u) {
-      const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
-      k0[u] = (c[u] > 0) ? src[0] : KEY_INF;
-      k1[u] = (c[u] > 1) ? src[1] : KEY_INF;
-      if (c[u] > 0) flag_seen |= (uint32_t)k0[u];
-      if (c[u] > 1) flag_seen |= (uint32_t)k1[u];
-    }
-#pragma unroll
-    for (int u = 0; u < NBATCH; ++u) {
-      const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
-      int maxc = c[u];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
-      if (maxc > 0) sel.push(k0[u], c[u] > 0);
-      if (maxc > 1) sel.push(k1[u], c[u] > 1);
-      for (int t = 2; t < maxc; ++t) {
-        const bool valid = t < c[u];
-        const u64 kk = valid ? src[t] : KEY_INF;
-        if (valid) flag_seen |= (uint32_t)kk;
-        sel.push(kk, valid);
-      }
-    }
+  } else {
+    sweep([&](u64 kk, bool v) { sel.push(kk, v); }, 0, 64 * NBATCH, flag_seen);
   }
   sel.finish();
   if (a.ablate & 8) {
     if (lane < k) a.out_ids[(size_t)q * k + lane] = (int32_t)sel.acc[0];
     if (lane == 0) sh_n = 0;
-    __syncthreads();
     __syncthreads();
     return;
   }
@@ -948,7 +1004,6 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
         sh_n = 0;
       }
       __syncthreads();
-      __syncthreads();
       return;
     }
     if (!all_in && !any_flag) {
@@ -959,6 +1014,37 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
       }
       queued = __popcll(in_mask);
       __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // More qualifying rows than were kept (a dense neighbourhood: hundreds of rows within E of the 2k-th smallest bound --
+  // common for batches over the flat PQ table): all waves collect them, then the usual rounds of NC rows.  Only if
+  // even that queue overflows does wave 0 walk the regions alone (below).
+  auto round4 = [&](int n1) {     // the first n1 <= NC queue entries, refined by the four waves together
+    if (lane == 0) sh_n = n1;
+    __syncthreads();
+    tile_work(0, sq, n1);
+    __syncthreads();
+    finalize(n1);
+  };
+  if (NWV > 1 && revisit) {
+    if (lane == 0) { sh_T = T_bits; bq_n = 0; sh_n = -1; }
+    __syncthreads();
+    collect();
+    __syncthreads();
+    const int cnt = bq_n;
+    if (cnt <= BQ) {
+      revisit = false;
+      for (int base = 0; base < cnt; base += NC) {
+        const int n = cnt - base < NC ? cnt - base : NC;
+        if (lane < n) {
+          const u64 kk = bq_key[base + lane];
+          cq_key[lane] = kk;
+          cq_cell[lane] = a.blk_cell[((uint32_t)kk & 0x7fffffffu) >> 6];
+        }
+        queued = n;
+        __builtin_amdgcn_wave_barrier();
+        if (!(a.ablate & 1)) round4(n); else queued = 0;
+      }
     }
   }
   for (int jb = 0; revisit && jb < R; jb += 64) {
@@ -976,14 +1062,12 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     }
   }
   if (a.ablate & 1) queued = 0;
-  // the normal case's rows (at most NC of them) are refined by the four waves together
+  // the queued rows are refined by the four waves together, NC per round (normally one round: <= NC rows; a batch over
+  // the flat PQ table has 20 .. 60 rows within E of its 2k-th smallest bound)
   if (NWV > 1) {
-    const int n1 = revisit ? 0 : (queued < NC ? queued : NC);
-    if (lane == 0) sh_n = n1;
-    __syncthreads();
-    if (n1 > 0) tile_work(0, sq, n1);
-    __syncthreads();
-    if (n1 > 0) finalize(n1);
+    while (queued > 0) round4(queued < NC ? queued : NC);
+    if (lane == 0) sh_n = 0;
+    __syncthreads();                         // (the other waves leave)
   }
   while (queued > 0) refine(queued < NC ? queued : NC);
   sel2.finish();

@@ -175,6 +175,10 @@ class _Index:
         cb = _f32(codebook)
         _check(self.lib.freddy_gpu_update_codebook(self.h, _p(cb)))
 
+    def bound_violations(self):
+        """Rows of the filter + refine scan's exact stage whose distance left the proven bracket (must be 0)."""
+        return int(self.lib.freddy_gpu_filter_bound_violations(self.h))
+
     def set_option(self, name, value):
         """Tuning / debug switch of this pinned index (include/freddy_gpu.h: freddy_gpu_set_option)."""
         _check(self.lib.freddy_gpu_set_option(self.h, name.encode(), int(value)))
@@ -294,10 +298,6 @@ class IVFIndex(_Index):
         n, r = C.c_int64(0), C.c_int64(0)
         _check(self.lib.freddy_gpu_last_probed_cells(self.h, C.byref(n), C.byref(r)))
         return n.value, r.value
-
-    def bound_violations(self):
-        """Rows of the filter + refine scan's exact stage whose distance left the proven bracket (must be 0)."""
-        return int(self.lib.freddy_gpu_filter_bound_violations(self.h))
 
     def coarse_bound_checked(self):
         return int(self.lib.freddy_gpu_coarse_bound_checked(self.h))

@@ -815,3 +815,40 @@ def test_scan_share_gives_the_same_lists(gpu, oracle, share):
         util.assert_same_lists(got_i, got_d, exp, f"scan_share={share}")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+@pytest.mark.parametrize("K", [256, 1024])
+def test_pq_batch_through_the_cell_grouped_scan(gpu, oracle, K):
+    """Batches over the flat PQ table take the filter + refine scan over pseudo-lists of 4096 rows with zero centroids
+    (option pq_fused, automatic from 16 queries on): same lists as pq_search (freddy.c:28-152) for every k
+    the selection width admits, with the guard dist < sentinel biting, for a forced 3-query batch, with the path switched
+    off, and after rows were appended (the pseudo-lists are rebuilt).  1 % of the rows are duplicates: equal distances."""
+    N = 20000   # 4 full pseudo-lists + one of 3616 rows
+    t = util.pq_tables(N=N, K=K)
+    ot = oracle.pq_table(t["codebook"], t["ids"], t["codes"])
+    idx = gpu.PQIndex(t["codebook"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 40, seed=21)
+    qs[7] *= np.float32(20.0)   # a query farther than the sentinel 100.0 from everything: the empty list survives
+    for k in (1, 5, 32):
+        exp = np.stack([oracle.pq_search(ot, q, k) for q in qs])
+        for mode in (-1, 0):
+            idx.set_option("pq_fused", mode)
+            gi, gd = idx.search(qs, k, sentinel=100.0)
+            util.assert_same_lists(gi, gd, exp, f"pq batch K={K} k={k} pq_fused={mode}")
+            if k == 5:
+                assert (gi[7] == -1).all() and (gi[:7] >= 0).all()
+    idx.set_option("pq_fused", 1)
+    gi, gd = idx.search(qs[:3], 5, sentinel=100.0)
+    util.assert_same_lists(gi, gd, np.stack([oracle.pq_search(ot, q, 5) for q in qs[:3]]), "forced 3-query batch")
+    assert idx.bound_violations() == 0
+    # append: rows 20001.. with the codes of existing rows (more equal distances)
+    idx.set_option("pq_fused", -1)
+    extra = 700
+    new_ids = np.arange(N + 1, N + 1 + extra, dtype=np.int32)
+    new_codes = np.ascontiguousarray(t["codes"][100:100 + extra])
+    idx.append_rows(new_ids, codes=new_codes)
+    ot2 = oracle.pq_table(t["codebook"], np.concatenate([t["ids"], new_ids]), np.concatenate([t["codes"], new_codes]))
+    gi, gd = idx.search(qs, 5, sentinel=100.0)
+    util.assert_same_lists(gi, gd, np.stack([oracle.pq_search(ot2, q, 5) for q in qs]), "pq batch after append_rows")
+    assert idx.bound_violations() == 0
+    idx.close()
