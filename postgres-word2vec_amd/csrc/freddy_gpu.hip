@@ -220,7 +220,9 @@ struct freddy_gpu_index {
   // flat PQ table through the cell-grouped scan (pq_shadow_build): an IVF-shaped view of this table -- pseudo-lists of
   // 4096 consecutive rows, zero centroids -- that shares packed / codebook tables with its owner
   freddy_gpu_index* pq_shadow = nullptr;
+  freddy_gpu_index* pq_sub_view = nullptr; // the same for the rows of an "id IN (...)" subset, refreshed by every such call
   freddy_gpu_index* shadow_of = nullptr;   // set in the shadow: profile records and shared arrays belong to this index
+  DevBuf v_coarse, v_list_off, v_blk_off, v_blk_cell, v_pos, v_rterm;   // a shadow's own arrays (grown on demand)
   // workspaces: one per stream the caller searches on (searches on different streams may overlap)
   Workspace ws[FREDDY_MAX_WS];
   Workspace* last_ws = nullptr;   // of the most recent search (freddy_gpu_last_* read its counters)
@@ -277,12 +279,14 @@ static void free_index(freddy_gpu_index* ix) {
   if (ix->stream) (void)hipStreamSynchronize(ix->stream);
   for (Workspace& w : ix->ws) { if (w.used && w.owner) (void)hipStreamSynchronize(w.owner); w.release(); }
   if (ix->shadow_of) {   // a PQ table's IVF-shaped view: its own arrays only (packed, codebook tables and the stream are the owner's)
-    void* own[] = {ix->coarse, ix->rterm, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->pos};
-    for (void* p : own) if (p) (void)hipFree(p);
+    DevBuf* own[] = {&ix->v_coarse, &ix->v_list_off, &ix->v_blk_off, &ix->v_blk_cell, &ix->v_pos, &ix->v_rterm};
+    for (DevBuf* b : own) b->release();
+    if (ix->viol) (void)hipFree(ix->viol);
     delete ix;
     return;
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
+  if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
   void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
@@ -456,6 +460,7 @@ static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
     // batches over the flat table take the cell-grouped filter + refine scan (pq_shadow_build): its codebook-derived tables,
     // with "centroids" that are zero
     if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
+    if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
     if (ix->m == 12 && ix->S == 25 && ix->K <= FUSED_T * FUSED_E && ix->tune.filter_table_mb > 0) {
       std::vector<float> cmaxp((size_t)ix->m);
       for (int p = 0; p < ix->m; ++p) {
@@ -704,7 +709,10 @@ extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_
 }
 
 static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
-  if (ix && ix->pq_shadow) ix = ix->pq_shadow;
+  if (ix && (ix->pq_shadow || ix->pq_sub_view)) {   // a PQ handle: the counters of its two views
+    const int64_t a = ix->pq_shadow ? read_viol(ix->pq_shadow, which) : 0, b = ix->pq_sub_view ? read_viol(ix->pq_sub_view, which) : 0;
+    return (a < 0 || b < 0) ? -1 : a + b;
+  }
   if (!ix || !ix->viol) return 0;
   int32_t h[4] = {0, 0, 0, 0};
   if (hipSetDevice(ix->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
@@ -1488,54 +1496,67 @@ static bool pq_use_fused(const freddy_gpu_index* ix, int Q, int k) {
   return ix->tune.pq_fused > 0 || Q >= 16;
 }
 // survivor regions: 32 KiB per (query, pseudo-list) within the workspace budget; the buckets [lists][queries] within 256 MiB
-static int pq_fused_queries_per_chunk(const freddy_gpu_index* ix) {
-  const size_t lists = (size_t)((ix->n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+static int pq_fused_queries_per_chunk(const freddy_gpu_index* ix, int64_t n_blocks) {
+  const size_t lists = (size_t)((n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   size_t n = ((size_t)ix->tune.lut_budget_mb << 20) / (sizeof(u64) * lists * FUSED_NW * FUSED_RMAX * 64);
   n = std::min<size_t>(n, ((size_t)256 << 20) / (sizeof(int32_t) * lists));
   return (int)std::max<size_t>(16, std::min<size_t>(n, 1u << 16));
 }
 
+// An IVF-shaped view (*view; created on first use) of `n_rows` rows in `n_blocks` packed blocks: pseudo-lists, zero centroids,
+// row terms, ids.  Everything is enqueued on s; nothing is synchronised.
+static int pq_view_refresh(freddy_gpu_index* ix, freddy_gpu_index** view, hipStream_t s, const uint32_t* packed, const int32_t* pos,
+                           int64_t n_blocks, int64_t n_rows) {
+  freddy_gpu_index* fx = *view;
+  if (!fx) {
+    fx = new freddy_gpu_index();
+    fx->shadow_of = ix;
+    fx->kind = KIND_IVF; fx->device = ix->device; fx->stream = ix->stream; fx->n_cus = ix->n_cus;
+    fx->d = ix->d; fx->m = ix->m; fx->K = ix->K; fx->S = ix->S; fx->M2 = ix->M2;
+    if (hipMalloc((void**)&fx->viol, 4 * sizeof(int32_t)) != hipSuccess || hipMemset(fx->viol, 0, 4 * sizeof(int32_t)) != hipSuccess) {
+      free_index(fx);
+      return fail(FREDDY_E_NOMEM, "device allocation failed (PQ table as pseudo-lists)");
+    }
+    *view = fx;
+  }
+  fx->tune = ix->tune;
+  fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp;   // shared with the owner
+  fx->packed = const_cast<uint32_t*>(packed);
+  fx->N = n_rows; fx->n_blocks = n_blocks; fx->max_list_blocks = FUSED_UNIT_BLOCKS;
+  const int lists = (int)((n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
+  fx->C = lists;
+  const size_t slots = (size_t)n_blocks * 64;
+  if (fx->v_coarse.ensure(sizeof(float) * (size_t)lists * ix->d) || fx->v_list_off.ensure(sizeof(int32_t) * ((size_t)lists + 1)) ||
+      fx->v_blk_off.ensure(sizeof(int32_t) * ((size_t)lists + 1)) || fx->v_blk_cell.ensure(sizeof(int32_t) * (size_t)n_blocks) ||
+      fx->v_pos.ensure(sizeof(int32_t) * slots) || fx->v_rterm.ensure(sizeof(float) * slots))
+    return fail(FREDDY_E_NOMEM, "device allocation failed (PQ table as pseudo-lists)");
+  fx->coarse = fx->v_coarse.as<float>(); fx->list_off = fx->v_list_off.as<int32_t>(); fx->blk_off = fx->v_blk_off.as<int32_t>();
+  fx->blk_cell = fx->v_blk_cell.as<int32_t>(); fx->pos = fx->v_pos.as<int32_t>(); fx->rterm = fx->v_rterm.as<float>();
+  HIP_TRY(hipMemsetAsync(fx->coarse, 0, sizeof(float) * (size_t)lists * ix->d, s));
+  hipLaunchKernelGGL(pq_shadow_meta_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, pos, ix->ids, n_blocks, n_rows, lists,
+                     fx->list_off, fx->blk_off, fx->blk_cell, fx->pos);
+  hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, fx->packed, fx->blk_cell, fx->coarse, fx->cbR,
+                     fx->rterm, (int64_t)slots, fx->M2, fx->d, fx->m, fx->K, fx->S);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// the whole table's view: built once (and again after rows were appended or the codebook was replaced)
 static int pq_shadow_build(freddy_gpu_index* ix) {
   if (ix->pq_shadow) return 0;
-  freddy_gpu_index* fx = new freddy_gpu_index();
-  fx->shadow_of = ix;
-  fx->kind = KIND_IVF; fx->device = ix->device; fx->tune = ix->tune; fx->stream = ix->stream; fx->n_cus = ix->n_cus;
-  fx->d = ix->d; fx->m = ix->m; fx->K = ix->K; fx->S = ix->S; fx->M2 = ix->M2; fx->N = ix->N;
-  fx->n_blocks = ix->n_blocks; fx->max_list_blocks = FUSED_UNIT_BLOCKS;
-  const int lists = (int)((ix->n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
-  fx->C = lists;
-  fx->packed = ix->packed; fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp;   // shared
-  const size_t slots = (size_t)ix->n_blocks * 64;
-  int rc = 0;
-  if (hipMalloc((void**)&fx->coarse, sizeof(float) * (size_t)lists * ix->d) != hipSuccess ||
-      hipMalloc((void**)&fx->list_off, sizeof(int32_t) * ((size_t)lists + 1)) != hipSuccess ||
-      hipMalloc((void**)&fx->blk_off, sizeof(int32_t) * ((size_t)lists + 1)) != hipSuccess ||
-      hipMalloc((void**)&fx->blk_cell, sizeof(int32_t) * (size_t)ix->n_blocks) != hipSuccess ||
-      hipMalloc((void**)&fx->pos, sizeof(int32_t) * slots) != hipSuccess ||
-      hipMalloc((void**)&fx->viol, 4 * sizeof(int32_t)) != hipSuccess)
-    rc = fail(FREDDY_E_NOMEM, "device allocation failed (PQ table as pseudo-lists)");
-  if (!rc) {
-    hipStream_t s = ix->stream;
-    (void)hipMemsetAsync(fx->coarse, 0, sizeof(float) * (size_t)lists * ix->d, s);
-    (void)hipMemsetAsync(fx->viol, 0, 4 * sizeof(int32_t), s);
-    hipLaunchKernelGGL(pq_shadow_meta_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, ix->pos, ix->ids, ix->n_blocks,
-                       ix->N, lists, fx->list_off, fx->blk_off, fx->blk_cell, fx->pos);
-    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess) rc = fail(FREDDY_E_HIP, "building the PQ pseudo-lists failed");
+  if (int rc = pq_view_refresh(ix, &ix->pq_shadow, ix->stream, ix->packed, ix->pos, ix->n_blocks, ix->N)) {
+    if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
+    return rc;
   }
-  if (!rc) rc = refresh_row_terms(fx);
-  if (rc) { free_index(fx); return rc; }
-  fx->bytes = (int64_t)(sizeof(float) * (size_t)lists * ix->d + sizeof(int32_t) * (2 * ((size_t)lists + 1) + (size_t)ix->n_blocks + slots) + sizeof(float) * slots);
-  ix->bytes += fx->bytes;
-  ix->pq_shadow = fx;
+  HIP_TRY(hipStreamSynchronize(ix->stream));   // (searches may come in on other streams)
   return 0;
 }
 
 static int ivf_work_table(IvfRun& r, WorkTable& wt);
 static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt);
 
-static int pq_fused_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
+static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
                           int32_t* d_out_ids, float* d_out_dist) {
-  freddy_gpu_index* fx = ix->pq_shadow;
   fx->tune = ix->tune;
   Workspace* ws = workspace_for(fx, s);
   const int lists = fx->C, m = fx->m, K = fx->K;
@@ -1625,10 +1646,10 @@ extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_q
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ix->stream;
   if (pq_use_fused(ix, Q, k)) {
     if (int rc = pq_shadow_build(ix)) return rc;
-    const int qf = pq_fused_queries_per_chunk(ix);
+    const int qf = pq_fused_queries_per_chunk(ix, ix->n_blocks);
     for (int q0 = 0; q0 < Q; q0 += qf) {
       const int n = std::min(qf, Q - q0);
-      if (int rc = pq_fused_chunk(ix, s, d_queries + (size_t)q0 * ix->d, n, k, sentinel, d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k))
+      if (int rc = pq_fused_chunk(ix, ix->pq_shadow, s, d_queries + (size_t)q0 * ix->d, n, k, sentinel, d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k))
         return rc;
     }
     return FREDDY_OK;
@@ -1646,7 +1667,7 @@ extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_q
 // "WHERE id IN (...)" over the flat PQ table: unknown ids vanish, duplicates collapse, order = table
 // order; the rows' packed codes are gathered into a temporary one-list table (synchronises the stream).
 static int pq_subset(freddy_gpu_index* ix, hipStream_t s, const int32_t* subset_ids, int64_t n_subset, const int32_t** blk_off,
-                     const uint32_t** packed, const int32_t** pos, int64_t* n_blocks) {
+                     const uint32_t** packed, const int32_t** pos, int64_t* n_blocks, int64_t* n_rows_out = nullptr) {
   Workspace* ws = workspace_for(ix, s);
   std::vector<int32_t> rows;
   rows.reserve((size_t)n_subset);
@@ -1678,6 +1699,7 @@ static int pq_subset(freddy_gpu_index* ix, hipStream_t s, const int32_t* subset_
   *packed = ws->w_sub_packed.as<uint32_t>();
   *pos = ws->w_sub_pos.as<int32_t>();
   *n_blocks = nb;
+  if (n_rows_out) *n_rows_out = n_rows;
   return 0;
 }
 
@@ -1697,16 +1719,22 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   const int32_t* blk_off = ix->blk_off;
   const uint32_t* packed = ix->packed;
   const int32_t* pos = ix->pos;
-  int64_t n_blocks = ix->n_blocks;
+  int64_t n_blocks = ix->n_blocks, n_rows = ix->N;
   if (subset_ids)
-    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
-  const bool fused_path = !subset_ids && pq_use_fused(ix, Q, k);
-  if (fused_path) if (int rc = pq_shadow_build(ix)) return rc;
-  const int qc = fused_path ? pq_fused_queries_per_chunk(ix) : max_queries_per_chunk(ix, 1);
+    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks, &n_rows)) return rc;
+  // (a subset of at least one full pseudo-list: its gathered rows get a view of their own, refreshed on this stream)
+  const bool fused_path = pq_use_fused(ix, Q, k) && (!subset_ids || n_blocks >= FUSED_UNIT_BLOCKS);
+  freddy_gpu_index* view = nullptr;
+  if (fused_path && !subset_ids) { if (int rc = pq_shadow_build(ix)) return rc; view = ix->pq_shadow; }
+  if (fused_path && subset_ids) {
+    if (int rc = pq_view_refresh(ix, &ix->pq_sub_view, s, packed, pos, n_blocks, n_rows)) return rc;
+    view = ix->pq_sub_view;
+  }
+  const int qc = fused_path ? pq_fused_queries_per_chunk(ix, n_blocks) : max_queries_per_chunk(ix, 1);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     if (fused_path) {
-      if (int rc = pq_fused_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel,
+      if (int rc = pq_fused_chunk(ix, view, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel,
                                   ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k))
         return rc;
       continue;
@@ -1740,9 +1768,9 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
   const int32_t* blk_off = ix->blk_off;
   const uint32_t* packed = ix->packed;
   const int32_t* pos = ix->pos;
-  int64_t n_blocks = ix->n_blocks;
+  int64_t n_blocks = ix->n_blocks, n_rows = ix->N;
   if (subset_ids)
-    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
+    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks, &n_rows)) return rc;
   (void)blk_off;
   if (n_blocks == 0) return FREDDY_OK;
   if (ws->w_q.ensure(sizeof(float) * (size_t)G * d) || ws->w_lut.ensure(sizeof(float) * (size_t)G * lutN) ||

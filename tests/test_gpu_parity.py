@@ -852,3 +852,25 @@ def test_pq_batch_through_the_cell_grouped_scan(gpu, oracle, K):
     util.assert_same_lists(gi, gd, np.stack([oracle.pq_search(ot2, q, 5) for q in qs]), "pq batch after append_rows")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+def test_pq_subset_batch_through_the_cell_grouped_scan(gpu, oracle):
+    """pq_search_in_batch (freddy.c:414-653) with an input set of at least one pseudo-list: the gathered rows get a view of
+    their own (pseudo-lists, row terms, ids; refreshed by every call) and the batch takes the filter + refine scan.  Same
+    lists with the path switched off, for a second call with a different set, and for a set below 4096 rows (old kernels)."""
+    N = 20000
+    t = util.pq_tables(N=N, K=256)
+    ot = oracle.pq_table(t["codebook"], t["ids"], t["codes"])
+    idx = gpu.PQIndex(t["codebook"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 24, seed=33)
+    rng = np.random.default_rng(5)
+    for n_sub, k in ((9000, 5), (4500, 17), (1500, 5)):
+        targets = rng.choice(np.arange(1, N + 1), size=n_sub, replace=False).astype(np.int32)
+        targets = np.concatenate([targets, targets[:40], np.array([N + 9, -2], np.int32)])   # duplicates + unknown ids
+        exp = oracle.pq_search_in_batch(ot, qs, k, targets, use_target_lists=True)
+        for mode in (-1, 0):
+            idx.set_option("pq_fused", mode)
+            gi, gd = idx.search(qs, k, sentinel=1000.0, subset_ids=targets)
+            util.assert_same_lists(gi, gd, exp, f"pq_search_in_batch n_sub={n_sub} k={k} pq_fused={mode}")
+    assert idx.bound_violations() == 0
+    idx.close()
