@@ -189,12 +189,12 @@ def run_dry(a, rank, world):
     return 0 if ok else 1
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, config=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
-    (profiles/latest_pmc.json, written by tools/profile_round.sh): 2 x FETCH_SIZE (gfx950 reports half of
-    wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  None if there is no such record."""
+    (profiles/latest_pmc.json, or latest_pmc_<config>.json for --config pq / join; written by tools/profile_round.sh):
+    2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  None if there is no such record."""
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{config}.json" if config else "latest_pmc.json")))
         if kernel in pmc:
             return int((2 * pmc[kernel].get("fetch_kib", 0) + pmc[kernel].get("write_kib", 0)) * 1024)
     except Exception:
@@ -206,7 +206,7 @@ def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
     ach = algorithmic_bytes / avg_s / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-         "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc passes of this command, 2*FETCH_SIZE + WRITE_SIZE)",
+         "traffic_source": "profiles/latest_pmc*.json (rocprofv3 --pmc passes of this command, 2*FETCH_SIZE + WRITE_SIZE)",
          "algorithmic_bytes_per_launch": int(algorithmic_bytes), "algorithmic_model": model,
          "avg_launch_us": round(avg_s * 1e6, 2)}
     if traffic:
@@ -254,6 +254,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     # library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of two
     # batches -- merge of batch i, cell selection of batch i+1 -- overlap.  --in-flight 1 is the strict sequence.
     n_fl = max(1, min(a.in_flight, 8))
+    a.warmup = max(a.warmup, n_fl)   # (every stream's workspace is allocated by its first search: never inside the timed region)
     _skipped = [torch.cuda.Stream(dev) for _ in range(a.stream_skip)]   # (tools/sweep_queues.sh: shifts the streams' hardware queues)
     streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
     with torch.cuda.stream(streams[0]):
@@ -479,7 +480,7 @@ def run_pq(a, rank, world, dev, dev_index):
     per_query = Q * (N * row_bytes + a.m * a.K * 4)
     roof = roofline(dom_kernel, avg_s, once,
                     "the code table once per batch (28 B per row) + one 48 KiB LUT, query and result per query",
-                    pmc_traffic(dom_kernel) if dom == "adc_scan" else None,
+                    pmc_traffic(dom_kernel, "pq"),
                     {"per_query_model": {"bytes_per_launch": int(per_query), "achieved": round(per_query / avg_s / 1e9, 1), "unit": "GB/s",
                                          "note": "SURVEY 8d: N*(m*2+4) = 28 MB per QUERY / kernel time (an equivalent rate: the "
                                                  "cell-grouped scan reads a 4096-row pseudo-list once per 16 queries; adc_scan_kernel, "

@@ -26,8 +26,15 @@ def test_config2_pq_search_1m(oracle):
     qs = x[torch.arange(0, N, N // 16, device=x.device)[:16]].cpu().numpy()
     gi, gd = idx.search(qs, 5, sentinel=100.0)
     exp = np.stack([oracle.pq_search(ot, q, 5) for q in qs])
-    util.assert_same_lists(gi, gd, exp, "config 2 pq_search")
+    util.assert_same_lists(gi, gd, exp, "config 2 pq_search (16 queries: the cell-grouped scan over 245 pseudo-lists)")
     assert (gi[:, 0] >= 1).all() and (np.diff(gd, axis=1) >= 0).all()
+    assert idx.bound_violations() == 0
+    idx.set_option("pq_fused", 0)
+    gi0, gd0 = idx.search(qs, 5, sentinel=100.0)
+    util.assert_same_lists(gi0, gd0, exp, "config 2 pq_search (LUT build + adc_scan_kernel)")
+    idx.set_option("pq_fused", -1)
+    gi1, gd1 = idx.search(qs[:1], 5, sentinel=100.0)
+    util.assert_same_lists(gi1, gd1, exp[:1], "config 2 pq_search, one query")
     # knn_in_pq: 5,000 targets
     targets = np.random.default_rng(1).choice(np.arange(1, N + 1), 5000, replace=False).astype(np.int32)
     gi, gd = idx.search(qs, 5, sentinel=1000.0, subset_ids=targets)
