@@ -36,6 +36,7 @@ static constexpr float COARSE_EPS = 1.2e-4f;
 static constexpr int COARSE_DP_ALIGN = 64;    // padded dimension count: whole blocks of 8 iterations x 8 dimensions (zeros)
 static constexpr int COARSE_TQ = 32;          // queries per MFMA tile (a workgroup = 32 queries x 128 cells)
 static constexpr int COARSE_MAX_CPAD = 1024;  // the plan keeps a query's approximate distances in registers: 16 per lane
+static constexpr int COARSE_STREAM_MAX_CPAD = 16384;   // beyond 1024 cells the plan streams them twice (minima, then candidates as a bitmap)
 
 // ---------------------------------------------------------------------------------------
 // a[q][j] for a 32-query x 128-cell tile per workgroup; wave w owns the 32 x 32 block of cells [32 w, 32 w + 32).
@@ -192,7 +193,11 @@ __device__ __forceinline__ uint32_t float_order_bits(float f) {   // monotone ma
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-template <int ABL>   // 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
+// STREAM = false: up to COARSE_MAX_CPAD cells, a query's approximate distances stay in registers between the threshold and
+// the candidate pass.  STREAM = true (up to COARSE_STREAM_MAX_CPAD cells): the distance row is read twice -- per-lane
+// minima first, then the candidates, kept as a BITMAP in LDS (2 KB; the i-th candidate = the i-th set bit, found through
+// per-word prefix counts) -- so any number of cells and of candidates fits the same footprint.
+template <int ABL, bool STREAM = false>   // ABL: 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
 __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args g) {   // (<= 128 registers: four workgroups per CU, what the LDS admits)
   const PlanArgs& a = g.p;
   constexpr int NW = PLAN2_NW, NCB = PLAN2_NCB, RC = NW * NCB;   // RC candidates per round
@@ -201,7 +206,10 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
   __shared__ float mins[NW][64];
   __shared__ int nws[NW];
   __shared__ float thr_s;
-  __shared__ uint16_t clw[NW][64 * NV];   // candidate cells of each wave's cell range, ascending
+  __shared__ uint16_t clw[STREAM ? 1 : NW][STREAM ? 1 : 64 * NV];   // candidate cells of each wave's cell range, ascending
+  constexpr int SW = STREAM ? COARSE_STREAM_MAX_CPAD / 32 : 1;
+  __shared__ uint32_t cbits[SW];           // STREAM: candidate bitmap over the cells
+  __shared__ uint16_t cpre[SW + 1];        // STREAM: candidates before word w
   __shared__ float cdist[PLAN2_PASS];     // exact distances of the pass's candidates
   __shared__ __attribute__((aligned(16))) float sq[RC * PLAN2_PITCH];   // row i % RC: candidate i of the round
   __shared__ __attribute__((aligned(16))) float qs[320];
@@ -220,12 +228,17 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
   // ---- A (all waves): this wave's 256 cells, masked; per-lane minimum; the query into LDS ----
   float av[NV];
   uint32_t uw[NV];
+  const int nvt = STREAM ? a.Cpad / (64 * NW) : NV;   // cells per lane of this wave (Cpad is a multiple of 256)
+  if constexpr (!STREAM) {
 #pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int j = (wave * NV + u) * 64 + lane;
-    const int jc = j < a.C ? j : a.C - 1;
-    av[u] = drow[jc];
-    uw[u] = used[jc >> 5];
+    for (int u = 0; u < NV; ++u) {
+      const int j = (wave * NV + u) * 64 + lane;
+      const int jc = j < a.C ? j : a.C - 1;
+      av[u] = drow[jc];
+      uw[u] = used[jc >> 5];
+    }
+  } else {
+    for (int i = threadIdx.x; i < SW; i += 64 * NW) cbits[i] = 0u;
   }
   const int d4n = d >> 2;   // (d % 4 == 0, d <= 320)
   {
@@ -234,13 +247,31 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
     if ((int)threadIdx.x < d4n) *reinterpret_cast<float4*>(qs + 4 * threadIdx.x) = qreg;
   }
   float mn = INF;
+  // the masked value of cell j: INF = not a candidate (past the end / already probed), -INF = NaN (always one)
+  auto masked = [&](int j) -> float {
+    const int jc = j < a.C ? j : a.C - 1;
+    const float v = drow[jc];
+    const uint32_t w = used[jc >> 5];
+    const bool valid = j < a.C && !((w >> (j & 31)) & 1u);
+    return !valid ? INF : (v == v ? v : -INF);
+  };
+  if constexpr (!STREAM) {
 #pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const int j = (wave * NV + u) * 64 + lane;
-    const bool valid = j < a.C && !((uw[u] >> (j & 31)) & 1u);
-    if (!valid) av[u] = INF;
-    if (av[u] == av[u]) mn = fminf(mn, av[u]);
-    else av[u] = -INF;                          // NaN (non-finite table entries): always a candidate, never a threshold
+    for (int u = 0; u < NV; ++u) {
+      const int j = (wave * NV + u) * 64 + lane;
+      const bool valid = j < a.C && !((uw[u] >> (j & 31)) & 1u);
+      if (!valid) av[u] = INF;
+      if (av[u] == av[u]) mn = fminf(mn, av[u]);
+      else av[u] = -INF;                          // NaN (non-finite table entries): always a candidate, never a threshold
+    }
+  } else {
+    for (int u0 = 0; u0 < nvt; u0 += 4) {         // (four loads in flight)
+      float v4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v4[t] = u0 + t < nvt ? masked((wave * nvt + u0 + t) * 64 + lane) : INF;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) if (v4[t] > -INF) mn = fminf(mn, v4[t]);
+    }
   }
   mins[wave][lane] = mn;
   tick(0);
@@ -273,18 +304,63 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
   // ---- C (all waves): this wave's candidates, ascending, into its own list ----
   const float thr = thr_s;
   int n_mine = 0;
+  if constexpr (!STREAM) {
 #pragma unroll
-  for (int u = 0; u < NV; ++u) {
-    const bool c = av[u] <= thr && av[u] < INF;
-    const u64 mask = __ballot(c);
-    if (mask != 0ull) {
-      if (c) clw[wave][n_mine + lanes_below(mask)] = (uint16_t)((wave * NV + u) * 64 + lane);
-      n_mine += __popcll(mask);
+    for (int u = 0; u < NV; ++u) {
+      const bool c = av[u] <= thr && av[u] < INF;
+      const u64 mask = __ballot(c);
+      if (mask != 0ull) {
+        if (c) clw[wave][n_mine + lanes_below(mask)] = (uint16_t)((wave * NV + u) * 64 + lane);
+        n_mine += __popcll(mask);
+      }
+    }
+  } else {
+    for (int u0 = 0; u0 < nvt; u0 += 4) {
+      float v4[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v4[t] = u0 + t < nvt ? masked((wave * nvt + u0 + t) * 64 + lane) : INF;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool c = v4[t] <= thr && v4[t] < INF;
+        const u64 mask = __ballot(c);
+        if (mask != 0ull) {
+          if (lane == 0) {
+            const int w0 = ((wave * nvt + u0 + t) * 64) >> 5;
+            cbits[w0] = (uint32_t)mask;
+            cbits[w0 + 1] = (uint32_t)(mask >> 32);
+          }
+          n_mine += __popcll(mask);
+        }
+      }
     }
   }
   if (lane == 0) nws[wave] = n_mine;
   tick(2);
   __syncthreads();
+  if constexpr (STREAM) {   // candidates before every word of the bitmap: wave w scans words [w * wpw, (w + 1) * wpw), two per lane and step
+    const int nwords = a.Cpad >> 5, wpw = nwords / NW;
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) before += (w < wave) ? nws[w] : 0;
+    for (int b0 = 0; b0 < wpw; b0 += 128) {
+      const int w0 = wave * wpw + b0 + 2 * lane;
+      const bool in = b0 + 2 * lane < wpw;
+      const int c0 = in ? __popc(cbits[w0]) : 0, c1 = in ? __popc(cbits[w0 + 1]) : 0;
+      int inc = c0 + c1;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+      }
+      if (in) {
+        cpre[w0] = (uint16_t)(before + inc - c0 - c1);
+        cpre[w0 + 1] = (uint16_t)(before + inc - c1);
+      }
+      before += __shfl(inc, 63, 64);
+    }
+    if (threadIdx.x == 0) cpre[nwords] = (uint16_t)(nws[0] + nws[1] + nws[2] + nws[3]);
+    __syncthreads();
+  }
   // the query's candidate list = the four lists one after the other: candidate i lives in list wi(i) at i - off[wi]
   int off[NW + 1];
   off[0] = 0;
@@ -292,6 +368,22 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
   for (int w = 0; w < NW; ++w) off[w + 1] = off[w] + nws[w];
   const int n_all = off[NW];
   auto cell_of = [&](int i) -> int {
+    if constexpr (STREAM) {   // the i-th set bit of the bitmap: the word by bisection over the prefix counts, then the bit
+      int lo = 0, hi = a.Cpad >> 5;          // invariant: cpre[lo] <= i < cpre[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int)cpre[mid] <= i) lo = mid; else hi = mid;
+      }
+      uint32_t x = cbits[lo];
+      int r = i - (int)cpre[lo], pos = 0;
+#pragma unroll
+      for (int sh = 16; sh > 0; sh >>= 1) {
+        const uint32_t lowmask = (1u << sh) - 1u;
+        const int c = __popc(x & lowmask);
+        if (r >= c) { r -= c; x >>= sh; pos += sh; } else x &= lowmask;
+      }
+      return (lo << 5) + pos;
+    }
     int w = 0;
 #pragma unroll
     for (int t = 1; t < NW; ++t) w += i >= off[t] ? 1 : 0;

@@ -996,7 +996,10 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
     Plan2Args g;
     g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ws->w_qn2.as<float>(); g.item_dist = pa.item_dist;
     g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all; g.prof = nullptr;
-    timed_launch(ix, s, "probe_plan", [&] { hipLaunchKernelGGL(probe_plan2_kernel<0>, dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g); });
+    timed_launch(ix, s, "probe_plan", [&] {
+      if (ix->Cpad <= COARSE_MAX_CPAD) hipLaunchKernelGGL((probe_plan2_kernel<0, false>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);
+      else hipLaunchKernelGGL((probe_plan2_kernel<0, true>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);   // (more than 1024 cells: streamed)
+    });
   } else
   timed_launch(ix, s, "probe_plan", [&] {
     switch (PV) {
@@ -1286,7 +1289,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : ix->tune.scan_kernel == 5 ? 5 : 4;
   r.tiled = Q >= 32;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
-  r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
+  r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_STREAM_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
   // CU partition: only for the filter + refine scan, whose persistent workgroups take whole CUs
   hipStream_t s_caller = s;
   r.s_scan = s;

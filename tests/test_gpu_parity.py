@@ -874,3 +874,41 @@ def test_pq_subset_batch_through_the_cell_grouped_scan(gpu, oracle):
             util.assert_same_lists(gi, gd, exp, f"pq_search_in_batch n_sub={n_sub} k={k} pq_fused={mode}")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+@pytest.mark.parametrize("kind", ["plain", "duplicate_centroids", "refine_all"])
+def test_coarse_filter_refine_beyond_1024_cells(gpu, oracle, kind, monkeypatch):
+    """More than 1024 coarse cells: the plan streams a query's approximate distances twice (per-lane minima, then the
+    candidates as a bitmap in LDS; probe_plan2_kernel<0, true>) instead of holding them in registers.  C = 1500 cells over
+    30 000 rows; identical centroids (exactly equal coarse distances, hundreds of candidates when every cell is refined),
+    probing rounds beyond the first, W up to 16; against the oracle and the all-exact coarse kernel."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    from freddy_amd import index_build as ib
+    N, C = 30000, 1500
+    x = util.corpus(N)
+    t = dict(ib.build_ivf_index(x, C=C, m=12, K=256, train_size=8000, iters=3, seed=4))
+    coarse = t["coarse"].copy()
+    if kind == "duplicate_centroids":
+        coarse[700] = coarse[3]
+        coarse[1499] = coarse[3]
+        coarse[1100] = coarse[1024]
+    t["coarse"] = coarse
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 70, seed=3)
+    for k, W, rule, sent in ((5, 10, 0, 1000.0), (30, 3, 0, 1000.0), (10, 1, 1, 100.0), (5, 16, 0, 1000.0)):
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        idx.set_option("coarse_approx", 1)
+        if kind == "refine_all":
+            idx.set_option("coarse_refine_all", 1)
+            before = idx.coarse_bound_checked()
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"{kind}: streamed plan k={k} W={W} rule={rule}")
+        if kind == "refine_all":
+            assert idx.coarse_bound_checked() - before >= len(qs) * C
+            idx.set_option("coarse_refine_all", 0)
+        idx.set_option("coarse_approx", 0)
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"{kind}: all-exact coarse kernel k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0
+    idx.close()
