@@ -1771,9 +1771,9 @@ extern "C" int freddy_gpu_grouping_pq(freddy_gpu_index_t* ix, const float* group
   const int32_t* blk_off = ix->blk_off;
   const uint32_t* packed = ix->packed;
   const int32_t* pos = ix->pos;
-  int64_t n_blocks = ix->n_blocks, n_rows = ix->N;
+  int64_t n_blocks = ix->n_blocks;
   if (subset_ids)
-    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks, &n_rows)) return rc;
+    if (int rc = pq_subset(ix, s, subset_ids, n_subset, &blk_off, &packed, &pos, &n_blocks)) return rc;
   (void)blk_off;
   if (n_blocks == 0) return FREDDY_OK;
   if (ws->w_q.ensure(sizeof(float) * (size_t)G * d) || ws->w_lut.ensure(sizeof(float) * (size_t)G * lutN) ||
