@@ -52,3 +52,40 @@ def test_soak_random_index(gpu, oracle, seed):
                                                     f"k={k} W={W} rule={rule}")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_soak_random_pq_table(gpu, oracle, seed):
+    """Batches over random flat PQ tables (tools/soak_pq.py with a fixed seed budget): sizes around the pseudo-list
+    boundaries, duplicate-heavy code pools, both paths, subsets."""
+    rng = np.random.default_rng(5000 + seed)
+    d, m = 300, 12
+    K = int(rng.choice([16, 64, 256, 1024]))
+    N = int(rng.choice([60, 4095, 4096, 4097, 9000, 40000, 70000]))
+    codebook = (rng.standard_normal((m, K, 25)) * 0.3).astype(np.float32)
+    ids = (np.arange(N) * 2 + 5).astype(np.int32)
+    n_distinct = int(rng.choice([1, 7, 300, 100000]))
+    pool = rng.integers(0, K, size=(n_distinct, m)).astype(np.int16)
+    codes = pool[rng.integers(0, n_distinct, size=N)]
+    ot = oracle.pq_table(codebook, ids, codes)
+    idx = gpu.PQIndex(codebook, ids, codes)
+    Q = int(rng.choice([16, 17, 48, 130]))
+    qs = (0.5 * rng.standard_normal((Q, d))).astype(np.float32)
+    if seed % 4 == 0:
+        qs[0] *= np.float32(40.0)      # beyond the sentinel 100.0
+    for k in (1, 5, 32):
+        exp = np.stack([oracle.pq_search(ot, q, k) for q in qs])
+        for mode in (1, 0):
+            idx.set_option("pq_fused", mode)
+            gi, gd = idx.search(qs, k, sentinel=100.0)
+            util.assert_same_lists(gi, gd, exp, f"seed={seed} K={K} N={N} Q={Q} k={k} pq_fused={mode}")
+    if N >= 9000:
+        sub = rng.choice(ids, size=int(rng.choice([4200, 6000])), replace=False).astype(np.int32)
+        sub = np.concatenate([sub, sub[:30], np.array([2, 4], np.int32)])
+        exp = oracle.pq_search_in_batch(ot, qs, 5, sub, use_target_lists=True)
+        for mode in (-1, 0):
+            idx.set_option("pq_fused", mode)
+            gi, gd = idx.search(qs, 5, sentinel=1000.0, subset_ids=sub)
+            util.assert_same_lists(gi, gd, exp, f"seed={seed} subset K={K} N={N} Q={Q} pq_fused={mode}")
+    assert idx.bound_violations() == 0
+    idx.close()

@@ -37,7 +37,7 @@ for seed in range(seeds):
     idx = gpu.IVFIndex(coarse, codebook, list_off, ids_sorted, codes)
     Q = int(rng.choice([1, 40, 300, 700]))
     qs = (coarse[rng.integers(0, C, size=Q)] + 0.2 * rng.standard_normal((Q, d))).astype(np.float32)
-    for variant in (4, 3):
+    for variant in (5, 4, 3):
         idx.set_option("fused_kernel", variant)
         for k, W in [(1, 1), (5, min(3, C)), (32, min(C, 12))]:
             for rule, sent in [(0, 1000.0), (1, 100.0)]:
