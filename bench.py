@@ -279,7 +279,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         qps = world * q_local * a.steps / dt
         gather_ok = verify_gather(pg, rank, world)
         # the same steps strictly one after the other (one stream): the latency of a batch
-        time.sleep(0.01)   # (the library counts the streams that searched within the last 2 ms as batches in flight)
+        time.sleep(0.012)  # (the library counts the streams that searched within the last 5 ms as batches in flight)
         counter[0] = 0
         step1 = step_on(1)
         dt1, _ = sharded_steps(step1, pg, a.steps, 2, lambda: torch.cuda.synchronize(dev), world)

@@ -262,7 +262,7 @@ int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
 /* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
  * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (5 filter +
  * refine with int16 slabs, 4 the same with fp32 slabs, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
- * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "scan_share" (the persistent scan takes n_cus / share CUs; 0 = auto: the streams that searched on the handle within the last 2 ms, i.e. the batches in flight; 1 = the whole chip), "pq_fused" (batches over the flat PQ table through the cell-grouped filter + refine scan over pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "merge_waves" (waves per query in the merge: 4, 1, or 0 = four for one batch at a time, one with batches in flight), "partition_cus" (R > 0: a batch's small kernels on a stream masked to R CUs, its scan on a stream masked to the rest; R < 0: only the scan masked; 0 = off, the default -- measured slower), "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
+ * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "scan_share" (the persistent scan takes n_cus / share CUs; 0 = auto: the streams that searched on the handle within the last 5 ms, i.e. the batches in flight; 1 = the whole chip), "pq_fused" (batches over the flat PQ table through the cell-grouped filter + refine scan over pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "merge_waves" (waves per query in the merge: 4, 1, or 0 = four for one batch at a time, one with batches in flight), "partition_cus" (R > 0: a batch's small kernels on a stream masked to R CUs, its scan on a stream masked to the rest; R < 0: only the scan masked; 0 = off, the default -- measured slower), "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
  * "coarse_refine_all", "fused_prof", "debug_surv",
  * "lut_budget_mb".  No setting changes a result. */
 int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);

@@ -78,7 +78,7 @@ struct Tuning {
   int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
   int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
   int scan_share = 0;          // FREDDY_GPU_SCAN_SHARE: the persistent scan takes n_cus / share CUs; 0 = auto: share = the streams that searched on
-                               // this handle within the last 2 ms (batches in flight), 1 = always the whole chip
+                               // this handle within the last 5 ms (batches in flight), 1 = always the whole chip
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
@@ -1159,6 +1159,8 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     const bool many_regions = (size_t)r.W * r.upi * FUSED_NW > 256;
     if (!many_regions && (r.share > 1 ? ix->tune.merge_waves != 4 : ix->tune.merge_waves == 1))
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 1>), dim3(r.n_active), dim3(64), 0, s, mr);
+    else if (many_regions)
+      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 4, true>), dim3(r.n_active), dim3(256), 0, s, mr);
     else
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 4>), dim3(r.n_active), dim3(256), 0, s, mr);
   });
@@ -1271,7 +1273,7 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
     const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ws->last_use_ms = now;
     int active = 0;
-    for (const Workspace& w : ix->ws) active += (w.used && now - w.last_use_ms < 2.0) ? 1 : 0;
+    for (const Workspace& w : ix->ws) active += (w.used && now - w.last_use_ms < 5.0) ? 1 : 0;
     r.share = ix->tune.scan_share > 0 ? ix->tune.scan_share : std::max(1, active);
   }
   // FREDDY_FOUND_BATCH_UDF = the accepted-rows rule + the batch UDF's cell limit (argmin from minDist = 1000,
@@ -1572,7 +1574,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
     const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
     ws->last_use_ms = now;
     int active = 0;
-    for (const Workspace& w : fx->ws) active += (w.used && now - w.last_use_ms < 2.0) ? 1 : 0;
+    for (const Workspace& w : fx->ws) active += (w.used && now - w.last_use_ms < 5.0) ? 1 : 0;
     r.share = ix->tune.scan_share > 0 ? ix->tune.scan_share : std::max(1, active);
   }
   const size_t items = (size_t)Q * lists;

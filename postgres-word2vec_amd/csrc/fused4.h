@@ -729,8 +729,12 @@ struct MergeRefineArgs {
   uint32_t ablate;   // timing experiments only (FREDDY_GPU_MERGE_ABLATE): 1 = skip the exact stage
 };
 
-template <int S, int M, int NWV>
+// MANY = true (with NWV = 4): the instantiation for queries with hundreds of survivor regions (a batch over the flat PQ
+// table: 245 pseudo-lists x 8 waves) -- the selection of the lower bounds split over the four waves, dense neighbourhoods
+// collected by all of them.  It needs 145 registers (three workgroups per CU); the IVFADC instantiation stays at 128.
+template <int S, int M, int NWV, bool MANY = false>
 __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineArgs a) {
+  static_assert(!MANY || NWV > 1, "the split selection needs the four waves");
   // NWV = 4: four waves per query.  Wave 0 selects and replays; the exact stage of the normal case (<= NC rows)
   // is spread over all four -- one tile of 64 (row, position) chains each -- because a wave spends it
   // waiting for two dependent round trips per tile: the shortest latency for ONE batch.
@@ -741,10 +745,10 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   constexpr int NC = NT * 64 / M;           // = 21 candidates
   constexpr int SQ = S + 1;                 // row pitch of the squared differences
   constexpr int M2 = M / 2;
-  __shared__ u64 stage_all[NWV][64];
+  __shared__ u64 stage_all[MANY ? NWV : 1][64];
   u64* const stage = stage_all[0];
-  __shared__ u64 part_key[NWV > 1 ? NWV : 1][64];        // pass 1 split over the waves (many survivor regions: the flat PQ table)
-  __shared__ uint32_t part_flag[NWV > 1 ? NWV : 1][64];
+  __shared__ u64 part_key[MANY ? NWV : 1][64];        // pass 1 split over the waves (many survivor regions: the flat PQ table)
+  __shared__ uint32_t part_flag[MANY ? NWV : 1][64];
   __shared__ float qs[M * S];
   __shared__ float sq[(NWV == 1 ? 1 : NT) * 64 * SQ];
   __shared__ float lutv[NT * 64];
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   __shared__ u64 cq_key[64 + NC];
   __shared__ int32_t cq_cell[64 + NC];
   __shared__ int sh_n;
-  constexpr int BQ = NWV > 1 ? 512 : 1;     // rows with d_lo <= T beyond the kept keys, collected by all waves (dense neighbourhoods)
+  constexpr int BQ = MANY ? 512 : 1;     // rows with d_lo <= T beyond the kept keys, collected by all waves (dense neighbourhoods)
   __shared__ u64 bq_key[BQ];
   __shared__ int bq_n;
   __shared__ uint32_t sh_T;
@@ -865,15 +869,15 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   // More regions than one sweep of a wave covers (W x chunks x 8 > 256: a batch over the flat PQ table "probes" hundreds of
   // pseudo-lists): every wave selects from a quarter of them -- the sweeps are chains of dependent round trips -- and
   // wave 0 merges the four selections.
-  const bool split1 = NWV > 1 && R > 64 * NBATCH;
-  if (split1) {
+  const bool split1 = MANY && R > 64 * NBATCH;
+  if (MANY && split1) {
     WaveSelect<1> sp;
-    sp.init(stage_all[wave], KEY_INF, LW);
+    sp.init(stage_all[MANY ? wave : 0], KEY_INF, LW);
     uint32_t fs = 0u;
     sweep([&](u64 kk, bool v) { sp.push(kk, v); }, wave * 64 * NBATCH, NWV * 64 * NBATCH, fs);
     sp.finish();
-    part_key[wave][lane] = sp.acc[0];
-    part_flag[wave][lane] = fs;
+    part_key[MANY ? wave : 0][lane] = sp.acc[0];
+    part_flag[MANY ? wave : 0][lane] = fs;
     __syncthreads();
   }
 
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     for (;;) {                               // rounds of <= NC rows until wave 0 announces none
       __syncthreads();                       // wave 0 has queued the rows to refine
       const int n1 = sh_n;
-      if (n1 < 0) { collect(); __syncthreads(); continue; }
+      if (MANY && n1 < 0) { collect(); __syncthreads(); continue; }
       if (n1 <= 0) break;
       if (wave * 64 < n1 * M) tile_work(wave, sq + wave * 64 * SQ, n1);
       __syncthreads();
@@ -909,9 +913,9 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   WaveSelect<1> sel;
   sel.init(stage, KEY_INF, LW);
   uint32_t flag_seen = 0u;
-  if (split1) {
+  if (MANY && split1) {
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) {
+    for (int w = 0; w < (MANY ? NWV : 1); ++w) {
       const u64 kk = part_key[w][lane];
       flag_seen |= part_flag[w][lane];
       sel.push(kk, kk != KEY_INF);
@@ -1026,7 +1030,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     __syncthreads();
     finalize(n1);
   };
-  if (NWV > 1 && revisit) {
+  if (MANY && revisit) {
     if (lane == 0) { sh_T = T_bits; bq_n = 0; sh_n = -1; }
     __syncthreads();
     collect();

@@ -802,7 +802,7 @@ def test_cu_partitioned_streams_give_the_same_lists(gpu, oracle, partition):
 @pytest.mark.parametrize("share", [0, 3, 8])
 def test_scan_share_gives_the_same_lists(gpu, oracle, share):
     """Option scan_share: the persistent scan on n_cus / share workgroups (0 = the streams that searched
-    within the last 2 ms).  The number of workgroups that pull work entries changes nothing in the lists."""
+    within the last 5 ms).  The number of workgroups that pull work entries changes nothing in the lists."""
     N = 60000
     t = util.ivf_tables(N=N, C=64, K=1024)
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
