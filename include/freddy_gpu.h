@@ -225,9 +225,10 @@ int freddy_gpu_update_codebook(freddy_gpu_index_t* index, const float* codebook 
  * them through freddy_gpu_ivfadc_search.  Single round only.
  *
  * Concurrency: everything a search writes besides its outputs lives in a workspace that belongs to the stream
- * the search is enqueued on (up to four streams per handle; a fifth takes over a slot after its owner has
+ * the search is enqueued on (up to eight streams per handle; a ninth takes over a slot after its owner has
  * drained).  Searches enqueued on DIFFERENT streams may therefore be in flight together on one handle --
- * bench.py keeps three batches going that way, the front end of batch i+1 beside the merge of batch i --;
+ * bench.py keeps four batches going that way; the library then gives each batch's persistent scan its share of
+ * the CUs (option scan_share) so that the scans run side by side and the small kernels fit in between --;
  * searches on the same stream are ordered by it.  Calls from several host threads must not share a stream.
  * The synchronous calls above use the library's own stream.  freddy_gpu_last_* report on the most recent call. */
 int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ivf, const float* d_queries, int32_t Q,
