@@ -912,3 +912,34 @@ def test_coarse_filter_refine_beyond_1024_cells(gpu, oracle, kind, monkeypatch):
         util.assert_same_lists(gi, gd, exp, f"{kind}: all-exact coarse kernel k={k} W={W} rule={rule}")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+def test_more_streams_than_workspaces(gpu, oracle):
+    """A handle keeps eight workspaces, one per searching stream; a ninth and tenth stream take over a slot after its
+    owner drained (workspace_for).  Ten streams, three rounds, interleaved: every stream's lists are the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    N = 60000
+    t = util.ivf_tables(N=N, C=64, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qa = util.queries_from_corpus(N, 280)
+    ns = 10
+    qs = [np.ascontiguousarray(np.roll(qa, 11 * i, axis=0)) for i in range(ns)]
+    exp = [oracle.ivfadc_search_many(ot, q, 5, 4, sentinel=1000.0, found_rule=0) for q in qs]
+    dq = [torch.from_numpy(q).to(dev) for q in qs]
+    res = [torch.zeros((2, 280, 5), dtype=torch.int32, device=dev) for _ in qs]
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    streams = [torch.cuda.Stream(dev) for _ in qs]
+    torch.cuda.synchronize(dev)
+    for rounds in range(3):
+        for i in range(ns):
+            with torch.cuda.stream(streams[i]):
+                res[i].zero_()
+                idx.search_dev(dq[i].data_ptr(), 280, 5, 4, 1000.0, gpu.FOUND_ROWS, res[i][0].data_ptr(), res[i][1].data_ptr(),
+                               st.data_ptr(), streams[i].cuda_stream)
+    torch.cuda.synchronize(dev)
+    for i in range(ns):
+        util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i} of {ns}")
+    assert idx.bound_violations() == 0
+    idx.close()
