@@ -896,7 +896,6 @@ struct SimRow { float sim; int qid; int tid; };
 // query = 1-based centroid index) for k = all tokens; target as 1-based token index
 static int cluster_knn(freddy_session_t* s, int method, const std::vector<float>& centroids, int kc, const int32_t* token_ids, int n,
                        std::vector<SimRow>& rows) {
-  const int d = s->d;
   rows.clear();
   std::vector<int32_t> ids((size_t)kc * n); std::vector<float> val((size_t)kc * n);
   if (method == 0) {          // knn_in_exact per centroid: cosine_similarity_bytea DESC (freddy--0.0.1.sql:456-476, 1041-1054)
