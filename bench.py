@@ -66,6 +66,9 @@ def parse(argv=None):
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="config ivfadc on one GPU also runs bounded passes of --config pq and --config join and reports them "
+                         "under other_configs; this switches that off")
     ap.add_argument("--stream-skip", type=int, default=0, help="experiment: create this many unused streams first")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU (config ivfadc): consecutive steps alternate between this many HIP streams, "
@@ -189,12 +192,18 @@ def run_dry(a, rank, world):
     return 0 if ok else 1
 
 
-def pmc_traffic(kernel, config=None):
+def pmc_traffic(kernel, config=None, shape=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
     (profiles/latest_pmc.json, or latest_pmc_<config>.json for --config pq / join; written by tools/profile_round.sh):
-    2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  None if there is no such record."""
+    2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  The file records the
+    workload shape it was taken on ("_shape"); None if there is no record or the shape differs from this run's."""
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{config}.json" if config else "latest_pmc.json")))
+        have = pmc.get("_shape")
+        if shape is not None and have is not None and any(have.get(k) != v for k, v in shape.items()):
+            return None
+        if shape is not None and have is None and shape != DEFAULT_SHAPES.get(config or "ivfadc"):
+            return None   # (files written before the shape was recorded were taken on the default workload)
         if kernel in pmc:
             return int((2 * pmc[kernel].get("fetch_kib", 0) + pmc[kernel].get("write_kib", 0)) * 1024)
     except Exception:
@@ -202,11 +211,16 @@ def pmc_traffic(kernel, config=None):
     return None
 
 
+DEFAULT_SHAPES = {"ivfadc": {"N": 3_000_000, "Q": 1024, "C": 1000, "nprobe": 10}, "pq": {"N": 1_000_000, "Q": 64},
+                  "join": {"N": 1_000_000, "Q": 5000}}
+
+
 def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
     ach = algorithmic_bytes / avg_s / 1e9
     r = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
-         "traffic_source": "profiles/latest_pmc*.json (rocprofv3 --pmc passes of this command, 2*FETCH_SIZE + WRITE_SIZE)",
+         "traffic_source": ("profiles/latest_pmc*.json (rocprofv3 --pmc passes of this command on this workload shape, 2*FETCH_SIZE + WRITE_SIZE)"
+                            if traffic else "no PMC pass on this workload shape"),
          "algorithmic_bytes_per_launch": int(algorithmic_bytes), "algorithmic_model": model,
          "avg_launch_us": round(avg_s * 1e6, 2)}
     if traffic:
@@ -240,21 +254,24 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=dev_index)
     log(rank, f"pinned {index.nbytes / 1e6:.1f} MB in {time.time() - t0:.1f}s")
 
-    # queries = indexed vectors themselves (ivfadc_batch_search takes ids), distinct per rank
+    # queries = indexed vectors themselves (ivfadc_batch_search takes ids), distinct per rank AND per stream: the
+    # batches in flight are different batches
+    n_fl = max(1, min(a.in_flight, 8))
     rng = np.random.default_rng(7 + rank)
-    qids = np.sort(rng.choice(np.arange(1, N + 1), size=q_local, replace=False)).astype(np.int64)
-    d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
+    qids = [np.sort(rng.choice(np.arange(1, N + 1), size=q_local, replace=False)).astype(np.int64) for _ in range(n_fl)]
+    d_qs = [x[torch.from_numpy(q - 1).to(dev)].contiguous() for q in qids]
     d_status = torch.zeros(4, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
     # Everything of a step -- the search kernels (through the C ABI, on this stream's handle) and the RCCL
     # gather -- is ordered on ONE explicit non-default stream, so the collective reads a shard's results
     # only after the search wrote them and the buffer is rewritten only after the collective read it.
     # (GPU_MAX_HW_QUEUES = 6 above: a hardware queue per stream plus spares for the default stream and RCCL.)
-    # Consecutive steps alternate between `in_flight` streams (each with its own result buffer and, inside the
-    # library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of two
-    # batches -- merge of batch i, cell selection of batch i+1 -- overlap.  --in-flight 1 is the strict sequence.
-    n_fl = max(1, min(a.in_flight, 8))
+    # Consecutive steps alternate between `in_flight` streams (each with its own query set, its own result buffer and,
+    # inside the library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of
+    # the batches overlap with the scans of the others.  --in-flight 1 is the strict sequence.
     a.warmup = max(a.warmup, n_fl)   # (every stream's workspace is allocated by its first search: never inside the timed region)
+    if a.steps < n_fl:
+        raise SystemExit(f"--steps must be at least --in-flight ({n_fl}): every stream's buffer is verified after the timed region")
     _skipped = [torch.cuda.Stream(dev) for _ in range(a.stream_skip)]   # (tools/sweep_queues.sh: shifts the streams' hardware queues)
     streams = [torch.cuda.Stream(dev) for _ in range(n_fl)]
     with torch.cuda.stream(streams[0]):
@@ -264,22 +281,35 @@ def run_ivfadc(a, rank, world, dev, dev_index):
 
     def step_on(n_streams):
         def step():
-            st = streams[counter[0] % n_streams]
+            i = counter[0] % n_streams
+            st = streams[i]
             counter[0] += 1
             with torch.cuda.stream(st):
                 res = pg.next_buffer()
-                index.search_dev(d_q.data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
+                index.search_dev(d_qs[i].data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
                                  res[1].data_ptr(), d_status.data_ptr(), st.cuda_stream)
                 pg.submit()
         return step
 
     if True:
+        # the *_dev contract: the caller states how many batches it keeps in flight (a scan takes n_cus / share CUs)
+        index.set_option("scan_share", n_fl)
         step = step_on(n_fl)
         dt, barrier = sharded_steps(step, pg, a.steps, a.warmup, lambda: torch.cuda.synchronize(dev), world)
         qps = world * q_local * a.steps / dt
         gather_ok = verify_gather(pg, rank, world)
-        # the same steps strictly one after the other (one stream): the latency of a batch
-        time.sleep(0.012)  # (the library counts the streams that searched within the last 5 ms as batches in flight)
+        # What the TIMED region left in every stream's result buffer (steps and buffers both advance round-robin, so
+        # buffer b was last written by the last timed step of stream b' = the step index modulo n_fl): kept here,
+        # compared bit for bit with the oracle below -- verify what is timed.
+        depth = max(2, n_fl)
+        total_steps = counter[0]
+        timed_results = []
+        for back in range(min(n_fl, a.steps)):
+            sidx = total_steps - 1 - back
+            timed_results.append((sidx % n_fl, pg.res[sidx % depth].clone()))
+        straggler = int(d_status[0].item())
+        # the same steps strictly one after the other (one stream, the scan on every CU): the latency of a batch
+        index.set_option("scan_share", 1)
         counter[0] = 0
         step1 = step_on(1)
         dt1, _ = sharded_steps(step1, pg, a.steps, 2, lambda: torch.cuda.synchronize(dev), world)
@@ -293,12 +323,15 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         index.profile_enable(False)
         prof_ov = {}
         if n_fl > 1:   # ... and with the batches in flight as in the timed region: durations under overlap
+            index.set_option("scan_share", n_fl)
             index.profile_enable(True)
             for _ in range(a.steps):
                 step()
             barrier()
             prof_ov = index.profile_read()
             index.profile_enable(False)
+            index.set_option("scan_share", 1)
+        counter[0] = 0
         step1()
         barrier()
         res_last, _ = pg.last()
@@ -306,20 +339,51 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     scanned_rows = index.last_scanned_rows()
     n_cells, cell_rows = index.last_probed_cells()
     bound_violations = index.bound_violations()   # self-check of the filter + refine scan (must be 0)
-    straggler = int(d_status[0].item())
 
     out = None
     if rank == 0:
-        # ---- the same batch through the synchronous host-buffer ABI (H2D of queries, D2H of results, one
-        # stream sync per call, stragglers re-run): reported beside `value`, never as `value`
-        h_q = d_q.cpu().numpy()
-        hi, hd = index.search(h_q, a.k, a.nprobe)
+        # ---- the host-buffer ABI (what pg/freddy_srf.c calls: queries in host memory, lists into host memory, one
+        # synchronous call per batch; inside: pinned staging, sub-batches of 1024 on up to four lanes, transfers
+        # overlapped with the neighbours' kernels): first-class numbers at three batch sizes, never `value`.
+        h_sets = [q.cpu().numpy() for q in d_qs]
+        dev_lists = {i: r for i, r in timed_results}
+        host_abi = {}
+        for mult in (1, 4, 8):
+            hq = np.ascontiguousarray(np.concatenate([h_sets[j % n_fl] for j in range(mult)]))
+            hi, hd = index.search(hq, a.k, a.nprobe)
+            reps = max(3, 24 // mult)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                hi, hd = index.search(hq, a.k, a.nprobe)
+            hdt = (time.perf_counter() - t0) / reps
+            same = True
+            for j in range(mult):   # the same bits as the timed region's device-resident lists of that query set
+                ref = dev_lists.get(j % n_fl)
+                if ref is None:
+                    continue
+                blk = slice(j * q_local, (j + 1) * q_local)
+                same = same and bool(np.array_equal(hi[blk], ref[0].cpu().numpy()) and
+                                     np.array_equal(hd[blk].view(np.uint32), ref[1].cpu().numpy().view(np.uint32)))
+            host_abi[f"Q{mult * q_local}"] = {"queries_per_s": round(mult * q_local / hdt, 1), "ms_per_call": round(1e3 * hdt, 4),
+                                             "same_results_as_device_path": same}
+        one = h_sets[0][:1]
+        index.search(one, a.k, a.nprobe)
         t0 = time.perf_counter()
-        for _ in range(10):
-            hi, hd = index.search(h_q, a.k, a.nprobe)
-        host_qps = 10 * q_local / (time.perf_counter() - t0)
-        host_same = bool(np.array_equal(hi, d_ids.cpu().numpy()) and
-                         np.array_equal(hd.view(np.uint32), d_dist.cpu().numpy().view(np.uint32)))
+        for _ in range(50):
+            index.search(one, a.k, a.nprobe)
+        host_abi["Q1"] = {"ms_per_call": round((time.perf_counter() - t0) / 50 * 1e3, 4),
+                          "note": "ONE query per call: the shape of the reference's ivfadc_search(bytea, int) SRF (freddy.c:174-393)"}
+        pb = gpu.PinnedBuffer((4 * q_local, 300))
+        pb.array[:] = np.concatenate([h_sets[j % n_fl] for j in range(4)])
+        index.search(pb.array, a.k, a.nprobe)
+        t0 = time.perf_counter()
+        for _ in range(6):
+            index.search(pb.array, a.k, a.nprobe)
+        host_abi[f"Q{4 * q_local}_pinned_queries"] = {"queries_per_s": round(6 * 4 * q_local / (time.perf_counter() - t0), 1),
+                                                       "note": "queries written into a freddy_gpu_host_alloc buffer: no staging copy"}
+        pb.close()
+        host_qps = host_abi[f"Q{q_local}"]["queries_per_s"]
+        host_same = all(v.get("same_results_as_device_path", True) for v in host_abi.values())
 
         row_bytes = a.m * 2 + 4
         per_query_bytes = scanned_rows * row_bytes + q_local * (300 * 4 + a.k * 8)          # SURVEY 8d, per query
@@ -344,7 +408,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                 "cell-grouped, as the reference's own loop (freddy.c:939-974 reads a probed cell's rows once per round and "
                 "offers each to every query of the cell): 28 B per row of every DISTINCT probed list + queries + results + "
                 "coarse and codebook tables once",
-                pmc_traffic(kname),
+                pmc_traffic(kname, None, {"N": N, "Q": q_local, "C": a.C, "nprobe": a.nprobe}),
                 {"lds_gather": {"achieved": round(lds, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(lds / LDS_PEAK_GBS, 5),
                                 "bytes_per_launch": int(lds_bytes),
                                 "note": f"the resource that binds this kernel's main loop: {slab_b} B of slab per (query, probed row, "
@@ -368,39 +432,50 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                  "note": f"the {index.nbytes / 1e6:.0f} MB index is Infinity-Cache (256 MiB) resident after first touch; a "
                          "non-resident corpus (N = 40 M) is measured in profiles/ (DESIGN.md 5.6)"})
 
-        # ---- recall@5 vs exact search, and parity of a sample against the oracle ---------------
+        # ---- recall@5 vs exact search (over every stream's batch of the TIMED region) -------------------------
         recall = None
         if not a.no_recall:
-            exact = ib.exact_topk(x, d_q, a.k)
-            recall = ib.recall_at_k(d_ids.cpu().numpy(), exact)
+            rec = [ib.recall_at_k(r[0].cpu().numpy(), ib.exact_topk(x, d_qs[i], a.k)) for i, r in timed_results]
+            recall = float(np.mean(rec))
 
+        # ---- CPU oracle: timed on a bounded sample; EVERY list the timed region left behind compared bit for bit ----
         cpu = None
+        timed_parity = None
         if a.cpu_sample > 0 and world == 1:   # reported at N=1 only
             from oracle.oracle import Oracle
             o = Oracle()
             ot = o.ivf_table(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"])
             ns = min(a.cpu_sample, q_local)
             cores = os.cpu_count() or 1
-            qs = d_q[:ns].cpu().numpy()
-            t0 = time.perf_counter()
-            exp = o.ivfadc_search_many(ot, qs, a.k, a.nprobe, sentinel=1000.0, found_rule=0, n_threads=cores)
-            cdt = time.perf_counter() - t0
-            got_i = d_ids[:ns].cpu().numpy()
-            got_d = d_dist[:ns].cpu().numpy()
-            parity = bool(np.array_equal(exp["id"], got_i) and
-                          np.array_equal(exp["dist"].view(np.uint32), got_d.view(np.uint32)))
+            timed_parity = {"buffers_checked": 0, "queries_checked": 0, "all_equal": True}
+            cdt = None
+            for i, r in sorted(timed_results):
+                nq = q_local if a.cpu_sample >= q_local else ns
+                qs = d_qs[i][:nq].cpu().numpy()
+                t0 = time.perf_counter()
+                exp = o.ivfadc_search_many(ot, qs, a.k, a.nprobe, sentinel=1000.0, found_rule=0, n_threads=cores)
+                if cdt is None:
+                    cdt, ns = time.perf_counter() - t0, nq
+                ok = bool(np.array_equal(exp["id"], r[0][:nq].cpu().numpy()) and
+                          np.array_equal(exp["dist"].view(np.uint32), r[1][:nq].cpu().numpy().view(np.uint32)))
+                timed_parity["buffers_checked"] += 1
+                timed_parity["queries_checked"] += nq
+                timed_parity["all_equal"] = timed_parity["all_equal"] and ok
+            parity = timed_parity["all_equal"]
             n1 = min(64, ns)   # one thread = one PostgreSQL backend
             t0 = time.perf_counter()
-            o.ivfadc_search_many(ot, qs[:n1], a.k, a.nprobe, sentinel=1000.0, found_rule=0, n_threads=1)
+            o.ivfadc_search_many(ot, d_qs[0][:n1].cpu().numpy(), a.k, a.nprobe, sentinel=1000.0, found_rule=0, n_threads=1)
             one_core = n1 / (time.perf_counter() - t0)
             cpu = {"value": round(ns / cdt, 2), "unit": "queries/s", "cores": cores, "kind": "port",
                    "value_1_core": round(one_core, 2),
-                   "sample": f"first {ns} of the {q_local} bench queries, same index, nprobe={a.nprobe}, k={a.k}",
+                   "sample": f"the first {ns} queries of one of the {n_fl} bench batches ({q_local} queries each), same index, nprobe={a.nprobe}, k={a.k}",
                    "loop": "oracle/fo_ivfadc_search_many: per query the W-probe loop of ivfadc_search (freddy.c:174-393: W best "
                            "cells, W LUTs, rows of the W lists merged by id, updateTopK), OpenMP over queries = one backend per "
                            "core; gcc -O2 without -march=native (PGXS defaults).  SPI / tuple / per-call table reload cost of the "
                            "real UDF is NOT included (README: ~0.01 s per query end to end)",
-                   "parity_with_gpu_on_sample": parity}
+                   "parity_with_gpu_on_sample": parity,
+                   "parity_scope": f"the result buffer every one of the {n_fl} in-flight streams held when the TIMED region ended "
+                                   f"({timed_parity['queries_checked']} queries, {n_fl} different batches), ids and distance bits"}
 
         out = {
             "metric": METRIC,
@@ -421,13 +496,16 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             "pipelining": {"batches_in_flight": n_fl, "serial_ms_per_step": round(1e3 * dt1 / a.steps, 4),
                            "serial_queries_per_s": round(world * q_local * a.steps / dt1, 1),
                            "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                           "note": "value = throughput with consecutive batches on alternating HIP streams (separate "
-                                   "workspaces; the library gives each batch's persistent scan n_cus / batches-in-flight "
-                                   "workgroups so the scans run side by side); serial_* = the same steps strictly one after "
-                                   "the other (the scan takes every CU)"},
-            "host_buffer_abi": {"queries_per_s": round(host_qps, 1), "same_results_as_device_path": host_same,
-                                "note": "freddy_gpu_ivfadc_search: H2D of the queries, D2H of the results, one stream sync, "
-                                        "extra probing rounds for stragglers -- per call"},
+                           "note": "value = throughput with consecutive batches (different query sets) on alternating HIP "
+                                   "streams, option scan_share = batches in flight (each batch's persistent scan takes n_cus / "
+                                   "scan_share workgroups so the scans run side by side); serial_* = the same steps strictly one "
+                                   "after the other (scan_share = 1: the scan takes every CU)"},
+            "timed_region_parity": timed_parity,
+            "host_buffer_abi": dict(host_abi, queries_per_s=round(host_qps, 1), same_results_as_device_path=host_same,
+                                    note="freddy_gpu_ivfadc_search, the call the PostgreSQL hosts make (pageable host buffers in and "
+                                         "out, synchronous): sub-batches of 1024 queries on up to four library-owned lanes with pinned "
+                                         "staging, H2D / D2H overlapped with the neighbours' kernels, extra probing rounds where the "
+                                         "host waits for a lane; queries_per_s = the 1024-query call"),
             "roofline": roof, "kernels": kern,
             "kernels_overlapped": {n: {"launches": l, "avg_us": round(1e3 * ms / max(l, 1), 2)} for n, (l, ms) in prof_ov.items()},
             "cpu_baseline": cpu,
@@ -480,7 +558,7 @@ def run_pq(a, rank, world, dev, dev_index):
     per_query = Q * (N * row_bytes + a.m * a.K * 4)
     roof = roofline(dom_kernel, avg_s, once,
                     "the code table once per batch (28 B per row) + one 48 KiB LUT, query and result per query",
-                    pmc_traffic(dom_kernel, "pq"),
+                    pmc_traffic(dom_kernel, "pq", {"N": N, "Q": Q}),
                     {"per_query_model": {"bytes_per_launch": int(per_query), "achieved": round(per_query / avg_s / 1e9, 1), "unit": "GB/s",
                                          "note": "SURVEY 8d: N*(m*2+4) = 28 MB per QUERY / kernel time (an equivalent rate: the "
                                                  "cell-grouped scan reads a 4096-row pseudo-list once per 16 queries; adc_scan_kernel, "
@@ -548,7 +626,7 @@ def run_join(a, rank, world, dev, dev_index):
     alg = rows * (30 * 2 + 4) + Q * (a.k * pvf * 300 * 4 + 300 * 4 + a.k * 8)   # codes + ids, PV vectors, query, result
     roof = roofline("join_query_kernel", kernel_s, alg,
                     "SURVEY 8d: sum over queries of the target rows in their cells x (m*2+4) B + k*pvf PV vectors (1200 B each) + query + result",
-                    pmc_traffic("join_query_kernel"),
+                    pmc_traffic("join_query_kernel", "join", {"N": N, "Q": Q}),
                     {"candidate_rows_per_call": int(rows), "iterations": track["iterations"],
                      "note": "the call is a host loop (alpha doubling, multi-index traversal in libm on the host cores): "
                              "the kernel is " + f"{100 * kernel_s / (dt / a.steps):.0f} % of a call"})
@@ -606,6 +684,21 @@ def main():
             dist.init_process_group(a.backend, rank=rank, world_size=world)
     if a.config == "ivfadc":
         out = run_ivfadc(a, rank, world, dev, dev_index)
+        if world == 1 and not a.no_other_configs and a.N is None and a.Q is None:
+            # BASELINE configs[1] and configs[3] beside the metric's configuration: bounded passes (a few seconds each)
+            import copy
+            other = {}
+            for cfg, fn in (("pq", run_pq), ("join", run_join)):
+                b = copy.copy(a)
+                b.config, b.steps, b.warmup = cfg, min(a.steps, 20), 3
+                try:
+                    torch.cuda.empty_cache()
+                    o = fn(b, rank, world, dev, dev_index)
+                    other[cfg] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline",
+                                                    "single_query_host_abi_ms", "track", "kernels") if k in o}
+                except Exception as e:   # the headline line must not be lost to a side measurement
+                    other[cfg] = {"error": f"{type(e).__name__}: {e}"}
+            out["other_configs"] = other
     elif a.config == "pq":
         out = run_pq(a, rank, world, dev, dev_index)
     else:

@@ -21,6 +21,7 @@
 #ifndef FREDDY_GPU_H
 #define FREDDY_GPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -121,6 +122,28 @@ int freddy_gpu_pq_search(freddy_gpu_index_t* pq, const float* queries, int32_t Q
 int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ivf, const float* queries, int32_t Q, int32_t k,
                              int32_t W, float sentinel, int32_t found_rule, int32_t* out_ids,
                              float* out_dist);
+
+/* How the host-buffer IVFADC call runs (the reference makes one synchronous call per batch, freddy.c:679-999): a batch
+ * larger than `pipeline_batch` (1024) queries is cut into equal sub-batches that go round-robin to up to four
+ * library-owned streams ("lanes"), each with pinned staging buffers: host copy of the sub-batch's queries into pinned
+ * memory -> asynchronous H2D -> round one of the search, the lanes' persistent scans sharing the CUs -> asynchronous D2H
+ * of the lists into pinned memory.  The host waits only when it needs a lane again and once per lane at the end; a
+ * sub-batch's (rare) further probing rounds run where the host waits for it.  Results do not depend on how a batch is cut.
+ *
+ * Query buffers obtained from freddy_gpu_host_alloc (pinned host memory) skip the staging copy: a host that decodes
+ * its bytea / array arguments can write the floats straight into such a buffer.  freddy_gpu_host_free releases it. */
+int freddy_gpu_host_alloc(void** out, size_t bytes);
+int freddy_gpu_host_free(void* p);
+
+/* Product-level multi-GPU (north_star: "partition queries across the 8 MI355X with a replicated index"): the ivf tables
+ * pinned on EVERY device of devices[0 .. n_devices) behind one handle.  freddy_gpu_ivfadc_search on such a handle splits
+ * the host batch contiguously over the devices (sizes differ by at most one; one host thread per device inside the
+ * call) -- queries are independent (freddy.c:835-982 keeps no cross-query state) and the lists land in the caller's
+ * host buffers, so no collective is needed.  The same device may be listed more than once (tests).  append_rows /
+ * update_codebook / set_option / the self-check counters act on every replica; the *_dev entry point, the profile and
+ * the freddy_gpu_last_* diagnostics act on devices[0] only.  freddy_gpu_replica_count: number of devices behind a handle. */
+int freddy_gpu_pin_ivf_multi(const freddy_ivf_desc* desc, const int* devices, int n_devices, freddy_gpu_index_t** out);
+int freddy_gpu_replica_count(const freddy_gpu_index_t* index);
 
 /* Body of ivpq_search_in (ivpq_search_in.c:61-699), the kNN-join.  Arguments are the
  * SRF's own (ivpq_search_in.c:168-208).  iterations_out (may be NULL) receives the
@@ -225,12 +248,14 @@ int freddy_gpu_update_codebook(freddy_gpu_index_t* index, const float* codebook 
  * them through freddy_gpu_ivfadc_search.  Single round only.
  *
  * Concurrency: everything a search writes besides its outputs lives in a workspace that belongs to the stream
- * the search is enqueued on (up to eight streams per handle; a ninth takes over a slot after its owner has
- * drained).  Searches enqueued on DIFFERENT streams may therefore be in flight together on one handle --
- * bench.py keeps four batches going that way; the library then gives each batch's persistent scan its share of
- * the CUs (option scan_share) so that the scans run side by side and the small kernels fit in between --;
- * searches on the same stream are ordered by it.  Calls from several host threads must not share a stream.
- * The synchronous calls above use the library's own stream.  freddy_gpu_last_* report on the most recent call. */
+ * the search is enqueued on (twelve slots per handle; with all taken a new stream takes over the least recently
+ * used one after the device has drained).  Searches enqueued on DIFFERENT streams may therefore be in flight
+ * together on one handle -- bench.py keeps four batches going that way.  The caller states how many with option
+ * "scan_share" (an explicit contract; the library does not guess it): a batch's persistent scan then takes
+ * n_cus / scan_share CUs so that the scans run side by side and the small kernels fit in between.  Searches on the
+ * same stream are ordered by it.  Host threads may call concurrently as long as they do not share a stream (the
+ * slot table and the profile map are locked).  The synchronous calls above use the library's own streams.
+ * freddy_gpu_last_* report on the most recent call. */
 int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ivf, const float* d_queries, int32_t Q,
                                  int32_t k, int32_t W, float sentinel, int32_t found_rule,
                                  int32_t* d_out_ids, float* d_out_dist, int32_t* d_status,
@@ -263,9 +288,10 @@ int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
 /* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
  * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (5 filter +
  * refine with int16 slabs, 4 the same with fp32 slabs, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
- * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "scan_share" (the persistent scan takes n_cus / share CUs; 0 = auto: the streams that searched on the handle within the last 5 ms, i.e. the batches in flight; 1 = the whole chip), "pq_fused" (batches over the flat PQ table through the cell-grouped filter + refine scan over pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "merge_waves" (waves per query in the merge: 4, 1, or 0 = four for one batch at a time, one with batches in flight), "partition_cus" (R > 0: a batch's small kernels on a stream masked to R CUs, its scan on a stream masked to the rest; R < 0: only the scan masked; 0 = off, the default -- measured slower), "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
+ * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "scan_share" (the batches the caller keeps in flight through the *_dev entry points, one stream each: a persistent scan takes n_cus / scan_share CUs; default 1 = the whole chip), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls: queries per sub-batch, 1024; sub-batches in flight, 1..4), "pq_fused" (batches over the flat PQ table through the cell-grouped filter + refine scan over pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "merge_waves" (waves per query in the merge: 4, 1, or 0 = four for one batch at a time, one with batches in flight), "partition_cus" (R > 0: a batch's small kernels on a stream masked to R CUs, its scan on a stream masked to the rest; R < 0: only the scan masked; 0 = off, the default -- measured slower), "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
  * "coarse_refine_all", "fused_prof", "debug_surv",
- * "lut_budget_mb".  No setting changes a result. */
+ * "lut_budget_mb".  No setting changes a result -- except "fused_ablate" / "merge_ablate", which switch parts of a kernel
+ * off for timing experiments (tools/ablate.sh) and are not for production use. */
 int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);
 
 /* Thread-local message of the last failing call; valid until the next call. */

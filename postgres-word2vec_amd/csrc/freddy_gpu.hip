@@ -77,8 +77,11 @@ struct Tuning {
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
   int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
   int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
-  int scan_share = 0;          // FREDDY_GPU_SCAN_SHARE: the persistent scan takes n_cus / share CUs; 0 = auto: share = the streams that searched on
-                               // this handle within the last 5 ms (batches in flight), 1 = always the whole chip
+  int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches the CALLER keeps in flight on this handle through the *_dev entry points
+                               // (one stream each): a persistent scan takes n_cus / share CUs so that the scans run side by side (DESIGN.md
+                               // 5.2c).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
+  int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
+  int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
@@ -100,8 +103,10 @@ static Tuning read_tuning() {
   t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
   t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
   t.partition_cus = (int)env_int("FREDDY_GPU_PARTITION_CUS", t.partition_cus);
-  t.scan_share = (int)env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share);
+  t.scan_share = (int)std::max<int64_t>(1, env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share));
   t.merge_waves = (int)env_int("FREDDY_GPU_MERGE_WAVES", t.merge_waves);
+  t.pipeline_batch = (int)std::max<int64_t>(16, env_int("FREDDY_GPU_PIPELINE_BATCH", t.pipeline_batch));
+  t.pipeline_lanes = (int)std::min<int64_t>(4, std::max<int64_t>(1, env_int("FREDDY_GPU_PIPELINE_LANES", t.pipeline_lanes)));
   t.pq_fused = (int)env_int("FREDDY_GPU_PQ_FUSED", t.pq_fused);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
@@ -135,7 +140,7 @@ struct DevBuf {
 struct Workspace {
   bool used = false;
   hipStream_t owner = nullptr;
-  double last_use_ms = -1e30;      // host clock of the most recent search enqueued on this workspace (scan_share)
+  uint64_t last_use = 0;           // claim order (the slot a new stream takes over is the least recently used one)
   hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
   hipEvent_t ev_q = nullptr, ev_qc = nullptr;
   // CU-partitioned mode (Tuning::partition_cus): the batch's small kernels on a stream masked to the reserved CUs, its
@@ -167,7 +172,46 @@ struct Workspace {
     owner = nullptr;
   }
 };
-static constexpr int FREDDY_MAX_WS = 8;
+static constexpr int FREDDY_MAX_WS = 12;
+
+// One lane of the host-buffer pipeline (freddy_gpu_ivfadc_search): a library-owned stream, pinned staging for the
+// queries going in and the lists coming out, device buffers, and the state of the sub-batch it has in flight.
+// State of one chunk of queries while its probing rounds are enqueued.
+struct IvfRun {
+  freddy_gpu_index* ix;
+  Workspace* ws;
+  hipStream_t s;       // the stream the small kernels are enqueued on (the caller's, or the workspace's masked fe stream)
+  hipStream_t s_scan;  // the stream of the scan kernel (== s unless the CUs are partitioned)
+  int share;           // batches in flight on this handle (the scan takes n_cus / share CUs)
+  const float* d_q;
+  int Q, k, W, L, found_rule, upi;
+  float sentinel, cell_limit;
+  int32_t *d_out_ids, *d_status;
+  float* d_out_dist;
+  bool fused;          // cell-grouped scans (fused3.h / fused4.h) instead of lut_build + adc_scan
+  int scan_kernel;     // 4: filter + refine, 3: exact fused scan
+  bool tiled;          // the batch coarse kernel also clears the round-one scratch
+  bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
+  bool qc_pending;     // the query x codebook table is being built on the side stream
+  // per round
+  int n_active, round;
+  const int32_t* active;
+  int32_t* next;
+  hipStream_t s_caller; // the stream the search was enqueued on (results are complete on it after rejoin)
+  bool first() const { return round == 0; }
+};
+
+struct Lane {
+  hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;
+  void* h_in = nullptr;  size_t h_in_cap = 0;    // pinned: queries of the sub-batch
+  void* h_out = nullptr; size_t h_out_cap = 0;   // pinned: [ids n*k][dist n*k][n_next]
+  DevBuf d_q, d_ids, d_dist;
+  bool busy = false;
+  int q0 = 0, n = 0;
+  IvfRun run;
+};
+static constexpr int FREDDY_LANES = 4;
 
 struct ProfRec {
   int64_t launches = 0;
@@ -226,6 +270,13 @@ struct freddy_gpu_index {
   // workspaces: one per stream the caller searches on (searches on different streams may overlap)
   Workspace ws[FREDDY_MAX_WS];
   Workspace* last_ws = nullptr;   // of the most recent search (freddy_gpu_last_* read its counters)
+  uint64_t ws_clock = 0;
+  std::mutex mu;                  // guards the workspace slots and the profile map (host threads on different streams)
+  // host-buffer pipeline (created by the first host-buffer IVFADC call)
+  Lane lanes[FREDDY_LANES];
+  // replicas of this index on further devices (freddy_gpu_pin_ivf_multi): a host batch is split contiguously over
+  // this handle and its replicas; every replica is a complete pinned index of its own
+  std::vector<freddy_gpu_index*> replicas;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -241,26 +292,32 @@ static inline void timed_launch(freddy_gpu_index* ix, hipStream_t s, const char*
   (void)hipEventRecord(a, s);
   f();
   (void)hipEventRecord(b, s);
+  std::lock_guard<std::mutex> lock(ix->mu);
   ProfRec& r = ix->prof[name];
   r.launches++;
   r.open.emplace_back(a, b);
 }
 
-// The workspace of the stream a search is enqueued on.  A fifth stream takes over the least recently claimed slot
-// after that slot's stream has drained.
+// The workspace of the stream a search is enqueued on.  With every slot taken a new stream takes over the least
+// recently used one -- after the whole device has drained (rare; no handle of a possibly destroyed caller stream is touched).
 static Workspace* workspace_for(freddy_gpu_index* ix, hipStream_t s) {
-  for (Workspace& w : ix->ws)
-    if (w.used && w.owner == s) { ix->last_ws = &w; return &w; }
-  for (Workspace& w : ix->ws)
-    if (!w.used) { w.used = true; w.owner = s; ix->last_ws = &w; return &w; }
-  Workspace& w = ix->ws[FREDDY_MAX_WS - 1];
-  (void)hipStreamSynchronize(w.owner);
-  if (w.stream2) (void)hipStreamSynchronize(w.stream2);
-  if (w.fe_stream) (void)hipStreamSynchronize(w.fe_stream);
-  if (w.scan_stream) (void)hipStreamSynchronize(w.scan_stream);
-  w.owner = s;
-  ix->last_ws = &w;
-  return &w;
+  std::lock_guard<std::mutex> lock(ix->mu);
+  Workspace* w = nullptr;
+  for (Workspace& c : ix->ws)
+    if (c.used && c.owner == s) { w = &c; break; }
+  if (!w)
+    for (Workspace& c : ix->ws)
+      if (!c.used) { c.used = true; c.owner = s; w = &c; break; }
+  if (!w) {
+    w = &ix->ws[0];
+    for (Workspace& c : ix->ws)
+      if (c.last_use < w->last_use) w = &c;
+    (void)hipDeviceSynchronize();
+    w->owner = s;
+  }
+  w->last_use = ++ix->ws_clock;
+  ix->last_ws = w;
+  return w;
 }
 
 template <class T>
@@ -275,9 +332,19 @@ static int upload(T** dst, const T* src, size_t n, int64_t* bytes) {
 
 static void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
+  for (freddy_gpu_index* r : ix->replicas) free_index(r);
+  ix->replicas.clear();
   (void)hipSetDevice(ix->device);
-  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
-  for (Workspace& w : ix->ws) { if (w.used && w.owner) (void)hipStreamSynchronize(w.owner); w.release(); }
+  (void)hipDeviceSynchronize();   // (every stream that searched on this handle, without touching a caller's stream handle)
+  for (Workspace& w : ix->ws) w.release();
+  for (Lane& l : ix->lanes) {
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+    if (l.done) (void)hipEventDestroy(l.done);
+    if (l.h_in) (void)hipHostFree(l.h_in);
+    if (l.h_out) (void)hipHostFree(l.h_out);
+    l.d_q.release(); l.d_ids.release(); l.d_dist.release();
+    l = Lane();
+  }
   if (ix->shadow_of) {   // a PQ table's IVF-shaped view: its own arrays only (packed, codebook tables and the stream are the owner's)
     DevBuf* own[] = {&ix->v_coarse, &ix->v_list_off, &ix->v_blk_off, &ix->v_blk_cell, &ix->v_pos, &ix->v_rterm};
     for (DevBuf* b : own) b->release();
@@ -540,6 +607,10 @@ static int refresh_row_terms(freddy_gpu_index* ix) {
 }
 
 static int open_device(freddy_gpu_index* ix, int device) {
+  // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the
+  // runtime starts: the pipeline's four lanes want a queue each beside the library's own stream (DESIGN.md 5.2c:
+  // 6 queues measured best).  Set here unless the host chose a value; without effect if the runtime is already up.
+  setenv("GPU_MAX_HW_QUEUES", "6", 0);
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));
   if (device < 0 || device >= n) return fail(FREDDY_E_ARG, "device %d out of range (%d visible)", device, n);
@@ -709,6 +780,18 @@ extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_
 }
 
 static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
+  if (ix && !ix->replicas.empty()) {
+    int64_t sum = 0;
+    for (const freddy_gpu_index* r : ix->replicas) { const int64_t v = read_viol(r, which); if (v < 0) return -1; sum += v; }
+    std::vector<freddy_gpu_index*> none;
+    // (this device's own counters: the same function on a handle seen without its replicas)
+    freddy_gpu_index* self = const_cast<freddy_gpu_index*>(ix);
+    none.swap(self->replicas);
+    const int64_t v = read_viol(ix, which);
+    none.swap(self->replicas);
+    (void)hipSetDevice(ix->device);
+    return v < 0 ? -1 : sum + v;
+  }
   if (ix && (ix->pq_shadow || ix->pq_sub_view)) {   // a PQ handle: the counters of its two views
     const int64_t a = ix->pq_shadow ? read_viol(ix->pq_shadow, which) : 0, b = ix->pq_sub_view ? read_viol(ix->pq_sub_view, which) : 0;
     return (a < 0 || b < 0) ? -1 : a + b;
@@ -760,6 +843,8 @@ extern "C" int freddy_gpu_profile_read(freddy_gpu_index_t* ix, int32_t cap, char
 
 extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FREDDY_E_ARG, "NULL argument");
+  for (freddy_gpu_index* r : ix->replicas)
+    if (int rc = freddy_gpu_set_option(r, name, value)) return rc;
   Tuning& t = ix->tune;
   const std::string n(name);
   if (n == "fused") t.fused = (int)value;
@@ -769,7 +854,9 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "side_stream") t.side_stream = (int)value;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "partition_cus") t.partition_cus = (int)value;
-  else if (n == "scan_share") t.scan_share = (int)value;
+  else if (n == "scan_share") t.scan_share = (int)std::max<int64_t>(1, value);
+  else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
+  else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
   else if (n == "pq_fused") t.pq_fused = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
@@ -862,29 +949,6 @@ static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, co
 // ---------------------------------------------------------------------------------------
 // IVFADC
 // ---------------------------------------------------------------------------------------
-// State of one chunk of queries while its probing rounds are enqueued.
-struct IvfRun {
-  freddy_gpu_index* ix;
-  Workspace* ws;
-  hipStream_t s;       // the stream the small kernels are enqueued on (the caller's, or the workspace's masked fe stream)
-  hipStream_t s_scan;  // the stream of the scan kernel (== s unless the CUs are partitioned)
-  int share;           // batches in flight on this handle (the scan takes n_cus / share CUs)
-  const float* d_q;
-  int Q, k, W, L, found_rule, upi;
-  float sentinel, cell_limit;
-  int32_t *d_out_ids, *d_status;
-  float* d_out_dist;
-  bool fused;          // cell-grouped scans (fused3.h / fused4.h) instead of lut_build + adc_scan
-  int scan_kernel;     // 4: filter + refine, 3: exact fused scan
-  bool tiled;          // the batch coarse kernel also clears the round-one scratch
-  bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
-  bool qc_pending;     // the query x codebook table is being built on the side stream
-  // per round
-  int n_active, round;
-  const int32_t* active;
-  int32_t* next;
-  bool first() const { return round == 0; }
-};
 
 // coarse distances (a6/a7) of every query of the chunk, and -- for the filter + refine scan -- the
 // per-batch query x codebook table beside them on the side stream
@@ -942,9 +1006,7 @@ static int ivf_coarse(IvfRun& r) {
     }
     // (only while ONE stream searches: the runtime maps streams onto four hardware queues, and a side stream per
     // workspace ends up sharing an in-order queue with another batch's main stream -- measured: no overlap at all)
-    int n_ws = 0;
-    for (const Workspace& w : ix->ws) n_ws += w.used ? 1 : 0;
-    const bool side = ix->tune.side_stream != 0 && n_ws == 1 && r.s_scan == r.s;
+    const bool side = ix->tune.side_stream != 0 && r.share == 1 && r.s_scan == r.s;
     hipStream_t sq = side ? ws->stream2 : s;
     if (side) {
       HIP_TRY(hipEventRecord(ws->ev_q, s));
@@ -1257,25 +1319,38 @@ static int partition_streams(freddy_gpu_index* ix, Workspace* ws) {
   return 0;
 }
 
-// One chunk of queries (device pointers).  sync_rounds: run the extra rounds of the reference's
-// "while (foundInstances < k)" loop with a host sync per round; otherwise only round one is enqueued and
-// d_status reports stragglers.
-static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, int W,
+// One probing round of a chunk: cell selection, then the scan + merge of the path the chunk takes.
+static int ivfadc_round(IvfRun& r) {
+  PlanArgs pa;
+  if (int rc = ivf_plan(r, pa)) return rc;
+  if (r.fused) {
+    WorkTable wt;
+    if (int rc = ivf_work_table(r, wt)) return rc;
+    return (r.scan_kernel >= 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt);
+  }
+  return ivf_scan_generic(r, pa);
+}
+
+// (the caller's stream continues after everything enqueued on the internal streams)
+static int ivfadc_rejoin(IvfRun& r) {
+  if (r.s == r.s_caller) return 0;
+  HIP_TRY(hipEventRecord(r.ws->ev_out, r.s));
+  HIP_TRY(hipStreamWaitEvent(r.s_caller, r.ws->ev_out, 0));
+  return 0;
+}
+
+// One chunk of queries (device pointers): workspace, coarse distances and round one are enqueued on s, nothing is
+// synchronised.  `share` = the batches in flight on this handle (the persistent scan takes n_cus / share CUs).  The
+// state for further rounds stays in r (and in the stream's workspace): ivfadc_finish() runs them.
+static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const float* d_q, int Q, int k, int W,
                         float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
-                        int32_t* d_status, bool sync_rounds) {
+                        int32_t* d_status, IvfRun& r) {
   Workspace* ws = workspace_for(ix, s);
   const int C = ix->C, m = ix->m, K = ix->K;
   if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
-  IvfRun r;
   r.ix = ix; r.ws = ws; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
   r.sentinel = sentinel; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = d_status;
-  {
-    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    ws->last_use_ms = now;
-    int active = 0;
-    for (const Workspace& w : ix->ws) active += (w.used && now - w.last_use_ms < 5.0) ? 1 : 0;
-    r.share = ix->tune.scan_share > 0 ? ix->tune.scan_share : std::max(1, active);
-  }
+  r.share = std::max(1, share);
   // FREDDY_FOUND_BATCH_UDF = the accepted-rows rule + the batch UDF's cell limit (argmin from minDist = 1000,
   // freddy.c:853-866); ivfadc_search's cell list starts at 100.0 (freddy.c:266-283)
   r.found_rule = found_rule == FREDDY_FOUND_ROWS ? 0 : 1;
@@ -1293,25 +1368,18 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_STREAM_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
   // CU partition: only for the filter + refine scan, whose persistent workgroups take whole CUs
-  hipStream_t s_caller = s;
+  r.s_caller = s;
   r.s_scan = s;
   if (ix->tune.partition_cus != 0 && r.fused && r.scan_kernel >= 4) {
     if (int rc = partition_streams(ix, ws)) return rc;
     if (ix->tune.partition_cus > 0) {
-      HIP_TRY(hipEventRecord(ws->ev_in, s_caller));
+      HIP_TRY(hipEventRecord(ws->ev_in, r.s_caller));
       HIP_TRY(hipStreamWaitEvent(ws->fe_stream, ws->ev_in, 0));
       r.s = s = ws->fe_stream;
     }
     // (negative: only the scan is masked -- the R CUs it never takes stay open to the small kernels of every stream)
     r.s_scan = ws->scan_stream;
   }
-  // (the caller's stream continues after everything enqueued on the internal streams)
-  auto rejoin = [&]() -> int {
-    if (s == s_caller) return 0;
-    HIP_TRY(hipEventRecord(ws->ev_out, s));
-    HIP_TRY(hipStreamWaitEvent(s_caller, ws->ev_out, 0));
-    return 0;
-  };
   const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
   if (ws->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ws->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
@@ -1341,28 +1409,35 @@ static int ivfadc_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, i
   if (int rc = ivf_coarse(r)) return rc;
   ix->last_Q = Q;
   r.n_active = Q; r.active = nullptr; r.next = ws->w_act0.as<int32_t>();
-  const int max_rounds = (C + W - 1) / W + 1;
-  for (r.round = 0; r.round < max_rounds && r.n_active > 0; ++r.round) {
-    PlanArgs pa;
-    if (int rc = ivf_plan(r, pa)) return rc;
-    if (r.fused) {
-      WorkTable wt;
-      if (int rc = ivf_work_table(r, wt)) return rc;
-      if (int rc = (r.scan_kernel >= 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt)) return rc;
-    } else {
-      if (int rc = ivf_scan_generic(r, pa)) return rc;
+  r.round = 0;
+  if (int rc = ivfadc_round(r)) return rc;
+  return ivfadc_rejoin(r);
+}
+
+// The extra rounds of the reference's "while (foundInstances < k)" loop (freddy.c:262, :835), one host sync per
+// round.  n_next: the number of queries round one left unfinished if the caller has already read it back
+// (ws->w_cnt[0], after the stream drained), -1 = read it here.
+static int ivfadc_finish(IvfRun& r, int n_next) {
+  Workspace* ws = r.ws;
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int max_rounds = (ix->C + r.W - 1) / r.W + 1;
+  for (;;) {
+    if (n_next < 0) {
+      int32_t h = 0;
+      HIP_TRY(hipMemcpyAsync(&h, ws->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      n_next = h;
     }
-    if (!sync_rounds) break;
-    int32_t n_next = 0;
-    HIP_TRY(hipMemcpyAsync(&n_next, ws->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    if (n_next <= 0) break;
+    if (n_next <= 0 || ++r.round >= max_rounds) break;
     HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t), s));
     r.active = r.next;
     r.next = (r.next == ws->w_act0.as<int32_t>()) ? ws->w_act1.as<int32_t>() : ws->w_act0.as<int32_t>();
     r.n_active = n_next;
+    if (int rc = ivfadc_round(r)) return rc;
+    n_next = -1;
   }
-  return rejoin();
+  return ivfadc_rejoin(r);
 }
 
 static int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q, int k, const void* oi,
@@ -1402,11 +1477,151 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
   const int qc = max_queries_per_chunk(ix, W);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
-    if (int rc = ivfadc_chunk(ix, s, d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
-                              d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_status, false))
+    IvfRun r;
+    if (int rc = ivfadc_begin(ix, s, ix->tune.scan_share, d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+                              d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_status, r))
       return rc;
   }
   return FREDDY_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// The host-buffer call (what the PostgreSQL hosts make: one synchronous call per batch, freddy.c:679-999) as a
+// pipeline.  The batch is cut into sub-batches of <= pipeline_batch queries; sub-batch j goes to lane j mod L
+// (L <= 4 library-owned streams, each with its own workspace, pinned staging and device buffers):
+//   host memcpy of its queries into the lane's pinned buffer (skipped when the caller's buffer is pinned itself:
+//   freddy_gpu_host_alloc) -> asynchronous H2D -> round one of the search with an explicit scan share of L -> asynchronous
+//   D2H of the lists and of the round's straggler count into pinned memory -> event.
+// The host only waits when it needs a lane again (or at the end), and that is where a sub-batch's rare extra probing
+// rounds run and its lists are copied out: the transfers and the latency-bound ends of one sub-batch hide under the
+// scans of its neighbours, and ONE stream synchronisation per lane ends the call.
+// ---------------------------------------------------------------------------------------
+static int lane_open(freddy_gpu_index* ix, Lane& l, size_t in_bytes, size_t n_out) {
+  if (!l.stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+  }
+  if (in_bytes > l.h_in_cap) {
+    if (l.h_in) (void)hipHostFree(l.h_in);
+    l.h_in = nullptr; l.h_in_cap = 0;
+    const size_t want = in_bytes + in_bytes / 8 + 256;
+    if (hipHostMalloc(&l.h_in, want, hipHostMallocDefault) != hipSuccess) { l.h_in = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+    l.h_in_cap = want;
+  }
+  const size_t out_bytes = n_out * 8 + 16;
+  if (out_bytes > l.h_out_cap) {
+    if (l.h_out) (void)hipHostFree(l.h_out);
+    l.h_out = nullptr; l.h_out_cap = 0;
+    const size_t want = out_bytes + out_bytes / 8 + 256;
+    if (hipHostMalloc(&l.h_out, want, hipHostMallocDefault) != hipSuccess) { l.h_out = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+    l.h_out_cap = want;
+  }
+  if (l.d_q.ensure(in_bytes) || l.d_ids.ensure(n_out * 4) || l.d_dist.ensure(n_out * 4))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  (void)ix;
+  return 0;
+}
+
+// enqueue the D2H of a lane's lists (+ the straggler count of the round before) and the event the host waits for
+static int lane_copy_out(Lane& l, int k) {
+  const size_t n_out = (size_t)l.n * k;
+  char* ho = static_cast<char*>(l.h_out);
+  HIP_TRY(hipMemcpyAsync(ho, l.d_ids.p, n_out * 4, hipMemcpyDeviceToHost, l.stream));
+  HIP_TRY(hipMemcpyAsync(ho + n_out * 4, l.d_dist.p, n_out * 4, hipMemcpyDeviceToHost, l.stream));
+  HIP_TRY(hipMemcpyAsync(ho + n_out * 8, l.run.ws->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, l.stream));
+  HIP_TRY(hipEventRecord(l.done, l.stream));
+  return 0;
+}
+
+// wait for a lane's sub-batch, run its extra rounds if round one left queries unfinished, hand its lists to the caller
+static int lane_retire(Lane& l, int k, int32_t* out_ids, float* out_dist) {
+  if (!l.busy) return 0;
+  l.busy = false;
+  HIP_TRY(hipEventSynchronize(l.done));
+  const size_t n_out = (size_t)l.n * k;
+  char* ho = static_cast<char*>(l.h_out);
+  int32_t n_next = 0;
+  memcpy(&n_next, ho + n_out * 8, sizeof(int32_t));
+  if (n_next > 0) {
+    if (int rc = ivfadc_finish(l.run, n_next)) return rc;
+    if (int rc = lane_copy_out(l, k)) return rc;
+    HIP_TRY(hipEventSynchronize(l.done));
+  }
+  memcpy(out_ids + (size_t)l.q0 * k, ho, n_out * 4);
+  memcpy(out_dist + (size_t)l.q0 * k, ho + n_out * 4, n_out * 4);
+  return 0;
+}
+
+static bool host_pointer_is_pinned(const void* p) {
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return attr.type == hipMemoryTypeHost;
+}
+
+// the batch [0, Q) of one device's handle
+static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q, int k, int W, float sentinel, int found_rule,
+                              int32_t* out_ids, float* out_dist) {
+  HIP_TRY(hipSetDevice(ix->device));
+  const int cap = std::max(1, std::min(max_queries_per_chunk(ix, W), ix->tune.pipeline_batch));
+  const int n_sub = (Q + cap - 1) / cap;
+  const int per = (Q + n_sub - 1) / n_sub;               // equal sub-batches rather than full ones and a remainder
+  const int n_lanes = std::min(n_sub, std::min(ix->tune.pipeline_lanes, FREDDY_LANES));
+  const bool pinned_in = host_pointer_is_pinned(queries);
+  const size_t row = sizeof(float) * (size_t)ix->d;
+  int rc = 0;
+  for (int j = 0; j < n_sub && !rc; ++j) {
+    Lane& l = ix->lanes[j % n_lanes];
+    if ((rc = lane_retire(l, k, out_ids, out_dist))) break;
+    const int q0 = j * per, n = std::min(per, Q - q0);
+    if ((rc = lane_open(ix, l, row * n, (size_t)n * k))) break;
+    l.q0 = q0; l.n = n;
+    const float* src = queries + (size_t)q0 * ix->d;
+    if (!pinned_in) { memcpy(l.h_in, src, row * n); src = static_cast<const float*>(l.h_in); }
+    if (hipMemcpyAsync(l.d_q.p, src, row * n, hipMemcpyHostToDevice, l.stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "H2D of the queries failed"); break; }
+    if ((rc = ivfadc_begin(ix, l.stream, n_lanes, l.d_q.as<float>(), n, k, W, sentinel, found_rule, l.d_ids.as<int32_t>(),
+                           l.d_dist.as<float>(), nullptr, l.run)))
+      break;
+    if ((rc = lane_copy_out(l, k))) break;
+    l.busy = true;
+  }
+  // drain in submission order (oldest first)
+  for (int j = std::max(0, n_sub - n_lanes); j < n_sub && !rc; ++j) rc = lane_retire(ix->lanes[j % n_lanes], k, out_ids, out_dist);
+  if (rc)   // a failed call: nothing of it may still be in flight when the caller gets its buffers back
+    for (Lane& l : ix->lanes) {
+      if (l.stream) (void)hipStreamSynchronize(l.stream);
+      l.busy = false;
+    }
+  return rc;
+}
+
+// Q queries split contiguously over a handle and its replicas (freddy_gpu_pin_ivf_multi): part g of G gets
+// [lo, hi) with sizes differing by at most one.  fn(part, index of that part, lo, hi) runs on its own host thread
+// for every part but the first; the first failure's code and message are returned on the caller's thread.
+template <class F>
+static int over_replicas(freddy_gpu_index* ix, int Q, F&& fn) {
+  const int G = 1 + (int)ix->replicas.size();
+  if (G == 1 || Q < 2 * G) return fn(ix, 0, Q);
+  std::vector<int> rcs((size_t)G, 0);
+  std::vector<std::string> msgs((size_t)G);
+  std::vector<std::thread> th;
+  const int base = Q / G, rem = Q % G;
+  auto bounds = [&](int g, int* lo, int* hi) { *lo = g * base + std::min(g, rem); *hi = *lo + base + (g < rem ? 1 : 0); };
+  for (int g = 1; g < G; ++g)
+    th.emplace_back([&, g] {
+      int lo, hi;
+      bounds(g, &lo, &hi);
+      rcs[(size_t)g] = fn(ix->replicas[(size_t)g - 1], lo, hi);
+      if (rcs[(size_t)g]) msgs[(size_t)g] = g_err;
+    });
+  int lo, hi;
+  bounds(0, &lo, &hi);
+  rcs[0] = fn(ix, lo, hi);
+  if (rcs[0]) msgs[0] = g_err;
+  for (std::thread& t : th) t.join();
+  for (int g = 0; g < G; ++g)
+    if (rcs[(size_t)g]) return fail(rcs[(size_t)g], "device %d: %s", g == 0 ? ix->device : ix->replicas[(size_t)g - 1]->device, msgs[(size_t)g].c_str());
+  return 0;
 }
 
 extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* queries, int32_t Q, int32_t k, int32_t W,
@@ -1417,26 +1632,37 @@ extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* que
     return fail(FREDDY_E_ARG, "bad found_rule (FREDDY_FOUND_BATCH_UDF needs W == 1)");
   if (W > ix->C) W = ix->C;
   if (Q == 0) return FREDDY_OK;
-  HIP_TRY(hipSetDevice(ix->device));
-  Workspace* ws = workspace_for(ix, ix->stream);
-  hipStream_t s = ix->stream;
-  if (ws->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
-      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
-    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
-  const int qc = max_queries_per_chunk(ix, W);
-  for (int q0 = 0; q0 < Q; q0 += qc) {
-    const int n = std::min(qc, Q - q0);
-    if (int rc = ivfadc_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
-                              ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k,
-                              nullptr, true))
-      return rc;
-  }
-  HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(out_dist, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  return over_replicas(ix, Q, [&](freddy_gpu_index* part, int lo, int hi) {
+    return ivfadc_host_search(part, queries + (size_t)lo * ix->d, hi - lo, k, W, sentinel, found_rule, out_ids + (size_t)lo * k,
+                              out_dist + (size_t)lo * k);
+  });
+}
+
+extern "C" int freddy_gpu_host_alloc(void** out, size_t bytes) {
+  if (!out) return fail(FREDDY_E_ARG, "NULL argument");
+  *out = nullptr;
+  if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(FREDDY_E_NOMEM, "pinned host allocation of %zu bytes failed", bytes); }
   return FREDDY_OK;
 }
+extern "C" int freddy_gpu_host_free(void* p) {
+  if (p) HIP_TRY(hipHostFree(p));
+  return FREDDY_OK;
+}
+
+extern "C" int freddy_gpu_pin_ivf_multi(const freddy_ivf_desc* t, const int* devices, int n_devices, freddy_gpu_index_t** out) {
+  if (!devices || n_devices < 1 || !out) return fail(FREDDY_E_ARG, "bad device list");
+  freddy_gpu_index* first = nullptr;
+  if (int rc = freddy_gpu_pin_ivf(t, devices[0], &first)) return rc;
+  for (int g = 1; g < n_devices; ++g) {
+    freddy_gpu_index* rep = nullptr;
+    if (int rc = freddy_gpu_pin_ivf(t, devices[g], &rep)) { free_index(first); return rc; }
+    first->replicas.push_back(rep);
+  }
+  (void)hipSetDevice(devices[0]);
+  *out = first;
+  return FREDDY_OK;
+}
+extern "C" int freddy_gpu_replica_count(const freddy_gpu_index_t* ix) { return ix ? 1 + (int)ix->replicas.size() : 0; }
 
 // ---------------------------------------------------------------------------------------
 // exhaustive / subset PQ
@@ -1570,13 +1796,8 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   r.sentinel = sentinel; r.cell_limit = 0.0f; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = nullptr;
   r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.approx = false; r.qc_pending = false;
   r.n_active = Q; r.round = 0; r.active = nullptr;
-  {
-    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    ws->last_use_ms = now;
-    int active = 0;
-    for (const Workspace& w : fx->ws) active += (w.used && now - w.last_use_ms < 5.0) ? 1 : 0;
-    r.share = ix->tune.scan_share > 0 ? ix->tune.scan_share : std::max(1, active);
-  }
+  r.share = std::max(1, ix->tune.scan_share);   // (the caller's contract: its batches in flight on this handle)
+  r.s_caller = s;
   const size_t items = (size_t)Q * lists;
   if (ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
       ws->w_item_dist.ensure(sizeof(float) * items) || ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
@@ -2118,6 +2339,8 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
   if (!ix) return fail(FREDDY_E_ARG, "NULL index");
   if (n < 0 || (n > 0 && !ids)) return fail(FREDDY_E_ARG, "bad argument");
   if (n == 0) return FREDDY_OK;
+  for (freddy_gpu_index* r : ix->replicas)   // (every replica holds the same tables)
+    if (int rc = freddy_gpu_append_rows(r, n, ids, coarse_id, codes, vectors)) return rc;
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   const int32_t last_id = ix->kind == KIND_IVPQ ? (ix->join.h_ids.empty() ? -1 : ix->join.h_ids.back())
@@ -2194,8 +2417,10 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
 
 extern "C" int freddy_gpu_update_codebook(freddy_gpu_index_t* ix, const float* codebook) {
   if (!ix || !codebook) return fail(FREDDY_E_ARG, "NULL argument");
+  for (freddy_gpu_index* r : ix->replicas)
+    if (int rc = freddy_gpu_update_codebook(r, codebook)) return rc;
   HIP_TRY(hipSetDevice(ix->device));
-  HIP_TRY(hipStreamSynchronize(ix->stream));
+  HIP_TRY(hipDeviceSynchronize());   // (searches of every stream and lane have drained before the tables change)
   if (ix->kind == KIND_PQ) return derive_codebook_tables(ix, codebook);
   if (ix->kind == KIND_IVF) {
     if (int rc = derive_codebook_tables(ix, codebook)) return rc;

@@ -25,6 +25,7 @@ EXPORTS = [
     "freddy_gpu_last_scanned_rows", "freddy_gpu_filter_bound_violations", "freddy_gpu_filter_bound_checked", "freddy_gpu_pin_vectors", "freddy_gpu_exact_search", "freddy_gpu_grouping_pq",
     "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells", "freddy_gpu_coarse_bound_checked",
     "freddy_gpu_insert_quantize", "freddy_gpu_append_rows", "freddy_gpu_update_codebook", "freddy_gpu_kmeans",
+    "freddy_gpu_host_alloc", "freddy_gpu_host_free", "freddy_gpu_pin_ivf_multi", "freddy_gpu_replica_count",
 ]
 
 
@@ -90,6 +91,10 @@ def load():
     lib.freddy_gpu_pin_pq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivf.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_pin_ivpq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.freddy_gpu_pin_ivf_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.freddy_gpu_replica_count.argtypes = [C.c_void_p]
+    lib.freddy_gpu_host_alloc.argtypes = [C.c_void_p, C.c_size_t]
+    lib.freddy_gpu_host_free.argtypes = [C.c_void_p]
     lib.freddy_gpu_unpin.argtypes = [C.c_void_p]
     lib.freddy_gpu_pin_vectors.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.freddy_gpu_exact_search.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64,
@@ -265,14 +270,24 @@ class IVFIndex(_Index):
     """coarse_quantization + residual_codebook + fine_quantization pinned in HBM."""
     kind = "ivf"
 
-    def __init__(self, coarse, codebook, list_off, ids, codes, device=0):
+    def __init__(self, coarse, codebook, list_off, ids, codes, device=0, devices=None):
+        """devices: a list of device ordinals -> the tables replicated on each of them behind one handle
+        (freddy_gpu_pin_ivf_multi); host batches are then split contiguously over the devices."""
         super().__init__()
         cq, cb, lo, ids, codes = _f32(coarse), _f32(codebook), _i32(list_off), _i32(ids), _i16(codes)
         m, K, s = cb.shape
         assert cq.shape[1] == m * s and lo.size == cq.shape[0] + 1
         self.d, self.m, self.K, self.C, self.N = m * s, m, K, cq.shape[0], ids.size
         desc = IVFDesc(self.d, m, K, self.C, ids.size, _p(cq), _p(cb), _p(lo), _p(ids), _p(codes))
-        _check(self.lib.freddy_gpu_pin_ivf(C.byref(desc), device, C.byref(self.h)))
+        if devices is None:
+            _check(self.lib.freddy_gpu_pin_ivf(C.byref(desc), device, C.byref(self.h)))
+        else:
+            devs = (C.c_int * len(devices))(*devices)
+            _check(self.lib.freddy_gpu_pin_ivf_multi(C.byref(desc), devs, len(devices), C.byref(self.h)))
+
+    @property
+    def replicas(self):
+        return int(self.lib.freddy_gpu_replica_count(self.h))
 
     def search(self, queries, k, W, sentinel=1000.0, found_rule=FOUND_ROWS):
         qs = _f32(queries).reshape(-1, self.d)
@@ -436,3 +451,28 @@ def train_pq_codebook(vectors, m, K, iters=10, seed=0, device=0):
         init = rng.choice(v.shape[0], K, replace=v.shape[0] < K).astype(np.int32)
         out[p], _ = kmeans(np.ascontiguousarray(v[:, p * s_:(p + 1) * s_]), K, iters, init, device)
     return out
+
+
+class PinnedBuffer:
+    """Pinned host memory from freddy_gpu_host_alloc as a numpy array: query batches written into it skip the
+    staging copy of the host-buffer calls (include/freddy_gpu.h)."""
+
+    def __init__(self, shape, dtype=np.float32):
+        self.lib = load()
+        self.ptr = C.c_void_p()
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        _check(self.lib.freddy_gpu_host_alloc(C.byref(self.ptr), n))
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr.value)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.lib.freddy_gpu_host_free(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -97,6 +97,37 @@ def test_config3_ivfadc_batch_3m(oracle):
     idx.set_option("fused_kernel", 3)
     gi3, gd3 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
     assert np.array_equal(gi0, gi3) and np.array_equal(gd0.view(np.uint32), gd3.view(np.uint32))
+    idx.set_option("fused_kernel", 5)
+    # The TIMED configuration of bench.py at full size: four batches in flight on four streams, scan_share = 4 (four
+    # 64-workgroup scans side by side), the one-wave merge -- four DIFFERENT 1024-query sets, every list against the oracle.
+    dev = x.device
+    sets = []
+    for i in range(4):
+        ids_i = np.sort(np.random.default_rng(100 + i).choice(np.arange(1, N + 1), 1024, replace=False))
+        sets.append(x[torch.from_numpy(ids_i - 1).to(dev)].contiguous())
+    exp4 = [oracle.ivfadc_search_many(ot, s_.cpu().numpy(), 5, 10, sentinel=1000.0, found_rule=0, n_threads=os.cpu_count() or 1) for s_ in sets]
+    res = [torch.zeros((2, 1024, 5), dtype=torch.int32, device=dev) for _ in sets]
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    streams = [torch.cuda.Stream(dev) for _ in sets]
+    idx.set_option("scan_share", 4)
+    torch.cuda.synchronize(dev)
+    for rounds in range(5):
+        for i in range(4):
+            with torch.cuda.stream(streams[i]):
+                res[i].zero_()
+                idx.search_dev(sets[i].data_ptr(), 1024, 5, 10, 1000.0, gpu.FOUND_ROWS, res[i][0].data_ptr(), res[i][1].data_ptr(),
+                               st.data_ptr(), streams[i].cuda_stream)
+    torch.cuda.synchronize(dev)
+    for i in range(4):
+        util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp4[i], f"config 3, four in flight, stream {i}")
+    assert int(st[0].item()) == 0
+    idx.set_option("scan_share", 1)
+    # ... and the host-buffer pipeline (the call pg/freddy_srf.c makes) on all 4096 queries at once: four lanes
+    allq = torch.cat(sets).cpu().numpy()
+    gi4, gd4 = idx.search(allq, 5, 10, sentinel=1000.0, found_rule=0)
+    util.assert_same_lists(gi4, gd4, {"id": np.concatenate([e["id"] for e in exp4]), "dist": np.concatenate([e["dist"] for e in exp4])},
+                           "config 3, host-buffer pipeline, 4096 queries")
+    assert idx.bound_violations() == 0
     idx.close()
 
 

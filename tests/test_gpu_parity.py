@@ -801,8 +801,8 @@ def test_cu_partitioned_streams_give_the_same_lists(gpu, oracle, partition):
 
 @pytest.mark.parametrize("share", [0, 3, 8])
 def test_scan_share_gives_the_same_lists(gpu, oracle, share):
-    """Option scan_share: the persistent scan on n_cus / share workgroups (0 = the streams that searched
-    within the last 5 ms).  The number of workgroups that pull work entries changes nothing in the lists."""
+    """Option scan_share: the persistent scan on n_cus / share workgroups (the caller's statement of its
+    batches in flight; values below 1 mean 1).  The number of workgroups that pull work entries changes nothing in the lists."""
     N = 60000
     t = util.ivf_tables(N=N, C=64, K=1024)
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
@@ -915,8 +915,8 @@ def test_coarse_filter_refine_beyond_1024_cells(gpu, oracle, kind, monkeypatch):
 
 
 def test_more_streams_than_workspaces(gpu, oracle):
-    """A handle keeps eight workspaces, one per searching stream; a ninth and tenth stream take over a slot after its
-    owner drained (workspace_for).  Ten streams, three rounds, interleaved: every stream's lists are the oracle's."""
+    """A handle keeps twelve workspaces, one per searching stream; further streams take over the least recently used slot
+    after the device drained (workspace_for).  Fifteen streams, three rounds, interleaved: every stream's lists are the oracle's."""
     import torch
     dev = torch.device("cuda", 0)
     N = 60000
@@ -924,7 +924,7 @@ def test_more_streams_than_workspaces(gpu, oracle):
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     _, qa = util.queries_from_corpus(N, 280)
-    ns = 10
+    ns = 15
     qs = [np.ascontiguousarray(np.roll(qa, 11 * i, axis=0)) for i in range(ns)]
     exp = [oracle.ivfadc_search_many(ot, q, 5, 4, sentinel=1000.0, found_rule=0) for q in qs]
     dq = [torch.from_numpy(q).to(dev) for q in qs]

@@ -17,7 +17,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/fetch -o r -- $B > /dev/nul
 python3 tools/prof_summary.py FETCH_SIZE $T/fetch gpurun_out/prof/${TAG}_pmc_fetch_size.txt > /dev/null
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $T/write -o r -- $B > /dev/null 2> $T/write.err
 python3 tools/prof_summary.py WRITE_SIZE $T/write gpurun_out/prof/${TAG}_pmc_write_size.txt > /dev/null
-python3 - "$TAG" <<'PY'
+python3 - "$TAG" "$@" <<'PY'
 import json, re, sys
 tag = sys.argv[1]
 out = {}
@@ -28,6 +28,17 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
             k = m.group(1).split("(")[0].replace("void ", "").replace("freddy::", "").strip()
             k = re.sub(r"<.*", "", k)
             out.setdefault(k, {})[key] = float(m.group(3))
+# the workload shape these passes were taken on: bench.py's pmc_traffic() refuses the record for any other shape
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--config", default="ivfadc"); ap.add_argument("--N", type=int); ap.add_argument("--Q", type=int)
+ap.add_argument("--C", type=int, default=1000); ap.add_argument("--nprobe", type=int, default=10)
+a, _ = ap.parse_known_args(extra)
+dflt = {"ivfadc": (3_000_000, 1024), "pq": (1_000_000, 64), "join": (1_000_000, 5000)}[a.config]
+shape = {"N": a.N or dflt[0], "Q": a.Q or dflt[1]}
+if a.config == "ivfadc":
+    shape.update({"C": a.C, "nprobe": a.nprobe})
+out["_shape"] = shape
 json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(out))
 PY
