@@ -125,10 +125,13 @@ int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ivf, const float* queries, int3
 
 /* How the host-buffer IVFADC call runs (the reference makes one synchronous call per batch, freddy.c:679-999): a batch
  * larger than `pipeline_batch` (1024) queries is cut into equal sub-batches that go round-robin to up to four
- * library-owned streams ("lanes"), each with pinned staging buffers: host copy of the sub-batch's queries into pinned
- * memory -> asynchronous H2D -> round one of the search, the lanes' persistent scans sharing the CUs -> asynchronous D2H
- * of the lists into pinned memory.  The host waits only when it needs a lane again and once per lane at the end; a
- * sub-batch's (rare) further probing rounds run where the host waits for it.  Results do not depend on how a batch is cut.
+ * library-owned streams ("lanes", two sub-batches queued on each), with pinned staging buffers: host copy of the
+ * sub-batch's queries into pinned memory -> a copy kernel reads them over PCIe -> round one of the search, the lanes'
+ * persistent scans sharing the CUs -> a copy kernel writes the lists into pinned memory.  The host waits only when it
+ * needs a staging slot again and once per slot at the end.  Queries that round one leaves unfinished (their first W
+ * cells hold fewer than k rows: rare) are searched again from the start with all their rounds where the host waits for
+ * their sub-batch -- the search is deterministic, so that is the list the round-by-round continuation gives.  Results
+ * do not depend on how a batch is cut.
  *
  * Query buffers obtained from freddy_gpu_host_alloc (pinned host memory) skip the staging copy: a host that decodes
  * its bytea / array arguments can write the floats straight into such a buffer.  freddy_gpu_host_free releases it. */

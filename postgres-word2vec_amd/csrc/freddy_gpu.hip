@@ -82,6 +82,7 @@ struct Tuning {
                                // 5.2c).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
   int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
+  int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
@@ -111,6 +112,7 @@ static Tuning read_tuning() {
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
+  t.pipe_trace = (int)env_int("FREDDY_GPU_PIPE_TRACE", 0);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
@@ -201,15 +203,17 @@ struct IvfRun {
   bool first() const { return round == 0; }
 };
 
-struct Lane {
-  hipStream_t stream = nullptr;
+struct LaneSlot {
   hipEvent_t done = nullptr;
   void* h_in = nullptr;  size_t h_in_cap = 0;    // pinned: queries of the sub-batch
-  void* h_out = nullptr; size_t h_out_cap = 0;   // pinned: [ids n*k][dist n*k][n_next]
+  void* h_out = nullptr; size_t h_out_cap = 0;   // pinned: [ids n*k][dist n*k][n_next][unfinished queries n]
   DevBuf d_q, d_ids, d_dist;
   bool busy = false;
   int q0 = 0, n = 0;
-  IvfRun run;
+};
+struct Lane {
+  hipStream_t stream = nullptr;
+  LaneSlot slot[2];        // two sub-batches queued per lane: the stream never runs dry while the host stages the next one
 };
 static constexpr int FREDDY_LANES = 4;
 
@@ -339,11 +343,14 @@ static void free_index(freddy_gpu_index* ix) {
   for (Workspace& w : ix->ws) w.release();
   for (Lane& l : ix->lanes) {
     if (l.stream) (void)hipStreamDestroy(l.stream);
-    if (l.done) (void)hipEventDestroy(l.done);
-    if (l.h_in) (void)hipHostFree(l.h_in);
-    if (l.h_out) (void)hipHostFree(l.h_out);
-    l.d_q.release(); l.d_ids.release(); l.d_dist.release();
-    l = Lane();
+    for (LaneSlot& c : l.slot) {
+      if (c.done) (void)hipEventDestroy(c.done);
+      if (c.h_in) (void)hipHostFree(c.h_in);
+      if (c.h_out) (void)hipHostFree(c.h_out);
+      c.d_q.release(); c.d_ids.release(); c.d_dist.release();
+      c = LaneSlot();
+    }
+    l.stream = nullptr;
   }
   if (ix->shadow_of) {   // a PQ table's IVF-shaped view: its own arrays only (packed, codebook tables and the stream are the owner's)
     DevBuf* own[] = {&ix->v_coarse, &ix->v_list_off, &ix->v_blk_off, &ix->v_blk_cell, &ix->v_pos, &ix->v_rterm};
@@ -855,6 +862,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
   else if (n == "partition_cus") t.partition_cus = (int)value;
   else if (n == "scan_share") t.scan_share = (int)std::max<int64_t>(1, value);
+  else if (n == "pipe_trace") t.pipe_trace = (int)value;
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
@@ -1496,67 +1504,117 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
 // rounds run and its lists are copied out: the transfers and the latency-bound ends of one sub-batch hide under the
 // scans of its neighbours, and ONE stream synchronisation per lane ends the call.
 // ---------------------------------------------------------------------------------------
-static int lane_open(freddy_gpu_index* ix, Lane& l, size_t in_bytes, size_t n_out) {
-  if (!l.stream) {
-    HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-  }
-  if (in_bytes > l.h_in_cap) {
-    if (l.h_in) (void)hipHostFree(l.h_in);
-    l.h_in = nullptr; l.h_in_cap = 0;
+// The lanes move their data with KERNELS, not with hipMemcpyAsync: pinned host memory is mapped into the device's address
+// space, so a grid-stride copy reads the staged queries over PCIe (1.2 MB per 1024 queries: ~25 us) and a second one
+// writes the lists, the straggler count and the stragglers' numbers back -- ordinary launches in the lane's stream.
+// Measured (tools/pipe_trace.py): with hipMemcpyAsync (SDMA copies ordered against kernels by signals) the four lanes'
+// chains ran in pairs one after the other, 1.4 ms per 4096 queries; with copy kernels they overlap like the
+// device-resident batches of bench.py: 0.68 ms.
+__global__ __launch_bounds__(256) void lane_copy_in_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void lane_copy_out_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dist,
+                                                           const int32_t* __restrict__ n_next, const int32_t* __restrict__ unfinished,
+                                                           int32_t* __restrict__ h_out, int n_out, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_out) { h_out[i] = ids[i]; h_out[n_out + i] = __float_as_int(dist[i]); }
+  const int nn = n_next[0];
+  if (i == 0) h_out[2 * n_out] = nn;
+  if (i < nn && i < n) h_out[2 * n_out + 1 + i] = unfinished[i];
+}
+
+static int lane_open(Lane& l, LaneSlot& c, size_t in_bytes, size_t n, size_t n_out) {
+  if (!l.stream) HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+  if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
+  if (in_bytes > c.h_in_cap) {
+    if (c.h_in) (void)hipHostFree(c.h_in);
+    c.h_in = nullptr; c.h_in_cap = 0;
     const size_t want = in_bytes + in_bytes / 8 + 256;
-    if (hipHostMalloc(&l.h_in, want, hipHostMallocDefault) != hipSuccess) { l.h_in = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
-    l.h_in_cap = want;
+    if (hipHostMalloc(&c.h_in, want, hipHostMallocDefault) != hipSuccess) { c.h_in = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+    c.h_in_cap = want;
   }
-  const size_t out_bytes = n_out * 8 + 16;
-  if (out_bytes > l.h_out_cap) {
-    if (l.h_out) (void)hipHostFree(l.h_out);
-    l.h_out = nullptr; l.h_out_cap = 0;
+  const size_t out_bytes = (n_out * 2 + 1 + n) * 4;
+  if (out_bytes > c.h_out_cap) {
+    if (c.h_out) (void)hipHostFree(c.h_out);
+    c.h_out = nullptr; c.h_out_cap = 0;
     const size_t want = out_bytes + out_bytes / 8 + 256;
-    if (hipHostMalloc(&l.h_out, want, hipHostMallocDefault) != hipSuccess) { l.h_out = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
-    l.h_out_cap = want;
+    if (hipHostMalloc(&c.h_out, want, hipHostMallocDefault) != hipSuccess) { c.h_out = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+    c.h_out_cap = want;
   }
-  if (l.d_q.ensure(in_bytes) || l.d_ids.ensure(n_out * 4) || l.d_dist.ensure(n_out * 4))
+  if (c.d_q.ensure(in_bytes + 16) || c.d_ids.ensure(n_out * 4) || c.d_dist.ensure(n_out * 4))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  (void)ix;
   return 0;
 }
 
-// enqueue the D2H of a lane's lists (+ the straggler count of the round before) and the event the host waits for
-static int lane_copy_out(Lane& l, int k) {
-  const size_t n_out = (size_t)l.n * k;
-  char* ho = static_cast<char*>(l.h_out);
-  HIP_TRY(hipMemcpyAsync(ho, l.d_ids.p, n_out * 4, hipMemcpyDeviceToHost, l.stream));
-  HIP_TRY(hipMemcpyAsync(ho + n_out * 4, l.d_dist.p, n_out * 4, hipMemcpyDeviceToHost, l.stream));
-  HIP_TRY(hipMemcpyAsync(ho + n_out * 8, l.run.ws->w_cnt.p, sizeof(int32_t), hipMemcpyDeviceToHost, l.stream));
-  HIP_TRY(hipEventRecord(l.done, l.stream));
-  return 0;
-}
-
-// wait for a lane's sub-batch, run its extra rounds if round one left queries unfinished, hand its lists to the caller
-static int lane_retire(Lane& l, int k, int32_t* out_ids, float* out_dist) {
-  if (!l.busy) return 0;
-  l.busy = false;
-  HIP_TRY(hipEventSynchronize(l.done));
-  const size_t n_out = (size_t)l.n * k;
-  char* ho = static_cast<char*>(l.h_out);
-  int32_t n_next = 0;
-  memcpy(&n_next, ho + n_out * 8, sizeof(int32_t));
-  if (n_next > 0) {
-    if (int rc = ivfadc_finish(l.run, n_next)) return rc;
-    if (int rc = lane_copy_out(l, k)) return rc;
-    HIP_TRY(hipEventSynchronize(l.done));
+// The old shape of the call, kept for what the pipeline hands back: a (small) batch searched to the end on the library's
+// own stream -- round one, then the extra rounds of the reference's "while (foundInstances < k)" loop with a host sync each.
+static int ivfadc_sync_search(freddy_gpu_index* ix, const float* queries, int Q, int k, int W, float sentinel, int found_rule,
+                              int32_t* out_ids, float* out_dist) {
+  Workspace* ws = workspace_for(ix, ix->stream);
+  hipStream_t s = ix->stream;
+  if (ws->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
+  const int qc = max_queries_per_chunk(ix, W);
+  for (int q0 = 0; q0 < Q; q0 += qc) {
+    const int n = std::min(qc, Q - q0);
+    IvfRun r;
+    if (int rc = ivfadc_begin(ix, s, 1, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+                              ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k, nullptr, r))
+      return rc;
+    if (int rc = ivfadc_finish(r, -1)) return rc;
   }
-  memcpy(out_ids + (size_t)l.q0 * k, ho, n_out * 4);
-  memcpy(out_dist + (size_t)l.q0 * k, ho + n_out * 4, n_out * 4);
+  HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(out_dist, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
   return 0;
 }
 
-static bool host_pointer_is_pinned(const void* p) {
+struct PipeCall {   // the arguments of one host-buffer call, for the lanes' retire step
+  freddy_gpu_index* ix;
+  const float* queries;
+  int k, W, found_rule;
+  float sentinel;
+  int32_t* out_ids;
+  float* out_dist;
+};
+
+// Wait for a slot's sub-batch and hand its lists to the caller.  Queries that round one left unfinished (their first W
+// cells hold fewer than k rows -- rare) are searched again from the start, synchronously, with all their rounds: the
+// search is deterministic, so that is the list the round-by-round continuation would have produced, and no lane has to
+// keep per-round state while its stream already runs the next sub-batch.
+static int lane_retire(LaneSlot& c, const PipeCall& pc) {
+  if (!c.busy) return 0;
+  c.busy = false;
+  HIP_TRY(hipEventSynchronize(c.done));
+  const int k = pc.k;
+  const size_t n_out = (size_t)c.n * k;
+  const int32_t* ho = static_cast<const int32_t*>(c.h_out);
+  memcpy(pc.out_ids + (size_t)c.q0 * k, ho, n_out * 4);
+  memcpy(pc.out_dist + (size_t)c.q0 * k, ho + n_out, n_out * 4);
+  const int n_next = std::min(ho[2 * n_out], c.n);
+  if (n_next <= 0) return 0;
+  const int d = pc.ix->d;
+  std::vector<int32_t> who(ho + 2 * n_out + 1, ho + 2 * n_out + 1 + n_next);
+  std::vector<float> q((size_t)n_next * d);
+  std::vector<int32_t> ri((size_t)n_next * k);
+  std::vector<float> rd((size_t)n_next * k);
+  for (int i = 0; i < n_next; ++i) memcpy(&q[(size_t)i * d], pc.queries + ((size_t)c.q0 + who[(size_t)i]) * d, sizeof(float) * d);
+  if (int rc = ivfadc_sync_search(pc.ix, q.data(), n_next, k, pc.W, pc.sentinel, pc.found_rule, ri.data(), rd.data())) return rc;
+  for (int i = 0; i < n_next; ++i) {
+    memcpy(pc.out_ids + ((size_t)c.q0 + who[(size_t)i]) * k, &ri[(size_t)i * k], sizeof(int32_t) * k);
+    memcpy(pc.out_dist + ((size_t)c.q0 + who[(size_t)i]) * k, &rd[(size_t)i * k], sizeof(float) * k);
+  }
+  return 0;
+}
+
+// the device-side address of a pinned (hipHostMalloc / freddy_gpu_host_alloc) host buffer, or NULL for ordinary memory
+static const void* pinned_device_pointer(const void* p) {
   hipPointerAttribute_t attr;
   memset(&attr, 0, sizeof(attr));
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-  return attr.type == hipMemoryTypeHost;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
 }
 
 // the batch [0, Q) of one device's handle
@@ -1567,30 +1625,59 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
   const int n_sub = (Q + cap - 1) / cap;
   const int per = (Q + n_sub - 1) / n_sub;               // equal sub-batches rather than full ones and a remainder
   const int n_lanes = std::min(n_sub, std::min(ix->tune.pipeline_lanes, FREDDY_LANES));
-  const bool pinned_in = host_pointer_is_pinned(queries);
+  const float* pinned_in = static_cast<const float*>(pinned_device_pointer(queries));
   const size_t row = sizeof(float) * (size_t)ix->d;
+  const PipeCall pc{ix, queries, k, W, found_rule, sentinel, out_ids, out_dist};
   int rc = 0;
+  const bool trace = ix->tune.pipe_trace != 0;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = trace ? now_us() : 0.0;
+  auto slot_of = [&](int j) -> LaneSlot& { return ix->lanes[j % n_lanes].slot[(j / n_lanes) & 1]; };
   for (int j = 0; j < n_sub && !rc; ++j) {
     Lane& l = ix->lanes[j % n_lanes];
-    if ((rc = lane_retire(l, k, out_ids, out_dist))) break;
+    LaneSlot& c = slot_of(j);
+    double t0 = trace ? now_us() : 0.0, t1 = 0, t2 = 0, t3 = 0;
+    if ((rc = lane_retire(c, pc))) break;
+    if (trace) t1 = now_us();
     const int q0 = j * per, n = std::min(per, Q - q0);
-    if ((rc = lane_open(ix, l, row * n, (size_t)n * k))) break;
-    l.q0 = q0; l.n = n;
-    const float* src = queries + (size_t)q0 * ix->d;
-    if (!pinned_in) { memcpy(l.h_in, src, row * n); src = static_cast<const float*>(l.h_in); }
-    if (hipMemcpyAsync(l.d_q.p, src, row * n, hipMemcpyHostToDevice, l.stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "H2D of the queries failed"); break; }
-    if ((rc = ivfadc_begin(ix, l.stream, n_lanes, l.d_q.as<float>(), n, k, W, sentinel, found_rule, l.d_ids.as<int32_t>(),
-                           l.d_dist.as<float>(), nullptr, l.run)))
+    if ((rc = lane_open(l, c, row * n, (size_t)n, (size_t)n * k))) break;
+    c.q0 = q0; c.n = n;
+    const float* src = pinned_in ? pinned_in + (size_t)q0 * ix->d : nullptr;
+    if (!src || reinterpret_cast<uintptr_t>(src) % 16 || (row * n) % 16) {   // (the copy kernel moves whole 16-byte words)
+      memcpy(c.h_in, queries + (size_t)q0 * ix->d, row * n);
+      src = static_cast<const float*>(c.h_in);
+    }
+    if (trace) t2 = now_us();
+    {
+      const size_t n16 = (row * n + 15) / 16;
+      hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, l.stream,
+                         reinterpret_cast<const uint4*>(src), c.d_q.as<uint4>(), n16);
+      if (hipGetLastError() != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the query copy failed"); break; }
+    }
+    IvfRun r;
+    if ((rc = ivfadc_begin(ix, l.stream, n_lanes, c.d_q.as<float>(), n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
+                           c.d_dist.as<float>(), nullptr, r)))
       break;
-    if ((rc = lane_copy_out(l, k))) break;
-    l.busy = true;
+    if (trace) t3 = now_us();
+    const int n_out = n * k;
+    hipLaunchKernelGGL(lane_copy_out_kernel, dim3((unsigned)((std::max(n_out, n) + 255) / 256)), dim3(256), 0, l.stream, c.d_ids.as<int32_t>(),
+                       c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(c.done, l.stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the result copy failed"); break; }
+    c.busy = true;
+    if (trace)
+      fprintf(stderr, "[pipe] sub %d lane %d n=%d  t=%.0f us: retire %.0f, stage %.0f, launches %.0f, copy-out + event %.0f\n", j, j % n_lanes, n,
+              t0 - t_start, t1 - t0, t2 - t1, t3 - t2, now_us() - t3);
   }
   // drain in submission order (oldest first)
-  for (int j = std::max(0, n_sub - n_lanes); j < n_sub && !rc; ++j) rc = lane_retire(ix->lanes[j % n_lanes], k, out_ids, out_dist);
+  for (int j = std::max(0, n_sub - 2 * n_lanes); j < n_sub && !rc; ++j) {
+    const double t0 = trace ? now_us() : 0.0;
+    rc = lane_retire(slot_of(j), pc);
+    if (trace) fprintf(stderr, "[pipe] drain sub %d  t=%.0f us: %.0f\n", j, t0 - t_start, now_us() - t0);
+  }
   if (rc)   // a failed call: nothing of it may still be in flight when the caller gets its buffers back
     for (Lane& l : ix->lanes) {
       if (l.stream) (void)hipStreamSynchronize(l.stream);
-      l.busy = false;
+      for (LaneSlot& c : l.slot) c.busy = false;
     }
   return rc;
 }
