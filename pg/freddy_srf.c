@@ -20,6 +20,7 @@
 
 #include "executor/spi.h"
 #include "utils/builtins.h"
+#include "utils/memutils.h"
 
 #include "index_utils.h"
 
@@ -51,9 +52,11 @@ Datum pq_search(PG_FUNCTION_ARGS)
         FuncCallContext *funcctx;
         int    k = PG_GETARG_INT32(1), n;
         float *q = freddy_glue_bytea_f32(PG_GETARG_BYTEA_P(0), &n);
+        freddy_gpu_index_t *h = freddy_glue_pq();
         FreddyRows *r = begin_rows(fcinfo, &funcctx, 1, k, false);
+        freddy_glue_check_dim(n, freddy_glue_dim(h));
         /* replaces freddy.c:69-132: all rows, list sentinel 100.0 */
-        freddy_glue_check(freddy_gpu_pq_search(freddy_glue_pq(), q, 1, k, 100.0f, NULL, 0, r->ids, r->dist));
+        freddy_glue_check(freddy_gpu_pq_search(h, q, 1, k, 100.0f, NULL, 0, r->ids, r->dist));
     }
     return freddy_glue_emit(fcinfo, SRF_PERCALL_SETUP());
 }
@@ -67,9 +70,11 @@ Datum pq_search_in(PG_FUNCTION_ARGS)
         float *q = freddy_glue_bytea_f32(PG_GETARG_BYTEA_P(0), &n);
         int32 *ids = freddy_glue_int_array(PG_GETARG_ARRAYTYPE_P(2), &n_ids);
         int32  none = -1;
+        freddy_gpu_index_t *h = freddy_glue_pq();
         FreddyRows *r = begin_rows(fcinfo, &funcctx, 1, k, false);
+        freddy_glue_check_dim(n, freddy_glue_dim(h));
         /* replaces freddy.c:1086-1143: "WHERE id IN (...)" -- unknown ids vanish, duplicates collapse; sentinel 1000.0 */
-        freddy_glue_check(freddy_gpu_pq_search(freddy_glue_pq(), q, 1, k, 1000.0f, n_ids ? ids : &none, n_ids ? n_ids : 1, r->ids, r->dist));
+        freddy_glue_check(freddy_gpu_pq_search(h, q, 1, k, 1000.0f, n_ids ? ids : &none, n_ids ? n_ids : 1, r->ids, r->dist));
     }
     return freddy_glue_emit(fcinfo, SRF_PERCALL_SETUP());
 }
@@ -85,11 +90,13 @@ Datum pq_search_in_batch(PG_FUNCTION_ARGS)
         int32 *ids = freddy_glue_int_array(PG_GETARG_ARRAYTYPE_P(3), &n_ids);
         int32  none = -1;
         FreddyRows *r;
+        freddy_gpu_index_t *h = freddy_glue_pq();
         if (n_qids != Q) elog(ERROR, "Number of query vectors and query vector ids differs!");   /* freddy.c:495 */
+        if (Q > 0) freddy_glue_check_dim(dim, freddy_glue_dim(h));
         r = begin_rows(fcinfo, &funcctx, Q, k, true);
         memcpy(r->query_ids, qids, sizeof(int32) * Q);
         /* replaces freddy.c:518-631; both useTargetLists branches (arg 4) give the same lists */
-        freddy_glue_check(freddy_gpu_pq_search(freddy_glue_pq(), qs, Q, k, 1000.0f, n_ids ? ids : &none, n_ids ? n_ids : 1, r->ids, r->dist));
+        freddy_glue_check(freddy_gpu_pq_search(h, qs, Q, k, 1000.0f, n_ids ? ids : &none, n_ids ? n_ids : 1, r->ids, r->dist));
     }
     return freddy_glue_emit(fcinfo, SRF_PERCALL_SETUP());
 }
@@ -101,10 +108,12 @@ Datum ivfadc_search(PG_FUNCTION_ARGS)
         FuncCallContext *funcctx;
         int    k = PG_GETARG_INT32(1), n, w = 0;
         float *q = freddy_glue_bytea_f32(PG_GETARG_BYTEA_P(0), &n);
+        freddy_gpu_index_t *h = freddy_glue_ivf();
         FreddyRows *r = begin_rows(fcinfo, &funcctx, 1, k, false);
+        freddy_glue_check_dim(n, freddy_glue_dim(h));
         getParameter(PARAM_W, &w);                                                      /* freddy.c:229 */
         /* replaces freddy.c:239-378: W cells per round, rounds while fewer than k rows were retrieved (:377) */
-        freddy_glue_check(freddy_gpu_ivfadc_search(freddy_glue_ivf(), q, 1, k, w, 1000.0f, FREDDY_FOUND_ROWS, r->ids, r->dist));
+        freddy_glue_check(freddy_gpu_ivfadc_search(h, q, 1, k, w, 1000.0f, FREDDY_FOUND_ROWS, r->ids, r->dist));
     }
     return freddy_glue_emit(fcinfo, SRF_PERCALL_SETUP());
 }
@@ -136,11 +145,12 @@ Datum ivfadc_batch_search(PG_FUNCTION_ARGS)
                 old = MemoryContextSwitchTo(caller);
                 found_ids = palloc(sizeof(int32) * (Q > 0 ? Q : 1));
                 for (int i = 0; i < Q; i++) {
-                    bool   isnull;
-                    bytea *b = DatumGetByteaP(SPI_getbinval(SPI_tuptable->vals[i], SPI_tuptable->tupdesc, 2, &isnull));
-                    int    len = VARSIZE_ANY_EXHDR(b) / sizeof(float4);
-                    if (i == 0) { d = len; qs = palloc(sizeof(float) * (size_t) Q * d); }
-                    found_ids[i] = DatumGetInt32(SPI_getbinval(SPI_tuptable->vals[i], SPI_tuptable->tupdesc, 1, &isnull));
+                    bool   isnull, isnull2;
+                    bytea *b = DatumGetByteaPP(SPI_getbinval(SPI_tuptable->vals[i], SPI_tuptable->tupdesc, 2, &isnull));
+                    int    len = isnull ? -1 : (int) (VARSIZE_ANY_EXHDR(b) / sizeof(float4));
+                    if (i == 0) { d = len; qs = MemoryContextAllocHuge(caller, sizeof(float) * (size_t) Q * (d > 0 ? d : 1)); }
+                    found_ids[i] = DatumGetInt32(SPI_getbinval(SPI_tuptable->vals[i], SPI_tuptable->tupdesc, 1, &isnull2));
+                    if (isnull || isnull2 || len != d || d <= 0) elog(ERROR, "freddy_gpu: NULL or ragged vector in %s", vecName);
                     memcpy(qs + (size_t) i * d, VARDATA_ANY(b), sizeof(float) * d);
                 }
                 MemoryContextSwitchTo(old);
@@ -149,10 +159,12 @@ Datum ivfadc_batch_search(PG_FUNCTION_ARGS)
         }
         r = begin_rows(fcinfo, &funcctx, Q, k, true);
         if (Q > 0) {
+            freddy_gpu_index_t *h = freddy_glue_ivf();
+            freddy_glue_check_dim(d, freddy_glue_dim(h));
             memcpy(r->query_ids, found_ids, sizeof(int32) * Q);
             /* replaces the whole while (!finished) loop, freddy.c:835-982: one cell per query and round (argmin from
              * minDist = 1000), rounds until k candidates were ACCEPTED (:971), list sentinel 100.0 */
-            freddy_glue_check(freddy_gpu_ivfadc_search(freddy_glue_ivf(), qs, Q, k, 1, 100.0f, FREDDY_FOUND_BATCH_UDF, r->ids, r->dist));
+            freddy_glue_check(freddy_gpu_ivfadc_search(h, qs, Q, k, 1, 100.0f, FREDDY_FOUND_BATCH_UDF, r->ids, r->dist));
         }
     }
     return freddy_glue_emit(fcinfo, SRF_PERCALL_SETUP());

@@ -31,6 +31,7 @@ Datum ivpq_search_in(PG_FUNCTION_ARGS)
         float4 confidence = PG_GETARG_FLOAT4(8);
         int    double_threshold = PG_GETARG_INT32(9);
         freddy_track t;
+        freddy_gpu_index_t *h;
         FreddyRows *r;
         if (n_qids != Q)                                                                   /* :180 */
             elog(ERROR, "Number of query vectors and query vector ids differs! ( %d, %d)", n_qids, Q);
@@ -52,9 +53,11 @@ Datum ivpq_search_in(PG_FUNCTION_ARGS)
             funcctx->user_fctx = r;
             MemoryContextSwitchTo(old);
         }
-        freddy_glue_check(freddy_gpu_knn_join(freddy_glue_ivpq(), qs, Q, k, targets, n_targets, alpha, pvf, method,
+        h = freddy_glue_ivpq();
+        if (Q > 0) freddy_glue_check_dim(dim, freddy_glue_dim(h));
+        freddy_glue_check(freddy_gpu_knn_join(h, qs, Q, k, targets, n_targets, alpha, pvf, method,
                                               use_target_lists ? 1 : 0, confidence, double_threshold, r->ids, r->dist, &iterations));
-        if (freddy_gpu_last_track(freddy_glue_ivpq(), &t) == FREDDY_OK) {
+        if (freddy_gpu_last_track(h, &t) == FREDDY_OK) {
             elog(INFO, "TRACK precomputation_time %f", t.precomputation_time);                                   /* :294 */
             elog(INFO, "TRACK determine_coarse_quantization_time %f", t.determine_coarse_quantization_time);     /* :341 */
             elog(INFO, "TRACK query_construction_time %f", t.query_construction_time);                           /* :397 */

@@ -129,13 +129,22 @@ def test_pg_hosts_bind_the_declared_abi():
     import re
     hdr = open(os.path.join(ROOT, "include", "freddy_gpu.h")).read()
     declared = set(re.findall(r"\b(freddy_gpu_\w+)\s*\(", hdr))
-    srcs = {f: open(os.path.join(ROOT, "pg", f)).read() for f in ("freddy_srf.c", "ivpq_search_in.c", "freddy_gpu_glue.c")}
+    srcs = {f: open(os.path.join(ROOT, "pg", f)).read() for f in ("freddy_srf.c", "ivpq_search_in.c", "freddy_gpu_glue.c", "freddy_insert.c")}
     called = set()
     for text in srcs.values():
         called |= set(re.findall(r"\b(freddy_gpu_\w+)\s*\(", text))
     assert called and called <= declared, called - declared
-    v1 = set(re.findall(r"PG_FUNCTION_INFO_V1\((\w+)\)", srcs["freddy_srf.c"] + srcs["ivpq_search_in.c"]))
-    assert v1 == {"pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search", "ivpq_search_in"}
+    v1 = set(re.findall(r"PG_FUNCTION_INFO_V1\((\w+)\)", srcs["freddy_srf.c"] + srcs["ivpq_search_in.c"] + srcs["freddy_insert.c"]))
+    assert v1 == {"pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search", "ivpq_search_in",
+                  "insert_batch", "grouping_pq"}
+    # every glue function a host calls is declared in the glue header and defined in the glue
+    glue_h = open(os.path.join(ROOT, "pg", "freddy_gpu_glue.h")).read()
+    glue_calls = set()
+    for f in ("freddy_srf.c", "ivpq_search_in.c", "freddy_insert.c"):
+        glue_calls |= set(re.findall(r"\b(freddy_glue_\w+)\s*\(", srcs[f]))
+    for fn in glue_calls:
+        assert re.search(r"\b%s\s*\(" % fn, glue_h), f"{fn} is not declared in pg/freddy_gpu_glue.h"
+        assert re.search(r"^[\w \*]+\b%s\s*\(" % fn, srcs["freddy_gpu_glue.c"], re.M), f"{fn} is not defined in pg/freddy_gpu_glue.c"
     mk = open(os.path.join(ROOT, "pg", "Makefile")).read()
-    for fn in ("pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search"):
+    for fn in ("pq_search", "ivfadc_search", "pq_search_in", "pq_search_in_batch", "ivfadc_batch_search", "grouping_pq", "insert_batch"):
         assert f"-D{fn}=freddy_cpu_{fn}" in mk      # the reference's own copies step aside
