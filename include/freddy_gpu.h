@@ -285,6 +285,11 @@ typedef struct freddy_track {
   int64_t candidate_rows;                    /* sum over queries of the target rows in their selected cells (what the kernel scans) */
   int32_t iterations;                        /* alpha-doubling rounds */
   int32_t reserved;
+  int64_t host_traversals;                   /* (query, round) pairs whose multi-index traversal ran on the host heap: every one with more than
+                                              * 1024 cells; with the device traversal only those it hands back (equal keys in the taken prefix,
+                                              * or the host's libm disagreeing with the proposed stop) */
+  int64_t libm_checks;                       /* evaluations of getConfidenceHyp by the host's libm on device-proposed stops (only where the device's
+                                              * own value lies within 1e-5 of the confidence) */
 } freddy_track;
 int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
 

@@ -82,6 +82,8 @@ struct Tuning {
                                // 5.2c).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
   int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
+  int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
+  int scan_quota_wgs = 0;      // FREDDY_GPU_SCAN_QUOTA_WGS: number of quota-limited workgroups in front of the persistent ones (0 = from the batch's size)
   int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
@@ -113,6 +115,8 @@ static Tuning read_tuning() {
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
   t.pipe_trace = (int)env_int("FREDDY_GPU_PIPE_TRACE", 0);
+  t.scan_quota = (int)env_int("FREDDY_GPU_SCAN_QUOTA", t.scan_quota);
+  t.scan_quota_wgs = (int)env_int("FREDDY_GPU_SCAN_QUOTA_WGS", t.scan_quota_wgs);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
@@ -744,6 +748,7 @@ extern "C" int freddy_gpu_pin_ivpq(const freddy_ivpq_desc* t, int device, freddy
   int rc = open_device(ix, device);
   if (!rc) {
     rc = join_pin(&ix->join, t, &ix->bytes);
+    ix->join.host_traversal = env_int("FREDDY_GPU_JOIN_HOST_TRAVERSAL", 0) != 0;
     if (rc) rc = fail(rc, "%s", join_error());
   }
   if (rc) { free_index(ix); return rc; }
@@ -863,6 +868,10 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "partition_cus") t.partition_cus = (int)value;
   else if (n == "scan_share") t.scan_share = (int)std::max<int64_t>(1, value);
   else if (n == "pipe_trace") t.pipe_trace = (int)value;
+  else if (n == "join_host_traversal") ix->join.host_traversal = value != 0;
+  else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
+  else if (n == "scan_quota") t.scan_quota = (int)value;
+  else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
@@ -1173,7 +1182,17 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   // each (a shorter tail).  Measured: 4 batches in flight, 256 / 192 / 128 / 64 workgroups: 7.86 / 8.0 / 8.26 / 8.6 M q/s.
   const int scan_cus = parted ? ix->n_cus - ws->part_cus
                               : std::max(ix->n_cus / std::max(1, r.share), std::min(ix->n_cus, 32)) - ix->tune.reserve_cus;
-  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
+  unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
+  fl.quota = 0; fl.quota_wgs = 0;
+  if (v5 && ix->tune.scan_quota > 0 && !parted) {
+    // quota-limited workgroups in front of the persistent ones: grid > CUs, the hardware hands a CU to whatever is queued
+    // next whenever one of them leaves -- the batches in flight share the chip at work-entry granularity
+    const size_t est = std::min<size_t>(wt.max_groups, (size_t)r.n_active * r.W / SCAN5_G + std::min<size_t>((size_t)ix->C, (size_t)r.n_active * r.W));
+    const int qw = ix->tune.scan_quota_wgs > 0 ? ix->tune.scan_quota_wgs : (int)(est * 6 / 10 / (size_t)ix->tune.scan_quota);
+    fl.quota = ix->tune.scan_quota;
+    fl.quota_wgs = std::max(0, qw);
+    n_persist += (unsigned)fl.quota_wgs;
+  }
   hipStream_t ss = r.s_scan;
   if (parted) {   // records (and everything before them) -> scan, on the stream masked to the scan's CUs
     HIP_TRY(hipEventRecord(ws->ev_fe, s));
@@ -2465,7 +2484,7 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
       }
       const size_t o = (size_t)j.N, nn = (size_t)(j.N + n);
       if (grow_device_array(&j.ids, o, nn, ids, (size_t)n) || grow_device_array(&j.cell, o, nn, coarse_id, (size_t)n) ||
-          grow_device_array(&j.codes, o * j.m, nn * j.m, codes, (size_t)n * j.m) ||
+          grow_device_array(&j.codes, o * j.MP, nn * j.MP, join_pad_codes(codes, n, j.m, j.MP).data(), (size_t)n * j.MP) ||
           (j.has_vectors && grow_device_array(&j.vectors, o * j.d, nn * j.d, vectors, (size_t)n * j.d)))
         return fail(FREDDY_E_NOMEM, "device allocation failed");
       if (j.markbits) (void)hipFree(j.markbits);

@@ -49,6 +49,9 @@ struct FilterArgs {
   uint32_t desc_offset;
   uint32_t ablate;
   long long* prof;
+  // Quota-limited workgroups (fused5.h): the first `quota_wgs` workgroups of the grid stop after `quota` work entries;
+  // the rest are persistent and drain the table.  quota_wgs = 0: every workgroup persistent.
+  int quota, quota_wgs;
 };
 
 static constexpr float FILT_EPS = 2048.0f * 5.9604644775390625e-8f * 1.0001f;   // E = FILT_EPS * B

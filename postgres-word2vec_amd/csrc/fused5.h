@@ -227,7 +227,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   const int n_work = a.n_groups[0];
 
   int cur = 0, ei = 0;
-  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = atomicAdd(a.work_counter, 1); }
+  // entries this workgroup may take: the first quota_wgs workgroups of the grid leave after `quota` entries (their CU goes
+  // to whatever is queued next -- another batch's scan or small kernels), the others stay until the table is empty
+  const int quota = ((int)blockIdx.x < a.quota_wgs) ? a.quota : 0x7fffffff;
+  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = quota > 1 ? atomicAdd(a.work_counter, 1) : 0x7fffffff; }
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
   __syncthreads();
   if (gidq[0] >= n_work) return;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         else issue(set, j + 3 - NP, nqid);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
         if (j == 2) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
         if (j == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
-        if (j == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
+        if (j == 0 && tid == 0) gid2 = ei + 2 < quota ? atomicAdd(a.work_counter, 1) : 0x7fffffff;
         tick(0);
         lds_barrier();
         tick(1);

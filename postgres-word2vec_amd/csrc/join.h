@@ -3,10 +3,16 @@
 // Split of work
 //   GPU  sub_dist_kernel : the 2 x coarse_codes sub-distances of every query to the
 //                          multi-index centroids (index_utils.c:297-305), fp32 sequential.
-//   host multi-index cell selection with statistics (index_utils.c:252-443): per-position
-//        stable sort, heap traversal, getConfidenceHyp (:673-682) in the host's libm --
-//        a confidence that lands on the other side of the threshold changes the candidate
-//        set, so erf/sqrt stay where the reference evaluates them.
+//   GPU  join_traverse_kernel : multi-index cell selection with statistics (index_utils.c:252-443)
+//        for up to 1024 cells, one wave per query.  The reference's heap pops the cells in ascending
+//        d0[c0] + d1[c1]; with no two equal keys among the cells a query takes (and the first it leaves)
+//        that sequence IS the sorted order, so the wave sorts the 1024 keys, forms the running sum of the
+//        cells' statistics in that order (sequential binary32 adds, as :424) and finds the first count n
+//        whose getConfidenceHyp (:673-682) reaches the confidence.  The HOST's libm keeps the last word:
+//        it evaluates the reference's expression at the stop the device proposes and one step before it
+//        (the confidence is non-decreasing in the running sum); a query whose check fails, or whose
+//        prefix holds two equal keys (the heap's order among equals is history-dependent), is traversed
+//        on the host exactly as before (join_select_cells).  More than 1024 cells: the host path.
 //   host "WHERE coarse_id IN (...) AND id IN (...)" (ivpq_search_in.c:352-401): targets are
 //        bucketed by cell once per call; a query's candidates are the buckets of its cells.
 //   GPU  join_query_kernel : one workgroup per query: LUT (index_utils.c:445-455, pair LUT
@@ -69,16 +75,22 @@ static inline int join_fail(int code, const char* fmt, ...) {
 
 struct JoinIndex {
   int d = 0, m = 0, K = 0, S = 0, Kc = 0, cells = 0;
+  int MP = 0;                 // pitch of a code row in int16: m rounded up to a multiple of 8 (16-byte aligned rows, zero padded)
   int64_t N = 0;
   bool has_vectors = false;
   // device
   float* cbT = nullptr;       // [m][S][K]
   float* coarseT = nullptr;   // [2][d/2][Kc]
   int32_t* ids = nullptr;     // [N]
-  int16_t* codes = nullptr;   // [N][m]
+  int16_t* codes = nullptr;   // [N][MP] -- a lane fetches a row with 16-byte loads
   float* vectors = nullptr;   // [N][d]
   int32_t* cell = nullptr;    // [N] coarse cell of each row
   uint32_t* markbits = nullptr;  // [ceil(N/32)] scratch bitmap of the "id IN (targets)" resolution
+  float* d_stats = nullptr;      // [cells+1] the statistics row (device traversal)
+  void* h_q = nullptr;           // pinned staging of the query batch (read by a copy kernel: no SDMA ordering hops)
+  size_t h_q_cap = 0;
+  void* h_sum = nullptr;         // pinned: per-round traversal summaries and result lists come back here
+  size_t h_sum_cap = 0;
   // host
   std::vector<int32_t> h_ids, h_cell;
   std::vector<float> h_stats;
@@ -86,6 +98,8 @@ struct JoinIndex {
   // workspaces
   void* w[16] = {nullptr};
   size_t wcap[16] = {0};
+  float libm_margin = 1e-5f;     // option join_libm_margin_ppm: device confidences this close to the threshold are re-evaluated by the host's libm
+  bool host_traversal = false;   // option join_host_traversal / FREDDY_GPU_JOIN_HOST_TRAVERSAL: every traversal on the host heap
   // stage timers of the last call under the reference's TRACK names (ivpq_search_in.c:234-697)
   freddy_track track;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -105,8 +119,10 @@ static inline int join_buf(JoinIndex* j, int slot, size_t bytes, void** out) {
 }
 
 static inline void join_free(JoinIndex* j) {
-  void* ptrs[] = {j->cbT, j->coarseT, j->ids, j->codes, j->vectors, j->cell, j->markbits};
+  void* ptrs[] = {j->cbT, j->coarseT, j->ids, j->codes, j->vectors, j->cell, j->markbits, j->d_stats};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (j->h_q) (void)hipHostFree(j->h_q);
+  if (j->h_sum) (void)hipHostFree(j->h_sum);
   for (int i = 0; i < 16; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
   if (j->ev0) (void)hipEventDestroy(j->ev0);
   if (j->ev1) (void)hipEventDestroy(j->ev1);
@@ -122,9 +138,16 @@ static inline int join_upload(T** dst, const T* src, size_t n, int64_t* bytes) {
   return 0;
 }
 
+static inline std::vector<int16_t> join_pad_codes(const int16_t* codes, int64_t n, int m, int MP) {
+  std::vector<int16_t> out((size_t)std::max<int64_t>(n, 1) * MP, 0);
+  for (int64_t r = 0; r < n; ++r) memcpy(&out[(size_t)r * MP], codes + (size_t)r * m, sizeof(int16_t) * m);
+  return out;
+}
+
 static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* bytes) {
   j->d = t->d; j->m = t->m; j->K = t->K; j->S = t->d / t->m; j->Kc = t->coarse_codes;
   j->cells = t->coarse_codes * t->coarse_codes;
+  j->MP = (t->m + 7) & ~7;
   j->N = t->N;
   j->has_vectors = t->vectors != nullptr;
   if (t->K > 32767) return join_fail(FREDDY_E_LIMIT, "K=%d does not fit an int16 code", t->K);
@@ -146,8 +169,8 @@ static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* byt
     for (int c = 0; c < Kc; ++c)
       for (int i = 0; i < half; ++i) cqT[((size_t)p * half + i) * Kc + c] = t->coarse[((size_t)p * Kc + c) * half + i];
   if (join_upload(&j->cbT, cbT.data(), cbT.size(), bytes) || join_upload(&j->coarseT, cqT.data(), cqT.size(), bytes) ||
-      join_upload(&j->ids, t->ids, (size_t)t->N, bytes) || join_upload(&j->codes, t->codes, (size_t)t->N * m, bytes) ||
-      join_upload(&j->cell, t->coarse_id, (size_t)t->N, bytes) ||
+      join_upload(&j->ids, t->ids, (size_t)t->N, bytes) || join_upload(&j->codes, join_pad_codes(t->codes, t->N, m, j->MP).data(), (size_t)t->N * j->MP, bytes) ||
+      join_upload(&j->cell, t->coarse_id, (size_t)t->N, bytes) || join_upload(&j->d_stats, t->stats, (size_t)j->cells + 1, bytes) ||
       (t->vectors && join_upload(&j->vectors, t->vectors, (size_t)t->N * t->d, bytes)))
     return join_fail(FREDDY_E_NOMEM, "device allocation failed while pinning the ivpq tables");
   j->h_ids.assign(t->ids, t->ids + t->N);
@@ -157,6 +180,11 @@ static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* byt
     return join_fail(FREDDY_E_NOMEM, "device allocation failed while pinning the ivpq tables");
   j->ids_affine = t->N > 0 && (int64_t)t->ids[t->N - 1] - t->ids[0] == t->N - 1;   // strictly ascending => consecutive
   return 0;
+}
+
+// pinned host memory -> device (the queries of a call; pinned memory is mapped into the device's address space)
+__global__ __launch_bounds__(256) void join_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -261,12 +289,15 @@ __global__ __launch_bounds__(256) void join_place_kernel(const int32_t* __restri
 struct JoinArgs {
   const float* queries;       // [Q][d]
   const int32_t* scan_query;  // [n_scan] query index
-  const int32_t* qcell_off;   // [n_scan+1] offsets into qcells
+  const int32_t* qcell_off;   // [n_scan+1] offsets into qcells (host traversal), or NULL:
+  const int32_t* qcell_cnt;   // [Q] cells in row q of qcells[Q][qstride] (device traversal)
+  int qstride;
   const int32_t* qcells;      // cells probed by each scanned query
   const int32_t* tcell_off;   // [cells+1] target buckets by cell
   const int32_t* trow;        // target rows, ascending inside a bucket
   const int32_t* ids;         // [N]
-  const int16_t* codes;       // [N][m]
+  const int16_t* codes;       // [N][MP], rows 16-byte aligned
+  int MP;
   const float* vectors;       // [N][d]
   const float* cbT;           // [m][S][K]
   int32_t* out_ids;           // [n_scan][k]
@@ -280,6 +311,20 @@ __device__ __forceinline__ float sqdist_seq(const float* a, const float* __restr
     const float t = a[i] - b[i];
     const float p = t * t;
     acc = acc + p;
+  }
+  return acc;
+}
+
+// the same chain, the vector read with 16-byte loads (a lane walks its own row: a quarter of the load instructions)
+__device__ __forceinline__ float sqdist_seq4(const float* a, const float* __restrict__ b, int n) {
+  const float4* b4 = reinterpret_cast<const float4*>(b);
+  float acc = 0.0f;
+  for (int i = 0; i < n; i += 4) {
+    const float4 v = b4[i >> 2];
+    float t = a[i] - v.x;     float p = t * t; acc = acc + p;
+    t = a[i + 1] - v.y; p = t * t; acc = acc + p;
+    t = a[i + 2] - v.z; p = t * t; acc = acc + p;
+    t = a[i + 3] - v.w; p = t * t; acc = acc + p;
   }
   return acc;
 }
@@ -332,10 +377,12 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
     }
   }
   const float* tab = a.double_codes ? lut2 : lut;
+  const bool vec4 = (d & 3) == 0;   // (rows of d floats are then 16-byte aligned: hipMalloc'd base, pitch 4 d)
 
   WaveSelect<V> sel;
   sel.init(stage + wave * 64, (u64)__float_as_uint(JOIN_MAX_DIST) << 32, L);
-  const int c_begin = a.qcell_off[x], c_end = a.qcell_off[x + 1];
+  const int c_begin = a.qcell_off ? a.qcell_off[x] : q * a.qstride;
+  const int c_end = a.qcell_off ? a.qcell_off[x + 1] : c_begin + a.qcell_cnt[q];
   for (int ci = c_begin + wave; ci < c_end; ci += JOIN_WAVES) {
     const int cell = a.qcells[ci];
     const int r0 = a.tcell_off[cell], r1 = a.tcell_off[cell + 1];
@@ -347,16 +394,39 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
       if (valid) {
         row = a.trow[t];
         if (a.method == FREDDY_METHOD_EXACT) {
-          dist = sqdist_seq(qv, a.vectors + (size_t)row * d, d);
+          dist = vec4 ? sqdist_seq4(qv, a.vectors + (size_t)row * d, d) : sqdist_seq(qv, a.vectors + (size_t)row * d, d);
         } else {
-          const int16_t* cd = a.codes + (size_t)row * m;
-          if (a.double_codes) {
-            for (int l = 0; l < n_codes; ++l) {                 // ivpq_search_in.c:446-451 (int16 pair code)
-              const int pc = (int16_t)(cd[2 * l] + cd[2 * l + 1] * K);
-              dist = dist + tab[range * l + pc];
+          // the row's codes: MP / 8 loads of 16 bytes (the first four issued together), eight codes each
+          const uint4* cd4 = reinterpret_cast<const uint4*>(a.codes + (size_t)row * a.MP);
+          const int nch = a.MP >> 3;
+          uint4 w4[4];
+#pragma unroll
+          for (int c8 = 0; c8 < 4; ++c8) w4[c8] = c8 < nch ? cd4[c8] : uint4{0u, 0u, 0u, 0u};
+          for (int c0 = 0; c0 < nch; c0 += 4) {
+            if (c0 > 0) {
+#pragma unroll
+              for (int c8 = 0; c8 < 4; ++c8) w4[c8] = c0 + c8 < nch ? cd4[c0 + c8] : uint4{0u, 0u, 0u, 0u};
             }
-          } else {
-            for (int l = 0; l < m; ++l) dist = dist + tab[K * l + cd[l]];   // index_utils.c:1126-1133
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+              const uint32_t ww[4] = {w4[c8].x, w4[c8].y, w4[c8].z, w4[c8].w};
+              if (a.double_codes) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {                     // ivpq_search_in.c:446-451 (int16 pair code)
+                  const int l = (c0 + c8) * 4 + u;
+                  if (l < n_codes) {
+                    const int pc = (int16_t)((int)(ww[u] & 0xffffu) + (int)(ww[u] >> 16) * K);
+                    dist = dist + tab[range * l + pc];
+                  }
+                }
+              } else {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {                     // index_utils.c:1126-1133
+                  const int l = (c0 + c8) * 8 + u;
+                  if (l < m) dist = dist + tab[K * l + (int)((ww[u >> 1] >> ((u & 1) * 16)) & 0xffffu)];
+                }
+              }
+            }
           }
         }
       }
@@ -394,9 +464,14 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
   __syncthreads();
   if (a.method == FREDDY_METHOD_PQ_PV) {
     // postverify, index_utils.c:477-498: exact distance of each of the k*pvf survivors
-    for (int e = threadIdx.x; e < L; e += JOIN_WG) {
-      const u64 c = lists[e];
-      exact[e] = (c == KEY_INF) ? 0.0f : sqdist_seq(qv, a.vectors + (size_t)key_pos(c) * d, d);
+    // (survivor e on lane e / 4 of wave e % 4: the four waves' loads run side by side)
+    for (int e0 = 0; e0 < L; e0 += JOIN_WG) {
+      const int e = e0 + (int)(threadIdx.x & 63) * JOIN_WAVES + (int)(threadIdx.x >> 6);
+      if (e < L) {
+        const u64 c = lists[e];
+        exact[e] = (c == KEY_INF) ? 0.0f
+                   : vec4 ? sqdist_seq4(qv, a.vectors + (size_t)key_pos(c) * d, d) : sqdist_seq(qv, a.vectors + (size_t)key_pos(c) * d, d);
+      }
     }
     __syncthreads();
   }
@@ -442,6 +517,148 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
   for (int i = threadIdx.x; i < k; i += JOIN_WG) {
     a.out_ids[(size_t)x * k + i] = s_id[i];
     a.out_dist[(size_t)x * k + i] = s_d[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// device: a10 multi-index traversal for <= 1024 cells             index_utils.c:252-443
+// ---------------------------------------------------------------------------------------
+// getConfidenceHyp (index_utils.c:673-682) with the reference's types: float variables, double sub-expressions.
+// The device's erf is not glibc's bit for bit: the host re-evaluates the expression at the proposed stop.
+__host__ __device__ __forceinline__ float join_confidence_expr(int expect, int size, float p, int stat_size) {
+  if (expect > size) return 0;
+  float mu = size * p;
+  float sig = sqrt(size * p * (1.0 - p)) * (((float)stat_size - size) / ((float)stat_size - 1.0));
+  return 1.0 - 0.5 * (1.0 + erf((((float)expect) - 0.5 - mu) / (sig * sqrt(2.0))));
+}
+
+static constexpr int TRAV_SUM_DW = 8;   // per query: n, cells with targets, target rows, flags (1 tie, 2 exhausted), bits(P_n), bits(P_{n-1})
+struct TravArgs {
+  const float* sub;          // [Q][2][Kc]
+  const int32_t* active;     // [n_active]
+  const float* stats;        // [cells+1]
+  const int32_t* tcell_off;  // [cells+1]
+  int32_t* qcells;           // [Q][cells]: the taken cells that hold targets, in the order they are taken
+  int32_t* qcell_cnt;        // [Q]
+  int32_t* summary;          // [n_active][TRAV_SUM_DW]
+  int Kc, cells, n_targets, min_target;
+  float confidence;
+};
+
+// One wave per query.  Most queries take a few dozen cells: the 64 smallest keys come from a streaming selection
+// (WaveSelect) and decide the stop; only a query that needs more than 63 cells sorts all of them -- a bitonic sort in LDS
+// with ROLLED loops: the fully unrolled register sort of 1024 keys is ~100 KB of straight-line code that every wave
+// streamed through the 64 KB instruction cache once (380 us per launch for 5 000 queries, as long as the join itself).
+template <int V>
+__global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
+  __shared__ u64 s_key[64 * V];        // (distance bits << 32) | cell, ascending from index 0 as far as they are sorted
+  __shared__ float s_stat[64 * V];
+  __shared__ float s_P[64 * V + 1];
+  __shared__ u64 s_stage[64];
+  const int lane = threadIdx.x, x = blockIdx.x;
+  const int q = a.active[x];
+  const int Kc = a.Kc, cells = a.cells;
+  const float* d0 = a.sub + ((size_t)q * 2) * Kc;
+  const float* d1 = d0 + Kc;
+  auto cell_key = [&](int c) -> u64 {
+    if (c >= cells) return KEY_INF;
+    float acc = 0;            // 0 + D0[c0] + D1[c1], index_utils.c:306-313
+    acc += d0[c % Kc];
+    acc += d1[c / Kc];
+    return make_key(acc, (uint32_t)c);
+  };
+  const int stat_size = (int)a.stats[cells];
+  // ---- the 64 smallest keys, ascending
+  {
+    WaveSelect<1> sel;
+    sel.init(s_stage, KEY_INF, 64);
+#pragma unroll 1
+    for (int v = 0; v < V; ++v) {
+      const u64 kk = cell_key(v * 64 + lane);
+      sel.push(kk, kk != KEY_INF);
+    }
+    sel.finish();
+    s_key[lane] = sel.acc[0];
+    s_stat[lane] = (sel.acc[0] != KEY_INF) ? a.stats[key_pos(sel.acc[0])] : 0.0f;
+  }
+  if (lane == 0) s_P[0] = 0.0f;
+  __syncthreads();
+  // n = the first count whose confidence reaches the threshold ("while (conf(prob) < confidence && emitted < cells)"):
+  // lane 0 extends the running sum by a chunk of 64 cells (prob += statistics[cell], :424, sequential binary32 adds),
+  // then the 64 lanes test the chunk's 64 counts
+  int n = cells;
+  bool sorted_all = (V == 1);
+  for (int base = 0; base < cells; base += 64) {
+    if (base > 0 && !sorted_all) {
+      // more than 63 cells: every key, sorted (rolled bitonic network over LDS; 64 V is a power of two)
+#pragma unroll 1
+      for (int v = 0; v < V; ++v) s_key[v * 64 + lane] = cell_key(v * 64 + lane);
+      __syncthreads();
+#pragma unroll 1
+      for (int k = 2; k <= 64 * V; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll 1
+          for (int t = lane; t < 32 * V; t += 64) {
+            const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            const int l = i | j;
+            const u64 lo = s_key[i], hi = s_key[l];
+            const bool up = (i & k) == 0;
+            if ((lo > hi) == up) { s_key[i] = hi; s_key[l] = lo; }
+          }
+          __syncthreads();
+        }
+      }
+#pragma unroll 1
+      for (int v = 0; v < V; ++v) {
+        const u64 kk = s_key[v * 64 + lane];
+        s_stat[v * 64 + lane] = (kk != KEY_INF) ? a.stats[key_pos(kk)] : 0.0f;
+      }
+      sorted_all = true;
+      __syncthreads();
+    }
+    if (lane == 0) {
+      float P = s_P[base];
+      const int hi = base + 64 < cells ? base + 64 : cells;
+      for (int i = base; i < hi; ++i) { P = P + s_stat[i]; s_P[i + 1] = P; }
+    }
+    __syncthreads();
+    const int cnt = base + lane;
+    const bool ok = cnt < cells && !(join_confidence_expr(a.min_target, a.n_targets, s_P[cnt < cells ? cnt : 0], stat_size) < a.confidence);
+    const u64 m = __ballot(ok);
+    if (m != 0ull) { n = base + (int)__builtin_ctzll(m); break; }
+  }
+  // (n <= 63 when only the 64 smallest keys are sorted; n == cells needs all of them)
+  // equal keys among the first n + 1 sorted cells: the heap's order is history-dependent there -> the host decides
+  bool tie = false;
+  for (int i = lane; i < n && i + 1 < cells; i += 64) tie = tie || ((uint32_t)(s_key[i] >> 32) == (uint32_t)(s_key[i + 1] >> 32));
+  const bool any_tie = __ballot(tie) != 0ull;
+  // the taken cells that hold targets, compacted in order; their rows
+  int n_keep = 0, rows = 0;
+  int32_t* dst = a.qcells + (size_t)q * cells;
+  for (int base = 0; base < n; base += 64) {
+    const int i = base + lane;
+    int tc = 0, c = 0;
+    if (i < n) { c = (int)key_pos(s_key[i]); tc = a.tcell_off[c + 1] - a.tcell_off[c]; }
+    const u64 m = __ballot(tc > 0);
+    if (tc > 0) dst[n_keep + lanes_below(m)] = c;
+    n_keep += (int)__popcll(m);
+    rows += tc;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) rows += __shfl_xor(rows, o, 64);
+  if (lane == 0) {
+    a.qcell_cnt[q] = n_keep;
+    int32_t* sm = a.summary + (size_t)x * TRAV_SUM_DW;
+    sm[0] = n; sm[1] = n_keep; sm[2] = rows; sm[3] = (any_tie ? 1 : 0) | (n >= cells ? 2 : 0);
+    sm[4] = (int32_t)__float_as_uint(s_P[n]);
+    sm[5] = (int32_t)__float_as_uint(n > 0 ? s_P[n - 1] : 0.0f);
+    // the device's own values of the expression at the stop and one step before it: the host re-evaluates with its
+    // libm only where one of them is within 1e-5 of the confidence (the arguments of erf are IEEE-identical on both
+    // sides -- float / double products, correctly rounded sqrt and division -- and the two erf implementations differ
+    // by a few units in the last place of a double)
+    sm[6] = (int32_t)__float_as_uint(join_confidence_expr(a.min_target, a.n_targets, s_P[n], stat_size));
+    sm[7] = (int32_t)__float_as_uint(n > 0 ? join_confidence_expr(a.min_target, a.n_targets, s_P[n - 1], stat_size) : 0.0f);
   }
 }
 
@@ -690,7 +907,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
 
   // "fq.id IN (targets)": resolved, de-duplicated and bucketed by cell on the device (see join_mark_kernel)
   std::vector<int32_t> tcell_off(cells + 1, 0);
-  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells, *d_oi, *d_od, *d_tids, *d_win, *d_cnt, *d_sorted;
+  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells = nullptr, *d_oi, *d_od, *d_tids, *d_win, *d_cnt, *d_sorted;
   if (join_buf(j, 0, sizeof(float) * (size_t)Q * d, &d_q) || join_buf(j, 1, sizeof(float) * (size_t)Q * 2 * Kc, &d_sub) ||
       join_buf(j, 2, sizeof(int32_t) * (size_t)(cells + 1), &d_tcell) ||
       join_buf(j, 3, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_trow) ||
@@ -719,92 +936,218 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     JOIN_HIP(hipMemcpyAsync(tcell_off.data(), d_tcell, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToHost, s));
   }
   track(&freddy_track::data_retrieval_time);   // "fq.id IN (targets)" (enqueue only: the device work overlaps what follows)
-  JOIN_HIP(hipMemcpyAsync(d_q, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
+  {   // queries: host copy into pinned staging, read by a copy kernel (1.2 KB per query over PCIe)
+    const size_t qbytes = sizeof(float) * (size_t)Q * d;
+    if (qbytes > j->h_q_cap) {
+      if (j->h_q) (void)hipHostFree(j->h_q);
+      j->h_q = nullptr; j->h_q_cap = 0;
+      if (hipHostMalloc(&j->h_q, qbytes + qbytes / 4 + 256, hipHostMallocDefault) != hipSuccess) { j->h_q = nullptr; return join_fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+      j->h_q_cap = qbytes + qbytes / 4 + 256;
+    }
+    // (in pieces: the host copies piece i + 1 while the kernel pulls piece i over PCIe)
+    const size_t n4 = qbytes / 4, piece = std::max<size_t>((n4 + 3) / 4, 65536);
+    for (size_t o = 0; o < n4; o += piece) {
+      const size_t len = std::min(piece, n4 - o);
+      memcpy(static_cast<uint32_t*>(j->h_q) + o, reinterpret_cast<const uint32_t*>(queries) + o, len * 4);
+      hipLaunchKernelGGL(join_copy_kernel, dim3((unsigned)std::min<size_t>((len + 255) / 256, 1024)), dim3(256), 0, s, (const uint32_t*)j->h_q + o, (uint32_t*)d_q + o, len);
+    }
+    JOIN_HIP(hipGetLastError());
+  }
   hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc);
   JOIN_HIP(hipGetLastError());
   const int SV = join_pick_V(Kc);
   if (SV == 0) return join_fail(FREDDY_E_LIMIT, "coarse_codes=%d exceeds this build's limit of 1024", Kc);
-  switch (SV) {
-    case 1: hipLaunchKernelGGL((side_sort_kernel<1>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-    case 2: hipLaunchKernelGGL((side_sort_kernel<2>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-    case 4: hipLaunchKernelGGL((side_sort_kernel<4>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-    case 8: hipLaunchKernelGGL((side_sort_kernel<8>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-    default: hipLaunchKernelGGL((side_sort_kernel<16>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+  // The multi-index traversal runs on the device for <= 1024 cells (join_traverse_kernel; the host's libm checks every
+  // stop); larger multi-indexes, option join_host_traversal and the queries the device hands back use the host heap.
+  const bool dev_trav = cells <= 1024 && !j->host_traversal;
+  const int TV = join_pick_V(cells);
+  std::vector<float> sub;
+  std::vector<JoinSide> sides;   // per-query sorted sides (they do not depend on alpha)
+  bool host_sides = false;
+  auto fetch_sides = [&]() -> int {     // the host heap's inputs: sub-distances and their stable per-side order
+    if (host_sides) return 0;
+    sub.resize((size_t)Q * 2 * Kc);
+    sides.resize((size_t)Q * 2 * Kc);
+    switch (SV) {
+      case 1: hipLaunchKernelGGL((side_sort_kernel<1>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+      case 2: hipLaunchKernelGGL((side_sort_kernel<2>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+      case 4: hipLaunchKernelGGL((side_sort_kernel<4>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+      case 8: hipLaunchKernelGGL((side_sort_kernel<8>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+      default: hipLaunchKernelGGL((side_sort_kernel<16>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+    }
+    JOIN_HIP(hipGetLastError());
+    static_assert(sizeof(JoinSide) == 8, "side_sort_kernel writes JoinSide records");
+    JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
+    JOIN_HIP(hipMemcpyAsync(sides.data(), d_sorted, sizeof(JoinSide) * sides.size(), hipMemcpyDeviceToHost, s));
+    JOIN_HIP(hipStreamSynchronize(s));
+    host_sides = true;
+    return 0;
+  };
+  if (!dev_trav) { if (int rc = fetch_sides()) return rc; }
+  // pinned landing zone: [Q][TRAV_SUM_DW] traversal summaries, [Q][k] ids, [Q][k] distances
+  void *d_active = nullptr, *d_qstrided = nullptr, *d_qcnt = nullptr, *d_summary = nullptr;
+  int32_t* h_summary = nullptr; int32_t* h_oi_p = nullptr; float* h_od_p = nullptr;
+  {
+    const size_t need = sizeof(int32_t) * (size_t)Q * (TRAV_SUM_DW + 2 * (size_t)k) + 64;
+    if (need > j->h_sum_cap) {
+      if (j->h_sum) (void)hipHostFree(j->h_sum);
+      j->h_sum = nullptr; j->h_sum_cap = 0;
+      if (hipHostMalloc(&j->h_sum, need + need / 4, hipHostMallocDefault) != hipSuccess) { j->h_sum = nullptr; return join_fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+      j->h_sum_cap = need + need / 4;
+    }
+    h_summary = static_cast<int32_t*>(j->h_sum);
+    h_oi_p = h_summary + (size_t)Q * TRAV_SUM_DW;
+    h_od_p = reinterpret_cast<float*>(h_oi_p + (size_t)Q * k);
   }
-  JOIN_HIP(hipGetLastError());
-  static_assert(sizeof(JoinSide) == 8, "side_sort_kernel writes JoinSide records");
-  std::vector<float> sub((size_t)Q * 2 * Kc);
-  std::vector<JoinSide> sides((size_t)Q * 2 * Kc);   // per-query sorted sides (they do not depend on alpha)
-  JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
-  JOIN_HIP(hipMemcpyAsync(sides.data(), d_sorted, sizeof(JoinSide) * sides.size(), hipMemcpyDeviceToHost, s));
-  JOIN_HIP(hipStreamSynchronize(s));
+  if (dev_trav) {
+    if (join_buf(j, 13, sizeof(int32_t) * (size_t)Q, &d_active) || join_buf(j, 14, sizeof(int32_t) * (size_t)Q * cells, &d_qstrided) ||
+        join_buf(j, 15, sizeof(int32_t) * (size_t)Q * (1 + TRAV_SUM_DW), &d_qcnt))
+      return FREDDY_E_NOMEM;
+    d_summary = static_cast<int32_t*>(d_qcnt) + Q;
+  }
+  if (!dev_trav) JOIN_HIP(hipStreamSynchronize(s));   // (tcell_off is on the host now; the device path waits with its first summaries)
 
-  track(&freddy_track::precomputation_time);   // sub-distances, side sorts and their way back to the host
+  track(&freddy_track::precomputation_time);   // queries in, sub-distances (+ side sorts and their way back for the host heap)
   std::vector<int32_t> active(Q), target_count(Q, 0);
   for (int i = 0; i < Q; ++i) active[i] = i;
-  std::vector<std::vector<int32_t>> qcells(Q);
-  std::vector<int32_t> scan, qoff, flat, h_oi;
-  std::vector<float> h_od;
+  std::vector<std::vector<int32_t>> qcells(Q);          // host-traversed queries only
+  std::vector<int32_t> scan, scan_fb, qoff, flat;
+  std::vector<int32_t> q_n(Q, 0), q_rows(Q, 0);         // this round: cells taken, target rows in them
+  std::vector<uint8_t> q_host(Q, 0), q_exh(Q, 0);        // this round: traversed on the host / exhausted every cell
   int iterations = 0;
+  // Traversal of the n_act queries listed in d_active for `min_target` expected targets; the summaries are on their way to
+  // h_summary (row x of the list) when this returns.  Round r + 1's traversal (alpha doubled) is launched right behind
+  // round r's join kernel, for every query still active: its summaries arrive with round r's lists in one
+  // synchronisation, and the queries that go on find theirs at spec_index[q].
+  std::vector<int32_t> spec_index((size_t)Q, 0);
+  bool spec_valid = false;
+  auto launch_traverse = [&](int n_act, int min_target) -> int {
+    TravArgs ta;
+    ta.sub = (const float*)d_sub; ta.active = (const int32_t*)d_active; ta.stats = j->d_stats; ta.tcell_off = (const int32_t*)d_tcell;
+    ta.qcells = (int32_t*)d_qstrided; ta.qcell_cnt = (int32_t*)d_qcnt; ta.summary = (int32_t*)d_summary;
+    ta.Kc = Kc; ta.cells = cells; ta.n_targets = (int)n_targets; ta.min_target = min_target; ta.confidence = confidence;
+    switch (TV) {
+      case 1: hipLaunchKernelGGL((join_traverse_kernel<1>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+      case 2: hipLaunchKernelGGL((join_traverse_kernel<2>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+      case 4: hipLaunchKernelGGL((join_traverse_kernel<4>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+      case 8: hipLaunchKernelGGL((join_traverse_kernel<8>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+      default: hipLaunchKernelGGL((join_traverse_kernel<16>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+    }
+    JOIN_HIP(hipGetLastError());
+    JOIN_HIP(hipMemcpyAsync(h_summary, d_summary, sizeof(int32_t) * (size_t)n_act * TRAV_SUM_DW, hipMemcpyDeviceToHost, s));
+    return 0;
+  };
   while (!active.empty()) {                                                                 // :299
     ++iterations;
     const int n_active = (int)active.size();
-    std::atomic<int> all_last(1);
-    join_parallel_for(n_active, [&](int lo, int hi, int) {                                    // :327-331
-      JoinTraversal w;
-      bool any_open = false;   // (one shared store per worker, not per query: the flag's cache line was ping-ponging)
-      for (int x = lo; x < hi; ++x) {
-        const int q = active[x];
-        qcells[q].clear();
-        const bool exhausted = join_select_cells(sides.data() + ((size_t)q * 2) * Kc, sides.data() + ((size_t)q * 2 + 1) * Kc,
-                                                 sub.data() + ((size_t)q * 2) * Kc, sub.data() + ((size_t)q * 2 + 1) * Kc, Kc,
-                                                 j->h_stats.data(), (int)n_targets, k * alpha, confidence, w, qcells[q]);
-        if (!exhausted) any_open = true;
+    const int min_target = k * alpha;
+    std::vector<int32_t> fb;                            // queries the host heap has to traverse
+    if (dev_trav) {
+      // (the list on the device is this round's in any case: the traversal launched behind this round's join reads it)
+      JOIN_HIP(hipMemcpyAsync(d_active, active.data(), sizeof(int32_t) * n_active, hipMemcpyHostToDevice, s));
+      if (!spec_valid) {
+        if (int rc = launch_traverse(n_active, min_target)) return rc;
+        JOIN_HIP(hipStreamSynchronize(s));
+        for (int x = 0; x < n_active; ++x) spec_index[(size_t)active[x]] = x;
       }
-      if (any_open) all_last.store(0);
-    });
-    const bool last = all_last.load() != 0;
+      spec_valid = false;
+      // the host's libm decides: the reference's expression at the proposed stop and one step before it
+      const int stat_size = (int)j->h_stats[(size_t)cells];
+      for (int x = 0; x < n_active; ++x) {
+        const int q = active[x];
+        const int32_t* sm = h_summary + (size_t)spec_index[(size_t)q] * TRAV_SUM_DW;
+        const int n = sm[0];
+        float Pn, Pm, Cn, Cm;
+        memcpy(&Pn, &sm[4], 4); memcpy(&Pm, &sm[5], 4); memcpy(&Cn, &sm[6], 4); memcpy(&Cm, &sm[7], 4);
+        bool ok = !(sm[3] & 1) && n >= 0 && n <= cells;
+        const float margin = j->libm_margin;
+        if (ok && n < cells) {
+          ok = !(Cn < confidence);
+          if (!(fabsf(Cn - confidence) > margin)) { ok = !(join_confidence_hyp(min_target, (int)n_targets, Pn, stat_size) < confidence); ++j->track.libm_checks; }
+        }
+        if (ok && n > 0) {
+          ok = Cm < confidence;
+          if (!(fabsf(Cm - confidence) > margin)) { ok = join_confidence_hyp(min_target, (int)n_targets, Pm, stat_size) < confidence; ++j->track.libm_checks; }
+        }
+        q_host[q] = ok ? 0 : 1;
+        if (ok) { q_n[q] = n; q_rows[q] = sm[2]; q_exh[q] = n >= cells; }
+      }
+      for (int q : active) if (q_host[q]) fb.push_back(q);
+    } else {
+      fb = active;
+    }
+    if (!fb.empty()) {
+      if (int rc = fetch_sides()) return rc;
+      for (int q : fb) q_host[q] = 1;
+      join_parallel_for((int)fb.size(), [&](int lo, int hi, int) {                            // :327-331
+        JoinTraversal w;
+        for (int x = lo; x < hi; ++x) {
+          const int q = fb[x];
+          qcells[q].clear();
+          const bool exhausted = join_select_cells(sides.data() + ((size_t)q * 2) * Kc, sides.data() + ((size_t)q * 2 + 1) * Kc,
+                                                   sub.data() + ((size_t)q * 2) * Kc, sub.data() + ((size_t)q * 2 + 1) * Kc, Kc,
+                                                   j->h_stats.data(), (int)n_targets, min_target, confidence, w, qcells[q]);
+          q_exh[q] = exhausted ? 1 : 0;
+          int64_t cnt = 0;
+          for (int32_t c : qcells[q]) cnt += tcell_off[c + 1] - tcell_off[c];
+          q_rows[q] = (int)cnt;
+          q_n[q] = (int)qcells[q].size();
+        }
+      });
+    }
+    j->track.host_traversals += (int64_t)fb.size();
+    bool last = true;
+    for (int q : active) if (!q_exh[q]) { last = false; break; }
     track(&freddy_track::determine_coarse_quantization_time);
     // targetCounts (:459) and the target-list skip rule (:553-557)
-    scan.clear(); qoff.assign(1, 0); flat.clear();
+    scan.clear(); scan_fb.clear(); qoff.assign(1, 0); flat.clear();
     for (int x = 0; x < n_active; ++x) {
       const int q = active[x];
-      int64_t cnt = 0;
-      for (int32_t c : qcells[q]) cnt += tcell_off[c + 1] - tcell_off[c];
-      target_count[q] += (int)cnt;
+      target_count[q] += q_rows[q];
       if (use_tl && target_count[q] < k * alpha_original && !last) { target_count[q] = 0; continue; }
-      scan.push_back(q);
+      j->track.candidate_rows += q_rows[q];
+      if (!q_host[q]) { scan.push_back(q); continue; }
+      scan_fb.push_back(q);
       for (int32_t c : qcells[q]) if (tcell_off[c + 1] > tcell_off[c]) flat.push_back(c);
       qoff.push_back((int32_t)flat.size());
     }
-    const int n_scan = (int)scan.size();
+    const int n_dev = (int)scan.size(), n_fb = (int)scan_fb.size(), n_scan = n_dev + n_fb;
+    scan.insert(scan.end(), scan_fb.begin(), scan_fb.end());
     track(&freddy_track::query_construction_time);
     if (n_scan > 0) {
-      if (join_buf(j, 6, sizeof(int32_t) * std::max<size_t>(flat.size(), 1), &d_qcells)) return FREDDY_E_NOMEM;
       JOIN_HIP(hipMemcpyAsync(d_scan, scan.data(), sizeof(int32_t) * n_scan, hipMemcpyHostToDevice, s));
-      JOIN_HIP(hipMemcpyAsync(d_qoff, qoff.data(), sizeof(int32_t) * (n_scan + 1), hipMemcpyHostToDevice, s));
-      if (!flat.empty()) JOIN_HIP(hipMemcpyAsync(d_qcells, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, s));
       JoinArgs a;
-      a.queries = (const float*)d_q; a.scan_query = (const int32_t*)d_scan; a.qcell_off = (const int32_t*)d_qoff;
-      a.qcells = (const int32_t*)d_qcells; a.tcell_off = (const int32_t*)d_tcell; a.trow = (const int32_t*)d_trow;
-      a.ids = j->ids; a.codes = j->codes; a.vectors = j->vectors; a.cbT = j->cbT;
-      a.out_ids = (int32_t*)d_oi; a.out_dist = (float*)d_od;
+      a.queries = (const float*)d_q; a.tcell_off = (const int32_t*)d_tcell; a.trow = (const int32_t*)d_trow;
+      a.ids = j->ids; a.codes = j->codes; a.MP = j->MP; a.vectors = j->vectors; a.cbT = j->cbT;
       a.d = d; a.m = m; a.K = K; a.S = j->S; a.k = k; a.L = L; a.method = method; a.double_codes = double_codes ? 1 : 0;
-      for (int x = 0; x < n_scan; ++x)
-        for (int i = qoff[(size_t)x]; i < qoff[(size_t)x + 1]; ++i) j->track.candidate_rows += tcell_off[(size_t)flat[(size_t)i] + 1] - tcell_off[(size_t)flat[(size_t)i]];
       if (!j->ev0) { JOIN_HIP(hipEventCreate(&j->ev0)); JOIN_HIP(hipEventCreate(&j->ev1)); }
       JOIN_HIP(hipEventRecord(j->ev0, s));
-      if (int rc = join_launch(s, a, n_scan, V, lds)) return rc;
+      if (n_dev > 0) {     // cell lists written by the traversal kernel: row q of [Q][cells]
+        a.scan_query = (const int32_t*)d_scan; a.qcell_off = nullptr; a.qcell_cnt = (const int32_t*)d_qcnt; a.qstride = cells;
+        a.qcells = (const int32_t*)d_qstrided; a.out_ids = (int32_t*)d_oi; a.out_dist = (float*)d_od;
+        if (int rc = join_launch(s, a, n_dev, V, lds)) return rc;
+      }
+      if (n_fb > 0) {      // host-traversed queries: flat lists with offsets
+        if (join_buf(j, 6, sizeof(int32_t) * std::max<size_t>(flat.size(), 1), &d_qcells)) return FREDDY_E_NOMEM;
+        JOIN_HIP(hipMemcpyAsync(d_qoff, qoff.data(), sizeof(int32_t) * (n_fb + 1), hipMemcpyHostToDevice, s));
+        if (!flat.empty()) JOIN_HIP(hipMemcpyAsync(d_qcells, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, s));
+        a.scan_query = (const int32_t*)d_scan + n_dev; a.qcell_off = (const int32_t*)d_qoff; a.qcell_cnt = nullptr; a.qstride = 0;
+        a.qcells = (const int32_t*)d_qcells; a.out_ids = (int32_t*)d_oi + (size_t)n_dev * k; a.out_dist = (float*)d_od + (size_t)n_dev * k;
+        if (int rc = join_launch(s, a, n_fb, V, lds)) return rc;
+      }
       JOIN_HIP(hipEventRecord(j->ev1, s));
-      h_oi.resize((size_t)n_scan * k);
-      h_od.resize((size_t)n_scan * k);
-      JOIN_HIP(hipMemcpyAsync(h_oi.data(), d_oi, sizeof(int32_t) * h_oi.size(), hipMemcpyDeviceToHost, s));
-      JOIN_HIP(hipMemcpyAsync(h_od.data(), d_od, sizeof(float) * h_od.size(), hipMemcpyDeviceToHost, s));
+      if (dev_trav && !last && (int64_t)k * alpha * 2 < INT32_MAX) {   // the next round's cells for everyone still active (see launch_traverse)
+        if (int rc = launch_traverse(n_active, k * (alpha + alpha))) return rc;
+        for (int x = 0; x < n_active; ++x) spec_index[(size_t)active[x]] = x;
+        spec_valid = true;
+      }
+      JOIN_HIP(hipMemcpyAsync(h_oi_p, d_oi, sizeof(int32_t) * (size_t)n_scan * k, hipMemcpyDeviceToHost, s));
+      JOIN_HIP(hipMemcpyAsync(h_od_p, d_od, sizeof(float) * (size_t)n_scan * k, hipMemcpyDeviceToHost, s));
       JOIN_HIP(hipStreamSynchronize(s));
       { float ms = 0.0f; if (hipEventElapsedTime(&ms, j->ev0, j->ev1) == hipSuccess) j->track.join_kernel_time += 1e-3 * ms; }
       for (int x = 0; x < n_scan; ++x) {
-        memcpy(out_ids + (size_t)scan[x] * k, h_oi.data() + (size_t)x * k, sizeof(int32_t) * k);
-        memcpy(out_dist + (size_t)scan[x] * k, h_od.data() + (size_t)x * k, sizeof(float) * k);
+        memcpy(out_ids + (size_t)scan[x] * k, h_oi_p + (size_t)x * k, sizeof(int32_t) * k);
+        memcpy(out_dist + (size_t)scan[x] * k, h_od_p + (size_t)x * k, sizeof(float) * k);
       }
     }
     track(&freddy_track::computation_time);   // LUTs, ADC / exact distances, post verification: one kernel

@@ -364,7 +364,8 @@ class Track(C.Structure):
                 ("computation_time", C.c_double), ("pv_computation_time", C.c_double),
                 ("recalculate_query_indices_time", C.c_double), ("total_time", C.c_double),
                 ("join_kernel_time", C.c_double), ("candidate_rows", C.c_int64),
-                ("iterations", C.c_int32), ("reserved", C.c_int32)]
+                ("iterations", C.c_int32), ("reserved", C.c_int32), ("host_traversals", C.c_int64),
+                ("libm_checks", C.c_int64)]
 
 
 class EncodeDesc(C.Structure):

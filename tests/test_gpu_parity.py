@@ -943,3 +943,62 @@ def test_more_streams_than_workspaces(gpu, oracle):
         util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i} of {ns}")
     assert idx.bound_violations() == 0
     idx.close()
+
+
+@pytest.mark.parametrize("k_coarse", [32, 8])
+def test_knn_join_device_traversal(gpu, oracle, k_coarse):
+    """The multi-index traversal on the device (join_traverse_kernel: sorted keys + the running statistics sum, every
+    stop checked by the host's libm) against the oracle's literal heap (index_utils.c:252-443): 1024 cells (the
+    reference's default 2 x 32 multi-index) and 64; the same calls with every traversal forced onto the host heap."""
+    N = 20000
+    t = util.ivpq_tables(N=N, k_coarse=k_coarse)
+    ot = oracle.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    idx = gpu.IVPQIndex(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    _, qs = util.queries_from_corpus(N, 300, seed=41)
+    rng = np.random.default_rng(12)
+    targets = rng.choice(np.arange(1, N + 1), size=5000, replace=False).astype(np.int32)
+    cases = [(5, 100, 20, 2, 0.8, True), (5, 3, 4, 0, 0.8, True), (5, 1, 3, 2, 0.3, True), (3, 1, 3, 0, 0.05, False),
+             (5, 1000, 3, 0, 0.8, True), (10, 7, 5, 1, 0.95, True)]
+    for host in (0, 1, 2):
+        # 0: device traversal, the host's libm re-evaluates a stop only where the device's value is within 1e-5 of the
+        # confidence; 2: the same with the margin at 2.0 -- EVERY proposed stop checked by libm; 1: the host heap
+        idx.set_option("join_host_traversal", 1 if host == 1 else 0)
+        idx.set_option("join_libm_margin_ppm", 2_000_000 if host == 2 else 10)
+        handed_back = 0
+        for (k, alpha, pvf, method, conf, tl) in cases:
+            gi, gd, git = idx.knn_join(qs, k, targets, alpha, pvf, method, use_target_lists=tl, confidence=conf)
+            exp, eit = oracle.ivpq_search_in(ot, qs, k, targets, alpha, pvf, method, use_target_lists=tl, confidence=conf)
+            assert git == eit, (git, eit)
+            util.assert_same_lists(gi, gd, exp, f"traversal host={host} Kc={k_coarse} k={k} alpha={alpha} conf={conf}")
+            tr = idx.last_track()
+            handed_back += tr["host_traversals"]
+            if host == 1:
+                assert tr["host_traversals"] >= qs.shape[0]
+            if host == 2:
+                assert tr["libm_checks"] >= 0.9 * qs.shape[0]
+        if host != 1:   # equal float sums among a query's nearest cells are rare: the device keeps nearly every traversal
+            assert handed_back < 0.2 * len(cases) * qs.shape[0], handed_back
+    idx.close()
+
+
+def test_knn_join_device_traversal_hands_ties_to_the_host(gpu, oracle):
+    """Duplicate multi-index centroids make equal keys among the nearest cells: the heap's order among equals depends
+    on its history, so the device hands those queries to the host heap -- the lists stay the oracle's."""
+    N = 20000
+    t = dict(util.ivpq_tables(N=N, k_coarse=32))
+    coarse = t["coarse"].copy()            # [2][32][150]
+    coarse[0, 5] = coarse[0, 3]; coarse[1, 9] = coarse[1, 2]; coarse[1, 10] = coarse[1, 2]
+    t["coarse"] = coarse
+    ot = oracle.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    idx = gpu.IVPQIndex(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
+    _, qs = util.queries_from_corpus(N, 200, seed=43)
+    targets = np.random.default_rng(13).choice(np.arange(1, N + 1), size=6000, replace=False).astype(np.int32)
+    total = 0
+    for (k, alpha, method, conf) in [(5, 50, 2, 0.8), (5, 2, 0, 0.9), (4, 1, 0, 0.2)]:
+        gi, gd, git = idx.knn_join(qs, k, targets, alpha, 5, method, confidence=conf)
+        exp, eit = oracle.ivpq_search_in(ot, qs, k, targets, alpha, 5, method, confidence=conf)
+        assert git == eit
+        util.assert_same_lists(gi, gd, exp, f"ties k={k} alpha={alpha} conf={conf}")
+        total += idx.last_track()["host_traversals"]
+    assert total > 0
+    idx.close()
