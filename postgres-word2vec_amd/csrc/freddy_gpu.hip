@@ -196,7 +196,8 @@ struct IvfRun {
   float* d_out_dist;
   bool fused;          // cell-grouped scans (fused3.h / fused4.h) instead of lut_build + adc_scan
   int scan_kernel;     // 4: filter + refine, 3: exact fused scan
-  bool tiled;          // the batch coarse kernel also clears the round-one scratch
+  bool tiled;          // batch coarse kernels (tiles of queries)
+  bool zeroed;         // the coarse kernel has cleared the round-one scratch (ZeroArgs): no memsets in round one
   bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
   bool qc_pending;     // the query x codebook table is being built on the side stream
   // per round
@@ -282,6 +283,10 @@ struct freddy_gpu_index {
   std::mutex mu;                  // guards the workspace slots and the profile map (host threads on different streams)
   // host-buffer pipeline (created by the first host-buffer IVFADC call)
   Lane lanes[FREDDY_LANES];
+  // pinned staging of the other synchronous host-buffer calls (pq_search): queries in, lists out -- read / written by
+  // kernels, no SDMA copies in the stream
+  void* hio_in = nullptr;  size_t hio_in_cap = 0;
+  void* hio_out = nullptr; size_t hio_out_cap = 0;
   // replicas of this index on further devices (freddy_gpu_pin_ivf_multi): a host batch is split contiguously over
   // this handle and its replicas; every replica is a complete pinned index of its own
   std::vector<freddy_gpu_index*> replicas;
@@ -345,6 +350,8 @@ static void free_index(freddy_gpu_index* ix) {
   (void)hipSetDevice(ix->device);
   (void)hipDeviceSynchronize();   // (every stream that searched on this handle, without touching a caller's stream handle)
   for (Workspace& w : ix->ws) w.release();
+  if (ix->hio_in) { (void)hipHostFree(ix->hio_in); ix->hio_in = nullptr; ix->hio_in_cap = 0; }
+  if (ix->hio_out) { (void)hipHostFree(ix->hio_out); ix->hio_out = nullptr; ix->hio_out_cap = 0; }
   for (Lane& l : ix->lanes) {
     if (l.stream) (void)hipStreamDestroy(l.stream);
     for (LaneSlot& c : l.slot) {
@@ -977,9 +984,10 @@ static int ivf_coarse(IvfRun& r) {
   const int used_words = (C + 31) / 32;
   const size_t items = (size_t)Q * r.W;
   // round-one scratch that must start at zero: the probe bitmaps, the counters (n_next, n_groups, work
-  // counter), the per-cell item counts and the accepted-candidate counts.  The tiled coarse kernel clears
-  // them itself; the small-batch kernel gets memsets.
-  if (!r.tiled) {
+  // counter), the per-cell item counts and the accepted-candidate counts: every coarse kernel clears them itself
+  // (ZeroArgs) -- except the small-batch kernel for vectors of more than 1024 dimensions, which gets memsets.
+  const bool small_zero = !r.tiled && d <= 1024;
+  if (!r.tiled && !small_zero) {
     HIP_TRY(hipMemsetAsync(ws->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
     HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 4, s));
   }
@@ -1000,6 +1008,8 @@ static int ivf_coarse(IvfRun& r) {
       else if (r.tiled)
         hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
                            ws->w_distT.as<float>(), Q, Cpad, d, za);
+      else if (small_zero)
+        hipLaunchKernelGGL((coarse_small_kernel<50>), dim3(Cpad / 64, Q), dim3(64), 0, s, r.d_q, ix->coarseT, ws->w_distT.as<float>(), Q, Cpad, d, za);
       else
         hipLaunchKernelGGL((coarse_dist_kernel<16>), dim3(Cpad / WG, (Q + 15) / 16), dim3(WG), (size_t)d * 16 * sizeof(float), s, r.d_q,
                            ix->coarseT, ws->w_distT.as<float>(), Q, Cpad, d);
@@ -1065,7 +1075,7 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
   pa.cell_items = r.fused ? ws->w_sorted.as<int32_t>() : nullptr; pa.cell_cap = r.n_active;
   pa.cell_limit = r.cell_limit;
   const int n_items = r.n_active * W;
-  if (r.fused && !(r.tiled && r.first())) {
+  if (r.fused && !(r.zeroed && r.first())) {
     HIP_TRY(hipMemsetAsync(ws->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)C * 2, s));   // counts + fill cursors
     HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * (size_t)n_items * r.upi * FUSED_NW, s));
   }
@@ -1090,7 +1100,7 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
     }
   });
   HIP_TRY(hipGetLastError());
-  if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(ws->w_cand.p, 0, sizeof(int32_t) * r.Q, s));
+  if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(ws->w_cand.p, 0, sizeof(int32_t) * r.Q, s));
   return 0;
 }
 
@@ -1115,7 +1125,7 @@ static int ivf_work_table(IvfRun& r, WorkTable& wt) {
                        wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : r.scan_kernel == 4 ? 1 : 0);
   });
   HIP_TRY(hipGetLastError());
-  if (!(r.tiled && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, sizeof(int32_t), s));
+  if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, sizeof(int32_t), s));
   return 0;
 }
 
@@ -1296,6 +1306,11 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   return 0;
 }
 
+// row blocks per workgroup of the generic scan: one workgroup per (query, probed cell) unless the list is huge -- but a
+// handful of items (the reference's single-query ivfadc_search: W of them) would leave the chip to W workgroups: 32-block
+// chunks then (one query over 10 lists of 3 000 rows: 30 instead of 10 workgroups)
+static int generic_chunk_blocks(int n_items) { return n_items <= 64 ? 32 : 256; }
+
 // Generic path (small batches, other m / S / K, k > 32): residual -> lut_build -> adc_scan -> merge_replay;
 // the LUTs round-trip through memory.
 static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
@@ -1303,7 +1318,7 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int n_items = r.n_active * r.W;
-  const int chunk_blocks = 256;   // one workgroup per (query, probed cell) unless the list is huge
+  const int chunk_blocks = generic_chunk_blocks(n_items);
   const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
   timed_launch(ix, s, "residual", [&] {
     hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, r.d_q, ix->coarse, pa.item_cell, pa.item_query,
@@ -1392,6 +1407,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
             (ix->tune.fused == 1 || items >= 256);
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : ix->tune.scan_kernel == 5 ? 5 : 4;
   r.tiled = Q >= 32;
+  r.zeroed = r.tiled || ix->d <= 1024;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_STREAM_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
   // CU partition: only for the filter + refine scan, whose persistent workgroups take whole CUs
@@ -1427,9 +1443,11 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
         (ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
-    const int nchunk = std::max(1, (ix->max_list_blocks + 255) / 256);
+    // (a later probing round has fewer items and may take the finer chunks: room for either)
+    const size_t nchunk_big = (size_t)std::max(1, (ix->max_list_blocks + 255) / 256), nchunk_small = (size_t)std::max(1, (ix->max_list_blocks + 31) / 32);
+    const size_t parts = std::max(items * nchunk_big, std::min<size_t>(items, 64) * nchunk_small);
     if (ws->w_resid.ensure(sizeof(float) * items * (size_t)ix->d) || ws->w_lut.ensure(sizeof(float) * items * (size_t)m * K) ||
-        ws->w_part.ensure(sizeof(u64) * items * nchunk * SCAN_WAVES * r.L))
+        ws->w_part.ensure(sizeof(u64) * parts * SCAN_WAVES * r.L))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   }
 
@@ -1540,6 +1558,11 @@ __global__ __launch_bounds__(256) void lane_copy_out_kernel(const int32_t* __res
   const int nn = n_next[0];
   if (i == 0) h_out[2 * n_out] = nn;
   if (i < nn && i < n) h_out[2 * n_out + 1 + i] = unfinished[i];
+}
+
+__global__ __launch_bounds__(256) void host_io_out_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dist, int32_t* __restrict__ h_out, int n_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n_out) { h_out[i] = ids[i]; h_out[n_out + i] = __float_as_int(dist[i]); }
 }
 
 static int lane_open(Lane& l, LaneSlot& c, size_t in_bytes, size_t n, size_t n_out) {
@@ -1667,14 +1690,17 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
       src = static_cast<const float*>(c.h_in);
     }
     if (trace) t2 = now_us();
-    {
+    const float* d_queries = c.d_q.as<float>();
+    if (n <= 8) {
+      d_queries = src;     // a handful of queries: the kernels read them where they are staged (pinned, mapped) -- one launch less
+    } else {
       const size_t n16 = (row * n + 15) / 16;
       hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, l.stream,
                          reinterpret_cast<const uint4*>(src), c.d_q.as<uint4>(), n16);
       if (hipGetLastError() != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the query copy failed"); break; }
     }
     IvfRun r;
-    if ((rc = ivfadc_begin(ix, l.stream, n_lanes, c.d_q.as<float>(), n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
+    if ((rc = ivfadc_begin(ix, l.stream, n_lanes, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
                            c.d_dist.as<float>(), nullptr, r)))
       break;
     if (trace) t3 = now_us();
@@ -1900,7 +1926,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   IvfRun r;
   r.ix = fx; r.ws = ws; r.s = s; r.s_scan = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = lists; r.L = 2 * k;
   r.sentinel = sentinel; r.cell_limit = 0.0f; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = nullptr;
-  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.approx = false; r.qc_pending = false;
+  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false; r.qc_pending = false;
   r.n_active = Q; r.round = 0; r.active = nullptr;
   r.share = std::max(1, ix->tune.scan_share);   // (the caller's contract: its batches in flight on this handle)
   r.s_caller = s;
@@ -2043,10 +2069,34 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   HIP_TRY(hipSetDevice(ix->device));
   Workspace* ws = workspace_for(ix, ix->stream);
   hipStream_t s = ix->stream;
-  if (ws->w_q.ensure(sizeof(float) * (size_t)Q * ix->d) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
-      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+  // queries in, lists out through pinned staging that the kernels read and write themselves (mapped host memory): a
+  // handful of queries are read where they are staged and their lists written straight back; larger batches cross PCIe
+  // once, by a copy kernel each way.  No hipMemcpyAsync in the stream (each one is an SDMA hop with its own latency).
+  const size_t q_bytes = sizeof(float) * (size_t)Q * ix->d, n_out = (size_t)Q * k;
+  auto pinned_fit = [](void** p, size_t* cap, size_t need) -> int {
+    if (need <= *cap) return 0;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipHostMalloc(p, need + need / 4 + 256, hipHostMallocDefault) != hipSuccess) { *p = nullptr; return -1; }
+    *cap = need + need / 4 + 256;
+    return 0;
+  };
+  if (pinned_fit(&ix->hio_in, &ix->hio_in_cap, q_bytes + 16) || pinned_fit(&ix->hio_out, &ix->hio_out_cap, n_out * 8 + 16))
+    return fail(FREDDY_E_NOMEM, "pinned staging allocation failed");
+  memcpy(ix->hio_in, queries, q_bytes);
+  const bool direct = Q <= 8;
+  if (!direct && (ws->w_q.ensure(q_bytes + 16) || ws->w_out_ids.ensure(sizeof(int32_t) * n_out) || ws->w_out_dist.ensure(sizeof(float) * n_out)))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
+  const float* d_q = static_cast<const float*>(ix->hio_in);
+  int32_t* d_oi = static_cast<int32_t*>(ix->hio_out);
+  float* d_od = reinterpret_cast<float*>(d_oi + n_out);
+  if (!direct) {
+    const size_t n16 = (q_bytes + 15) / 16;
+    hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4*>(ix->hio_in), ws->w_q.as<uint4>(), n16);
+    HIP_TRY(hipGetLastError());
+    d_q = ws->w_q.as<float>(); d_oi = ws->w_out_ids.as<int32_t>(); d_od = ws->w_out_dist.as<float>();
+  }
 
   const int32_t* blk_off = ix->blk_off;
   const uint32_t* packed = ix->packed;
@@ -2066,18 +2116,21 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     if (fused_path) {
-      if (int rc = pq_fused_chunk(ix, view, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel,
-                                  ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k))
+      if (int rc = pq_fused_chunk(ix, view, s, d_q + (size_t)q0 * ix->d, n, k, sentinel, d_oi + (size_t)q0 * k, d_od + (size_t)q0 * k))
         return rc;
       continue;
     }
-    if (int rc = pq_chunk(ix, s, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, sentinel, blk_off, packed, pos, n_blocks,
-                          ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k))
+    if (int rc = pq_chunk(ix, s, d_q + (size_t)q0 * ix->d, n, k, sentinel, blk_off, packed, pos, n_blocks, d_oi + (size_t)q0 * k,
+                          d_od + (size_t)q0 * k))
       return rc;
   }
-  HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(out_dist, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+  if (!direct) {
+    hipLaunchKernelGGL(host_io_out_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, d_oi, d_od, static_cast<int32_t*>(ix->hio_out), (int)n_out);
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipStreamSynchronize(s));
+  memcpy(out_ids, ix->hio_out, n_out * 4);
+  memcpy(out_dist, static_cast<const int32_t*>(ix->hio_out) + n_out, n_out * 4);
   return FREDDY_OK;
 }
 

@@ -105,6 +105,46 @@ struct ZeroArgs {
   uint32_t* p[5];
   int n[5];
 };
+
+// Small batches (below 32 queries -- the reference's ivfadc_search takes ONE, freddy.c:174-393): one wave per (64 cells,
+// query).  The chain r = r + (q_i - c_i)^2 is sequential in i (index_utils.c:500-508), but its loads are not: DB centroid
+// values per lane are requested together, then summed in order -- coarse_dist_kernel's four workgroups walked the 300
+// dimensions with 8 loads in flight and took 39 us for one query; this takes the round trips of d / DB batches.
+// Also clears the round-one scratch (ZeroArgs), as the batch kernels do: no memset launches in front of a small call.
+template <int DB>
+__global__ __launch_bounds__(64) void coarse_small_kernel(const float* __restrict__ queries, const float* __restrict__ coarseT,
+                                                         float* __restrict__ dist, int Q, int Cpad, int d, ZeroArgs z) {
+  {
+    const int gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 64 + threadIdx.x, gsz = gridDim.x * gridDim.y * 64;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+      for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
+  }
+  __shared__ float qs[1024];
+  const int j = blockIdx.x * 64 + threadIdx.x, q = blockIdx.y;
+  for (int i = threadIdx.x; i < d; i += 64) qs[i] = queries[(size_t)q * d + i];
+  __syncthreads();
+  float acc = 0.0f;
+  // (no guards around the loads: hipcc turns a guarded load into a basic block of its own with a full memory wait)
+  const int nfull = d / DB * DB;
+  for (int i0 = 0; i0 < nfull; i0 += DB) {
+    float cc[DB];
+#pragma unroll
+    for (int u = 0; u < DB; ++u) cc[u] = coarseT[(size_t)(i0 + u) * Cpad + j];
+#pragma unroll
+    for (int u = 0; u < DB; ++u) {
+      const float t = qs[i0 + u] - cc[u];
+      const float pr = t * t;
+      acc = acc + pr;
+    }
+  }
+  for (int i = nfull; i < d; ++i) {
+    const float t = qs[i] - coarseT[(size_t)i * Cpad + j];
+    const float pr = t * t;
+    acc = acc + pr;
+  }
+  dist[(size_t)q * Cpad + j] = acc;
+}
 // TCW = cells per thread (4: 64x64 tile, one workgroup per CU for Q = C = 1024; 2: 64x32 tile, twice
 // the workgroups -- two waves per SIMD issue packed ops ~25 % faster than one)
 template <int TCW, int DK>
