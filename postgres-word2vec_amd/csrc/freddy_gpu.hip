@@ -535,17 +535,41 @@ static int raise_lds_limits(int device) {
 // LUT kernel, the paired layout of the exact fused scan, and -- for the filter + refine scan -- the row-major
 // copy and the norm bounds.  (Re)built at pin time and by freddy_gpu_update_codebook; the row terms follow
 // in refresh_row_terms once the rows are in place.
+// Everything that is derived from the codebook.  The new tables are built beside the old ones and swapped in only when
+// every upload has succeeded (freddy_gpu_update_codebook on a live handle: a failed call leaves the handle as it was).
+static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebook);
 static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
-  void* old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
-  for (void* p : old) if (p) (void)hipFree(p);
+  float* const old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
+  const int64_t bytes_before = ix->bytes;
   ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = nullptr;
+  const int rc = derive_codebook_tables_into(ix, codebook);
+  if (rc) {   // put the old tables back
+    float* const fresh[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
+    for (float* p : fresh) if (p) (void)hipFree(p);
+    ix->cbT = old[0]; ix->cbP = old[1]; ix->cbR = old[2]; ix->pmax = old[3]; ix->cmaxp = old[4];
+    ix->bytes = bytes_before;
+    return rc;
+  }
+  int64_t old_bytes = 0;
+  if (old[0]) old_bytes += (int64_t)sizeof(float) * ix->m * ix->S * ix->K;
+  if (old[1]) old_bytes += (int64_t)sizeof(float) * ix->m * (((ix->S + 3) & ~3) / 4) * FUSED_T * 8;
+  if (old[2]) old_bytes += (int64_t)sizeof(float) * ix->m * ix->K * ix->S;
+  if (old[3]) old_bytes += (int64_t)sizeof(float) * ix->m;
+  if (old[4]) old_bytes += (int64_t)sizeof(float) * ix->m;
+  ix->bytes -= old_bytes;       // (the footprint changes by the difference, not by a second copy)
+  for (float* p : old) if (p) (void)hipFree(p);
+  if (ix->kind == KIND_PQ) {    // views of the flat table are rebuilt from the new tables on next use
+    if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
+    if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
+  }
+  return 0;
+}
+static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebook) {
   std::vector<float> cbT = transpose_codebook(codebook, ix->m, ix->K, ix->S);
   if (upload(&ix->cbT, cbT.data(), cbT.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
   if (ix->kind == KIND_PQ) {
     // batches over the flat table take the cell-grouped filter + refine scan (pq_shadow_build): its codebook-derived tables,
     // with "centroids" that are zero
-    if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
-    if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
     if (ix->m == 12 && ix->S == 25 && ix->K <= FUSED_T * FUSED_E && ix->tune.filter_table_mb > 0) {
       std::vector<float> cmaxp((size_t)ix->m);
       for (int p = 0; p < ix->m; ++p) {
