@@ -67,6 +67,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--host-abi-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-host-abi", action="store_true", help="skip the host-buffer ABI measurement (a child process); profiling runs")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="config ivfadc on one GPU also runs bounded passes of --config pq and --config join and reports them "
                          "under other_configs; this switches that off")
@@ -198,17 +199,20 @@ def pmc_traffic(kernel, config=None, shape=None):
     (profiles/latest_pmc.json, or latest_pmc_<config>.json for --config pq / join; written by tools/profile_round.sh):
     2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads) + WRITE_SIZE, KiB -> bytes.  The file records the
     workload shape it was taken on ("_shape"); None if there is no record or the shape differs from this run's."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", f"latest_pmc_{config}.json" if config else "latest_pmc.json")))
+    import glob
+    first = os.path.join(ROOT, "profiles", f"latest_pmc_{config}.json" if config else "latest_pmc.json")
+    for path in [first] + sorted(glob.glob(os.path.join(ROOT, "profiles", "latest_pmc_*.json"))):
+        try:
+            pmc = json.load(open(path))
+        except Exception:
+            continue
         have = pmc.get("_shape")
-        if shape is not None and have is not None and any(have.get(k) != v for k, v in shape.items()):
-            return None
-        if shape is not None and have is None and shape != DEFAULT_SHAPES.get(config or "ivfadc"):
-            return None   # (files written before the shape was recorded were taken on the default workload)
+        if shape is not None and have is not None and (set(have) != set(shape) or any(have.get(k) != v for k, v in shape.items())):
+            continue
+        if shape is not None and have is None and (path != first or shape != DEFAULT_SHAPES.get(config or "ivfadc")):
+            continue   # (files written before the shape was recorded were taken on the default workload)
         if kernel in pmc:
             return int((2 * pmc[kernel].get("fetch_kib", 0) + pmc[kernel].get("write_kib", 0)) * 1024)
-    except Exception:
-        pass
     return None
 
 
@@ -362,6 +366,8 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             cmd = [sys.executable, os.path.abspath(__file__), "--host-abi-child", path, "--N", str(N), "--C", str(a.C), "--m", str(a.m),
                    "--K", str(a.K), "--nprobe", str(a.nprobe), "--k", str(a.k)]
             try:
+                if a.no_host_abi:
+                    raise RuntimeError("skipped (--no-host-abi)")
                 cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 host_abi = json.loads(cp.stdout.strip().splitlines()[-1])
             except Exception as e:   # the headline line must not be lost to a side measurement

@@ -9,8 +9,8 @@ export TMPDIR=/tmp
 T=/tmp/prof_$TAG; rm -rf $T; mkdir -p $T gpurun_out/prof
 # (--in-flight 1: one batch at a time, so that a kernel's duration in the trace is the kernel alone -- what bench.py's
 #  instrumented re-run and its roofline object report; the default command's overlapped timeline is the last pass)
-B="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall --in-flight 1 $*"
-B2="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall $*"
+B="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall --no-other-configs --no-host-abi --in-flight 1 $*"
+B2="python3 bench.py --steps 20 --warmup 3 --cpu-sample 0 --no-recall --no-other-configs --no-host-abi $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $T/trace -o r -- $B > gpurun_out/prof/${TAG}_bench_under_trace.json 2> $T/trace.err
 python3 tools/prof_summary.py stats $T/trace gpurun_out/prof/${TAG}_kernel_stats.txt > /dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $T/fetch -o r -- $B > /dev/null 2> $T/fetch.err
@@ -20,6 +20,7 @@ python3 tools/prof_summary.py WRITE_SIZE $T/write gpurun_out/prof/${TAG}_pmc_wri
 python3 - "$TAG" "$@" <<'PY'
 import json, re, sys
 tag = sys.argv[1]
+extra = sys.argv[2:]
 out = {}
 for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
     for line in open(f"gpurun_out/prof/{tag}_pmc_{name}.txt"):

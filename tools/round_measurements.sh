@@ -26,9 +26,14 @@ PY
 done
 cp profiles/latest_pmc.json gpurun_out/prof/${TAG}_latest_pmc.json
 # larger batches on one GPU (SURVEY 8e asks for a Q >= 8192 variant)
-python3 bench.py --steps 20 --warmup 4 --Q 8192 --cpu-sample 0 --no-recall > gpurun_out/prof/${TAG}_bench_Q8192.json 2> /dev/null
+python3 bench.py --steps 20 --warmup 4 --Q 8192 --cpu-sample 0 --no-recall --no-host-abi > gpurun_out/prof/${TAG}_bench_Q8192.json 2> /dev/null
+python3 bench.py --steps 300 --warmup 10 --no-other-configs > gpurun_out/prof/${TAG}_bench_300steps.json 2> /dev/null
 # a corpus that does NOT fit the 256 MiB Infinity Cache: N = 40 M rows (1.1 GB of lists), same list length
-# (its own FETCH / WRITE passes: tools/profile_n40m.sh; bench.py's pmc_traffic() refuses the 3 M-row record for this shape)
-timeout 1500 python3 bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --cpu-sample 64 --no-recall > gpurun_out/prof/${TAG}_bench_N40M.json 2> gpurun_out/prof/${TAG}_bench_N40M.err
+# with its OWN FETCH / WRITE passes (bench.py's pmc_traffic() refuses the 3 M-row record for this shape)
+cp profiles/latest_pmc.json gpurun_out/prof/${TAG}_latest_pmc_3M.json
+timeout 1200 tools/profile_round.sh ${TAG}_N40M --N 40000000 --C 13000 > gpurun_out/prof/${TAG}_N40M_profile.log 2>&1
+if [ -s gpurun_out/prof/${TAG}_N40M_pmc.json ]; then cp gpurun_out/prof/${TAG}_N40M_pmc.json profiles/latest_pmc.json; fi
+timeout 1500 python3 bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --cpu-sample 64 --no-recall --no-host-abi > gpurun_out/prof/${TAG}_bench_N40M.json 2> gpurun_out/prof/${TAG}_bench_N40M.err
+cp gpurun_out/prof/${TAG}_latest_pmc_3M.json profiles/latest_pmc.json
 tail -2 gpurun_out/prof/${TAG}_bench_N40M.err
 ls -la gpurun_out/prof | tail -30
