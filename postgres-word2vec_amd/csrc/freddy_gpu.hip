@@ -28,7 +28,6 @@
 #include "scan_common.h"
 #include "fused3.h"
 #include "fused5.h"
-#include "fused6.h"
 #include "coarse.h"
 #include "exact.h"
 #include "join.h"
@@ -83,7 +82,6 @@ struct Tuning {
                                // 5.2c).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
   int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
-  int qc_mfma = 1;             // FREDDY_GPU_QC_MFMA: the query x codebook table on the matrix cores (fused6.h); 0 = packed fp32 fmas (fused5.h)
   int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
   int scan_quota_wgs = 0;      // FREDDY_GPU_SCAN_QUOTA_WGS: number of quota-limited workgroups in front of the persistent ones (0 = from the batch's size)
   int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
@@ -118,7 +116,6 @@ static Tuning read_tuning() {
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
   t.pipe_trace = (int)env_int("FREDDY_GPU_PIPE_TRACE", 0);
   t.scan_quota = (int)env_int("FREDDY_GPU_SCAN_QUOTA", t.scan_quota);
-  t.qc_mfma = (int)env_int("FREDDY_GPU_QC_MFMA", t.qc_mfma);
   t.scan_quota_wgs = (int)env_int("FREDDY_GPU_SCAN_QUOTA_WGS", t.scan_quota_wgs);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
@@ -258,8 +255,6 @@ struct freddy_gpu_index {
   float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
-  uint4* cbF = nullptr;         // codebook in f16-split MFMA fragment order (fused6.h), with its per-position multipliers
-  float* cbmul = nullptr;       // [m]
   int32_t* viol = nullptr;      // [4] self-check counters: scan bracket violations / rows checked, coarse bracket violations / cells checked
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
@@ -377,7 +372,7 @@ static void free_index(freddy_gpu_index* ix) {
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->cbF, ix->cbmul, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   for (auto& kv : ix->prof)
@@ -542,29 +537,16 @@ static int raise_lds_limits(int device) {
 // in refresh_row_terms once the rows are in place.
 // Everything that is derived from the codebook.  The new tables are built beside the old ones and swapped in only when
 // every upload has succeeded (freddy_gpu_update_codebook on a live handle: a failed call leaves the handle as it was).
-// the codebook in f16-split matrix-core fragment order (fused6.h: the query x codebook table kernel)
-static int upload_fragments(freddy_gpu_index* ix, const float* codebook) {
-  std::vector<uint16_t> frag;
-  std::vector<float> mul;
-  build_codebook_fragments(codebook, ix->m, ix->K, ix->S, frag, mul);
-  uint16_t* dfrag = nullptr;
-  if (upload(&dfrag, frag.data(), frag.size(), &ix->bytes)) return -1;
-  ix->cbF = reinterpret_cast<uint4*>(dfrag);
-  return upload(&ix->cbmul, mul.data(), mul.size(), &ix->bytes);
-}
-
 static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebook);
 static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
-  float* const old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp, reinterpret_cast<float*>(ix->cbF), ix->cbmul};
+  float* const old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
   const int64_t bytes_before = ix->bytes;
-  ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = ix->cbmul = nullptr;
-  ix->cbF = nullptr;
+  ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = nullptr;
   const int rc = derive_codebook_tables_into(ix, codebook);
   if (rc) {   // put the old tables back
-    float* const fresh[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp, reinterpret_cast<float*>(ix->cbF), ix->cbmul};
+    float* const fresh[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
     for (float* p : fresh) if (p) (void)hipFree(p);
     ix->cbT = old[0]; ix->cbP = old[1]; ix->cbR = old[2]; ix->pmax = old[3]; ix->cmaxp = old[4];
-    ix->cbF = reinterpret_cast<uint4*>(old[5]); ix->cbmul = old[6];
     ix->bytes = bytes_before;
     return rc;
   }
@@ -574,8 +556,6 @@ static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
   if (old[2]) old_bytes += (int64_t)sizeof(float) * ix->m * ix->K * ix->S;
   if (old[3]) old_bytes += (int64_t)sizeof(float) * ix->m;
   if (old[4]) old_bytes += (int64_t)sizeof(float) * ix->m;
-  if (old[5]) old_bytes += (int64_t)ix->m * 32 * QC6_STEPS * 64 * 16;
-  if (old[6]) old_bytes += (int64_t)sizeof(float) * ix->m;
   ix->bytes -= old_bytes;       // (the footprint changes by the difference, not by a second copy)
   for (float* p : old) if (p) (void)hipFree(p);
   if (ix->kind == KIND_PQ) {    // views of the flat table are rebuilt from the new tables on next use
@@ -603,7 +583,7 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
       }
       if (upload(&ix->cbR, codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
           upload(&ix->pmax, cmaxp.data(), cmaxp.size(), &ix->bytes) ||
-          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes) || upload_fragments(ix, codebook))
+          upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
         return fail(FREDDY_E_NOMEM, "device allocation failed");
     }
     return 0;
@@ -647,7 +627,7 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
     }
     if (upload(&ix->cbR, codebook, (size_t)ix->m * ix->K * ix->S, &ix->bytes) ||
         upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
-        upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes) || upload_fragments(ix, codebook))
+        upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
       return fail(FREDDY_E_NOMEM, "device allocation failed");
   }
   return 0;
@@ -922,7 +902,6 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "join_host_traversal") ix->join.host_traversal = value != 0;
   else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
   else if (n == "scan_quota") t.scan_quota = (int)value;
-  else if (n == "qc_mfma") t.qc_mfma = (int)value;
   else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
@@ -1086,11 +1065,7 @@ static int ivf_coarse(IvfRun& r) {
     }
     if (r.scan_kernel == 5) {
       timed_launch(ix, sq, "query_codebook", [&] {
-        if (ix->tune.qc_mfma && ix->cbF)
-          hipLaunchKernelGGL((query_codebook6_kernel<25>), dim3(m, (Q + QC6_TQ - 1) / QC6_TQ), dim3(256), 0, sq, r.d_q, ix->cbF, ix->cbmul, ix->cmaxp,
-                             ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, (int)env_int("FREDDY_QC6_ABLATE", 0));
-        else
-          hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
+        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
                              ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
       });
     } else
@@ -1932,7 +1907,7 @@ static int pq_view_refresh(freddy_gpu_index* ix, freddy_gpu_index** view, hipStr
     *view = fx;
   }
   fx->tune = ix->tune;
-  fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp; fx->cbF = ix->cbF; fx->cbmul = ix->cbmul;   // shared with the owner
+  fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp;   // shared with the owner
   fx->packed = const_cast<uint32_t*>(packed);
   fx->N = n_rows; fx->n_blocks = n_blocks; fx->max_list_blocks = FUSED_UNIT_BLOCKS;
   const int lists = (int)((n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
@@ -1995,11 +1970,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   HIP_TRY(hipMemsetAsync(ws->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)lists * 3, s));
   HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * items * r.upi * FUSED_NW, s));
   timed_launch(fx, s, "query_codebook", [&] {
-    if (fx->tune.qc_mfma && fx->cbF)
-      hipLaunchKernelGGL((query_codebook6_kernel<25>), dim3(m, (Q + QC6_TQ - 1) / QC6_TQ), dim3(256), 0, s, d_q, fx->cbF, fx->cbmul, fx->cmaxp,
-                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, fx->d, m, 0);
-    else
-      hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, d_q, fx->cbT, fx->cmaxp,
+    hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, d_q, fx->cbT, fx->cmaxp,
                          ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, fx->d, m, K);
   });
   HIP_TRY(hipGetLastError());

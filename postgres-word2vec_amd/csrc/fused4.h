@@ -79,7 +79,7 @@ __device__ __forceinline__ float filter_width5(const float* __restrict__ qn, con
     const float t = qn[p] + pmax[p];
     sb = __builtin_fmaf(t, t, sb);
   }
-  return __builtin_fmaf(sb, FILT5_EPS, __builtin_fmaf(32.0f, scale, 1e-30f));   // (32: room for the f16-split matrix-core table, fused6.h)
+  return __builtin_fmaf(sb, FILT5_EPS, __builtin_fmaf(28.0f, scale, 1e-30f));
 }
 
 struct ItemBounds {

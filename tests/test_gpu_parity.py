@@ -621,14 +621,12 @@ def _every_row_check(idx, oracle, ot, qs, k, W, what, kernel=5):
     return gi, gd
 
 
-@pytest.mark.parametrize("kernel,qc_mfma", [(4, 1), (5, 1), (5, 0)])
-def test_filter_refine_bracket_every_row_K1024(gpu, oracle, kernel, qc_mfma, monkeypatch):
+@pytest.mark.parametrize("kernel", [4, 5])
+def test_filter_refine_bracket_every_row_K1024(gpu, oracle, kernel, monkeypatch):
     """The instantiations the benchmark runs -- ivf_filter5_kernel<12, true> / ivf_filter_kernel<12, true>, K = 1024 --
     in the every-row mode: brackets checked == rows probed, none violated, lists equal to the oracle's, to the exact
-    scan's (fused3.h) and to the normal filter + refine run.  The integer scan's query x codebook table from the
-    f16-split matrix-core kernel (fused6.h, the default) and from the packed-fp32 kernel (fused5.h)."""
+    scan's (fused3.h) and to the normal filter + refine run."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
-    monkeypatch.setenv("FREDDY_GPU_QC_MFMA", str(qc_mfma))
     for scale in (1.0, 1e-12, 8.0, 1e4):
         t, ot, idx, qs = _fr_setup(gpu, oracle, K=1024, scale=scale)
         qs = qs[:96]
