@@ -819,28 +819,48 @@ int insert_batch(freddy_session_t* s, const float* norm_vectors, int32_t n, int3
     int factor = 1;
     for (int p = 0; p < s->cq_multi.m; ++p) { cq_multi_id[(size_t)i] += factor * multi[(size_t)i * s->cq_multi.m + p]; factor *= s->cq_multi.m; }
   }
-  // the three codebooks (index_utils.c:940-991)
-  update_codebook_host(s->pq_cb, s->pq_counts, pq_codes.data(), n);
-  update_codebook_host(s->res_cb, s->res_counts, res_codes.data(), n);
-  update_codebook_host(s->ivpq_cb, s->ivpq_counts, iv_codes.data(), n);
+  // the three codebooks (index_utils.c:940-991) -- on COPIES: the session's tables change only after every device
+  // mutation below has succeeded; a failure midway leaves the host tables as they were and drops the pinned handles
+  // (they may hold part of the batch): searches then fail loudly with "not loaded" until the tables are loaded again
+  Codebook pq_cb = s->pq_cb, res_cb = s->res_cb, ivpq_cb = s->ivpq_cb;
+  std::vector<int32_t> pq_counts = s->pq_counts, res_counts = s->res_counts, ivpq_counts = s->ivpq_counts;
+  update_codebook_host(pq_cb, pq_counts, pq_codes.data(), n);
+  update_codebook_host(res_cb, res_counts, res_codes.data(), n);
+  update_codebook_host(ivpq_cb, ivpq_counts, iv_codes.data(), n);
   // the rows: every INSERT takes (SELECT max(id) + 1 FROM <its table>)   index_utils.c:1003-1021, 1046-1058
   std::vector<int32_t> id_pq((size_t)n), id_fine((size_t)n), id_iv((size_t)n), id_norm((size_t)n);
   std::vector<float> stored((size_t)n * dim);
   for (size_t i = 0; i < stored.size(); ++i) stored[i] = text_roundtrip(norm_vectors[i]);
   for (int i = 0; i < n; ++i) {
-    id_pq[(size_t)i] = ++s->pq_max_id;
-    id_fine[(size_t)i] = ++s->fine_max_id;
-    id_iv[(size_t)i] = ++s->ivpq_max_id;
+    id_pq[(size_t)i] = s->pq_max_id + 1 + i;
+    id_fine[(size_t)i] = s->fine_max_id + 1 + i;
+    id_iv[(size_t)i] = s->ivpq_max_id + 1 + i;
     id_norm[(size_t)i] = s->norm_ids.back() + 1 + i;
   }
-  if (int rc = freddy_gpu_append_rows(s->pq, n, id_pq.data(), nullptr, pq_codes.data(), nullptr)) return gpu_fail(rc);
-  if (int rc = freddy_gpu_append_rows(s->ivf, n, id_fine.data(), cq.data(), res_codes.data(), nullptr)) return gpu_fail(rc);
-  // (a cell id built with factor = positions can exceed codes^2 only if positions > codes; it is stored as the reference stores it)
-  if (int rc = freddy_gpu_append_rows(s->ivpq, n, id_iv.data(), cq_multi_id.data(), iv_codes.data(), stored.data())) return gpu_fail(rc);
-  if (int rc = freddy_gpu_update_codebook(s->pq, s->pq_cb.dense.data())) return gpu_fail(rc);
-  if (int rc = freddy_gpu_update_codebook(s->ivf, s->res_cb.dense.data())) return gpu_fail(rc);
-  if (int rc = freddy_gpu_update_codebook(s->ivpq, s->ivpq_cb.dense.data())) return gpu_fail(rc);
-  if (s->vecs) if (int rc = freddy_gpu_append_rows(s->vecs, n, id_norm.data(), nullptr, nullptr, stored.data())) return gpu_fail(rc);
+  auto device_side = [&]() -> int {
+    if (int rc = freddy_gpu_append_rows(s->pq, n, id_pq.data(), nullptr, pq_codes.data(), nullptr)) return rc;
+    if (int rc = freddy_gpu_append_rows(s->ivf, n, id_fine.data(), cq.data(), res_codes.data(), nullptr)) return rc;
+    // (a cell id built with factor = positions can exceed codes^2 only if positions > codes; it is stored as the reference stores it)
+    if (int rc = freddy_gpu_append_rows(s->ivpq, n, id_iv.data(), cq_multi_id.data(), iv_codes.data(), stored.data())) return rc;
+    if (int rc = freddy_gpu_update_codebook(s->pq, pq_cb.dense.data())) return rc;
+    if (int rc = freddy_gpu_update_codebook(s->ivf, res_cb.dense.data())) return rc;
+    if (int rc = freddy_gpu_update_codebook(s->ivpq, ivpq_cb.dense.data())) return rc;
+    if (s->vecs) if (int rc = freddy_gpu_append_rows(s->vecs, n, id_norm.data(), nullptr, nullptr, stored.data())) return rc;
+    return 0;
+  };
+  if (int rc = device_side()) {
+    const int code = gpu_fail(rc);     // (the message first: unpinning below may overwrite the library's)
+    // the handles may hold part of the batch: drop them, the host tables of the session are unchanged
+    if (s->pq) { freddy_gpu_unpin(s->pq); s->pq = nullptr; }
+    if (s->ivf) { freddy_gpu_unpin(s->ivf); s->ivf = nullptr; }
+    if (s->ivpq) { freddy_gpu_unpin(s->ivpq); s->ivpq = nullptr; }
+    if (s->vecs) { freddy_gpu_unpin(s->vecs); s->vecs = nullptr; }
+    return code;
+  }
+  // commit
+  s->pq_cb = std::move(pq_cb); s->res_cb = std::move(res_cb); s->ivpq_cb = std::move(ivpq_cb);
+  s->pq_counts = std::move(pq_counts); s->res_counts = std::move(res_counts); s->ivpq_counts = std::move(ivpq_counts);
+  s->pq_max_id += n; s->fine_max_id += n; s->ivpq_max_id += n;
   s->norm_ids.insert(s->norm_ids.end(), id_norm.begin(), id_norm.end());
   s->norm_vecs.insert(s->norm_vecs.end(), stored.begin(), stored.end());
   if (new_ids) memcpy(new_ids, id_norm.data(), sizeof(int32_t) * (size_t)n);
