@@ -211,8 +211,8 @@ def pmc_traffic(kernel, config=None, shape=None):
             continue
         if shape is not None and have is None and (path != first or shape != DEFAULT_SHAPES.get(config or "ivfadc")):
             continue   # (files written before the shape was recorded were taken on the default workload)
-        if kernel in pmc:
-            return int((2 * pmc[kernel].get("fetch_kib", 0) + pmc[kernel].get("write_kib", 0)) * 1024)
+        if kernel in pmc and "fetch_kib" in pmc[kernel] and "write_kib" in pmc[kernel]:   # (both passes must have succeeded)
+            return int((2 * pmc[kernel]["fetch_kib"] + pmc[kernel]["write_kib"]) * 1024)
     return None
 
 
