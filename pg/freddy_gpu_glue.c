@@ -28,18 +28,9 @@
 
 #include "index_utils.h"
 
-#define MAX_TABS 5
+#include "freddy_pure.h"   /* FreddyStamp, freddy_compare_stamp, payload codecs: the PostgreSQL-free parts (compiled and tested in this repository) */
 
-typedef struct FreddyStamp {
-    int    n_tabs;
-    Oid    rel[MAX_TABS];        /* [0] = the row table (ids + codes), [1] = its codebook, others: coarse quantizer, vectors, statistics */
-    Oid    filenode[MAX_TABS];
-    int64  appends[MAX_TABS];    /* freddy_gpu_generation, or -1 without the watch script */
-    int64  rewrites[MAX_TABS];
-    int64  weak[MAX_TABS];       /* fallback stamp: pg_relation_size; for [1] sum(count) of the codebook */
-    int32  max_id;               /* largest id of the row table that is pinned */
-    int    d, m;
-} FreddyStamp;
+#define MAX_TABS FREDDY_MAX_TABS
 
 typedef struct FreddyPin {
     freddy_gpu_index_t *h;
@@ -109,10 +100,10 @@ float *freddy_glue_bytea_f32(bytea *b, int *n)
 {
     Size   bytes = VARSIZE_ANY_EXHDR(b);
     float *out;
-    if (bytes % sizeof(float4) != 0) elog(ERROR, "freddy_gpu: a float4 vector of %zu bytes", (size_t) bytes);
-    *n = (int) (bytes / sizeof(float4));
+    *n = freddy_payload_count(bytes, sizeof(float4), -1);
+    if (*n < 0) elog(ERROR, "freddy_gpu: a float4 vector of %zu bytes", (size_t) bytes);
     out = palloc(sizeof(float) * (*n > 0 ? *n : 1));
-    memcpy(out, VARDATA_ANY(b), bytes);
+    (void) freddy_payload_f32(VARDATA_ANY(b), bytes, *n, out);
     return out;
 }
 
@@ -144,15 +135,14 @@ float *freddy_glue_bytea_array_f32(ArrayType *a, int *rows, int *dim)
         if (nulls[i]) elog(ERROR, "freddy_gpu: NULL query vector");
         b = DatumGetByteaPP(elems[i]);
         bytes = VARSIZE_ANY_EXHDR(b);
-        if (bytes % sizeof(float4) != 0) elog(ERROR, "freddy_gpu: a float4 vector of %zu bytes", (size_t) bytes);
+        if (freddy_payload_count(bytes, sizeof(float4), -1) < 0) elog(ERROR, "freddy_gpu: a float4 vector of %zu bytes", (size_t) bytes);
         if (i == 0) {
             *dim = (int) (bytes / sizeof(float4));
             /* pinned host memory: the library reads the batch from here without a staging copy (not palloc'd: the
              * backend's reusable buffer, valid until the next call of this function) */
             out = query_buffer(sizeof(float) * (Size) (*rows) * (*dim > 0 ? *dim : 1));
         }
-        if ((int) (bytes / sizeof(float4)) != *dim) elog(ERROR, "query vectors of different dimensionality");
-        memcpy(out + (size_t) i * (*dim), VARDATA_ANY(b), bytes);
+        if (freddy_payload_f32(VARDATA_ANY(b), bytes, *dim, out + (size_t) i * (*dim)) < 0) elog(ERROR, "query vectors of different dimensionality");
     }
     return out ? out : query_buffer(sizeof(float));
 }
@@ -225,31 +215,19 @@ static void take_stamp(FreddyStamp *st, int n_tabs, char names[][100])
 
 typedef enum { PIN_CURRENT, PIN_APPENDED, PIN_CODEBOOK, PIN_STALE } PinState;
 
-/* compare a pinned handle's stamp with the tables now.  appended / codebook may both be set (insert_batch does both) */
-static PinState compare_stamp(const FreddyStamp *old, const FreddyStamp *now, const char *row_table, bool *appended, bool *codebook)
+/* compare a pinned handle's stamp with the tables now (the decision itself: freddy_compare_stamp, freddy_pure.h).
+ * appended / codebook may both be set (insert_batch does both) */
+static PinState compare_stamp(const FreddyStamp *old, const FreddyStamp *now, const char *row_table, unsigned ignore_inserts_mask,
+                              bool *appended, bool *codebook)
 {
-    *appended = *codebook = false;
-    if (old->n_tabs != now->n_tabs) return PIN_STALE;
-    for (int i = 0; i < now->n_tabs; i++) {
-        if (old->rel[i] != now->rel[i] || old->filenode[i] != now->filenode[i]) return PIN_STALE;
-        if ((old->appends[i] < 0) != (now->appends[i] < 0)) return PIN_STALE;          /* the watch script came or went */
-        if (now->appends[i] >= 0) {
-            bool ins = now->appends[i] != old->appends[i], rew = now->rewrites[i] != old->rewrites[i];
-            if (i == 0) { if (rew) return PIN_STALE; *appended = *appended || ins; }
-            else if (i == 1) { if (ins) return PIN_STALE; *codebook = *codebook || rew; }
-            else if (ins || rew) return PIN_STALE;                                      /* coarse quantizer, vectors, statistics */
-        } else if (now->weak[i] != old->weak[i]) {
-            if (i == 0) *appended = true;               /* the file grew: rows with a larger id are looked for below */
-            else if (i == 1) *codebook = true;
-            else return PIN_STALE;
-        }
-    }
-    if (now->appends[0] < 0) {   /* fallback: an append shows as a larger max(id) even if the file did not grow */
-        int64 mx = spi_int64(psprintf("SELECT max(id)::bigint FROM %s", row_table), -1);
-        if (mx > old->max_id) *appended = true;
-        if (mx < old->max_id) return PIN_STALE;
-    }
-    return (*appended || *codebook) ? PIN_APPENDED : PIN_CURRENT;
+    int app = 0, cbk = 0;
+    int64 row_max = -1;
+    FreddyPinState ps;
+    if (now->appends[0] < 0)   /* no trigger on the row table: an append shows as a larger max(id) */
+        row_max = spi_int64(psprintf("SELECT max(id)::bigint FROM %s", row_table), -1);
+    ps = freddy_compare_stamp(old, now, row_max, ignore_inserts_mask, &app, &cbk);
+    *appended = app != 0; *codebook = cbk != 0;
+    return ps == FREDDY_PIN_STALE ? PIN_STALE : ps == FREDDY_PIN_CATCH_UP ? PIN_APPENDED : PIN_CURRENT;
 }
 
 /* ---- table flattening ---------------------------------------------------------------------------- */
@@ -322,9 +300,8 @@ static int64 fetch_code_rows(const char *sql, bool with_cell, int m_expected, in
             if (with_cell) (*cells)[n] = DatumGetInt32(SPI_getbinval(t, SPI_tuptable->tupdesc, 2, &null2));
             b = DatumGetByteaPP(SPI_getbinval(t, SPI_tuptable->tupdesc, with_cell ? 3 : 2, &null3));
             if (isnull || null2 || null3) elog(ERROR, "freddy_gpu: NULL in a quantization row");
-            if ((int) (VARSIZE_ANY_EXHDR(b) / sizeof(int16)) != *m || VARSIZE_ANY_EXHDR(b) % sizeof(int16))
+            if (freddy_payload_i16(VARDATA_ANY(b), VARSIZE_ANY_EXHDR(b), *m, *codes + (Size) n * *m) < 0)
                 elog(ERROR, "freddy_gpu: code rows of different lengths");
-            memcpy(*codes + (Size) n * *m, VARDATA_ANY(b), sizeof(int16) * *m);
         }
         SPI_freetuptable(SPI_tuptable);
     }
@@ -393,7 +370,7 @@ freddy_gpu_index_t *freddy_glue_pq(void)
     getTableName(CODEBOOK, names[1], 100);
     take_stamp(&now, 2, names);
     if (pin_pq.h) {
-        PinState ps = compare_stamp(&pin_pq.st, &now, names[0], &appended, &codebook);
+        PinState ps = compare_stamp(&pin_pq.st, &now, names[0], 0u, &appended, &codebook);
         if (ps == PIN_STALE) drop_pin(&pin_pq);
         else if (ps != PIN_CURRENT) {
             now.max_id = pin_pq.st.max_id; now.d = pin_pq.st.d; now.m = pin_pq.st.m;
@@ -431,7 +408,7 @@ freddy_gpu_index_t *freddy_glue_ivf(void)
     getTableName(COARSE_QUANTIZATION, names[2], 100);
     take_stamp(&now, 3, names);
     if (pin_ivf.h) {
-        PinState ps = compare_stamp(&pin_ivf.st, &now, names[0], &appended, &codebook);
+        PinState ps = compare_stamp(&pin_ivf.st, &now, names[0], 0u, &appended, &codebook);
         if (ps == PIN_STALE) drop_pin(&pin_ivf);
         else if (ps != PIN_CURRENT) {
             now.d = pin_ivf.st.d; now.m = pin_ivf.st.m;
@@ -490,13 +467,8 @@ freddy_gpu_index_t *freddy_glue_ivpq(void)
     getTableName(STATISTICS, names[4], 100);
     take_stamp(&now, 5, names);
     if (pin_ivpq.h) {
-        /* an INSERT into the vector table accompanies every appended ivpq row (updateWordVectorsRelation): table [3]
-         * may gain rows; its generation is folded into the row table's by looking only at rewrites there */
-        FreddyStamp cmp = now;
-        PinState ps;
-        cmp.appends[3] = pin_ivpq.st.appends[3];
-        if (cmp.appends[3] < 0) cmp.weak[3] = pin_ivpq.st.weak[3];
-        ps = compare_stamp(&pin_ivpq.st, &cmp, names[0], &appended, &codebook);
+        /* an INSERT into the vector table [3] accompanies every appended ivpq row (updateWordVectorsRelation): expected */
+        PinState ps = compare_stamp(&pin_ivpq.st, &now, names[0], 1u << 3, &appended, &codebook);
         if (ps == PIN_STALE) drop_pin(&pin_ivpq);
         else if (ps != PIN_CURRENT) {
             now.d = pin_ivpq.st.d; now.m = pin_ivpq.st.m;

@@ -33,6 +33,7 @@
 #include "utils/builtins.h"
 
 #include "index_utils.h"
+#include "freddy_pure.h"
 
 /* dense [m][K][s] copy of a codebook-with-counts (entries carry their own pos / code) */
 static float *dense_of(CodebookWithCounts cb, int m, int K, int s)
@@ -45,35 +46,15 @@ static float *dense_of(CodebookWithCounts cb, int m, int K, int s)
     return out;
 }
 
-/* updateCodebook (index_utils.c:908-957) for codes found on the device: nearestCentroids[i][pos] = codes[i*m + pos];
- * everything after the 1-NN search is the reference's statement sequence */
+/* updateCodebook's bookkeeping for codes found on the device: freddy_update_codebook_known_codes (freddy_pure.h -- the
+ * PostgreSQL-free part, compiled and compared with the oracle's literal restatement in this repository's tests).  It works
+ * on the reference's own entries: the two struct layouts are the same. */
+StaticAssertDecl(sizeof(FreddyCbEntry) == sizeof(CodebookEntryComplete) && offsetof(FreddyCbEntry, vector) == offsetof(CodebookEntryComplete, vector) &&
+                 offsetof(FreddyCbEntry, count) == offsetof(CodebookEntryComplete, count), "FreddyCbEntry mirrors CodebookEntryComplete");
 static void update_codebook_known_codes(int rawVectorsSize, int subvectorSize, CodebookWithCounts cb, int cbPositions, int cbCodes,
                                         const int16 *codes, int **nearestCentroids, int *countIncs)
 {
-    float **differences = palloc(cbPositions * cbCodes * sizeof(float *));
-    float **entry_of = palloc(cbPositions * cbCodes * sizeof(float *));   /* (pos, code) -> the entry's vector */
-    for (int i = 0; i < cbPositions * cbCodes; i++) {
-        differences[i] = palloc0(subvectorSize * sizeof(float));
-        countIncs[i] = 0;
-        entry_of[cb[i].pos * cbCodes + cb[i].code] = cb[i].vector;
-    }
-    for (int i = 0; i < rawVectorsSize; i++) {
-        /* the reference keeps ONE nearestCentroidRaw across positions: after its scan over the table (position-major in
-         * every table the index scripts write) it is the nearest entry of the LAST position (index_utils.c:931-938) */
-        float *nearestCentroidRaw = entry_of[(cbPositions - 1) * cbCodes + codes[(size_t) i * cbPositions + cbPositions - 1]];
-        nearestCentroids[i] = palloc(sizeof(int) * cbPositions);
-        for (int j = 0; j < cbPositions; j++) nearestCentroids[i][j] = codes[(size_t) i * cbPositions + j];
-        for (int j = 0; j < cbPositions; j++) {
-            int code = nearestCentroids[i][j];
-            countIncs[j * cbCodes + code] += 1;
-            for (int k = 0; k < subvectorSize; k++) differences[j * cbCodes + code][k] += nearestCentroidRaw[k];
-        }
-    }
-    for (int i = 0; i < cbPositions * cbCodes; i++) {   /* recalculate codebook (index_utils.c:949-956) */
-        cb[i].count += countIncs[cb[i].pos * cbCodes + cb[i].code];
-        for (int j = 0; j < subvectorSize; j++)
-            cb[i].vector[j] += (1.0 / cb[i].count) * differences[cb[i].pos + cb[i].code][j];
-    }
+    freddy_update_codebook_known_codes(rawVectorsSize, subvectorSize, (FreddyCbEntry *) cb, cbPositions, cbCodes, codes, nearestCentroids, countIncs);
 }
 
 PG_FUNCTION_INFO_V1(insert_batch);
