@@ -443,7 +443,7 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
       for (int v = 0; v < V; ++v) {
         const u64 key = lists[(size_t)w * 64 * V + v * 64 + lane];
         if (__ballot(key != KEY_INF) == 0ull) break;   // lists are ascending: the rest is empty too
-        wave_topk_absorb<V>(sel.acc, key);
+        wave_topk_absorb_sorted<V>(sel.acc, key);
       }
     }
     if (a.method == FREDDY_METHOD_PQ_PV) {
