@@ -67,6 +67,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=1024, help="queries timed on the CPU oracle (0 = skip)")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--host-abi-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--same-queries", action="store_true",
+                    help="every in-flight stream searches the SAME query set (round 2's setup; the default gives each stream its own)")
     ap.add_argument("--no-host-abi", action="store_true", help="skip the host-buffer ABI measurement (a child process); profiling runs")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="config ivfadc on one GPU also runs bounded passes of --config pq and --config join and reports them "
@@ -264,6 +266,8 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     n_fl = max(1, min(a.in_flight, 8))
     rng = np.random.default_rng(7 + rank)
     qids = [np.sort(rng.choice(np.arange(1, N + 1), size=q_local, replace=False)).astype(np.int64) for _ in range(n_fl)]
+    if a.same_queries:
+        qids = [qids[0]] * n_fl
     d_qs = [x[torch.from_numpy(q - 1).to(dev)].contiguous() for q in qids]
     d_status = torch.zeros(4, dtype=torch.int32, device=dev)
     torch.cuda.synchronize(dev)
