@@ -60,6 +60,17 @@ __device__ __forceinline__ uint32_t widen_threshold5(uint32_t tau_key, float E) 
   return __float_as_uint(t + __builtin_fabsf(t) * 2.4e-7f + 1e-37f);
 }
 
+// The table stores v + bias(p) >= 0 with sum_p bias(p) = 2^15 (m = 12: 2731 for the first eight positions, 2730 for the
+// others): a (row, item) sum is then an UNSIGNED 16-bit field in [8, 65528] at every step, so two fields per register are
+// added with plain 32-bit adds (v_add3_u32: two positions at once, no carry ever crosses the halves), and field ^ 0x8000 is
+// the signed sum V in two's complement.
+__host__ __device__ __forceinline__ constexpr int filt5_bias(int p, int m) { return FILT5_VMAX + (p < 32768 - FILT5_VMAX * m ? 1 : 0); }
+// 4 x lane id, never hoisted or spilled (two instructions where it is used)
+__device__ __forceinline__ uint32_t lane_byte4() {
+  uint32_t x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_lshlrev_b32 %0, 2, %0" : "=v"(x));
+  return x;
+}
 typedef short s2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_pk_add_u16 (wrap-around: never reached)
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, x) + __builtin_bit_cast(s2v, y));
@@ -141,15 +152,16 @@ __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __res
     }
     const int buf = (qi >> 2) & 1;
     const float vmax = (float)FILT5_VMAX;
+    const int bias = filt5_bias(p, m);
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const float inv = inv_s[qi + w];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int b = tid + 256 * e;
-        const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].x * inv), -vmax), vmax);
-        const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].y * inv), -vmax), vmax);
-        ob[buf][w][4 * (b & 127) + (b >> 7)] = ((uint32_t)i0 & 0xffffu) | ((uint32_t)i1 << 16);
+        const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].x * inv), -vmax), vmax) + bias;
+        const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].y * inv), -vmax), vmax) + bias;
+        ob[buf][w][4 * (b & 127) + (b >> 7)] = (uint32_t)i0 | ((uint32_t)i1 << 16);
       }
     }
     __syncthreads();
@@ -207,6 +219,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
   constexpr int NP = M / 2;             // phases per entry
   constexpr int ROWB = G * 2;           // bytes of a slab row: two 16-byte halves of 8 items
+  constexpr int HROWB = 16;             // a half row; the halves of a position live in two planes of K half rows each
   static_assert(M == 12 && G == 16 && SPEC2_NB == 8, "layout");
   typedef uint32_t u2 __attribute__((ext_vector_type(2)));
   typedef uint32_t u4 __attribute__((ext_vector_type(4)));
@@ -222,7 +235,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool builder = wave < SPEC2_NB;
   const int K = FULLK ? 1024 : a.K;
-  const uint32_t POSB = (uint32_t)K * ROWB;          // bytes of one position's slab
+  const uint32_t HALFB = (uint32_t)K * HROWB;        // bytes of one plane: the values of 8 items for every code of a position
+  const uint32_t POSB = 2u * HALFB;                  // bytes of one position's slab
   const uint32_t BUFB = 2u * POSB;                   // bytes of one buffer
   const int n_work = a.n_groups[0];
 
@@ -239,69 +253,64 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
 
   if (builder) {
     // =====================================================================================
-    // BUILDERS: a pair of waves per item quad; lane li of the pair <-> code pairs li + 128 k (k < 4), one 16-byte
-    // load per item and position.  Two register sets of one PHASE each (2 positions x 4 items): the set that
-    // phase j + 1 is written from at the start of phase j is refilled at once with phase j + 3.
+    // BUILDERS: a pair of waves per (position of the phase, half = 8 items); lane li of the pair <-> code pairs
+    // li + 128 k (k < 4), one 16-byte load per item.  A lane holds the values of ALL eight items of its half for its
+    // eight codes, so a half row leaves as ONE 16-byte store and consecutive lanes store consecutive half rows: no bank
+    // conflicts (8-byte stores per item quad were 4-way conflicts: half of the kernel's conflict cycles).
+    // Two register sets of one PHASE each: the set that phase j + 1 is written from at the start of phase j is
+    // refilled at once with phase j + 3.
     // =====================================================================================
-    const int grp = wave >> 1;
-    constexpr bool has_quad = true;      // (four quads, four wave pairs)
+    const int hpos = (wave >> 1) & 1;    // position 2 j + hpos of phase j
+    const int half = wave >> 2;          // items 8 half .. 8 half + 7
     const int li = (wave & 1) * 64 + lane;
-    // byte offset of this quad inside a slab row: half (grp >> 1), swizzled with bit 3 of the code -- the same for all
-    // codes li + 128 k (+ 512) of this lane
-    const uint32_t qoff = (uint32_t)((((grp >> 1) ^ ((li >> 3) & 1)) << 4) + ((grp & 1) << 3));
-    const uint32_t vq = (uint32_t)li * 16u;
-    u4 qw[2][2][4];   // [set][position of the phase][item]
+    const uint32_t qoff = (uint32_t)hpos * POSB + (uint32_t)half * HALFB + (uint32_t)li * HROWB;
+    const uint32_t vq = (uint32_t)li * 16u + (uint32_t)hpos * 2048u;
+    u4 qw[2][8];   // [set][item of the half]
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) qw[s][h][g] = u4{0u, 0u, 0u, 0u};
+      for (int g = 0; g < 8; ++g) qw[s][g] = u4{0u, 0u, 0u, 0u};
     typedef const char __attribute__((address_space(1))) * gptrc;
     typedef const u4 __attribute__((address_space(1))) * gptr4u;
-    auto issue = [&](int set, int phase, const int (&qids)[4]) {   // positions 2 phase, 2 phase + 1 of the quad's 4 items
-      if (!has_quad || (a.ablate & 32)) return;
+    auto issue = [&](int set, int phase, const int (&qids)[8], int nh) {   // position 2 phase + hpos of the half's 8 items
+      if (half >= nh || (a.ablate & 32)) return;
       uint32_t voff = vq + (uint32_t)phase * 4096u;
       asm volatile("" : "+v"(voff));
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[u] * (size_t)(M * 2048);
-          qw[set][h][u] = *(gptr4u)(qb + voff + (uint32_t)h * 2048u);
-        }
+      for (int u = 0; u < 8; ++u) {
+        const gptrc qb = (gptrc)(uintptr_t)a.qc + (size_t)(uint32_t)qids[u] * (size_t)(M * 2048);
+        qw[set][u] = *(gptr4u)(qb + voff);
+      }
     };
-    // slab rows are [code][12 items] int16: 8 bytes per item quad and code -- the quad's four table words of
-    // code pair b = li + 128 k interleaved: low halves -> row b, high halves -> row b + 512
-    auto emit = [&](int set, unsigned char* dst, int nq) {
-      if (!has_quad || grp >= nq || (a.ablate & 16)) return;
+    // the eight table words of code pair b = li + 128 k interleaved: low halves -> half row b, high halves -> b + 512
+    auto emit = [&](int set, unsigned char* dst, int nh) {
+      if (half >= nh || (a.ablate & 16)) return;
+      unsigned char* dp = dst + qoff;
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        unsigned char* dp = dst + (uint32_t)h * POSB + qoff;
+      for (int k = 0; k < 4; ++k) {
+        uint32_t w[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          uint32_t w[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            w[u] = k == 0 ? qw[set][h][u].x : k == 1 ? qw[set][h][u].y : k == 2 ? qw[set][h][u].z : qw[set][h][u].w;
-          // v_perm_b32: bytes 0-3 come from the second operand, 4-7 from the first
-          const u2 lo = u2{__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u)};
-          const u2 hi = u2{__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u)};
-          const int b = li + 128 * k;
-          if (FULLK || b < K) *reinterpret_cast<u2*>(dp + (uint32_t)b * ROWB) = lo;
-          if (FULLK || b + 512 < K) *reinterpret_cast<u2*>(dp + (uint32_t)(b + 512) * ROWB) = hi;
-        }
+        for (int u = 0; u < 8; ++u)
+          w[u] = k == 0 ? qw[set][u].x : k == 1 ? qw[set][u].y : k == 2 ? qw[set][u].z : qw[set][u].w;
+        // v_perm_b32: bytes 0-3 come from the second operand, 4-7 from the first
+        const u4 lo = u4{__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u),
+                         __builtin_amdgcn_perm(w[5], w[4], 0x05040100u), __builtin_amdgcn_perm(w[7], w[6], 0x05040100u)};
+        const u4 hi = u4{__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u),
+                         __builtin_amdgcn_perm(w[5], w[4], 0x07060302u), __builtin_amdgcn_perm(w[7], w[6], 0x07060302u)};
+        const int b = li + 128 * k;
+        if (FULLK || b < K) *reinterpret_cast<u4*>(dp + (uint32_t)(128 * k) * HROWB) = lo;
+        if (FULLK || b + 512 < K) *reinterpret_cast<u4*>(dp + (uint32_t)(128 * k + 512) * HROWB) = hi;
       }
     };
 
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
     auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
     if (a.prof) pc = clock64();
-    int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 3) >> 2;
-    const int g0 = has_quad ? grp * 4 : 0;
-    int qid[4], nqid[4];
+    int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 7) >> 3;   // halves in use
+    const int g0 = half * 8;
+    int qid[8], nqid[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { qid[u] = __builtin_amdgcn_readfirstlane(dsc[24 + g0 + u]); nqid[u] = qid[u]; }
+    for (int u = 0; u < 8; ++u) { qid[u] = __builtin_amdgcn_readfirstlane(dsc[24 + g0 + u]); nqid[u] = qid[u]; }
     float rtv[RMAX];
     auto fetch_row_terms = [&](const int32_t* rc) {
       const int b0 = __builtin_amdgcn_readfirstlane(rc[3]), nbk = __builtin_amdgcn_readfirstlane(rc[4]);
@@ -317,10 +326,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     };
     fetch_row_terms(dsc);
     stash_row_terms();
-    issue(0, 0, qid);
-    issue(1, 1, qid);
+    issue(0, 0, qid, nq);
+    issue(1, 1, qid, nq);
     emit(0, slab, nq);          // phase 0 -> buffer 0 (waits for set 0)
-    issue(0, 2, qid);
+    issue(0, 2, qid, nq);
     lds_barrier();
     for (;;) {
       const int nb = cur ^ 1;
@@ -338,17 +347,17 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
         }
         if (j == NP - 3) {   // (the next entry's record is in LDS since the barrier of phase 1)
-          next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 3) >> 2 : 0;
+          next_nq = have_next ? (__builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) + 7) >> 3 : 0;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) nqid[u] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g0 + u]) : qid[u];
+          for (int u = 0; u < 8; ++u) nqid[u] = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g0 + u]) : qid[u];
         }
         // slab of phase j + 1 of this entry -- or phase 0 of the next one -- from the set requested two phases ago,
         // then the same set again for phase j + 3
         const int set = (j + 1) & 1;
         if (j + 1 < NP) emit(set, slab + (uint32_t)((j + 1) & 1) * BUFB, nq);
         else emit(set, slab, next_nq);
-        if (j + 3 < NP) issue(set, j + 3, qid);
-        else issue(set, j + 3 - NP, nqid);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
+        if (j + 3 < NP) issue(set, j + 3, qid, nq);
+        else issue(set, j + 3 - NP, nqid, next_nq);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
         if (j == 2) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
         if (j == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
         if (j == 0 && tid == 0) gid2 = ei + 2 < quota ? atomicAdd(a.work_counter, 1) : 0x7fffffff;
@@ -383,7 +392,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       ++ei;
       nq = next_nq;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) qid[u] = nqid[u];
+      for (int u = 0; u < 8; ++u) qid[u] = nqid[u];
     }
     if (a.prof && tid == 0) {
       for (int i = 0; i < 8; ++i) if (i != 2 && i != 4 && i != 5) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];   // (2, 4, 5: gatherer wave 0)
@@ -416,9 +425,15 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       };
       auto main_loop = [&](auto nqc, auto rlc) {
         constexpr int NQ = decltype(nqc)::value, RL = decltype(rlc)::value;
+        // (uniform 64-bit row address + this lane's byte offset, recomputed where it is needed: hoisted out of the entry
+        // loop it was spilled, and every phase waited for the reload)
         auto load_codes = [&](uint32_t (&cw)[RMAX], int pair) {
+          const uint32_t l4 = lane_byte4();
 #pragma unroll
-          for (int r = 0; r < RL; ++r) cw[r] = a.packed[(row_block(r) * (uint32_t)(M / 2) + (uint32_t)pair) * 64u + (uint32_t)lane];
+          for (int r = 0; r < RL; ++r) {
+            const char* rowp = reinterpret_cast<const char*>(a.packed) + (size_t)((row_block(r) * (uint32_t)(M / 2) + (uint32_t)pair) * 256u);
+            cw[r] = *reinterpret_cast<const uint32_t*>(rowp + l4);
+          }
         };
         // both positions of a phase, one row at a time: NQ ds_read_b128 per position fetch the values of 8 items each.
         // Half h of row c sits at byte 32 c + 16 (h ^ bit 3 of c): with the plain layout the first halves of all rows
@@ -427,17 +442,18 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         // flight per wave the LDS pipe idled while the waves added (a closed loop: 8 waves x 4 reads, ~15 cycles of
         // service each, then ~100 cycles of adds before the next batch).
         auto gather = [&](const uint32_t (&cw)[RMAX], int j) {
-          const unsigned char* bufp = slab + (uint32_t)(j & 1) * BUFB;
           constexpr int DEPTH = NQ == 1 ? 4 : 2;   // rows in flight (32 registers either way; 3 rows of two halves spill)
           u4 va[DEPTH][2][NQ];   // [row slot][position of the phase][half]
+          // byte offsets of the two codes' half rows: 16 c (| the buffer); halves and positions are constant offsets
+          uint32_t bb = (uint32_t)(j & 1) * BUFB;
+          asm volatile("" : "+s"(bb));   // (kept out of the constant folder: the halves / positions stay immediate offsets)
           auto issue_row = [&](int r) {
-            const uint32_t c0 = cw[r] & 0xffffu, c1 = cw[r] >> 16;
-            const uint32_t a0 = c0 * (uint32_t)ROWB + ((c0 & 8u) << 1);
-            const uint32_t a1 = c1 * (uint32_t)ROWB + ((c1 & 8u) << 1) + POSB;
+            const uint32_t a0 = ((cw[r] << 4) & 0x3ff0u) + bb;
+            const uint32_t a1 = ((cw[r] >> 12) & 0x3ff0u) + bb;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) va[r % DEPTH][0][q] = *reinterpret_cast<const u4*>(bufp + (a0 ^ (uint32_t)(q * 16)));
+            for (int q = 0; q < NQ; ++q) va[r % DEPTH][0][q] = *reinterpret_cast<const u4*>(slab + a0 + (uint32_t)q * HALFB);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) va[r % DEPTH][1][q] = *reinterpret_cast<const u4*>(bufp + (a1 ^ (uint32_t)(q * 16)));
+            for (int q = 0; q < NQ; ++q) va[r % DEPTH][1][q] = *reinterpret_cast<const u4*>(slab + a1 + POSB + (uint32_t)q * HALFB);
           };
 #pragma unroll
           for (int r = 0; r < DEPTH - 1; ++r) if (r < RL) issue_row(r);
@@ -447,10 +463,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
               const u4 x = va[r % DEPTH][0][q], y = va[r % DEPTH][1][q];
-              acc[q * 4 + 0][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 0][r], x.x), y.x);
-              acc[q * 4 + 1][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 1][r], x.y), y.y);
-              acc[q * 4 + 2][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 2][r], x.z), y.z);
-              acc[q * 4 + 3][r] = pk_add_i16(pk_add_i16(acc[q * 4 + 3][r], x.w), y.w);
+              acc[q * 4 + 0][r] = acc[q * 4 + 0][r] + x.x + y.x;   // (v_add3_u32: unsigned fields, see filt5_bias)
+              acc[q * 4 + 1][r] = acc[q * 4 + 1][r] + x.y + y.y;
+              acc[q * 4 + 2][r] = acc[q * 4 + 2][r] + x.z + y.z;
+              acc[q * 4 + 3][r] = acc[q * 4 + 3][r] + x.w + y.w;
             }
             if (r + 1 < RL) __builtin_amdgcn_sched_barrier(0);
           }
@@ -507,6 +523,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           if (r >= rl_wave || (r == rs2 && !live_lane)) base[r] = __uint_as_float(0x7f800000u);
         }
       }
+#pragma unroll
+      for (int h = 0; h < G / 2; ++h)
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) acc[h][r] ^= 0x80008000u;   // biased unsigned fields -> signed sums
       gtick(0);
       auto sval = [&](int g, int r, float sc) -> float {
         const uint32_t w = acc[g >> 1][r];
