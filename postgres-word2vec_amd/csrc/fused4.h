@@ -761,6 +761,8 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   __shared__ int sh_n;
   constexpr int BQ = MANY ? 512 : 1;     // rows with d_lo <= T beyond the kept keys, collected by all waves (dense neighbourhoods)
   __shared__ u64 bq_key[BQ];
+  constexpr int PB = 256;                // survivor regions per block of the dense sweep
+  __shared__ int pref_all[MANY ? NWV : 1][PB + 1];
   __shared__ int bq_n;
   __shared__ uint32_t sh_T;
   const int x = blockIdx.x, lane = threadIdx.x & 63;
@@ -831,53 +833,71 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   // ---- pass 1: the L smallest lower bounds ----
   // (a few more than L are kept: the rows to refine are normally all among them)
   const int LW = (a.ablate & 4) ? a.L : ((a.L + 22 < 64 && R <= 64 * NBATCH) ? a.L + 22 : 64);
-  // one sweep over survivor regions jb0, jb0 + jstep, ... (64 x NBATCH regions at a time: counts, then the first two keys
-  // of every region, in flight together); every key goes to sink(key, valid), called by the whole wave
-  auto sweep = [&](auto&& sink, int jb0, int jstep, uint32_t& flag_seen) {
-    for (int jb = jb0; jb < R; jb += jstep) {
+  // Dense sweep.  The survivors of a query sit in R regions (item x chunk x gatherer wave) of a few keys each; walking them
+  // region by region (a lane per region) is a chain of dependent round trips as long as the fullest region.  Instead: the
+  // counts of a block of <= PB regions (one round trip) -> exclusive prefix in LDS -> lane s of the wave takes the s-th key
+  // of the block (binary search in the prefix), 64 x NBATCH keys per round trip.  Every key goes to sink(key, valid,
+  // region), called by the whole wave.
+  int* const pref = pref_all[MANY ? wave : 0];
+  auto dense_block = [&](auto&& sink, int jb0, int nreg) {
+    int carry = 0;
+    for (int i0 = 0; i0 < nreg; i0 += 64 * NBATCH) {
       int c[NBATCH];
-      size_t region[NBATCH];
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
-        const int j = jb + u * 64 + lane;
-        region[u] = (size_t)x * R + (size_t)(j < R ? j : 0);
-        c[u] = (j < R) ? a.surv_count[region[u]] : 0;
-      }
-      u64 k0[NBATCH], k1[NBATCH];
-#pragma unroll
-      for (int u = 0; u < NBATCH; ++u) {
-        const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
-        k0[u] = (c[u] > 0) ? src[0] : KEY_INF;
-        k1[u] = (c[u] > 1) ? src[1] : KEY_INF;
-        if (c[u] > 0) flag_seen |= (uint32_t)k0[u];
-        if (c[u] > 1) flag_seen |= (uint32_t)k1[u];
+        const int j = i0 + u * 64 + lane;
+        c[u] = (j < nreg) ? a.surv_count[(size_t)x * R + (size_t)(jb0 + j)] : 0;
       }
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u) {
-        const u64* src = a.surv + region[u] * (size_t)(FUSED_RMAX * 64);
-        int maxc = c[u];
+        int inc = c[u];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
-        if (maxc > 0) sink(k0[u], c[u] > 0);
-        if (maxc > 1) sink(k1[u], c[u] > 1);
-        for (int t = 2; t < maxc; ++t) {
-          const bool valid = t < c[u];
-          const u64 kk = valid ? src[t] : KEY_INF;
-          if (valid) flag_seen |= (uint32_t)kk;
-          sink(kk, valid);
+        for (int o = 1; o < 64; o <<= 1) {
+          const int up = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += up;
         }
+        const int j = i0 + u * 64 + lane;
+        if (j < nreg) pref[j] = carry + inc - c[u];
+        carry += __shfl(inc, 63, 64);
       }
     }
+    const int total = carry;
+    if (lane == 0) pref[nreg] = total;
+    __builtin_amdgcn_wave_barrier();
+    for (int s0 = 0; s0 < total; s0 += 64 * NBATCH) {
+      u64 kk[NBATCH];
+      int jj[NBATCH];
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u) {
+        const int sidx = s0 + u * 64 + lane;
+        int lo = 0;   // the largest region index with pref <= sidx: the (non-empty) region holding key sidx
+#pragma unroll
+        for (int step = PB / 2; step >= 1; step >>= 1) {
+          const int mid = lo + step;
+          if (mid < nreg && pref[mid] <= sidx) lo = mid;
+        }
+        jj[u] = lo;
+        kk[u] = (sidx < total) ? a.surv[((size_t)x * R + (size_t)(jb0 + lo)) * (size_t)(FUSED_RMAX * 64) + (size_t)(sidx - pref[lo])] : KEY_INF;
+      }
+#pragma unroll
+      for (int u = 0; u < NBATCH; ++u)
+        if (s0 + u * 64 < total) sink(kk[u], s0 + u * 64 + lane < total, jb0 + jj[u]);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  // blocks jb0, jb0 + jstep, ... of the query's regions
+  auto sweep = [&](auto&& sink, int jb0, int jstep) {
+    for (int jb = jb0; jb < R; jb += jstep) dense_block(sink, jb, R - jb < PB ? R - jb : PB);
   };
   // More regions than one sweep of a wave covers (W x chunks x 8 > 256: a batch over the flat PQ table "probes" hundreds of
   // pseudo-lists): every wave selects from a quarter of them -- the sweeps are chains of dependent round trips -- and
   // wave 0 merges the four selections.
-  const bool split1 = MANY && R > 64 * NBATCH;
+  const bool split1 = MANY && R > PB;
   if (MANY && split1) {
     WaveSelect<1> sp;
     sp.init(stage_all[MANY ? wave : 0], KEY_INF, LW);
     uint32_t fs = 0u;
-    sweep([&](u64 kk, bool v) { sp.push(kk, v); }, wave * 64 * NBATCH, NWV * 64 * NBATCH, fs);
+    sweep([&](u64 kk, bool v, int) { if (v) fs |= (uint32_t)kk; sp.push(kk, v); }, wave * PB, NWV * PB);
     sp.finish();
     part_key[MANY ? wave : 0][lane] = sp.acc[0];
     part_flag[MANY ? wave : 0][lane] = fs;
@@ -887,8 +907,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   // every row with d_lo <= T (or a pending sentinel decision) of this wave's share of the regions -> bq_key
   auto collect = [&]() {
     const uint32_t Tb = sh_T;
-    uint32_t unused = 0u;
-    sweep([&](u64 kk, bool valid) {
+    sweep([&](u64 kk, bool valid, int) {
       const bool need = valid && (((uint32_t)(kk >> 32) <= Tb) || ((uint32_t)kk & 0x80000000u));
       const u64 mask = __ballot(need);
       if (mask != 0ull) {
@@ -898,7 +917,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
         const int slot = base + (int)lanes_below(mask);
         if (need && slot < BQ) bq_key[slot] = kk;
       }
-    }, wave * 64 * NBATCH, NWV * 64 * NBATCH, unused);
+    }, wave * PB, NWV * PB);
   };
 
   if (wave != 0) {
@@ -924,7 +943,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
       sel.push(kk, kk != KEY_INF);
     }
   } else {
-    sweep([&](u64 kk, bool v) { sel.push(kk, v); }, 0, 64 * NBATCH, flag_seen);
+    sweep([&](u64 kk, bool v, int) { if (v) flag_seen |= (uint32_t)kk; sel.push(kk, v); }, 0, PB);
   }
   sel.finish();
   if (a.ablate & 8) {
@@ -1054,20 +1073,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
       }
     }
   }
-  for (int jb = 0; revisit && jb < R; jb += 64) {
-    const int j = jb + lane;
-    const size_t region = (size_t)x * R + (size_t)(j < R ? j : 0);
-    const int c = (j < R) ? a.surv_count[region] : 0;
-    const int cell = (j < R) ? a.item_cell[(size_t)x * a.W + j / per_item] : 0;
-    const u64* src = a.surv + region * (size_t)(FUSED_RMAX * 64);
-    int maxc = c;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o, 64));
-    for (int t = 0; t < maxc; ++t) {
-      const bool valid = t < c;
-      offer(valid ? src[t] : KEY_INF, valid, cell);
-    }
-  }
+  if (revisit) sweep([&](u64 kk, bool valid, int j) { offer(kk, valid, valid ? a.item_cell[(size_t)x * a.W + j / per_item] : 0); }, 0, PB);
   if (a.ablate & 1) queued = 0;
   // the queued rows are refined by the four waves together, NC per round (normally one round: <= NC rows; a batch over
   // the flat PQ table has 20 .. 60 rows within E of its 2k-th smallest bound)
