@@ -28,6 +28,7 @@
 #include "scan_common.h"
 #include "fused3.h"
 #include "fused5.h"
+#include "sparse5.h"
 #include "coarse.h"
 #include "exact.h"
 #include "join.h"
@@ -83,6 +84,7 @@ struct Tuning {
   int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
   int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
+  int sparse_items = 2;        // FREDDY_GPU_SPARSE_ITEMS: cells that at most this many queries of a batch probe are scanned item by item (sparse5.h) instead of as cell-grouped work entries (0 = never)
   int scan_quota_wgs = 0;      // FREDDY_GPU_SCAN_QUOTA_WGS: number of quota-limited workgroups in front of the persistent ones (0 = from the batch's size)
   int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
   int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
@@ -117,6 +119,7 @@ static Tuning read_tuning() {
   t.pipe_trace = (int)env_int("FREDDY_GPU_PIPE_TRACE", 0);
   t.scan_quota = (int)env_int("FREDDY_GPU_SCAN_QUOTA", t.scan_quota);
   t.scan_quota_wgs = (int)env_int("FREDDY_GPU_SCAN_QUOTA_WGS", t.scan_quota_wgs);
+  t.sparse_items = (int)env_int("FREDDY_GPU_SPARSE_ITEMS", t.sparse_items);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
@@ -903,6 +906,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
   else if (n == "scan_quota") t.scan_quota = (int)value;
   else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
+  else if (n == "sparse_items") t.sparse_items = std::max(0, std::min(16, (int)value));
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
@@ -1013,11 +1017,11 @@ static int ivf_coarse(IvfRun& r) {
   const bool small_zero = !r.tiled && d <= 1024;
   if (!r.tiled && !small_zero) {
     HIP_TRY(hipMemsetAsync(ws->w_used.p, 0, sizeof(uint32_t) * (size_t)Q * used_words, s));
-    HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 4, s));
+    HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 8, s));
   }
   ZeroArgs za;
   za.p[0] = ws->w_used.as<uint32_t>(); za.n[0] = Q * used_words;
-  za.p[1] = ws->w_cnt.as<uint32_t>(); za.n[1] = 4;
+  za.p[1] = ws->w_cnt.as<uint32_t>(); za.n[1] = 8;
   za.p[2] = r.fused ? ws->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = r.fused ? C * 2 : 0;
   za.p[3] = ws->w_cand.as<uint32_t>(); za.n[3] = Q;
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
@@ -1133,6 +1137,9 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
 struct WorkTable {
   size_t max_groups;
   int32_t *group_cell, *group_first, *group_cnt, *n_groups, *work_counter;
+  // (item, chunk) units of the cells that few queries probe (sparse5.h); sp_cap = 0: none
+  size_t sp_cap;
+  int32_t *sp_cell, *sp_first, *sp_chunk, *n_sparse, *sp_counter;
 };
 static int ivf_work_table(IvfRun& r, WorkTable& wt) {
   Workspace* ws = r.ws;
@@ -1144,12 +1151,21 @@ static int ivf_work_table(IvfRun& r, WorkTable& wt) {
   wt.group_cell = base; wt.group_first = base + wt.max_groups; wt.group_cnt = base + 2 * wt.max_groups;
   wt.n_groups = ws->w_cnt.as<int32_t>() + 1;
   wt.work_counter = ws->w_cnt.as<int32_t>() + 2;
+  wt.sp_counter = ws->w_cnt.as<int32_t>() + 3;
+  wt.n_sparse = ws->w_cnt.as<int32_t>() + 4;
+  // cells that one or two queries probe are scanned item by item -- where such cells are the rule (fewer than four items per
+  // cell on average: a corpus with more cells than the batch has probes, or a small batch); a dense batch does not pay the
+  // extra launch for its handful of thin cells
+  const int sparse_max = (r.scan_kernel == 5 && (size_t)n_items < 4 * (size_t)ix->C) ? ix->tune.sparse_items : 0;
+  wt.sp_cap = sparse_max > 0 ? (size_t)n_items * r.upi : 0;
+  wt.sp_cell = base + 3 * wt.max_groups; wt.sp_first = wt.sp_cell + wt.sp_cap; wt.sp_chunk = wt.sp_first + wt.sp_cap;
   timed_launch(ix, s, "work_table", [&] {
     hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ws->w_cellcnt.as<int32_t>(), ix->C, r.n_active, r.scan_kernel == 5 ? SCAN5_G : SPEC2_G, ix->blk_off,
-                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : r.scan_kernel == 4 ? 1 : 0);
+                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : r.scan_kernel == 4 ? 1 : 0,
+                       sparse_max, wt.sp_cell, wt.sp_first, wt.sp_chunk, wt.n_sparse);
   });
   HIP_TRY(hipGetLastError());
-  if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, sizeof(int32_t), s));
+  if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, 2 * sizeof(int32_t), s));   // (both work counters)
   return 0;
 }
 
@@ -1245,6 +1261,21 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
   });
   HIP_TRY(hipGetLastError());
+  if (v5 && wt.sp_cap > 0) {
+    // cells that one or two queries of the batch probe: item by item (sparse5.h), six workgroups of four waves per CU
+    SparseArgs sp;
+    sp.qc = fl.qc; sp.qscale = ra.qscale; sp.qn = ra.qn; sp.pmax = ix->pmax; sp.rterm = ix->rterm; sp.packed = ix->packed;
+    sp.blk_off = ix->blk_off; sp.list_off = ix->list_off; sp.sorted_item = ra.sorted_item; sp.item_query = pa.item_query;
+    sp.item_dist = pa.item_dist; sp.sp_cell = wt.sp_cell; sp.sp_first = wt.sp_first; sp.sp_chunk = wt.sp_chunk;
+    sp.n_units = wt.n_sparse; sp.work_counter = wt.sp_counter; sp.surv = fl.surv; sp.surv_count = fl.surv_count;
+    sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.ablate = fl.ablate;
+    const unsigned sp_grid = (unsigned)std::min<size_t>(wt.sp_cap, (size_t)std::max(1, scan_cus) * 6);
+    timed_launch(ix, ss, "sparse_items", [&] {
+      if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
+      else hipLaunchKernelGGL((sparse_item5_kernel<12, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
+    });
+    HIP_TRY(hipGetLastError());
+  }
   if (parted) {
     HIP_TRY(hipEventRecord(ws->ev_scan, ss));
     HIP_TRY(hipStreamWaitEvent(s, ws->ev_scan, 0));
@@ -1454,12 +1485,12 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
       ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
       ws->w_qn2.ensure(sizeof(float) * Q) || ws->w_item_dist.ensure(sizeof(float) * items) ||
       ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) ||
-      ws->w_act1.ensure(sizeof(int32_t) * Q) || ws->w_cnt.ensure(sizeof(int32_t) * 4))
+      ws->w_act1.ensure(sizeof(int32_t) * Q) || ws->w_cnt.ensure(sizeof(int32_t) * 8))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   if (r.fused) {
     // cell_count[C] + cursors; cell_items[C][Q]; work table: 3 arrays of (items/G + C + 1) * upi entries
     if (ws->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ws->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
-        ws->w_groups.ensure(sizeof(int32_t) * 3 * (items / SPEC2_G + (size_t)C + 1) * r.upi) ||
+        ws->w_groups.ensure(sizeof(int32_t) * 3 * ((items / SPEC2_G + (size_t)C + 1) * r.upi + items * r.upi)) ||   // + the (item, chunk) units of sparse cells
         ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
         ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
@@ -1960,7 +1991,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
       ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) || ws->w_act1.ensure(sizeof(int32_t) * Q) ||
       ws->w_cnt.ensure(sizeof(int32_t) * 8) || ws->w_cellcnt.ensure(sizeof(int32_t) * (size_t)lists * 3) ||
       ws->w_sorted.ensure(sizeof(int32_t) * (size_t)lists * Q) ||
-      ws->w_groups.ensure(sizeof(int32_t) * 3 * (items / SPEC2_G + (size_t)lists + 1) * r.upi) ||
+      ws->w_groups.ensure(sizeof(int32_t) * 3 * ((items / SPEC2_G + (size_t)lists + 1) * r.upi + items * r.upi)) ||
       ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
       ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW) ||
       ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))

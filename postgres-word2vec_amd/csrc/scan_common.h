@@ -37,13 +37,18 @@ static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row bloc
 __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
                                                          const int32_t* __restrict__ blk_off, int32_t* __restrict__ out_cell,
                                                          int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
-                                                         int32_t* __restrict__ n_groups, int cost_mode) {
+                                                         int32_t* __restrict__ n_groups, int cost_mode,
+                                                         int sparse_max = 0, int32_t* __restrict__ sp_cell = nullptr,
+                                                         int32_t* __restrict__ sp_first = nullptr, int32_t* __restrict__ sp_chunk = nullptr,
+                                                         int32_t* __restrict__ n_sparse = nullptr) {
   constexpr int NB = 128;   // cost classes, descending (cost_mode 0 uses FUSED_G * 4 + 4 of them: (items, quarter of a full chunk))
   constexpr int T = 1024, CPT = 4;   // the first T * CPT cells are read once and kept in registers for both sweeps
   __shared__ int hist[NB];
   __shared__ int start[NB];
+  __shared__ int sp_n;   // (item, chunk) units of the cells with <= sparse_max items: sparse5.h takes them one by one
   const int tid = threadIdx.x;
   for (int i = tid; i < NB; i += T) hist[i] = 0;
+  if (tid == 0) sp_n = 0;
   int cn[CPT], cb[CPT];
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -57,6 +62,17 @@ __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restr
   auto cell = [&](bool emit, int c, int n, int nblk) {
     if (n == 0) return;
     const int chunks = (nblk + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
+    if (n <= sparse_max) {
+      if (!emit)
+        for (int f = 0; f < n; ++f)
+          for (int ch = 0; ch < chunks; ++ch) {
+            const int slot = atomicAdd(&sp_n, 1);
+            sp_cell[slot] = c;
+            sp_first[slot] = c * cell_cap + f;
+            sp_chunk[slot] = ch;
+          }
+      return;
+    }
     for (int f = 0; f < n; f += gsz) {
       const int cnt = (n - f < gsz) ? n - f : gsz;
       for (int ch = 0; ch < chunks; ++ch) {
@@ -108,6 +124,7 @@ __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restr
     start[2 * tid] = inc - h0 - h1;
     start[2 * tid + 1] = inc - h1;
     if (tid == 63) n_groups[0] = inc;
+    if (tid == 0 && n_sparse) n_sparse[0] = sp_n;
   }
   __syncthreads();
   sweep(true);
