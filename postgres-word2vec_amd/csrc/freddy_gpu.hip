@@ -906,7 +906,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
   else if (n == "scan_quota") t.scan_quota = (int)value;
   else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
-  else if (n == "sparse_items") t.sparse_items = std::max(0, std::min(16, (int)value));
+  else if (n == "sparse_items") t.sparse_items = std::max(-16, std::min(16, (int)value));
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
@@ -1157,8 +1157,10 @@ static int ivf_work_table(IvfRun& r, WorkTable& wt) {
   // cell on average: a corpus with more cells than the batch has probes) and there are enough of them to fill the chip's
   // workgroup slots several times (the item-wise scan is built for throughput: a 256-query batch on 1000 cells took 0.187
   // instead of 0.155 ms with it); a dense batch does not pay the extra launch for its handful of thin cells
-  const int sparse_max = (r.scan_kernel == 5 && (size_t)n_items < 4 * (size_t)ix->C && n_items >= 16 * ix->n_cus)
-                             ? ix->tune.sparse_items : 0;
+  // (a negative option value forces the item-wise scan for cells of up to that many items whatever the batch: tests)
+  const int sparse_max = r.scan_kernel != 5 ? 0
+                         : ix->tune.sparse_items < 0 ? -ix->tune.sparse_items
+                         : ((size_t)n_items < 4 * (size_t)ix->C && n_items >= 16 * ix->n_cus) ? ix->tune.sparse_items : 0;
   wt.sp_cap = sparse_max > 0 ? (size_t)n_items * r.upi : 0;
   wt.sp_cell = base + 3 * wt.max_groups; wt.sp_first = wt.sp_cell + wt.sp_cap; wt.sp_chunk = wt.sp_first + wt.sp_cap;
   timed_launch(ix, s, "work_table", [&] {

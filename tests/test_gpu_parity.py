@@ -531,6 +531,67 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------
+# item-wise scan of thin cells (sparse5.h): the same brackets, regions and lists as the cell-grouped scan
+# ---------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [256, 1024])
+def test_sparse_item_scan_matches_oracle(gpu, oracle, K, monkeypatch):
+    """Option sparse_items < 0 forces the item-wise scan for every cell with at most that many items: all cells (-16: the
+    cell-grouped scan gets nothing), a mix (-2), none (0); every rule of counting found rows; multi-round searches."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, K=K, dup_rows=3)
+    for force in (-16, -2, 0):
+        idx.set_option("sparse_items", force)
+        for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 4, 1, 100.0), (5, 1, 2, 100.0), (32, 2, 0, 1000.0)):
+            gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+            exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} K={K} k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+@pytest.mark.gpu
+def test_sparse_item_scan_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
+    """As test_filter_refine_bracket_holds_for_every_row, every cell scanned item by item."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    for scale in (1.0, 1e-12, 8.0):
+        t, ot, idx, qs = _fr_setup(gpu, oracle, scale=scale)
+        idx.set_option("sparse_items", -16)
+        idx.set_option("fused_ablate", 8)
+        idx.set_option("merge_ablate", 32)
+        qs = qs[:48]
+        gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
+        exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"every row refined, item-wise scan, scale {scale}")
+        assert idx.bound_checked() > 20000, f"scale {scale}: {idx.bound_checked()} brackets checked"
+        assert idx.bound_violations() == 0
+        idx.close()
+
+
+@pytest.mark.gpu
+def test_sparse_item_scan_by_its_own_rule(gpu, oracle, monkeypatch):
+    """More cells than the batch has probes and enough probes to fill the chip: the library picks the item-wise scan for
+    the thin cells itself (default options); the lists equal the oracle's and those of the cell-grouped scan alone."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t = dict(util.ivf_tables(N=120000, C=3000, K=256))
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(120000, 1024)
+    exp = oracle.ivfadc_search_many(ot, qs, 5, 5, sentinel=1000.0, found_rule=0, n_threads=8)
+    idx.profile_enable(True)
+    gi, gd = idx.search(qs, 5, 5, sentinel=1000.0, found_rule=0)
+    prof = idx.profile_read()
+    idx.profile_enable(False)
+    util.assert_same_lists(gi, gd, exp, "thin cells by rule")
+    assert "sparse_items" in prof, f"the item-wise scan did not run: {sorted(prof)}"
+    idx.set_option("sparse_items", 0)
+    g2, d2 = idx.search(qs, 5, 5, sentinel=1000.0, found_rule=0)
+    assert np.array_equal(gi, g2) and np.array_equal(gd.view(np.uint32), d2.view(np.uint32))
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------
 # coarse-cell selection as filter + refine (coarse.h): MFMA distances with a proven bracket, the reference's
 # squareDistance for the candidate cells only
 # ---------------------------------------------------------------------------------------
