@@ -74,6 +74,7 @@ def parse(argv=None):
                     help="config ivfadc on one GPU also runs bounded passes of --config pq and --config join and reports them "
                          "under other_configs; this switches that off")
     ap.add_argument("--stream-skip", type=int, default=0, help="experiment: create this many unused streams first")
+    ap.add_argument("--scan-share", type=int, default=0, help="experiment: option scan_share of the timed region (0 = the batches in flight)")
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU (config ivfadc): consecutive steps alternate between this many HIP streams, "
                          "so the front end of batch i+1 runs beside the merge of batch i; 1 = strictly one batch at a time")
@@ -302,7 +303,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
 
     if True:
         # the *_dev contract: the caller states how many batches it keeps in flight (a scan takes n_cus / share CUs)
-        index.set_option("scan_share", n_fl)
+        index.set_option("scan_share", a.scan_share or n_fl)
         step = step_on(n_fl)
         dt, barrier = sharded_steps(step, pg, a.steps, a.warmup, lambda: torch.cuda.synchronize(dev), world)
         qps = world * q_local * a.steps / dt
@@ -332,7 +333,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         index.profile_enable(False)
         prof_ov = {}
         if n_fl > 1:   # ... and with the batches in flight as in the timed region: durations under overlap
-            index.set_option("scan_share", n_fl)
+            index.set_option("scan_share", a.scan_share or n_fl)
             index.profile_enable(True)
             for _ in range(a.steps):
                 step()
