@@ -37,3 +37,9 @@ timeout 1500 python3 bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --cpu
 cp gpurun_out/prof/${TAG}_latest_pmc_3M.json profiles/latest_pmc.json
 tail -2 gpurun_out/prof/${TAG}_bench_N40M.err
 ls -la gpurun_out/prof | tail -30
+# the driver's own invocation (20 steps), LDS counters of the scan, the reference's other index shape, small-batch latencies
+python3 bench.py --steps 20 --warmup 5 > gpurun_out/prof/${TAG}_bench_20steps.json 2> /dev/null
+bash tools/lds_pmc.sh > gpurun_out/prof/${TAG}_lds_counters.txt 2>&1
+python3 tools/other_shape.py > gpurun_out/prof/${TAG}_other_shape.json 2> /dev/null
+python3 tools/latency.py > gpurun_out/prof/${TAG}_latency.txt 2> /dev/null
+python3 tools/single_query.py > gpurun_out/prof/${TAG}_single_query.txt 2> /dev/null
