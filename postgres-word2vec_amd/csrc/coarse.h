@@ -54,15 +54,17 @@ static constexpr int COARSE_STREAM_MAX_CPAD = 16384;   // beyond 1024 cells the 
 //   cn2 [Cpad] = |c_j|^2 (fp64 sum rounded once, pin time), out [Q][Cpad], qn2 [Q] = |q|^2.
 // Also clears the round-one scratch (ZeroArgs), as coarse_tile_kernel does.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
-                                                           const float* __restrict__ cn2, float* __restrict__ out,
-                                                           float* __restrict__ qn2, int Q, int Cpad, int d, int dp, ZeroArgs z) {
+// (the body takes its block coordinates and its LDS from the caller: coarse_table5_kernel, fused5.h, runs it beside the
+// query x codebook table in one launch)
+__device__ __forceinline__ void coarse_approx_body(const float* __restrict__ queries, const float* __restrict__ coarseF,
+                                                   const float* __restrict__ cn2, float* __restrict__ out,
+                                                   float* __restrict__ qn2, int Q, int Cpad, int d, int dp, const ZeroArgs& z,
+                                                   int bx, int by, int gx, int gy, unsigned char* smem) {
   // (host guarantees: d % 4 == 0, dp % 64 == 0 -- whole blocks of UN = 8 iterations, zero padded on both sides,
   // so that the loops below carry no guards: guarded loads made hipcc emit a branch per element)
   typedef float f16v __attribute__((ext_vector_type(16)));
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   {
-    const int gtid = (blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x, gsz = gridDim.x * gridDim.y * 256;
+    const int gtid = (by * gx + bx) * 256 + threadIdx.x, gsz = gx * gy * 256;
 #pragma unroll
     for (int a = 0; a < 5; ++a)
       for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int q0w = 0;
-  const int q0 = blockIdx.y * TQ, c0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = by * TQ, c0 = bx * 128 + wave * 32;
   const int nit = dp >> 3;
   const float4* bp = reinterpret_cast<const float4*>(coarseF) + ((size_t)(c0 >> 5) * nit) * 64 + lane;
   constexpr int UN = 8;   // B operands in flight per wave
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
   nrm += __shfl_xor(nrm, 32, 64);
   if (h == 0) {
     rown[wave * 32 + r] = nrm;
-    if (wave == 0 && blockIdx.x == 0 && q0 + q0w + r < Q) qn2[q0 + q0w + r] = nrm;
+    if (wave == 0 && bx == 0 && q0 + q0w + r < Q) qn2[q0 + q0w + r] = nrm;
   }
   __syncthreads();
   const float cn = cn2[c0 + r];
@@ -151,6 +153,12 @@ __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restr
     const int i = 8 * (v >> 2) + 4 * h + (v & 3);
     if (q0 + q0w + i < Q) out[(size_t)(q0 + q0w + i) * Cpad + c0 + r] = __builtin_fmaf(-2.0f, acc[v], rown[wave * 32 + i] + cn);
   }
+}
+__global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
+                                                           const float* __restrict__ cn2, float* __restrict__ out,
+                                                           float* __restrict__ qn2, int Q, int Cpad, int d, int dp, ZeroArgs z) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  coarse_approx_body(queries, coarseF, cn2, out, qn2, Q, Cpad, d, dp, z, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -84,6 +84,7 @@ struct Tuning {
   int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
   int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
+  int fuse_table = 1;          // FREDDY_GPU_FUSE_TABLE: the MFMA cell-selection distances and the query x codebook table as ONE launch (heterogeneous workgroups)
   int sparse_items = 2;        // FREDDY_GPU_SPARSE_ITEMS: cells that at most this many queries of a batch probe are scanned item by item (sparse5.h) instead of as cell-grouped work entries (0 = never)
   int scan_quota_wgs = 0;      // FREDDY_GPU_SCAN_QUOTA_WGS: number of quota-limited workgroups in front of the persistent ones (0 = from the batch's size)
   int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
@@ -120,6 +121,7 @@ static Tuning read_tuning() {
   t.scan_quota = (int)env_int("FREDDY_GPU_SCAN_QUOTA", t.scan_quota);
   t.scan_quota_wgs = (int)env_int("FREDDY_GPU_SCAN_QUOTA_WGS", t.scan_quota_wgs);
   t.sparse_items = (int)env_int("FREDDY_GPU_SPARSE_ITEMS", t.sparse_items);
+  t.fuse_table = (int)env_int("FREDDY_GPU_FUSE_TABLE", t.fuse_table);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
@@ -906,6 +908,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
   else if (n == "scan_quota") t.scan_quota = (int)value;
   else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
+  else if (n == "fuse_table") t.fuse_table = (int)value;
   else if (n == "sparse_items") t.sparse_items = std::max(-16, std::min(16, (int)value));
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
@@ -1050,9 +1053,24 @@ static int ivf_coarse(IvfRun& r) {
   // would only delay it -- the kernel launched first gets the CUs -- so there it is forked AFTER the coarse
   // kernel and runs beside the latency-bound plan / work-table kernels; the all-exact coarse kernel is long
   // and VALU-bound like the table kernel, and the table beside it measured 2 % faster than after it.
+  r.qc_pending = false;
+  if (r.approx && r.fused && r.scan_kernel == 5 && ix->tune.fuse_table) {
+    // coarse tiles and table units as the workgroups of one launch (fused5.h coarse_table5_kernel)
+    CoarseTableArgs ct;
+    ct.queries = r.d_q; ct.coarseF = ix->coarseP; ct.cn2 = ix->cn2; ct.dist = ws->w_distT.as<float>(); ct.qn2 = ws->w_qn2.as<float>();
+    ct.Q = Q; ct.Cpad = Cpad; ct.d = d; ct.dp = ix->dp; ct.z = za; ct.coarse_gx = Cpad / 128; ct.coarse_gy = (Q + COARSE_TQ - 1) / COARSE_TQ;
+    ct.cbT = ix->cbT; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
+    ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K;
+    const size_t lds = std::max<size_t>((size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
+    const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
+    timed_launch(ix, s, "coarse_table", [&] {
+      hipLaunchKernelGGL((coarse_table5_kernel<25, 16>), dim3(grid), dim3(256), lds, s, ct);
+    });
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   const bool coarse_first = r.approx && !ix->tune.qc_first;
   if (coarse_first) if (int rc = launch_coarse()) return rc;
-  r.qc_pending = false;
   if (r.fused && r.scan_kernel >= 4) {
     if (!ws->stream2) {
       HIP_TRY(hipStreamCreateWithFlags(&ws->stream2, hipStreamNonBlocking));

@@ -40,6 +40,7 @@
 #include <stdint.h>
 
 #include "fused4.h"
+#include "coarse.h"
 
 namespace freddy {
 
@@ -82,16 +83,17 @@ __device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_
 // the same maximum in every workgroup); the workgroups of position 0 also write qn[q][p] = |q_p| (rounded up) and
 // scale[q] for the record and merge kernels.
 template <int S, int QT>
-__global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
-                                                             const float* __restrict__ cmax, float* __restrict__ qn,
-                                                             float* __restrict__ qscale, uint32_t* __restrict__ qc,
-                                                             int Q, int d, int m, int K) {
+__device__ __forceinline__ void query_codebook5_body(const float* __restrict__ queries, const float* __restrict__ cbT,
+                                                     const float* __restrict__ cmax, float* __restrict__ qn,
+                                                     float* __restrict__ qscale, uint32_t* __restrict__ qc,
+                                                     int Q, int d, int m, int K, int bx, int by, unsigned char* smem) {
   static_assert(QT == 16, "one 16-lane group per query");
   constexpr int SP = (S + 3) & ~3;
-  __shared__ __attribute__((aligned(16))) float qs[QT][SP];
-  __shared__ float inv_s[QT];
-  __shared__ __attribute__((aligned(16))) uint32_t ob[2][4][512];
-  const int tid = threadIdx.x, p = blockIdx.x, q0 = blockIdx.y * QT;
+  // LDS from the caller: ob [2][4][512] u32 (16 KB), qs [QT][SP] floats, inv_s [QT]
+  uint32_t (*ob)[4][512] = reinterpret_cast<uint32_t (*)[4][512]>(smem);
+  float (*qs)[SP] = reinterpret_cast<float (*)[SP]>(smem + 2 * 4 * 512 * 4);
+  float* inv_s = reinterpret_cast<float*>(smem + 2 * 4 * 512 * 4 + QT * SP * 4);
+  const int tid = threadIdx.x, p = bx, q0 = by * QT;
   for (int i = tid; i < QT * SP; i += 256) {
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
@@ -172,6 +174,42 @@ __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __res
       if (qi + w < nq)
         *reinterpret_cast<uint4*>(qc + ((size_t)(q0 + qi + w) * m + p) * 512 + 4 * e4) = *reinterpret_cast<const uint4*>(&ob[buf][w][4 * e4]);
     }
+  }
+}
+template <int S, int QT>
+static constexpr int query_codebook5_lds() { return 2 * 4 * 512 * 4 + QT * ((S + 3) & ~3) * 4 + QT * 4; }
+template <int S, int QT>
+__global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
+                                                             const float* __restrict__ cmax, float* __restrict__ qn,
+                                                             float* __restrict__ qscale, uint32_t* __restrict__ qc,
+                                                             int Q, int d, int m, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[query_codebook5_lds<S, QT>()];
+  query_codebook5_body<S, QT>(queries, cbT, cmax, qn, qscale, qc, Q, d, m, K, blockIdx.x, blockIdx.y, smem);
+}
+
+// The MFMA cell-selection distances (coarse.h) and the query x codebook table in ONE launch: the first `n_coarse`
+// workgroups are coarse tiles, the others table units (position, 16 queries).  Neither depends on the other and both are a
+// few tens of microseconds of small workgroups; as two kernels of a batch's chain they cost two launches, two
+// dependencies (with batches in flight the table kernel runs in line: a side stream per batch collides with the other
+// batches' streams in the hardware queues).  The workgroups keep their own shape and lifetime -- a version in which every
+// workgroup did both jobs was 40 % slower with batches in flight (big workgroups that live long keep the scans of the
+// other batches from finding CUs).
+struct CoarseTableArgs {
+  const float* queries;
+  const float* coarseF; const float* cn2; float* dist; float* qn2; int Q, Cpad, d, dp; ZeroArgs z; int coarse_gx, coarse_gy;
+  const float* cbT; const float* cmax; float* qn; float* qscale; uint32_t* qc; int m, K;
+};
+template <int S, int QT>
+__global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n_coarse = a.coarse_gx * a.coarse_gy;
+  const int b = blockIdx.x;
+  if (b < n_coarse) {
+    coarse_approx_body(a.queries, a.coarseF, a.cn2, a.dist, a.qn2, a.Q, a.Cpad, a.d, a.dp, a.z, b % a.coarse_gx, b / a.coarse_gx,
+                       a.coarse_gx, a.coarse_gy, smem);
+  } else {
+    const int t = b - n_coarse;
+    query_codebook5_body<S, QT>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, t % a.m, t / a.m, smem);
   }
 }
 
