@@ -524,7 +524,7 @@ static int raise_lds_limits(int device) {
       (const void*)&adc_scan_kernel<0, 2>, (const void*)&adc_scan_kernel<0, 4>, (const void*)&adc_scan_kernel<0, 8>,
       (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
       (const void*)&ivf_spec2_kernel<25, 12, false>, (const void*)&ivf_filter_kernel<12, true>,
-      (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true, false>,
+      (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true, false>, (const void*)&ivf_filter5_kernel<12, true, false, true>,
       (const void*)&ivf_filter5_kernel<12, false, false>, (const void*)&ivf_filter5_kernel<12, true, true>,
       (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
@@ -1277,7 +1277,8 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
       if (fl.cand_count) {
         if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
         else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      } else if (K == 1024 && fl.prof) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
       else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
     } else if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
     else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
@@ -1302,7 +1303,7 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     HIP_TRY(hipEventRecord(ws->ev_scan, ss));
     HIP_TRY(hipStreamWaitEvent(s, ws->ev_scan, 0));
   }
-  if (fl.prof) if (int rc = scan_prof_print(ix, ss, fl.prof, n_persist)) return rc;
+  if (fl.prof && (!v5 || (K == 1024 && !fl.cand_count))) if (int rc = scan_prof_print(ix, ss, fl.prof, n_persist)) return rc;   // (v5: the counters live in one instantiation)
 
   MergeRefineArgs mr;
   mr.surv = fl.surv; mr.surv_count = fl.surv_count; mr.active = r.active; mr.round_rows = pa.round_rows;

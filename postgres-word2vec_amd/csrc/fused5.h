@@ -252,7 +252,9 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
 // phases j = 0 .. M/2 - 1 cover positions 2j and 2j + 1.
 //   LDS: slab[2 buffers][2 positions][K][12] int16 = 96 KB, then colmin / thresholds / records / row terms.
 // ---------------------------------------------------------------------------------------
-template <int M, bool FULLK, bool CAND>
+// PROF: the per-phase cycle counters of option fused_prof (18 registers of a builder wave, 8 of a gatherer wave: an
+// instantiation of its own, the production kernel does not carry them)
+template <int M, bool FULLK, bool CAND, bool PROF = false>
 __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
   constexpr int NP = M / 2;             // phases per entry
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     };
 
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pc = 0;
-    auto tick = [&](int slot) { if (a.prof) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
-    if (a.prof) pc = clock64();
+    auto tick = [&](int slot) { if constexpr (PROF) { const long long t = clock64(); pt[slot] += t - pc; pc = t; } };
+    if constexpr (PROF) pc = clock64();
     int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 7) >> 3;   // halves in use
     const int g0 = half * 8;
     int qid[8], nqid[8];
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       stash_row_terms();   // (the gatherers took the current entry's into registers before their S1 barrier)
       lds_barrier();   // S2
       tick(3);
-      pt[7] += 1;
+      if constexpr (PROF) pt[7] += 1;
       if (!have_next) break;
       cur = nb;
       ++ei;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
 #pragma unroll
       for (int u = 0; u < 8; ++u) qid[u] = nqid[u];
     }
-    if (a.prof && tid == 0) {
+    if (PROF && a.prof && tid == 0) {
       for (int i = 0; i < 8; ++i) if (i != 2 && i != 4 && i != 5) a.prof[(size_t)blockIdx.x * 8 + i] = pt[i];   // (2, 4, 5: gatherer wave 0)
       a.prof[(size_t)blockIdx.x * 8 + 6] = wall_clock64();
     }
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     uint32_t cwa[RMAX], cwb[RMAX]; // code dwords of the even / odd phases (double buffered: requested a phase ahead)
     lds_barrier();   // (pairs with the builders' barrier after the first slab)
     long long gt[3] = {0, 0, 0}, gc = 0;
-    auto gtick = [&](int slot) { if (a.prof) { const long long t = clock64(); if (slot >= 0) gt[slot] += t - gc; gc = t; } };
+    auto gtick = [&](int slot) { if constexpr (PROF) { const long long t = clock64(); if (slot >= 0) gt[slot] += t - gc; gc = t; } };
     for (;;) {
       gtick(-1);
       const int32_t* rec = dsc + cur * REC_DW;
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       if (next_ok < 0) break;
       cur = nb;
     }
-    if (a.prof && gw == 0 && lane == 0) {
+    if (PROF && a.prof && gw == 0 && lane == 0) {
       a.prof[(size_t)blockIdx.x * 8 + 2] = gt[0];
       a.prof[(size_t)blockIdx.x * 8 + 4] = gt[1];
       a.prof[(size_t)blockIdx.x * 8 + 5] = gt[2];
