@@ -353,7 +353,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     out = None
     if rank == 0:
         # ---- the host-buffer ABI (what pg/freddy_srf.c calls: queries in host memory, lists into host memory, one
-        # synchronous call per batch; inside: pinned staging, sub-batches of 1024 on up to four lanes, transfers by copy
+        # synchronous call per batch; inside: pinned staging, sub-batches of up to 2048 on up to four lanes, transfers by copy
         # kernels overlapped with the neighbours' kernels): first-class numbers at three batch sizes, never `value`.
         # Measured in a CHILD process that owns nothing but the library's streams -- what a PostgreSQL backend is.  In THIS
         # process the four torch streams of the timed region were created first, and the runtime then puts the library's
@@ -514,7 +514,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             "timed_region_parity": timed_parity,
             "host_buffer_abi": dict(host_abi, queries_per_s=host_qps, same_results_as_device_path=host_same,
                                     note="freddy_gpu_ivfadc_search, the call the PostgreSQL hosts make (pageable host buffers in and "
-                                         "out, synchronous): sub-batches of 1024 queries on up to four library-owned lanes with pinned "
+                                         "out, synchronous): sub-batches of up to 2048 queries on up to four library-owned lanes with pinned "
                                          "staging, H2D / D2H overlapped with the neighbours' kernels, extra probing rounds where the "
                                          "host waits for a lane; queries_per_s = the 1024-query call"),
             "roofline": roof, "kernels": kern,

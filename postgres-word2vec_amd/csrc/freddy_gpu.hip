@@ -81,7 +81,7 @@ struct Tuning {
   int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches the CALLER keeps in flight on this handle through the *_dev entry points
                                // (one stream each): a persistent scan takes n_cus / share CUs so that the scans run side by side (DESIGN.md
                                // 5.2c).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
-  int pipeline_batch = 1024;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
+  int pipeline_batch = 2048;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
   int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
   int fuse_table = 1;          // FREDDY_GPU_FUSE_TABLE: the MFMA cell-selection distances and the query x codebook table as ONE launch (heterogeneous workgroups)
