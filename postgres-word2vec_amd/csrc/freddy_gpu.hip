@@ -982,8 +982,9 @@ static int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a)
   return 0;
 }
 
+// coarse != NULL: `vecs` are the queries and the kernel forms the residual q - coarse[cell] itself (no residual_kernel launch)
 static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int32_t* item_cell,
-                      float* lut, int n_items) {
+                      float* lut, int n_items, const float* coarse = nullptr, const int32_t* item_query = nullptr) {
   if (n_items <= 0) return 0;
   // enough workgroups to fill 256 CUs several times over, while amortising the register
   // fill of the codebook slice over as many items as possible
@@ -992,10 +993,10 @@ static int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, co
   dim3 grid((unsigned)ix->m, (unsigned)((n_items + ipw - 1) / ipw));
   const int m = ix->m, K = ix->K, d = ix->d, S = ix->S;
   timed_launch(ix, s, "lut_build", [&] {
-    if (S == 25) hipLaunchKernelGGL((lut_build_kernel<25, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d);
-    else if (S == 10) hipLaunchKernelGGL((lut_build_kernel<10, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d);
-    else if (S == 20) hipLaunchKernelGGL((lut_build_kernel<20, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d);
-    else hipLaunchKernelGGL(lut_build_generic_kernel, grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d, S);
+    if (S == 25) hipLaunchKernelGGL((lut_build_kernel<25, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d, coarse, item_query);
+    else if (S == 10) hipLaunchKernelGGL((lut_build_kernel<10, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d, coarse, item_query);
+    else if (S == 20) hipLaunchKernelGGL((lut_build_kernel<20, 4>), grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d, coarse, item_query);
+    else hipLaunchKernelGGL(lut_build_generic_kernel, grid, dim3(WG), 0, s, vecs, item_cell, ix->cbT, lut, n_items, ipw, m, K, d, S, coarse, item_query);
   });
   HIP_TRY(hipGetLastError());
   return 0;
@@ -1389,7 +1390,7 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
 // chunks then (one query over 10 lists of 3 000 rows: 30 instead of 10 workgroups)
 static int generic_chunk_blocks(int n_items) { return n_items <= 64 ? 32 : 256; }
 
-// Generic path (small batches, other m / S / K, k > 32): residual -> lut_build -> adc_scan -> merge_replay;
+// Generic path (small batches, other m / S / K, k > 32): lut_build (residual inline) -> adc_scan -> merge_replay;
 // the LUTs round-trip through memory.
 static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   Workspace* ws = r.ws;
@@ -1398,12 +1399,8 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   const int n_items = r.n_active * r.W;
   const int chunk_blocks = generic_chunk_blocks(n_items);
   const int nchunk = std::max(1, (ix->max_list_blocks + chunk_blocks - 1) / chunk_blocks);
-  timed_launch(ix, s, "residual", [&] {
-    hipLaunchKernelGGL(residual_kernel, dim3(n_items), dim3(WG), 0, s, r.d_q, ix->coarse, pa.item_cell, pa.item_query,
-                       ws->w_resid.as<float>(), ix->d, ix->S, ix->S);
-  });
-  HIP_TRY(hipGetLastError());
-  if (int rc = launch_lut(ix, s, ws->w_resid.as<float>(), pa.item_cell, ws->w_lut.as<float>(), n_items)) return rc;
+  // (the residual r = q - coarse[cell] is formed by the LUT kernel: one launch less in a single query's chain)
+  if (int rc = launch_lut(ix, s, r.d_q, pa.item_cell, ws->w_lut.as<float>(), n_items, ix->coarse, pa.item_query)) return rc;
   ScanArgs sa;
   sa.lut = ws->w_lut.as<float>(); sa.item_list = pa.item_cell; sa.item_query = pa.item_query;
   sa.blk_off = ix->blk_off; sa.packed = ix->packed; sa.pos = ix->pos; sa.part = ws->w_part.as<u64>();

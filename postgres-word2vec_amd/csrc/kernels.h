@@ -443,7 +443,9 @@ __global__ __launch_bounds__(WG) void lut_build_kernel(const float* __restrict__
                                                       const int32_t* __restrict__ item_cell,  // NULL: every item valid
                                                       const float* __restrict__ cbT,
                                                       float* __restrict__ lut, int n_items,
-                                                      int items_per_wg, int m, int K, int d) {
+                                                      int items_per_wg, int m, int K, int d,
+                                                      const float* __restrict__ coarse = nullptr,       // non-NULL: vecs are QUERIES and the
+                                                      const int32_t* __restrict__ item_query = nullptr) { // residual q - coarse[cell] (freddy.c:296-303) is formed here
   const int p = blockIdx.x;
   const int it0 = blockIdx.y * items_per_wg;
   const int it1 = (it0 + items_per_wg < n_items) ? it0 + items_per_wg : n_items;
@@ -458,13 +460,14 @@ __global__ __launch_bounds__(WG) void lut_build_kernel(const float* __restrict__
     }
     for (int it = it0; it < it1; ++it) {
       if (item_cell && item_cell[it] < 0) continue;
-      const float* r = vecs + (size_t)it * d + (size_t)p * S;
+      const float* r = vecs + (size_t)(coarse && item_query ? item_query[it] : it) * d + (size_t)p * S;
+      const float* co = coarse ? coarse + (size_t)item_cell[it] * d + (size_t)p * S : nullptr;
       float acc[E];
 #pragma unroll
       for (int e = 0; e < E; ++e) acc[e] = 0.0f;
 #pragma unroll
       for (int j = 0; j < S; ++j) {
-        const float rj = r[j];
+        const float rj = co ? r[j] - co[j] : r[j];   // (the residual_kernel's value: one binary32 subtraction)
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const float t = rj - cb[e][j];
@@ -641,18 +644,21 @@ __global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __re
                                                               const float* __restrict__ cbT,
                                                               float* __restrict__ lut, int n_items,
                                                               int items_per_wg, int m, int K, int d,
-                                                              int S) {
+                                                              int S, const float* __restrict__ coarse = nullptr,
+                                                              const int32_t* __restrict__ item_query = nullptr) {
   const int p = blockIdx.x;
   const int it0 = blockIdx.y * items_per_wg;
   const int it1 = (it0 + items_per_wg < n_items) ? it0 + items_per_wg : n_items;
   const size_t lutN = (size_t)m * K;
   for (int it = it0; it < it1; ++it) {
     if (item_cell && item_cell[it] < 0) continue;
-    const float* r = vecs + (size_t)it * d + (size_t)p * S;
+    const float* r = vecs + (size_t)(coarse && item_query ? item_query[it] : it) * d + (size_t)p * S;
+    const float* co = coarse ? coarse + (size_t)item_cell[it] * d + (size_t)p * S : nullptr;
     for (int c = threadIdx.x; c < K; c += WG) {
       float acc = 0.0f;
       for (int j = 0; j < S; ++j) {
-        const float t = r[j] - cbT[((size_t)p * S + j) * K + c];
+        const float rj = co ? r[j] - co[j] : r[j];
+        const float t = rj - cbT[((size_t)p * S + j) * K + c];
         const float pr = t * t;
         acc = acc + pr;
       }
