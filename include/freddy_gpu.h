@@ -297,6 +297,8 @@ int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
  * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (5 filter +
  * refine with int16 slabs, 4 the same with fp32 slabs, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
  * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "scan_share" (the batches the caller keeps in flight through the *_dev entry points, one stream each: a persistent scan takes n_cus / scan_share CUs; default 1 = the whole chip), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls: queries per sub-batch, 2048; sub-batches in flight, 1..4), "pq_fused" (batches over the flat PQ table through the cell-grouped filter + refine scan over pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "merge_waves" (waves per query in the merge: 4, 1, or 0 = four for one batch at a time, one with batches in flight), "partition_cus" (R > 0: a batch's small kernels on a stream masked to R CUs, its scan on a stream masked to the rest; R < 0: only the scan masked; 0 = off, the default -- measured slower), "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
+ * "fuse_table" (1, the default: the cell-selection distances and the query x codebook table of a batch are the workgroups of
+ * one launch; 0: two kernels),
  * "sparse_items" (cells that at most this many queries of a batch probe are scanned item by item instead of as cell-grouped
  * work entries -- used where such cells are the rule: fewer than four (query, probe) items per cell and at least 16 per CU;
  * default 2, 0 = never, a negative value forces it for cells of up to that many items whatever the batch),

@@ -591,6 +591,32 @@ def test_sparse_item_scan_by_its_own_rule(gpu, oracle, monkeypatch):
     idx.close()
 
 
+@pytest.mark.gpu
+def test_combined_coarse_table_launch_matches_separate_kernels(gpu, oracle, monkeypatch):
+    """coarse_table5_kernel (cell-selection tiles and query-table units as the workgroups of one launch) against the two
+    kernels launched separately (option fuse_table = 0): the same lists, bit for bit, and the oracle's; batch sizes that
+    leave partial tiles / query groups."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, K=1024)
+    for Q in (120, 33, 17):
+        q = qs[:Q]
+        exp = oracle.ivfadc_search_many(ot, q, 5, 3, sentinel=1000.0, found_rule=0)
+        res = []
+        for fuse in (1, 0):
+            idx.set_option("fuse_table", fuse)
+            idx.profile_enable(True)
+            gi, gd = idx.search(q, 5, 3, sentinel=1000.0, found_rule=0)
+            prof = idx.profile_read()
+            idx.profile_enable(False)
+            if Q >= 32:   # (below 32 queries the cell-selection distances are exact and a kernel of their own either way)
+                assert ("coarse_table" in prof) == bool(fuse), sorted(prof)
+            util.assert_same_lists(gi, gd, exp, f"fuse_table {fuse} Q={Q}")
+            res.append((gi, gd))
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
 # ---------------------------------------------------------------------------------------
 # coarse-cell selection as filter + refine (coarse.h): MFMA distances with a proven bracket, the reference's
 # squareDistance for the candidate cells only

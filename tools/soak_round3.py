@@ -3,7 +3,8 @@
     tiny cells that force extra probing rounds, pinned and pageable query buffers, single queries, replicated handles);
   * the kNN-join with the traversal on the device (random multi-index sizes incl. duplicate centroids, targets, k, alpha,
     pvf, methods, confidences, target lists on / off; every call also with the host heap);
-  * single-query pq_search through the pinned direct I/O.
+  * single-query pq_search through the pinned direct I/O;
+  * the item-wise scan of thin cells forced on / off, the combined coarse + table launch on / off.
 usage: python tools/soak_round3.py [seeds]"""
 import os, sys, time
 import numpy as np
@@ -33,6 +34,8 @@ for seed in range(seeds):
     qs = x.numpy()[rng.integers(0, N, size=Q)].astype(np.float32) * np.float32(rng.choice([1.0, 1.0, 1.03]))
     idx.set_option("pipeline_batch", int(rng.choice([16, 100, 256, 1024])))
     idx.set_option("pipeline_lanes", int(rng.choice([1, 2, 4])))
+    idx.set_option("sparse_items", int(rng.choice([2, 0, -1, -3, -16])))   # (negative: the item-wise scan forced for cells of up to that many items)
+    idx.set_option("fuse_table", int(rng.integers(0, 2)))
     for (W, k, rule, sent) in [(int(rng.choice([1, 2, 5])), int(rng.choice([1, 5, 20])), 0, 1000.0), (1, 5, 2, 100.0), (3, 10, 1, 100.0)]:
         W = min(W, C)
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule, n_threads=8)
