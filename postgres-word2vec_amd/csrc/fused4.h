@@ -732,7 +732,7 @@ struct MergeRefineArgs {
   uint32_t ablate;   // timing experiments only (FREDDY_GPU_MERGE_ABLATE): 1 = skip the exact stage
 };
 
-// MANY = true (with NWV = 4): the instantiation for queries with hundreds of survivor regions (a batch over the flat PQ
+// MANY = true (with NWV = 12): the instantiation for queries with hundreds of survivor regions (a batch over the flat PQ
 // table: 245 pseudo-lists x 8 waves) -- the selection of the lower bounds split over the four waves, dense neighbourhoods
 // collected by all of them.  It needs 145 registers (three workgroups per CU); the IVFADC instantiation stays at 128.
 template <int S, int M, int NWV, bool MANY = false>
@@ -744,7 +744,8 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   // NWV = 1: one wave per query does everything, tile after tile -- a quarter of the wave slots and 12 instead of
   // 30 KB of LDS per query: with several batches in flight, when this kernel has to fit into the CUs the scans of the
   // other batches leave, the smaller footprint is worth more than the latency.
-  constexpr int NT = 4;                     // tiles of 64 chains refined together
+  constexpr int NT = NWV > 4 ? NWV : 4;     // tiles of 64 chains refined together (one per wave in the multi-wave rounds)
+  static_assert(NT * 64 / M <= 64, "a round's rows are finalised by one wave");
   constexpr int NC = NT * 64 / M;           // = 21 candidates
   constexpr int SQ = S + 1;                 // row pitch of the squared differences
   constexpr int M2 = M / 2;
