@@ -1337,8 +1337,10 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     const bool many_regions = (size_t)r.W * r.upi * FUSED_NW > 256;
     if (!many_regions && (r.share > 1 ? ix->tune.merge_waves != 4 : ix->tune.merge_waves == 1))
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 1>), dim3(r.n_active), dim3(64), 0, s, mr);
-    else if (many_regions)
-      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 12, true>), dim3(r.n_active), dim3(768), 0, s, mr);   // (twelve waves: 64 rows per round of the exact stage)
+    else if (many_regions && r.n_active <= 256)   // (a few queries with many qualifying rows each: twelve waves, 64 rows per round of the exact stage)
+      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 12, true>), dim3(r.n_active), dim3(768), 0, s, mr);
+    else if (many_regions)                         // (a large batch: the workgroups' footprint decides, 95 against 52 us at 1024 queries)
+      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 4, true>), dim3(r.n_active), dim3(256), 0, s, mr);
     else
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 4>), dim3(r.n_active), dim3(256), 0, s, mr);
   });
