@@ -36,6 +36,9 @@ import time
 # own streams and RCCL take; measured (tools/sweep_queues.sh): 4 queues / 3 batches 7.5 M q/s,
 # 6 queues / 4 batches 7.9 M, 8 queues 6.3-6.8 M (queues start sharing the four pipes of the command processor).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+# the CPU oracle's OpenMP workers (cpu_baseline: one per core) go to sleep after their parallel region instead of spinning on the
+# cores the host side of the measurements that follow needs (the kNN-join pass right after it read 1.5 instead of 1.1 ms)
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
 import numpy as np
 import torch
