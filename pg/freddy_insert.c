@@ -54,7 +54,10 @@ StaticAssertDecl(sizeof(FreddyCbEntry) == sizeof(CodebookEntryComplete) && offse
 static void update_codebook_known_codes(int rawVectorsSize, int subvectorSize, CodebookWithCounts cb, int cbPositions, int cbCodes,
                                         const int16 *codes, int **nearestCentroids, int *countIncs)
 {
-    freddy_update_codebook_known_codes(rawVectorsSize, subvectorSize, (FreddyCbEntry *) cb, cbPositions, cbCodes, codes, nearestCentroids, countIncs);
+    /* the row writer (updateProductQuantizationRelation) takes one int pointer per row: rows of one flat array */
+    int *row_codes = palloc(sizeof(int) * (size_t) Max(rawVectorsSize, 1) * cbPositions);
+    freddy_update_codebook_known_codes(rawVectorsSize, subvectorSize, (FreddyCbEntry *) cb, cbPositions, cbCodes, codes, row_codes, countIncs);
+    for (int i = 0; i < rawVectorsSize; i++) nearestCentroids[i] = row_codes + (size_t) i * cbPositions;
 }
 
 PG_FUNCTION_INFO_V1(insert_batch);

@@ -4,6 +4,8 @@
  * driver that tests/test_pg_pure.py compiles with gcc in this repository's image (with malloc) -- the PostgreSQL side
  * itself (SPI, varlena / array macros, fmgr) cannot be compiled here, this can.
  *
+ *   freddy_catch_up_rows_ok, freddy_pin_survives_abort   transaction safety of a handle that was brought up to date
+ *                            inside a transaction that may still roll back            
  *   freddy_compare_stamp     what a changed table means for a pinned handle: nothing / append rows / reload the codebook /
  *                            pin again                                                     
  *   freddy_payload_f32/_i16  a bytea's payload (what VARDATA_ANY / VARSIZE_ANY_EXHDR give) -> typed array, with the
@@ -19,6 +21,9 @@
 
 #ifndef FREDDY_ALLOC
 #define FREDDY_ALLOC palloc
+#endif
+#ifndef FREDDY_FREE
+#define FREDDY_FREE pfree
 #endif
 
 /* ---- staleness ----------------------------------------------------------------------------------------- */
@@ -52,6 +57,10 @@ static inline FreddyPinState freddy_compare_stamp(const FreddyStamp *old, const 
         if ((old->appends[i] < 0) != (now->appends[i] < 0)) return FREDDY_PIN_STALE;                       /* the watch script came or went */
         if (now->appends[i] >= 0) {
             const int ins = now->appends[i] != old->appends[i], rew = now->rewrites[i] != old->rewrites[i];
+            /* a counter that went BACKWARDS: the statements the handle was brought up to date with were rolled back
+             * (insert_batch refreshes the handles inside its own transaction) -- the pinned copy holds rows no snapshot
+             * will ever see, and ids it has seen will be handed out again */
+            if (now->appends[i] < old->appends[i] || now->rewrites[i] < old->rewrites[i]) return FREDDY_PIN_STALE;
             if (i == 0) { if (rew) return FREDDY_PIN_STALE; if (ins) *appended = 1; }
             else if (i == 1) { if (ins) return FREDDY_PIN_STALE; if (rew) *codebook = 1; }
             else if (rew || (ins && !((ignore_inserts_mask >> i) & 1u))) return FREDDY_PIN_STALE;           /* coarse quantizer, vectors, statistics */
@@ -66,6 +75,35 @@ static inline FreddyPinState freddy_compare_stamp(const FreddyStamp *old, const 
         if (row_max_id_now < old->max_id) return FREDDY_PIN_STALE;
     }
     return (*appended || *codebook) ? FREDDY_PIN_CATCH_UP : FREDDY_PIN_CURRENT;
+}
+
+/* The catch-up fetch "id > max_id ORDER BY id" after an append was flagged: what it returned must be the continuation of
+ * what is pinned.  insert_batch numbers its rows max(id) + 1, + 2, ... (freddy.c:1521-1545), so the first fetched id is
+ * max_id + 1 and the ids are consecutive; anything else -- no row at all although the append counter moved (the rows
+ * were rolled back, or committed below ids this handle already holds from an aborted transaction), a gap, a row that
+ * committed out of id order in another backend -- cannot be repaired by appending: pin again.  1 = append, 0 = stale. */
+static inline int freddy_catch_up_rows_ok(int32_t pinned_max_id, int64_t n_fetched, const int32_t *fetched_ids)
+{
+    if (n_fetched <= 0) return 0;
+    for (int64_t i = 0; i < n_fetched; i++)
+        if ((int64_t) fetched_ids[i] != (int64_t) pinned_max_id + 1 + i) return 0;
+    return 1;
+}
+
+/* Handles that were changed inside a transaction (rows appended, codebook reloaded, freshly pinned from uncommitted
+ * tables) carry that transaction's nesting level; when a (sub)transaction of that level or deeper aborts, the handle
+ * must go (PostgreSQL: RegisterXactCallback / RegisterSubXactCallback).  0 = never touched inside an open transaction.
+ * freddy_pin_survives_abort: 1 if a handle last mutated at `mutated_level` survives the abort of a (sub)transaction at
+ * `aborted_level` (1 = the top-level transaction). */
+static inline int freddy_pin_survives_abort(int mutated_level, int aborted_level)
+{
+    return mutated_level == 0 || mutated_level < aborted_level;
+}
+/* after a commit of (sub)transaction `level` its changes belong to the parent: the new level of a mark */
+static inline int freddy_pin_level_after_commit(int mutated_level, int committed_level)
+{
+    if (mutated_level < committed_level) return mutated_level;
+    return committed_level <= 1 ? 0 : committed_level - 1;
 }
 
 /* ---- bytea payloads ------------------------------------------------------------------------------------- */
@@ -90,44 +128,50 @@ static inline int freddy_payload_i16(const void *data, size_t bytes, int expect,
     return n;
 }
 
-/* ---- insert_batch: updateCodebook after the 1-NN search ---------------------------------------------------- */
-/* layout of the reference's CodebookEntryComplete (index_utils.h:58-63) */
+/* ---- insert_batch: the codebook bookkeeping that follows the device's 1-NN search ------------------------------- */
+/* One codebook entry as the hosts hold it (same layout as the reference's CodebookEntryComplete, index_utils.h:58-63,
+ * so pg/freddy_insert.c can hand the reference's own array over). */
 typedef struct FreddyCbEntry { int pos; int code; float *vector; int count; } FreddyCbEntry;
 
-/* updateCodebook (index_utils.c:908-957) for codes found on the device: nearestCentroids[i][pos] = codes[i*m + pos];
- * everything after the 1-NN search is the reference's statement sequence, slips included:
- *   - ONE nearestCentroidRaw across positions: after the reference's scan over the table (position-major in every table
- *     the index scripts write) it is the nearest entry of the LAST position (:931-938) -- that vector is what every
- *     position of the row adds to its bucket (:944-946);
- *   - the recalculation reads bucket [pos + code] (:954), adds (1.0 / count) * bucket in double (:953-955).
- * cb: cbPositions * cbCodes entries in table order, updated in place (vector, count); countIncs [cbPositions*cbCodes]. */
-static inline void freddy_update_codebook_known_codes(int rawVectorsSize, int subvectorSize, FreddyCbEntry *cb, int cbPositions, int cbCodes,
-                                                      const int16_t *codes, int **nearestCentroids, int *countIncs)
+/* What updateCodebook (index_utils.c:940-956) leaves behind, given the codes the device found (codes[r*m + p] = code of
+ * new row r at position p).  Flat working arrays, three passes:
+ *   1. slot (p, c) = p*K + c.  Every new row adds ONE vector to the bucket of each of its m slots and bumps the slot's
+ *      increment.  Documented behaviour of the reference kept on purpose (the rows written must equal its rows): the
+ *      vector added is the same for all positions of a row -- the entry of the row's code at the LAST position (its
+ *      1-NN loop keeps a single pointer across positions, and the tables are position-major).
+ *   2. an entry's count grows by its slot's increment.
+ *   3. an entry's vector moves by bucket[pos + code] / count, the quotient formed as (1.0 / count) in double -- the
+ *      bucket index is the SUM pos + code, not the slot (documented behaviour, kept).
+ * entries: m*K of them in any table order, updated in place; incs[m*K] by slot (out); row_codes[n*m] (out): the codes
+ * widened to int, row-major (what the reference's row writer takes, one pointer per row). */
+static inline void freddy_update_codebook_known_codes(int n, int s, FreddyCbEntry *entries, int m, int K,
+                                                      const int16_t *codes, int *row_codes, int *incs)
 {
-    const int E = cbPositions * cbCodes;
-    float **differences = (float **) FREDDY_ALLOC(sizeof(float *) * (size_t) E);
-    float **entry_of = (float **) FREDDY_ALLOC(sizeof(float *) * (size_t) E);   /* (pos, code) -> the entry's vector */
-    for (int i = 0; i < E; i++) {
-        differences[i] = (float *) FREDDY_ALLOC(sizeof(float) * (size_t) subvectorSize);
-        for (int j = 0; j < subvectorSize; j++) differences[i][j] = 0;
-        countIncs[i] = 0;
-        entry_of[cb[i].pos * cbCodes + cb[i].code] = cb[i].vector;
-    }
-    for (int i = 0; i < rawVectorsSize; i++) {
-        float *nearestCentroidRaw = entry_of[(cbPositions - 1) * cbCodes + codes[(size_t) i * cbPositions + cbPositions - 1]];
-        nearestCentroids[i] = (int *) FREDDY_ALLOC(sizeof(int) * (size_t) cbPositions);
-        for (int j = 0; j < cbPositions; j++) nearestCentroids[i][j] = codes[(size_t) i * cbPositions + j];
-        for (int j = 0; j < cbPositions; j++) {
-            const int code = nearestCentroids[i][j];
-            countIncs[j * cbCodes + code] += 1;
-            for (int k = 0; k < subvectorSize; k++) differences[j * cbCodes + code][k] += nearestCentroidRaw[k];
+    const size_t slots = (size_t) m * (size_t) K;
+    float *bucket = (float *) FREDDY_ALLOC(sizeof(float) * slots * (size_t) s);
+    const float **vec_of_slot = (const float **) FREDDY_ALLOC(sizeof(float *) * slots);
+    memset(bucket, 0, sizeof(float) * slots * (size_t) s);
+    memset(incs, 0, sizeof(int) * slots);
+    for (size_t e = 0; e < slots; e++) vec_of_slot[(size_t) entries[e].pos * K + entries[e].code] = entries[e].vector;
+    for (int r = 0; r < n; r++) {
+        const int16_t *rc = codes + (size_t) r * m;
+        const float *added = vec_of_slot[(size_t) (m - 1) * K + rc[m - 1]];
+        for (int p = 0; p < m; p++) {
+            const size_t slot = (size_t) p * K + rc[p];
+            float *b = bucket + slot * (size_t) s;
+            row_codes[(size_t) r * m + p] = rc[p];
+            incs[slot] += 1;
+            for (int t = 0; t < s; t++) b[t] += added[t];
         }
     }
-    for (int i = 0; i < E; i++) {   /* recalculate codebook (index_utils.c:949-956) */
-        cb[i].count += countIncs[cb[i].pos * cbCodes + cb[i].code];
-        for (int j = 0; j < subvectorSize; j++)
-            cb[i].vector[j] += (1.0 / cb[i].count) * differences[cb[i].pos + cb[i].code][j];
+    for (size_t e = 0; e < slots; e++) {
+        FreddyCbEntry *en = &entries[e];
+        const float *b = bucket + (size_t) (en->pos + en->code) * (size_t) s;
+        en->count += incs[(size_t) en->pos * K + en->code];
+        for (int t = 0; t < s; t++) en->vector[t] += (1.0 / en->count) * b[t];
     }
+    FREDDY_FREE(bucket);
+    FREDDY_FREE((void *) vec_of_slot);
 }
 
 #endif /* FREDDY_PURE_H */

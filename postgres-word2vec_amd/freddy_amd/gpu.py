@@ -305,6 +305,22 @@ class IVFIndex(_Index):
                                                      C.c_void_p(d_out_ids_ptr), C.c_void_p(d_out_dist_ptr),
                                                      C.c_void_p(d_status_ptr or 0), C.c_void_p(stream or 0)))
 
+    def bind_search_dev(self, d_queries_ptr, Q, k, W, sentinel, found_rule, d_out_ids_ptr, d_out_dist_ptr,
+                        d_status_ptr=0, stream=None):
+        """search_dev with every argument converted ONCE: returns a zero-argument callable that makes the C call and
+        raises on a non-zero status.  (A loop that enqueues the same batch again and again -- bench.py -- spent a
+        quarter of its host time per step converting the eleven arguments.)"""
+        fn = self.lib.freddy_gpu_ivfadc_search_dev
+        args = (self.h, C.c_void_p(d_queries_ptr), C.c_int32(Q), C.c_int32(k), C.c_int32(W), C.c_float(sentinel),
+                C.c_int32(found_rule), C.c_void_p(d_out_ids_ptr), C.c_void_p(d_out_dist_ptr),
+                C.c_void_p(d_status_ptr or 0), C.c_void_p(stream or 0))
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                _check(rc)
+        return call
+
     def last_scanned_rows(self):
         return int(self.lib.freddy_gpu_last_scanned_rows(self.h))
 

@@ -86,6 +86,43 @@ def test_staleness_decisions_without_the_watch_triggers(drv):
     assert compare(drv, old, mk(3, watched=False, filenode_0=9), row_max=100)[0] == STALE
 
 
+def test_rolled_back_insert_batch_makes_the_handle_stale(drv):
+    """insert_batch refreshes the pinned handles INSIDE its transaction (appended rows, max_id and the stamp
+    advance).  After ROLLBACK the generation counters are lower than the stamp: that must read as STALE, never as an
+    append -- the catch-up fetch `id > max_id` would find nothing, the phantom rows would stay pinned and the ids they
+    hold would be handed out again by the next insert_batch."""
+    before = mk(3)                                   # appends 5, rewrites 7, max_id 100
+    inside = mk(3, appends_0=6, rewrites_1=8)        # what the handle was brought up to date with inside the transaction
+    inside.max_id = 103
+    assert compare(drv, before, inside) == (CATCH_UP, 1, 1)
+    after_rollback = mk(3)                           # the counters are back where they were
+    assert compare(drv, inside, after_rollback)[0] == STALE
+    assert compare(drv, inside, mk(3, appends_0=6, rewrites_1=7))[0] == STALE      # only the codebook UPDATEs rolled back (savepoint)
+    assert compare(drv, inside, mk(3, appends_0=5, rewrites_1=8))[0] == STALE      # only the INSERTs rolled back
+    # a later committed insert_batch reuses ids 101.. : the append counter is equal again -- the catch-up fetch decides
+    ids = np.array([101, 102, 103], np.int32)
+    ok = lambda mx, a: drv.drv_catch_up_ok(mx, C.c_longlong(len(a)), a.ctypes.data_as(C.c_void_p))
+    assert ok(100, ids) == 1                                                        # the continuation of what is pinned
+    assert ok(103, np.zeros(0, np.int32)) == 0                                      # append flagged, nothing above max_id: phantom rows
+    assert ok(100, np.array([102, 103], np.int32)) == 0                             # a gap: a row committed out of id order elsewhere
+    assert ok(100, np.array([101, 103], np.int32)) == 0
+    assert ok(2**31 - 2, np.array([2**31 - 1], np.int32)) == 1                      # no overflow at the top of int32
+
+
+def test_handles_mutated_in_an_aborted_transaction_are_dropped(drv):
+    # level 0 = not touched inside an open transaction; 1 = top level; 2.. = savepoints
+    assert drv.drv_survives_abort(0, 1) == 1
+    assert drv.drv_survives_abort(1, 1) == 0         # ROLLBACK of the transaction that appended
+    assert drv.drv_survives_abort(2, 1) == 0
+    assert drv.drv_survives_abort(1, 2) == 1         # ROLLBACK TO SAVEPOINT: the append happened outside it
+    assert drv.drv_survives_abort(2, 2) == 0
+    assert drv.drv_survives_abort(3, 2) == 0
+    assert drv.drv_level_after_commit(2, 2) == 1     # RELEASE SAVEPOINT: the change now belongs to the parent
+    assert drv.drv_level_after_commit(1, 2) == 1
+    assert drv.drv_level_after_commit(1, 1) == 0     # COMMIT: durable
+    assert drv.drv_level_after_commit(3, 2) == 1
+
+
 def test_bytea_payload_codecs(drv):
     v = np.arange(300, dtype=np.float32) * np.float32(0.25)
     out = np.zeros(300, np.float32)
