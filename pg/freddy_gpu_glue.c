@@ -28,6 +28,7 @@
 
 #include "index_utils.h"
 
+#include "access/xact.h"   /* RegisterXactCallback, GetCurrentTransactionNestLevel */
 #include "freddy_pure.h"   /* FreddyStamp, freddy_compare_stamp, payload codecs: the PostgreSQL-free parts (compiled and tested in this repository) */
 
 #define MAX_TABS FREDDY_MAX_TABS
@@ -35,6 +36,7 @@
 typedef struct FreddyPin {
     freddy_gpu_index_t *h;
     FreddyStamp         st;
+    int                 mut_level;   /* nesting level of the open (sub)transaction that last changed the pinned copy; 0 = none (freddy_pure.h) */
 } FreddyPin;
 
 static FreddyPin pin_pq, pin_ivf, pin_ivpq;
@@ -55,6 +57,34 @@ static void drop_pin(FreddyPin *p)
 {
     if (p->h) { freddy_gpu_unpin(p->h); p->h = NULL; }
     memset(&p->st, 0, sizeof p->st);
+    p->mut_level = 0;
+}
+
+/* A handle that was pinned / appended to / given a new codebook inside a transaction holds what that transaction saw.
+ * If the (sub)transaction aborts, those rows never existed: the handle goes (the next search pins again); on commit the
+ * change belongs to the parent level.  Decisions: freddy_pure.h (tested in tests/test_pg_pure.py). */
+static void mark_mutated(FreddyPin *p) { p->mut_level = GetCurrentTransactionNestLevel(); }
+static void pins_after_abort(int level)
+{
+    FreddyPin *all[3] = {&pin_pq, &pin_ivf, &pin_ivpq};
+    for (int i = 0; i < 3; i++)
+        if (all[i]->h && !freddy_pin_survives_abort(all[i]->mut_level, level)) drop_pin(all[i]);
+}
+static void pins_after_commit(int level)
+{
+    FreddyPin *all[3] = {&pin_pq, &pin_ivf, &pin_ivpq};
+    for (int i = 0; i < 3; i++) all[i]->mut_level = freddy_pin_level_after_commit(all[i]->mut_level, level);
+}
+static void freddy_xact_cb(XactEvent event, void *arg)
+{
+    if (event == XACT_EVENT_ABORT || event == XACT_EVENT_PARALLEL_ABORT) pins_after_abort(1);
+    else if (event == XACT_EVENT_COMMIT || event == XACT_EVENT_PARALLEL_COMMIT || event == XACT_EVENT_PREPARE) pins_after_commit(1);
+}
+static void freddy_subxact_cb(SubXactEvent event, SubTransactionId mySubid, SubTransactionId parentSubid, void *arg)
+{
+    /* (callbacks run while the aborting / committing subtransaction is still current: its own nesting level) */
+    if (event == SUBXACT_EVENT_ABORT_SUB) pins_after_abort(GetCurrentTransactionNestLevel());
+    else if (event == SUBXACT_EVENT_COMMIT_SUB) pins_after_commit(GetCurrentTransactionNestLevel());
 }
 
 void freddy_glue_unpin_all(void)
@@ -86,7 +116,12 @@ static float *query_buffer(Size bytes)
 
 static void ensure_exit_hook(void)
 {
-    if (!exit_hook_set) { on_proc_exit(on_exit_unpin, (Datum) 0); exit_hook_set = true; }
+    if (!exit_hook_set) {
+        on_proc_exit(on_exit_unpin, (Datum) 0);
+        RegisterXactCallback(freddy_xact_cb, NULL);
+        RegisterSubXactCallback(freddy_subxact_cb, NULL);
+        exit_hook_set = true;
+    }
 }
 
 /* arrays of a 3 M x 300 table exceed MaxAllocSize (1 GB): huge allocations in the caller's context */
@@ -322,7 +357,10 @@ static void append_new_rows(FreddyPin *p, const char *table, bool with_cell, int
     snprintf(sql, sizeof sql, with_cell ? "SELECT id, coarse_id, vector FROM %s WHERE id > %d ORDER BY id"
                                         : "SELECT id, vector FROM %s WHERE id > %d ORDER BY id", table, p->st.max_id);
     n = fetch_code_rows(sql, with_cell, p->st.m, &ids, &cells, &codes, &m);
-    if (n == 0) return;
+    /* the rows above max_id must be the continuation of what is pinned (max_id + 1, + 2, ...): an append that was flagged
+     * but shows no row, a gap, or ids this handle already holds from a rolled-back transaction cannot be repaired by
+     * appending -- pin again (freddy_pure.h freddy_catch_up_rows_ok) */
+    if (!freddy_catch_up_rows_ok(p->st.max_id, n, ids)) { drop_pin(p); return; }
     if (with_cell)
         for (int64 i = 0; i < n; i++)
             if (cells[i] < 0 || cells[i] >= n_cells) elog(ERROR, "freddy_gpu: coarse_id %d outside [0, %d)", cells[i], n_cells);
@@ -342,6 +380,7 @@ static void append_new_rows(FreddyPin *p, const char *table, bool with_cell, int
     }
     freddy_glue_check(freddy_gpu_append_rows(p->h, n, ids, cells, codes, vectors));
     p->st.max_id = ids[n - 1];
+    mark_mutated(p);
 }
 
 static void reload_codebook(FreddyPin *p, char *cbName)
@@ -350,6 +389,7 @@ static void reload_codebook(FreddyPin *p, char *cbName)
     int s = codebook_subdim(cbName);
     if (cb.positions != p->st.m || cb.positions * s != p->st.d) { drop_pin(p); return; }   /* another shape: pin again */
     freddy_glue_check(freddy_gpu_update_codebook(p->h, dense_codebook(cb, s)));
+    mark_mutated(p);
 }
 
 static int32 last_id(const int32 *ids, int64 n, bool ascending)
@@ -392,6 +432,7 @@ freddy_gpu_index_t *freddy_glue_pq(void)
         desc.codebook = dense_codebook(cb, s); desc.ids = ids; desc.codes = codes;
         freddy_glue_check(freddy_gpu_pin_pq(&desc, 0, &pin_pq.h));
         pin_pq.st = now; pin_pq.st.max_id = last_id(ids, n, true); pin_pq.st.d = desc.d; pin_pq.st.m = desc.m;
+        mark_mutated(&pin_pq);   /* (pinned from this transaction's snapshot, which may include its own uncommitted rows) */
         ensure_exit_hook();
     }
     return pin_pq.h;
@@ -449,6 +490,7 @@ freddy_gpu_index_t *freddy_glue_ivf(void)
         freddy_glue_check(freddy_gpu_pin_ivf(&desc, 0, &pin_ivf.h));
         pin_ivf.st = now; pin_ivf.st.max_id = last_id(ids, n, false); pin_ivf.st.d = d; pin_ivf.st.m = desc.m;
         pinned_C = C;
+        mark_mutated(&pin_ivf);
         ensure_exit_hook();
     }
     return pin_ivf.h;
@@ -529,6 +571,7 @@ freddy_gpu_index_t *freddy_glue_ivpq(void)
         pin_ivpq.st = now; pin_ivpq.st.max_id = last_id(ids, n, true); pin_ivpq.st.d = d; pin_ivpq.st.m = desc.m;
         pinned_cells = n_cells;
         pfree(vectors);
+        mark_mutated(&pin_ivpq);
         ensure_exit_hook();
     }
     return pin_ivpq.h;
