@@ -15,7 +15,7 @@ import numpy as np
 from . import gpu as _gpu
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libfreddy_host.so")
+LIB_PATH = os.environ.get("FREDDY_HOST_SO") or os.path.join(_PKG, "libfreddy_host.so")   # (tests/test_sanitizers.py: the ASan + UBSan build)
 
 ROW2 = np.dtype([("id", np.int32), ("distance", np.float32)])
 ROW3 = np.dtype([("query_id", np.int32), ("id", np.int32), ("distance", np.float32)])

@@ -14,7 +14,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def drv(tmp_path_factory):
     so = tmp_path_factory.mktemp("pgpure") / "libpgpure.so"
-    subprocess.check_call(["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-ffp-contract=off", "-fPIC", "-shared", "-o", str(so),
+    flags = ["-O2"]
+    if os.environ.get("FREDDY_SANITIZE") == "1":   # tests/test_sanitizers.py re-runs this file under ASan + UBSan
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+    subprocess.check_call(["gcc"] + flags + ["-std=c11", "-Wall", "-Werror", "-ffp-contract=off", "-fPIC", "-shared", "-o", str(so),
                            os.path.join(ROOT, "tests", "c", "pg_pure_driver.c")])
     lib = C.CDLL(str(so))
     lib.drv_stamp_size.restype = C.c_size_t
