@@ -292,6 +292,16 @@ typedef struct freddy_track {
                                               * own value lies within 1e-5 of the confidence) */
 } freddy_track;
 int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
+/* The same with the caller's idea of the struct's size: at most `out_size` bytes are written (a host built against an older
+ * header, whose freddy_track ends earlier, gets the fields it knows); returns the number of bytes written, or < 0.  Hosts
+ * that are built separately from the library (the PostgreSQL extension) call this one. */
+int freddy_gpu_last_track_sized(const freddy_gpu_index_t* ivpq, void* out, size_t out_size);
+
+/* ABI version of the library: bumped whenever a struct of this header grows or an entry point changes meaning.  A host
+ * compares it with the FREDDY_GPU_ABI_VERSION it was compiled against when it loads the library (pg/freddy_gpu_glue.c
+ * does, in _PG_init) and refuses a mismatch instead of overrunning a stack variable. */
+#define FREDDY_GPU_ABI_VERSION 4
+int freddy_gpu_abi_version(void);
 
 /* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
  * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (5 filter +

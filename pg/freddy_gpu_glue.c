@@ -116,6 +116,9 @@ static float *query_buffer(Size bytes)
 
 static void ensure_exit_hook(void)
 {
+    /* (first use of the library in this backend) the library this extension was linked against may have been replaced */
+    if (freddy_gpu_abi_version() != FREDDY_GPU_ABI_VERSION)
+        elog(ERROR, "freddy_gpu: libfreddy_gpu.so has ABI version %d, this extension was built against %d", freddy_gpu_abi_version(), FREDDY_GPU_ABI_VERSION);
     if (!exit_hook_set) {
         on_proc_exit(on_exit_unpin, (Datum) 0);
         RegisterXactCallback(freddy_xact_cb, NULL);

@@ -57,7 +57,8 @@ Datum ivpq_search_in(PG_FUNCTION_ARGS)
         if (Q > 0) freddy_glue_check_dim(dim, freddy_glue_dim(h));
         freddy_glue_check(freddy_gpu_knn_join(h, qs, Q, k, targets, n_targets, alpha, pvf, method,
                                               use_target_lists ? 1 : 0, confidence, double_threshold, r->ids, r->dist, &iterations));
-        if (freddy_gpu_last_track(h, &t) == FREDDY_OK) {
+        memset(&t, 0, sizeof t);
+        if (freddy_gpu_last_track_sized(h, &t, sizeof t) > 0) {   /* (sized: a library newer than this host's header cannot overrun t) */
             elog(INFO, "TRACK precomputation_time %f", t.precomputation_time);                                   /* :294 */
             elog(INFO, "TRACK determine_coarse_quantization_time %f", t.determine_coarse_quantization_time);     /* :341 */
             elog(INFO, "TRACK query_construction_time %f", t.query_construction_time);                           /* :397 */

@@ -295,6 +295,9 @@ struct freddy_gpu_index {
   // replicas of this index on further devices (freddy_gpu_pin_ivf_multi): a host batch is split contiguously over
   // this handle and its replicas; every replica is a complete pinned index of its own
   std::vector<freddy_gpu_index*> replicas;
+  // set when a mutation (append_rows / update_codebook / set_option) failed after it had already changed some of the devices
+  // behind this handle: the replicas no longer hold the same tables, so every search fails loudly until the handle is unpinned
+  bool poisoned = false;
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -827,21 +830,10 @@ extern "C" int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* ix, int64_
   return FREDDY_OK;
 }
 
-static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
-  if (ix && !ix->replicas.empty()) {
-    int64_t sum = 0;
-    for (const freddy_gpu_index* r : ix->replicas) { const int64_t v = read_viol(r, which); if (v < 0) return -1; sum += v; }
-    std::vector<freddy_gpu_index*> none;
-    // (this device's own counters: the same function on a handle seen without its replicas)
-    freddy_gpu_index* self = const_cast<freddy_gpu_index*>(ix);
-    none.swap(self->replicas);
-    const int64_t v = read_viol(ix, which);
-    none.swap(self->replicas);
-    (void)hipSetDevice(ix->device);
-    return v < 0 ? -1 : sum + v;
-  }
-  if (ix && (ix->pq_shadow || ix->pq_sub_view)) {   // a PQ handle: the counters of its two views
-    const int64_t a = ix->pq_shadow ? read_viol(ix->pq_shadow, which) : 0, b = ix->pq_sub_view ? read_viol(ix->pq_sub_view, which) : 0;
+// one device's own counters (a PQ handle: those of its two views)
+static int64_t read_viol_one(const freddy_gpu_index* ix, int which) {
+  if (ix && (ix->pq_shadow || ix->pq_sub_view)) {
+    const int64_t a = ix->pq_shadow ? read_viol_one(ix->pq_shadow, which) : 0, b = ix->pq_sub_view ? read_viol_one(ix->pq_sub_view, which) : 0;
     return (a < 0 || b < 0) ? -1 : a + b;
   }
   if (!ix || !ix->viol) return 0;
@@ -850,6 +842,13 @@ static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
       hipMemcpy(h, ix->viol, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
     return -1;
   return which == 0 ? (int64_t)h[0] + h[2] : h[which];
+}
+static int64_t read_viol(const freddy_gpu_index_t* ix, int which) {
+  if (!ix) return 0;
+  int64_t sum = 0;
+  for (const freddy_gpu_index* r : ix->replicas) { const int64_t v = read_viol_one(r, which); if (v < 0) return -1; sum += v; }
+  const int64_t v = read_viol_one(ix, which);   // (last: the calling thread is left on the primary's device)
+  return v < 0 ? -1 : sum + v;
 }
 extern "C" int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* ix) { return read_viol(ix, 0); }
 extern "C" int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* ix) { return read_viol(ix, 1); }
@@ -891,8 +890,16 @@ extern "C" int freddy_gpu_profile_read(freddy_gpu_index_t* ix, int32_t cap, char
 
 extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, int64_t value) {
   if (!ix || !name) return fail(FREDDY_E_ARG, "NULL argument");
-  for (freddy_gpu_index* r : ix->replicas)
-    if (int rc = freddy_gpu_set_option(r, name, value)) return rc;
+  if (!ix->replicas.empty()) {   // the primary first: an unknown name is rejected before any device has changed
+    std::vector<freddy_gpu_index*> reps;
+    reps.swap(ix->replicas);
+    int rc = freddy_gpu_set_option(ix, name, value);
+    reps.swap(ix->replicas);
+    if (rc) return rc;
+    for (freddy_gpu_index* r : ix->replicas)
+      if ((rc = freddy_gpu_set_option(r, name, value))) { ix->poisoned = true; return rc; }
+    return FREDDY_OK;
+  }
   Tuning& t = ix->tune;
   const std::string n(name);
   if (n == "fused") t.fused = (int)value;
@@ -1566,6 +1573,7 @@ static int check_search_args(const freddy_gpu_index* ix, int kind, const void* q
                              const void* od) {
   if (!ix) return fail(FREDDY_E_ARG, "NULL index");
   if (ix->kind != kind) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  if (ix->poisoned) return fail(FREDDY_E_HIP, "this handle's devices hold different tables (an append / codebook update failed part-way): unpin it and pin again");
   if (Q < 0 || k <= 0) return fail(FREDDY_E_ARG, "Q must be >= 0 and k > 0");
   if (Q > 0 && (!q || !oi || !od)) return fail(FREDDY_E_ARG, "NULL buffer");
   if (2 * k > 1024) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 512", k);
@@ -1707,6 +1715,7 @@ static int lane_retire(LaneSlot& c, const PipeCall& pc) {
   if (!c.busy) return 0;
   c.busy = false;
   HIP_TRY(hipEventSynchronize(c.done));
+  HIP_TRY(hipGetLastError());   // (a fault in one of the lane's kernels surfaces here, before its output is trusted)
   const int k = pc.k;
   const size_t n_out = (size_t)c.n * k;
   const int32_t* ho = static_cast<const int32_t*>(c.h_out);
@@ -1716,6 +1725,10 @@ static int lane_retire(LaneSlot& c, const PipeCall& pc) {
   if (n_next <= 0) return 0;
   const int d = pc.ix->d;
   std::vector<int32_t> who(ho + 2 * n_out + 1, ho + 2 * n_out + 1 + n_next);
+  // (device-written numbers index the caller's buffers: a value outside the sub-batch -- e.g. after a kernel fault whose
+  // error has not surfaced yet -- must never become a host read or write out of bounds)
+  for (int i = 0; i < n_next; ++i)
+    if (who[(size_t)i] < 0 || who[(size_t)i] >= c.n) return fail(FREDDY_E_HIP, "sub-batch returned a straggler index %d outside [0, %d)", who[(size_t)i], c.n);
   std::vector<float> q((size_t)n_next * d);
   std::vector<int32_t> ri((size_t)n_next * k);
   std::vector<float> rd((size_t)n_next * k);
@@ -1848,6 +1861,7 @@ extern "C" int freddy_gpu_ivfadc_search(freddy_gpu_index_t* ix, const float* que
 }
 
 extern "C" int freddy_gpu_host_alloc(void** out, size_t bytes) {
+  setenv("GPU_MAX_HW_QUEUES", "6", 0);   // (as open_device: this call may be the process's first HIP call; a deployment sets it in the environment)
   if (!out) return fail(FREDDY_E_ARG, "NULL argument");
   *out = nullptr;
   if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(FREDDY_E_NOMEM, "pinned host allocation of %zu bytes failed", bytes); }
@@ -2575,8 +2589,19 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
   if (!ix) return fail(FREDDY_E_ARG, "NULL index");
   if (n < 0 || (n > 0 && !ids)) return fail(FREDDY_E_ARG, "bad argument");
   if (n == 0) return FREDDY_OK;
-  for (freddy_gpu_index* r : ix->replicas)   // (every replica holds the same tables)
-    if (int rc = freddy_gpu_append_rows(r, n, ids, coarse_id, codes, vectors)) return rc;
+  if (!ix->replicas.empty()) {
+    // every replica holds the same tables: the primary goes first (argument errors are found there before anything has
+    // changed anywhere); a failure after that leaves the devices with different tables -> the handle is poisoned and
+    // every search on it fails loudly until it is unpinned
+    std::vector<freddy_gpu_index*> reps;
+    reps.swap(ix->replicas);
+    int rc = freddy_gpu_append_rows(ix, n, ids, coarse_id, codes, vectors);
+    reps.swap(ix->replicas);
+    if (rc) { if (rc == FREDDY_E_HIP || rc == FREDDY_E_NOMEM) ix->poisoned = true; return rc; }
+    for (freddy_gpu_index* r : ix->replicas)
+      if ((rc = freddy_gpu_append_rows(r, n, ids, coarse_id, codes, vectors))) { ix->poisoned = true; return rc; }
+    return FREDDY_OK;
+  }
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
   const int32_t last_id = ix->kind == KIND_IVPQ ? (ix->join.h_ids.empty() ? -1 : ix->join.h_ids.back())
@@ -2653,8 +2678,21 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
 
 extern "C" int freddy_gpu_update_codebook(freddy_gpu_index_t* ix, const float* codebook) {
   if (!ix || !codebook) return fail(FREDDY_E_ARG, "NULL argument");
-  for (freddy_gpu_index* r : ix->replicas)
-    if (int rc = freddy_gpu_update_codebook(r, codebook)) return rc;
+  if (!ix->replicas.empty()) {   // every device or none: a failure after the first device has changed poisons the handle
+    size_t done = 0;
+    int rc = 0;
+    for (freddy_gpu_index* r : ix->replicas) { if ((rc = freddy_gpu_update_codebook(r, codebook))) break; ++done; }
+    if (!rc) {
+      std::vector<freddy_gpu_index*> none;
+      none.swap(ix->replicas);
+      rc = freddy_gpu_update_codebook(ix, codebook);
+      none.swap(ix->replicas);
+      if (!rc) return FREDDY_OK;
+      done = ix->replicas.size();
+    }
+    if (done > 0 || rc == FREDDY_E_HIP || rc == FREDDY_E_NOMEM) ix->poisoned = true;
+    return rc;
+  }
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipDeviceSynchronize());   // (searches of every stream and lane have drained before the tables change)
   if (ix->kind == KIND_PQ) return derive_codebook_tables(ix, codebook);
@@ -2699,6 +2737,15 @@ extern "C" int freddy_gpu_last_track(const freddy_gpu_index_t* ix, freddy_track*
   *out = ix->join.track;
   return FREDDY_OK;
 }
+
+extern "C" int freddy_gpu_last_track_sized(const freddy_gpu_index_t* ix, void* out, size_t out_size) {
+  if (!ix || !out) return fail(FREDDY_E_ARG, "NULL argument");
+  if (ix->kind != KIND_IVPQ) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
+  const size_t n = std::min(out_size, sizeof(freddy_track));
+  memcpy(out, &ix->join.track, n);
+  return (int)n;
+}
+extern "C" int freddy_gpu_abi_version(void) { return FREDDY_GPU_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------
 // exact brute-force kNN

@@ -26,7 +26,9 @@ EXPORTS = [
     "freddy_gpu_encode", "freddy_gpu_set_option", "freddy_gpu_last_track", "freddy_gpu_last_probed_cells", "freddy_gpu_coarse_bound_checked",
     "freddy_gpu_insert_quantize", "freddy_gpu_append_rows", "freddy_gpu_update_codebook", "freddy_gpu_kmeans",
     "freddy_gpu_host_alloc", "freddy_gpu_host_free", "freddy_gpu_pin_ivf_multi", "freddy_gpu_replica_count",
+    "freddy_gpu_last_track_sized", "freddy_gpu_abi_version",
 ]
+ABI_VERSION = 4   # include/freddy_gpu.h FREDDY_GPU_ABI_VERSION this binding was written against
 
 
 class FreddyGpuError(RuntimeError):
@@ -77,6 +79,9 @@ def load():
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     lib = C.CDLL(LIB_PATH)
+    if lib.freddy_gpu_abi_version() != ABI_VERSION:
+        raise FreddyGpuError(f"{LIB_PATH} has ABI version {lib.freddy_gpu_abi_version()}, this binding expects {ABI_VERSION}: rebuild")
+    lib.freddy_gpu_last_track_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.freddy_gpu_last_error.restype = C.c_char_p
     lib.freddy_gpu_index_bytes.restype = C.c_int64
     lib.freddy_gpu_index_bytes.argtypes = [C.c_void_p]
@@ -369,7 +374,9 @@ class IVPQIndex(_Index):
     def last_track(self):
         """{stage name: seconds} of the most recent knn_join call (the reference's TRACK lines)."""
         t = Track()
-        _check(self.lib.freddy_gpu_last_track(self.h, C.byref(t)))
+        n = self.lib.freddy_gpu_last_track_sized(self.h, C.byref(t), C.sizeof(t))
+        if n < 0:
+            _check(n)
         return {n: getattr(t, n) for n, _ in Track._fields_ if n != "reserved"}
 
 
