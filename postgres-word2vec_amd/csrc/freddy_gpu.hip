@@ -31,6 +31,7 @@
 #include "sparse5.h"
 #include "coarse.h"
 #include "exact.h"
+#include "exact2.h"
 #include "join.h"
 
 using namespace freddy;
@@ -92,6 +93,8 @@ struct Tuning {
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
+  int exact_filter = -1;       // FREDDY_GPU_EXACT_FILTER: exact kNN as MFMA filter + exact refine (exact2.h): -1 auto (tables of >= 8192 rows, k <= 32), 0 never, 1 always
+  int exact_refine_all = 0;    // tests: every row is refined (exhaustive check of the similarity bracket)
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
   int64_t lut_budget_mb = 8192;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit); 288 GB of HBM: 8 GiB = 12 800 queries at nprobe 10
   int64_t filter_table_mb = 8192;    // FREDDY_GPU_FILTER_TABLE_MB (pin time): 0 = no filter + refine tables
@@ -123,6 +126,7 @@ static Tuning read_tuning() {
   t.sparse_items = (int)env_int("FREDDY_GPU_SPARSE_ITEMS", t.sparse_items);
   t.fuse_table = (int)env_int("FREDDY_GPU_FUSE_TABLE", t.fuse_table);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
+  t.exact_filter = (int)env_int("FREDDY_GPU_EXACT_FILTER", t.exact_filter);
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
   t.filter_table_mb = env_int("FREDDY_GPU_FILTER_TABLE_MB", t.filter_table_mb);
@@ -273,6 +277,13 @@ struct freddy_gpu_index {
   int32_t max_id = -1;          // largest row id pinned (appended rows must be larger)
   // raw vectors (exact kNN): 64-row blocks [block][d][64]
   float* xb = nullptr;
+  // exact kNN as filter + refine (exact2.h): the table's statistics (pin time / append) and the per-call buffers
+  bool exf_ok = false;          // every element finite, d % 4 == 0, d <= 512
+  float exf_xnorm = 0.0f;       // largest row norm, rounded up
+  int exf_ex = 0;               // power-of-two scale of the rows for the f16 split
+  DevBuf exf_qfrag, exf_small, exf_sample, exf_cand;
+  DevBuf exf_xf;                // the rows in MFMA A-fragment order, scaled and split into f16 hi / lo (exf_layout_kernel)
+  int64_t exf_xf_strips = 0;    // 32-row strips laid out (capacity is exf_xf.cap)
   // ivpq extras
   JoinIndex join;
   // flat PQ table through the cell-grouped scan (pq_shadow_build): an IVF-shaped view of this table -- pseudo-lists of
@@ -358,6 +369,7 @@ static void free_index(freddy_gpu_index* ix) {
   (void)hipSetDevice(ix->device);
   (void)hipDeviceSynchronize();   // (every stream that searched on this handle, without touching a caller's stream handle)
   for (Workspace& w : ix->ws) w.release();
+  for (DevBuf* b : {&ix->exf_qfrag, &ix->exf_small, &ix->exf_sample, &ix->exf_cand, &ix->exf_xf}) b->release();
   if (ix->hio_in) { (void)hipHostFree(ix->hio_in); ix->hio_in = nullptr; ix->hio_in_cap = 0; }
   if (ix->hio_out) { (void)hipHostFree(ix->hio_out); ix->hio_out = nullptr; ix->hio_out_cap = 0; }
   for (Lane& l : ix->lanes) {
@@ -531,7 +543,9 @@ static int raise_lds_limits(int device) {
       (const void*)&ivf_filter5_kernel<12, false, false>, (const void*)&ivf_filter5_kernel<12, true, true>,
       (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
-      (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>};
+      (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>,
+      (const void*)&exf_filter_kernel<1, false>, (const void*)&exf_filter_kernel<2, false>, (const void*)&exf_filter_kernel<1, true>,
+      (const void*)&exf_filter_kernel<2, true>};
   for (const void* k : kernels)
     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);
@@ -926,6 +940,8 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "fused_prof") t.scan_prof = (int)value;
   else if (n == "debug_surv") t.debug_surv = (int)value;
   else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
+  else if (n == "exact_filter") t.exact_filter = (int)value;
+  else if (n == "exact_refine_all") t.exact_refine_all = (int)value;
   else return fail(FREDDY_E_ARG, "unknown option '%s'", name);
   return FREDDY_OK;
 }
@@ -2584,6 +2600,7 @@ static int append_packed_rows(freddy_gpu_index* ix, int n_lists, int64_t n, cons
   return 0;
 }
 
+static int exf_table_stats(freddy_gpu_index* ix, int64_t r0, int64_t n);
 extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const int32_t* ids, const int32_t* coarse_id,
                                       const int16_t* codes, const float* vectors) {
   if (!ix) return fail(FREDDY_E_ARG, "NULL index");
@@ -2670,7 +2687,7 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
       if (ix->xb) (void)hipFree(ix->xb);
       ix->xb = xb; ix->n_blocks = new_blocks; ix->N += n;
       ix->h_ids.insert(ix->h_ids.end(), ids, ids + n);
-      return FREDDY_OK;
+      return exf_table_stats(ix, (int64_t)o, n);   // (the filter's scale and norm bound cover the new rows)
     }
   }
   return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
@@ -2750,6 +2767,137 @@ extern "C" int freddy_gpu_abi_version(void) { return FREDDY_GPU_ABI_VERSION; }
 // ---------------------------------------------------------------------------------------
 // exact brute-force kNN
 // ---------------------------------------------------------------------------------------
+// ---- exact kNN as filter + refine (exact2.h) ----------------------------------------------------------------------
+// The table's largest |element| / largest row norm over rows [r0, r0 + n) of the row-major copy, folded into the handle's.
+static int exf_table_stats(freddy_gpu_index* ix, int64_t r0, int64_t n) {
+  const bool shape_ok = ix->d % 4 == 0 && ix->d <= 512 && ix->d >= 16;
+  if (!shape_ok) { ix->exf_ok = false; return 0; }
+  if (n <= 0) return 0;
+  if (ix->exf_small.ensure(4096)) return fail(FREDDY_E_NOMEM, "device allocation failed");
+  uint32_t* st = ix->exf_small.as<uint32_t>() + 512;   // (the upper part of the small buffer; the lower one is per-call state)
+  HIP_TRY(hipMemsetAsync(st, 0, 16, ix->stream));
+  const unsigned grid = (unsigned)std::min<int64_t>((n + 3) / 4, (int64_t)ix->n_cus * 8);
+  hipLaunchKernelGGL(exf_table_stats_kernel, dim3(grid), dim3(256), 0, ix->stream, ix->coarse + (size_t)r0 * ix->d, n, ix->d, st);
+  HIP_TRY(hipGetLastError());
+  uint32_t h[4] = {0, 0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(h, st, 16, hipMemcpyDeviceToHost, ix->stream));
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  float amax, n2;
+  memcpy(&amax, &h[0], 4); memcpy(&n2, &h[1], 4);
+  const bool first = r0 == 0;
+  if (h[2] || !(n2 < 1e30f)) { ix->exf_ok = false; return 0; }
+  const float xn = std::sqrt(n2) * (1.0f + 1e-5f);
+  int64_t relayout_from = r0;
+  if (first) { ix->exf_ok = true; ix->exf_xnorm = xn; ix->exf_ex = exf_scale_exp(amax); }
+  else if (ix->exf_ok) {
+    ix->exf_xnorm = std::max(ix->exf_xnorm, xn);
+    const int ex_new = std::min(ix->exf_ex, exf_scale_exp(amax));   // (a larger element: a smaller scale -> everything is laid out again)
+    if (ex_new != ix->exf_ex) relayout_from = 0;
+    ix->exf_ex = ex_new;
+  } else return 0;
+  // the fragment-order copy: rows [relayout_from, r0 + n) (whole strips; the strip the old last row sat in is rewritten)
+  const int T = (ix->d + 15) / 16;
+  const int64_t n_total = r0 + n, strips = (n_total + 31) / 32, strip0 = relayout_from / 32;
+  const size_t need = (size_t)strips * T * 2 * 64 * 16;
+  if (need > ix->exf_xf.cap) {
+    DevBuf bigger;
+    if (bigger.ensure(need)) { ix->exf_ok = false; return 0; }   // (no room for the copy: the all-exact kernels stay)
+    if (ix->exf_xf.p && strip0 > 0) HIP_TRY(hipMemcpy(bigger.p, ix->exf_xf.p, (size_t)strip0 * T * 2 * 64 * 16, hipMemcpyDeviceToDevice));
+    ix->bytes += (int64_t)bigger.cap - (int64_t)ix->exf_xf.cap;
+    ix->exf_xf.release();
+    ix->exf_xf = bigger;
+  }
+  const int64_t threads = (strips - strip0) * T * 64;
+  hipLaunchKernelGGL(exf_layout_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ix->stream, ix->coarse, n_total, ix->d, T, ix->exf_ex,
+                     strip0, strips - strip0, ix->exf_xf.as<h8v>());
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  ix->exf_xf_strips = strips;
+  return 0;
+}
+
+// The filter + refine path for all rows of the table.  *fell_back = 1: a candidate buffer overflowed or a query was not
+// finite -- nothing was written, the caller runs the all-exact kernels.
+static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t s, const float* d_queries, int Q, int k, int* fell_back) {
+  *fell_back = 0;
+  const int d = ix->d, T = (d + 15) / 16, L = k, V = pick_V(L);
+  const int64_t N = ix->N;
+  const bool all = ix->tune.exact_refine_all != 0;
+  const int64_t cap64 = all ? N : std::min<int64_t>(N, 8192);
+  const int cap = (int)cap64;
+  const int n_sample = (int)std::min<int64_t>(N, EXF_SAMPLE);
+  // small per-call state: [0..63] thr, [64..127] qeps, [128..191] qunscale, [192..255] cand_cnt, [256] qbad
+  if (ix->exf_small.ensure(4096) || ix->exf_qfrag.ensure((size_t)2 * T * 2 * 64 * 16) ||
+      ix->exf_sample.ensure(sizeof(float) * (size_t)EXF_QT * n_sample) || ix->exf_cand.ensure(sizeof(uint2) * (size_t)EXF_QT * cap) ||
+      ws->w_part.ensure(sizeof(u64) * (size_t)Q * EXF_TW * L) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
+      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (!ix->viol) {
+    HIP_TRY(hipMalloc((void**)&ix->viol, 4 * sizeof(int32_t)));
+    HIP_TRY(hipMemset(ix->viol, 0, 4 * sizeof(int32_t)));
+  }
+  float* sm = ix->exf_small.as<float>();
+  float* thr = sm; float* qeps = sm + 64; float* qunscale = sm + 128;
+  int32_t* cand_cnt = reinterpret_cast<int32_t*>(sm + 192);
+  int32_t* qbad = reinterpret_cast<int32_t*>(sm + 256);
+  HIP_TRY(hipMemsetAsync(qbad, 0, 4, s));
+  HIP_TRY(hipMemsetAsync(ix->viol + 3, 0, 4, s));
+  const size_t lds1 = (size_t)1 * T * 2 * 64 * 16, lds2 = 2 * lds1;
+  for (int q0 = 0; q0 < Q; q0 += EXF_QT) {
+    const int nq = std::min(EXF_QT, Q - q0);
+    const int NT = nq <= 32 ? 1 : 2;
+    ExfPrepArgs pa;
+    pa.queries = d_queries + (size_t)q0 * d; pa.nq = nq; pa.d = d; pa.T = T; pa.xmax_norm = ix->exf_xnorm; pa.ex = ix->exf_ex;
+    pa.eps_factor = exf_eps_factor(d); pa.qfrag = ix->exf_qfrag.as<h8v>(); pa.qeps = qeps; pa.qunscale = qunscale; pa.qbad = qbad;
+    timed_launch(ix, s, "exact_prep", [&] { hipLaunchKernelGGL(exf_prep_kernel, dim3(EXF_QT), dim3(256), 0, s, pa); });
+    HIP_TRY(hipGetLastError());
+    ExfArgs fa;
+    fa.xf = ix->exf_xf.as<h8v>(); fa.n_rows = n_sample; fa.T = T; fa.qfrag = ix->exf_qfrag.as<h8v>();
+    fa.qunscale = qunscale; fa.sample_out = ix->exf_sample.as<float>(); fa.thr = thr; fa.cand_cnt = cand_cnt; fa.cand = ix->exf_cand.as<uint2>(); fa.cap = cap;
+    auto grid_for = [&](int64_t rows) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, (int64_t)ix->n_cus * 2)); };
+    timed_launch(ix, s, "exact_sample", [&] {
+      if (NT == 1) hipLaunchKernelGGL((exf_filter_kernel<1, true>), dim3(grid_for(n_sample)), dim3(EXF_WG), lds1, s, fa);
+      else hipLaunchKernelGGL((exf_filter_kernel<2, true>), dim3(grid_for(n_sample)), dim3(EXF_WG), lds2, s, fa);
+    });
+    HIP_TRY(hipGetLastError());
+    ExfThrArgs ta;
+    ta.sample = fa.sample_out; ta.n_sample = n_sample; ta.nq = nq; ta.k = k; ta.qeps = qeps; ta.qunscale = qunscale; ta.thr = thr; ta.refine_all = all ? 1 : 0;
+    timed_launch(ix, s, "exact_threshold", [&] { hipLaunchKernelGGL(exf_threshold_kernel, dim3(EXF_QT), dim3(64 * EXF_TW), 0, s, ta); });
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemsetAsync(cand_cnt, 0, sizeof(int32_t) * EXF_QT, s));
+    fa.n_rows = N; fa.sample_out = nullptr;
+    timed_launch(ix, s, "exact_filter", [&] {
+      if (NT == 1) hipLaunchKernelGGL((exf_filter_kernel<1, false>), dim3(grid_for(N)), dim3(EXF_WG), lds1, s, fa);
+      else hipLaunchKernelGGL((exf_filter_kernel<2, false>), dim3(grid_for(N)), dim3(EXF_WG), lds2, s, fa);
+    });
+    HIP_TRY(hipGetLastError());
+    ExfRefineArgs ra;
+    ra.rows = ix->coarse; ra.queries = d_queries + (size_t)q0 * d; ra.cand = fa.cand; ra.cand_cnt = cand_cnt; ra.qeps = qeps;
+    ra.part = ws->w_part.as<u64>() + (size_t)q0 * EXF_TW * L; ra.viol = ix->viol; ra.cap = cap; ra.d = d; ra.L = L; ra.count_checked = all ? 1 : 0;
+    const size_t rlds = (((size_t)d * 4 + 15) & ~(size_t)15) + (size_t)EXF_TW * 64 * sizeof(u64);
+    timed_launch(ix, s, "exact_refine", [&] {
+      switch (V) {
+        case 1: hipLaunchKernelGGL((exf_refine_kernel<1>), dim3(nq), dim3(64 * EXF_TW), rlds, s, ra); break;
+        default: hipLaunchKernelGGL((exf_refine_kernel<2>), dim3(nq), dim3(64 * EXF_TW), rlds, s, ra); break;
+      }
+    });
+    HIP_TRY(hipGetLastError());
+  }
+  timed_launch(ix, s, "exact_merge", [&] {
+    switch (V) {
+      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (1 + 1) * sizeof(u64), s, ws->w_part.as<u64>(), EXF_TW, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+      default: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (2 + 1) * sizeof(u64), s, ws->w_part.as<u64>(), EXF_TW, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+    }
+  });
+  HIP_TRY(hipGetLastError());
+  int32_t flags[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&flags[0], ix->viol + 3, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(&flags[1], qbad, 4, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (flags[0] || flags[1]) *fell_back = 1;
+  return 0;
+}
+
 extern "C" int freddy_gpu_pin_vectors(const freddy_vec_desc* t, int device, freddy_gpu_index_t** out) {
   if (!t || !out || t->d <= 0 || t->N < 0 || (t->N && (!t->ids || !t->vectors))) return fail(FREDDY_E_ARG, "bad argument");
   if (t->N > (int64_t)INT32_MAX - 64) return fail(FREDDY_E_LIMIT, "N too large for 32-bit row positions");
@@ -2784,6 +2932,7 @@ extern "C" int freddy_gpu_pin_vectors(const freddy_vec_desc* t, int device, fred
     ix->h_ids.assign(t->ids, t->ids + t->N);
     // the source rows are only needed again for "id = ANY(...)" subsets: keep them row-major too
     if (t->N && upload(&ix->coarse, t->vectors, (size_t)t->N * t->d, &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+    if (!rc && t->N) rc = exf_table_stats(ix, 0, t->N);
   }
   if (rc) { free_index(ix); return rc; }
   *out = ix;
@@ -2829,6 +2978,21 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
     }
     xb = ws->w_resid.as<float>();
     pos = ws->w_sub_pos.as<int32_t>();
+  }
+  // Filter + refine (exact2.h): the whole table, k <= 32, finite rows of a supported shape; identical lists.
+  const bool want_filter = !subset_ids && ix->exf_ok && k <= 32 && ix->tune.exact_filter != 0 &&
+                           (ix->tune.exact_filter == 1 || n_rows >= 8192) && n_rows >= 1;
+  if (want_filter) {
+    if (ws->w_q.ensure(sizeof(float) * (size_t)Q * d)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
+    int fell_back = 0;
+    if (int rc = exact_filter_search(ix, ws, s, ws->w_q.as<float>(), Q, k, &fell_back)) return rc;
+    if (!fell_back) {
+      HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipMemcpyAsync(out_sim, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      return FREDDY_OK;
+    }
   }
   int chunk_blocks = 8;   // 512 rows per workgroup-chunk; longer chunks once the grid is large enough
   const int EX_QT = ex_qt(V, Q);

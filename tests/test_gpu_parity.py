@@ -354,6 +354,120 @@ def test_exact_knn_matches_oracle(gpu, oracle):
     idx.close()
 
 
+def _exact_expect(oracle, x, ids, qs, k):
+    return [oracle.exact_knn(x, ids, q, k) for q in qs]
+
+
+@pytest.mark.parametrize("scale", [1.0, 3000.0, 2e-4])
+def test_exact_knn_filter_refine_matches_oracle(gpu, oracle, scale):
+    """exact2.h: f16-split MFMA similarities with a proven bracket rank the rows, the reference's chain runs for the rows
+    that can reach the k-th largest similarity -- ids, ranks and similarity bits equal fo_exact_knn / the all-exact kernel.
+    `scale`: unnormalised tables (large / tiny elements exercise the power-of-two operand scaling)."""
+    N = 24000
+    x = (util.corpus(N).numpy() * np.float32(scale)).astype(np.float32)
+    x[5000:5040] = x[100:140]                       # duplicate rows: equal similarities, ties by id
+    ids = (np.arange(N) * 3 + 7).astype(np.int32)
+    idx = gpu.VectorIndex(ids, x)
+    qs = x[::331][:70].copy()                       # 70 queries: a full pass of 64 (two MFMA tiles) and one of 6 (one tile)
+    qs[3] = -qs[3]
+    qs[9] = x[100]                                  # a query with 2 exact copies in the table
+    for k in (1, 5, 32):
+        idx.set_option("exact_filter", -1)
+        gi, gs = idx.search(qs, k)
+        idx.set_option("exact_filter", 0)
+        hi, hs = idx.search(qs, k)                  # the all-exact kernels
+        assert np.array_equal(gi, hi) and np.array_equal(gs.view(np.uint32), hs.view(np.uint32)), k
+        for qi in (0, 3, 9, 33, 64, 69):
+            exp = oracle.exact_knn(x, ids, qs[qi], k)
+            assert gi[qi].tolist() == exp["id"].tolist(), (k, qi)
+            assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32)), (k, qi)
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+def test_exact_knn_filter_bracket_holds_for_every_row(gpu, oracle):
+    """Option exact_refine_all: EVERY row goes through the refine stage, which has both the MFMA value and the reference's
+    similarity in hand -- the bracket |a - s| <= eps(q) is checked for every (row, query) pair, and the lists still equal
+    the oracle's."""
+    N = 16384 + 77
+    rng = np.random.default_rng(5)
+    x = util.corpus(N).numpy()
+    x[1000:1100] *= np.float32(37.5)                # a few long rows: the norm bound X is their norm
+    x[2000:2050] = 0.0
+    ids = np.arange(1, N + 1, dtype=np.int32)
+    idx = gpu.VectorIndex(ids, x)
+    qs = np.concatenate([x[::777][:20], rng.standard_normal((4, x.shape[1])).astype(np.float32) * np.float32(0.01)])
+    idx.set_option("exact_refine_all", 1)
+    gi, gs = idx.search(qs, 5)
+    assert idx.bound_violations() == 0
+    assert int(idx.lib.freddy_gpu_filter_bound_checked(idx.h)) == qs.shape[0] * N
+    for qi in range(qs.shape[0]):
+        exp = oracle.exact_knn(x, ids, qs[qi], 5)
+        assert gi[qi].tolist() == exp["id"].tolist(), qi
+        assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32)), qi
+    idx.close()
+
+
+def test_exact_knn_filter_after_append_rows(gpu, oracle):
+    """freddy_gpu_append_rows on a vector handle extends the fragment-order copy the filter reads (the strip the old last
+    row sat in is rewritten; a new largest element changes the power-of-two scale and lays everything out again)."""
+    N0, N1, N2 = 9000, 9500, 10007
+    x = util.corpus(N2).numpy()
+    x[N1 + 5] *= np.float32(300.0)                  # arrives with the second append: a smaller scale for the whole table
+    ids = np.arange(1, N2 + 1, dtype=np.int32)
+    idx = gpu.VectorIndex(ids[:N0], x[:N0])
+    qs = np.concatenate([x[::1111][:9], x[N0 + 3:N0 + 5], x[N1 + 5:N1 + 6]])
+    for n in (N1, N2):
+        lo = N0 if n == N1 else N1
+        idx.append_rows(ids[lo:n], vectors=x[lo:n])
+        gi, gs = idx.search(qs, 5)
+        for qi in range(qs.shape[0]):
+            exp = oracle.exact_knn(x[:n], ids[:n], qs[qi], 5)
+            assert gi[qi].tolist() == exp["id"].tolist(), (n, qi)
+            assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32)), (n, qi)
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+def test_exact_knn_filter_edge_cases(gpu, oracle):
+    x = util.corpus(300).numpy()
+    ids = (np.arange(300) + 1).astype(np.int32)
+    idx = gpu.VectorIndex(ids, x)
+    idx.set_option("exact_filter", 1)               # forced: fewer rows than the sample, than a strip, than k
+    for n_q, k in ((1, 5), (3, 32)):
+        gi, gs = idx.search(x[:n_q], k)
+        for qi in range(n_q):
+            exp = oracle.exact_knn(x, ids, x[qi], k)
+            assert gi[qi].tolist() == exp["id"].tolist()
+            assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32))
+    idx.close()
+    idx = gpu.VectorIndex(ids[:3], x[:3])
+    idx.set_option("exact_filter", 1)
+    gi, gs = idx.search(x[:2], 8)                    # fewer rows than k
+    assert (gi[:, 3:] == -1).all() and np.isneginf(gs[:, 3:]).all()
+    assert gi[0, :3].tolist() == oracle.exact_knn(x[:3], ids[:3], x[0], 8)["id"].tolist()
+    # a dense neighbourhood: more rows within the bracket of the k-th than the candidate buffer holds -> all-exact kernels
+    N = 20000
+    y = np.tile(util.corpus(1).numpy(), (N, 1))
+    y[::2] *= np.float32(1.0 - 1e-7)
+    yid = np.arange(1, N + 1, dtype=np.int32)
+    idx2 = gpu.VectorIndex(yid, y)
+    gi, gs = idx2.search(y[:2], 5)
+    for qi in range(2):
+        exp = oracle.exact_knn(y, yid, y[qi], 5)
+        assert gi[qi].tolist() == exp["id"].tolist()
+        assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32))
+    # a query that is not finite: the all-exact kernels answer (same bits as before)
+    bad = y[:1].copy(); bad[0, 7] = np.inf
+    idx2.set_option("exact_filter", 0)
+    hi, hs = idx2.search(bad, 5)
+    idx2.set_option("exact_filter", -1)
+    gi, gs = idx2.search(bad, 5)
+    assert np.array_equal(gi, hi) and np.array_equal(gs.view(np.uint32), hs.view(np.uint32))
+    idx2.close()
+    idx.close()
+
+
 @pytest.mark.parametrize("K,m", [(256, 12), (1024, 12), (32, 30)])
 def test_encode_matches_oracle(gpu, oracle, K, m):
     """Next row 8f-2, encoding step of the index build: cells and PQ codes bit-identical to the oracle

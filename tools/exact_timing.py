@@ -30,6 +30,17 @@ for Q in (1, 8, 64, 1024):
                     "algorithmic_GBps": round(Q * N * 1200 / dt / 1e9, 1),
                     "valu_Tlaneops": round(Q * N * 600 / dt / 1e12, 2)}
     idx.profile_enable(False)
+if os.environ.get("FAKE") == "1":   # timing experiment: coalesced (lane-linear) row loads, results are garbage
+    idx.set_option("exact_fake_coalesced", 1)
+    for Q in (1, 64):
+        idx.search(qs[:Q], 5)
+        idx.profile_enable(True)
+        for _ in range(3):
+            idx.search(qs[:Q], 5)
+        prof = idx.profile_read()
+        out[f"FAKE_Q{Q}"] = {k: round(v[1] / v[0] * 1e3, 1) for k, v in prof.items()}
+        idx.profile_enable(False)
+    idx.set_option("exact_fake_coalesced", 0)
 sub = rng.choice(ids, 100000, replace=False).astype(np.int32)
 t0 = time.perf_counter(); idx.search(qs[:64], 5, subset_ids=sub); out["subset_100k_Q64_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
 o = Oracle()
