@@ -93,6 +93,9 @@ struct Tuning {
                                // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
   int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
+  int direct = 0;              // FREDDY_GPU_DIRECT: the integer-slab scan claims static (cell, chunk) units and reads record slots the probe plan filled --
+                               // no work-table / record kernels in a batch's chain (fused5.h): 0 never (the default: measured no faster, profiles/HISTORY.md
+                               // round 4), -1 = dense first rounds, 1 whenever possible
   int exact_filter = -1;       // FREDDY_GPU_EXACT_FILTER: exact kNN as MFMA filter + exact refine (exact2.h): -1 auto (tables of >= 8192 rows, k <= 32), 0 never, 1 always
   int exact_refine_all = 0;    // tests: every row is refined (exhaustive check of the similarity bracket)
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
@@ -127,6 +130,7 @@ static Tuning read_tuning() {
   t.fuse_table = (int)env_int("FREDDY_GPU_FUSE_TABLE", t.fuse_table);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.exact_filter = (int)env_int("FREDDY_GPU_EXACT_FILTER", t.exact_filter);
+  t.direct = (int)env_int("FREDDY_GPU_DIRECT", t.direct);
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
   t.filter_table_mb = env_int("FREDDY_GPU_FILTER_TABLE_MB", t.filter_table_mb);
@@ -165,7 +169,7 @@ struct Workspace {
   hipEvent_t ev_in = nullptr, ev_fe = nullptr, ev_scan = nullptr, ev_out = nullptr;
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs;
   void release_partition() {
     if (fe_stream) { (void)hipStreamSynchronize(fe_stream); (void)hipStreamDestroy(fe_stream); fe_stream = nullptr; }
     if (scan_stream) { (void)hipStreamSynchronize(scan_stream); (void)hipStreamDestroy(scan_stream); scan_stream = nullptr; }
@@ -181,7 +185,7 @@ struct Workspace {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -209,6 +213,7 @@ struct IvfRun {
   bool zeroed;         // the coarse kernel has cleared the round-one scratch (ZeroArgs): no memsets in round one
   bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
   bool qc_pending;     // the query x codebook table is being built on the side stream
+  bool direct;         // round one without work-table / record kernels (fused5.h DIRECT mode)
   // per round
   int n_active, round;
   const int32_t* active;
@@ -268,6 +273,8 @@ struct freddy_gpu_index {
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
+  int32_t* scan_units = nullptr;  // IVF: [n_scan_units][4] static (cell, chunk) units of the scan's DIRECT mode, longest first
+  int n_scan_units = 0;
   uint32_t* packed = nullptr;   // [blocks][M2][64]
   int32_t* pos = nullptr;       // [blocks*64]
   int32_t* ids = nullptr;       // PQ: [N] position -> id
@@ -392,7 +399,7 @@ static void free_index(freddy_gpu_index* ix) {
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   for (auto& kv : ix->prof)
@@ -526,6 +533,37 @@ static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off
   return 0;
 }
 
+// The scan's DIRECT mode (fused5.h): one unit per (cell, 4096-row chunk) of every non-empty list, longest first -- what the
+// work table's longest-processing-time order is made of when every cell holds items.  (Re)built whenever the lists change.
+static int build_scan_units(freddy_gpu_index* ix) {
+  const int C = ix->C;
+  if (ix->scan_units) { (void)hipFree(ix->scan_units); ix->scan_units = nullptr; ix->n_scan_units = 0; }
+  if (C <= 0 || C >= (1 << 24) || (int)ix->h_list_off.size() != C + 1) return 0;
+  struct U { int32_t w[4]; int rows; };
+  std::vector<U> us;
+  int64_t b = 0;
+  for (int c = 0; c < C; ++c) {
+    const int64_t len = (int64_t)ix->h_list_off[(size_t)c + 1] - ix->h_list_off[(size_t)c];
+    const int64_t nblk = (len + 63) / 64;
+    for (int64_t ch = 0; ch * FUSED_UNIT_BLOCKS < nblk; ++ch) {
+      if (ch > 255) return 0;   // (never: the cell-grouped scans take lists of <= 8 chunks)
+      const int nb = (int)std::min<int64_t>(FUSED_UNIT_BLOCKS, nblk - ch * FUSED_UNIT_BLOCKS);
+      const int rows = (int)std::min<int64_t>((int64_t)FUSED_UNIT_BLOCKS * 64, len - ch * FUSED_UNIT_BLOCKS * 64);
+      U u;
+      u.w[0] = c | (int32_t)((uint32_t)ch << 24); u.w[1] = (int32_t)(b + ch * FUSED_UNIT_BLOCKS); u.w[2] = nb | (rows << 8); u.w[3] = 0; u.rows = rows;
+      us.push_back(u);
+    }
+    b += nblk;
+  }
+  std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.rows > y.rows; });
+  std::vector<int32_t> flat(us.size() * 4);
+  for (size_t i = 0; i < us.size(); ++i) memcpy(&flat[i * 4], us[i].w, 16);
+  if (flat.empty()) return 0;
+  if (upload(&ix->scan_units, flat.data(), flat.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
+  ix->n_scan_units = (int)us.size();
+  return 0;
+}
+
 // Kernels that want more than the default 64 KiB of dynamic LDS: the limit is a per-device function
 // attribute, so it is raised once for every device an index is pinned on.
 static int raise_lds_limits(int device) {
@@ -544,6 +582,8 @@ static int raise_lds_limits(int device) {
       (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>,
+      (const void*)&ivf_filter5_kernel<12, true, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, false, false, true>,
+      (const void*)&ivf_filter5_kernel<12, true, true, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, true>,
       (const void*)&exf_filter_kernel<1, false>, (const void*)&exf_filter_kernel<2, false>, (const void*)&exf_filter_kernel<1, true>,
       (const void*)&exf_filter_kernel<2, true>};
   for (const void* k : kernels)
@@ -779,6 +819,7 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
     if (!rc) { ix->h_coarse.assign(t->coarse, t->coarse + (size_t)t->C * t->d); rc = derive_codebook_tables(ix, t->codebook); }
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
+  if (!rc) rc = build_scan_units(ix);
   if (!rc) rc = refresh_row_terms(ix);   // one float per row slot: the (cell, row) part of the filter's cheap distance
   if (!rc) {
     if (ix->rterm) ix->bytes += (int64_t)sizeof(float) * std::max<int64_t>(ix->n_blocks, 1) * 64;
@@ -941,6 +982,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "debug_surv") t.debug_surv = (int)value;
   else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
   else if (n == "exact_filter") t.exact_filter = (int)value;
+  else if (n == "direct") t.direct = (int)value;
   else if (n == "exact_refine_all") t.exact_refine_all = (int)value;
   else return fail(FREDDY_E_ARG, "unknown option '%s'", name);
   return FREDDY_OK;
@@ -1155,6 +1197,11 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
     Plan2Args g;
     g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ws->w_qn2.as<float>(); g.item_dist = pa.item_dist;
     g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all; g.prof = nullptr;
+    g.drecs = nullptr; g.qn = nullptr; g.qscale = nullptr; g.pmax = nullptr; g.submax = 0; g.sentinel = r.sentinel;
+    if (r.direct && r.first()) {
+      g.drecs = ws->w_drecs.as<int32_t>(); g.qn = ws->w_qn.as<float>(); g.qscale = ws->w_qn.as<float>() + (size_t)r.Q * ix->m;
+      g.pmax = ix->pmax; g.submax = (r.n_active + SCAN5_G - 1) / SCAN5_G;
+    }
     timed_launch(ix, s, "probe_plan", [&] {
       if (ix->Cpad <= COARSE_MAX_CPAD) hipLaunchKernelGGL((probe_plan2_kernel<0, false>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);
       else hipLaunchKernelGGL((probe_plan2_kernel<0, true>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);   // (more than 1024 cells: streamed)
@@ -1248,27 +1295,32 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   hipStream_t s = r.s;
   const int Q = r.Q, m = ix->m, K = ix->K;
   const bool v5 = r.scan_kernel == 5;
-  if (ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (!(r.direct && r.first()) && ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
   ra.sorted_item = ws->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
   ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
   ra.records = ws->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
   if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ws->ev_qc, 0)); r.qc_pending = false; }
+  const bool direct = r.direct && r.first();
+  if (!direct) {
   timed_launch(ix, s, "entry_records", [&] {
     if (v5) hipLaunchKernelGGL((entry_record5_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
     else hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
   });
   HIP_TRY(hipGetLastError());
+  }
   FilterArgs fl;
   fl.qc = ws->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ws->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
   fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
   fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.ablate = ix->tune.scan_ablate;
+  fl.units = direct ? ix->scan_units : nullptr; fl.n_units = direct ? ix->n_scan_units : 0; fl.cell_count = ws->w_cellcnt.as<int32_t>();
+  fl.drecs = direct ? ws->w_drecs.as<int32_t>() : nullptr; fl.submax = (r.n_active + SCAN5_G - 1) / SCAN5_G;
   if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
   // slabs: [2 buffers][K][12 items] fp32, or [2 buffers][2 positions][K][16 items] int16 (fused5.h)
   const size_t desc_off = v5 ? (size_t)4 * SCAN5_G * 2 * K : (((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15);
-  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
+  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float) + (v5 ? DQ_INTS * sizeof(int32_t) : 0);
   fl.desc_offset = (uint32_t)desc_off;
   // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
   const bool parted = r.s_scan != s;
@@ -1295,7 +1347,13 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     HIP_TRY(hipStreamWaitEvent(ss, ws->ev_fe, 0));
   }
   timed_launch(ix, ss, "ivf_filter", [&] {
-    if (v5) {
+    if (v5 && direct) {
+      if (fl.cand_count) {
+        if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+        else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+    } else if (v5) {
       // (four instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is
       // larger than the instruction cache as it is)
       if (fl.cand_count) {
@@ -1461,12 +1519,19 @@ static int partition_streams(freddy_gpu_index* ix, Workspace* ws) {
   return 0;
 }
 
+static int ix_units(const IvfRun& r) { return r.ix->n_scan_units; }
 // One probing round of a chunk: cell selection, then the scan + merge of the path the chunk takes.
 static int ivfadc_round(IvfRun& r) {
   PlanArgs pa;
   if (int rc = ivf_plan(r, pa)) return rc;
   if (r.fused) {
     WorkTable wt;
+    if (r.direct && r.first()) {   // no work table: the scan claims static units (fused5.h DIRECT mode)
+      wt.max_groups = (size_t)ix_units(r); wt.group_cell = wt.group_first = wt.group_cnt = nullptr;
+      wt.n_groups = r.ws->w_cnt.as<int32_t>() + 1; wt.work_counter = r.ws->w_cnt.as<int32_t>() + 2;
+      wt.sp_cap = 0; wt.sp_cell = wt.sp_first = wt.sp_chunk = nullptr; wt.n_sparse = r.ws->w_cnt.as<int32_t>() + 4; wt.sp_counter = r.ws->w_cnt.as<int32_t>() + 3;
+      return ivf_scan_filter(r, pa, wt);
+    }
     if (int rc = ivf_work_table(r, wt)) return rc;
     return (r.scan_kernel >= 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt);
   }
@@ -1508,8 +1573,20 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : ix->tune.scan_kernel == 5 ? 5 : 4;
   r.tiled = Q >= 32;
   r.zeroed = r.tiled || ix->d <= 1024;
+  r.direct = false;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_STREAM_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
+  // DIRECT mode of the scan (no work-table / record kernels): round one of a DENSE batch -- (almost) every cell holds items,
+  // so the static unit list has no holes worth a table -- with the MFMA cell selection (whose plan kernel writes the slots)
+  {
+    const size_t submax = ((size_t)Q + SCAN5_G - 1) / SCAN5_G;
+    const size_t drec_bytes = sizeof(int32_t) * (size_t)C * submax * DREC_DW;
+    const bool sparse_batch = items < 4 * (size_t)C;
+    r.direct = r.fused && r.scan_kernel == 5 && r.approx && ix->tune.fuse_table && ix->scan_units && ix->n_scan_units > 0 && !ix->shadow_of &&
+               ix->tune.direct != 0 && (ix->tune.direct == 1 || !sparse_batch) && drec_bytes <= ((size_t)512 << 20) &&
+               !ix->tune.scan_prof && ix->tune.scan_quota == 0 && ix->tune.sparse_items >= 0;
+    if (r.direct && ws->w_drecs.ensure(drec_bytes)) return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+  }
   // CU partition: only for the filter + refine scan, whose persistent workgroups take whole CUs
   r.s_caller = s;
   r.s_scan = s;
@@ -2033,7 +2110,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   IvfRun r;
   r.ix = fx; r.ws = ws; r.s = s; r.s_scan = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = lists; r.L = 2 * k;
   r.sentinel = sentinel; r.cell_limit = 0.0f; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = nullptr;
-  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false; r.qc_pending = false;
+  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false; r.qc_pending = false; r.direct = false;
   r.n_active = Q; r.round = 0; r.active = nullptr;
   r.share = std::max(1, ix->tune.scan_share);   // (the caller's contract: its batches in flight on this handle)
   r.s_caller = s;
@@ -2597,6 +2674,7 @@ static int append_packed_rows(freddy_gpu_index* ix, int n_lists, int64_t n, cons
   ix->max_list_blocks = max_blocks;
   ix->h_list_off = new_list_off;
   ix->N += n;
+  if (ix->kind == KIND_IVF && !ix->shadow_of) return build_scan_units(ix);
   return 0;
 }
 

@@ -52,6 +52,12 @@ struct FilterArgs {
   // Quota-limited workgroups (fused5.h): the first `quota_wgs` workgroups of the grid stop after `quota` work entries;
   // the rest are persistent and drain the table.  quota_wgs = 0: every workgroup persistent.
   int quota, quota_wgs;
+  // DIRECT mode of the integer-slab scan (fused5.h): static (cell, chunk) units, the cells' item counts of this batch, the
+  // static record slots the probe plan filled, record slots per cell
+  const int32_t* units;        // [n_units][4]: cell | chunk << 24, first row block, row blocks | rows << 8, 0
+  const int32_t* cell_count;   // [C]
+  const int32_t* drecs;        // [C][submax][DREC_DW]
+  int n_units, submax;
 };
 
 static constexpr float FILT_EPS = 2048.0f * 5.9604644775390625e-8f * 1.0001f;   // E = FILT_EPS * B

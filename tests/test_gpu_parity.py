@@ -96,6 +96,31 @@ def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
     idx.close()
 
 
+@pytest.mark.parametrize("C,Q,W,k,rule", [(32, 200, 4, 5, 0), (32, 200, 1, 3, 1), (32, 64, 2, 32, 0), (3, 300, 2, 5, 0), (128, 48, 3, 5, 0), (32, 1000, 6, 5, 2)])
+def test_scan_direct_mode_equals_the_work_table_path(gpu, oracle, C, Q, W, k, rule):
+    """fused5.h DIRECT mode: the scan's workgroups claim static (cell, chunk) units and cut them into entries from the cells'
+    item counts; the record fields come from static slots the probe plan filled -- no work-table and no record kernel.
+    Same lists as the work-table path and as the oracle: cells with several entries (hundreds of items), lists of two
+    chunks (C = 3: ~6 700 rows), mostly EMPTY cells (48 queries x 3 probes over 128 cells: bubbles of the unit pipeline),
+    both found rules and the batch UDF's rule."""
+    N = 20000
+    t = util.ivf_tables(N=N, C=C, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx.set_option("fused", 1)
+    _, qs = util.queries_from_corpus(N, Q)
+    W_ = 1 if rule == 2 else W
+    sentinel = 1000.0 if rule == 0 else 100.0
+    fr = {0: gpu.FOUND_ROWS, 1: gpu.FOUND_ACCEPTED, 2: gpu.FOUND_BATCH_UDF}[rule]
+    exp = oracle.ivfadc_batch_search(ot, qs, k) if rule == 2 else oracle.ivfadc_search_many(ot, qs, k, W_, sentinel=sentinel, found_rule=rule)
+    for direct in (1, 0):
+        idx.set_option("direct", direct)
+        gi, gd = idx.search(qs, k, W_, sentinel=sentinel, found_rule=fr)
+        util.assert_same_lists(gi, gd, exp, f"direct={direct} C={C} Q={Q} W={W_} k={k} rule={rule}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_ivfadc_batch_udf_semantics(gpu, oracle, fused, monkeypatch):
     """W=1, sentinel 100.0, found = accepted insertions == ivfadc_batch_search (freddy.c:679-999)."""
