@@ -2699,6 +2699,7 @@ extern "C" int freddy_gpu_append_rows(freddy_gpu_index_t* ix, int64_t n, const i
   }
   HIP_TRY(hipSetDevice(ix->device));
   HIP_TRY(hipStreamSynchronize(ix->stream));
+  if (ix->kind == KIND_IVPQ) ix->join.tl_valid = false;   // (the cached "id IN (targets)" resolution refers to the rows as they were)
   const int32_t last_id = ix->kind == KIND_IVPQ ? (ix->join.h_ids.empty() ? -1 : ix->join.h_ids.back())
                           : ix->kind == KIND_IVF ? ix->max_id : (ix->h_ids.empty() ? -1 : ix->h_ids.back());
   for (int64_t i = 0; i < n; ++i)

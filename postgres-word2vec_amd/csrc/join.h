@@ -95,6 +95,10 @@ struct JoinIndex {
   std::vector<int32_t> h_ids, h_cell;
   std::vector<float> h_stats;
   bool ids_affine = false;       // ids[r] == ids[0] + r: O(1) id -> row
+  // "fq.id IN (targets)" of the previous call: the same target array (compared word for word) finds its rows resolved,
+  // de-duplicated and bucketed by cell already (workspaces 2 and 3 stay as they are); invalidated when rows are appended
+  std::vector<int32_t> tl_ids, tl_tcell_off;
+  bool tl_valid = false;
   // workspaces
   void* w[16] = {nullptr};
   size_t wcap[16] = {0};
@@ -212,8 +216,10 @@ __global__ __launch_bounds__(64) void sub_dist_kernel(const float* __restrict__ 
 // distances; equal distances keep their code order): key = (distance bits << 32 | code), one wave per
 // (query, position).  Kc <= 64 * V.
 template <int V>
-__global__ __launch_bounds__(64) void side_sort_kernel(const float* __restrict__ sub, u64* __restrict__ sorted, int Kc) {
-  const size_t row = (size_t)blockIdx.x;   // (query * 2 + position)
+__global__ __launch_bounds__(64) void side_sort_kernel(const float* __restrict__ sub, u64* __restrict__ sorted, int Kc,
+                                                      const int32_t* __restrict__ only = nullptr) {
+  // (query * 2 + position); `only`: the queries to sort (a handful that the device traversal handed back)
+  const size_t row = only ? (size_t)only[blockIdx.x >> 1] * 2 + (blockIdx.x & 1) : (size_t)blockIdx.x;
   const int lane = threadIdx.x;
   u64 key[V];
 #pragma unroll
@@ -917,7 +923,12 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       join_buf(j, 10, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_win) ||
       join_buf(j, 11, sizeof(int32_t) * (size_t)cells * 2, &d_cnt) || join_buf(j, 12, sizeof(u64) * (size_t)Q * 2 * Kc, &d_sorted))
     return FREDDY_E_NOMEM;
-  {
+  const bool tl_hit = j->tl_valid && (int64_t)j->tl_ids.size() == n_targets && (int)j->tl_tcell_off.size() == cells + 1 &&
+                      (n_targets == 0 || memcmp(j->tl_ids.data(), target_ids, sizeof(int32_t) * (size_t)n_targets) == 0);
+  if (tl_hit) {
+    tcell_off = j->tl_tcell_off;    // (d_tcell / d_trow still hold this target array's buckets)
+  } else {
+    j->tl_valid = false;
     int32_t* cnt = (int32_t*)d_cnt;
     int32_t* fill = cnt + cells;
     JOIN_HIP(hipMemsetAsync(j->markbits, 0, sizeof(uint32_t) * (size_t)((j->N + 31) / 32 + 1), s));
@@ -934,6 +945,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
                          (int)n_targets, (const int32_t*)j->cell, fill, (int32_t*)d_trow);
     JOIN_HIP(hipGetLastError());
     JOIN_HIP(hipMemcpyAsync(tcell_off.data(), d_tcell, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToHost, s));
+    j->tl_ids.assign(target_ids, target_ids + n_targets);   // (becomes valid once the offsets have arrived: first synchronisation below)
   }
   track(&freddy_track::data_retrieval_time);   // "fq.id IN (targets)" (enqueue only: the device work overlaps what follows)
   {   // queries: host copy into pinned staging, read by a copy kernel (1.2 KB per query over PCIe)
@@ -963,32 +975,67 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   const int TV = join_pick_V(cells);
   std::vector<float> sub;
   std::vector<JoinSide> sides;   // per-query sorted sides (they do not depend on alpha)
-  bool host_sides = false;
-  auto fetch_sides = [&]() -> int {     // the host heap's inputs: sub-distances and their stable per-side order
-    if (host_sides) return 0;
-    sub.resize((size_t)Q * 2 * Kc);
-    sides.resize((size_t)Q * 2 * Kc);
+  std::vector<int32_t> side_slot;   // query -> its rows in sub / sides (-1: not fetched)
+  bool host_sides_all = false;
+  auto sort_sides = [&](unsigned rows, const int32_t* only) {
     switch (SV) {
-      case 1: hipLaunchKernelGGL((side_sort_kernel<1>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-      case 2: hipLaunchKernelGGL((side_sort_kernel<2>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-      case 4: hipLaunchKernelGGL((side_sort_kernel<4>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-      case 8: hipLaunchKernelGGL((side_sort_kernel<8>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
-      default: hipLaunchKernelGGL((side_sort_kernel<16>), dim3((unsigned)Q * 2), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc); break;
+      case 1: hipLaunchKernelGGL((side_sort_kernel<1>), dim3(rows), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc, only); break;
+      case 2: hipLaunchKernelGGL((side_sort_kernel<2>), dim3(rows), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc, only); break;
+      case 4: hipLaunchKernelGGL((side_sort_kernel<4>), dim3(rows), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc, only); break;
+      case 8: hipLaunchKernelGGL((side_sort_kernel<8>), dim3(rows), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc, only); break;
+      default: hipLaunchKernelGGL((side_sort_kernel<16>), dim3(rows), dim3(64), 0, s, (const float*)d_sub, (u64*)d_sorted, Kc, only); break;
     }
-    JOIN_HIP(hipGetLastError());
+  };
+  // the host heap's inputs -- sub-distances and their stable per-side order -- for the queries of `need`: all queries at
+  // once when many are asked for, else just those (the device traversal hands back a query or two per call: sorting and
+  // copying 5 000 queries' sides for them cost 0.2 ms)
+  auto fetch_sides = [&](const std::vector<int32_t>& need) -> int {
+    if (host_sides_all) return 0;
     static_assert(sizeof(JoinSide) == 8, "side_sort_kernel writes JoinSide records");
-    JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
-    JOIN_HIP(hipMemcpyAsync(sides.data(), d_sorted, sizeof(JoinSide) * sides.size(), hipMemcpyDeviceToHost, s));
+    std::vector<int32_t> miss;
+    for (int32_t q : need) if (side_slot.empty() || side_slot[(size_t)q] < 0) miss.push_back(q);
+    if (miss.empty()) return 0;
+    const size_t row = (size_t)2 * Kc;
+    if (miss.size() * 8 > (size_t)Q) {
+      sub.resize((size_t)Q * row);
+      sides.resize((size_t)Q * row);
+      sort_sides((unsigned)Q * 2, nullptr);
+      JOIN_HIP(hipGetLastError());
+      JOIN_HIP(hipMemcpyAsync(sub.data(), d_sub, sizeof(float) * sub.size(), hipMemcpyDeviceToHost, s));
+      JOIN_HIP(hipMemcpyAsync(sides.data(), d_sorted, sizeof(JoinSide) * sides.size(), hipMemcpyDeviceToHost, s));
+      JOIN_HIP(hipStreamSynchronize(s));
+      side_slot.resize((size_t)Q);
+      for (int q = 0; q < Q; ++q) side_slot[(size_t)q] = q;
+      host_sides_all = true;
+      return 0;
+    }
+    if (side_slot.empty()) side_slot.assign((size_t)Q, -1);
+    const size_t base = sub.size() / row;
+    sub.resize((base + miss.size()) * row);
+    sides.resize((base + miss.size()) * row);
+    JOIN_HIP(hipMemcpyAsync(d_scan, miss.data(), sizeof(int32_t) * miss.size(), hipMemcpyHostToDevice, s));   // (the scan list goes into this buffer later, in stream order)
+    sort_sides((unsigned)miss.size() * 2, (const int32_t*)d_scan);
+    JOIN_HIP(hipGetLastError());
+    for (size_t i = 0; i < miss.size(); ++i) {
+      JOIN_HIP(hipMemcpyAsync(sub.data() + (base + i) * row, (const float*)d_sub + (size_t)miss[i] * row, sizeof(float) * row, hipMemcpyDeviceToHost, s));
+      JOIN_HIP(hipMemcpyAsync(sides.data() + (base + i) * row, (const JoinSide*)d_sorted + (size_t)miss[i] * row, sizeof(JoinSide) * row, hipMemcpyDeviceToHost, s));
+    }
     JOIN_HIP(hipStreamSynchronize(s));
-    host_sides = true;
+    for (size_t i = 0; i < miss.size(); ++i) side_slot[(size_t)miss[i]] = (int32_t)(base + i);
     return 0;
   };
-  if (!dev_trav) { if (int rc = fetch_sides()) return rc; }
+  std::vector<int32_t> all_queries;
+  if (!dev_trav) {
+    all_queries.resize((size_t)Q);
+    for (int i = 0; i < Q; ++i) all_queries[(size_t)i] = i;
+    if (int rc = fetch_sides(all_queries)) return rc;
+  }
   // pinned landing zone: [Q][TRAV_SUM_DW] traversal summaries, [Q][k] ids, [Q][k] distances
   void *d_active = nullptr, *d_qstrided = nullptr, *d_qcnt = nullptr, *d_summary = nullptr;
-  int32_t* h_summary = nullptr; int32_t* h_oi_p = nullptr; float* h_od_p = nullptr;
+  int32_t* h_summary = nullptr; int32_t* h_oi_p = nullptr; float* h_od_p = nullptr; int32_t* h_active = nullptr; int32_t* h_scan = nullptr;
+  int32_t* p_summary = nullptr; int32_t* p_oi = nullptr; float* p_od = nullptr; int32_t* p_active = nullptr; int32_t* p_scan = nullptr;   // the same block as the device sees it
   {
-    const size_t need = sizeof(int32_t) * (size_t)Q * (TRAV_SUM_DW + 2 * (size_t)k) + 64;
+    const size_t need = sizeof(int32_t) * (size_t)Q * (TRAV_SUM_DW + 2 * (size_t)k + 2) + 64;   // + the active list and the scan list
     if (need > j->h_sum_cap) {
       if (j->h_sum) (void)hipHostFree(j->h_sum);
       j->h_sum = nullptr; j->h_sum_cap = 0;
@@ -998,6 +1045,18 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     h_summary = static_cast<int32_t*>(j->h_sum);
     h_oi_p = h_summary + (size_t)Q * TRAV_SUM_DW;
     h_od_p = reinterpret_cast<float*>(h_oi_p + (size_t)Q * k);
+    h_active = reinterpret_cast<int32_t*>(h_od_p + (size_t)Q * k);
+    h_scan = h_active + Q;
+    // The kernels read the lists and write summaries / results in this pinned block DIRECTLY (it is mapped into the device's
+    // address space): every hipMemcpyAsync between two kernels of a stream is an SDMA copy ordered against them by signals,
+    // ~12 us per hop, and a round had five of them.
+    void* dp = nullptr;
+    JOIN_HIP(hipHostGetDevicePointer(&dp, j->h_sum, 0));
+    p_summary = static_cast<int32_t*>(dp);
+    p_oi = p_summary + (size_t)Q * TRAV_SUM_DW;
+    p_od = reinterpret_cast<float*>(p_oi + (size_t)Q * k);
+    p_active = reinterpret_cast<int32_t*>(p_od + (size_t)Q * k);
+    p_scan = p_active + Q;
   }
   if (dev_trav) {
     if (join_buf(j, 13, sizeof(int32_t) * (size_t)Q, &d_active) || join_buf(j, 14, sizeof(int32_t) * (size_t)Q * cells, &d_qstrided) ||
@@ -1024,7 +1083,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   auto launch_traverse = [&](int n_act, int min_target) -> int {
     TravArgs ta;
     ta.sub = (const float*)d_sub; ta.active = (const int32_t*)d_active; ta.stats = j->d_stats; ta.tcell_off = (const int32_t*)d_tcell;
-    ta.qcells = (int32_t*)d_qstrided; ta.qcell_cnt = (int32_t*)d_qcnt; ta.summary = (int32_t*)d_summary;
+    ta.qcells = (int32_t*)d_qstrided; ta.qcell_cnt = (int32_t*)d_qcnt; ta.summary = p_summary;
     ta.Kc = Kc; ta.cells = cells; ta.n_targets = (int)n_targets; ta.min_target = min_target; ta.confidence = confidence;
     switch (TV) {
       case 1: hipLaunchKernelGGL((join_traverse_kernel<1>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
@@ -1034,7 +1093,6 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       default: hipLaunchKernelGGL((join_traverse_kernel<16>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
     }
     JOIN_HIP(hipGetLastError());
-    JOIN_HIP(hipMemcpyAsync(h_summary, d_summary, sizeof(int32_t) * (size_t)n_act * TRAV_SUM_DW, hipMemcpyDeviceToHost, s));
     return 0;
   };
   while (!active.empty()) {                                                                 // :299
@@ -1044,7 +1102,10 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     std::vector<int32_t> fb;                            // queries the host heap has to traverse
     if (dev_trav) {
       // (the list on the device is this round's in any case: the traversal launched behind this round's join reads it)
-      JOIN_HIP(hipMemcpyAsync(d_active, active.data(), sizeof(int32_t) * n_active, hipMemcpyHostToDevice, s));
+      // (lists go host -> pinned -> a copy kernel: a workgroup that reads its query number over PCIe starts 2 us late, 20 workgroups
+      // deep per CU that was +70 us on the join kernel; nothing of the previous round is in flight: it ended with a synchronisation)
+      memcpy(h_active, active.data(), sizeof(int32_t) * (size_t)n_active);
+      hipLaunchKernelGGL(join_copy_kernel, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, s, (const uint32_t*)p_active, (uint32_t*)d_active, (size_t)n_active);
       if (!spec_valid) {
         if (int rc = launch_traverse(n_active, min_target)) return rc;
         JOIN_HIP(hipStreamSynchronize(s));
@@ -1077,15 +1138,16 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       fb = active;
     }
     if (!fb.empty()) {
-      if (int rc = fetch_sides()) return rc;
+      if (int rc = fetch_sides(fb)) return rc;
       for (int q : fb) q_host[q] = 1;
       join_parallel_for((int)fb.size(), [&](int lo, int hi, int) {                            // :327-331
         JoinTraversal w;
         for (int x = lo; x < hi; ++x) {
           const int q = fb[x];
           qcells[q].clear();
-          const bool exhausted = join_select_cells(sides.data() + ((size_t)q * 2) * Kc, sides.data() + ((size_t)q * 2 + 1) * Kc,
-                                                   sub.data() + ((size_t)q * 2) * Kc, sub.data() + ((size_t)q * 2 + 1) * Kc, Kc,
+          const size_t sl = (size_t)side_slot[(size_t)q];
+          const bool exhausted = join_select_cells(sides.data() + (sl * 2) * Kc, sides.data() + (sl * 2 + 1) * Kc,
+                                                   sub.data() + (sl * 2) * Kc, sub.data() + (sl * 2 + 1) * Kc, Kc,
                                                    j->h_stats.data(), (int)n_targets, min_target, confidence, w, qcells[q]);
           q_exh[q] = exhausted ? 1 : 0;
           int64_t cnt = 0;
@@ -1115,7 +1177,8 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     scan.insert(scan.end(), scan_fb.begin(), scan_fb.end());
     track(&freddy_track::query_construction_time);
     if (n_scan > 0) {
-      JOIN_HIP(hipMemcpyAsync(d_scan, scan.data(), sizeof(int32_t) * n_scan, hipMemcpyHostToDevice, s));
+      memcpy(h_scan, scan.data(), sizeof(int32_t) * (size_t)n_scan);
+      hipLaunchKernelGGL(join_copy_kernel, dim3((unsigned)((n_scan + 255) / 256)), dim3(256), 0, s, (const uint32_t*)p_scan, (uint32_t*)d_scan, (size_t)n_scan);
       JoinArgs a;
       a.queries = (const float*)d_q; a.tcell_off = (const int32_t*)d_tcell; a.trow = (const int32_t*)d_trow;
       a.ids = j->ids; a.codes = j->codes; a.MP = j->MP; a.vectors = j->vectors; a.cbT = j->cbT;
@@ -1124,7 +1187,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       JOIN_HIP(hipEventRecord(j->ev0, s));
       if (n_dev > 0) {     // cell lists written by the traversal kernel: row q of [Q][cells]
         a.scan_query = (const int32_t*)d_scan; a.qcell_off = nullptr; a.qcell_cnt = (const int32_t*)d_qcnt; a.qstride = cells;
-        a.qcells = (const int32_t*)d_qstrided; a.out_ids = (int32_t*)d_oi; a.out_dist = (float*)d_od;
+        a.qcells = (const int32_t*)d_qstrided; a.out_ids = p_oi; a.out_dist = p_od;
         if (int rc = join_launch(s, a, n_dev, V, lds)) return rc;
       }
       if (n_fb > 0) {      // host-traversed queries: flat lists with offsets
@@ -1132,7 +1195,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
         JOIN_HIP(hipMemcpyAsync(d_qoff, qoff.data(), sizeof(int32_t) * (n_fb + 1), hipMemcpyHostToDevice, s));
         if (!flat.empty()) JOIN_HIP(hipMemcpyAsync(d_qcells, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, s));
         a.scan_query = (const int32_t*)d_scan + n_dev; a.qcell_off = (const int32_t*)d_qoff; a.qcell_cnt = nullptr; a.qstride = 0;
-        a.qcells = (const int32_t*)d_qcells; a.out_ids = (int32_t*)d_oi + (size_t)n_dev * k; a.out_dist = (float*)d_od + (size_t)n_dev * k;
+        a.qcells = (const int32_t*)d_qcells; a.out_ids = p_oi + (size_t)n_dev * k; a.out_dist = p_od + (size_t)n_dev * k;
         if (int rc = join_launch(s, a, n_fb, V, lds)) return rc;
       }
       JOIN_HIP(hipEventRecord(j->ev1, s));
@@ -1141,8 +1204,6 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
         for (int x = 0; x < n_active; ++x) spec_index[(size_t)active[x]] = x;
         spec_valid = true;
       }
-      JOIN_HIP(hipMemcpyAsync(h_oi_p, d_oi, sizeof(int32_t) * (size_t)n_scan * k, hipMemcpyDeviceToHost, s));
-      JOIN_HIP(hipMemcpyAsync(h_od_p, d_od, sizeof(float) * (size_t)n_scan * k, hipMemcpyDeviceToHost, s));
       JOIN_HIP(hipStreamSynchronize(s));
       { float ms = 0.0f; if (hipEventElapsedTime(&ms, j->ev0, j->ev1) == hipSuccess) j->track.join_kernel_time += 1e-3 * ms; }
       for (int x = 0; x < n_scan; ++x) {
@@ -1166,6 +1227,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     alpha += alpha;                                                                         // :680
     track(&freddy_track::recalculate_query_indices_time);
   }
+  if (!tl_hit) { j->tl_tcell_off = tcell_off; j->tl_valid = true; }   // (the offsets arrived with the first synchronisation)
   j->track.iterations = iterations;
   j->track.total_time = std::chrono::duration<double>(now() - t_start).count();
   if (iterations_out) *iterations_out = iterations;
