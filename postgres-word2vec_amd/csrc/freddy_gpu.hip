@@ -214,6 +214,8 @@ struct IvfRun {
   bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
   bool qc_pending;     // the query x codebook table is being built on the side stream
   bool direct;         // round one without work-table / record kernels (fused5.h DIRECT mode)
+  bool records_ready;  // a batch over the flat PQ table: the entry records were written by pq_records_kernel (no work-table / record kernels)
+  int merge_slices;    // > 0: the merge of such a batch as `merge_slices` partial merges per query + merge_replay_kernel
   // per round
   int n_active, round;
   const int32_t* active;
@@ -1295,7 +1297,7 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   hipStream_t s = r.s;
   const int Q = r.Q, m = ix->m, K = ix->K;
   const bool v5 = r.scan_kernel == 5;
-  if (!(r.direct && r.first()) && ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (!(r.direct && r.first()) && !r.records_ready && ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
   ra.sorted_item = ws->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
@@ -1303,7 +1305,7 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   ra.records = ws->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
   if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ws->ev_qc, 0)); r.qc_pending = false; }
   const bool direct = r.direct && r.first();
-  if (!direct) {
+  if (!direct && !r.records_ready) {
   timed_launch(ix, s, "entry_records", [&] {
     if (v5) hipLaunchKernelGGL((entry_record5_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
     else hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
@@ -1411,6 +1413,23 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     }
     fprintf(stderr, "[surv] items=%d survivors=%lld (%.2f per item, max %lld), largest region %d\n", n_items, tot,
             (double)tot / std::max(n_items, 1), item_mx, mx);
+  }
+  mr.slices = 0; mr.part = nullptr;
+  if (r.merge_slices > 0) {
+    // a batch over the flat PQ table: `merge_slices` workgroups per query, each over its share of the pseudo-lists (r.W is the
+    // padded item count per query, a multiple of the slices), then merge_replay_kernel over the slices' keys
+    const int SL = r.merge_slices;
+    if (ws->w_part.ensure(sizeof(u64) * (size_t)r.n_active * SL * r.L)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    mr.slices = SL; mr.part = ws->w_part.as<u64>(); mr.W = r.W / SL; mr.n_active = r.n_active * SL;
+    timed_launch(ix, s, "merge_refine", [&] {
+      hipLaunchKernelGGL((merge_refine_kernel<25, 12, 12, true, true>), dim3(r.n_active * SL), dim3(768), 0, s, mr);
+    });
+    HIP_TRY(hipGetLastError());
+    MergeArgs ma;
+    ma.part = ws->w_part.as<u64>(); ma.active = nullptr; ma.pos_to_id = nullptr; ma.round_rows = nullptr; ma.cand_count = nullptr;
+    ma.out_ids = r.d_out_ids; ma.out_dist = r.d_out_dist; ma.found = nullptr; ma.next_active = nullptr; ma.n_next = nullptr; ma.status = nullptr;
+    ma.n_active = r.n_active; ma.parts_per_query = SL; ma.L = r.L; ma.k = r.k; ma.found_rule = 0; ma.first_round = 1; ma.sentinel = r.sentinel;
+    return launch_merge(ix, s, ma);
   }
   timed_launch(ix, s, "merge_refine", [&] {
     // (one batch at a time: four waves per query, the shortest latency; batches in flight: one wave per query, the smallest footprint)
@@ -1573,7 +1592,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : ix->tune.scan_kernel == 5 ? 5 : 4;
   r.tiled = Q >= 32;
   r.zeroed = r.tiled || ix->d <= 1024;
-  r.direct = false;
+  r.direct = false; r.records_ready = false; r.merge_slices = 0;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_STREAM_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
   // DIRECT mode of the scan (no work-table / record kernels): round one of a DENSE batch -- (almost) every cell holds items,
@@ -2042,6 +2061,63 @@ static bool pq_use_fused(const freddy_gpu_index* ix, int Q, int k) {
   if (ix->tune.pq_fused == 0 || !pq_fused_shape(ix) || 2 * k > 64) return false;
   return ix->tune.pq_fused > 0 || Q >= 16;
 }
+// A batch over the flat PQ table needs no probe plan and no work table: every query "probes" every pseudo-list, so the
+// work entries are (group of 16 queries, pseudo-list) and their records follow from the query's table scale alone.  One
+// workgroup per query: |q|^2 in the reference's order (squareDistance(q, 0): the coarse distance of the zero centroid, the
+// bound item_bounds builds on), then the query's lane of every record of its group; the first query of a group also writes
+// the records' headers.  Replaces pq_items + work_table + entry_record kernels (27 us of three dependent launches).
+// item index = q * W + list (W >= lists: padded to a multiple of the merge's slices; the padding items have no entry, their
+// survivor regions stay zero).
+__global__ __launch_bounds__(256) void pq_records_kernel(const float* __restrict__ queries, int Q, int d, int lists, int W, int64_t n_rows,
+                                                        const int32_t* __restrict__ blk_off, const int32_t* __restrict__ list_off,
+                                                        const float* __restrict__ qn, const float* __restrict__ qscale, const float* __restrict__ pmax,
+                                                        float sentinel, int32_t* __restrict__ item_cell, int32_t* __restrict__ item_query,
+                                                        float* __restrict__ item_dist, int32_t* __restrict__ round_rows,
+                                                        int32_t* __restrict__ records, int32_t* __restrict__ n_groups) {
+  __shared__ float sqs[1024];
+  __shared__ float A_s;
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < d; i += 256) { const float t = queries[(size_t)q * d + i] - 0.0f; sqs[i] = t * t; }
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.0f;
+    for (int i = 0; i < d; ++i) acc = acc + sqs[i];     // index_utils.c:500-508, i ascending
+    A_s = acc;
+    round_rows[q] = (int32_t)n_rows;
+    if (q == 0) n_groups[0] = ((Q + SCAN5_G - 1) / SCAN5_G) * lists;
+  }
+  __syncthreads();
+  const float A = A_s;
+  const float sc = qscale[q];
+  const ItemBounds ib = item_bounds(A, filter_width5<12>(qn + (size_t)q * 12, pmax, sc), sentinel);
+  const int g = q / SCAN5_G, slot = q % SCAN5_G;
+  const int cnt = (Q - g * SCAN5_G < SCAN5_G) ? Q - g * SCAN5_G : SCAN5_G;
+  for (int c = tid; c < lists; c += 256) {
+    const int it = q * W + c;
+    item_cell[it] = c; item_query[it] = q; item_dist[it] = A;
+    int32_t* rec = records + ((size_t)g * lists + c) * REC_DW;
+    rec[8 + slot] = it;
+    rec[24 + slot] = q;
+    rec[40 + slot] = (int32_t)__float_as_uint(ib.off);
+    rec[56 + slot] = (int32_t)__float_as_uint(ib.e);
+    rec[72 + slot] = (int32_t)__float_as_uint(ib.shift);
+    rec[88 + slot] = (int32_t)ib.lo_bits;
+    rec[104 + slot] = (int32_t)ib.hi_bits;
+    rec[128 + slot] = (int32_t)__float_as_uint(sc < 1e30f ? sc : 0.0f);
+    if (slot == 0) {
+      const int b0 = blk_off[c];
+      rec[0] = c; rec[1] = cnt; rec[2] = 0; rec[3] = b0; rec[4] = blk_off[c + 1] - b0; rec[5] = list_off[c + 1] - list_off[c];
+      // the slots beyond the group's queries: no item, the first query's number (a valid table), no bounds (entry_record5_kernel)
+      const ItemBounds none = item_bounds(0.0f, 0.0f, sentinel);
+      for (int u = cnt; u < SCAN5_G; ++u) {
+        rec[8 + u] = -1; rec[24 + u] = q;
+        rec[40 + u] = (int32_t)__float_as_uint(none.off); rec[56 + u] = (int32_t)__float_as_uint(none.e); rec[72 + u] = (int32_t)__float_as_uint(none.shift);
+        rec[88 + u] = (int32_t)none.lo_bits; rec[104 + u] = (int32_t)none.hi_bits; rec[128 + u] = 0;
+      }
+    }
+  }
+}
+
 // survivor regions: 32 KiB per (query, pseudo-list) within the workspace budget; the buckets [lists][queries] within 256 MiB
 static int pq_fused_queries_per_chunk(const freddy_gpu_index* ix, int64_t n_blocks) {
   const size_t lists = (size_t)((n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
@@ -2107,27 +2183,31 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   fx->tune = ix->tune;
   Workspace* ws = workspace_for(fx, s);
   const int lists = fx->C, m = fx->m, K = fx->K;
+  // the merge of a small batch over many pseudo-lists: four workgroups per query, each over a quarter of the lists (64 queries
+  // x 1 960 survivor regions on 64 workgroups took 62 us on a quarter of the chip); the item space of a query is padded to
+  // a multiple of the slices
+  const int SL = (lists >= 32 && Q <= 256 && (size_t)lists * FUSED_NW > 256) ? 4 : 0;
+  const int W = SL ? ((lists + SL - 1) / SL) * SL : lists;
   IvfRun r;
-  r.ix = fx; r.ws = ws; r.s = s; r.s_scan = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = lists; r.L = 2 * k;
+  r.ix = fx; r.ws = ws; r.s = s; r.s_scan = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = 2 * k;
   r.sentinel = sentinel; r.cell_limit = 0.0f; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = nullptr;
   r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false; r.qc_pending = false; r.direct = false;
+  r.records_ready = true; r.merge_slices = SL;
   r.n_active = Q; r.round = 0; r.active = nullptr;
   r.share = std::max(1, ix->tune.scan_share);   // (the caller's contract: its batches in flight on this handle)
   r.s_caller = s;
-  const size_t items = (size_t)Q * lists;
+  const size_t items = (size_t)Q * W;
+  const size_t n_entries = (size_t)((Q + SCAN5_G - 1) / SCAN5_G) * lists;
   if (ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
       ws->w_item_dist.ensure(sizeof(float) * items) || ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
       ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) || ws->w_act1.ensure(sizeof(int32_t) * Q) ||
-      ws->w_cnt.ensure(sizeof(int32_t) * 8) || ws->w_cellcnt.ensure(sizeof(int32_t) * (size_t)lists * 3) ||
-      ws->w_sorted.ensure(sizeof(int32_t) * (size_t)lists * Q) ||
-      ws->w_groups.ensure(sizeof(int32_t) * 3 * ((items / SPEC2_G + (size_t)lists + 1) * r.upi + items * r.upi)) ||
+      ws->w_cnt.ensure(sizeof(int32_t) * 8) || ws->w_records.ensure(sizeof(int32_t) * REC_DW * n_entries) ||
       ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
       ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW) ||
       ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d over %d pseudo-lists)", Q, lists);
   r.next = ws->w_act0.as<int32_t>();
   HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 8, s));
-  HIP_TRY(hipMemsetAsync(ws->w_cellcnt.p, 0, sizeof(int32_t) * (size_t)lists * 3, s));
   HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * items * r.upi * FUSED_NW, s));
   timed_launch(fx, s, "query_codebook", [&] {
     hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, d_q, fx->cbT, fx->cmaxp,
@@ -2137,14 +2217,18 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   PlanArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.item_cell = ws->w_item_cell.as<int32_t>(); pa.item_query = ws->w_item_query.as<int32_t>(); pa.item_dist = ws->w_item_dist.as<float>();
-  pa.round_rows = ws->w_rows.as<int32_t>(); pa.n_active = Q; pa.C = lists; pa.W = lists;
-  timed_launch(fx, s, "pq_items", [&] {
-    hipLaunchKernelGGL(pq_items_kernel, dim3(Q), dim3(256), 0, s, d_q, Q, fx->d, lists, fx->N, pa.item_cell, pa.item_query, pa.item_dist,
-                       ws->w_sorted.as<int32_t>(), ws->w_cellcnt.as<int32_t>(), pa.round_rows);
+  pa.round_rows = ws->w_rows.as<int32_t>(); pa.n_active = Q; pa.C = lists; pa.W = W;
+  WorkTable wt;
+  wt.max_groups = n_entries; wt.group_cell = wt.group_first = wt.group_cnt = nullptr;
+  wt.n_groups = ws->w_cnt.as<int32_t>() + 1; wt.work_counter = ws->w_cnt.as<int32_t>() + 2;
+  wt.sp_cap = 0; wt.sp_cell = wt.sp_first = wt.sp_chunk = nullptr; wt.sp_counter = ws->w_cnt.as<int32_t>() + 3; wt.n_sparse = ws->w_cnt.as<int32_t>() + 4;
+  // the entry records straight from the queries' table scales: no item / work-table / record kernels (pq_records_kernel)
+  timed_launch(fx, s, "pq_records", [&] {
+    hipLaunchKernelGGL(pq_records_kernel, dim3(Q), dim3(256), 0, s, d_q, Q, fx->d, lists, W, fx->N, fx->blk_off, fx->list_off,
+                       ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, fx->pmax, sentinel, pa.item_cell, pa.item_query, pa.item_dist,
+                       pa.round_rows, ws->w_records.as<int32_t>(), wt.n_groups);
   });
   HIP_TRY(hipGetLastError());
-  WorkTable wt;
-  if (int rc = ivf_work_table(r, wt)) return rc;
   return ivf_scan_filter(r, pa, wt);
 }
 

@@ -736,14 +736,21 @@ struct MergeRefineArgs {
   int n_active, W, upi, L, k, found_rule, first_round, K, d;
   float sentinel;
   uint32_t ablate;   // timing experiments only (FREDDY_GPU_MERGE_ABLATE): 1 = skip the exact stage
+  // PARTIAL instantiation (a batch over the flat PQ table): workgroup x = (query x / slices, slice x % slices) merges the
+  // survivors of ITS W items (the query's items are slices * W wide) and leaves its L smallest exact keys in part[x][L];
+  // merge_replay_kernel selects among the slices' keys and replays.  (Each slice's 2k smallest exact keys contain the
+  // query's 2k smallest that lie in the slice: selection-then-replay as before, on 4 x as many workgroups.)
+  int slices;
+  u64* part;
 };
 
 // MANY = true (with NWV = 12): the instantiation for queries with hundreds of survivor regions (a batch over the flat PQ
 // table: 245 pseudo-lists x 8 waves) -- the selection of the lower bounds split over the four waves, dense neighbourhoods
 // collected by all of them.  It needs 145 registers (three workgroups per CU); the IVFADC instantiation stays at 128.
-template <int S, int M, int NWV, bool MANY = false>
+template <int S, int M, int NWV, bool MANY = false, bool PARTIAL = false>
 __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineArgs a) {
   static_assert(!MANY || NWV > 1, "the split selection needs the four waves");
+  static_assert(!PARTIAL || MANY, "slices of a query: the flat PQ table's instantiation");
   // NWV = 4: four waves per query.  Wave 0 selects and replays; the exact stage of the normal case (<= NC rows)
   // is spread over all four -- one tile of 64 (row, position) chains each -- because a wave spends it
   // waiting for two dependent round trips per tile: the shortest latency for ONE batch.
@@ -774,7 +781,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   __shared__ uint32_t sh_T;
   const int x = blockIdx.x, lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int q = a.active ? a.active[x] : x;
+  const int q = PARTIAL ? x / a.slices : (a.active ? a.active[x] : x);
   const int k = a.k;
   const int per_item = a.upi * FUSED_NW;
   const int R = a.W * per_item;
@@ -1091,6 +1098,10 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   }
   while (queued > 0) refine(queued < NC ? queued : NC);
   sel2.finish();
+  if constexpr (PARTIAL) {   // this slice's L smallest exact keys (distance bits, id); the rest is merge_replay_kernel's
+    if (lane < a.L) a.part[(size_t)x * a.L + lane] = sel2.acc[0];
+    return;
+  }
 
   u64 byp = (sel2.acc[0] == KEY_INF || lane >= a.L) ? KEY_INF : ((sel2.acc[0] << 32) | (sel2.acc[0] >> 32));
   byp = wave_sort64(byp);
