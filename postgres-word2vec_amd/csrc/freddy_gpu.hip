@@ -96,6 +96,7 @@ struct Tuning {
   int direct = 0;              // FREDDY_GPU_DIRECT: the integer-slab scan claims static (cell, chunk) units and reads record slots the probe plan filled --
                                // no work-table / record kernels in a batch's chain (fused5.h): 0 never (the default: measured no faster, profiles/HISTORY.md
                                // round 4), -1 = dense first rounds, 1 whenever possible
+  int codes_u8 = 1;            // FREDDY_GPU_CODES_U8: K <= 256: the integer-slab scans read one byte per code (packed8, 16 instead of 28 B per row); 0 = the int16 layout
   int exact_filter = -1;       // FREDDY_GPU_EXACT_FILTER: exact kNN as MFMA filter + exact refine (exact2.h): -1 auto (tables of >= 8192 rows, k <= 32), 0 never, 1 always
   int exact_refine_all = 0;    // tests: every row is refined (exhaustive check of the similarity bracket)
   int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
@@ -131,6 +132,7 @@ static Tuning read_tuning() {
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.exact_filter = (int)env_int("FREDDY_GPU_EXACT_FILTER", t.exact_filter);
   t.direct = (int)env_int("FREDDY_GPU_DIRECT", t.direct);
+  t.codes_u8 = (int)env_int("FREDDY_GPU_CODES_U8", t.codes_u8);
   t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
   t.filter_table_mb = env_int("FREDDY_GPU_FILTER_TABLE_MB", t.filter_table_mb);
@@ -278,6 +280,8 @@ struct freddy_gpu_index {
   int32_t* scan_units = nullptr;  // IVF: [n_scan_units][4] static (cell, chunk) units of the scan's DIRECT mode, longest first
   int n_scan_units = 0;
   uint32_t* packed = nullptr;   // [blocks][M2][64]
+  uint32_t* packed8 = nullptr;  // K <= 256, m = 12: [blocks][3][64], one BYTE per code -- what the integer-slab scans read (16 B per row with its row term)
+  bool packed8_own = false;     // (a PQ handle's view shares its owner's array)
   int32_t* pos = nullptr;       // [blocks*64]
   int32_t* ids = nullptr;       // PQ: [N] position -> id
   std::vector<int32_t> h_ids;   // PQ: ascending ids for "id IN (...)" resolution
@@ -401,7 +405,7 @@ static void free_index(freddy_gpu_index* ix) {
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units, ix->packed8_own ? ix->packed8 : nullptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   for (auto& kv : ix->prof)
@@ -535,6 +539,33 @@ static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off
   return 0;
 }
 
+// packed[block][6][64] (two int16 codes per dword) -> packed8[block][3][64] (four one-byte codes per dword)
+__global__ __launch_bounds__(256) void pack8_kernel(const uint32_t* __restrict__ packed, uint32_t* __restrict__ packed8, int64_t n_blocks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (block, t, lane)
+  if (i >= n_blocks * 3 * 64) return;
+  const int lane = (int)(i & 63);
+  const int64_t bt = i >> 6;
+  const int t = (int)(bt % 3);
+  const int64_t b = bt / 3;
+  const uint32_t p0 = packed[((size_t)b * 6 + 2 * t) * 64 + lane], p1 = packed[((size_t)b * 6 + 2 * t + 1) * 64 + lane];
+  packed8[i] = (p0 & 0xffu) | (((p0 >> 16) & 0xffu) << 8) | ((p1 & 0xffu) << 16) | (((p1 >> 16) & 0xffu) << 24);
+}
+// (Re)build the one-byte code array of a handle whose codes fit a byte (K <= 256, m = 12: the cell-grouped scans' shape).
+static int build_packed8(freddy_gpu_index* ix) {
+  if (ix->packed8 && ix->packed8_own) { (void)hipFree(ix->packed8); }
+  ix->packed8 = nullptr; ix->packed8_own = false;
+  if (ix->K > 256 || ix->m != 12 || ix->M2 != 6 || !ix->packed || ix->n_blocks <= 0) return 0;
+  const size_t bytes = sizeof(uint32_t) * (size_t)ix->n_blocks * 3 * 64;
+  if (hipMalloc((void**)&ix->packed8, bytes) != hipSuccess) { ix->packed8 = nullptr; return 0; }   // (no room: the int16 layout serves)
+  ix->packed8_own = true;
+  ix->bytes += (int64_t)bytes;
+  const int64_t n = ix->n_blocks * 3 * 64;
+  hipLaunchKernelGGL(pack8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ix->stream, ix->packed, ix->packed8, ix->n_blocks);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(ix->stream));
+  return 0;
+}
+
 // The scan's DIRECT mode (fused5.h): one unit per (cell, 4096-row chunk) of every non-empty list, longest first -- what the
 // work table's longest-processing-time order is made of when every cell holds items.  (Re)built whenever the lists change.
 static int build_scan_units(freddy_gpu_index* ix) {
@@ -584,6 +615,7 @@ static int raise_lds_limits(int device) {
       (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>,
+      (const void*)&ivf_filter5_kernel<12, false, false, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, false, true>,
       (const void*)&ivf_filter5_kernel<12, true, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, false, false, true>,
       (const void*)&ivf_filter5_kernel<12, true, true, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, true>,
       (const void*)&exf_filter_kernel<1, false>, (const void*)&exf_filter_kernel<2, false>, (const void*)&exf_filter_kernel<1, true>,
@@ -755,6 +787,7 @@ extern "C" int freddy_gpu_pin_pq(const freddy_pq_desc* t, int device, freddy_gpu
   if (!rc) {
     const int32_t off[2] = {0, (int32_t)t->N};
     rc = pack_lists(ix, 1, off, t->codes, nullptr);
+    if (!rc) rc = build_packed8(ix);
   }
   if (!rc) { ix->h_ids.assign(t->ids, t->ids + t->N); ix->max_id = t->N ? t->ids[t->N - 1] : -1; }
   if (rc) { free_index(ix); return rc; }
@@ -822,6 +855,7 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
   if (!rc) rc = build_scan_units(ix);
+  if (!rc) rc = build_packed8(ix);
   if (!rc) rc = refresh_row_terms(ix);   // one float per row slot: the (cell, row) part of the filter's cheap distance
   if (!rc) {
     if (ix->rterm) ix->bytes += (int64_t)sizeof(float) * std::max<int64_t>(ix->n_blocks, 1) * 64;
@@ -985,6 +1019,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
   else if (n == "exact_filter") t.exact_filter = (int)value;
   else if (n == "direct") t.direct = (int)value;
+  else if (n == "codes_u8") t.codes_u8 = (int)value;
   else if (n == "exact_refine_all") t.exact_refine_all = (int)value;
   else return fail(FREDDY_E_ARG, "unknown option '%s'", name);
   return FREDDY_OK;
@@ -1343,6 +1378,9 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     fl.quota_wgs = std::max(0, qw);
     n_persist += (unsigned)fl.quota_wgs;
   }
+  // K <= 256: one byte per code (packed8); the DIRECT and profiling instantiations stay with the int16 layout
+  const bool u8 = v5 && !direct && ix->packed8 && ix->tune.codes_u8 != 0 && K <= 256 && !fl.prof;
+  fl.packed8 = u8 ? ix->packed8 : nullptr;
   hipStream_t ss = r.s_scan;
   if (parted) {   // records (and everything before them) -> scan, on the stream masked to the scan's CUs
     HIP_TRY(hipEventRecord(ws->ev_fe, s));
@@ -1355,6 +1393,9 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
         else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
       } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
       else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+    } else if (u8) {
+      if (fl.cand_count) hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
     } else if (v5) {
       // (four instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is
       // larger than the instruction cache as it is)
@@ -1374,11 +1415,14 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     sp.qc = fl.qc; sp.qscale = ra.qscale; sp.qn = ra.qn; sp.pmax = ix->pmax; sp.rterm = ix->rterm; sp.packed = ix->packed;
     sp.blk_off = ix->blk_off; sp.list_off = ix->list_off; sp.sorted_item = ra.sorted_item; sp.item_query = pa.item_query;
     sp.item_dist = pa.item_dist; sp.sp_cell = wt.sp_cell; sp.sp_first = wt.sp_first; sp.sp_chunk = wt.sp_chunk;
-    sp.n_units = wt.n_sparse; sp.work_counter = wt.sp_counter; sp.surv = fl.surv; sp.surv_count = fl.surv_count;
+    sp.n_units = wt.n_sparse; sp.work_counter = wt.sp_counter; sp.surv = fl.surv; sp.surv_count = fl.surv_count; sp.packed8 = fl.packed8;
     sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.ablate = fl.ablate;
     const unsigned sp_grid = (unsigned)std::min<size_t>(wt.sp_cap, (size_t)std::max(1, scan_cus) * 6);
     timed_launch(ix, ss, "sparse_items", [&] {
-      if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
+      if (u8) {
+        if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
+        else hipLaunchKernelGGL((sparse_item5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
+      } else if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
       else hipLaunchKernelGGL((sparse_item5_kernel<12, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
     });
     HIP_TRY(hipGetLastError());
@@ -2145,6 +2189,7 @@ static int pq_view_refresh(freddy_gpu_index* ix, freddy_gpu_index** view, hipStr
   fx->tune = ix->tune;
   fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp;   // shared with the owner
   fx->packed = const_cast<uint32_t*>(packed);
+  fx->packed8 = (packed == ix->packed) ? ix->packed8 : nullptr; fx->packed8_own = false;   // (a subset's gathered rows: the int16 layout)
   fx->N = n_rows; fx->n_blocks = n_blocks; fx->max_list_blocks = FUSED_UNIT_BLOCKS;
   const int lists = (int)((n_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   fx->C = lists;
@@ -2758,6 +2803,7 @@ static int append_packed_rows(freddy_gpu_index* ix, int n_lists, int64_t n, cons
   ix->max_list_blocks = max_blocks;
   ix->h_list_off = new_list_off;
   ix->N += n;
+  if (!ix->shadow_of) { if (int rc = build_packed8(ix)) return rc; }
   if (ix->kind == KIND_IVF && !ix->shadow_of) return build_scan_units(ix);
   return 0;
 }

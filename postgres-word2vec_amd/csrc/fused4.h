@@ -58,6 +58,7 @@ struct FilterArgs {
   const int32_t* cell_count;   // [C]
   const int32_t* drecs;        // [C][submax][DREC_DW]
   int n_units, submax;
+  const uint32_t* packed8;     // U8 instantiation of the integer-slab scan: [blocks][3][64], one byte per code (K <= 256)
 };
 
 static constexpr float FILT_EPS = 2048.0f * 5.9604644775390625e-8f * 1.0001f;   // E = FILT_EPS * B

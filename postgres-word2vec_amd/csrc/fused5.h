@@ -259,8 +259,12 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
 // ---------------------------------------------------------------------------------------
 // PROF: the per-phase cycle counters of option fused_prof (18 registers of a builder wave, 8 of a gatherer wave: an
 // instantiation of its own, the production kernel does not carry them)
-template <int M, bool FULLK, bool CAND, bool PROF = false, bool DIRECT = false>
+// U8: the rows' codes as one byte each (K <= 256: what the reference's shipped default indexes use) -- packed8[block][3][64],
+// dword t of a row = its codes 4 t .. 4 t + 3: 12 instead of 24 bytes of codes per row, three code loads per row and entry
+// instead of six (the dword of phases 2 t and 2 t + 1 is the same)
+template <int M, bool FULLK, bool CAND, bool PROF = false, bool DIRECT = false, bool U8 = false>
 __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
+  static_assert(!(U8 && FULLK), "one byte per code: K <= 256");
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
   constexpr int NP = M / 2;             // phases per entry
   constexpr int ROWB = G * 2;           // bytes of a slab row: two 16-byte halves of 8 items
@@ -631,7 +635,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           const uint32_t l4 = lane_byte4();
 #pragma unroll
           for (int r = 0; r < RL; ++r) {
-            const char* rowp = reinterpret_cast<const char*>(a.packed) + (size_t)((row_block(r) * (uint32_t)(M / 2) + (uint32_t)pair) * 256u);
+            const char* rowp = U8 ? reinterpret_cast<const char*>(a.packed8) + (size_t)((row_block(r) * (uint32_t)(M / 4) + (uint32_t)(pair >> 1)) * 256u)
+                                  : reinterpret_cast<const char*>(a.packed) + (size_t)((row_block(r) * (uint32_t)(M / 2) + (uint32_t)pair) * 256u);
             cw[r] = *reinterpret_cast<const uint32_t*>(rowp + l4);
           }
         };
@@ -648,8 +653,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           uint32_t bb = (uint32_t)(j & 1) * BUFB;
           asm volatile("" : "+s"(bb));   // (kept out of the constant folder: the halves / positions stay immediate offsets)
           auto issue_row = [&](int r) {
-            const uint32_t a0 = ((cw[r] << 4) & 0x3ff0u) + bb;
-            const uint32_t a1 = ((cw[r] >> 12) & 0x3ff0u) + bb;
+            // (U8: phase j's two codes are bytes 2 (j & 1) and 2 (j & 1) + 1 of the dword)
+            const uint32_t a0 = (U8 ? ((j & 1) ? ((cw[r] >> 12) & 0xff0u) : ((cw[r] << 4) & 0xff0u)) : ((cw[r] << 4) & 0x3ff0u)) + bb;
+            const uint32_t a1 = (U8 ? ((j & 1) ? ((cw[r] >> 20) & 0xff0u) : ((cw[r] >> 4) & 0xff0u)) : ((cw[r] >> 12) & 0x3ff0u)) + bb;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) va[r % DEPTH][0][q] = *reinterpret_cast<const u4*>(slab + a0 + (uint32_t)q * HALFB);
 #pragma unroll

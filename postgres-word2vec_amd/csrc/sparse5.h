@@ -38,6 +38,7 @@ struct SparseArgs {
   const int32_t* sp_chunk;
   const int32_t* n_units;      // [1]
   int32_t* work_counter;       // [1] zeroed before the launch
+  const uint32_t* packed8;     // U8 instantiation: [blocks][3][64], one byte per code
   u64* surv;
   int32_t* surv_count;
   int32_t* cand_count;         // [Q] or NULL
@@ -46,7 +47,7 @@ struct SparseArgs {
   uint32_t ablate;             // debugging: 8 = keep every row (as ivf_filter5_kernel)
 };
 
-template <int M, bool CAND>
+template <int M, bool CAND, bool U8 = false>   // U8: one byte per code (K <= 256), packed8[block][3][64]
 __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
   static_assert(M == 12, "table layout");
   constexpr int RS = 16;       // row slots per lane: 4 waves x 16 x 64 = a chunk of 4096 rows
@@ -100,14 +101,16 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
     const unsigned char* lut_b = reinterpret_cast<const unsigned char*>(&lut[0][0]);
 #pragma unroll
     for (int r0 = 0; r0 < RS; r0 += RB) {
-      uint32_t cw[RB][M / 2];
+      constexpr int NCW = U8 ? M / 4 : M / 2;
+      uint32_t cw[RB][NCW];
       float rt[RB];
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
         const int bl = (r0 + u) * 4 + wave;
         const uint32_t blk = (uint32_t)(b0 + (bl < nb - 1 ? bl : (nb > 0 ? nb - 1 : 0)));
 #pragma unroll
-        for (int pr = 0; pr < M / 2; ++pr) cw[u][pr] = a.packed[((size_t)blk * (M / 2) + pr) * 64u + (uint32_t)lane];
+        for (int pr = 0; pr < NCW; ++pr)
+          cw[u][pr] = U8 ? a.packed8[((size_t)blk * NCW + pr) * 64u + (uint32_t)lane] : a.packed[((size_t)blk * NCW + pr) * 64u + (uint32_t)lane];
         rt[u] = a.rterm[(size_t)blk * 64u + (uint32_t)lane];
       }
 #pragma unroll
@@ -116,8 +119,9 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
         uint32_t sum = 0u;
 #pragma unroll
         for (int pr = 0; pr < M / 2; ++pr) {
-          const uint32_t w = cw[u][pr];
-          const uint32_t a0 = (w << 1) & 0x7feu, a1 = (w >> 15) & 0x7feu;
+          const uint32_t w = U8 ? cw[u][pr >> 1] : cw[u][pr];
+          const uint32_t a0 = U8 ? ((pr & 1) ? ((w >> 15) & 0x1feu) : ((w << 1) & 0x1feu)) : ((w << 1) & 0x7feu);
+          const uint32_t a1 = U8 ? ((pr & 1) ? ((w >> 23) & 0x1feu) : ((w >> 7) & 0x1feu)) : ((w >> 15) & 0x7feu);
           const uint32_t v0 = *reinterpret_cast<const uint16_t*>(lut_b + a0 + (uint32_t)(2 * pr) * 2048u);
           const uint32_t v1 = *reinterpret_cast<const uint16_t*>(lut_b + a1 + (uint32_t)(2 * pr + 1) * 2048u);
           sum = sum + v0 + v1;

@@ -708,6 +708,54 @@ def test_sparse_item_scan_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_one_byte_code_layout_equals_the_int16_layout(gpu, oracle, monkeypatch):
+    """K <= 256 (the reference's shipped default indexes): the integer-slab scans read packed8 -- one byte per code, 16 instead of
+    28 B per row -- unless option codes_u8 = 0 keeps the int16 layout.  Same lists from both, for the cell-grouped scan and the
+    item-wise one, with every row's bracket checked, and after rows were appended (the byte array is rebuilt)."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, K=256, dup_rows=3)
+    for sparse in (0, -16):
+        idx.set_option("sparse_items", sparse)
+        for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 4, 1, 100.0), (32, 2, 0, 1000.0)):
+            exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+            for u8 in (1, 0):
+                idx.set_option("codes_u8", u8)
+                gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+                util.assert_same_lists(gi, gd, exp, f"codes_u8={u8} sparse_items={sparse} k={k} W={W} rule={rule}")
+    # every probed row through the exact stage: the brackets of the byte layout
+    idx.set_option("sparse_items", 0); idx.set_option("codes_u8", 1)
+    idx.set_option("fused_ablate", 8); idx.set_option("merge_ablate", 32)
+    before = idx.bound_checked()
+    gi, gd = idx.search(qs[:48], 5, 2, sentinel=1000.0, found_rule=0)
+    util.assert_same_lists(gi, gd, oracle.ivfadc_search_many(ot, qs[:48], 5, 2, sentinel=1000.0, found_rule=0), "every row, byte layout")
+    assert idx.bound_checked() - before > 20000
+    idx.set_option("fused_ablate", 0); idx.set_option("merge_ablate", 0)
+    # appended rows
+    rng = np.random.default_rng(3)
+    n_new = 500
+    new_ids = (np.arange(n_new) + int(t["ids"].max()) + 1).astype(np.int32)
+    new_cell = rng.integers(0, 32, n_new).astype(np.int32)
+    new_codes = rng.integers(0, 256, (n_new, 12)).astype(np.int16)
+    idx.append_rows(new_ids, coarse_id=new_cell, codes=new_codes)
+    order = np.argsort(new_cell, kind="stable")
+    lo = t["list_off"]
+    ids2, codes2, off2 = [], [], [0]
+    for c in range(32):
+        sel = order[new_cell[order] == c]
+        ids2.append(np.concatenate([t["ids"][lo[c]:lo[c + 1]], new_ids[sel]]))
+        codes2.append(np.concatenate([t["codes"][lo[c]:lo[c + 1]], new_codes[sel]]))
+        off2.append(off2[-1] + len(ids2[-1]))
+    ot2 = oracle.ivf_table(t["coarse"], t["codebook"], np.array(off2, np.int32), np.concatenate(ids2), np.concatenate(codes2))
+    exp = oracle.ivfadc_search_many(ot2, qs, 5, 3, sentinel=1000.0, found_rule=0)
+    for u8 in (1, 0):
+        idx.set_option("codes_u8", u8)
+        gi, gd = idx.search(qs, 5, 3, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"after append, codes_u8={u8}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+@pytest.mark.gpu
 def test_sparse_item_scan_by_its_own_rule(gpu, oracle, monkeypatch):
     """More cells than the batch has probes and enough probes to fill the chip: the library picks the item-wise scan for
     the thin cells itself (default options); the lists equal the oracle's and those of the cell-grouped scan alone."""
