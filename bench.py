@@ -56,8 +56,8 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="ivfadc", choices=["ivfadc", "pq", "join"],
-                    help="ivfadc = BASELINE configs[2] (the metric's), pq = configs[1], join = configs[3]")
+    ap.add_argument("--config", default="ivfadc", choices=["ivfadc", "pq", "join", "exact"],
+                    help="ivfadc = BASELINE configs[2] (the metric's), pq = configs[1], join = configs[3], exact = brute-force kNN (SURVEY 8f-1)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --Q queries per GPU per step; strong: --Q queries per step in total")
     ap.add_argument("--N", type=int, default=None)
@@ -223,7 +223,7 @@ def pmc_traffic(kernel, config=None, shape=None):
 
 
 DEFAULT_SHAPES = {"ivfadc": {"N": 3_000_000, "Q": 1024, "C": 1000, "nprobe": 10}, "pq": {"N": 1_000_000, "Q": 64},
-                  "join": {"N": 1_000_000, "Q": 5000}}
+                  "join": {"N": 1_000_000, "Q": 5000}, "exact": {"N": 3_000_000, "Q": 64}}
 
 
 def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
@@ -248,7 +248,7 @@ def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
 # exact brute-force kNN (k_nearest_neighbour / knn_in_exact, core_functions.c:67-81): the bench's recall
 # ground truth AND a measured path of its own (other_configs.exact)
 # ---------------------------------------------------------------------------------------------------
-def exact_truth(x, d_qs, k, dev_index, cpu_queries=4):
+def exact_truth(x, d_qs, k, dev_index, cpu_queries=4, steps=5):
     """Pins the raw vectors (freddy_gpu_pin_vectors) and returns ([ids [Q][k] per query set], measurement dict)."""
     from freddy_amd import gpu
     N, d = x.shape
@@ -266,7 +266,7 @@ def exact_truth(x, d_qs, k, dev_index, cpu_queries=4):
     for Q in (1, 64):
         hq = np.ascontiguousarray(h_qs[0][:Q])
         vi.search(hq, k)
-        reps = 5
+        reps = max(3, steps)
         t0 = time.perf_counter()
         for _ in range(reps):
             got_i, got_s = vi.search(hq, k)
@@ -283,9 +283,10 @@ def exact_truth(x, d_qs, k, dev_index, cpu_queries=4):
         passes = (Q + 15) // 16 if Q > 8 else 1      # (a tile of queries streams the table once)
         info[f"Q{Q}"] = {
             "value": round(Q / dt, 2), "ms_per_call": round(1e3 * dt, 4), "kernels_us": kern,
-            "roofline": roofline({"exact_scan": "exact_scan_kernel", "exact_filter": "exact_filter_kernel"}.get(dom, dom), avg_s, table_bytes + Q * (d * 4 + k * 8),
+            "roofline": roofline({"exact_scan": "exact_scan_kernel", "exact_filter": "exf_filter_kernel"}.get(dom, dom), avg_s, table_bytes + Q * (d * 4 + k * 8),
                                  "the raw vectors once per call (N*d*4 B = 3.6 GB: larger than the 256 MiB Infinity Cache, so this IS HBM traffic) + queries + results",
-                                 None, {"table_passes_of_this_launch": passes,
+                                 pmc_traffic({"exact_scan": "exact_scan_kernel", "exact_filter": "exf_filter_kernel"}.get(dom, dom), "exact", {"N": N, "Q": Q}),
+                                 {"table_passes_of_this_launch": passes,
                                         "flops": {"per_call": flops, "achieved_tflops": round(flops / avg_s / 1e12, 3),
                                                   "note": "2*N*d*Q multiply-adds of the similarity chain (separately rounded mul + add on the VALU for "
                                                           "the exact chain; the matrix cores when the filter + refine path is taken)"}})}
@@ -817,6 +818,24 @@ def run_join(a, rank, world, dev, dev_index):
                          "parity_with_gpu_on_sample": parity}}
 
 
+def run_exact(a, rank, world, dev, dev_index):
+    """--config exact: brute-force kNN over the raw vectors (k_nearest_neighbour / knn_in_exact) alone -- for the rocprofv3 passes."""
+    from freddy_amd import index_build as ib
+    N = a.N or 3_000_000
+    Q = a.Q or 64
+    x = ib.make_corpus(N, d=300, seed=20260101, device=dev)
+    rng = np.random.default_rng(7)
+    qids = np.sort(rng.choice(np.arange(1, N + 1), size=max(Q, 64), replace=False)).astype(np.int64)
+    d_q = x[torch.from_numpy(qids - 1).to(dev)].contiguous()
+    _, info = exact_truth(x, [d_q], a.k, dev_index, steps=a.steps)
+    key = f"Q{Q}" if f"Q{Q}" in info else "Q64"
+    out = {"metric": info["metric"], "value": info[key]["value"], "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": info[key]["ms_per_call"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic", "config": info["config"], "roofline": info[key]["roofline"], "cpu_baseline": info["cpu_baseline"],
+           "kernels": info[key]["kernels_us"], "Q1": info["Q1"], "Q64": info["Q64"]}
+    return out
+
+
 def run_host_abi_child(a):
     """bench.py --host-abi-child sets.npz: the host-buffer ABI in a process of its own (see run_ivfadc).  Prints one JSON object."""
     from freddy_amd import gpu, index_build as ib
@@ -908,7 +927,7 @@ def main():
     dev = torch.device("cuda", dev_index)
     if world > 1:
         if a.config != "ivfadc":
-            raise SystemExit("--config pq / join are single-GPU measurements")
+            raise SystemExit("--config pq / join / exact are single-GPU measurements")
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -966,6 +985,8 @@ def main():
                 out["roofline"]["other_configs"] = dig
     elif a.config == "pq":
         out = run_pq(a, rank, world, dev, dev_index)
+    elif a.config == "exact":
+        out = run_exact(a, rank, world, dev, dev_index)
     else:
         out = run_join(a, rank, world, dev, dev_index)
     if world > 1:

@@ -33,12 +33,14 @@ for name, key in (("fetch_size", "fetch_kib"), ("write_size", "write_kib")):
 import argparse
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="ivfadc"); ap.add_argument("--N", type=int); ap.add_argument("--Q", type=int)
-ap.add_argument("--C", type=int, default=1000); ap.add_argument("--nprobe", type=int, default=10)
+ap.add_argument("--C", type=int, default=1000); ap.add_argument("--nprobe", type=int, default=10); ap.add_argument("--K", type=int, default=1024)
 a, _ = ap.parse_known_args(extra)
-dflt = {"ivfadc": (3_000_000, 1024), "pq": (1_000_000, 64), "join": (1_000_000, 5000)}[a.config]
+dflt = {"ivfadc": (3_000_000, 1024), "pq": (1_000_000, 64), "join": (1_000_000, 5000), "exact": (3_000_000, 64)}[a.config]
 shape = {"N": a.N or dflt[0], "Q": a.Q or dflt[1]}
 if a.config == "ivfadc":
     shape.update({"C": a.C, "nprobe": a.nprobe})
+    if a.K != 1024:
+        shape["K"] = a.K
 out["_shape"] = shape
 json.dump(out, open(f"gpurun_out/prof/{tag}_pmc.json", "w"), indent=1)
 print(json.dumps(out))

@@ -8,7 +8,7 @@ tools/profile_round.sh $TAG > gpurun_out/prof/${TAG}_profile.log 2>&1
 cp gpurun_out/prof/${TAG}_pmc.json profiles/latest_pmc.json
 python3 bench.py > gpurun_out/prof/${TAG}_bench.json 2> gpurun_out/prof/${TAG}_bench.err
 # configs 2 and 4 (BASELINE configs[1], configs[3]) with their own kernel stats + PMC passes
-for cfg in pq join; do
+for cfg in pq join exact; do
   tools/profile_round.sh ${TAG}_${cfg} --config $cfg > gpurun_out/prof/${TAG}_${cfg}_profile.log 2>&1
   cp gpurun_out/prof/${TAG}_${cfg}_pmc.json profiles/latest_pmc_${cfg}.json 2>/dev/null
   python3 - <<PY
@@ -35,6 +35,9 @@ timeout 1200 tools/profile_round.sh ${TAG}_N40M --N 40000000 --C 13000 > gpurun_
 if [ -s gpurun_out/prof/${TAG}_N40M_pmc.json ]; then cp gpurun_out/prof/${TAG}_N40M_pmc.json profiles/latest_pmc.json; fi
 timeout 1500 python3 bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --cpu-sample 64 --no-recall --no-host-abi > gpurun_out/prof/${TAG}_bench_N40M.json 2> gpurun_out/prof/${TAG}_bench_N40M.err
 cp gpurun_out/prof/${TAG}_latest_pmc_3M.json profiles/latest_pmc.json
+# the same non-resident corpus with the reference's default codebook size K = 256: one byte per code (16 B per row)
+timeout 1500 python3 bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --K 256 --cpu-sample 64 --no-recall --no-host-abi > gpurun_out/prof/${TAG}_bench_N40M_K256.json 2> gpurun_out/prof/${TAG}_bench_N40M_K256.err
+FREDDY_GPU_CODES_U8=0 timeout 1500 python3 bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --K 256 --cpu-sample 0 --no-recall --no-host-abi > gpurun_out/prof/${TAG}_bench_N40M_K256_int16.json 2> /dev/null
 tail -2 gpurun_out/prof/${TAG}_bench_N40M.err
 ls -la gpurun_out/prof | tail -30
 # the driver's own invocation (20 steps), LDS counters of the scan, the reference's other index shape, small-batch latencies
