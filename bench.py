@@ -190,7 +190,8 @@ def run_dry(a, rank, world):
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
            "scaling": a.scaling, "vs_baseline": None, "dtype": "none (dry run)", "data": "synthetic",
            "config": {"workload": "DRY RUN: stand-in search on CPU tensors, gloo", "batch_per_gpu": q_local,
-                      "parallelism": f"dp{world}"},
+                      "parallelism": f"dp{world}", "world_size": (dist.get_world_size() if world > 1 else 1),
+                      "backend": (dist.get_backend() if world > 1 else "none (single rank)")},
            "dry_run": True, "gather_verified": ok, "roofline": None, "cpu_baseline": None}
     if world > 1:
         dist.barrier()

@@ -34,6 +34,16 @@ def test_bench_gpus_2_spawns_two_ranks_and_gathers(scaling):
     assert out["dry_run"] is True and out["value"] > 0
 
 
+def test_bench_strong_scaling_preset_q8192():
+    """`--scaling strong --Q 8192`: the run that can show >= 3.5x at 8 GPUs -- one batch of 8192 queries split
+    over the ranks; the line records the world size torch.distributed reports and the backend."""
+    out = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--Q", "8192", "--scaling", "strong")
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["batch_per_gpu"] == 4096
+    assert out["config"]["world_size"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["gather_verified"] is True
+
+
 def test_bench_single_rank_dry_run():
     out = _run("--dry-run", "--steps", "3", "--warmup", "1", "--Q", "16")
     assert out["n_gpus"] == 1 and out["gather_verified"] is True
