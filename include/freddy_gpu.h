@@ -313,7 +313,11 @@ int freddy_gpu_abi_version(void);
  * work entries -- used where such cells are the rule: fewer than four (query, probe) items per cell and at least 16 per CU;
  * default 2, 0 = never, a negative value forces it for cells of up to that many items whatever the batch),
  * "coarse_refine_all", "fused_prof", "debug_surv",
- * "lut_budget_mb".  No setting changes a result -- except "fused_ablate" / "merge_ablate", which switch parts of a kernel
+ * "lut_budget_mb",
+ * "codes_u8" (1, the default: indexes with K <= 256 are scanned from one byte per code -- 16 instead of 28 bytes per row; 0: the
+ * int16 layout), "exact_filter" (exact brute-force kNN as f16-split MFMA filter + exact refine: -1 = tables of >= 8192 rows and
+ * k <= 32, 0 never, 1 always), "exact_refine_all" (tests: every row refined, every similarity bracket checked), "direct" (the
+ * integer-slab scan without work-table / record kernels: 0 off -- the default, measured no faster --, -1 dense first rounds, 1 always).  No setting changes a result -- except "fused_ablate" / "merge_ablate", which switch parts of a kernel
  * off for timing experiments (tools/ablate.sh) and are not for production use. */
 int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);
 

@@ -60,7 +60,8 @@ static constexpr int COARSE_STREAM_MAX_CPAD = 16384;   // beyond 1024 cells the 
 __device__ __forceinline__ void coarse_approx_body(const float* __restrict__ queries, const float* __restrict__ coarseF,
                                                    const float* __restrict__ cn2, float* __restrict__ out,
                                                    float* __restrict__ qn2, int Q, int Cpad, int d, int dp, const ZeroArgs& z,
-                                                   int bx, int by, int gx, int gy, unsigned char* smem) {
+                                                   int bx, int by, int gx, int gy, unsigned char* smem,
+                                                   float* __restrict__ tmin = nullptr, int C = 0) {
   // (host guarantees: d % 4 == 0, dp % 64 == 0 -- whole blocks of UN = 8 iterations, zero padded on both sides,
   // so that the loops below carry no guards: guarded loads made hipcc emit a branch per element)
   typedef float f16v __attribute__((ext_vector_type(16)));
@@ -149,17 +150,181 @@ __device__ __forceinline__ void coarse_approx_body(const float* __restrict__ que
   __syncthreads();
   const float cn = cn2[c0 + r];
   // C layout of the 32x32 MFMA: register v of lane l holds row 8 (v / 4) + 4 (l / 32) + v % 4, column l % 32
+  float tv[16];
 #pragma unroll
   for (int v = 0; v < 16; ++v) {
     const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-    if (q0 + q0w + i < Q) out[(size_t)(q0 + q0w + i) * Cpad + c0 + r] = __builtin_fmaf(-2.0f, acc[v], rown[wave * 32 + i] + cn);
+    tv[v] = __builtin_fmaf(-2.0f, acc[v], rown[wave * 32 + i] + cn);
+    if (q0 + q0w + i < Q) out[(size_t)(q0 + q0w + i) * Cpad + c0 + r] = tv[v];
+  }
+  // Two-level selection for many cells (probe_plan2_kernel<.., STREAM>): the minimum of every (query, 128-cell tile) -- the plan
+  // takes its threshold from these and reads only the tiles that can hold a candidate.  Padding cells do not count; a NaN
+  // makes its tile one that is always read (-inf).
+  if (tmin) {
+    const float INF = __uint_as_float(0x7f800000u);
+    __syncthreads();                       // (rown is reused below)
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      float m = (c0 + r < C) ? (tv[v] == tv[v] ? tv[v] : -INF) : INF;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));   // (lanes of one half: the 32 cells of the block)
+      if (r == 0) rown[wave * 32 + 8 * (v >> 2) + 4 * h + (v & 3)] = m;
+    }
+    __syncthreads();
+    if (tid < TQ && q0 + tid < Q)
+      tmin[(size_t)(q0 + tid) * gx + bx] = fminf(fminf(rown[tid], rown[32 + tid]), fminf(rown[64 + tid], rown[96 + tid]));
   }
 }
+// ---------------------------------------------------------------------------------------
+// The same tile on f16-SPLIT operands (v_mfma_f32_32x32x16_f16, fp32 accumulate): every fp32 input is hi + lo with
+// hi = f16(v), lo = f16(v - hi) after a power-of-two scaling into f16's range, and q.c ~ hi.hi + hi.lo + lo.hi -- 57 matrix
+// instructions of 32 cycles per 32 x 32 block instead of 160 of 64 cycles.  For MANY cells (the 40 M-row corpus: 13 000) the
+// fp32 version is bound by the matrix pipe (8.6 GFLOP at the fp32 MFMA rate = 55 us of the kernel's 100); with <= 1024 cells the
+// kernel is a latency chain and stays as it is.  Error of the dot product: dropped lo.lo and the f16 rounding of lo
+// <= 3 * 2^-22 |q||c|, fp32 accumulation (<= 64 roundings, doubled in case the matrix core truncates) <= 128 u |q||c|:
+// together < 0.9e-5 |q||c| -- below the 0.91e-5 (|q| + |c|)^2 the fp32 chain is given in COARSE_EPS's budget (|q||c| <= (|q| + |c|)^2 / 4).
+//   coarseH [Cpad / 32][T][hi / lo][64 lanes][8 halves]: lane = cell r + 32 g of the group, its 8 values = dimensions
+//   16 t + 8 g .. + 7, scaled by 2^ec (pin time).  The queries are split per tile: LDS [T][hi / lo][64 lanes] with lane = row + 32 g.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 ch8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void coarse_approx16_body(const float* __restrict__ queries, const ch8v* __restrict__ coarseH, int ec,
+                                                     const float* __restrict__ cn2, float* __restrict__ out,
+                                                     float* __restrict__ qn2, int Q, int Cpad, int d, const ZeroArgs& z,
+                                                     int bx, int by, int gx, int gy, unsigned char* smem,
+                                                     float* __restrict__ tmin, int C) {
+  typedef float f16v __attribute__((ext_vector_type(16)));
+  {
+    const int gtid = (by * gx + bx) * 256 + threadIdx.x, gsz = gx * gy * 256;
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+      for (int i = gtid; i < z.n[a]; i += gsz) z.p[a][i] = 0u;
+  }
+  constexpr int TQ = COARSE_TQ;
+  const int T = (d + 15) >> 4;
+  ch8v* Ah = reinterpret_cast<ch8v*>(smem);                     // [T][2][64]
+  float* rown = reinterpret_cast<float*>(Ah + (size_t)T * 128);  // [4][32]
+  float* qsc = rown + 128;                                       // [32] 2^-(eq + ec) of the tile's queries
+  int* qe = reinterpret_cast<int*>(qsc + 32);                    // [32] eq
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = by * TQ, c0 = bx * 128 + wave * 32;
+  const ch8v* bp = coarseH + ((size_t)(c0 >> 5) * T) * 128 + lane;
+  constexpr int UN = 4;   // k-steps of B operands in flight per wave
+  ch8v bh[UN], bl[UN];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) { const int t = u < T ? u : T - 1; bh[u] = bp[(size_t)t * 128]; bl[u] = bp[(size_t)t * 128 + 64]; }
+  // norms and scales of the tile's queries: eight threads per row, every load of a thread in flight together (one thread per
+  // row, one dependent load after the other, made this prologue 30 us of every workgroup: 134 -> 214 us for the launch)
+  {
+    const int row = tid >> 3, part = tid & 7;
+    const int q = q0 + row < Q ? q0 + row : Q - 1;
+    const float4* qv = reinterpret_cast<const float4*>(queries + (size_t)q * d);
+    const int d4n = d >> 2;
+    constexpr int NL = 10;                 // float4 per thread: 8 x 10 x 4 = 320 dimensions
+    float4 v[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) { const int i = part + 8 * u; v[u] = qv[i < d4n ? i : d4n - 1]; }
+    float n0 = 0.0f, am = 0.0f;
+#pragma unroll
+    for (int u = 0; u < NL; ++u)
+      if (part + 8 * u < d4n) {
+        n0 = __builtin_fmaf(v[u].x, v[u].x, n0); n0 = __builtin_fmaf(v[u].y, v[u].y, n0);
+        n0 = __builtin_fmaf(v[u].z, v[u].z, n0); n0 = __builtin_fmaf(v[u].w, v[u].w, n0);
+        am = fmaxf(am, fmaxf(fmaxf(__builtin_fabsf(v[u].x), __builtin_fabsf(v[u].y)), fmaxf(__builtin_fabsf(v[u].z), __builtin_fabsf(v[u].w))));
+      }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { n0 += __shfl_xor(n0, o, 64); am = fmaxf(am, __shfl_xor(am, o, 64)); }
+    if (part == 0) {
+      int e = 0;
+      if (am > 0.0f && am < 3e38f) { (void)__builtin_frexpf(am, &e); e = 14 - e; }
+      rown[row] = n0; rown[32 + row] = n0; rown[64 + row] = n0; rown[96 + row] = n0;
+      qsc[row] = __builtin_ldexpf(1.0f, -(e + ec));
+      reinterpret_cast<float*>(qe)[row] = __builtin_ldexpf(1.0f, e);     // the scale itself (a power of two: v * 2^e is exact)
+      if (bx == 0 && q0 + row < Q) qn2[q0 + row] = n0;
+    }
+  }
+  __syncthreads();
+  {
+    const int d4n = d >> 2;
+    for (int i = tid; i < T * 64; i += 256) {
+      const int t = i >> 6, l = i & 63, row = l & 31, g = l >> 5;
+      const int q = q0 + row < Q ? q0 + row : Q - 1;
+      const float sc = reinterpret_cast<const float*>(qe)[row];
+      const float4* qv = reinterpret_cast<const float4*>(queries + (size_t)q * d);
+      const int c = 4 * t + 2 * g;
+      float4 a0 = qv[c < d4n ? c : d4n - 1], a1 = qv[c + 1 < d4n ? c + 1 : d4n - 1];
+      if (c >= d4n) a0 = float4{0.f, 0.f, 0.f, 0.f};
+      if (c + 1 >= d4n) a1 = float4{0.f, 0.f, 0.f, 0.f};
+      const float f[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
+      ch8v hi, lo;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const _Float16 hh = (_Float16)f[u];
+        hi[u] = hh;
+        lo[u] = (_Float16)(f[u] - (float)hh);
+      }
+      Ah[(size_t)(t * 2 + 0) * 64 + l] = hi;
+      Ah[(size_t)(t * 2 + 1) * 64 + l] = lo;
+    }
+  }
+  __syncthreads();
+  f16v acc;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+  for (int t0 = 0; t0 < T; t0 += UN) {
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int t = t0 + u;
+      if (t < T) {
+        const ch8v ch = bh[u], cl = bl[u];
+        const int tn = t + UN < T ? t + UN : T - 1;
+        bh[u] = bp[(size_t)tn * 128]; bl[u] = bp[(size_t)tn * 128 + 64];
+        const ch8v ah = Ah[(size_t)(t * 2 + 0) * 64 + lane], al = Ah[(size_t)(t * 2 + 1) * 64 + lane];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, cl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ch, acc, 0, 0, 0);
+      }
+    }
+  }
+  const float cn = cn2[c0 + r];
+  float tv[16];
+#pragma unroll
+  for (int v = 0; v < 16; ++v) {
+    const int i = 8 * (v >> 2) + 4 * h + (v & 3);
+    tv[v] = __builtin_fmaf(-2.0f * qsc[i], acc[v], rown[wave * 32 + i] + cn);   // (the scales are powers of two: -2 q.c exactly as accumulated)
+    if (q0 + i < Q) out[(size_t)(q0 + i) * Cpad + c0 + r] = tv[v];
+  }
+  if (tmin) {
+    const float INF = __uint_as_float(0x7f800000u);
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      float m = (c0 + r < C) ? (tv[v] == tv[v] ? tv[v] : -INF) : INF;
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+      if (r == 0) rown[wave * 32 + 8 * (v >> 2) + 4 * h + (v & 3)] = m;
+    }
+    __syncthreads();
+    if (tid < TQ && q0 + tid < Q)
+      tmin[(size_t)(q0 + tid) * gx + bx] = fminf(fminf(rown[tid], rown[32 + tid]), fminf(rown[64 + tid], rown[96 + tid]));
+  }
+}
+// LDS of the f16-split tile: [T][2][64] fragments + row norms + scales
+__host__ __device__ inline size_t coarse_approx16_lds(int d) { return (size_t)((d + 15) >> 4) * 128 * 16 + 128 * 4 + 32 * 4 + 32 * 4; }
+__global__ __launch_bounds__(256) void coarse_approx16_kernel(const float* __restrict__ queries, const ch8v* __restrict__ coarseH, int ec,
+                                                             const float* __restrict__ cn2, float* __restrict__ out,
+                                                             float* __restrict__ qn2, int Q, int Cpad, int d, ZeroArgs z,
+                                                             float* __restrict__ tmin, int C) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  coarse_approx16_body(queries, coarseH, ec, cn2, out, qn2, Q, Cpad, d, z, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, tmin, C);
+}
+
 __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
                                                            const float* __restrict__ cn2, float* __restrict__ out,
-                                                           float* __restrict__ qn2, int Q, int Cpad, int d, int dp, ZeroArgs z) {
+                                                           float* __restrict__ qn2, int Q, int Cpad, int d, int dp, ZeroArgs z,
+                                                           float* __restrict__ tmin = nullptr, int C = 0) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  coarse_approx_body(queries, coarseF, cn2, out, qn2, Q, Cpad, d, dp, z, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+  coarse_approx_body(queries, coarseF, cn2, out, qn2, Q, Cpad, d, dp, z, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, tmin, C);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -195,6 +360,8 @@ struct Plan2Args {
   const float* pmax;        // [12]
   int submax;
   float sentinel;
+  // STREAM, first round: the minima of the (query, 128-cell tile) blocks (coarse_approx_body) -- NULL: every cell is read twice
+  const float* tmin;        // [Q][Cpad / 128]
 };
 
 static constexpr int PLAN2_NW = 4;       // waves per query
@@ -227,6 +394,7 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
   constexpr int SW = STREAM ? COARSE_STREAM_MAX_CPAD / 32 : 1;
   __shared__ uint32_t cbits[SW];           // STREAM: candidate bitmap over the cells
   __shared__ uint16_t cpre[SW + 1];        // STREAM: candidates before word w
+  __shared__ float tms[STREAM ? COARSE_STREAM_MAX_CPAD / 128 : 1];   // STREAM: the query's tile minima
   __shared__ float cdist[PLAN2_PASS];     // exact distances of the pass's candidates
   __shared__ __attribute__((aligned(16))) float sq[RC * PLAN2_PITCH];   // row i % RC: candidate i of the round
   __shared__ __attribute__((aligned(16))) float qs[320];
@@ -280,6 +448,15 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
       if (!valid) av[u] = INF;
       if (av[u] == av[u]) mn = fminf(mn, av[u]);
       else av[u] = -INF;                          // NaN (non-finite table entries): always a candidate, never a threshold
+    }
+  } else if (g.tmin) {
+    // two-level: the threshold from the tiles' minima (every one of them is some cell's distance: the 2W-th smallest of them
+    // is >= the 2W-th smallest distance), the candidates from the tiles whose minimum can reach it
+    const int gx = a.Cpad >> 7;
+    for (int i = threadIdx.x; i < gx; i += 64 * NW) {
+      const float tm = g.tmin[(size_t)q * gx + i];
+      tms[i] = tm;
+      if (tm > -INF) mn = fminf(mn, tm);
     }
   } else {
     for (int u0 = 0; u0 < nvt; u0 += 4) {         // (four loads in flight)
@@ -335,7 +512,11 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
     for (int u0 = 0; u0 < nvt; u0 += 4) {
       float v4[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) v4[t] = u0 + t < nvt ? masked((wave * nvt + u0 + t) * 64 + lane) : INF;
+      for (int t = 0; t < 4; ++t) {
+        // (64 cells = half a tile: read only if the tile's minimum can reach the threshold; -inf / NaN: always)
+        const bool rd = u0 + t < nvt && (!g.tmin || !(tms[(wave * nvt + u0 + t) >> 1] > thr));
+        v4[t] = rd ? masked((wave * nvt + u0 + t) * 64 + lane) : INF;
+      }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const bool c = v4[t] <= thr && v4[t] < INF;

@@ -171,7 +171,7 @@ struct Workspace {
   hipEvent_t ev_in = nullptr, ev_fe = nullptr, ev_scan = nullptr, ev_out = nullptr;
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs, w_tmin;
   void release_partition() {
     if (fe_stream) { (void)hipStreamSynchronize(fe_stream); (void)hipStreamDestroy(fe_stream); fe_stream = nullptr; }
     if (scan_stream) { (void)hipStreamSynchronize(scan_stream); (void)hipStreamDestroy(scan_stream); scan_stream = nullptr; }
@@ -187,7 +187,7 @@ struct Workspace {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs, &w_tmin};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -262,6 +262,8 @@ struct freddy_gpu_index {
   float* coarse = nullptr;      // [C][d]
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
   float* coarseP = nullptr;     // centroids in MFMA fragment order [Cpad/32][dp/8][64][4], zero padded (coarse.h)
+  void* coarseH = nullptr;      // more than 1024 cells: the centroids split into f16 hi / lo, [Cpad/32][T][2][64][8] (coarse_approx16_body)
+  int coarse_ec = 0;            // their power-of-two scale
   float* cn2 = nullptr;         // [Cpad] |c_j|^2
   float cmax = 0.0f;            // max_j |c_j|, rounded up
   int dp = 0;
@@ -405,7 +407,7 @@ static void free_index(freddy_gpu_index* ix) {
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units, ix->packed8_own ? ix->packed8 : nullptr};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->coarseH, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units, ix->packed8_own ? ix->packed8 : nullptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   for (auto& kv : ix->prof)
@@ -613,7 +615,7 @@ static int raise_lds_limits(int device) {
       (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true, false>, (const void*)&ivf_filter5_kernel<12, true, false, true>,
       (const void*)&ivf_filter5_kernel<12, false, false>, (const void*)&ivf_filter5_kernel<12, true, true>,
       (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
-      (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
+      (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&coarse_approx16_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>,
       (const void*)&ivf_filter5_kernel<12, false, false, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, false, true>,
       (const void*)&ivf_filter5_kernel<12, true, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, false, false, true>,
@@ -847,6 +849,29 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
         cmax2 = std::max(cmax2, n2);
       }
       ix->cmax = (float)(std::sqrt(cmax2) * (1.0 + 1e-6));
+      if (ix->Cpad > COARSE_MAX_CPAD && t->d % 4 == 0) {   // many cells: the f16-split copy for the matrix cores (coarse.h)
+        float amax = 0.0f;
+        for (size_t i = 0; i < (size_t)t->C * t->d; ++i) amax = std::max(amax, std::fabs(t->coarse[i]));
+        int e = 0;
+        if (amax > 0.0f && amax < 3e38f) { (void)frexpf(amax, &e); e = 14 - e; }
+        ix->coarse_ec = e;
+        const int T = (t->d + 15) / 16;
+        std::vector<_Float16> cH((size_t)ix->Cpad * T * 2 * 8 * 2, (_Float16)0.0f);   // [Cpad/32][T][2][64][8]
+        for (int c = 0; c < t->C; ++c)
+          for (int i = 0; i < t->d; ++i) {
+            const float v = ldexpf(t->coarse[(size_t)c * t->d + i], e);
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)(v - (float)hi);
+            const int tt = i >> 4, g = (i >> 3) & 1, u = i & 7;
+            const size_t base = (((size_t)(c >> 5) * T + tt) * 2) * 64;
+            cH[(base + (size_t)g * 32 + (c & 31)) * 8 + u] = hi;
+            cH[(base + 64 + (size_t)g * 32 + (c & 31)) * 8 + u] = lo;
+          }
+        _Float16* dH = nullptr;
+        if (upload(&dH, cH.data(), cH.size(), &ix->bytes)) rc = fail(FREDDY_E_NOMEM, "device allocation failed");
+        ix->coarseH = dH;
+      }
+      if (rc) {} else
       if (upload(&ix->coarseP, cP.data(), cP.size(), &ix->bytes) || upload(&ix->cn2, cn2.data(), cn2.size(), &ix->bytes) ||
           hipMalloc((void**)&ix->viol, 4 * sizeof(int32_t)) != hipSuccess || hipMemset(ix->viol, 0, 4 * sizeof(int32_t)) != hipSuccess)
         rc = fail(FREDDY_E_NOMEM, "device allocation failed");
@@ -1133,12 +1158,21 @@ static int ivf_coarse(IvfRun& r) {
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
   za.p[4] = r.fused ? ws->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = r.fused ? (int)(items * r.upi * FUSED_NW) : 0;
 
+  // more than 1024 cells: the (query, 128-cell tile) minima for the plan's two-level selection (round one: no cell is used yet)
+  float* tile_min = nullptr;
+  if (r.approx && Cpad > COARSE_MAX_CPAD) {
+    if (ws->w_tmin.ensure(sizeof(float) * (size_t)Q * (Cpad / 128))) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    tile_min = ws->w_tmin.as<float>();
+  }
   auto launch_coarse = [&]() -> int {
     timed_launch(ix, s, "coarse_dist", [&] {
-      if (r.approx)
+      if (r.approx && ix->coarseH)
+        hipLaunchKernelGGL(coarse_approx16_kernel, dim3(Cpad / 128, (Q + COARSE_TQ - 1) / COARSE_TQ), dim3(256), coarse_approx16_lds(d), s, r.d_q,
+                           (const ch8v*)ix->coarseH, ix->coarse_ec, ix->cn2, ws->w_distT.as<float>(), ws->w_qn2.as<float>(), Q, Cpad, d, za, tile_min, C);
+      else if (r.approx)
         hipLaunchKernelGGL(coarse_approx_kernel, dim3(Cpad / 128, (Q + COARSE_TQ - 1) / COARSE_TQ), dim3(256),
                            (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), s, r.d_q, ix->coarseP, ix->cn2,
-                           ws->w_distT.as<float>(), ws->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za);
+                           ws->w_distT.as<float>(), ws->w_qn2.as<float>(), Q, Cpad, d, ix->dp, za, tile_min, C);
       else if (r.tiled)
         hipLaunchKernelGGL((coarse_tile_kernel<2, 16>), dim3(Cpad / 32, (Q + 63) / 64), dim3(256), 0, s, r.d_q, ix->coarseT,
                            ws->w_distT.as<float>(), Q, Cpad, d, za);
@@ -1163,11 +1197,13 @@ static int ivf_coarse(IvfRun& r) {
     ct.queries = r.d_q; ct.coarseF = ix->coarseP; ct.cn2 = ix->cn2; ct.dist = ws->w_distT.as<float>(); ct.qn2 = ws->w_qn2.as<float>();
     ct.Q = Q; ct.Cpad = Cpad; ct.d = d; ct.dp = ix->dp; ct.z = za; ct.coarse_gx = Cpad / 128; ct.coarse_gy = (Q + COARSE_TQ - 1) / COARSE_TQ;
     ct.cbT = ix->cbT; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
-    ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K;
-    const size_t lds = std::max<size_t>((size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
+    ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K; ct.tmin = tile_min; ct.C = C;
+    ct.coarseH = (const ch8v*)ix->coarseH; ct.ec = ix->coarse_ec;
+    const size_t lds = std::max<size_t>(ix->coarseH ? coarse_approx16_lds(d) : (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
     const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
     timed_launch(ix, s, "coarse_table", [&] {
-      hipLaunchKernelGGL((coarse_table5_kernel<25, 16>), dim3(grid), dim3(256), lds, s, ct);
+      if (ix->coarseH) hipLaunchKernelGGL((coarse_table5_kernel<25, 16, true>), dim3(grid), dim3(256), lds, s, ct);
+      else hipLaunchKernelGGL((coarse_table5_kernel<25, 16>), dim3(grid), dim3(256), lds, s, ct);
     });
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1235,6 +1271,7 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
     g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ws->w_qn2.as<float>(); g.item_dist = pa.item_dist;
     g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all; g.prof = nullptr;
     g.drecs = nullptr; g.qn = nullptr; g.qscale = nullptr; g.pmax = nullptr; g.submax = 0; g.sentinel = r.sentinel;
+    g.tmin = (r.first() && ix->Cpad > COARSE_MAX_CPAD && ws->w_tmin.p) ? ws->w_tmin.as<float>() : nullptr;
     if (r.direct && r.first()) {
       g.drecs = ws->w_drecs.as<int32_t>(); g.qn = ws->w_qn.as<float>(); g.qscale = ws->w_qn.as<float>() + (size_t)r.Q * ix->m;
       g.pmax = ix->pmax; g.submax = (r.n_active + SCAN5_G - 1) / SCAN5_G;

@@ -203,15 +203,21 @@ struct CoarseTableArgs {
   const float* queries;
   const float* coarseF; const float* cn2; float* dist; float* qn2; int Q, Cpad, d, dp; ZeroArgs z; int coarse_gx, coarse_gy;
   const float* cbT; const float* cmax; float* qn; float* qscale; uint32_t* qc; int m, K;
+  float* tmin; int C;   // many cells: the (query, 128-cell tile) minima for the plan's two-level selection (NULL: not wanted)
+  const ch8v* coarseH; int ec;   // many cells: the centroids split into f16 hi / lo (coarse_approx16_body); NULL: the fp32 tile
 };
-template <int S, int QT>
-__global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {
+template <int S, int QT, bool H16 = false>   // H16: the coarse tiles on f16-split operands (many cells); an instantiation of its own, so
+__global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {   // that the <= 1024-cell kernel compiles as before
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n_coarse = a.coarse_gx * a.coarse_gy;
   const int b = blockIdx.x;
   if (b < n_coarse) {
+    if constexpr (H16)
+      coarse_approx16_body(a.queries, a.coarseH, a.ec, a.cn2, a.dist, a.qn2, a.Q, a.Cpad, a.d, a.z, b % a.coarse_gx, b / a.coarse_gx,
+                           a.coarse_gx, a.coarse_gy, smem, a.tmin, a.C);
+    else
     coarse_approx_body(a.queries, a.coarseF, a.cn2, a.dist, a.qn2, a.Q, a.Cpad, a.d, a.dp, a.z, b % a.coarse_gx, b / a.coarse_gx,
-                       a.coarse_gx, a.coarse_gy, smem);
+                       a.coarse_gx, a.coarse_gy, smem, a.tmin, a.C);
   } else {
     const int t = b - n_coarse;
     query_codebook5_body<S, QT>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, t % a.m, t / a.m, smem);

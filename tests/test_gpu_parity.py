@@ -1150,7 +1150,7 @@ def test_pq_subset_batch_through_the_cell_grouped_scan(gpu, oracle):
     idx.close()
 
 
-@pytest.mark.parametrize("kind", ["plain", "duplicate_centroids", "refine_all"])
+@pytest.mark.parametrize("kind", ["plain", "duplicate_centroids", "refine_all", "13000_cells"])
 def test_coarse_filter_refine_beyond_1024_cells(gpu, oracle, kind, monkeypatch):
     """More than 1024 coarse cells: the plan streams a query's approximate distances twice (per-lane minima, then the
     candidates as a bitmap in LDS; probe_plan2_kernel<0, true>) instead of holding them in registers.  C = 1500 cells over
@@ -1158,9 +1158,11 @@ def test_coarse_filter_refine_beyond_1024_cells(gpu, oracle, kind, monkeypatch):
     probing rounds beyond the first, W up to 16; against the oracle and the all-exact coarse kernel."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     from freddy_amd import index_build as ib
-    N, C = 30000, 1500
+    # (13000_cells: the 40 M-row benchmark's cell count -- 102 tiles of 128 cells for the plan's two-level selection: the
+    # threshold from the tiles' minima, candidates from the tiles that can reach it; mostly tiny or EMPTY lists)
+    N, C = (60000, 13000) if kind == "13000_cells" else (30000, 1500)
     x = util.corpus(N)
-    t = dict(ib.build_ivf_index(x, C=C, m=12, K=256, train_size=8000, iters=3, seed=4))
+    t = dict(ib.build_ivf_index(x, C=C, m=12, K=256, train_size=30000 if kind == "13000_cells" else 8000, iters=3, seed=4))
     coarse = t["coarse"].copy()
     if kind == "duplicate_centroids":
         coarse[700] = coarse[3]
