@@ -179,8 +179,8 @@ __device__ __forceinline__ void coarse_approx_body(const float* __restrict__ que
 // The same tile on f16-SPLIT operands (v_mfma_f32_32x32x16_f16, fp32 accumulate): every fp32 input is hi + lo with
 // hi = f16(v), lo = f16(v - hi) after a power-of-two scaling into f16's range, and q.c ~ hi.hi + hi.lo + lo.hi -- 57 matrix
 // instructions of 32 cycles per 32 x 32 block instead of 160 of 64 cycles.  For MANY cells (the 40 M-row corpus: 13 000) the
-// fp32 version is bound by the matrix pipe (8.6 GFLOP at the fp32 MFMA rate = 55 us of the kernel's 100); with <= 1024 cells the
-// kernel is a latency chain and stays as it is.  Error of the dot product: dropped lo.lo and the f16 rounding of lo
+// fp32 version is bound by the matrix pipe (8.6 GFLOP at the fp32 MFMA rate = 55 us of the kernel's 100); with 1000 cells it saves
+// 3 us alone and 8 us beside the other batches' kernels (the default since round 4; the fp32 tile stays for d % 4 != 0).  Error of the dot product: dropped lo.lo and the f16 rounding of lo
 // <= 3 * 2^-22 |q||c|, fp32 accumulation (<= 64 roundings, doubled in case the matrix core truncates) <= 128 u |q||c|:
 // together < 0.9e-5 |q||c| -- below the 0.91e-5 (|q| + |c|)^2 the fp32 chain is given in COARSE_EPS's budget (|q||c| <= (|q| + |c|)^2 / 4).
 //   coarseH [Cpad / 32][T][hi / lo][64 lanes][8 halves]: lane = cell r + 32 g of the group, its 8 values = dimensions

@@ -262,7 +262,7 @@ struct freddy_gpu_index {
   float* coarse = nullptr;      // [C][d]
   float* coarseT = nullptr;     // [d][Cpad] for the coarse-distance kernel
   float* coarseP = nullptr;     // centroids in MFMA fragment order [Cpad/32][dp/8][64][4], zero padded (coarse.h)
-  void* coarseH = nullptr;      // more than 1024 cells: the centroids split into f16 hi / lo, [Cpad/32][T][2][64][8] (coarse_approx16_body)
+  void* coarseH = nullptr;      // the centroids split into f16 hi / lo, [Cpad/32][T][2][64][8] (coarse_approx16_body)
   int coarse_ec = 0;            // their power-of-two scale
   float* cn2 = nullptr;         // [Cpad] |c_j|^2
   float cmax = 0.0f;            // max_j |c_j|, rounded up
@@ -849,7 +849,10 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
         cmax2 = std::max(cmax2, n2);
       }
       ix->cmax = (float)(std::sqrt(cmax2) * (1.0 + 1e-6));
-      if (ix->Cpad > COARSE_MAX_CPAD && t->d % 4 == 0) {   // many cells: the f16-split copy for the matrix cores (coarse.h)
+      // the f16-split copy of the centroids for the matrix cores (coarse.h coarse_approx16_body; FREDDY_GPU_COARSE_H16=0: the fp32 tiles).
+      // Many cells: the fp32 tiles are bound by the matrix pipe (134 -> 102 us at 13 000 cells); 1000 cells: 32 -> 29 us alone,
+      // 54 -> 46 us with four batches in flight (fewer matrix-pipe cycles beside the other batches' kernels)
+      if (env_int("FREDDY_GPU_COARSE_H16", 1) != 0 && t->d % 4 == 0) {
         float amax = 0.0f;
         for (size_t i = 0; i < (size_t)t->C * t->d; ++i) amax = std::max(amax, std::fabs(t->coarse[i]));
         int e = 0;
