@@ -765,10 +765,10 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   constexpr int M2 = M / 2;
   __shared__ u64 stage_all[MANY ? NWV : 1][64];
   u64* const stage = stage_all[0];
-  __shared__ u64 part_key[MANY ? NWV : 1][64];        // pass 1 split over the waves (many survivor regions: the flat PQ table)
-  __shared__ uint32_t part_flag[MANY ? NWV : 1][64];
+  __shared__ u64 part_key[MANY ? NWV : 1][MANY ? 64 : 1];        // pass 1 split over the waves (many survivor regions: the flat PQ table)
+  __shared__ uint32_t part_flag[MANY ? NWV : 1][MANY ? 64 : 1];
   __shared__ float qs[M * S];
-  __shared__ float sq[(NWV == 1 ? 1 : NT) * 64 * SQ];
+  __shared__ float sq[NWV == 1 ? 32 * SQ : NT * 64 * SQ];
   __shared__ float lutv[NT * 64];
   __shared__ int32_t cbo[NT * 64], coo[NT * 64];
   __shared__ u64 cq_key[64 + NC];
@@ -807,17 +807,24 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     }
     __builtin_amdgcn_wave_barrier();
     // round trips 2 and 3: every element (chain, dimension) -- consecutive lanes read consecutive floats
-    // of a codeword / centroid; two halves of H steps each, the loads of a half go out together (all S
-    // at once would need more than the 128 registers four resident workgroups per CU leave a wave)
-    constexpr int H = (S + 1) / 2;
+    // of a codeword / centroid; batches of H steps each, the loads of a batch go out together (all S
+    // at once would need more than the 128 registers four resident workgroups per CU leave a wave).
+    // CH chains are staged at a time: all 64 of the tile, or -- one wave per query (NWV = 1), where the kernel's LDS decides how
+    // many queries are resident beside the other batches' scans -- 32 and 32 (3.3 instead of 6.7 KB of squared differences:
+    // 9.2 KB per query, sixteen per CU instead of eleven).
+    constexpr int CH = (NWV == 1) ? 32 : 64;
+    constexpr int NSTEP = (CH * S + 63) / 64;
+    constexpr int H = (NWV == 1) ? (NSTEP + 1) / 2 : (S + 1) / 2;   // (one wave per query: 7 + 6 loads in flight -- with 13 the kernel spilled at 128 registers)
 #pragma unroll 1
-    for (int h0 = 0; h0 < S; h0 += H) {
+    for (int hh = 0; hh < 64 / CH; ++hh) {
+#pragma unroll 1
+    for (int h0 = 0; h0 < NSTEP; h0 += H) {
       float cv[H], cov[H];
 #pragma unroll
       for (int u = 0; u < H; ++u) {
         const int e = (h0 + u) * 64 + lane;
-        const int cl = t * 64 + e / S, j = e % S;
-        const bool live = (h0 + u < S) && cl < chains;
+        const int cl = t * 64 + hh * CH + e / S, j = e % S;
+        const bool live = (h0 + u < NSTEP) && e < CH * S && cl < chains;
         const uint32_t off = ((uint32_t)cbo[live ? cl : t * 64] + (uint32_t)j) * 4u;
         const uint32_t offc = ((uint32_t)coo[live ? cl : t * 64] + (uint32_t)j) * 4u;   // (C*d*4 < 2^32)
         cv[u] = live ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.cbR) + off) : 0.0f;
@@ -826,9 +833,9 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
 #pragma unroll
       for (int u = 0; u < H; ++u) {
         const int e = (h0 + u) * 64 + lane;
-        const int cl = e / S, j = e % S;
-        const int p = (t * 64 + cl) % M;
-        if ((h0 + u < S) && t * 64 + cl < chains) {
+        const int cl = e / S, j = e % S;                                 // (chain within the staged CH)
+        const int p = (t * 64 + hh * CH + cl) % M;
+        if ((h0 + u < NSTEP) && e < CH * S && t * 64 + hh * CH + cl < chains) {
           const float r = qs[p * S + j] - cov[u];                        // freddy.c:296-303
           const float tt = r - cv[u];
           sqb[cl * SQ + j] = tt * tt;                                    // index_utils.c:500-508
@@ -836,13 +843,15 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
       }
     }
     __builtin_amdgcn_wave_barrier();
-    if (ch < chains) {
+    const int mych = t * 64 + hh * CH + lane;
+    if (lane < CH && mych < chains) {
       float acc = 0.0f;
 #pragma unroll
       for (int j = 0; j < S; ++j) acc = acc + sqb[lane * SQ + j];
-      lutv[ch] = acc;
+      lutv[mych] = acc;
     }
     __builtin_amdgcn_wave_barrier();
+    }
   };
 
   // ---- pass 1: the L smallest lower bounds ----
