@@ -2152,28 +2152,56 @@ static bool pq_use_fused(const freddy_gpu_index* ix, int Q, int k) {
 // the records' headers.  Replaces pq_items + work_table + entry_record kernels (27 us of three dependent launches).
 // item index = q * W + list (W >= lists: padded to a multiple of the merge's slices; the padding items have no entry, their
 // survivor regions stay zero).
-__global__ __launch_bounds__(256) void pq_records_kernel(const float* __restrict__ queries, int Q, int d, int lists, int W, int64_t n_rows,
-                                                        const int32_t* __restrict__ blk_off, const int32_t* __restrict__ list_off,
-                                                        const float* __restrict__ qn, const float* __restrict__ qscale, const float* __restrict__ pmax,
-                                                        float sentinel, int32_t* __restrict__ item_cell, int32_t* __restrict__ item_query,
-                                                        float* __restrict__ item_dist, int32_t* __restrict__ round_rows,
-                                                        int32_t* __restrict__ records, int32_t* __restrict__ n_groups) {
-  __shared__ float sqs[1024];
-  __shared__ float A_s;
-  const int q = blockIdx.x, tid = threadIdx.x;
+struct PqFrontArgs {
+  const float* queries; int Q, d, lists, W; int64_t n_rows;
+  const int32_t* blk_off; const int32_t* list_off;
+  const float* cbT; const float* cmax; const float* pmax;
+  float* qn; float* qscale; uint32_t* qc; int m, K;
+  float sentinel;
+  int32_t* item_cell; int32_t* item_query; float* item_dist; int32_t* round_rows; int32_t* records; int32_t* n_groups;
+};
+__device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, unsigned char* smem) {
+  const float* __restrict__ queries = a.queries;
+  const int Q = a.Q, d = a.d, lists = a.lists, W = a.W;
+  const int64_t n_rows = a.n_rows;
+  const int32_t* __restrict__ blk_off = a.blk_off; const int32_t* __restrict__ list_off = a.list_off;
+  const float* __restrict__ pmax = a.pmax;
+  const float sentinel = a.sentinel;
+  int32_t* __restrict__ item_cell = a.item_cell; int32_t* __restrict__ item_query = a.item_query; float* __restrict__ item_dist = a.item_dist;
+  int32_t* __restrict__ round_rows = a.round_rows; int32_t* __restrict__ records = a.records; int32_t* __restrict__ n_groups = a.n_groups;
+  float* sqs = reinterpret_cast<float*>(smem);          // [1024]
+  float* qn_s = sqs + 1024;                              // [16] |q_p| rounded up, as query_codebook5_body forms it
+  float* fs = qn_s + 16;                                 // [0] A, [1] scale
+  const int tid = threadIdx.x;
   for (int i = tid; i < d; i += 256) { const float t = queries[(size_t)q * d + i] - 0.0f; sqs[i] = t * t; }
+  // the query's per-position norms and its table scale: the very operations of query_codebook5_body (same order, same roundings),
+  // so that this workgroup needs nothing from the table units of the same launch
+  if (tid < 16) {
+    const int pp = tid, S = d / a.m;
+    float best = 0.0f;
+    if (pp < a.m) {
+      float n2 = 0.0f;
+      for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + pp * S + j]; n2 = __builtin_fmaf(v, v, n2); }
+      const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+      qn_s[pp] = nrm;
+      best = 2.0f * nrm * a.cmax[pp];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (pp == 0) fs[1] = best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
+  }
   __syncthreads();
   if (tid == 0) {
     float acc = 0.0f;
     for (int i = 0; i < d; ++i) acc = acc + sqs[i];     // index_utils.c:500-508, i ascending
-    A_s = acc;
+    fs[0] = acc;
     round_rows[q] = (int32_t)n_rows;
     if (q == 0) n_groups[0] = ((Q + SCAN5_G - 1) / SCAN5_G) * lists;
   }
   __syncthreads();
-  const float A = A_s;
-  const float sc = qscale[q];
-  const ItemBounds ib = item_bounds(A, filter_width5<12>(qn + (size_t)q * 12, pmax, sc), sentinel);
+  const float A = fs[0];
+  const float sc = fs[1];
+  const ItemBounds ib = item_bounds(A, filter_width5<12>(qn_s, pmax, sc), sentinel);
   const int g = q / SCAN5_G, slot = q % SCAN5_G;
   const int cnt = (Q - g * SCAN5_G < SCAN5_G) ? Q - g * SCAN5_G : SCAN5_G;
   for (int c = tid; c < lists; c += 256) {
@@ -2200,6 +2228,16 @@ __global__ __launch_bounds__(256) void pq_records_kernel(const float* __restrict
       }
     }
   }
+}
+
+// The table units of query_codebook5_kernel and the record workgroups above as ONE launch (neither needs the other: the record
+// workgroups form the query's scale themselves): a dependent launch less in a PQ batch's chain.
+__global__ __launch_bounds__(256) void pq_front_kernel(PqFrontArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int n_table = a.m * ((a.Q + 15) / 16);
+  const int b = blockIdx.x;
+  if (b < n_table) query_codebook5_body<25, 16>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, b % a.m, b / a.m, smem);
+  else pq_records_body(a, b - n_table, smem);
 }
 
 // survivor regions: 32 KiB per (query, pseudo-list) within the workspace budget; the buckets [lists][queries] within 256 MiB
@@ -2294,11 +2332,6 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   r.next = ws->w_act0.as<int32_t>();
   HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 8, s));
   HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * items * r.upi * FUSED_NW, s));
-  timed_launch(fx, s, "query_codebook", [&] {
-    hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, d_q, fx->cbT, fx->cmaxp,
-                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, fx->d, m, K);
-  });
-  HIP_TRY(hipGetLastError());
   PlanArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.item_cell = ws->w_item_cell.as<int32_t>(); pa.item_query = ws->w_item_query.as<int32_t>(); pa.item_dist = ws->w_item_dist.as<float>();
@@ -2307,11 +2340,16 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   wt.max_groups = n_entries; wt.group_cell = wt.group_first = wt.group_cnt = nullptr;
   wt.n_groups = ws->w_cnt.as<int32_t>() + 1; wt.work_counter = ws->w_cnt.as<int32_t>() + 2;
   wt.sp_cap = 0; wt.sp_cell = wt.sp_first = wt.sp_chunk = nullptr; wt.sp_counter = ws->w_cnt.as<int32_t>() + 3; wt.n_sparse = ws->w_cnt.as<int32_t>() + 4;
-  // the entry records straight from the queries' table scales: no item / work-table / record kernels (pq_records_kernel)
-  timed_launch(fx, s, "pq_records", [&] {
-    hipLaunchKernelGGL(pq_records_kernel, dim3(Q), dim3(256), 0, s, d_q, Q, fx->d, lists, W, fx->N, fx->blk_off, fx->list_off,
-                       ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, fx->pmax, sentinel, pa.item_cell, pa.item_query, pa.item_dist,
-                       pa.round_rows, ws->w_records.as<int32_t>(), wt.n_groups);
+  // ONE launch: the table units (query x codebook, int16) and the record workgroups -- the entry records straight from the
+  // queries' table scales: no item / work-table / record kernels (pq_front_kernel)
+  PqFrontArgs fa;
+  fa.queries = d_q; fa.Q = Q; fa.d = fx->d; fa.lists = lists; fa.W = W; fa.n_rows = fx->N; fa.blk_off = fx->blk_off; fa.list_off = fx->list_off;
+  fa.cbT = fx->cbT; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
+  fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
+  fa.item_dist = pa.item_dist; fa.round_rows = pa.round_rows; fa.records = ws->w_records.as<int32_t>(); fa.n_groups = wt.n_groups;
+  const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 2) * sizeof(float));
+  timed_launch(fx, s, "pq_front", [&] {
+    hipLaunchKernelGGL(pq_front_kernel, dim3((unsigned)(m * ((Q + 15) / 16) + Q)), dim3(256), front_lds, s, fa);
   });
   HIP_TRY(hipGetLastError());
   return ivf_scan_filter(r, pa, wt);
