@@ -312,6 +312,7 @@ int freddy_gpu_abi_version(void);
  * "sparse_items" (cells that at most this many queries of a batch probe are scanned item by item instead of as cell-grouped
  * work entries -- used where such cells are the rule: fewer than four (query, probe) items per cell and at least 16 per CU;
  * default 2, 0 = never, a negative value forces it for cells of up to that many items whatever the batch),
+ * "sparse_pairs" (1, the default: the item-wise scan reads a cell that exactly two queries probe once for both; 0: twice),
  * "coarse_refine_all", "fused_prof", "debug_surv",
  * "lut_budget_mb",
  * "codes_u8" (1, the default: indexes with K <= 256 are scanned from one byte per code -- 16 instead of 28 bytes per row; 0: the

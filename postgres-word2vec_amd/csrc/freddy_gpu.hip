@@ -86,6 +86,7 @@ struct Tuning {
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
   int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
   int fuse_table = 1;          // FREDDY_GPU_FUSE_TABLE: the MFMA cell-selection distances and the query x codebook table as ONE launch (heterogeneous workgroups)
+  int sparse_pairs = 1;        // FREDDY_GPU_SPARSE_PAIRS: the item-wise scan reads a cell that exactly two queries probe once for both (sparse5.h NI = 2)
   int sparse_items = 2;        // FREDDY_GPU_SPARSE_ITEMS: cells that at most this many queries of a batch probe are scanned item by item (sparse5.h) instead of as cell-grouped work entries (0 = never)
   int scan_quota_wgs = 0;      // FREDDY_GPU_SCAN_QUOTA_WGS: number of quota-limited workgroups in front of the persistent ones (0 = from the batch's size)
   int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
@@ -128,6 +129,7 @@ static Tuning read_tuning() {
   t.scan_quota = (int)env_int("FREDDY_GPU_SCAN_QUOTA", t.scan_quota);
   t.scan_quota_wgs = (int)env_int("FREDDY_GPU_SCAN_QUOTA_WGS", t.scan_quota_wgs);
   t.sparse_items = (int)env_int("FREDDY_GPU_SPARSE_ITEMS", t.sparse_items);
+  t.sparse_pairs = (int)env_int("FREDDY_GPU_SPARSE_PAIRS", t.sparse_pairs);
   t.fuse_table = (int)env_int("FREDDY_GPU_FUSE_TABLE", t.fuse_table);
   t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.exact_filter = (int)env_int("FREDDY_GPU_EXACT_FILTER", t.exact_filter);
@@ -1036,6 +1038,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
   else if (n == "fuse_table") t.fuse_table = (int)value;
   else if (n == "sparse_items") t.sparse_items = std::max(-16, std::min(16, (int)value));
+  else if (n == "sparse_pairs") t.sparse_pairs = value != 0;
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
@@ -1306,6 +1309,7 @@ struct WorkTable {
   // (item, chunk) units of the cells that few queries probe (sparse5.h); sp_cap = 0: none
   size_t sp_cap;
   int32_t *sp_cell, *sp_first, *sp_chunk, *n_sparse, *sp_counter;
+  bool sp_pairs = false;   // units of up to two items (sparse5.h NI = 2)
 };
 static int ivf_work_table(IvfRun& r, WorkTable& wt) {
   Workspace* ws = r.ws;
@@ -1332,8 +1336,9 @@ static int ivf_work_table(IvfRun& r, WorkTable& wt) {
   timed_launch(ix, s, "work_table", [&] {
     hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ws->w_cellcnt.as<int32_t>(), ix->C, r.n_active, r.scan_kernel == 5 ? SCAN5_G : SPEC2_G, ix->blk_off,
                        wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : r.scan_kernel == 4 ? 1 : 0,
-                       sparse_max, wt.sp_cell, wt.sp_first, wt.sp_chunk, wt.n_sparse);
+                       sparse_max, wt.sp_cell, wt.sp_first, wt.sp_chunk, wt.n_sparse, (sparse_max >= 2 && ix->tune.sparse_pairs) ? 1 : 0);
   });
+  wt.sp_pairs = sparse_max >= 2 && ix->tune.sparse_pairs;
   HIP_TRY(hipGetLastError());
   if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, 2 * sizeof(int32_t), s));   // (both work counters)
   return 0;
@@ -1457,9 +1462,15 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     sp.item_dist = pa.item_dist; sp.sp_cell = wt.sp_cell; sp.sp_first = wt.sp_first; sp.sp_chunk = wt.sp_chunk;
     sp.n_units = wt.n_sparse; sp.work_counter = wt.sp_counter; sp.surv = fl.surv; sp.surv_count = fl.surv_count; sp.packed8 = fl.packed8;
     sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.ablate = fl.ablate;
-    const unsigned sp_grid = (unsigned)std::min<size_t>(wt.sp_cap, (size_t)std::max(1, scan_cus) * 6);
+    const unsigned sp_grid = (unsigned)std::min<size_t>(wt.sp_cap, (size_t)std::max(1, scan_cus) * (wt.sp_pairs ? 3 : 6));
     timed_launch(ix, ss, "sparse_items", [&] {
-      if (u8) {
+      if (wt.sp_pairs) {   // (cell, chunk) units of one or two items: the rows of a two-item cell are read once
+        if (u8) {
+          if (fl.cand_count) hipLaunchKernelGGL((sparse_pair5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
+          else hipLaunchKernelGGL((sparse_pair5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
+        } else if (fl.cand_count) hipLaunchKernelGGL((sparse_pair5_kernel<12, true, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
+        else hipLaunchKernelGGL((sparse_pair5_kernel<12, false, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
+      } else if (u8) {
         if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
         else hipLaunchKernelGGL((sparse_item5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
       } else if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true>), dim3(sp_grid), dim3(256), 0, ss, sp);

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restr
                                                          int32_t* __restrict__ n_groups, int cost_mode,
                                                          int sparse_max = 0, int32_t* __restrict__ sp_cell = nullptr,
                                                          int32_t* __restrict__ sp_first = nullptr, int32_t* __restrict__ sp_chunk = nullptr,
-                                                         int32_t* __restrict__ n_sparse = nullptr) {
+                                                         int32_t* __restrict__ n_sparse = nullptr, int sp_pairs = 0) {
   constexpr int NB = 128;   // cost classes, descending (cost_mode 0 uses FUSED_G * 4 + 4 of them: (items, quarter of a full chunk))
   constexpr int T = 1024, CPT = 4;   // the first T * CPT cells are read once and kept in registers for both sweeps
   __shared__ int hist[NB];
@@ -63,13 +63,16 @@ __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restr
     if (n == 0) return;
     const int chunks = (nblk + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
     if (n <= sparse_max) {
+      // sp_pairs: units of two items (and a last one of one: sparse_pair5_kernel reads a unit's rows once for both);
+      // bits 8.. of sp_chunk = items of the unit
+      const int per = sp_pairs ? 2 : 1;
       if (!emit)
-        for (int f = 0; f < n; ++f)
+        for (int f = 0; f < n; f += per)
           for (int ch = 0; ch < chunks; ++ch) {
             const int slot = atomicAdd(&sp_n, 1);
             sp_cell[slot] = c;
             sp_first[slot] = c * cell_cap + f;
-            sp_chunk[slot] = ch;
+            sp_chunk[slot] = ch | ((n - f < per ? n - f : per) << 8);
           }
       return;
     }

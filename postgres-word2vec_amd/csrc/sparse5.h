@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
     __syncthreads();
     const int unit = unit_sh;
     if (unit >= n_units) return;
-    const int cell = a.sp_cell[unit], chunk = a.sp_chunk[unit];
+    const int cell = a.sp_cell[unit], chunk = a.sp_chunk[unit] & 0xff;   // (bits 8..: items of the unit, always 1 here)
     const int it = a.sorted_item[a.sp_first[unit]];
     const int q = a.item_query[it];
     const float sc0 = a.qscale[q];
@@ -187,6 +187,198 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
       a.surv_count[region[0]] = run[0];
       a.surv_count[region[1]] = run[1];
       if (CAND && accepted) atomicAdd(a.cand_count + q, accepted);
+    }
+    __syncthreads();   // (colmin / thr_sh / unit_sh are rewritten by the next unit)
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// The same scan with units of ONE OR TWO items: a (cell, chunk) that exactly two queries of the batch probe is one unit
+// (work_table_kernel, sp_pairs: the count sits in bits 8.. of sp_chunk), its rows are read once and looked up in both
+// queries' tables (48 KB of LDS, three workgroups per CU).  On the 40 M-row corpus a fifth of the item-wise scan's bytes are
+// cells with exactly two items, read twice by sparse_item5_kernel.
+// ---------------------------------------------------------------------------------------
+template <int M, bool CAND, bool U8, int N>   // N = items of the unit
+__device__ __forceinline__ void sparse_rows5(const SparseArgs& a, const unsigned char* lut_b, int b0, int nb, int last_blk, int tail_rows,
+                                            int wave, int lane, const float (&sc)[2], float (&sv)[2][16]) {
+  constexpr int RS = 16, RB = 8;   // (eight rows' loads in flight: half the waves per CU of the one-item kernel)
+  constexpr int NCW = U8 ? M / 4 : M / 2;
+#pragma unroll
+  for (int r0 = 0; r0 < RS; r0 += RB) {
+    uint32_t cw[RB][NCW];
+    float rt[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int bl = (r0 + u) * 4 + wave;
+      const uint32_t blk = (uint32_t)(b0 + (bl < nb - 1 ? bl : (nb > 0 ? nb - 1 : 0)));
+#pragma unroll
+      for (int pr = 0; pr < NCW; ++pr)
+        cw[u][pr] = U8 ? a.packed8[((size_t)blk * NCW + pr) * 64u + (uint32_t)lane] : a.packed[((size_t)blk * NCW + pr) * 64u + (uint32_t)lane];
+      rt[u] = a.rterm[(size_t)blk * 64u + (uint32_t)lane];
+    }
+#pragma unroll
+    for (int u = 0; u < RB; ++u) {
+      const int bl = (r0 + u) * 4 + wave;
+      uint32_t sum[2] = {0u, 0u};
+#pragma unroll
+      for (int pr = 0; pr < M / 2; ++pr) {
+        const uint32_t w = U8 ? cw[u][pr >> 1] : cw[u][pr];
+        const uint32_t a0 = U8 ? ((pr & 1) ? ((w >> 15) & 0x1feu) : ((w << 1) & 0x1feu)) : ((w << 1) & 0x7feu);
+        const uint32_t a1 = U8 ? ((pr & 1) ? ((w >> 23) & 0x1feu) : ((w >> 7) & 0x1feu)) : ((w >> 15) & 0x7feu);
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          const uint32_t v0 = *reinterpret_cast<const uint16_t*>(lut_b + (uint32_t)i * (M * 2048u) + a0 + (uint32_t)(2 * pr) * 2048u);
+          const uint32_t v1 = *reinterpret_cast<const uint16_t*>(lut_b + (uint32_t)i * (M * 2048u) + a1 + (uint32_t)(2 * pr + 1) * 2048u);
+          sum[i] = sum[i] + v0 + v1;
+        }
+      }
+      const bool live = bl < nb && !(bl == last_blk && tail_rows != 0 && lane >= tail_rows);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int v = (int)sum[i] - 32768;   // (the biases add up to 2^15: filt5_bias)
+        sv[i][r0 + u] = (live && i < N) ? __builtin_fmaf(sc[i], (float)v, rt[u]) : __uint_as_float(0x7f800000u);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);   // (one group of RB rows in flight at a time: the scheduler otherwise hoists every load and spills)
+  }
+}
+
+template <int M, bool CAND, bool U8 = false>
+__global__ __launch_bounds__(256, 3) void sparse_pair5_kernel(SparseArgs a) {
+  static_assert(M == 12, "table layout");
+  constexpr int NI = 2;
+  constexpr int RS = 16;       // row slots per lane: 4 waves x 16 x 64 = a chunk of 4096 rows
+  constexpr int NGV = 8;       // survivor regions per (item, chunk): the cell-grouped scan's gatherer waves
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) uint16_t lut[NI][M][1024];
+  __shared__ uint32_t colmin[NI][64];
+  __shared__ uint32_t thr_sh[NI];
+  __shared__ int unit_sh;
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int n_units = a.n_units[0];
+  for (;;) {
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));   // (opaque per unit: lane-derived addresses are not hoisted out of the unit loop)
+    const int lane = tid & 63;
+    if (tid == 0) unit_sh = atomicAdd(a.work_counter, 1);
+    if (tid < 64) { colmin[0][tid] = 0xffffffffu; colmin[1][tid] = 0xffffffffu; }
+    __syncthreads();
+    const int unit = __builtin_amdgcn_readfirstlane(unit_sh);
+    if (unit >= n_units) return;
+    const int cell = a.sp_cell[unit];
+    const int chw = a.sp_chunk[unit];
+    const int chunk = chw & 0xff;
+    const int cnt = (chw >> 8) >= 2 ? 2 : 1;
+    int it[NI], q[NI];
+    float sc[NI];
+    ItemBounds ib[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      it[i] = a.sorted_item[a.sp_first[unit] + (i < cnt ? i : 0)];
+      q[i] = a.item_query[it[i]];
+      const float sc0 = a.qscale[q[i]];
+      sc[i] = sc0 < 1e30f ? sc0 : 0.0f;
+      ib[i] = item_bounds(a.item_dist[it[i]], filter_width5<M>(a.qn + (size_t)q[i] * M, a.pmax, sc0), a.sentinel);
+    }
+    const int b0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
+    int nb = a.blk_off[cell + 1] - b0;
+    nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
+    int rows = a.list_off[cell + 1] - a.list_off[cell] - chunk * (FUSED_UNIT_BLOCKS * 64);
+    rows = rows > FUSED_UNIT_BLOCKS * 64 ? FUSED_UNIT_BLOCKS * 64 : rows;
+    // the queries' tables -> LDS, [item][position][code]
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i < cnt) {
+        const u4* src = reinterpret_cast<const u4*>(a.qc + (size_t)q[i] * (M * 512));
+#pragma unroll
+        for (int k = 0; k < (M * 128) / 256; ++k) {
+          const int u = tid + 256 * k;
+          const int p = u >> 7, li = u & 127;
+          const u4 v = src[u];
+          uint16_t* row = lut[i][p];
+          row[li] = (uint16_t)v.x; row[li + 512] = (uint16_t)(v.x >> 16);
+          row[li + 128] = (uint16_t)v.y; row[li + 640] = (uint16_t)(v.y >> 16);
+          row[li + 256] = (uint16_t)v.z; row[li + 768] = (uint16_t)(v.z >> 16);
+          row[li + 384] = (uint16_t)v.w; row[li + 896] = (uint16_t)(v.w >> 16);
+        }
+      }
+    }
+    __syncthreads();
+    // s' of this lane's 16 rows (+inf: no such row), per item
+    float sv[NI][RS];
+    const int last_blk = rows > 0 ? (rows - 1) >> 6 : -1;
+    const int tail_rows = rows & 63;
+    const unsigned char* lut_b = reinterpret_cast<const unsigned char*>(&lut[0][0][0]);
+    if (cnt == 1) sparse_rows5<M, CAND, U8, 1>(a, lut_b, b0, nb, last_blk, tail_rows, wave, lane, sc, sv);
+    else sparse_rows5<M, CAND, U8, 2>(a, lut_b, b0, nb, last_blk, tail_rows, wave, lane, sc, sv);
+    // column minima over the 4 waves x 16 rows of a lane index -> tau' = the L-th smallest -> threshold
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i < cnt) {
+        float mn = sv[i][0];
+#pragma unroll
+        for (int r = 1; r < RS; ++r) mn = fminf(mn, sv[i][r]);
+        if (wave < nb) atomicMin(&colmin[i][lane], float_key(mn));
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (wave == i && i < cnt) {     // (wave i: item i's threshold)
+        const uint32_t c0 = wave_sort32(colmin[i][lane]);
+        const uint32_t t0 = __shfl(c0, a.L - 1, 64);
+        if (lane == 0) thr_sh[i] = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t0, ib[i].e);
+      }
+    }
+    __syncthreads();
+    // survivors: even row slots -> region `wave`, odd ones -> region `wave + 4`
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      if (i < cnt) {
+        const float thr = __uint_as_float(thr_sh[i]);
+        int run[2] = {0, 0};
+        int accepted = 0;
+        u64* dst[2];
+        size_t region[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          region[h] = ((size_t)it[i] * a.upi + chunk) * NGV + (size_t)(wave + 4 * h);
+          dst[h] = a.surv + region[h] * (size_t)(FUSED_RMAX * 64);
+        }
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+          const int bl = r * 4 + wave;
+          if (bl >= nb) break;   // (uniform)
+          const bool live = !(bl == last_blk && tail_rows != 0 && lane >= tail_rows);
+          bool pass;
+          uint32_t sb = 0u;
+          bool amb = false;
+          if constexpr (CAND) {   // rows below the sentinel are counted (freddy.c:971): bounds on the bits of s = s' + OFF > 0
+            sb = __float_as_uint(sv[i][r] + ib[i].off);
+            accepted += __popcll(__ballot(live && sb < ib[i].lo_bits));
+            amb = sb >= ib[i].lo_bits && sb < ib[i].hi_bits;
+            pass = live && (!(sv[i][r] > thr) || amb);
+          } else {
+            pass = live && !(sv[i][r] > thr);   // (a NaN passes: exact stage)
+          }
+          const u64 mask = __ballot(pass);
+          if (mask != 0ull) {
+            const int h = r & 1;
+            if (pass) {
+              const float dlo = CAND ? fmaxf(0.0f, __uint_as_float(sb) - ib[i].shift) : fmaxf(0.0f, (sv[i][r] + ib[i].off) - ib[i].shift);
+              const uint32_t loc = ((uint32_t)(b0 + bl) * 64u + (uint32_t)lane) | ((CAND && amb) ? 0x80000000u : 0u);
+              dst[h][run[h] + lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+            }
+            run[h] += __popcll(mask);
+          }
+        }
+        if (lane == 0) {
+          a.surv_count[region[0]] = run[0];
+          a.surv_count[region[1]] = run[1];
+          if (CAND && accepted) atomicAdd(a.cand_count + q[i], accepted);
+        }
+      }
     }
     __syncthreads();   // (colmin / thr_sh / unit_sh are rewritten by the next unit)
   }

@@ -673,18 +673,26 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
 # item-wise scan of thin cells (sparse5.h): the same brackets, regions and lists as the cell-grouped scan
 # ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
+@pytest.mark.parametrize("pairs", [1, 0])
 @pytest.mark.parametrize("K", [256, 1024])
-def test_sparse_item_scan_matches_oracle(gpu, oracle, K, monkeypatch):
+def test_sparse_item_scan_matches_oracle(gpu, oracle, K, pairs, monkeypatch):
     """Option sparse_items < 0 forces the item-wise scan for every cell with at most that many items: all cells (-16: the
-    cell-grouped scan gets nothing), a mix (-2), none (0); every rule of counting found rows; multi-round searches."""
+    cell-grouped scan gets nothing), a mix (-2), none (0); every rule of counting found rows; multi-round searches.
+    sparse_pairs: cells of exactly two items as one unit (their rows read once) or as two."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     t, ot, idx, qs = _fr_setup(gpu, oracle, K=K, dup_rows=3)
+    idx.set_option("sparse_pairs", pairs)
     for force in (-16, -2, 0):
         idx.set_option("sparse_items", force)
         for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 4, 1, 100.0), (5, 1, 2, 100.0), (32, 2, 0, 1000.0)):
             gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
             exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} K={K} k={k} W={W} rule={rule}")
+            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} pairs {pairs} K={K} k={k} W={W} rule={rule}")
+        # few queries: most probed cells have one or two items (the pair units' case)
+        for nq in (2, 7):
+            gi, gd = idx.search(qs[:nq], 5, 3, sentinel=1000.0, found_rule=0)
+            exp = oracle.ivfadc_search_many(ot, qs[:nq], 5, 3, sentinel=1000.0, found_rule=0)
+            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} pairs {pairs} K={K} {nq} queries")
     assert idx.bound_violations() == 0
     idx.close()
 
@@ -698,6 +706,8 @@ def test_sparse_item_scan_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
         idx.set_option("sparse_items", -16)
         idx.set_option("fused_ablate", 8)
         idx.set_option("merge_ablate", 32)
+        g2, d2 = idx.search(qs[:12], 5, 2, sentinel=1000.0, found_rule=0)   # (many cells with exactly two items: pair units)
+        util.assert_same_lists(g2, d2, oracle.ivfadc_search_many(ot, qs[:12], 5, 2, sentinel=1000.0, found_rule=0), f"12 queries, scale {scale}")
         qs = qs[:48]
         gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
         exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
