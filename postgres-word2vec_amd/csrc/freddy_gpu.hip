@@ -28,6 +28,7 @@
 #include "scan_common.h"
 #include "fused3.h"
 #include "fused5.h"
+#include "one.h"
 #include "sparse5.h"
 #include "coarse.h"
 #include "exact.h"
@@ -77,6 +78,7 @@ struct Tuning {
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
+  int one_launch = 1;          // FREDDY_GPU_ONE_LAUNCH: a single pq_search query through the host-buffer call as ONE launch (one.h) instead of three
   int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
   int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
   int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches the CALLER keeps in flight on this handle through the *_dev entry points
@@ -122,6 +124,7 @@ static Tuning read_tuning() {
   t.pipeline_batch = (int)std::max<int64_t>(16, env_int("FREDDY_GPU_PIPELINE_BATCH", t.pipeline_batch));
   t.pipeline_lanes = (int)std::min<int64_t>(4, std::max<int64_t>(1, env_int("FREDDY_GPU_PIPELINE_LANES", t.pipeline_lanes)));
   t.pq_fused = (int)env_int("FREDDY_GPU_PQ_FUSED", t.pq_fused);
+  t.one_launch = (int)env_int("FREDDY_GPU_ONE_LAUNCH", t.one_launch);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -173,7 +176,7 @@ struct Workspace {
   hipEvent_t ev_in = nullptr, ev_fe = nullptr, ev_scan = nullptr, ev_out = nullptr;
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs, w_tmin;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs, w_tmin, w_one;
   void release_partition() {
     if (fe_stream) { (void)hipStreamSynchronize(fe_stream); (void)hipStreamDestroy(fe_stream); fe_stream = nullptr; }
     if (scan_stream) { (void)hipStreamSynchronize(scan_stream); (void)hipStreamDestroy(scan_stream); scan_stream = nullptr; }
@@ -189,7 +192,7 @@ struct Workspace {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs, &w_tmin};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs, &w_tmin, &w_one};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -326,6 +329,7 @@ struct freddy_gpu_index {
   // set when a mutation (append_rows / update_codebook / set_option) failed after it had already changed some of the devices
   // behind this handle: the replicas no longer hold the same tables, so every search fails loudly until the handle is unpinned
   bool poisoned = false;
+  bool one_launch_failed = false;   // pq_one_kernel once ran out of its bounded polls on this handle: three launches from then on
   // profiling
   bool profiling = false;
   std::map<std::string, ProfRec> prof;
@@ -1043,6 +1047,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
   else if (n == "merge_waves") t.merge_waves = (int)value;
   else if (n == "pq_fused") t.pq_fused = (int)value;
+  else if (n == "one_launch") t.one_launch = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -2366,6 +2371,41 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   return ivf_scan_filter(r, pa, wt);
 }
 
+// ONE query over the flat table as one launch (one.h): table slices, grid barrier, scan, last-arriver merge.  `err` is a
+// word of mapped host memory the kernel sets when one of its bounded polls ran out (the grid was not co-resident): the
+// caller then re-arms the counters and takes the three-launch path.
+static bool pq_one_shape(const freddy_gpu_index* ix, int Q, int k, int64_t n_blocks) {
+  return ix->tune.one_launch && !ix->one_launch_failed && Q == 1 && ix->m == 12 && ix->S == 25 && ix->K <= 1024 && (ix->K & 3) == 0 && ix->d == 300 &&
+         2 * k <= 64 && n_blocks >= 64 && (int64_t)ix->h_ids.size() == ix->N;
+}
+static int pq_one(freddy_gpu_index* ix, hipStream_t s, const float* h_q, int k, float sentinel, const int32_t* blk_off,
+                  const uint32_t* packed, const int32_t* pos, int64_t n_blocks, int32_t* d_out_ids, float* d_out_dist, int32_t* err) {
+  Workspace* ws = workspace_for(ix, s);
+  const int K = ix->K, L = 2 * k;
+  const size_t lutN = (size_t)12 * K;
+  // (one workgroup per CU at most: all co-resident; the last arriver stages every list in LDS: G * L keys within 56 KB)
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ix->n_cus, (int64_t)256, (n_blocks + ONE_WAVES - 1) / ONE_WAVES, (int64_t)(56 * 1024) / (8 * L)}));
+  const int chunk_blocks = (int)((n_blocks + G - 1) / G);
+  const bool fresh = ws->w_one.p == nullptr;
+  if (ws->w_lut.ensure(sizeof(float) * lutN) || ws->w_part.ensure(sizeof(u64) * (size_t)G * L) || ws->w_one.ensure(256))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (fresh) HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 256, s));
+  OneArgs a;
+  memcpy(a.qv, h_q, sizeof(a.qv)); a.cbT = ix->cbT; a.lut_g = ws->w_lut.as<float>(); a.blk_off = blk_off; a.packed = packed; a.pos = pos;
+  a.pos_to_id = nullptr;   // (positions out: the caller maps them through its host copy of the ids -- no dependent gather at the kernel's end)
+  a.part = ws->w_part.as<u64>(); a.out_ids = d_out_ids; a.out_dist = d_out_dist;
+  a.sync = ws->w_one.as<uint32_t>(); a.err = err;
+  static const bool one_prof = getenv("FREDDY_GPU_ONE_PROF") != nullptr;
+  a.prof = one_prof ? ws->w_one.as<unsigned long long>() + 8 : nullptr;
+  a.K = K; a.L = L; a.k = k; a.chunk_blocks = chunk_blocks; a.sentinel = sentinel;
+  memcpy(&a.sentinel_bits, &sentinel, 4);
+  const size_t lds = std::max(((lutN * 4 + 15) & ~(size_t)15) + (size_t)ONE_WAVES * 64 * sizeof(u64),
+                              (size_t)ONE_WAVES * 64 * sizeof(u64) + (size_t)G * L * sizeof(u64));
+  timed_launch(ix, s, "pq_one", [&] { hipLaunchKernelGGL((pq_one_kernel<25>), dim3((unsigned)G), dim3(ONE_WG), lds, s, a); });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
                     const int32_t* blk_off, const uint32_t* packed, const int32_t* pos, int64_t n_blocks,
                     int32_t* d_out_ids, float* d_out_dist) {
@@ -2515,6 +2555,41 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
     view = ix->pq_sub_view;
   }
   const int qc = fused_path ? pq_fused_queries_per_chunk(ix, n_blocks) : max_queries_per_chunk(ix, 1);
+  if (!fused_path && direct && pq_one_shape(ix, Q, k, n_blocks)) {
+    int32_t* err = reinterpret_cast<int32_t*>(static_cast<char*>(ix->hio_out) + n_out * 8);   // (the staging block's spare 16 bytes)
+    *err = 0;
+    if (int rc = pq_one(ix, s, queries, k, sentinel, blk_off, packed, pos, n_blocks, d_oi, d_od, err)) return rc;
+    // the kernel's last store is this word (2 = list written, 1 = a bounded poll ran out): polled here for up to a millisecond
+    // -- a few microseconds sooner than the runtime's completion signal -- then the stream is waited for the usual way
+    {
+      volatile int32_t* flag = err;
+      const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(1000);
+      int spins = 0;
+      while (*flag == 0) {
+        __builtin_ia32_pause();
+        if ((++spins & 255) == 0 && std::chrono::steady_clock::now() > t_end) break;
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+      if (*flag != 2) HIP_TRY(hipStreamSynchronize(s));
+    }
+    if (getenv("FREDDY_GPU_ONE_PROF")) {
+      HIP_TRY(hipStreamSynchronize(s));
+      unsigned long long st[16];
+      (void)hipMemcpy(st, ws->w_one.as<unsigned long long>() + 8, sizeof(st), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[pq_one] wg0: slice %.2f barrier %.2f stage %.2f scan %.2f publish %.2f | last: since wg0 start %.2f merge %.2f replay %.2f us\n",
+              (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01,
+              (st[8] - st[0]) * 0.01, (st[9] - st[8]) * 0.01, (st[10] - st[9]) * 0.01);
+    }
+    if (*err == 2) {
+      const int32_t* h_pos = static_cast<const int32_t*>(ix->hio_out);
+      for (size_t i = 0; i < n_out; ++i) out_ids[i] = h_pos[i] >= 0 ? ix->h_ids[(size_t)h_pos[i]] : -1;
+      memcpy(out_dist, h_pos + n_out, n_out * 4);
+      return FREDDY_OK;
+    }
+    // the grid never met at its barrier (not co-resident): counters re-armed, this handle keeps to the three-launch path
+    ix->one_launch_failed = true;
+    HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 64, s));
+  }
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     if (fused_path) {

@@ -1,0 +1,340 @@
+// one.h -- pq_search for ONE query as a single launch (gfx950).
+//
+// The generic path answers a single query with three dependent launches -- lut_build_kernel, adc_scan_kernel,
+// merge_replay_kernel: 14 + 22 + 14 us under HIP events for 28 MB of codes that sit in the caches -- i.e. mostly launch
+// gaps.  pq_one_kernel is the same three stages in one grid of at most one workgroup per CU (all co-resident):
+//   1. every workgroup computes its slice of the query's table lut[pos*K + code] = squareDistance(q_pos, cb[pos][code])
+//      (index_utils.c:445-455; the sequential binary32 chain of lut_build_kernel) and publishes it with write-through
+//      stores; grid barrier (one arrival counter, agent scope);
+//   2. every workgroup stages the whole table in LDS and scans its chunk of row blocks exactly as adc_scan_kernel does
+//      (position-order sums, index_utils.c:1126-1133; WaveSelect of the L = 2k smallest (distance, position) keys), then
+//      publishes its L keys;
+//   3. the workgroup that arrives last merges the lists (eight waves, then one) and replays the reference's guarded
+//      insertion in scan order (merge_replay_kernel's tail: updateTopK + "dist < maxDist", index_utils.c:19-33,
+//      freddy.c:128-131), writes the result and re-arms the counters.
+// Inter-workgroup hand-offs follow the write-through recipe: payload stored with agent-scope (sc1) stores, every writing
+// wave drains its stores, workgroup barrier, one lane bumps the counter; the consumer polls with relaxed agent-scope loads,
+// one lane executes an agent-scope acquire, workgroup barrier, plain loads.  The polls are bounded: a grid that cannot
+// become co-resident reports through `err` instead of hanging (the host then takes the three-launch path).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+#include "wave_topk.h"
+
+namespace freddy {
+
+struct OneArgs {
+  float qv[300];             // the query, by value: it travels with the dispatch (no PCIe read at kernel start)
+  const float* cbT;          // [m][S][K]
+  float* lut_g;              // [m*K] workspace
+  const int32_t* blk_off;    // [2] row blocks of the (one) list
+  const uint32_t* packed;    // [blocks][M/2][64]
+  const int32_t* pos;        // [blocks*64] scan position, -1 = padding
+  const int32_t* pos_to_id;  // NULL: the position is the id
+  u64* part;                 // [grid][L] workspace
+  int32_t* out_ids;          // [k]
+  float* out_dist;           // [k]
+  uint32_t* sync;            // [2] arrival counters, zero on entry, zero again on exit
+  int32_t* err;              // [1] mapped host memory: 1 = a poll ran out; 2 = result written (the host may poll this word)
+  unsigned long long* prof;  // debugging: phase stamps (100 MHz) of workgroup 0 [0..7] and of the last arriver [8..15]
+  int K, L, k, chunk_blocks;
+  float sentinel;
+  uint32_t sentinel_bits;
+};
+
+static constexpr int ONE_WG = 512;
+static constexpr int ONE_WAVES = ONE_WG / 64;
+static constexpr uint32_t ONE_SPIN_LIMIT = 200000u;   // polls of >= 64 cycles each: tens of milliseconds
+
+__device__ __forceinline__ bool one_wait(uint32_t* counter, uint32_t target) {
+  uint32_t spins = 0;
+  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (++spins > ONE_SPIN_LIMIT) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+// Smallest key over the wave's lanes [0, 1 << STEPS) (the other lanes are ignored), in every lane.  The minimum of the
+// distance words decides almost every time (32-bit exchanges); only lanes that tie on it compare their position words.
+template <int STEPS>
+__device__ __forceinline__ u64 one_wave_min(u64 key) {
+  const uint32_t hi = (uint32_t)(key >> 32), lo = (uint32_t)key;
+  uint32_t m = hi;
+#pragma unroll
+  for (int st = 0; st < STEPS; ++st) m = min(m, (uint32_t)lane_xor((int)m, 1 << st));
+  m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+  const u64 in_range = STEPS == 6 ? ~0ull : ((1ull << (1 << (STEPS < 6 ? STEPS : 0))) - 1ull);
+  const u64 tied = __ballot(hi == m) & in_range;
+  uint32_t ml;
+  if (__popcll(tied) == 1) {
+    ml = (uint32_t)__builtin_amdgcn_readlane((int)lo, __builtin_ctzll(tied));
+  } else {
+    ml = hi == m ? lo : 0xffffffffu;
+#pragma unroll
+    for (int st = 0; st < STEPS; ++st) ml = min(ml, (uint32_t)lane_xor((int)ml, 1 << st));
+    ml = (uint32_t)__builtin_amdgcn_readfirstlane((int)ml);
+  }
+  return ((u64)m << 32) | (u64)ml;
+}
+
+// The L smallest keys of n <= 8 ascending lists held in LDS (list x: rows[r * stride + x], r = 0.., KEY_INF where a list
+// ends), ascending, lane r <- rank r (KEY_INF beyond L): lane x walks list x, each round the smallest head is taken and
+// its lane advances.  Keys are unique (the position is part of the key).
+__device__ __forceinline__ u64 one_multiway(const u64* rows, int stride, int n, int L, int lane) {
+  int h = 0;
+  u64 head = lane < n ? rows[lane] : KEY_INF;
+  u64 out = KEY_INF;
+  for (int r = 0; r < L; ++r) {
+    const u64 mn = one_wave_min<3>(head);
+    if (mn == KEY_INF) break;   // (uniform)
+    if (lane == r) out = mn;
+    if (head == mn) {
+      ++h;
+      head = h < L ? rows[(size_t)h * stride + lane] : KEY_INF;
+    }
+  }
+  return out;
+}
+
+// The same over up to 256 lists with ONE wave: lane x walks the lists x, x + 64, x + 128, x + 192 (rows[r * n + list]).
+__device__ __forceinline__ u64 one_multiway4(const u64* rows, int n, int L, int lane) {
+  int h[4] = {0, 0, 0, 0};
+  u64 head[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) head[t] = lane + 64 * t < n ? rows[lane + 64 * t] : KEY_INF;
+  u64 out = KEY_INF;
+  for (int r = 0; r < L; ++r) {
+    const u64 m01 = umin64(head[0], head[1]), m23 = umin64(head[2], head[3]);
+    const u64 mine = umin64(m01, m23);
+    const u64 mn = one_wave_min<6>(mine);
+    if (mn == KEY_INF) break;   // (uniform)
+    if (lane == r) out = mn;
+    if (mine == mn) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (head[t] == mn) {
+          ++h[t];
+          head[t] = h[t] < L ? rows[(size_t)h[t] * n + lane + 64 * t] : KEY_INF;
+        }
+      }
+    }
+  }
+  return out;
+}
+
+template <int S>
+__global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
+  constexpr int M = 12, M2T = 6;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int flag_sh;
+  const int K = a.K, lutN = M * K;
+  float* lut = reinterpret_cast<float*>(smem);
+  u64* stage = reinterpret_cast<u64*>(smem + (((size_t)lutN * 4 + 15) & ~(size_t)15));
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = blockIdx.x, G = gridDim.x;
+#define ONE_STAMP(i) do { if (a.prof && tid == 0 && w == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ONE_STAMP_LAST(i) do { if (a.prof && tid == 0) a.prof[8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  ONE_STAMP(0);
+
+  // (the first row blocks of every wave are requested between the drain of the table slice and the barrier's poll)
+  const int b0 = a.blk_off[0] + w * a.chunk_blocks;
+  int b1 = a.blk_off[1];
+  if (b0 + a.chunk_blocks < b1) b1 = b0 + a.chunk_blocks;
+  constexpr int PF = 8;
+  RowBlock<M2T> ring[PF];
+  auto fetch = [&](RowBlock<M2T>& rb, int blk) {
+    const int bc = blk < b1 ? blk : b1 - 1;           // (past the end: a repeat of the last block, never used)
+    const uint32_t* pk = a.packed + (size_t)bc * M2T * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < M2T; ++j) rb.w[j] = pk[j * 64];
+    rb.p = a.pos[(size_t)bc * 64 + lane];
+  };
+  int b = b0 + wave;
+  // ---- 1. this workgroup's slice of the table: unit = (position, range of codes) ----
+  {
+    static_assert(M * S == 300, "the query travels as 300 floats");
+    const int n_slot = G >= M ? G / M : 1, cw = (K + n_slot - 1) / n_slot;
+    for (int unit = w; unit < M * n_slot; unit += G) {
+      const int p = unit / n_slot, c0 = (unit - p * n_slot) * cw;   // (p: workgroup-uniform)
+      const int c1 = c0 + cw < K ? c0 + cw : K;
+      for (int c = c0 + tid; c < c1; c += ONE_WG) {
+        float cb[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) cb[j] = a.cbT[((size_t)p * S + j) * K + c];
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          const float t = a.qv[p * S + j] - cb[j];
+          const float pr = t * t;
+          acc = acc + pr;
+        }
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + p * K + c, __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ONE_STAMP(1);
+    if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b0 < b1) {   // (in flight while the barrier is polled)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) fetch(ring[u], b + u * ONE_WAVES);
+    }
+    if (tid == 0) {
+      const bool ok = one_wait(a.sync, (uint32_t)G);
+      if (!ok) a.err[0] = 1;
+      flag_sh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!flag_sh) return;
+    ONE_STAMP(2);
+  }
+
+  // ---- 2. the table -> LDS, this workgroup's chunk of row blocks ----
+  WaveSelect<1> sel;
+  const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
+  sel.init(stage + wave * 64, sentinel_key, a.L);
+  if (b0 < b1) {   // workgroup-uniform
+    {
+      // write-through (sc1) payload -> sc1 loads: served by the L2, never by this CU's L1 (no acquire fence needed); six
+      // 16-byte loads per lane in ONE asm statement that ends with the wait (the compiler cannot see that an asm load's
+      // result arrives later)
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4* s16 = reinterpret_cast<const f4*>(a.lut_g);
+      f4* d16 = reinterpret_cast<f4*>(lut);
+      const int n16 = lutN >> 2;   // (K is a multiple of 4: host check)
+      for (int i0 = 0; i0 < n16; i0 += ONE_WG * 6) {
+        f4 t0, t1, t2, t3, t4, t5;
+        const int i = i0 + tid;
+        const f4* p0 = s16 + (i < n16 ? i : n16 - 1);
+        const f4* p1 = s16 + (i + ONE_WG < n16 ? i + ONE_WG : n16 - 1);
+        const f4* p2 = s16 + (i + 2 * ONE_WG < n16 ? i + 2 * ONE_WG : n16 - 1);
+        const f4* p3 = s16 + (i + 3 * ONE_WG < n16 ? i + 3 * ONE_WG : n16 - 1);
+        const f4* p4 = s16 + (i + 4 * ONE_WG < n16 ? i + 4 * ONE_WG : n16 - 1);
+        const f4* p5 = s16 + (i + 5 * ONE_WG < n16 ? i + 5 * ONE_WG : n16 - 1);
+        asm volatile(
+            "global_load_dwordx4 %0, %6, off sc1\n\t"
+            "global_load_dwordx4 %1, %7, off sc1\n\t"
+            "global_load_dwordx4 %2, %8, off sc1\n\t"
+            "global_load_dwordx4 %3, %9, off sc1\n\t"
+            "global_load_dwordx4 %4, %10, off sc1\n\t"
+            "global_load_dwordx4 %5, %11, off sc1\n\t"
+            "s_waitcnt vmcnt(0)"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5)
+            : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+            : "memory");
+        if (i < n16) d16[i] = t0;
+        if (i + ONE_WG < n16) d16[i + ONE_WG] = t1;
+        if (i + 2 * ONE_WG < n16) d16[i + 2 * ONE_WG] = t2;
+        if (i + 3 * ONE_WG < n16) d16[i + 3 * ONE_WG] = t3;
+        if (i + 4 * ONE_WG < n16) d16[i + 4 * ONE_WG] = t4;
+        if (i + 5 * ONE_WG < n16) d16[i + 5 * ONE_WG] = t5;
+      }
+    }
+    __syncthreads();
+    ONE_STAMP(3);
+    for (; b < b1; b += PF * ONE_WAVES) {
+      u64 keys[PF];
+      uint32_t mn = 0xffffffffu;   // this lane's smallest distance (bits) among the group's valid rows
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const RowBlock<M2T> cur = ring[u];
+        const int bu = b + u * ONE_WAVES;
+        if (bu + PF * ONE_WAVES < b1) fetch(ring[u], bu + PF * ONE_WAVES);   // (wave-uniform)
+        keys[u] = KEY_INF;
+        if (bu < b1) {   // wave-uniform
+          float dist = 0.0f;
+#pragma unroll
+          for (int l = 0; l < M; ++l) {
+            const uint32_t code = (l & 1) ? (cur.w[l >> 1] >> 16) : (cur.w[l >> 1] & 0xffffu);
+            dist = dist + lut[l * K + code];
+          }
+          if (cur.p >= 0) {
+            keys[u] = make_key(dist, (uint32_t)cur.p);
+            mn = min(mn, __float_as_uint(dist));
+          }
+        }
+      }
+      // L rows of the group are at most as far as the L-th smallest lane minimum: nothing farther can be among the L
+      // smallest keys (one 32-bit sort instead of a 64-bit sort + merge per 64 passing keys while the threshold is loose)
+      const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)wave_sort32(mn), a.L - 1);
+      const u64 bound = ((u64)dL << 32) | 0xffffffffull;
+      if (bound < sel.tau) sel.tau = bound;
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (b + u * ONE_WAVES < b1) sel.push(keys[u], keys[u] != KEY_INF);
+    }
+    sel.finish();
+  }
+  ONE_STAMP(4);
+  // the eight waves' lists meet in LDS (the table is dead by now), wave 0 merges them and publishes the workgroup's list
+  // rank-major: part[r * G + w]
+  __syncthreads();
+  u64* lists = reinterpret_cast<u64*>(smem);   // [64 ranks][ONE_WAVES]
+  lists[lane * ONE_WAVES + wave] = sel.acc[0];
+  __syncthreads();
+  if (wave == 0) {
+    const u64 mine = one_multiway(lists, ONE_WAVES, ONE_WAVES, a.L, lane);
+    if (lane < a.L) __hip_atomic_store(a.part + (size_t)lane * G + w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) {
+      const uint32_t ticket = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag_sh = ticket == (uint32_t)(G - 1);
+    }
+  }
+  __syncthreads();
+  ONE_STAMP(5);
+  if (!flag_sh) return;
+  ONE_STAMP_LAST(0);
+
+  // ---- 3. the last workgroup: multiway merge of the G lists (lane <-> list, 64 lists per wave), replay ----
+  {
+    u64* all = reinterpret_cast<u64*>(smem) + ONE_WAVES * 64;   // [L][G] as published; behind the waves' result rows
+    const int total = G * a.L;
+    for (int i = tid; i < total; i += ONE_WG) all[i] = __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    // one wave, lane <-> the lists x = lane, lane + 64, ... (<= 4 for 256 CUs): each round takes the smallest head
+    if (wave != 0) return;
+    ONE_STAMP_LAST(1);
+    const u64 top = one_multiway4(all, G, a.L, lane);
+    // The reference's pass inserts in scan order behind a guard "dist < maxDist" (freddy.c:128-131): when no two of the 2k
+    // candidates have the same distance, the order of insertion does not matter and the list is the k smallest in ascending
+    // order (those below the sentinel).  Equal distances among them: re-key as (position, distance bits), sort, replay.
+    const uint32_t db = (uint32_t)(top >> 32);
+    const uint32_t db_next = (uint32_t)__shfl_down((int)db, 1, 64);
+    const bool tie = lane + 1 < a.L && top != KEY_INF && db == db_next;   // (top is ascending: equal distances are neighbours; KEY_INF's word is not a distance)
+    float d_slot = a.sentinel;
+    int32_t id_slot = -1;
+    if (__ballot(tie) == 0ull) {
+      if (lane < a.k && top != KEY_INF && __uint_as_float(db) < a.sentinel) {
+        d_slot = __uint_as_float(db);
+        id_slot = a.pos_to_id ? a.pos_to_id[(uint32_t)top] : (int32_t)(uint32_t)top;
+      }
+    } else {
+      u64 byp[1];
+      byp[0] = (top == KEY_INF || lane >= a.L) ? KEY_INF : ((top << 32) | (top >> 32));
+      wave_sort_full<1>(byp);
+      if (a.pos_to_id && byp[0] != KEY_INF) byp[0] = ((u64)(uint32_t)a.pos_to_id[(uint32_t)(byp[0] >> 32)] << 32) | (u64)(uint32_t)byp[0];
+      wave_list_replay(d_slot, id_slot, a.k, byp[0], a.L < 64 ? a.L : 64, [](uint32_t id) { return (int32_t)id; });
+    }
+    if (lane < a.k) {
+      a.out_ids[lane] = id_slot;
+      a.out_dist[lane] = d_slot;
+    }
+    ONE_STAMP_LAST(2);
+    // the list is in (mapped host) memory before the word the host polls
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (lane == 0) {   // re-arm (every other workgroup has left both counters behind)
+      __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+#undef ONE_STAMP
+#undef ONE_STAMP_LAST
+
+}  // namespace freddy

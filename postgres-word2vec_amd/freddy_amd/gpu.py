@@ -231,6 +231,22 @@ class PQIndex(_Index):
                                              0 if sub is None else sub.size, _p(out_i), _p(out_d)))
         return out_i, out_d
 
+    def bind_search(self, queries, k, sentinel=100.0):
+        """pq_search through the host-buffer call with every argument converted ONCE (the caller's loop then costs what a C
+        caller's costs): returns (call, out_ids, out_dist); call() fills the two arrays."""
+        qs = _f32(queries).reshape(-1, self.d)
+        Q = qs.shape[0]
+        out_i = np.empty((Q, k), np.int32)
+        out_d = np.empty((Q, k), np.float32)
+        fn = self.lib.freddy_gpu_pq_search
+        args = (self.h, _p(qs), C.c_int32(Q), C.c_int32(k), C.c_float(sentinel), None, C.c_int64(0), _p(out_i), _p(out_d))
+
+        def call(_keep=(qs,)):
+            rc = fn(*args)
+            if rc != 0:
+                _check(rc)
+        return call, out_i, out_d
+
     def grouping(self, group_vectors, subset_ids=None):
         """grouping_pq: (ids, group index) of every (requested) row; groups tried in the given order."""
         gv = _f32(group_vectors).reshape(-1, self.d)

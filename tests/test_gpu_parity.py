@@ -30,6 +30,72 @@ def test_pq_search_matches_oracle(gpu, oracle, K):
     idx.close()
 
 
+@pytest.mark.parametrize("K", [256, 1024])
+def test_pq_single_query_one_launch(gpu, oracle, K):
+    """A single pq_search query through the host-buffer call is ONE launch (one.h: table slices -> grid barrier -> scan ->
+    last-arriver merge; option one_launch).  Consecutive calls with different queries on one handle (the second call's table
+    must not be served from a cache line of the first), duplicates (equal distances), a sentinel that bites, k up to the
+    selection width, a subset; each list equal to the oracle's and to the three-launch path's."""
+    N = 60000
+    t = util.pq_tables(N=N, K=K)
+    codes = t["codes"].copy()
+    codes[1000:1300] = codes[999]   # 300 rows with the same code row: equal distances, order decided by the scan position
+    ot = oracle.pq_table(t["codebook"], t["ids"], codes)
+    idx = gpu.PQIndex(t["codebook"], t["ids"], codes)
+    _, qs = util.queries_from_corpus(N, 48, seed=5)
+    qs[3] *= np.float32(20.0)   # farther than the sentinel from everything
+    idx.profile_enable(True)
+    gi, gd = idx.search(qs[:1], 5, sentinel=100.0)
+    prof = idx.profile_read()
+    idx.profile_enable(False)
+    assert "pq_one" in prof, f"the one-launch kernel did not run: {sorted(prof)}"
+    for k in (1, 5, 32):
+        for i, q in enumerate(qs):
+            exp = oracle.pq_search(ot, q, k)[None]
+            gi, gd = idx.search(q[None], k, sentinel=100.0)
+            util.assert_same_lists(gi, gd, exp, f"one launch K={K} k={k} query {i}")
+    rng = np.random.default_rng(9)
+    targets = rng.choice(np.arange(1, N + 1), size=9000, replace=False).astype(np.int32)
+    for i, q in enumerate(qs[:8]):
+        exp = oracle.pq_search_in_batch(ot, q[None], 5, targets, use_target_lists=True)
+        gi, gd = idx.search(q[None], 5, sentinel=1000.0, subset_ids=targets)
+        util.assert_same_lists(gi, gd, exp, f"one launch, subset, query {i}")
+    idx.set_option("one_launch", 0)
+    for i, q in enumerate(qs[:8]):
+        gi, gd = idx.search(q[None], 5, sentinel=100.0)
+        util.assert_same_lists(gi, gd, oracle.pq_search(ot, q, 5)[None], f"three launches, query {i}")
+    idx.close()
+
+
+def test_pq_single_query_one_launch_under_load(gpu, oracle):
+    """The one-launch kernel's hand-offs (table slices -> every workgroup, lists -> last arriver) while other streams keep
+    the chip unevenly busy (matrix products of several sizes enqueued ahead on two torch streams): the grid's workgroups
+    start at different times and on whatever CUs come free; every list equals the oracle's."""
+    import torch
+    N = 60000
+    t = util.pq_tables(N=N, K=1024)
+    ot = oracle.pq_table(t["codebook"], t["ids"], t["codes"])
+    idx = gpu.PQIndex(t["codebook"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 40, seed=11)
+    exp = [oracle.pq_search(ot, q, 5)[None] for q in qs]
+    dev = torch.device("cuda", 0)
+    a = torch.randn(2048, 2048, device=dev)
+    b = torch.randn(512, 512, device=dev)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for rep in range(3):
+        for i, q in enumerate(qs):
+            with torch.cuda.stream(streams[0]):
+                for _ in range(1 + i % 3):
+                    a = (a @ a).clamp_(-1, 1)
+            with torch.cuda.stream(streams[1]):
+                for _ in range(4):
+                    b = (b @ b).clamp_(-1, 1)
+            gi, gd = idx.search(q[None], 5, sentinel=100.0)
+            util.assert_same_lists(gi, gd, exp[i], f"one launch under load, pass {rep} query {i}")
+    torch.cuda.synchronize()
+    idx.close()
+
+
 def test_pq_search_in_and_batch(gpu, oracle):
     N = 20000
     t = util.pq_tables(N=N, K=256)
