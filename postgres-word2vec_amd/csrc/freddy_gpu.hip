@@ -1962,9 +1962,97 @@ static const void* pinned_device_pointer(const void* p) {
 }
 
 // the batch [0, Q) of one device's handle
+// ONE ivfadc_search query as one launch (one.h ivf_one_kernel).  Returns through *verdict: 2 = the list is in out_ids /
+// out_dist; anything else = not answered here (shape not covered, the reference would probe a second time, or the grid
+// never met at a barrier): the caller takes the multi-round path.
+static bool ivf_one_shape(const freddy_gpu_index* ix, int Q, int k, int W, int found_rule) {
+  return ix->tune.one_launch && !ix->one_launch_failed && Q == 1 && ix->kind == KIND_IVF && ix->m == 12 && ix->S == 25 && ix->d == 300 &&
+         ix->K <= 1024 && (ix->K & 3) == 0 && W <= 32 && 2 * k <= 64 && ix->C <= 4096 && ix->coarse && ix->cbT &&
+         found_rule != FREDDY_FOUND_BATCH_UDF && ix->replicas.empty();
+}
+static int ivf_one(freddy_gpu_index* ix, const float* queries, int k, int W, float sentinel, int found_rule, int32_t* out_ids,
+                   float* out_dist, int* verdict) {
+  *verdict = 0;
+  hipStream_t s = ix->stream;
+  Workspace* ws = workspace_for(ix, s);
+  const int K = ix->K, C = ix->C, L = 2 * k;
+  const size_t lutN = (size_t)12 * K, n_out = (size_t)k;
+  const int G = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ix->n_cus, (int64_t)256, (int64_t)(56 * 1024) / (8 * L)}));
+  if (G < W) return 0;   // (an item per workgroup at least)
+  const size_t need_out = n_out * 8 + 16;
+  if (need_out > ix->hio_out_cap) {
+    if (ix->hio_out) (void)hipHostFree(ix->hio_out);
+    ix->hio_out = nullptr; ix->hio_out_cap = 0;
+    if (hipHostMalloc(&ix->hio_out, need_out + 256, hipHostMallocDefault) != hipSuccess) { ix->hio_out = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+    ix->hio_out_cap = need_out + 256;
+  }
+  const bool fresh = ws->w_one.p == nullptr;
+  if (ws->w_distT.ensure(sizeof(float) * ((size_t)C + 8)) || ws->w_lut.ensure(sizeof(float) * (size_t)W * lutN) ||
+      ws->w_part.ensure(sizeof(u64) * (size_t)G * L) || ws->w_one.ensure(256))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (fresh) HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 256, s));
+  int32_t* h_ids = static_cast<int32_t*>(ix->hio_out);
+  float* h_dist = reinterpret_cast<float*>(h_ids + n_out);
+  int32_t* err = reinterpret_cast<int32_t*>(static_cast<char*>(ix->hio_out) + n_out * 8);
+  *err = 0;
+  IvfOneArgs a;
+  memcpy(a.qv, queries, sizeof(a.qv));
+  a.coarse = ix->coarse; a.cbT = ix->cbT; a.list_off = ix->list_off; a.blk_off = ix->blk_off; a.packed = ix->packed; a.pos = ix->pos;
+  a.dist_g = ws->w_distT.as<float>(); a.lut_g = ws->w_lut.as<float>(); a.part = ws->w_part.as<u64>();
+  a.out_ids = h_ids; a.out_dist = h_dist; a.sync = ws->w_one.as<uint32_t>(); a.err = err;
+  a.C = C; a.K = K; a.W = W; a.L = L; a.k = k; a.found_rule = found_rule == FREDDY_FOUND_ROWS ? 0 : 1;
+  a.cell_limit = 100.0f; a.sentinel = sentinel;
+  static const bool one_prof = getenv("FREDDY_GPU_ONE_PROF") != nullptr;
+  a.prof = one_prof ? ws->w_one.as<unsigned long long>() + 8 : nullptr;
+  memcpy(&a.sentinel_bits, &sentinel, 4);
+  const size_t n_mine = ((size_t)C + G - 1) / G;
+  const size_t lds = std::max({(n_mine + 1) * 300 * sizeof(float), (size_t)C * 4 + 64 + 64 * sizeof(u64) + 64,
+                               ((lutN * 4 + 15) & ~(size_t)15) + (size_t)ONE_WAVES * 64 * sizeof(u64),
+                               (size_t)ONE_WAVES * 64 * sizeof(u64) + (size_t)G * L * sizeof(u64)});
+  if (lds > 60 * 1024) return 0;
+  timed_launch(ix, s, "ivf_one", [&] { hipLaunchKernelGGL((ivf_one_kernel<25>), dim3((unsigned)G), dim3(ONE_WG), lds, s, a); });
+  HIP_TRY(hipGetLastError());
+  {   // (the kernel's last store is this word: polled for up to a millisecond, then the stream is waited for the usual way)
+    volatile int32_t* flag = err;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(1000);
+    int spins = 0;
+    while (*flag == 0) {
+      __builtin_ia32_pause();
+      if ((++spins & 255) == 0 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag != 2) HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (one_prof) {
+    HIP_TRY(hipStreamSynchronize(s));
+    unsigned long long st[16];
+    (void)hipMemcpy(st, ws->w_one.as<unsigned long long>() + 8, sizeof(st), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[ivf_one] wg0: coarse %.2f barrier %.2f plan %.2f tables %.2f barrier %.2f stage %.2f scan %.2f publish %.2f | last: since wg0 start %.2f load %.2f merge+list %.2f us\n",
+            (st[1] - st[0]) * 0.01, (st[2] - st[1]) * 0.01, (st[3] - st[2]) * 0.01, (st[4] - st[3]) * 0.01, (st[5] - st[4]) * 0.01, (st[6] - st[5]) * 0.01,
+            (st[7] - st[6]) * 0.01, (st[8] - st[7]) * 0.01, (st[10] - st[0]) * 0.01, (st[11] - st[10]) * 0.01, (st[12] - st[11]) * 0.01);
+  }
+  if (*err == 2) {
+    memcpy(out_ids, h_ids, n_out * 4);
+    memcpy(out_dist, h_dist, n_out * 4);
+    *verdict = 2;
+    return 0;
+  }
+  if (*err != 3) {   // a poll ran out: counters re-armed, this handle keeps to the multi-launch paths
+    ix->one_launch_failed = true;
+    HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 256, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
 static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q, int k, int W, float sentinel, int found_rule,
                               int32_t* out_ids, float* out_dist) {
   HIP_TRY(hipSetDevice(ix->device));
+  if (ivf_one_shape(ix, Q, k, W, found_rule)) {
+    int verdict = 0;
+    if (int rc = ivf_one(ix, queries, k, W, sentinel, found_rule, out_ids, out_dist, &verdict)) return rc;
+    if (verdict == 2) return FREDDY_OK;
+  }
   const int cap = std::max(1, std::min(max_queries_per_chunk(ix, W), ix->tune.pipeline_batch));
   const int n_sub = (Q + cap - 1) / cap;
   const int per = (Q + n_sub - 1) / n_sub;               // equal sub-batches rather than full ones and a remainder

@@ -57,6 +57,43 @@ __device__ __forceinline__ bool one_wait(uint32_t* counter, uint32_t target) {
   return true;
 }
 
+// A published table (write-through sc1 stores) -> LDS with sc1 loads: served by the L2, never by this CU's L1 (no acquire
+// fence needed); six 16-byte loads per lane in ONE asm statement that ends with the wait (the compiler cannot see that an
+// asm load's result arrives later).  n_floats is a multiple of 4.
+__device__ __forceinline__ void one_stage_table(const float* g, float* lds, int n_floats, int tid) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4* s16 = reinterpret_cast<const f4*>(g);
+  f4* d16 = reinterpret_cast<f4*>(lds);
+  const int n16 = n_floats >> 2;
+  for (int i0 = 0; i0 < n16; i0 += ONE_WG * 6) {
+    f4 t0, t1, t2, t3, t4, t5;
+    const int i = i0 + tid;
+    const f4* p0 = s16 + (i < n16 ? i : n16 - 1);
+    const f4* p1 = s16 + (i + ONE_WG < n16 ? i + ONE_WG : n16 - 1);
+    const f4* p2 = s16 + (i + 2 * ONE_WG < n16 ? i + 2 * ONE_WG : n16 - 1);
+    const f4* p3 = s16 + (i + 3 * ONE_WG < n16 ? i + 3 * ONE_WG : n16 - 1);
+    const f4* p4 = s16 + (i + 4 * ONE_WG < n16 ? i + 4 * ONE_WG : n16 - 1);
+    const f4* p5 = s16 + (i + 5 * ONE_WG < n16 ? i + 5 * ONE_WG : n16 - 1);
+    asm volatile(
+        "global_load_dwordx4 %0, %6, off sc1\n\t"
+        "global_load_dwordx4 %1, %7, off sc1\n\t"
+        "global_load_dwordx4 %2, %8, off sc1\n\t"
+        "global_load_dwordx4 %3, %9, off sc1\n\t"
+        "global_load_dwordx4 %4, %10, off sc1\n\t"
+        "global_load_dwordx4 %5, %11, off sc1\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5)
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+        : "memory");
+    if (i < n16) d16[i] = t0;
+    if (i + ONE_WG < n16) d16[i + ONE_WG] = t1;
+    if (i + 2 * ONE_WG < n16) d16[i + 2 * ONE_WG] = t2;
+    if (i + 3 * ONE_WG < n16) d16[i + 3 * ONE_WG] = t3;
+    if (i + 4 * ONE_WG < n16) d16[i + 4 * ONE_WG] = t4;
+    if (i + 5 * ONE_WG < n16) d16[i + 5 * ONE_WG] = t5;
+  }
+}
+
 // Smallest key over the wave's lanes [0, 1 << STEPS) (the other lanes are ignored), in every lane.  The minimum of the
 // distance words decides almost every time (32-bit exchanges); only lanes that tie on it compare their position words.
 template <int STEPS>
@@ -197,42 +234,7 @@ __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
   const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
   sel.init(stage + wave * 64, sentinel_key, a.L);
   if (b0 < b1) {   // workgroup-uniform
-    {
-      // write-through (sc1) payload -> sc1 loads: served by the L2, never by this CU's L1 (no acquire fence needed); six
-      // 16-byte loads per lane in ONE asm statement that ends with the wait (the compiler cannot see that an asm load's
-      // result arrives later)
-      typedef float f4 __attribute__((ext_vector_type(4)));
-      const f4* s16 = reinterpret_cast<const f4*>(a.lut_g);
-      f4* d16 = reinterpret_cast<f4*>(lut);
-      const int n16 = lutN >> 2;   // (K is a multiple of 4: host check)
-      for (int i0 = 0; i0 < n16; i0 += ONE_WG * 6) {
-        f4 t0, t1, t2, t3, t4, t5;
-        const int i = i0 + tid;
-        const f4* p0 = s16 + (i < n16 ? i : n16 - 1);
-        const f4* p1 = s16 + (i + ONE_WG < n16 ? i + ONE_WG : n16 - 1);
-        const f4* p2 = s16 + (i + 2 * ONE_WG < n16 ? i + 2 * ONE_WG : n16 - 1);
-        const f4* p3 = s16 + (i + 3 * ONE_WG < n16 ? i + 3 * ONE_WG : n16 - 1);
-        const f4* p4 = s16 + (i + 4 * ONE_WG < n16 ? i + 4 * ONE_WG : n16 - 1);
-        const f4* p5 = s16 + (i + 5 * ONE_WG < n16 ? i + 5 * ONE_WG : n16 - 1);
-        asm volatile(
-            "global_load_dwordx4 %0, %6, off sc1\n\t"
-            "global_load_dwordx4 %1, %7, off sc1\n\t"
-            "global_load_dwordx4 %2, %8, off sc1\n\t"
-            "global_load_dwordx4 %3, %9, off sc1\n\t"
-            "global_load_dwordx4 %4, %10, off sc1\n\t"
-            "global_load_dwordx4 %5, %11, off sc1\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5)
-            : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
-            : "memory");
-        if (i < n16) d16[i] = t0;
-        if (i + ONE_WG < n16) d16[i + ONE_WG] = t1;
-        if (i + 2 * ONE_WG < n16) d16[i + 2 * ONE_WG] = t2;
-        if (i + 3 * ONE_WG < n16) d16[i + 3 * ONE_WG] = t3;
-        if (i + 4 * ONE_WG < n16) d16[i + 4 * ONE_WG] = t4;
-        if (i + 5 * ONE_WG < n16) d16[i + 5 * ONE_WG] = t5;
-      }
-    }
+    one_stage_table(a.lut_g, lut, lutN, tid);
     __syncthreads();
     ONE_STAMP(3);
     for (; b < b1; b += PF * ONE_WAVES) {
@@ -331,6 +333,325 @@ __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
     if (lane == 0) {   // re-arm (every other workgroup has left both counters behind)
       __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+#undef ONE_STAMP
+#undef ONE_STAMP_LAST
+
+// ---------------------------------------------------------------------------------------
+// ivfadc_search for ONE query as a single launch: the reference's own call shape (freddy.c:174-393).  The generic path is
+// five dependent launches (coarse_small -> probe_plan -> lut_build -> adc_scan -> merge_replay).  Here:
+//   A. every workgroup: the coarse distances of its <= ceil(C / G) cells (the centroid rows staged in LDS, one lane per
+//      cell walks the 300 dimensions in order: squareDistance, index_utils.c:500-508) -> published -> grid barrier;
+//   B. every workgroup, redundantly: the W nearest cells below the cell limit by the reference's guarded insertion in
+//      cell order (probe_plan_kernel's selection: freddy.c:266-283) -- every workgroup arrives at the same list;
+//   C. the W tables lut[i][pos*K + code] = squareDistance((q - coarse[cell_i])_pos, cb[pos][code]) (freddy.c:296-303,
+//      index_utils.c:445-455) in slices -> published -> grid barrier;
+//   D. workgroup (item, part): the item's table -> LDS, its share of the cell's row blocks (adc_scan_kernel's loop),
+//      its L smallest keys -> published; the accepted-row count (freddy.c:971) by atomics;
+//   E. the last arriver: merge, guarded insertion in scan (= id) order, the list; the query's "found" decides whether the
+//      reference would probe again (freddy.c:377): then the host runs the multi-round path instead (flag 3).
+// ---------------------------------------------------------------------------------------
+struct IvfOneArgs {
+  float qv[300];
+  const float* coarse;       // [C][d]
+  const float* cbT;          // [m][S][K]
+  const int32_t* list_off;   // [C+1]
+  const int32_t* blk_off;    // [C+1]
+  const uint32_t* packed;
+  const int32_t* pos;        // row ids (the scan position of an IVF table), -1 = padding
+  float* dist_g;             // [C] workspace
+  float* lut_g;              // [W][m*K] workspace
+  u64* part;                 // [L][grid] workspace
+  int32_t* out_ids;          // [k] mapped host memory
+  float* out_dist;           // [k]
+  uint32_t* sync;            // [4] three arrival counters + the accepted-row count; zero on entry and on exit
+  int32_t* err;              // mapped host word: 1 = a poll ran out, 2 = list written, 3 = list written, the reference would probe again
+  unsigned long long* prof;  // debugging: phase stamps (100 MHz) of workgroup 0 [0..9] and of the last arriver [10..12]
+  int C, K, W, L, k, found_rule;
+  float cell_limit, sentinel;
+  uint32_t sentinel_bits;
+};
+
+template <int S>
+__global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
+  constexpr int M = 12, M2T = 6, D = M * S;
+  static_assert(D == 300, "the query travels as 300 floats");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int flag_sh;
+  __shared__ int32_t cells_sh[32];
+  const int K = a.K, lutN = M * K, C = a.C, W = a.W;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int w = blockIdx.x, G = gridDim.x;
+#define ONE_STAMP(i) do { if (a.prof && tid == 0 && w == 0) a.prof[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ONE_STAMP_LAST(i) do { if (a.prof && tid == 0) a.prof[10 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  ONE_STAMP(0);
+
+  // ---- A. coarse distances of the cells w, w + G, ... ----
+  {
+    float* crow = reinterpret_cast<float*>(smem);   // [cells of this workgroup][D], then the query
+    const int n_mine = w < C ? (C - w + G - 1) / G : 0;
+    float* qs = crow + n_mine * D;
+    for (int i = tid; i < n_mine * D; i += ONE_WG) {
+      const int ci = i / D, j = i - ci * D;
+      crow[i] = a.coarse[(size_t)(w + ci * G) * D + j];
+    }
+    if (tid < D) qs[tid] = a.qv[tid];
+    __syncthreads();
+    // one lane per cell, the cells of a workgroup on different waves; 16-byte LDS reads, the chain in dimension order
+    for (int ci = wave; ci < n_mine; ci += ONE_WAVES) {
+      if (lane == 0) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* c4 = reinterpret_cast<const f4*>(crow + ci * D);
+        const f4* q4 = reinterpret_cast<const f4*>(qs);
+        float acc = 0.0f;
+#pragma unroll 5
+        for (int i = 0; i < D / 4; ++i) {
+          const f4 cv = c4[i], qv = q4[i];
+          { const float t = qv.x - cv.x; const float pr = t * t; acc = acc + pr; }
+          { const float t = qv.y - cv.y; const float pr = t * t; acc = acc + pr; }
+          { const float t = qv.z - cv.z; const float pr = t * t; acc = acc + pr; }
+          { const float t = qv.w - cv.w; const float pr = t * t; acc = acc + pr; }
+        }
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.dist_g) + (w + ci * G), __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ONE_STAMP(1);
+    if (tid == 0) {
+      __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ok = one_wait(a.sync, (uint32_t)G);
+      if (!ok) a.err[0] = 1;
+      flag_sh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!flag_sh) return;
+    ONE_STAMP(2);
+  }
+
+  // ---- B. the W nearest cells (every workgroup for itself) ----
+  int my_rows = 0;
+  bool any_cell = false;
+  {
+    float* dl = reinterpret_cast<float*>(smem);                       // [C rounded up to 4]
+    u64* prow = reinterpret_cast<u64*>(smem + (((size_t)C * 4 + 63) & ~(size_t)15));   // [64] wave 0's staging row
+    one_stage_table(a.dist_g, dl, (C + 3) & ~3, tid);                   // (dist_g is allocated to a multiple of 4)
+    __syncthreads();
+    if (wave == 0) {
+      const int L2 = 2 * W;
+      const u64 limit = (u64)__float_as_uint(a.cell_limit) << 32;
+      // the L2-th smallest lane minimum bounds the L2-th smallest distance: the selection starts with a tight threshold
+      uint32_t mn = 0xffffffffu;
+      for (int j = lane; j < C; j += 64) mn = min(mn, __float_as_uint(dl[j]));
+      const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)wave_sort32(mn), L2 - 1);
+      const u64 bound = ((u64)dL << 32) | 0xffffffffull;
+      WaveSelect<1> sel;
+      sel.init(prow, bound < limit ? bound : limit, L2);
+      for (int base = 0; base < C; base += 64) {
+        const int j = base + lane;
+        sel.push(make_key(dl[j < C ? j : C - 1], (uint32_t)j), j < C);
+      }
+      sel.finish();
+      // the reference keeps its W nearest cells by guarded insertion in cell order (freddy.c:266-283): with no two of the
+      // 2W candidates equally far that is the W smallest below the limit in ascending order; otherwise the replay
+      const u64 top = lane < L2 ? sel.acc[0] : KEY_INF;
+      const uint32_t db = (uint32_t)(top >> 32);
+      const uint32_t db_next = (uint32_t)__shfl_down((int)db, 1, 64);
+      const bool tie = lane + 1 < L2 && top != KEY_INF && db == db_next;
+      float d_slot = a.cell_limit;
+      int32_t c_slot = -1;
+      if (__ballot(tie) == 0ull) {
+        if (lane < W && top != KEY_INF && top < limit) { d_slot = __uint_as_float(db); c_slot = (int32_t)(uint32_t)top; }
+      } else {
+        u64 byp[1];
+        byp[0] = top == KEY_INF ? KEY_INF : ((top << 32) | (top >> 32));
+        wave_sort_full<1>(byp);
+        wave_list_replay(d_slot, c_slot, W, byp[0], L2, [](uint32_t hi) { return (int32_t)hi; });
+      }
+      const bool have = lane < W && c_slot >= 0;
+      my_rows = have ? (a.list_off[c_slot + 1] - a.list_off[c_slot]) : 0;   // (summed by the last arriver's wave 0)
+      any_cell = __ballot(have) != 0ull;
+      if (lane < 32) cells_sh[lane] = lane < W ? c_slot : -1;
+    }
+    __syncthreads();
+  }
+
+  ONE_STAMP(3);
+  // this workgroup's share of the scan: item = w / P, part = w % P of the item's row blocks
+  const int P = G >= W ? G / W : 1;
+  const int my_item = w / P;
+  const int my_cell = my_item < W ? cells_sh[my_item] : -1;
+  int b0 = 0, b1 = 0;
+  if (my_cell >= 0) {
+    const int c0 = a.blk_off[my_cell], c1 = a.blk_off[my_cell + 1];
+    const int chunk = (c1 - c0 + P - 1) / P;
+    b0 = c0 + (w - my_item * P) * chunk;
+    b1 = b0 + chunk < c1 ? b0 + chunk : c1;
+  }
+  constexpr int PF = 4;
+  RowBlock<M2T> ring[PF];
+  auto fetch = [&](RowBlock<M2T>& rb, int blk) {
+    const int bc = blk < b1 ? blk : b1 - 1;
+    const uint32_t* pk = a.packed + (size_t)bc * M2T * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < M2T; ++j) rb.w[j] = pk[j * 64];
+    rb.p = a.pos[(size_t)bc * 64 + lane];
+  };
+  int b = b0 + wave;
+
+  // ---- C. the items' tables in slices: unit = (item, position, range of codes) ----
+  {
+    const int n_slot = G >= W * M ? G / (W * M) : 1, cw = (K + n_slot - 1) / n_slot;
+    for (int unit = w; unit < W * M * n_slot; unit += G) {
+      const int i = unit / (M * n_slot), rem = unit - i * (M * n_slot);
+      const int p = rem / n_slot, c0 = (rem - p * n_slot) * cw;   // (i, p: workgroup-uniform)
+      const int cell = __builtin_amdgcn_readfirstlane(cells_sh[i]);
+      if (cell < 0) continue;
+      const int c1 = c0 + cw < K ? c0 + cw : K;
+      const float* co = a.coarse + (size_t)cell * D + (size_t)p * S;
+      for (int c = c0 + tid; c < c1; c += ONE_WG) {
+        float cb[S];
+#pragma unroll
+        for (int j = 0; j < S; ++j) cb[j] = a.cbT[((size_t)p * S + j) * K + c];
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          const float rj = a.qv[p * S + j] - co[j];   // (the residual: one binary32 subtraction, freddy.c:296-303)
+          const float t = rj - cb[j];
+          const float pr = t * t;
+          acc = acc + pr;
+        }
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + (size_t)i * lutN + p * K + c, __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ONE_STAMP(4);
+    if (tid == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (b0 < b1) {   // (the first row blocks in flight while the barrier is polled)
+#pragma unroll
+      for (int u = 0; u < PF; ++u) fetch(ring[u], b + u * ONE_WAVES);
+    }
+    if (tid == 0) {
+      const bool ok = one_wait(a.sync + 1, (uint32_t)G);
+      if (!ok) a.err[0] = 1;
+      flag_sh = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (!flag_sh) return;
+    ONE_STAMP(5);
+  }
+
+  // ---- D. the item's table -> LDS, this workgroup's row blocks ----
+  float* lut = reinterpret_cast<float*>(smem);
+  u64* stage = reinterpret_cast<u64*>(smem + (((size_t)lutN * 4 + 15) & ~(size_t)15));
+  WaveSelect<1> sel;
+  const u64 sentinel_key = (u64)a.sentinel_bits << 32;
+  sel.init(stage + wave * 64, sentinel_key, a.L);
+  int accepted = 0;
+  if (b0 < b1) {   // workgroup-uniform
+    one_stage_table(a.lut_g + (size_t)my_item * lutN, lut, lutN, tid);
+    __syncthreads();
+    ONE_STAMP(6);
+    for (; b < b1; b += PF * ONE_WAVES) {
+      u64 keys[PF];
+      uint32_t mn = 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const RowBlock<M2T> cur = ring[u];
+        const int bu = b + u * ONE_WAVES;
+        if (bu + PF * ONE_WAVES < b1) fetch(ring[u], bu + PF * ONE_WAVES);   // (wave-uniform)
+        keys[u] = KEY_INF;
+        if (bu < b1) {   // wave-uniform
+          float dist = 0.0f;
+#pragma unroll
+          for (int l = 0; l < M; ++l) {
+            const uint32_t code = (l & 1) ? (cur.w[l >> 1] >> 16) : (cur.w[l >> 1] & 0xffffu);
+            dist = dist + lut[l * K + code];
+          }
+          if (cur.p >= 0) {
+            keys[u] = make_key(dist, (uint32_t)cur.p);
+            mn = min(mn, __float_as_uint(dist));
+          }
+          accepted += __popcll(__ballot(cur.p >= 0 && keys[u] < sentinel_key));
+        }
+      }
+      const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)wave_sort32(mn), a.L - 1);
+      const u64 bound = ((u64)dL << 32) | 0xffffffffull;
+      if (bound < sel.tau) sel.tau = bound;
+#pragma unroll
+      for (int u = 0; u < PF; ++u)
+        if (b + u * ONE_WAVES < b1) sel.push(keys[u], keys[u] != KEY_INF);
+    }
+    sel.finish();
+  }
+  ONE_STAMP(7);
+  if (a.found_rule == 1 && lane == 0 && accepted) __hip_atomic_fetch_add(a.sync + 3, (uint32_t)accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  u64* lists = reinterpret_cast<u64*>(smem);   // [64 ranks][ONE_WAVES]
+  lists[lane * ONE_WAVES + wave] = sel.acc[0];
+  __syncthreads();
+  if (wave == 0) {
+    const u64 mine = one_multiway(lists, ONE_WAVES, ONE_WAVES, a.L, lane);
+    if (lane < a.L) __hip_atomic_store(a.part + (size_t)lane * G + w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every wave: its accepted-count atomic has landed before the arrival)
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t ticket = __hip_atomic_fetch_add(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flag_sh = ticket == (uint32_t)(G - 1);
+  }
+  __syncthreads();
+  ONE_STAMP(8);
+  if (!flag_sh) return;
+  ONE_STAMP_LAST(0);
+
+  // ---- E. the last workgroup: merge, replay, the list ----
+  {
+    u64* all = reinterpret_cast<u64*>(smem) + ONE_WAVES * 64;
+    const int total = G * a.L;
+    for (int i = tid; i < total; i += ONE_WG) all[i] = __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (wave != 0) return;
+    ONE_STAMP_LAST(1);
+    const u64 top = one_multiway4(all, G, a.L, lane);
+    const uint32_t db = (uint32_t)(top >> 32);
+    const uint32_t db_next = (uint32_t)__shfl_down((int)db, 1, 64);
+    const bool tie = lane + 1 < a.L && top != KEY_INF && db == db_next;
+    float d_slot = a.sentinel;
+    int32_t id_slot = -1;
+    if (__ballot(tie) == 0ull) {   // (no two candidates equally far: the order of insertion does not matter, pq_one_kernel)
+      if (lane < a.k && top != KEY_INF && __uint_as_float(db) < a.sentinel) {
+        d_slot = __uint_as_float(db);
+        id_slot = (int32_t)(uint32_t)top;
+      }
+    } else {
+      u64 byp[1];
+      byp[0] = (top == KEY_INF || lane >= a.L) ? KEY_INF : ((top << 32) | (top >> 32));
+      wave_sort_full<1>(byp);
+      wave_list_replay(d_slot, id_slot, a.k, byp[0], a.L < 64 ? a.L : 64, [](uint32_t id) { return (int32_t)id; });
+    }
+    if (lane < a.k) {
+      a.out_ids[lane] = id_slot;
+      a.out_dist[lane] = d_slot;
+    }
+    // "found" of the first round (freddy.c:377 rows rule, :971 accepted rule): fewer than k and a cell was probed -> the
+    // reference probes the next W cells; the host runs that path
+    int rows = my_rows;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) rows += __shfl_xor(rows, o, 64);
+    if (!any_cell) rows = -1;   // no cell below the limit: the query retires
+    const int found = a.found_rule == 1 ? (int)__hip_atomic_load(a.sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (rows > 0 ? rows : 0);
+    const int verdict = (found < a.k && rows >= 0) ? 3 : 2;
+    ONE_STAMP_LAST(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) {
+      __hip_atomic_store(a.err, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) __hip_atomic_store(a.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

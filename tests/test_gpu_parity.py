@@ -96,6 +96,43 @@ def test_pq_single_query_one_launch_under_load(gpu, oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("K", [256, 1024])
+def test_ivfadc_single_query_one_launch(gpu, oracle, K):
+    """ivfadc_search for ONE query -- the reference's own call shape (freddy.c:174-393) -- is one launch (one.h
+    ivf_one_kernel: coarse distances -> barrier -> the W nearest cells -> the cells' tables -> barrier -> scan ->
+    last-arriver merge).  Consecutive calls with different queries; both rules of counting found rows; W from 1 to 32; k up
+    to the selection width; duplicate rows (equal distances); a query far from every centroid (no cell below the limit: the
+    empty list); a sentinel so low that fewer than k rows are found (the reference probes again: the host falls back to the
+    multi-round path); each list equal to the oracle's and to the multi-launch path's."""
+    N = 40000
+    t = dict(util.ivf_tables(N=N, C=100, K=K))
+    codes = t["codes"].copy()
+    lo = t["list_off"]
+    for c in range(len(lo) - 1):   # the first rows of every list share a code row: equal distances
+        n = min(4, int(lo[c + 1] - lo[c]))
+        codes[lo[c]:lo[c] + n] = codes[lo[c]]
+    t["codes"] = codes
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 40, seed=17)
+    qs[5] *= np.float32(30.0)   # no centroid within the cell limit of 100
+    idx.profile_enable(True)
+    idx.search(qs[:1], 5, 10, sentinel=1000.0, found_rule=0)
+    prof = idx.profile_read()
+    idx.profile_enable(False)
+    assert "ivf_one" in prof, f"the one-launch kernel did not run: {sorted(prof)}"
+    for k, W, rule, sent in ((5, 10, 0, 1000.0), (1, 1, 0, 1000.0), (10, 4, 1, 100.0), (32, 32, 0, 1000.0), (5, 3, 1, 0.4), (17, 7, 0, 0.9)):
+        for i, q in enumerate(qs):
+            exp = oracle.ivfadc_search(ot, q, k, W, sentinel=sent, found_rule=rule)[None]
+            gi, gd = idx.search(q[None], k, W, sentinel=sent, found_rule=rule)
+            util.assert_same_lists(gi, gd, exp, f"one launch K={K} k={k} W={W} rule={rule} sentinel={sent} query {i}")
+    idx.set_option("one_launch", 0)
+    for i, q in enumerate(qs[:8]):
+        gi, gd = idx.search(q[None], 5, 10, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, oracle.ivfadc_search(ot, q, 5, 10, sentinel=1000.0, found_rule=0)[None], f"multi-launch, query {i}")
+    idx.close()
+
+
 def test_pq_search_in_and_batch(gpu, oracle):
     N = 20000
     t = util.pq_tables(N=N, K=256)
