@@ -889,6 +889,39 @@ __global__ __launch_bounds__(64) void merge_replay_kernel(MergeArgs a) {
       tau = wave_topk_at<V>(acc, a.L - 1);
     }
   }
+  if (V == 1 && k <= 64 && a.first_round) {
+    // First round, nothing carried: when no two of the L candidates are equally far, the order of the guarded insertions
+    // (freddy.c:128-131) does not matter -- the list is the k nearest below the sentinel in ascending order, which is how
+    // the accumulator already holds them.  (Equal distances: the replay in scan order below.)
+    const u64 top = lane < a.L ? acc[0] : KEY_INF;
+    const uint32_t db = (uint32_t)(top >> 32);
+    const uint32_t db_next = (uint32_t)__shfl_down((int)db, 1, 64);
+    const bool tie = lane + 1 < a.L && top != KEY_INF && db == db_next;
+    if (__ballot(tie) == 0ull) {
+      float d_slot = a.sentinel;
+      int32_t id_slot = -1;
+      if (lane < k && top != KEY_INF && __uint_as_float(db) < a.sentinel) {
+        d_slot = __uint_as_float(db);
+        id_slot = a.pos_to_id ? a.pos_to_id[(uint32_t)top] : (int32_t)(uint32_t)top;
+      }
+      if (lane < k) {
+        a.out_ids[(size_t)q * k + lane] = id_slot;
+        a.out_dist[(size_t)q * k + lane] = d_slot;
+      }
+      if (lane == 0) {
+        int f = 0;
+        const int rows = a.round_rows ? a.round_rows[x] : 0;
+        f += (a.found_rule == 1 && a.cand_count) ? a.cand_count[q] : (rows > 0 ? rows : 0);
+        if (a.found) a.found[q] = f;
+        if (a.next_active && f < k && rows >= 0) {
+          const int slot = atomicAdd(a.n_next, 1);
+          a.next_active[slot] = q;
+          if (a.status) a.status[0] = 1;
+        }
+      }
+      return;
+    }
+  }
   // order the survivors by scan position: re-key as (position, distance bits) and sort
   u64 byp[V];
 #pragma unroll
@@ -910,9 +943,10 @@ __global__ __launch_bounds__(64) void merge_replay_kernel(MergeArgs a) {
     // lane i = slot i of the carried list; candidates replayed in scan order
     float d_slot = (a.first_round || lane >= k) ? a.sentinel : a.out_dist[(size_t)q * k + lane];
     int32_t id_slot = (a.first_round || lane >= k) ? -1 : a.out_ids[(size_t)q * k + lane];
-    wave_list_replay(d_slot, id_slot, k, byp[0], a.L < 64 ? a.L : 64, [&](uint32_t p) {
-      return a.pos_to_id ? a.pos_to_id[p] : (int32_t)p;
-    });
+    // (the candidates' ids gathered by all lanes at once: a load inside the replay is a round trip per insertion)
+    u64 cand_id = byp[0];
+    if (a.pos_to_id && cand_id != KEY_INF) cand_id = ((u64)(uint32_t)a.pos_to_id[(uint32_t)(cand_id >> 32)] << 32) | (u64)(uint32_t)cand_id;
+    wave_list_replay(d_slot, id_slot, k, cand_id, a.L < 64 ? a.L : 64, [](uint32_t id) { return (int32_t)id; });
     if (lane < k) {
       a.out_ids[(size_t)q * k + lane] = id_slot;
       a.out_dist[(size_t)q * k + lane] = d_slot;
