@@ -176,7 +176,9 @@ struct Workspace {
   hipEvent_t ev_in = nullptr, ev_fe = nullptr, ev_scan = nullptr, ev_out = nullptr;
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs, w_tmin, w_one;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs, w_tmin, w_one, w_oneb;
+  uint64_t one_shape = 0;          // the one-launch kernels' buffer (w_oneb): shape of the call that wrote it last, and that call's epoch (one.h)
+  uint32_t one_epoch = 0;
   void release_partition() {
     if (fe_stream) { (void)hipStreamSynchronize(fe_stream); (void)hipStreamDestroy(fe_stream); fe_stream = nullptr; }
     if (scan_stream) { (void)hipStreamSynchronize(scan_stream); (void)hipStreamDestroy(scan_stream); scan_stream = nullptr; }
@@ -192,7 +194,7 @@ struct Workspace {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs, &w_tmin, &w_one};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs, &w_tmin, &w_one, &w_oneb};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -1962,6 +1964,23 @@ static const void* pinned_device_pointer(const void* p) {
 }
 
 // the batch [0, Q) of one device's handle
+// The one-launch kernels' hand-off buffer: every published word carries the call's epoch in its top bit (one.h).  Calls of
+// one shape write exactly the same words, so the epoch just flips; a different shape (or a new allocation) clears the
+// buffer to epoch 0 and starts with epoch 1.
+static int one_buffer(Workspace* ws, hipStream_t s, uint64_t shape, size_t bytes, uint32_t* epoch) {
+  void* before = ws->w_oneb.p;
+  if (ws->w_oneb.ensure(bytes)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (ws->w_oneb.p != before || ws->one_shape != shape) {
+    HIP_TRY(hipMemsetAsync(ws->w_oneb.p, 0, ws->w_oneb.cap, s));
+    ws->one_shape = shape;
+    ws->one_epoch = 1;
+  } else {
+    ws->one_epoch ^= 1u;
+  }
+  *epoch = ws->one_epoch;
+  return 0;
+}
+
 // ONE ivfadc_search query as one launch (one.h ivf_one_kernel).  Returns through *verdict: 2 = the list is in out_ids /
 // out_dist; anything else = not answered here (shape not covered, the reference would probe a second time, or the grid
 // never met at a barrier): the caller takes the multi-round path.
@@ -1986,11 +2005,15 @@ static int ivf_one(freddy_gpu_index* ix, const float* queries, int k, int W, flo
     if (hipHostMalloc(&ix->hio_out, need_out + 256, hipHostMallocDefault) != hipSuccess) { ix->hio_out = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
     ix->hio_out_cap = need_out + 256;
   }
-  const bool fresh = ws->w_one.p == nullptr;
-  if (ws->w_distT.ensure(sizeof(float) * ((size_t)C + 8)) || ws->w_lut.ensure(sizeof(float) * (size_t)W * lutN) ||
-      ws->w_part.ensure(sizeof(u64) * (size_t)G * L) || ws->w_one.ensure(256))
-    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (fresh) HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 256, s));
+  // the hand-off buffer: coarse distances | the W tables | the workgroups' lists | their accepted-row counts
+  const size_t lut_off = (sizeof(float) * ((size_t)C + 8) + 255) & ~(size_t)255;
+  const size_t part_off = (lut_off + sizeof(float) * (size_t)W * lutN + 255) & ~(size_t)255;
+  const size_t cnt_off = (part_off + sizeof(u64) * (size_t)G * L + 255) & ~(size_t)255;
+  uint32_t epoch = 0;
+  if (int rc = one_buffer(ws, s, (2ull << 60) | ((uint64_t)C << 44) | ((uint64_t)K << 32) | ((uint64_t)W << 24) | ((uint64_t)G << 12) | (uint64_t)L,
+                          cnt_off + sizeof(uint32_t) * (size_t)G, &epoch)) return rc;
+  static const bool one_prof = getenv("FREDDY_GPU_ONE_PROF") != nullptr;
+  if (one_prof && ws->w_one.ensure(256)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   int32_t* h_ids = static_cast<int32_t*>(ix->hio_out);
   float* h_dist = reinterpret_cast<float*>(h_ids + n_out);
   int32_t* err = reinterpret_cast<int32_t*>(static_cast<char*>(ix->hio_out) + n_out * 8);
@@ -1998,11 +2021,12 @@ static int ivf_one(freddy_gpu_index* ix, const float* queries, int k, int W, flo
   IvfOneArgs a;
   memcpy(a.qv, queries, sizeof(a.qv));
   a.coarse = ix->coarse; a.cbT = ix->cbT; a.list_off = ix->list_off; a.blk_off = ix->blk_off; a.packed = ix->packed; a.pos = ix->pos;
-  a.dist_g = ws->w_distT.as<float>(); a.lut_g = ws->w_lut.as<float>(); a.part = ws->w_part.as<u64>();
-  a.out_ids = h_ids; a.out_dist = h_dist; a.sync = ws->w_one.as<uint32_t>(); a.err = err;
+  char* ob = ws->w_oneb.as<char>();
+  a.dist_g = reinterpret_cast<float*>(ob); a.lut_g = reinterpret_cast<float*>(ob + lut_off); a.part = reinterpret_cast<u64*>(ob + part_off);
+  a.cnt_g = reinterpret_cast<uint32_t*>(ob + cnt_off);
+  a.out_ids = h_ids; a.out_dist = h_dist; a.epoch = epoch; a.err = err;
   a.C = C; a.K = K; a.W = W; a.L = L; a.k = k; a.found_rule = found_rule == FREDDY_FOUND_ROWS ? 0 : 1;
   a.cell_limit = 100.0f; a.sentinel = sentinel;
-  static const bool one_prof = getenv("FREDDY_GPU_ONE_PROF") != nullptr;
   a.prof = one_prof ? ws->w_one.as<unsigned long long>() + 8 : nullptr;
   memcpy(&a.sentinel_bits, &sentinel, 4);
   const size_t n_mine = ((size_t)C + G - 1) / G;
@@ -2039,7 +2063,7 @@ static int ivf_one(freddy_gpu_index* ix, const float* queries, int k, int W, flo
   }
   if (*err != 3) {   // a poll ran out: counters re-armed, this handle keeps to the multi-launch paths
     ix->one_launch_failed = true;
-    HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 256, s));
+    ws->one_shape = 0;
     HIP_TRY(hipStreamSynchronize(s));
   }
   return 0;
@@ -2474,16 +2498,16 @@ static int pq_one(freddy_gpu_index* ix, hipStream_t s, const float* h_q, int k, 
   // (one workgroup per CU at most: all co-resident; the last arriver stages every list in LDS: G * L keys within 56 KB)
   const int G = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)ix->n_cus, (int64_t)256, (n_blocks + ONE_WAVES - 1) / ONE_WAVES, (int64_t)(56 * 1024) / (8 * L)}));
   const int chunk_blocks = (int)((n_blocks + G - 1) / G);
-  const bool fresh = ws->w_one.p == nullptr;
-  if (ws->w_lut.ensure(sizeof(float) * lutN) || ws->w_part.ensure(sizeof(u64) * (size_t)G * L) || ws->w_one.ensure(256))
-    return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (fresh) HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 256, s));
-  OneArgs a;
-  memcpy(a.qv, h_q, sizeof(a.qv)); a.cbT = ix->cbT; a.lut_g = ws->w_lut.as<float>(); a.blk_off = blk_off; a.packed = packed; a.pos = pos;
-  a.pos_to_id = nullptr;   // (positions out: the caller maps them through its host copy of the ids -- no dependent gather at the kernel's end)
-  a.part = ws->w_part.as<u64>(); a.out_ids = d_out_ids; a.out_dist = d_out_dist;
-  a.sync = ws->w_one.as<uint32_t>(); a.err = err;
+  const size_t part_off = (lutN * sizeof(float) + 255) & ~(size_t)255;
+  uint32_t epoch = 0;
+  if (int rc = one_buffer(ws, s, (1ull << 60) | ((uint64_t)K << 32) | ((uint64_t)G << 16) | (uint64_t)L, part_off + sizeof(u64) * (size_t)G * L, &epoch)) return rc;
   static const bool one_prof = getenv("FREDDY_GPU_ONE_PROF") != nullptr;
+  if (one_prof && ws->w_one.ensure(256)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  OneArgs a;
+  memcpy(a.qv, h_q, sizeof(a.qv)); a.cbT = ix->cbT; a.lut_g = ws->w_oneb.as<float>(); a.blk_off = blk_off; a.packed = packed; a.pos = pos;
+  a.pos_to_id = nullptr;   // (positions out: the caller maps them through its host copy of the ids -- no dependent gather at the kernel's end)
+  a.part = reinterpret_cast<u64*>(ws->w_oneb.as<char>() + part_off); a.out_ids = d_out_ids; a.out_dist = d_out_dist;
+  a.epoch = epoch; a.err = err;
   a.prof = one_prof ? ws->w_one.as<unsigned long long>() + 8 : nullptr;
   a.K = K; a.L = L; a.k = k; a.chunk_blocks = chunk_blocks; a.sentinel = sentinel;
   memcpy(&a.sentinel_bits, &sentinel, 4);
@@ -2676,7 +2700,7 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
     }
     // the grid never met at its barrier (not co-resident): counters re-armed, this handle keeps to the three-launch path
     ix->one_launch_failed = true;
-    HIP_TRY(hipMemsetAsync(ws->w_one.p, 0, 64, s));
+    ws->one_shape = 0;
   }
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);

@@ -1,21 +1,19 @@
-// one.h -- pq_search for ONE query as a single launch (gfx950).
+// one.h -- ONE query as a single launch (gfx950): pq_one_kernel, ivf_one_kernel.
 //
-// The generic path answers a single query with three dependent launches -- lut_build_kernel, adc_scan_kernel,
+// The generic path answers a single pq_search query with three dependent launches -- lut_build_kernel, adc_scan_kernel,
 // merge_replay_kernel: 14 + 22 + 14 us under HIP events for 28 MB of codes that sit in the caches -- i.e. mostly launch
 // gaps.  pq_one_kernel is the same three stages in one grid of at most one workgroup per CU (all co-resident):
 //   1. every workgroup computes its slice of the query's table lut[pos*K + code] = squareDistance(q_pos, cb[pos][code])
-//      (index_utils.c:445-455; the sequential binary32 chain of lut_build_kernel) and publishes it with write-through
-//      stores; grid barrier (one arrival counter, agent scope);
-//   2. every workgroup stages the whole table in LDS and scans its chunk of row blocks exactly as adc_scan_kernel does
-//      (position-order sums, index_utils.c:1126-1133; WaveSelect of the L = 2k smallest (distance, position) keys), then
-//      publishes its L keys;
-//   3. the workgroup that arrives last merges the lists (eight waves, then one) and replays the reference's guarded
-//      insertion in scan order (merge_replay_kernel's tail: updateTopK + "dist < maxDist", index_utils.c:19-33,
-//      freddy.c:128-131), writes the result and re-arms the counters.
-// Inter-workgroup hand-offs follow the write-through recipe: payload stored with agent-scope (sc1) stores, every writing
-// wave drains its stores, workgroup barrier, one lane bumps the counter; the consumer polls with relaxed agent-scope loads,
-// one lane executes an agent-scope acquire, workgroup barrier, plain loads.  The polls are bounded: a grid that cannot
-// become co-resident reports through `err` instead of hanging (the host then takes the three-launch path).
+//      (index_utils.c:445-455; the sequential binary32 chain of lut_build_kernel) and publishes it;
+//   2. every workgroup waits for the table, stages it in LDS and scans its chunk of row blocks exactly as adc_scan_kernel
+//      does (position-order sums, index_utils.c:1126-1133; WaveSelect of the L = 2k smallest (distance, position) keys),
+//      then publishes its L keys;
+//   3. workgroup 0 collects the lists, merges them and forms the reference's list (merge_replay_kernel's tail: updateTopK +
+//      "dist < maxDist", index_utils.c:19-33, freddy.c:128-131), writes it to mapped host memory and then the completion
+//      word the host polls.
+// Hand-offs carry no counters: every published word carries the call's epoch in its top bit (below, "hand-offs without
+// counters").  All waits are bounded: a grid that cannot become co-resident reports through `err` instead of hanging (the
+// host then takes the three-launch path).  ivf_one_kernel: further down.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,7 +34,7 @@ struct OneArgs {
   u64* part;                 // [grid][L] workspace
   int32_t* out_ids;          // [k]
   float* out_dist;           // [k]
-  uint32_t* sync;            // [2] arrival counters, zero on entry, zero again on exit
+  uint32_t epoch;            // 0 / 1: the tag of this call's published words
   int32_t* err;              // [1] mapped host memory: 1 = a poll ran out; 2 = result written (the host may poll this word)
   unsigned long long* prof;  // debugging: phase stamps (100 MHz) of workgroup 0 [0..7] and of the last arriver [8..15]
   int K, L, k, chunk_blocks;
@@ -46,52 +44,76 @@ struct OneArgs {
 
 static constexpr int ONE_WG = 512;
 static constexpr int ONE_WAVES = ONE_WG / 64;
-static constexpr uint32_t ONE_SPIN_LIMIT = 200000u;   // polls of >= 64 cycles each: tens of milliseconds
-
-__device__ __forceinline__ bool one_wait(uint32_t* counter, uint32_t target) {
-  uint32_t spins = 0;
-  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    if (++spins > ONE_SPIN_LIMIT) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return true;
+// ---- hand-offs without counters: every published word carries the call's epoch ----
+// Distances are sums of squares: >= +0, so the sign bit of a published float -- and bit 63 of a published (distance,
+// position) key -- is free.  A producer stores (value | epoch << 31) with a write-through store and moves on: no drain, no
+// arrival counter.  A consumer loads with sc1 loads and accepts a word when its top bit equals the epoch, else loads again
+// (bounded).  Every word validates itself, so nothing needs ordering.  The host flips the epoch from call to call as long
+// as the calls' shapes are equal (then this call writes exactly the words the previous one wrote, all of which still carry
+// the other epoch) and clears the buffer to epoch 0 when the shape changes (freddy_gpu.hip one_buffer()).
+__device__ __forceinline__ uint32_t one_tag(float v, uint32_t ep) { return (__float_as_uint(v) & 0x7fffffffu) | (ep << 31); }
+__device__ __forceinline__ u64 one_tag_key(u64 key, uint32_t ep) {   // KEY_INF travels as 0x7fff...f
+  return ((key == KEY_INF ? 0x7fffffffffffffffull : key) & 0x7fffffffffffffffull) | ((u64)ep << 63);
 }
+__device__ __forceinline__ u64 one_untag_key(u64 w) {
+  const u64 k = w & 0x7fffffffffffffffull;
+  return k == 0x7fffffffffffffffull ? KEY_INF : k;
+}
+static constexpr int ONE_RETRY_LIMIT = 20000;   // rounds of >= 1 us each
 
-// A published table (write-through sc1 stores) -> LDS with sc1 loads: served by the L2, never by this CU's L1 (no acquire
-// fence needed); six 16-byte loads per lane in ONE asm statement that ends with the wait (the compiler cannot see that an
-// asm load's result arrives later).  n_floats is a multiple of 4.
-__device__ __forceinline__ void one_stage_table(const float* g, float* lds, int n_floats, int tid) {
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  const f4* s16 = reinterpret_cast<const f4*>(g);
-  f4* d16 = reinterpret_cast<f4*>(lds);
+// A table of tagged floats -> LDS (tags stripped) by six 16-byte sc1 loads per lane in ONE asm statement that ends with the
+// wait (the compiler cannot see that an asm load's result arrives later); words [0, n_valid) are checked, the rest (padding up to a multiple of 4)
+// is not.  Returns false when the table did not become valid within the bounded number of rounds.  All threads call.
+__device__ __forceinline__ bool one_stage_tagged(const float* g, float* lds, int n_floats, int n_valid, uint32_t ep, int tid, int* retry_sh) {
+  typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+  const w4* s16 = reinterpret_cast<const w4*>(g);
+  w4* d16 = reinterpret_cast<w4*>(lds);
   const int n16 = n_floats >> 2;
-  for (int i0 = 0; i0 < n16; i0 += ONE_WG * 6) {
-    f4 t0, t1, t2, t3, t4, t5;
-    const int i = i0 + tid;
-    const f4* p0 = s16 + (i < n16 ? i : n16 - 1);
-    const f4* p1 = s16 + (i + ONE_WG < n16 ? i + ONE_WG : n16 - 1);
-    const f4* p2 = s16 + (i + 2 * ONE_WG < n16 ? i + 2 * ONE_WG : n16 - 1);
-    const f4* p3 = s16 + (i + 3 * ONE_WG < n16 ? i + 3 * ONE_WG : n16 - 1);
-    const f4* p4 = s16 + (i + 4 * ONE_WG < n16 ? i + 4 * ONE_WG : n16 - 1);
-    const f4* p5 = s16 + (i + 5 * ONE_WG < n16 ? i + 5 * ONE_WG : n16 - 1);
-    asm volatile(
-        "global_load_dwordx4 %0, %6, off sc1\n\t"
-        "global_load_dwordx4 %1, %7, off sc1\n\t"
-        "global_load_dwordx4 %2, %8, off sc1\n\t"
-        "global_load_dwordx4 %3, %9, off sc1\n\t"
-        "global_load_dwordx4 %4, %10, off sc1\n\t"
-        "global_load_dwordx4 %5, %11, off sc1\n\t"
-        "s_waitcnt vmcnt(0)"
-        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5)
-        : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
-        : "memory");
-    if (i < n16) d16[i] = t0;
-    if (i + ONE_WG < n16) d16[i + ONE_WG] = t1;
-    if (i + 2 * ONE_WG < n16) d16[i + 2 * ONE_WG] = t2;
-    if (i + 3 * ONE_WG < n16) d16[i + 3 * ONE_WG] = t3;
-    if (i + 4 * ONE_WG < n16) d16[i + 4 * ONE_WG] = t4;
-    if (i + 5 * ONE_WG < n16) d16[i + 5 * ONE_WG] = t5;
+  for (int round = 0; round < ONE_RETRY_LIMIT; ++round) {
+    if (tid == 0) *retry_sh = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int i0 = 0; i0 < n16; i0 += ONE_WG * 6) {
+      w4 t[6];
+      const int i = i0 + tid;
+      const w4* p0 = s16 + (i < n16 ? i : n16 - 1);
+      const w4* p1 = s16 + (i + ONE_WG < n16 ? i + ONE_WG : n16 - 1);
+      const w4* p2 = s16 + (i + 2 * ONE_WG < n16 ? i + 2 * ONE_WG : n16 - 1);
+      const w4* p3 = s16 + (i + 3 * ONE_WG < n16 ? i + 3 * ONE_WG : n16 - 1);
+      const w4* p4 = s16 + (i + 4 * ONE_WG < n16 ? i + 4 * ONE_WG : n16 - 1);
+      const w4* p5 = s16 + (i + 5 * ONE_WG < n16 ? i + 5 * ONE_WG : n16 - 1);
+      asm volatile(
+          "global_load_dwordx4 %0, %6, off sc1\n\t"
+          "global_load_dwordx4 %1, %7, off sc1\n\t"
+          "global_load_dwordx4 %2, %8, off sc1\n\t"
+          "global_load_dwordx4 %3, %9, off sc1\n\t"
+          "global_load_dwordx4 %4, %10, off sc1\n\t"
+          "global_load_dwordx4 %5, %11, off sc1\n\t"
+          "s_waitcnt vmcnt(0)"
+          : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5])
+          : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5)
+          : "memory");
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int iu = i + u * ONE_WG;
+        if (iu < n16) {
+          const int f = iu * 4;
+          bad |= (f < n_valid && (t[u].x >> 31) != ep) || (f + 1 < n_valid && (t[u].y >> 31) != ep) ||
+                 (f + 2 < n_valid && (t[u].z >> 31) != ep) || (f + 3 < n_valid && (t[u].w >> 31) != ep);
+          w4 v = t[u];
+          v.x &= 0x7fffffffu; v.y &= 0x7fffffffu; v.z &= 0x7fffffffu; v.w &= 0x7fffffffu;
+          d16[iu] = v;
+        }
+      }
+    }
+    if (bad) *retry_sh = 1;
+    __syncthreads();
+    const int again = *retry_sh;
+    __syncthreads();   // (everyone has read the flag before the next round clears it)
+    if (!again) return true;
+    __builtin_amdgcn_s_sleep(16);
   }
+  return false;
 }
 
 // Smallest key over the wave's lanes [0, 1 << STEPS) (the other lanes are ignored), in every lane.  The minimum of the
@@ -166,7 +188,7 @@ template <int S>
 __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
   constexpr int M = 12, M2T = 6;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int flag_sh;
+  __shared__ int flag_sh, retry_sh;
   const int K = a.K, lutN = M * K;
   float* lut = reinterpret_cast<float*>(smem);
   u64* stage = reinterpret_cast<u64*>(smem + (((size_t)lutN * 4 + 15) & ~(size_t)15));
@@ -208,24 +230,31 @@ __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
           const float pr = t * t;
           acc = acc + pr;
         }
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + p * K + c, __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + p * K + c, one_tag(acc, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     ONE_STAMP(1);
-    if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (b0 < b1) {   // (in flight while the barrier is polled)
+    if (b0 < b1) {   // (the first row blocks of every wave: in flight while the table arrives)
 #pragma unroll
       for (int u = 0; u < PF; ++u) fetch(ring[u], b + u * ONE_WAVES);
     }
-    if (tid == 0) {
-      const bool ok = one_wait(a.sync, (uint32_t)G);
-      if (!ok) a.err[0] = 1;
-      flag_sh = ok ? 1 : 0;
+    // the first word of every slice is polled (a few hundred bytes) until all carry this call's epoch; the full table is
+    // then staged and verified word by word (and staged again in the rare case that a slice was still in flight)
+    if (wave == 0) {
+      bool ok = false;
+      for (int round = 0; round < ONE_RETRY_LIMIT && !ok; ++round) {
+        bool bad = false;
+        for (int unit = lane; unit < M * n_slot; unit += 64) {
+          const int p = unit / n_slot, c0 = (unit - p * n_slot) * cw;
+          if (c0 < K) bad |= (__hip_atomic_load(reinterpret_cast<uint32_t*>(a.lut_g) + p * K + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 31) != a.epoch;
+        }
+        ok = __ballot(bad) == 0ull;
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+      }
+      if (lane == 0) flag_sh = ok ? 1 : 0;
     }
     __syncthreads();
-    if (!flag_sh) return;
+    if (!flag_sh) { if (tid == 0) a.err[0] = 1; return; }
     ONE_STAMP(2);
   }
 
@@ -234,8 +263,7 @@ __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
   const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
   sel.init(stage + wave * 64, sentinel_key, a.L);
   if (b0 < b1) {   // workgroup-uniform
-    one_stage_table(a.lut_g, lut, lutN, tid);
-    __syncthreads();
+    if (!one_stage_tagged(a.lut_g, lut, lutN, lutN, a.epoch, tid, &retry_sh)) { if (tid == 0) a.err[0] = 1; return; }
     ONE_STAMP(3);
     for (; b < b1; b += PF * ONE_WAVES) {
       u64 keys[PF];
@@ -279,24 +307,35 @@ __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
   __syncthreads();
   if (wave == 0) {
     const u64 mine = one_multiway(lists, ONE_WAVES, ONE_WAVES, a.L, lane);
-    if (lane < a.L) __hip_atomic_store(a.part + (size_t)lane * G + w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) {
-      const uint32_t ticket = __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag_sh = ticket == (uint32_t)(G - 1);
-    }
+    if (lane < a.L) __hip_atomic_store(a.part + (size_t)lane * G + w, one_tag_key(mine, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
   ONE_STAMP(5);
-  if (!flag_sh) return;
+  if (w != 0) return;   // (workgroup 0 collects the lists)
   ONE_STAMP_LAST(0);
 
   // ---- 3. the last workgroup: multiway merge of the G lists (lane <-> list, 64 lists per wave), replay ----
   {
     u64* all = reinterpret_cast<u64*>(smem) + ONE_WAVES * 64;   // [L][G] as published; behind the waves' result rows
     const int total = G * a.L;
-    for (int i = tid; i < total; i += ONE_WG) all[i] = __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    {
+      bool ok = false;
+      for (int round = 0; round < ONE_RETRY_LIMIT && !ok; ++round) {
+        if (tid == 0) retry_sh = 0;
+        __syncthreads();
+        bool bad = false;
+        for (int i = tid; i < total; i += ONE_WG) {
+          const u64 word = __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad |= (uint32_t)(word >> 63) != a.epoch;
+          all[i] = one_untag_key(word);
+        }
+        if (bad) retry_sh = 1;
+        __syncthreads();
+        ok = retry_sh == 0;
+        __syncthreads();   // (everyone has read the flag before the next round clears it)
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+      }
+      if (!ok) { if (tid == 0) a.err[0] = 1; return; }
+    }
     // one wave, lane <-> the lists x = lane, lane + 64, ... (<= 4 for 256 CUs): each round takes the smallest head
     if (wave != 0) return;
     ONE_STAMP_LAST(1);
@@ -330,10 +369,6 @@ __global__ __launch_bounds__(ONE_WG) void pq_one_kernel(OneArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     if (lane == 0) __hip_atomic_store(a.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (lane == 0) {   // re-arm (every other workgroup has left both counters behind)
-      __hip_atomic_store(a.sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 #undef ONE_STAMP
@@ -366,7 +401,8 @@ struct IvfOneArgs {
   u64* part;                 // [L][grid] workspace
   int32_t* out_ids;          // [k] mapped host memory
   float* out_dist;           // [k]
-  uint32_t* sync;            // [4] three arrival counters + the accepted-row count; zero on entry and on exit
+  uint32_t* cnt_g;           // [grid] workspace: every workgroup's accepted-row count (tagged)
+  uint32_t epoch;            // 0 / 1: the tag of this call's published words (pq_one_kernel)
   int32_t* err;              // mapped host word: 1 = a poll ran out, 2 = list written, 3 = list written, the reference would probe again
   unsigned long long* prof;  // debugging: phase stamps (100 MHz) of workgroup 0 [0..9] and of the last arriver [10..12]
   int C, K, W, L, k, found_rule;
@@ -379,7 +415,7 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
   constexpr int M = 12, M2T = 6, D = M * S;
   static_assert(D == 300, "the query travels as 300 floats");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ int flag_sh;
+  __shared__ int flag_sh, retry_sh, acc_sh;
   __shared__ int32_t cells_sh[32];
   const int K = a.K, lutN = M * K, C = a.C, W = a.W;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -414,21 +450,12 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
           { const float t = qv.z - cv.z; const float pr = t * t; acc = acc + pr; }
           { const float t = qv.w - cv.w; const float pr = t * t; acc = acc + pr; }
         }
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.dist_g) + (w + ci * G), __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.dist_g) + (w + ci * G), one_tag(acc, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (tid == 0) acc_sh = 0;
+    __syncthreads();   // (the centroid rows in LDS are dead)
     ONE_STAMP(1);
-    if (tid == 0) {
-      __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool ok = one_wait(a.sync, (uint32_t)G);
-      if (!ok) a.err[0] = 1;
-      flag_sh = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!flag_sh) return;
-    ONE_STAMP(2);
   }
 
   // ---- B. the W nearest cells (every workgroup for itself) ----
@@ -437,8 +464,8 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
   {
     float* dl = reinterpret_cast<float*>(smem);                       // [C rounded up to 4]
     u64* prow = reinterpret_cast<u64*>(smem + (((size_t)C * 4 + 63) & ~(size_t)15));   // [64] wave 0's staging row
-    one_stage_table(a.dist_g, dl, (C + 3) & ~3, tid);                   // (dist_g is allocated to a multiple of 4)
-    __syncthreads();
+    if (!one_stage_tagged(a.dist_g, dl, (C + 3) & ~3, C, a.epoch, tid, &retry_sh)) { if (tid == 0) a.err[0] = 1; return; }
+    ONE_STAMP(2);
     if (wave == 0) {
       const int L2 = 2 * W;
       const u64 limit = (u64)__float_as_uint(a.cell_limit) << 32;
@@ -508,8 +535,12 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
       const int i = unit / (M * n_slot), rem = unit - i * (M * n_slot);
       const int p = rem / n_slot, c0 = (rem - p * n_slot) * cw;   // (i, p: workgroup-uniform)
       const int cell = __builtin_amdgcn_readfirstlane(cells_sh[i]);
-      if (cell < 0) continue;
       const int c1 = c0 + cw < K ? c0 + cw : K;
+      if (cell < 0) {   // no such item this time: its words still get this call's epoch (the next call may read them)
+        for (int c = c0 + tid; c < c1; c += ONE_WG)
+          __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + (size_t)i * lutN + p * K + c, a.epoch << 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
       const float* co = a.coarse + (size_t)cell * D + (size_t)p * S;
       for (int c = c0 + tid; c < c1; c += ONE_WG) {
         float cb[S];
@@ -523,24 +554,30 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
           const float pr = t * t;
           acc = acc + pr;
         }
-        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + (size_t)i * lutN + p * K + c, __float_as_uint(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<uint32_t*>(a.lut_g) + (size_t)i * lutN + p * K + c, one_tag(acc, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     ONE_STAMP(4);
-    if (tid == 0) __hip_atomic_fetch_add(a.sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (b0 < b1) {   // (the first row blocks in flight while the barrier is polled)
+    if (b0 < b1) {   // (the first row blocks in flight while the item's table arrives)
 #pragma unroll
       for (int u = 0; u < PF; ++u) fetch(ring[u], b + u * ONE_WAVES);
+      // the first word of every slice of this workgroup's item is polled until all carry this call's epoch
+      if (wave == 0) {
+        bool ok = false;
+        for (int round = 0; round < ONE_RETRY_LIMIT && !ok; ++round) {
+          bool bad = false;
+          for (int unit = lane; unit < M * n_slot; unit += 64) {
+            const int p = unit / n_slot, c0 = (unit - p * n_slot) * cw;
+            if (c0 < K) bad |= (__hip_atomic_load(reinterpret_cast<uint32_t*>(a.lut_g) + (size_t)my_item * lutN + p * K + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 31) != a.epoch;
+          }
+          ok = __ballot(bad) == 0ull;
+          if (!ok) __builtin_amdgcn_s_sleep(8);
+        }
+        if (lane == 0) flag_sh = ok ? 1 : 0;
+      }
+      __syncthreads();
+      if (!flag_sh) { if (tid == 0) a.err[0] = 1; return; }
     }
-    if (tid == 0) {
-      const bool ok = one_wait(a.sync + 1, (uint32_t)G);
-      if (!ok) a.err[0] = 1;
-      flag_sh = ok ? 1 : 0;
-    }
-    __syncthreads();
-    if (!flag_sh) return;
     ONE_STAMP(5);
   }
 
@@ -552,8 +589,7 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
   sel.init(stage + wave * 64, sentinel_key, a.L);
   int accepted = 0;
   if (b0 < b1) {   // workgroup-uniform
-    one_stage_table(a.lut_g + (size_t)my_item * lutN, lut, lutN, tid);
-    __syncthreads();
+    if (!one_stage_tagged(a.lut_g + (size_t)my_item * lutN, lut, lutN, lutN, a.epoch, tid, &retry_sh)) { if (tid == 0) a.err[0] = 1; return; }
     ONE_STAMP(6);
     for (; b < b1; b += PF * ONE_WAVES) {
       u64 keys[PF];
@@ -588,32 +624,50 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
     sel.finish();
   }
   ONE_STAMP(7);
-  if (a.found_rule == 1 && lane == 0 && accepted) __hip_atomic_fetch_add(a.sync + 3, (uint32_t)accepted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0 && accepted) atomicAdd(&acc_sh, accepted);
   __syncthreads();
   u64* lists = reinterpret_cast<u64*>(smem);   // [64 ranks][ONE_WAVES]
   lists[lane * ONE_WAVES + wave] = sel.acc[0];
   __syncthreads();
   if (wave == 0) {
     const u64 mine = one_multiway(lists, ONE_WAVES, ONE_WAVES, a.L, lane);
-    if (lane < a.L) __hip_atomic_store(a.part + (size_t)lane * G + w, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < a.L) __hip_atomic_store(a.part + (size_t)lane * G + w, one_tag_key(mine, a.epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(a.cnt_g + w, (uint32_t)acc_sh | (a.epoch << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (every wave: its accepted-count atomic has landed before the arrival)
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t ticket = __hip_atomic_fetch_add(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    flag_sh = ticket == (uint32_t)(G - 1);
-  }
-  __syncthreads();
   ONE_STAMP(8);
-  if (!flag_sh) return;
+  if (w != 0) return;   // (workgroup 0 collects the lists)
   ONE_STAMP_LAST(0);
 
   // ---- E. the last workgroup: merge, replay, the list ----
   {
     u64* all = reinterpret_cast<u64*>(smem) + ONE_WAVES * 64;
     const int total = G * a.L;
-    for (int i = tid; i < total; i += ONE_WG) all[i] = __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
+    {
+      bool ok = false;
+      for (int round = 0; round < ONE_RETRY_LIMIT && !ok; ++round) {
+        if (tid == 0) { retry_sh = 0; acc_sh = 0; }
+        __syncthreads();
+        bool bad = false;
+        for (int i = tid; i < total; i += ONE_WG) {
+          const u64 word = __hip_atomic_load(a.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad |= (uint32_t)(word >> 63) != a.epoch;
+          all[i] = one_untag_key(word);
+        }
+        int cnt = 0;
+        for (int i = tid; i < G; i += ONE_WG) {
+          const uint32_t word = __hip_atomic_load(a.cnt_g + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          bad |= (word >> 31) != a.epoch;
+          cnt += (int)(word & 0x7fffffffu);
+        }
+        if (cnt) atomicAdd(&acc_sh, cnt);
+        if (bad) retry_sh = 1;
+        __syncthreads();
+        ok = retry_sh == 0;
+        __syncthreads();   // (everyone has read the flag before the next round clears it)
+        if (!ok) __builtin_amdgcn_s_sleep(8);
+      }
+      if (!ok) { if (tid == 0) a.err[0] = 1; return; }
+    }
     if (wave != 0) return;
     ONE_STAMP_LAST(1);
     const u64 top = one_multiway4(all, G, a.L, lane);
@@ -643,16 +697,12 @@ __global__ __launch_bounds__(ONE_WG) void ivf_one_kernel(IvfOneArgs a) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) rows += __shfl_xor(rows, o, 64);
     if (!any_cell) rows = -1;   // no cell below the limit: the query retires
-    const int found = a.found_rule == 1 ? (int)__hip_atomic_load(a.sync + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (rows > 0 ? rows : 0);
+    const int found = a.found_rule == 1 ? acc_sh : (rows > 0 ? rows : 0);
     const int verdict = (found < a.k && rows >= 0) ? 3 : 2;
     ONE_STAMP_LAST(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if (lane == 0) {
-      __hip_atomic_store(a.err, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) __hip_atomic_store(a.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0) __hip_atomic_store(a.err, verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 #undef ONE_STAMP
