@@ -1859,6 +1859,23 @@ __global__ __launch_bounds__(256) void lane_copy_out_kernel(const int32_t* __res
   if (i < nn && i < n) h_out[2 * n_out + 1 + i] = unfinished[i];
 }
 
+// The same by ONE workgroup, followed by a completion word the host polls (lane_retire): the lists are in (mapped host)
+// memory before the word.  n_out * 2 + n + 1 words: a few tens of KB.
+__global__ __launch_bounds__(1024) void lane_copy_out_flag_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dist,
+                                                                 const int32_t* __restrict__ n_next, const int32_t* __restrict__ unfinished,
+                                                                 int32_t* __restrict__ h_out, int n_out, int n, int32_t* __restrict__ flag) {
+  const int nn = n_next[0];
+  for (int i = threadIdx.x; i < n_out; i += 1024) { h_out[i] = ids[i]; h_out[n_out + i] = __float_as_int(dist[i]); }
+  if (threadIdx.x == 0) h_out[2 * n_out] = nn;
+  for (int i = threadIdx.x; i < nn && i < n; i += 1024) h_out[2 * n_out + 1 + i] = unfinished[i];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ __launch_bounds__(256) void host_io_out_kernel(const int32_t* __restrict__ ids, const float* __restrict__ dist, int32_t* __restrict__ h_out, int n_out) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n_out) { h_out[i] = ids[i]; h_out[n_out + i] = __float_as_int(dist[i]); }
@@ -1874,7 +1891,7 @@ static int lane_open(Lane& l, LaneSlot& c, size_t in_bytes, size_t n, size_t n_o
     if (hipHostMalloc(&c.h_in, want, hipHostMallocDefault) != hipSuccess) { c.h_in = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
     c.h_in_cap = want;
   }
-  const size_t out_bytes = (n_out * 2 + 1 + n) * 4;
+  const size_t out_bytes = (n_out * 2 + 1 + n + 1) * 4;   // (+ the completion word)
   if (out_bytes > c.h_out_cap) {
     if (c.h_out) (void)hipHostFree(c.h_out);
     c.h_out = nullptr; c.h_out_cap = 0;
@@ -1928,11 +1945,26 @@ struct PipeCall {   // the arguments of one host-buffer call, for the lanes' ret
 static int lane_retire(LaneSlot& c, const PipeCall& pc) {
   if (!c.busy) return 0;
   c.busy = false;
-  HIP_TRY(hipEventSynchronize(c.done));
-  HIP_TRY(hipGetLastError());   // (a fault in one of the lane's kernels surfaces here, before its output is trusted)
   const int k = pc.k;
   const size_t n_out = (size_t)c.n * k;
   const int32_t* ho = static_cast<const int32_t*>(c.h_out);
+  {
+    // the copy-out kernel's last store is a completion word behind the lists: polled for up to a millisecond (a few
+    // microseconds sooner than the event), then the event is waited for the usual way -- which is also where a fault in one
+    // of the lane's kernels surfaces, before its output is trusted
+    volatile const int32_t* flag = ho + 2 * n_out + 1 + (size_t)c.n;
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(1000);
+    int spins = 0;
+    while (*flag == 0) {
+      __builtin_ia32_pause();
+      if ((++spins & 255) == 0 && std::chrono::steady_clock::now() > t_end) break;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag == 0) {
+      HIP_TRY(hipEventSynchronize(c.done));
+      HIP_TRY(hipGetLastError());
+    }
+  }
   memcpy(pc.out_ids + (size_t)c.q0 * k, ho, n_out * 4);
   memcpy(pc.out_dist + (size_t)c.q0 * k, ho + n_out, n_out * 4);
   const int n_next = std::min(ho[2 * n_out], c.n);
@@ -2099,19 +2131,31 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
     if ((rc = lane_open(l, c, row * n, (size_t)n, (size_t)n * k))) break;
     c.q0 = q0; c.n = n;
     const float* src = pinned_in ? pinned_in + (size_t)q0 * ix->d : nullptr;
-    if (!src || reinterpret_cast<uintptr_t>(src) % 16 || (row * n) % 16) {   // (the copy kernel moves whole 16-byte words)
-      memcpy(c.h_in, queries + (size_t)q0 * ix->d, row * n);
-      src = static_cast<const float*>(c.h_in);
-    }
-    if (trace) t2 = now_us();
+    const bool stage = !src || reinterpret_cast<uintptr_t>(src) % 16 || (row * n) % 16;   // (the copy kernel moves whole 16-byte words)
     const float* d_queries = c.d_q.as<float>();
     if (n <= 8) {
-      d_queries = src;     // a handful of queries: the kernels read them where they are staged (pinned, mapped) -- one launch less
+      // a handful of queries: the kernels read them where they are staged (pinned, mapped) -- one launch less
+      if (stage) { memcpy(c.h_in, queries + (size_t)q0 * ix->d, row * n); src = static_cast<const float*>(c.h_in); }
+      d_queries = src;
+      if (trace) t2 = now_us();
     } else {
-      const size_t n16 = (row * n + 15) / 16;
-      hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 512)), dim3(256), 0, l.stream,
-                         reinterpret_cast<const uint4*>(src), c.d_q.as<uint4>(), n16);
-      if (hipGetLastError() != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the query copy failed"); break; }
+      // pageable queries cross in pieces: the copy kernel of a piece reads it over PCIe while the host stages the next one
+      // (1.2 MB per 1024 queries: 28 us of memcpy + 25 us of PCIe, back to back until round 4)
+      const size_t total = row * n, n16_all = (total + 15) / 16;
+      const int pieces = stage && total >= (size_t)512 * 1024 ? 4 : 1;
+      const size_t per16 = (n16_all + pieces - 1) / pieces;
+      for (int pi = 0; pi < pieces; ++pi) {
+        const size_t w0 = (size_t)pi * per16, w1 = std::min(n16_all, w0 + per16);
+        if (w0 >= w1) break;
+        const size_t b0 = w0 * 16, b1 = std::min(total, w1 * 16);
+        if (stage) memcpy(static_cast<char*>(c.h_in) + b0, reinterpret_cast<const char*>(queries + (size_t)q0 * ix->d) + b0, b1 - b0);
+        const char* from = stage ? static_cast<const char*>(c.h_in) : reinterpret_cast<const char*>(src);
+        hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((w1 - w0 + 255) / 256, 512)), dim3(256), 0, l.stream,
+                           reinterpret_cast<const uint4*>(from + b0), reinterpret_cast<uint4*>(c.d_q.as<char>() + b0), w1 - w0);
+        if (hipGetLastError() != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the query copy failed"); break; }
+      }
+      if (rc) break;
+      if (trace) t2 = now_us();
     }
     IvfRun r;
     if ((rc = ivfadc_begin(ix, l.stream, n_lanes, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
@@ -2119,8 +2163,10 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
       break;
     if (trace) t3 = now_us();
     const int n_out = n * k;
-    hipLaunchKernelGGL(lane_copy_out_kernel, dim3((unsigned)((std::max(n_out, n) + 255) / 256)), dim3(256), 0, l.stream, c.d_ids.as<int32_t>(),
-                       c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n);
+    int32_t* h_flag = static_cast<int32_t*>(c.h_out) + 2 * (size_t)n_out + 1 + (size_t)n;
+    *h_flag = 0;
+    hipLaunchKernelGGL(lane_copy_out_flag_kernel, dim3(1), dim3(1024), 0, l.stream, c.d_ids.as<int32_t>(),
+                       c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n, h_flag);
     if (hipGetLastError() != hipSuccess || hipEventRecord(c.done, l.stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the result copy failed"); break; }
     c.busy = true;
     if (trace)
