@@ -1995,7 +1995,6 @@ static const void* pinned_device_pointer(const void* p) {
   return attr.type == hipMemoryTypeHost ? attr.devicePointer : nullptr;
 }
 
-// the batch [0, Q) of one device's handle
 // The one-launch kernels' hand-off buffer: every published word carries the call's epoch in its top bit (one.h).  Calls of
 // one shape write exactly the same words, so the epoch just flips; a different shape (or a new allocation) clears the
 // buffer to epoch 0 and starts with epoch 1.
@@ -2101,6 +2100,7 @@ static int ivf_one(freddy_gpu_index* ix, const float* queries, int k, int W, flo
   return 0;
 }
 
+// the batch [0, Q) of one device's handle
 static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q, int k, int W, float sentinel, int found_rule,
                               int32_t* out_ids, float* out_dist) {
   HIP_TRY(hipSetDevice(ix->device));

@@ -46,3 +46,9 @@ bash tools/lds_pmc.sh > gpurun_out/prof/${TAG}_lds_counters.txt 2>&1
 python3 tools/other_shape.py > gpurun_out/prof/${TAG}_other_shape.json 2> /dev/null
 python3 tools/latency.py > gpurun_out/prof/${TAG}_latency.txt 2> /dev/null
 python3 tools/single_query.py > gpurun_out/prof/${TAG}_single_query.txt 2> /dev/null
+# ONE query per call (the reference's own call shape): the one-launch kernels under the kernel trace + their in-kernel phases
+export TMPDIR=/tmp
+rm -rf /tmp/prof_${TAG}_lat; mkdir -p /tmp/prof_${TAG}_lat
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_${TAG}_lat -o r -- python3 tools/latency.py > /dev/null 2> /dev/null
+python3 tools/prof_summary.py stats /tmp/prof_${TAG}_lat gpurun_out/prof/${TAG}_latency_kernel_stats.txt > /dev/null
+FREDDY_GPU_ONE_PROF=1 python3 tools/latency.py 2>&1 | grep "ivf_one\]" | tail -3 > gpurun_out/prof/${TAG}_one_launch_phases.txt
