@@ -282,6 +282,7 @@ struct freddy_gpu_index {
   float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
+  float* cbF = nullptr;         // [m][8 groups][7 steps][64 lanes][8] the codebook in the B-fragment order of the table kernel's matrix instructions (fused5.h query_codebook5_body)
   int32_t* viol = nullptr;      // [4] self-check counters: scan bracket violations / rows checked, coarse bracket violations / cells checked
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
@@ -415,7 +416,7 @@ static void free_index(freddy_gpu_index* ix) {
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->coarseH, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units, ix->packed8_own ? ix->packed8 : nullptr};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->coarseH, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->cbF, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units, ix->packed8_own ? ix->packed8 : nullptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   for (auto& kv : ix->prof)
@@ -645,14 +646,14 @@ static int raise_lds_limits(int device) {
 // every upload has succeeded (freddy_gpu_update_codebook on a live handle: a failed call leaves the handle as it was).
 static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebook);
 static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
-  float* const old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
+  float* const old[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp, ix->cbF};
   const int64_t bytes_before = ix->bytes;
-  ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = nullptr;
+  ix->cbT = ix->cbP = ix->cbR = ix->pmax = ix->cmaxp = ix->cbF = nullptr;
   const int rc = derive_codebook_tables_into(ix, codebook);
   if (rc) {   // put the old tables back
-    float* const fresh[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp};
+    float* const fresh[] = {ix->cbT, ix->cbP, ix->cbR, ix->pmax, ix->cmaxp, ix->cbF};
     for (float* p : fresh) if (p) (void)hipFree(p);
-    ix->cbT = old[0]; ix->cbP = old[1]; ix->cbR = old[2]; ix->pmax = old[3]; ix->cmaxp = old[4];
+    ix->cbT = old[0]; ix->cbP = old[1]; ix->cbR = old[2]; ix->pmax = old[3]; ix->cmaxp = old[4]; ix->cbF = old[5];
     ix->bytes = bytes_before;
     return rc;
   }
@@ -662,12 +663,32 @@ static int derive_codebook_tables(freddy_gpu_index* ix, const float* codebook) {
   if (old[2]) old_bytes += (int64_t)sizeof(float) * ix->m * ix->K * ix->S;
   if (old[3]) old_bytes += (int64_t)sizeof(float) * ix->m;
   if (old[4]) old_bytes += (int64_t)sizeof(float) * ix->m;
+  if (old[5]) old_bytes += (int64_t)sizeof(float) * ix->m * 8 * 7 * 64 * 8;
   ix->bytes -= old_bytes;       // (the footprint changes by the difference, not by a second copy)
   for (float* p : old) if (p) (void)hipFree(p);
   if (ix->kind == KIND_PQ) {    // views of the flat table are rebuilt from the new tables on next use
     if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
     if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
   }
+  return 0;
+}
+// The codebook in the order the table kernel's v_mfma_f32_16x16x4_f32 B operands are read (m = 12, S = 25, K <= 1024): for
+// (position, group g of 16 code slots, step) lane l = (col = l & 15, kq = l >> 4) finds the eight values of dimension
+// 4 step + kq for the codes 128 i + 16 g + col + 512 e, (i, e) = (0,0) (0,1) (1,0) ... (3,1), as two 16-byte words: a wave's
+// load is 2 KB of consecutive bytes (the transposed copy gave 64-byte pieces of eight different lines).
+static int build_fragment_codebook(freddy_gpu_index* ix, const float* codebook) {
+  std::vector<float> f((size_t)ix->m * 8 * 7 * 64 * 8, 0.0f);
+  for (int p = 0; p < ix->m; ++p)
+    for (int g = 0; g < 8; ++g)
+      for (int st = 0; st < 7; ++st)
+        for (int l = 0; l < 64; ++l)
+          for (int i = 0; i < 4; ++i)
+            for (int e = 0; e < 2; ++e) {
+              const int j = 4 * st + (l >> 4), c = 128 * i + 16 * g + (l & 15) + 512 * e;
+              if (j < ix->S && c < ix->K)
+                f[((((size_t)p * 8 + g) * 7 + st) * 64 + l) * 8 + i * 2 + e] = codebook[((size_t)p * ix->K + c) * ix->S + j];
+            }
+  if (upload(&ix->cbF, f.data(), f.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
   return 0;
 }
 static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebook) {
@@ -691,6 +712,7 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
           upload(&ix->pmax, cmaxp.data(), cmaxp.size(), &ix->bytes) ||
           upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
         return fail(FREDDY_E_NOMEM, "device allocation failed");
+      if (int rc = build_fragment_codebook(ix, codebook)) return rc;
     }
     return 0;
   }
@@ -735,6 +757,7 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
         upload(&ix->pmax, pmax.data(), pmax.size(), &ix->bytes) ||
         upload(&ix->cmaxp, cmaxp.data(), cmaxp.size(), &ix->bytes))
       return fail(FREDDY_E_NOMEM, "device allocation failed");
+    if (int rc = build_fragment_codebook(ix, codebook)) return rc;
   }
   return 0;
 }
@@ -1209,7 +1232,7 @@ static int ivf_coarse(IvfRun& r) {
     CoarseTableArgs ct;
     ct.queries = r.d_q; ct.coarseF = ix->coarseP; ct.cn2 = ix->cn2; ct.dist = ws->w_distT.as<float>(); ct.qn2 = ws->w_qn2.as<float>();
     ct.Q = Q; ct.Cpad = Cpad; ct.d = d; ct.dp = ix->dp; ct.z = za; ct.coarse_gx = Cpad / 128; ct.coarse_gy = (Q + COARSE_TQ - 1) / COARSE_TQ;
-    ct.cbT = ix->cbT; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
+    ct.cbT = ix->cbF; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
     ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K; ct.tmin = tile_min; ct.C = C;
     ct.coarseH = (const ch8v*)ix->coarseH; ct.ec = ix->coarse_ec;
     const size_t lds = std::max<size_t>(ix->coarseH ? coarse_approx16_lds(d) : (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
@@ -1239,7 +1262,7 @@ static int ivf_coarse(IvfRun& r) {
     }
     if (r.scan_kernel == 5) {
       timed_launch(ix, sq, "query_codebook", [&] {
-        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
+        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbF, ix->cmaxp,
                              ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
       });
     } else
@@ -2439,7 +2462,7 @@ static int pq_view_refresh(freddy_gpu_index* ix, freddy_gpu_index** view, hipStr
     *view = fx;
   }
   fx->tune = ix->tune;
-  fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp;   // shared with the owner
+  fx->cbT = ix->cbT; fx->cbR = ix->cbR; fx->pmax = ix->pmax; fx->cmaxp = ix->cmaxp; fx->cbF = ix->cbF;   // shared with the owner
   fx->packed = const_cast<uint32_t*>(packed);
   fx->packed8 = (packed == ix->packed) ? ix->packed8 : nullptr; fx->packed8_own = false;   // (a subset's gathered rows: the int16 layout)
   fx->N = n_rows; fx->n_blocks = n_blocks; fx->max_list_blocks = FUSED_UNIT_BLOCKS;
@@ -2518,7 +2541,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   // queries' table scales: no item / work-table / record kernels (pq_front_kernel)
   PqFrontArgs fa;
   fa.queries = d_q; fa.Q = Q; fa.d = fx->d; fa.lists = lists; fa.W = W; fa.n_rows = fx->N; fa.blk_off = fx->blk_off; fa.list_off = fx->list_off;
-  fa.cbT = fx->cbT; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
+  fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
   fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
   fa.item_dist = pa.item_dist; fa.round_rows = pa.round_rows; fa.records = ws->w_records.as<int32_t>(); fa.n_groups = wt.n_groups;
   const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 2) * sizeof(float));

@@ -25,13 +25,15 @@
 // The bound (u = 2^-24, B and the reference's error as in fused4.h; D exact, d the reference's binary32 value):
 //   reference                                   |d - D|        <= 39 u B
 //   rterm (fp64, rounded once)                                  <=  1 u B
-//   per position: dot product (fmaf chain of 25) and quotient  <= 28 u 2|q_p||c| ; rint: <= 0.5 scale
+//   per position: dot product (25 terms; since round 4 on the matrix cores, seven v_mfma_f32_16x16x4_f32 steps -- any
+//                 order of binary32 products and sums of 25 terms stays below 56 u, the fmaf chain of rounds 2-3 below 26 u)
+//                 and quotient                                <= 58 u 2|q_p||c| ; rint: <= 0.5 scale
 //                 no clamping: 2 |q_p| max|c_p| <= 2730 scale by construction
-//       summed over 12 positions                                <= 28 u B + 6 scale
+//       summed over 12 positions                                <= 58 u B + 6 scale
 //   the sum V itself: exact (integers below 2^15)
 //   s' = fma(scale, V, rterm), s = s' + OFF: two roundings of values <= 3 B + E      <=  7 u B
 //   residual's own rounding (as fused4.h)                                    <=  2 u B
-//   =>  |(s - OFF + |r|^2) - d| <= e = 77 u B + 6 scale;  the construction needs e <= E / 4.2:
+//   =>  |(s - OFF + |r|^2) - d| <= e = 107 u B + 6 scale;  the construction needs e <= E / 4.2 = 121.9 u B + 6.67 scale:
 //   E = 512 u B + 28 scale   (typical: 2.0e-3 against 1.2e-3 of fused4.h -- 13.7 instead of 11.8 survivors per item).
 // Everything downstream (survivor regions, merge_refine_kernel with the same E, the self-check of the bracket on
 // every refined row) is fused4.h's.
@@ -82,8 +84,8 @@ __device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, x) + __builtin_bit_cast(s2v, y));
 }
 
-// The table: as query_codebook_kernel (whole 2 KB rows through an LDS transpose), values rint(-2 q_p . c / scale[q])
-// clamped to +-2730, scale[q] = max_p 2 |q_p| max|c_p| / 2730 -- ONE per query.  Every workgroup (position p, 16
+// The table: values rint(-2 q_p . c / scale[q]) clamped to +-2730, scale[q] = max_p 2 |q_p| max|c_p| / 2730 -- ONE per query;
+// row (query, position) = 128 uint4, word j of uint4 s = codes 128 j + s (low half) and 128 j + s + 512 (high half).  Every workgroup (position p, 16
 // queries) derives the scales of its queries itself (16 lanes per query, lane <-> position: the same fmaf chain and
 // the same maximum in every workgroup); the workgroups of position 0 also write qn[q][p] = |q_p| (rounded up) and
 // scale[q] for the record and merge kernels.
@@ -94,11 +96,26 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
                                                      int Q, int d, int m, int K, int bx, int by, unsigned char* smem) {
   static_assert(QT == 16, "one 16-lane group per query");
   constexpr int SP = (S + 3) & ~3;
-  // LDS from the caller: ob [2][4][512] u32 (16 KB), qs [QT][SP] floats, inv_s [QT]
-  uint32_t (*ob)[4][512] = reinterpret_cast<uint32_t (*)[4][512]>(smem);
-  float (*qs)[SP] = reinterpret_cast<float (*)[SP]>(smem + 2 * 4 * 512 * 4);
-  float* inv_s = reinterpret_cast<float*>(smem + 2 * 4 * 512 * 4 + QT * SP * 4);
+  // LDS from the caller: qs [QT][SP] floats, inv_s [QT]
+  float (*qs)[SP] = reinterpret_cast<float (*)[SP]>(smem);
+  float* inv_s = reinterpret_cast<float*>(smem + QT * SP * 4);
   const int tid = threadIdx.x, p = bx, q0 = by * QT;
+  // MFMA path: the B operands of the wave's FIRST group of code slots are requested before anything else -- the codebook
+  // round trip runs under the prologue (the workgroup is a chain of latencies: all 768 are resident at once); the second
+  // group's are requested into the same registers right after the first group's matrix instructions, under its conversion
+  constexpr int STEPS_B = (S + 3) / 4;
+  float bv[STEPS_B][4][2];
+  auto load_b = [&](int g) {   // (cbT here = the fragment-order copy, freddy_gpu.hip build_fragment_codebook)
+    typedef float f4b __attribute__((ext_vector_type(4)));
+    const f4b* src = reinterpret_cast<const f4b*>(cbT + ((((size_t)p * 8 + g) * STEPS_B) * 64 + (tid & 63)) * 8);
+#pragma unroll
+    for (int st = 0; st < STEPS_B; ++st) {
+      const f4b lo = src[(size_t)st * 128], hi = src[(size_t)st * 128 + 1];
+      bv[st][0][0] = lo.x; bv[st][0][1] = lo.y; bv[st][1][0] = lo.z; bv[st][1][1] = lo.w;
+      bv[st][2][0] = hi.x; bv[st][2][1] = hi.y; bv[st][3][0] = hi.z; bv[st][3][1] = hi.w;
+    }
+  };
+  load_b((tid >> 6) * 2);
   for (int i = tid; i < QT * SP; i += 256) {
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
@@ -121,68 +138,56 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
       if (p == 0 && q < Q) qscale[q] = sc;
     }
   }
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  v2f cb[2][S];
+  {
+    // The dot products on the matrix cores (v_mfma_f32_16x16x4_f32: A = 16 queries x 4 dimensions, B = 4 dimensions x 16
+    // codes, seven steps for S = 25): a wave takes two groups of 16 code slots and, per group, the eight tiles whose codes
+    // share a slot's uint4 (code 128 i + slot, i = 0..3, and its partner + 512) -- so a lane ends up with exactly the four
+    // words of one 16-byte store per query.  D[row = 4 (lane >> 4) + reg][col = lane & 15].  The sum's rounding differs from
+    // the fmaf chain's (order, product rounding): within the 28 u 2|q_p||c| -> 56 u the bracket's derivation (top of this
+    // file) leaves room for (e = 105 u B + 6 scale <= E / 4.2 = 122 u B + 6.67 scale).
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    __syncthreads();   // (qs, inv_s)
+    const int wave = tid >> 6, lane = tid & 63, col = lane & 15, kq = lane >> 4;
+    const int nq = (Q - q0 < QT) ? Q - q0 : QT;
+    constexpr int STEPS = (S + 3) / 4;
+    float av[STEPS];
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int b = tid + 256 * e;
-#pragma unroll
-    for (int j = 0; j < S; ++j) {
-      cb[e][j].x = b < K ? cbT[((size_t)p * S + j) * K + b] : 0.0f;
-      cb[e][j].y = b + 512 < K ? cbT[((size_t)p * S + j) * K + b + 512] : 0.0f;
-    }
-  }
-  __syncthreads();
-  const int nq = (Q - q0 < QT) ? Q - q0 : QT;
-  for (int qi = 0; qi < nq; qi += 4) {
-    v2f acc[4][2];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) acc[w][0] = acc[w][1] = v2f{0.0f, 0.0f};
-#pragma unroll
-    for (int jb = 0; jb < SP / 4; ++jb) {
-      float vv[4][4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float4 v = *reinterpret_cast<const float4*>(&qs[qi + w][jb * 4]);
-        vv[w][0] = v.x; vv[w][1] = v.y; vv[w][2] = v.z; vv[w][3] = v.w;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (jb * 4 + u < S) {
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            const v2f qq = v2f{vv[w][u], vv[w][u]};
-            acc[w][0] = __builtin_elementwise_fma(qq, cb[0][jb * 4 + u < S ? jb * 4 + u : 0], acc[w][0]);
-            acc[w][1] = __builtin_elementwise_fma(qq, cb[1][jb * 4 + u < S ? jb * 4 + u : 0], acc[w][1]);
-          }
-        }
-    }
-    const int buf = (qi >> 2) & 1;
+    for (int st = 0; st < STEPS; ++st) av[st] = 4 * st + kq < S ? qs[col][4 * st + kq] : 0.0f;   // (A: row = lane & 15 = the query)
     const float vmax = (float)FILT5_VMAX;
     const int bias = filt5_bias(p, m);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float inv = inv_s[qi + w];
+    for (int gg = 0; gg < 2; ++gg) {
+      const int g = wave * 2 + gg;
+      f4v acc[4][2];
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int b = tid + 256 * e;
-        const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].x * inv), -vmax), vmax) + bias;
-        const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[w][e].y * inv), -vmax), vmax) + bias;
-        ob[buf][w][4 * (b & 127) + (b >> 7)] = (uint32_t)i0 | ((uint32_t)i1 << 16);
+      for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = f4v{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int st = 0; st < STEPS; ++st)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st][i][e], acc[i][e], 0, 0, 0);
+      if (gg == 0) load_b(g + 1);
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int qi = 4 * kq + reg;
+        if (qi < nq) {
+          const float inv = inv_s[qi];
+          uint32_t wd[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int i0 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[i][0][reg] * inv), -vmax), vmax) + bias;
+            const int i1 = (int)fminf(fmaxf(__builtin_rintf(-2.0f * acc[i][1][reg] * inv), -vmax), vmax) + bias;
+            wd[i] = (uint32_t)i0 | ((uint32_t)i1 << 16);
+          }
+          *reinterpret_cast<uint4*>(qc + ((size_t)(q0 + qi) * m + p) * 512 + 4 * (16 * g + col)) = uint4{wd[0], wd[1], wd[2], wd[3]};
+        }
       }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = tid + 256 * h;
-      const int w = i >> 7, e4 = i & 127;
-      if (qi + w < nq)
-        *reinterpret_cast<uint4*>(qc + ((size_t)(q0 + qi + w) * m + p) * 512 + 4 * e4) = *reinterpret_cast<const uint4*>(&ob[buf][w][4 * e4]);
     }
   }
 }
 template <int S, int QT>
-static constexpr int query_codebook5_lds() { return 2 * 4 * 512 * 4 + QT * ((S + 3) & ~3) * 4 + QT * 4; }
+static constexpr int query_codebook5_lds() { return QT * ((S + 3) & ~3) * 4 + QT * 4; }
 template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
                                                              const float* __restrict__ cmax, float* __restrict__ qn,
