@@ -54,6 +54,7 @@
 namespace freddy {
 
 static constexpr float JOIN_MAX_DIST = 1000.0f;   // ivpq_search_in.c:62
+static constexpr int JOIN_CELL_CHUNK = 256;    // cells of a query whose target rows are laid out as ONE index space at a time
 static constexpr int JOIN_WG = 256;
 static constexpr int JOIN_WAVES = JOIN_WG / 64;
 
@@ -361,12 +362,13 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
   size_t off = 0;
   float* qv = reinterpret_cast<float*>(smem + off);            off += ((size_t)d * 4 + 15) & ~(size_t)15;
   float* lut = reinterpret_cast<float*>(smem + off);           off += ((size_t)lutN * 4 + 15) & ~(size_t)15;
-  float* lut2 = reinterpret_cast<float*>(smem + off);          off += a.double_codes ? (((size_t)n_codes * range * 4 + 15) & ~(size_t)15) : 0;
   u64* stage = reinterpret_cast<u64*>(smem + off);             off += (size_t)JOIN_WAVES * 64 * 8;
   u64* lists = reinterpret_cast<u64*>(smem + off);             off += (size_t)JOIN_WAVES * 64 * V * 8;
   float* exact = reinterpret_cast<float*>(smem + off);         off += ((size_t)64 * V * 4 + 15) & ~(size_t)15;
   float* s_d = reinterpret_cast<float*>(smem + off);           off += ((size_t)k * 4 + 15) & ~(size_t)15;
-  int32_t* s_id = reinterpret_cast<int32_t*>(smem + off);
+  int32_t* s_id = reinterpret_cast<int32_t*>(smem + off);      off += ((size_t)k * 4 + 15) & ~(size_t)15;
+  int32_t* c_start = reinterpret_cast<int32_t*>(smem + off);   off += (size_t)JOIN_CELL_CHUNK * 4;        // first target slot of a cell of the chunk
+  int32_t* c_pref = reinterpret_cast<int32_t*>(smem + off);                                               // [chunk + 1] rows before it
 
   const int x = blockIdx.x;
   const int q = a.scan_query[x];
@@ -387,33 +389,54 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
       lut[e] = acc;
     }
     __syncthreads();
-    if (a.double_codes) {
-      // getPrecomputedDistancesDouble, index_utils.c:457-475: sum of the two rounded sub-distances
-      for (int e = threadIdx.x; e < n_codes * range; e += JOIN_WG) {
-        const int i = e / range, j = e - i * range;
-        const int c0 = j % K, c1 = j / K;
-        lut2[e] = lut[(2 * i) * K + c0] + lut[(2 * i + 1) * K + c1];
-      }
-      __syncthreads();
-    }
+    // (pair codes -- getPrecomputedDistancesDouble, index_utils.c:457-475: a table of the sums of the two rounded
+    // sub-distances, n_codes x K^2 entries -- are NOT tabulated: the scan adds the two entries itself, the same binary32
+    // addition the table would hold.  15 x 32^2 floats = 61 KB of LDS per workgroup allowed two workgroups per CU.)
   }
-  const float* tab = a.double_codes ? lut2 : lut;
+  const float* tab = lut;
   const bool vec4 = (d & 3) == 0;   // (rows of d floats are then 16-byte aligned: hipMalloc'd base, pitch 4 d)
 
   WaveSelect<V> sel;
   sel.init(stage + wave * 64, (u64)__float_as_uint(JOIN_MAX_DIST) << 32, L);
   const int c_begin = a.qcell_off ? a.qcell_off[x] : q * a.qstride;
   const int c_end = a.qcell_off ? a.qcell_off[x + 1] : c_begin + a.qcell_cnt[q];
-  for (int ci = c_begin + wave; ci < c_end; ci += JOIN_WAVES) {
-    const int cell = a.qcells[ci];
-    const int r0 = a.tcell_off[cell], r1 = a.tcell_off[cell + 1];
-    for (int base = r0; base < r1; base += 64) {
-      const int t = base + lane;
-      const bool valid = t < r1;
+  // The target rows of the query's cells as ONE index space: a query takes ~40 cells of ~16 target rows each, and a loop
+  // "cell by cell, 64 rows at a time" left three quarters of the lanes idle and paid three dependent round trips (cell
+  // offsets -> row number -> codes) per cell and wave -- 25-33 us of a 48 us workgroup.  Here the cells' offsets are read
+  // once (all together), prefix-summed in LDS, and lane t of a pass takes row t of the concatenation (binary search in the
+  // prefix sums): every lane busy, two dependent round trips per 256 rows.
+  for (int cb = c_begin; cb < c_end; cb += JOIN_CELL_CHUNK) {
+    const int nc = c_end - cb < JOIN_CELL_CHUNK ? c_end - cb : JOIN_CELL_CHUNK;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += JOIN_WG) {
+      const int cell = a.qcells[cb + i];
+      const int r0 = a.tcell_off[cell], r1 = a.tcell_off[cell + 1];
+      c_start[i] = r0;
+      c_pref[i] = r1 - r0;
+    }
+    __syncthreads();
+    if (wave == 0) {   // exclusive prefix sums: a lane sums its stretch, the wave scans the 64 sums
+      const int per = (nc + 63) >> 6, lo = lane * per, hi = lo + per < nc ? lo + per : nc;
+      int sum = 0;
+      for (int i = lo; i < hi; ++i) sum += c_pref[i];
+      int incl = sum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+      int run = incl - sum;
+      for (int i = lo; i < hi; ++i) { const int c = c_pref[i]; c_pref[i] = run; run += c; }
+      if (lane == 63) c_pref[nc] = incl;
+    }
+    __syncthreads();
+    const int T = c_pref[nc];
+    for (int base = 0; base < T; base += JOIN_WG) {
+      const int t = base + (int)threadIdx.x;
+      const bool valid = t < T;
       float dist = 0.0f;
       int32_t row = 0;
       if (valid) {
-        row = a.trow[t];
+        int lo = 0, hi = nc;   // the last cell whose prefix is <= t (cells without target rows share a prefix with their successor)
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (c_pref[mid] <= t) lo = mid; else hi = mid; }
+        row = a.trow[c_start[lo] + (t - c_pref[lo])];
         if (a.method == FREDDY_METHOD_EXACT) {
           dist = vec4 ? sqdist_seq4(qv, a.vectors + (size_t)row * d, d) : sqdist_seq(qv, a.vectors + (size_t)row * d, d);
         } else {
@@ -435,9 +458,9 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {                     // ivpq_search_in.c:446-451 (int16 pair code)
                   const int l = (c0 + c8) * 4 + u;
-                  if (l < n_codes) {
-                    const int pc = (int16_t)((int)(ww[u] & 0xffffu) + (int)(ww[u] >> 16) * K);
-                    dist = dist + tab[range * l + pc];
+                  if (l < n_codes) {   // (K^2 <= 32768: the reference's int16 pair code never wraps, join.h host check)
+                    const float pair = tab[(2 * l) * K + (int)(ww[u] & 0xffffu)] + tab[(2 * l + 1) * K + (int)(ww[u] >> 16)];
+                    dist = dist + pair;
                   }
                 }
               } else {
@@ -921,9 +944,9 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   const int n_codes = double_codes ? m / 2 : m;
   const int range = double_codes ? K * K : K;
   auto r16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
-  size_t lds = r16((size_t)d * 4) + r16((size_t)m * K * 4) + (double_codes ? r16((size_t)n_codes * range * 4) : 0) +
+  size_t lds = r16((size_t)d * 4) + r16((size_t)m * K * 4) +
                (size_t)JOIN_WAVES * 64 * 8 + (size_t)JOIN_WAVES * 64 * V * 8 + r16((size_t)64 * V * 4) + r16((size_t)k * 4) +
-               r16((size_t)k * 4);
+               r16((size_t)k * 4) + (size_t)(2 * JOIN_CELL_CHUNK + 1) * 4 + 16;
   if (lds > 160 * 1024) return join_fail(FREDDY_E_LIMIT, "LDS need of %zu bytes exceeds 160 KiB (m=%d K=%d k*pvf=%d)", lds, m, K, L);
 
   // "fq.id IN (targets)": resolved, de-duplicated and bucketed by cell on the device (see join_mark_kernel)
