@@ -234,37 +234,38 @@ __device__ __forceinline__ void coarse_approx16_body(const float* __restrict__ q
       }
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1) { n0 += __shfl_xor(n0, o, 64); am = fmaxf(am, __shfl_xor(am, o, 64)); }
+    // (every thread of the row has the row's sum and maximum: xor-shuffles)
+    int e = 0;
+    if (am > 0.0f && am < 3e38f) { (void)__builtin_frexpf(am, &e); e = 14 - e; }
+    const float sc = __builtin_ldexpf(1.0f, e);     // the scale itself (a power of two: v * 2^e is exact)
     if (part == 0) {
-      int e = 0;
-      if (am > 0.0f && am < 3e38f) { (void)__builtin_frexpf(am, &e); e = 14 - e; }
       rown[row] = n0; rown[32 + row] = n0; rown[64 + row] = n0; rown[96 + row] = n0;
       qsc[row] = __builtin_ldexpf(1.0f, -(e + ec));
-      reinterpret_cast<float*>(qe)[row] = __builtin_ldexpf(1.0f, e);     // the scale itself (a power of two: v * 2^e is exact)
+      reinterpret_cast<float*>(qe)[row] = sc;
       if (bx == 0 && q0 + row < Q) qn2[q0 + row] = n0;
     }
-  }
-  __syncthreads();
-  {
-    const int d4n = d >> 2;
-    for (int i = tid; i < T * 64; i += 256) {
-      const int t = i >> 6, l = i & 63, row = l & 31, g = l >> 5;
-      const int q = q0 + row < Q ? q0 + row : Q - 1;
-      const float sc = reinterpret_cast<const float*>(qe)[row];
-      const float4* qv = reinterpret_cast<const float4*>(queries + (size_t)q * d);
-      const int c = 4 * t + 2 * g;
-      float4 a0 = qv[c < d4n ? c : d4n - 1], a1 = qv[c + 1 < d4n ? c + 1 : d4n - 1];
-      if (c >= d4n) a0 = float4{0.f, 0.f, 0.f, 0.f};
-      if (c + 1 >= d4n) a1 = float4{0.f, 0.f, 0.f, 0.f};
-      const float f[8] = {a0.x * sc, a0.y * sc, a0.z * sc, a0.w * sc, a1.x * sc, a1.y * sc, a1.z * sc, a1.w * sc};
-      ch8v hi, lo;
+    // the A fragments straight from the registers the norms were computed from (a second pass over the queries -- five more
+    // round trips per thread and a barrier -- was a third of the tile's time): float4 i of the row = dimensions 4 i .. 4 i + 3
+    // = half (i & 1) of the eight-dimension group g = (i & 3) >> 1 of k-step t = i >> 2
+    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const _Float16 hh = (_Float16)f[u];
-        hi[u] = hh;
-        lo[u] = (_Float16)(f[u] - (float)hh);
+    for (int u = 0; u < NL; ++u) {
+      const int i = part + 8 * u;
+      if (i < T * 4) {
+        float4 x = v[u];
+        if (i >= d4n) x = float4{0.f, 0.f, 0.f, 0.f};
+        const float f[4] = {x.x * sc, x.y * sc, x.z * sc, x.w * sc};
+        h4v hi, lo;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const _Float16 hh = (_Float16)f[w];
+          hi[w] = hh;
+          lo[w] = (_Float16)(f[w] - (float)hh);
+        }
+        const int t = i >> 2, g = (i & 3) >> 1, l = row + 32 * g;
+        reinterpret_cast<h4v*>(&Ah[(size_t)(t * 2 + 0) * 64 + l])[i & 1] = hi;
+        reinterpret_cast<h4v*>(&Ah[(size_t)(t * 2 + 1) * 64 + l])[i & 1] = lo;
       }
-      Ah[(size_t)(t * 2 + 0) * 64 + l] = hi;
-      Ah[(size_t)(t * 2 + 1) * 64 + l] = lo;
     }
   }
   __syncthreads();
