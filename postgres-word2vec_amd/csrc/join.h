@@ -188,6 +188,17 @@ static inline int join_pin(JoinIndex* j, const freddy_ivpq_desc* t, int64_t* byt
 }
 
 // pinned host memory -> device (the queries of a call; pinned memory is mapped into the device's address space)
+// Cell lists of the (few) queries whose traversal the host had to do (equal keys: the reference's heap order is history-dependent)
+// into the rows the device traversal writes for everybody else -- row q of qcells[Q][cells], qcell_cnt[q] -- so that ONE join
+// launch serves all queries of a round.  rows: [n][1 + cells] in mapped host memory (count, cells).
+__global__ __launch_bounds__(256) void join_fb_rows_kernel(const int32_t* __restrict__ rows, const int32_t* __restrict__ scan_q,
+                                                          int32_t* __restrict__ qcells, int32_t* __restrict__ qcell_cnt, int cells) {
+  const int x = blockIdx.x, q = scan_q[x];
+  const int32_t* r = rows + (size_t)x * (cells + 1);
+  const int n = r[0];
+  if (threadIdx.x == 0) qcell_cnt[q] = n;
+  for (int i = threadIdx.x; i < n; i += 256) qcells[(size_t)q * cells + i] = r[1 + i];
+}
 __global__ __launch_bounds__(256) void join_copy_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -1223,12 +1234,27 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       a.d = d; a.m = m; a.K = K; a.S = j->S; a.k = k; a.L = L; a.method = method; a.double_codes = double_codes ? 1 : 0;
       if (!j->ev0) { JOIN_HIP(hipEventCreate(&j->ev0)); JOIN_HIP(hipEventCreate(&j->ev1)); }
       JOIN_HIP(hipEventRecord(j->ev0, s));
-      if (n_dev > 0) {     // cell lists written by the traversal kernel: row q of [Q][cells]
+      // (a separate launch for the host-traversed queries ran behind the main one -- a lone workgroup's 45 us -- and its two
+      // list uploads were SDMA hops: a query with a tie cost the call 0.1 ms)
+      const bool fb_rows = dev_trav && n_fb > 0 && j->h_q && (size_t)n_fb * (size_t)(cells + 1) * sizeof(int32_t) <= j->h_q_cap;
+      if (fb_rows) {
+        int32_t* hf = static_cast<int32_t*>(j->h_q);   // (the query staging block: its copy kernels finished before the first synchronisation)
+        for (int x = 0; x < n_fb; ++x) {
+          int32_t* row = hf + (size_t)x * (cells + 1);
+          const int cnt = qoff[(size_t)x + 1] - qoff[(size_t)x];
+          row[0] = cnt;
+          memcpy(row + 1, flat.data() + qoff[(size_t)x], sizeof(int32_t) * (size_t)cnt);
+        }
+        hipLaunchKernelGGL(join_fb_rows_kernel, dim3((unsigned)n_fb), dim3(256), 0, s, (const int32_t*)j->h_q, (const int32_t*)d_scan + n_dev,
+                           (int32_t*)d_qstrided, (int32_t*)d_qcnt, cells);
+        JOIN_HIP(hipGetLastError());
+      }
+      if (n_dev > 0 || fb_rows) {     // cell lists written by the traversal kernel (and join_fb_rows_kernel): row q of [Q][cells]
         a.scan_query = (const int32_t*)d_scan; a.qcell_off = nullptr; a.qcell_cnt = (const int32_t*)d_qcnt; a.qstride = cells;
         a.qcells = (const int32_t*)d_qstrided; a.out_ids = p_oi; a.out_dist = p_od;
-        if (int rc = join_launch(s, a, n_dev, V, lds)) return rc;
+        if (int rc = join_launch(s, a, fb_rows ? n_scan : n_dev, V, lds)) return rc;
       }
-      if (n_fb > 0) {      // host-traversed queries: flat lists with offsets
+      if (n_fb > 0 && !fb_rows) {      // host-traversed queries: flat lists with offsets
         if (join_buf(j, 6, sizeof(int32_t) * std::max<size_t>(flat.size(), 1), &d_qcells)) return FREDDY_E_NOMEM;
         JOIN_HIP(hipMemcpyAsync(d_qoff, qoff.data(), sizeof(int32_t) * (n_fb + 1), hipMemcpyHostToDevice, s));
         if (!flat.empty()) JOIN_HIP(hipMemcpyAsync(d_qcells, flat.data(), sizeof(int32_t) * flat.size(), hipMemcpyHostToDevice, s));
