@@ -1222,6 +1222,18 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       for (int32_t c : qcells[q]) if (tcell_off[c + 1] > tcell_off[c]) flat.push_back(c);
       qoff.push_back((int32_t)flat.size());
     }
+    // longest first: a query's workgroup is a chain whose length grows with its target rows (a few queries have ten times
+    // the average), and the launch ends with whatever was started last -- counting sort on rows / 128, descending
+    if (scan.size() > 256) {
+      constexpr int NBK = 64;
+      int cnt[NBK + 1] = {0};
+      auto bucket = [&](int q) { const int b = q_rows[q] >> 7; return NBK - 1 - (b < NBK ? b : NBK - 1); };
+      for (int q : scan) ++cnt[bucket(q) + 1];
+      for (int b = 0; b < NBK; ++b) cnt[b + 1] += cnt[b];
+      std::vector<int32_t> sorted(scan.size());
+      for (int q : scan) sorted[(size_t)cnt[bucket(q)]++] = q;
+      scan.swap(sorted);
+    }
     const int n_dev = (int)scan.size(), n_fb = (int)scan_fb.size(), n_scan = n_dev + n_fb;
     scan.insert(scan.end(), scan_fb.begin(), scan_fb.end());
     track(&freddy_track::query_construction_time);
