@@ -312,6 +312,8 @@ int freddy_gpu_abi_version(void);
  * "sparse_items" (cells that at most this many queries of a batch probe are scanned item by item instead of as cell-grouped
  * work entries -- used where such cells are the rule: fewer than four (query, probe) items per cell and at least 16 per CU;
  * default 2, 0 = never, a negative value forces it for cells of up to that many items whatever the batch),
+ * "plan_waves" (0, the default: the cell-selection plan runs four waves per query for one batch at a time and ONE wave per
+ * query -- a quarter of the registers and of the LDS -- when the caller keeps batches in flight (scan_share > 1); 4: always four),
  * "one_launch" (1, the default: a host-buffer call with ONE query -- the reference's own call shape -- is a single launch,
  * pq_one_kernel / ivf_one_kernel: the stages of the multi-launch path behind in-kernel grid barriers, the host polls the
  * kernel's completion word; 0: the multi-launch path.  A handle whose grid once failed to meet at a barrier within the

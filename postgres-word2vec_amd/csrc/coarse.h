@@ -382,10 +382,14 @@ __device__ __forceinline__ uint32_t float_order_bits(float f) {   // monotone ma
 // the candidate pass.  STREAM = true (up to COARSE_STREAM_MAX_CPAD cells): the distance row is read twice -- per-lane
 // minima first, then the candidates, kept as a BITMAP in LDS (2 KB; the i-th candidate = the i-th set bit, found through
 // per-word prefix counts) -- so any number of cells and of candidates fits the same footprint.
-template <int ABL, bool STREAM = false>   // ABL: 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
-__global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args g) {   // (<= 128 registers: four workgroups per CU, what the LDS admits)
+// NWP = 4 waves per query: the shortest latency for ONE batch (34.5 KB of LDS, four queries per CU).  NWP = 1: one wave does
+// everything, seven candidates per round -- a quarter of the wave slots and of the LDS per query: with several batches in
+// flight, when this kernel has to fit into the CUs the other batches' scans leave, a whole batch is resident on a quarter of
+// the chip (as merge_refine_kernel's one-wave instantiation).
+template <int ABL, bool STREAM = false, int NWP = PLAN2_NW>   // ABL: 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
+__global__ __launch_bounds__(64 * NWP, NWP == 1 ? 4 : 4) void probe_plan2_kernel(Plan2Args g) {   // (<= 128 registers: four waves per SIMD)
   const PlanArgs& a = g.p;
-  constexpr int NW = PLAN2_NW, NCB = PLAN2_NCB, RC = NW * NCB;   // RC candidates per round
+  constexpr int NW = NWP, NCB = PLAN2_NCB, RC = NW * NCB;   // RC candidates per round
   constexpr int NV = COARSE_MAX_CPAD / 64 / NW;                  // cells per lane
   __shared__ u64 stage[64];
   __shared__ float mins[NW][64];
@@ -427,10 +431,16 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
     for (int i = threadIdx.x; i < SW; i += 64 * NW) cbits[i] = 0u;
   }
   const int d4n = d >> 2;   // (d % 4 == 0, d <= 320)
-  {
+  if constexpr (NW >= 2) {   // (d4n <= 80 <= 128 threads)
     const int tq = (int)threadIdx.x < d4n ? (int)threadIdx.x : d4n - 1;
     const float4 qreg = *reinterpret_cast<const float4*>(g.queries + (size_t)q * d + 4 * tq);
     if ((int)threadIdx.x < d4n) *reinterpret_cast<float4*>(qs + 4 * threadIdx.x) = qreg;
+  } else {                   // one wave: two float4 per lane
+    const int t0 = lane < d4n ? lane : d4n - 1, t1 = lane + 64 < d4n ? lane + 64 : d4n - 1;
+    const float4 q0r = *reinterpret_cast<const float4*>(g.queries + (size_t)q * d + 4 * t0);
+    const float4 q1r = *reinterpret_cast<const float4*>(g.queries + (size_t)q * d + 4 * t1);
+    if (lane < d4n) *reinterpret_cast<float4*>(qs + 4 * lane) = q0r;
+    if (lane + 64 < d4n) *reinterpret_cast<float4*>(qs + 4 * (lane + 64)) = q1r;
   }
   float mn = INF;
   // the masked value of cell j: INF = not a candidate (past the end / already probed), -INF = NaN (always one)
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(64 * PLAN2_NW, 4) void probe_plan2_kernel(Plan2Args
       }
       before += __shfl(inc, 63, 64);
     }
-    if (threadIdx.x == 0) cpre[nwords] = (uint16_t)(nws[0] + nws[1] + nws[2] + nws[3]);
+    if (threadIdx.x == 0) { int tot = 0; for (int w = 0; w < NW; ++w) tot += nws[w]; cpre[nwords] = (uint16_t)tot; }
     __syncthreads();
   }
   // the query's candidate list = the four lists one after the other: candidate i lives in list wi(i) at i - off[wi]

@@ -78,6 +78,7 @@ struct Tuning {
   int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
   int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
+  int plan_waves = 0;          // FREDDY_GPU_PLAN_WAVES: waves per query of the cell-selection plan: 0 = four for one batch at a time, one with batches in flight (scan_share > 1); 4 = always four
   int one_launch = 1;          // FREDDY_GPU_ONE_LAUNCH: a single pq_search query through the host-buffer call as ONE launch (one.h) instead of three
   int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
   int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
@@ -125,6 +126,7 @@ static Tuning read_tuning() {
   t.pipeline_lanes = (int)std::min<int64_t>(4, std::max<int64_t>(1, env_int("FREDDY_GPU_PIPELINE_LANES", t.pipeline_lanes)));
   t.pq_fused = (int)env_int("FREDDY_GPU_PQ_FUSED", t.pq_fused);
   t.one_launch = (int)env_int("FREDDY_GPU_ONE_LAUNCH", t.one_launch);
+  t.plan_waves = (int)env_int("FREDDY_GPU_PLAN_WAVES", t.plan_waves);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
   t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -1073,6 +1075,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "merge_waves") t.merge_waves = (int)value;
   else if (n == "pq_fused") t.pq_fused = (int)value;
   else if (n == "one_launch") t.one_launch = (int)value;
+  else if (n == "plan_waves") t.plan_waves = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
   else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
   else if (n == "fused_prof") t.scan_prof = (int)value;
@@ -1313,7 +1316,9 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
       g.pmax = ix->pmax; g.submax = (r.n_active + SCAN5_G - 1) / SCAN5_G;
     }
     timed_launch(ix, s, "probe_plan", [&] {
-      if (ix->Cpad <= COARSE_MAX_CPAD) hipLaunchKernelGGL((probe_plan2_kernel<0, false>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);
+      // (one batch at a time: four waves per query, the shortest latency; batches in flight: one wave per query, the smallest footprint)
+      if (ix->Cpad <= COARSE_MAX_CPAD && r.share > 1 && ix->tune.plan_waves != 4 && !r.direct) hipLaunchKernelGGL((probe_plan2_kernel<0, false, 1>), dim3(r.n_active), dim3(64), 0, s, g);
+      else if (ix->Cpad <= COARSE_MAX_CPAD) hipLaunchKernelGGL((probe_plan2_kernel<0, false>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);
       else hipLaunchKernelGGL((probe_plan2_kernel<0, true>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);   // (more than 1024 cells: streamed)
     });
   } else
