@@ -207,12 +207,33 @@ __global__ __launch_bounds__(256) void join_copy_kernel(const uint32_t* __restri
 // sub-distances of every query to the multi-index centroids       index_utils.c:297-305
 // out[q][pos][code]; lane <-> code (coalesced centroid reads), query half-vector via scalar cache
 // ---------------------------------------------------------------------------------------
+// copy_out != NULL: `queries` is the pinned staging block (mapped host memory) -- the workgroup pulls its half vector over
+// PCIe ONCE (16-byte loads), keeps it in LDS, and also writes it to the device copy the join kernel reads: the query batch
+// crosses PCIe inside this kernel, piece by piece behind the host's staging copy (no separate copy kernels, and the
+// sub-distances of a piece are done when its bytes have arrived).  q0: first query of the launch.
 __global__ __launch_bounds__(64) void sub_dist_kernel(const float* __restrict__ queries,
                                                      const float* __restrict__ coarseT,
-                                                     float* __restrict__ out, int d, int Kc) {
-  const int q = blockIdx.x, pos = blockIdx.y;
+                                                     float* __restrict__ out, int d, int Kc,
+                                                     float* __restrict__ copy_out = nullptr, int q0 = 0) {
+  __shared__ __attribute__((aligned(16))) float qh[512];
+  const int q = q0 + blockIdx.x, pos = blockIdx.y;
   const int half = d / 2;
   const float* qv = queries + (size_t)q * d + (size_t)pos * half;
+  const bool staged = copy_out != nullptr && half <= 512;
+  if (staged) {
+    if ((half & 3) == 0 && (((size_t)q * d + (size_t)pos * half) & 3) == 0) {
+      const int n4 = half >> 2;
+      for (int i = threadIdx.x; i < n4; i += 64) {
+        const float4 v = reinterpret_cast<const float4*>(qv)[i];
+        reinterpret_cast<float4*>(qh)[i] = v;
+        reinterpret_cast<float4*>(copy_out + (size_t)q * d + (size_t)pos * half)[i] = v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < half; i += 64) { const float v = qv[i]; qh[i] = v; copy_out[(size_t)q * d + (size_t)pos * half + i] = v; }
+    }
+    __syncthreads();
+    qv = qh;
+  }
   for (int c = threadIdx.x; c < Kc; c += 64) {
     float acc = 0.0f;
     // (the sum is sequential -- squareDistance's order -- but the loads are not: one at a time, each waited for, the kernel was
@@ -1005,17 +1026,23 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       if (hipHostMalloc(&j->h_q, qbytes + qbytes / 4 + 256, hipHostMallocDefault) != hipSuccess) { j->h_q = nullptr; return join_fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
       j->h_q_cap = qbytes + qbytes / 4 + 256;
     }
-    // (in pieces: the host copies piece i + 1 while the kernel pulls piece i over PCIe)
-    const size_t n4 = qbytes / 4, piece = std::max<size_t>((n4 + 3) / 4, 65536);
-    for (size_t o = 0; o < n4; o += piece) {
-      const size_t len = std::min(piece, n4 - o);
-      memcpy(static_cast<uint32_t*>(j->h_q) + o, reinterpret_cast<const uint32_t*>(queries) + o, len * 4);
-      hipLaunchKernelGGL(join_copy_kernel, dim3((unsigned)std::min<size_t>((len + 255) / 256, 1024)), dim3(256), 0, s, (const uint32_t*)j->h_q + o, (uint32_t*)d_q + o, len);
+    // (in pieces of whole queries: the host copies piece i + 1 while sub_dist_kernel pulls piece i over PCIe, writes the device
+    // copy and computes the piece's sub-distances)
+    const int piece_q = std::max((Q + 3) / 4, 64);
+    const bool fused_front = (d & 1) == 0 && d / 2 <= 512;   // (the kernel's staging buffer; odd d: the halves do not cover the vector)
+    for (int qa = 0; qa < Q; qa += piece_q) {
+      const int nq = std::min(piece_q, Q - qa);
+      memcpy(static_cast<float*>(j->h_q) + (size_t)qa * d, queries + (size_t)qa * d, sizeof(float) * (size_t)nq * d);
+      if (fused_front)
+        hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)nq, 2), dim3(64), 0, s, (const float*)j->h_q, j->coarseT, (float*)d_sub, d, Kc, (float*)d_q, qa);
+      else
+        hipLaunchKernelGGL(join_copy_kernel, dim3((unsigned)std::min<size_t>(((size_t)nq * d + 255) / 256, 1024)), dim3(256), 0, s,
+                           (const uint32_t*)j->h_q + (size_t)qa * d, (uint32_t*)d_q + (size_t)qa * d, (size_t)nq * d);
     }
+    if (!fused_front)
+      hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc, (float*)nullptr, 0);
     JOIN_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc);
-  JOIN_HIP(hipGetLastError());
   const int SV = join_pick_V(Kc);
   if (SV == 0) return join_fail(FREDDY_E_LIMIT, "coarse_codes=%d exceeds this build's limit of 1024", Kc);
   // The multi-index traversal runs on the device for <= 1024 cells (join_traverse_kernel; the host's libm checks every
