@@ -617,6 +617,7 @@ struct TravArgs {
   int32_t* qcells;           // [Q][cells]: the taken cells that hold targets, in the order they are taken
   int32_t* qcell_cnt;        // [Q]
   int32_t* summary;          // [n_active][TRAV_SUM_DW]
+  float* fb_sub;             // [n_active][2 * Kc] or NULL: the sub-distances of a query that is handed to the host (mapped host memory)
   int Kc, cells, n_targets, min_target;
   float confidence;
 };
@@ -625,11 +626,15 @@ struct TravArgs {
 // (WaveSelect) and decide the stop; only a query that needs more than 63 cells sorts all of them -- a bitonic sort in LDS
 // with ROLLED loops: the fully unrolled register sort of 1024 keys is ~100 KB of straight-line code that every wave
 // streamed through the 64 KB instruction cache once (380 us per launch for 5 000 queries, as long as the join itself).
-template <int V>
+// SMALL: only the 64 smallest keys are ever held (1.5 instead of 17 KB of LDS for 1024 cells: all 5 000 waves of a batch are
+// resident at once instead of nine per CU -- 43 -> 18 us); a query whose stop is not among its first 63 cells is handed to
+// the host heap like one with equal keys (flag 1).  The host picks SMALL when the expected number of cells is far below 63.
+template <int V, bool SMALL = false>
 __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
-  __shared__ u64 s_key[64 * V];        // (distance bits << 32) | cell, ascending from index 0 as far as they are sorted
-  __shared__ float s_stat[64 * V];
-  __shared__ float s_P[64 * V + 1];
+  constexpr int NS = SMALL ? 64 : 64 * V;
+  __shared__ u64 s_key[NS];            // (distance bits << 32) | cell, ascending from index 0 as far as they are sorted
+  __shared__ float s_stat[NS];
+  __shared__ float s_P[NS + 1];
   __shared__ u64 s_stage[64];
   const int lane = threadIdx.x, x = blockIdx.x;
   const int q = a.active[x];
@@ -664,8 +669,11 @@ __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
   // then the 64 lanes test the chunk's 64 counts
   int n = cells;
   bool sorted_all = (V == 1);
+  bool beyond = false;   // SMALL: the stop is not among the first 63 cells
   for (int base = 0; base < cells; base += 64) {
+    if constexpr (SMALL) { if (base > 0) { beyond = true; n = 0; break; } }
     if (base > 0 && !sorted_all) {
+     if constexpr (!SMALL) {
       // more than 63 cells: every key, sorted (rolled bitonic network over LDS; 64 V is a power of two)
 #pragma unroll 1
       for (int v = 0; v < V; ++v) s_key[v * 64 + lane] = cell_key(v * 64 + lane);
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
       }
       sorted_all = true;
       __syncthreads();
+     }
     }
     if (lane == 0) {
       float P = s_P[base];
@@ -723,10 +732,14 @@ __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) rows += __shfl_xor(rows, o, 64);
+  // a query the host heap has to traverse: its 2 x Kc sub-distances go along with the summary (the host sorts the two sides
+  // itself: a side-sort kernel, two small copies and a synchronisation per handed-back query cost 0.05 - 0.08 ms per call)
+  if ((any_tie || beyond) && a.fb_sub)
+    for (int i = lane; i < 2 * Kc; i += 64) a.fb_sub[(size_t)x * 2 * Kc + i] = d0[i];
   if (lane == 0) {
     a.qcell_cnt[q] = n_keep;
     int32_t* sm = a.summary + (size_t)x * TRAV_SUM_DW;
-    sm[0] = n; sm[1] = n_keep; sm[2] = rows; sm[3] = (any_tie ? 1 : 0) | (n >= cells ? 2 : 0);
+    sm[0] = n; sm[1] = n_keep; sm[2] = rows; sm[3] = ((any_tie || beyond) ? 1 : 0) | (n >= cells ? 2 : 0);
     sm[4] = (int32_t)__float_as_uint(s_P[n]);
     sm[5] = (int32_t)__float_as_uint(n > 0 ? s_P[n - 1] : 0.0f);
     // the device's own values of the expression at the stop and one step before it: the host re-evaluates with its
@@ -1110,8 +1123,9 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   void *d_active = nullptr, *d_qstrided = nullptr, *d_qcnt = nullptr, *d_summary = nullptr;
   int32_t* h_summary = nullptr; int32_t* h_oi_p = nullptr; float* h_od_p = nullptr; int32_t* h_active = nullptr; int32_t* h_scan = nullptr;
   int32_t* p_summary = nullptr; int32_t* p_oi = nullptr; float* p_od = nullptr; int32_t* p_active = nullptr; int32_t* p_scan = nullptr;   // the same block as the device sees it
+  float* h_fbsub = nullptr; float* p_fbsub = nullptr;   // [Q][2 * Kc]: sub-distances of the queries the device traversal hands back
   {
-    const size_t need = sizeof(int32_t) * (size_t)Q * (TRAV_SUM_DW + 2 * (size_t)k + 2) + 64;   // + the active list and the scan list
+    const size_t need = sizeof(int32_t) * (size_t)Q * (TRAV_SUM_DW + 2 * (size_t)k + 2 + 2 * (size_t)Kc) + 64;   // + the active list, the scan list, the handed-back queries' sub-distances
     if (need > j->h_sum_cap) {
       if (j->h_sum) (void)hipHostFree(j->h_sum);
       j->h_sum = nullptr; j->h_sum_cap = 0;
@@ -1123,6 +1137,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     h_od_p = reinterpret_cast<float*>(h_oi_p + (size_t)Q * k);
     h_active = reinterpret_cast<int32_t*>(h_od_p + (size_t)Q * k);
     h_scan = h_active + Q;
+    h_fbsub = reinterpret_cast<float*>(h_scan + Q);
     // The kernels read the lists and write summaries / results in this pinned block DIRECTLY (it is mapped into the device's
     // address space): every hipMemcpyAsync between two kernels of a stream is an SDMA copy ordered against them by signals,
     // ~12 us per hop, and a round had five of them.
@@ -1133,6 +1148,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     p_od = reinterpret_cast<float*>(p_oi + (size_t)Q * k);
     p_active = reinterpret_cast<int32_t*>(p_od + (size_t)Q * k);
     p_scan = p_active + Q;
+    p_fbsub = reinterpret_cast<float*>(p_scan + Q);
   }
   if (dev_trav) {
     if (join_buf(j, 13, sizeof(int32_t) * (size_t)Q, &d_active) || join_buf(j, 14, sizeof(int32_t) * (size_t)Q * cells, &d_qstrided) ||
@@ -1159,8 +1175,20 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   auto launch_traverse = [&](int n_act, int min_target) -> int {
     TravArgs ta;
     ta.sub = (const float*)d_sub; ta.active = (const int32_t*)d_active; ta.stats = j->d_stats; ta.tcell_off = (const int32_t*)d_tcell;
-    ta.qcells = (int32_t*)d_qstrided; ta.qcell_cnt = (int32_t*)d_qcnt; ta.summary = p_summary;
+    ta.qcells = (int32_t*)d_qstrided; ta.qcell_cnt = (int32_t*)d_qcnt; ta.summary = p_summary; ta.fb_sub = p_fbsub;
     ta.Kc = Kc; ta.cells = cells; ta.n_targets = (int)n_targets; ta.min_target = min_target; ta.confidence = confidence;
+    // (the 64 smallest keys suffice when the stop is expected far below 63 cells: four times the cells min_target needs at
+    // the targets' average density; a query that needs more goes to the host heap)
+    const double per_cell = (double)n_targets / (double)std::max(cells, 1);
+    const bool small = TV > 1 && per_cell > 0.0 && 4.0 * (double)min_target / per_cell < 63.0;
+    if (small) {
+      switch (TV) {
+        case 2: hipLaunchKernelGGL((join_traverse_kernel<2, true>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+        case 4: hipLaunchKernelGGL((join_traverse_kernel<4, true>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+        case 8: hipLaunchKernelGGL((join_traverse_kernel<8, true>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+        default: hipLaunchKernelGGL((join_traverse_kernel<16, true>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
+      }
+    } else
     switch (TV) {
       case 1: hipLaunchKernelGGL((join_traverse_kernel<1>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
       case 2: hipLaunchKernelGGL((join_traverse_kernel<2>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
@@ -1208,6 +1236,22 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
         }
         q_host[q] = ok ? 0 : 1;
         if (ok) { q_n[q] = n; q_rows[q] = sm[2]; q_exh[q] = n >= cells; }
+        if (!ok && (sm[3] & 1) && !host_sides_all && (side_slot.empty() || side_slot[(size_t)q] < 0)) {
+          // handed back by the device with its sub-distances: the two sides sorted here (stable: equal distances keep their code
+          // order, index_utils.c:306-320) -- what side_sort_kernel would have produced
+          if (side_slot.empty()) side_slot.assign((size_t)Q, -1);
+          const size_t row = (size_t)2 * Kc, base = sub.size() / row;
+          sub.resize((base + 1) * row); sides.resize((base + 1) * row);
+          const float* fs = h_fbsub + (size_t)spec_index[(size_t)q] * row;
+          memcpy(sub.data() + base * row, fs, sizeof(float) * row);
+          for (int sd = 0; sd < 2; ++sd) {
+            JoinSide* out = sides.data() + base * row + (size_t)sd * Kc;
+            for (int c = 0; c < Kc; ++c) { out[c].dist = fs[(size_t)sd * Kc + c]; out[c].code = c; }
+            std::stable_sort(out, out + Kc, [](const JoinSide& u, const JoinSide& v) {   // (the kernel's key: the distance's bit pattern, then the code)
+              uint32_t ub, vb; memcpy(&ub, &u.dist, 4); memcpy(&vb, &v.dist, 4); return ub < vb; });
+          }
+          side_slot[(size_t)q] = (int32_t)base;
+        }
       }
       for (int q : active) if (q_host[q]) fb.push_back(q);
     } else {
