@@ -626,9 +626,9 @@ struct TravArgs {
 // (WaveSelect) and decide the stop; only a query that needs more than 63 cells sorts all of them -- a bitonic sort in LDS
 // with ROLLED loops: the fully unrolled register sort of 1024 keys is ~100 KB of straight-line code that every wave
 // streamed through the 64 KB instruction cache once (380 us per launch for 5 000 queries, as long as the join itself).
-// SMALL: only the 64 smallest keys are ever held (1.5 instead of 17 KB of LDS for 1024 cells: all 5 000 waves of a batch are
-// resident at once instead of nine per CU -- 43 -> 18 us); a query whose stop is not among its first 63 cells is handed to
-// the host heap like one with equal keys (flag 1).  The host picks SMALL when the expected number of cells is far below 63.
+// SMALL: only the smallest keys are ever held (1.5 instead of 17 KB of LDS for 1024 cells), found with ONE sort + merge (below);
+// a query whose stop is not among them (at least its 31 nearest cells) is handed to the host heap like one with equal keys
+// (flag 1).  The host picks SMALL when the expected number of cells is far below that.
 template <int V, bool SMALL = false>
 __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
   constexpr int NS = SMALL ? 64 : 64 * V;
@@ -650,7 +650,27 @@ __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
   };
   const int stat_size = (int)a.stats[cells];
   // ---- the 64 smallest keys, ascending
-  {
+  int n_valid = 64;   // SMALL: how many of them are known to be the smallest (>= 32)
+  if constexpr (SMALL) {
+    // The kernel is bound by instruction issue (5 000 lone waves), and a streaming selection that starts without a threshold
+    // pays a 64-bit sort + merge for every other batch of 64 keys.  Here: the lane's V keys stay in registers, the 32nd
+    // smallest of the 64 lane minima (one 32-bit sort) bounds the 32nd smallest key, only keys up to it are offered (about
+    // 40 of 1024): one sort + merge.  Every key below the bound is in the result, so its first n_valid entries are exactly the
+    // n_valid smallest keys; a stop beyond them is handed to the host.
+    u64 kk[V];
+    uint32_t mn = 0xffffffffu;
+#pragma unroll
+    for (int v = 0; v < V; ++v) { kk[v] = cell_key(v * 64 + lane); mn = min(mn, (uint32_t)(kk[v] >> 32)); }
+    const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)wave_sort32(mn), 31);
+    WaveSelect<1> sel;
+    sel.init(s_stage, ((u64)dL << 32) | 0xffffffffull, 64);
+#pragma unroll
+    for (int v = 0; v < V; ++v) sel.push(kk[v], kk[v] != KEY_INF);
+    sel.finish();
+    n_valid = (int)__popcll(__ballot(sel.acc[0] != KEY_INF));
+    s_key[lane] = sel.acc[0];
+    s_stat[lane] = (sel.acc[0] != KEY_INF) ? a.stats[key_pos(sel.acc[0])] : 0.0f;
+  } else {
     WaveSelect<1> sel;
     sel.init(s_stage, KEY_INF, 64);
 #pragma unroll 1
@@ -709,7 +729,7 @@ __global__ __launch_bounds__(64) void join_traverse_kernel(TravArgs a) {
     }
     __syncthreads();
     const int cnt = base + lane;
-    const bool ok = cnt < cells && !(join_confidence_expr(a.min_target, a.n_targets, s_P[cnt < cells ? cnt : 0], stat_size) < a.confidence);
+    const bool ok = cnt < cells && (!SMALL || cnt + 1 < n_valid) && !(join_confidence_expr(a.min_target, a.n_targets, s_P[cnt < cells ? cnt : 0], stat_size) < a.confidence);
     const u64 m = __ballot(ok);
     if (m != 0ull) { n = base + (int)__builtin_ctzll(m); break; }
   }
@@ -1180,7 +1200,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     // (the 64 smallest keys suffice when the stop is expected far below 63 cells: four times the cells min_target needs at
     // the targets' average density; a query that needs more goes to the host heap)
     const double per_cell = (double)n_targets / (double)std::max(cells, 1);
-    const bool small = TV > 1 && per_cell > 0.0 && 4.0 * (double)min_target / per_cell < 63.0;
+    const bool small = TV > 1 && per_cell > 0.0 && 3.0 * (double)min_target / per_cell < 31.0;
     if (small) {
       switch (TV) {
         case 2: hipLaunchKernelGGL((join_traverse_kernel<2, true>), dim3((unsigned)n_act), dim3(64), 0, s, ta); break;
