@@ -863,7 +863,9 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   // of the block (binary search in the prefix), 64 x NBATCH keys per round trip.  Every key goes to sink(key, valid,
   // region), called by the whole wave.
   int* const pref = pref_all[MANY ? wave : 0];
-  auto dense_block = [&](auto&& sink, int jb0, int nreg) {
+  // pre(kk, s0, total): called once per round trip of up to 64 x NBATCH keys, before they go to the sink (pass 1 tightens its
+  // selection threshold from the keys' lane minima there)
+  auto dense_block = [&](auto&& sink, int jb0, int nreg, auto&& pre) {
     int carry = 0;
     for (int i0 = 0; i0 < nreg; i0 += 64 * NBATCH) {
       int c[NBATCH];
@@ -903,6 +905,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
         jj[u] = lo;
         kk[u] = (sidx < total) ? a.surv[((size_t)x * R + (size_t)(jb0 + lo)) * (size_t)(FUSED_RMAX * 64) + (size_t)(sidx - pref[lo])] : KEY_INF;
       }
+      pre(kk, s0, total);
 #pragma unroll
       for (int u = 0; u < NBATCH; ++u)
         if (s0 + u * 64 < total) sink(kk[u], s0 + u * 64 + lane < total, jb0 + jj[u]);
@@ -910,9 +913,11 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     __builtin_amdgcn_wave_barrier();
   };
   // blocks jb0, jb0 + jstep, ... of the query's regions
-  auto sweep = [&](auto&& sink, int jb0, int jstep) {
-    for (int jb = jb0; jb < R; jb += jstep) dense_block(sink, jb, R - jb < PB ? R - jb : PB);
+  auto no_pre = [](const u64 (&)[NBATCH], int, int) {};
+  auto sweep_pre = [&](auto&& sink, int jb0, int jstep, auto&& pre) {
+    for (int jb = jb0; jb < R; jb += jstep) dense_block(sink, jb, R - jb < PB ? R - jb : PB, pre);
   };
+  auto sweep = [&](auto&& sink, int jb0, int jstep) { sweep_pre(sink, jb0, jstep, no_pre); };
   // More regions than one sweep of a wave covers (W x chunks x 8 > 256: a batch over the flat PQ table "probes" hundreds of
   // pseudo-lists): every wave selects from a quarter of them -- the sweeps are chains of dependent round trips -- and
   // wave 0 merges the four selections.
@@ -967,7 +972,22 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
       sel.push(kk, kk != KEY_INF);
     }
   } else {
-    sweep([&](u64 kk, bool v, int) { if (v) flag_seen |= (uint32_t)kk; sel.push(kk, v); }, 0, PB);
+    // (a lone wave is bound by instruction issue, and a streaming selection that starts without a threshold pays a 64-bit
+    // sort + merge for nearly every batch of 64 keys: the LW-th smallest lane minimum of a round trip's keys -- one 32-bit
+    // sort -- bounds the LW-th smallest key, nothing farther can be among the LW smallest)
+    if constexpr (NWV != 1)   // (the four-wave instantiation has no register to spare: 56 B of scratch with the hook)
+      sweep([&](u64 kk, bool v, int) { if (v) flag_seen |= (uint32_t)kk; sel.push(kk, v); }, 0, PB);
+    else
+    sweep_pre([&](u64 kk, bool v, int) { if (v) flag_seen |= (uint32_t)kk; sel.push(kk, v); }, 0, PB,
+              [&](const u64 (&kk)[NBATCH], int s0, int total) {
+                uint32_t mn = 0xffffffffu;
+#pragma unroll
+                for (int u = 0; u < NBATCH; ++u)
+                  if (s0 + u * 64 + lane < total) mn = min(mn, (uint32_t)(kk[u] >> 32));
+                const uint32_t dL = (uint32_t)__builtin_amdgcn_readlane((int)wave_sort32(mn), LW - 1);
+                const u64 bound = ((u64)dL << 32) | 0xffffffffull;
+                if (bound < sel.tau) sel.tau = bound;
+              });
   }
   sel.finish();
   if (a.ablate & 8) {
