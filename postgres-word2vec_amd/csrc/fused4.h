@@ -926,7 +926,18 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     WaveSelect<1> sp;
     sp.init(stage_all[MANY ? wave : 0], KEY_INF, LW);
     uint32_t fs = 0u;
-    sweep([&](u64 kk, bool v, int) { if (v) fs |= (uint32_t)kk; sp.push(kk, v); }, wave * PB, NWV * PB);
+    // (every wave takes 1 / NWV of the regions: in blocks of PB = 256, a slice of 490 regions kept two of the twelve waves busy
+    // for 12 us and the other ten idle)
+    {
+      auto sink1 = [&](u64 kk, bool v, int) { if (v) fs |= (uint32_t)kk; sp.push(kk, v); };
+      const int chunk = (R + NWV - 1) / NWV;
+      if (chunk <= PB) {
+        const int j0 = wave * chunk;
+        if (j0 < R) dense_block(sink1, j0, R - j0 < chunk ? R - j0 : chunk, no_pre);
+      } else {
+        sweep(sink1, wave * PB, NWV * PB);
+      }
+    }
     sp.finish();
     part_key[MANY ? wave : 0][lane] = sp.acc[0];
     part_flag[MANY ? wave : 0][lane] = fs;
@@ -960,16 +971,18 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     }
     return;
   }
-
   WaveSelect<1> sel;
   sel.init(stage, KEY_INF, LW);
   uint32_t flag_seen = 0u;
   if (MANY && split1) {
+    // (the waves' selections are ascending lists: merged without re-sorting them)
+    sel.acc[0] = part_key[0][lane];
+    flag_seen |= part_flag[0][lane];
 #pragma unroll
-    for (int w = 0; w < (MANY ? NWV : 1); ++w) {
+    for (int w = 1; w < (MANY ? NWV : 1); ++w) {
       const u64 kk = part_key[w][lane];
       flag_seen |= part_flag[w][lane];
-      sel.push(kk, kk != KEY_INF);
+      if (__ballot(kk != KEY_INF) != 0ull) wave_topk_absorb_sorted<1>(sel.acc, kk);
     }
   } else {
     // (a lone wave is bound by instruction issue, and a streaming selection that starts without a threshold pays a 64-bit
@@ -1003,7 +1016,6 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     T_bits = (kth == KEY_INF || (a.ablate & 32)) ? 0xfffffffeu : widen_threshold((uint32_t)(kth >> 32), E);   // (32: tests, every row)
   }
   __builtin_amdgcn_wave_barrier();
-
   // ---- pass 2: exact distances of the rows with d_lo <= T (and of the flagged ones) ----
   WaveSelect<1> sel2;
   sel2.init(stage, KEY_INF, a.L);
