@@ -197,7 +197,7 @@ def run_dry(a, rank, world):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(headline(out)), flush=True)
     return 0 if ok else 1
 
 
@@ -243,6 +243,125 @@ def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
         r.update(extra)
     return r
 
+
+# ---------------------------------------------------------------------------------------------------
+# What the driver reads: the LAST stdout line, kept under 1900 bytes (its tail is 2000 characters; round 4's 21 KB line was
+# cut and the record lost the metric).  Everything else goes ONCE into bench_details.json beside this file (and into
+# gpurun_out/ when that exists, so it comes back from the GPU box) and, as bare numbers, onto an EARLIER stdout line.
+# ---------------------------------------------------------------------------------------------------
+HEADLINE_MAX_BYTES = 1900
+DIGEST_MAX_BYTES = 5000
+_CONFIG_KEYS = ("workload", "N", "d", "C", "m", "K", "nprobe", "k", "Q", "targets", "batch", "batch_per_gpu", "parallelism", "world_size",
+                "backend", "batches_in_flight", "recall_at_5")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us",
+              "survey_8d_step_frac", "serial_ms_per_step", "host_abi_q1024_qps")
+_CPU_KEYS = ("value", "unit", "cores", "value_1_core", "kind", "sample", "parity_with_gpu_on_sample", "queries_checked")
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+def headline(out):
+    """The contract line: metric / value / config{workload...} / roofline / cpu_baseline and nothing that is prose."""
+    if not isinstance(out, dict):
+        return out
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out.get(k) for k in top}
+    line["dtype"] = _short((line["dtype"] or "f32").split(" ")[0], 16)
+    cfg = out.get("config") or {}
+    line["config"] = {k: (_short(cfg[k], 200) if k == "workload" else cfg[k]) for k in _CONFIG_KEYS if k in cfg}
+    roof = out.get("roofline")
+    if roof is None:
+        line["roofline"] = None
+    else:
+        r = {k: roof.get(k) for k in _ROOF_KEYS if k in roof}
+        step = roof.get("step") or {}
+        if "serial_ms_per_step" in step:
+            r["serial_ms_per_step"] = step["serial_ms_per_step"]
+        q1024 = (roof.get("host_buffer_abi") or {}).get("Q1024") or {}
+        if q1024.get("queries_per_s") is not None:
+            r["host_abi_q1024_qps"] = q1024["queries_per_s"]
+        line["roofline"] = r
+    cpu = out.get("cpu_baseline")
+    if cpu is None:
+        line["cpu_baseline"] = None
+    else:
+        c = {k: (_short(cpu[k], 120) if k == "sample" else cpu[k]) for k in _CPU_KEYS if k in cpu}
+        tp = cpu.get("timed_region_parity") or {}
+        if "queries_checked" in tp:
+            c["queries_checked"] = tp["queries_checked"]
+        line["cpu_baseline"] = c
+    for k in ("dry_run", "gather_verified", "filter_bound_violations"):
+        if k in out:
+            line[k] = out[k]
+    line["details"] = "bench_details.json"
+    # never over the limit: shorten the two strings first, then drop optional keys
+    for cut in (120, 60):
+        if len(json.dumps(line)) <= HEADLINE_MAX_BYTES:
+            break
+        line["config"]["workload"] = _short(line["config"].get("workload"), cut)
+        if line.get("cpu_baseline"):
+            line["cpu_baseline"]["sample"] = _short(line["cpu_baseline"].get("sample"), cut)
+    for k in ("details", "filter_bound_violations", "gather_verified"):
+        if len(json.dumps(line)) > HEADLINE_MAX_BYTES:
+            line.pop(k, None)
+    assert len(json.dumps(line)) <= HEADLINE_MAX_BYTES, len(json.dumps(line))
+    return line
+
+
+def _numbers_only(o, depth=0):
+    """A digest of a measurement object: numbers, booleans and short identifiers; no prose."""
+    if isinstance(o, dict):
+        r = {}
+        for k, v in o.items():
+            if k in ("note", "loop", "sample", "algorithmic_model", "traffic_source", "survey_8d_note", "parity_scope", "measurement_order",
+                     "process", "timing", "recall", "metric", "workload", "unit", "peak", "bound", "higher_is_better", "data", "dtype",
+                     "vs_baseline", "scaling", "hbm_counter", "lds_gather", "per_query_model", "timed_region", "kernels", "kernels_us",
+                     "kernels_overlapped", "track", "config", "flops", "index_bytes", "pin_seconds"):
+                continue
+            v = _numbers_only(v, depth + 1)
+            if v is not None and v != {}:
+                r[k] = v
+        return r
+    if isinstance(o, (bool, int, float)):
+        return o
+    if isinstance(o, str) and len(o) <= 40:
+        return o
+    return None
+
+
+def digest(out):
+    d = {"bench_digest": {k: _numbers_only(out[k]) for k in ("pipelining", "host_buffer_abi", "other_configs", "timed_region_parity")
+                          if isinstance(out.get(k), dict)}}
+    for drop in ("timed_region_parity", "pipelining"):
+        if len(json.dumps(d)) > DIGEST_MAX_BYTES:
+            d["bench_digest"].pop(drop, None)
+    if len(json.dumps(d)) > DIGEST_MAX_BYTES:   # still too long: keep value / ms_per_step / frac per config
+        oc = d["bench_digest"].get("other_configs") or {}
+        d["bench_digest"]["other_configs"] = {c: {k: v for k, v in o.items() if k in ("value", "ms_per_step", "error", "Q1", "Q64")}
+                                              for c, o in oc.items()}
+    return d if len(json.dumps(d)) <= DIGEST_MAX_BYTES else None
+
+
+def emit(out):
+    """Details into bench_details.json (once), a digest line, then the headline as the LAST stdout line."""
+    if not isinstance(out, dict):
+        print(json.dumps(out), flush=True)
+        return
+    out.pop("_exact", None)
+    blob = json.dumps(out, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                    f.write(blob + "\n")
+            except OSError as e:
+                print(f"[bench] could not write {d}/bench_details.json: {e}", file=sys.stderr)
+    dg = digest(out)
+    if dg and dg["bench_digest"]:
+        print(json.dumps(dg), flush=True)
+    print(json.dumps(headline(out)), flush=True)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -602,8 +721,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             roof["survey_8d_note"] = ("whole-step rate in SURVEY 8d's per-QUERY bytes (every probed row once per query) / 8 TB/s; can "
                                       "approach or exceed 1 because a list is read once for up to 16 queries of its cell, as freddy.c:939-974 does")
             roof["step"] = {"ms_per_step": round(1e3 * dt / a.steps, 4), "serial_ms_per_step": serial_ms, "batches_in_flight": n_fl}
-            roof["host_buffer_abi"] = dict(abi_brief, note="freddy_gpu_ivfadc_search (pageable host buffers, one synchronous call per batch: "
-                                                           "what pg/freddy_srf.c makes), measured in a child process; PCIe-inclusive, never `value`")
+            roof["host_abi_q1024_qps"] = (abi_brief.get("Q1024") or {}).get("queries_per_s")   # (PCIe-inclusive; never `value`; all sizes: host_buffer_abi)
         if cpu is not None:
             cpu["timed_region_parity"] = timed_parity
             cpu["filter_bound_violations"] = bound_violations
@@ -764,22 +882,41 @@ def run_join(a, rank, world, dev, dev_index):
     index = gpu.IVPQIndex(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"], device=dev_index)
     rng = np.random.default_rng(4)
     qid = rng.choice(np.arange(1, N + 1), Q, replace=False)
-    targets = rng.choice(np.arange(1, N + 1), T, replace=False).astype(np.int32)
+    # THREE different target arrays, taken in turn: the library keeps the resolution of the last call's "fq.id IN (targets)"
+    # (join.h: mark / offsets / place kernels + the 400 KB upload) and a call with the same array finds its buckets in place.
+    # The reference resolves the array on every call (ivpq_search_in.c:357-395), so `value` is the COLD figure -- no step of the
+    # timed region repeats its predecessor's array; the repeated-array figure is reported beside it (cached_targets).
+    target_sets = [rng.choice(np.arange(1, N + 1), T, replace=False).astype(np.int32) for _ in range(3)]
     qs = t["vectors"][qid - 1]
     alpha, pvf, method = 100, 20, 2
+    n_call = [0]
+
+    def call(cached=False):
+        tg = target_sets[0] if cached else target_sets[n_call[0] % 3]
+        n_call[0] += 1
+        return (tg,) + tuple(index.knn_join(qs, a.k, tg, alpha, pvf, method))
+
     for _ in range(max(a.warmup, 1)):
-        gi, gd, it = index.knn_join(qs, a.k, targets, alpha, pvf, method)
+        call()
     track = None
     step_s = []
     t0 = time.perf_counter()
     for _ in range(a.steps):
         t1 = time.perf_counter()
-        gi, gd, it = index.knn_join(qs, a.k, targets, alpha, pvf, method)
+        targets, gi, gd, it = call()
         step_s.append(time.perf_counter() - t1)
         tr = index.last_track()
         track = tr if track is None else {n: track[n] + tr[n] for n in tr}
     dt = time.perf_counter() - t0
-    med = float(np.median(step_s))   # (a host hiccup -- one 66 ms step among twenty of 0.9 ms was seen in the combined run -- must not set the figure)
+    med = float(np.median(step_s))   # (a host hiccup -- one 66 ms step among twenty of 0.9 ms was seen in the combined run -- must not set the median)
+    mean = dt / a.steps
+    call(cached=True)
+    call(cached=True)
+    cached_s = []
+    for _ in range(a.steps):
+        t1 = time.perf_counter()
+        call(cached=True)
+        cached_s.append(time.perf_counter() - t1)
     track = {n: (v / a.steps) for n, v in track.items()}
     kernel_s = track["join_kernel_time"]
     rows = track["candidate_rows"]
@@ -793,7 +930,7 @@ def run_join(a, rank, world, dev, dev_index):
                     {"candidate_rows_per_call": int(rows), "iterations": track["iterations"], "dispatches_per_call": n_disp,
                      "traffic_per_dispatch": per_dispatch,
                      "note": "the call is a host loop (alpha doubling, multi-index traversal in libm on the host cores): "
-                             "the kernel is " + f"{100 * kernel_s / med:.0f} % of a call"})
+                             "the kernel is " + f"{100 * kernel_s / mean:.0f} % of a call"})
     from oracle.oracle import Oracle
     o = Oracle()
     ot = o.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])
@@ -804,9 +941,12 @@ def run_join(a, rank, world, dev, dev_index):
                   np.array_equal(exp["dist"].reshape(gd.shape).view(np.uint32), gd.view(np.uint32)) and eit == it)
     return {
         "metric": "kNN-join queries/sec (ivpq_search_in, 5000 x 100000, k=5, alpha=100, pvf=20, method 2)",
-        "value": round(Q / med, 1), "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(1e3 * med, 4), "mean_ms_per_step": round(1e3 * dt / a.steps, 4), "slowest_step_ms": round(1e3 * max(step_s), 3),
-        "timing": "median over the steps (one synchronous call each)",
+        "value": round(Q / mean, 1), "unit": "queries/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(1e3 * mean, 4), "median_ms_per_step": round(1e3 * med, 4), "slowest_step_ms": round(1e3 * max(step_s), 3),
+        "cached_targets": {"mean_ms_per_step": round(1e3 * float(np.mean(cached_s)), 4), "median_ms_per_step": round(1e3 * float(np.median(cached_s)), 4),
+                           "note": "every call repeats ONE target array: the library finds the array's buckets in place (not what the reference does per call)"},
+        "timing": "value / ms_per_step = total time of the timed region / steps (mean), one synchronous call per step, no step with the target "
+                  "array of its predecessor (three arrays in turn: the resolution of fq.id IN (targets) is inside every step); median beside it",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"knn_join (ivpq_search_in): {Q} queries x {T} targets of {N} rows, k={a.k}, alpha={alpha}, "
@@ -960,32 +1100,12 @@ def main():
                     torch.cuda.empty_cache()
                     o = fn(b, rank, world, dev, dev_index)
                     other[cfg] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline",
-                                                    "single_query_host_abi_ms", "single_query", "track", "kernels") if k in o}
+                                                    "single_query_host_abi_ms", "single_query", "track", "kernels", "median_ms_per_step", "cached_targets", "timing") if k in o}
                 except Exception as e:   # the headline line must not be lost to a side measurement
                     other[cfg] = {"error": f"{type(e).__name__}: {e}"}
             if out is not None and out.get("_exact") is not None:
                 other["exact"] = out.pop("_exact")
             out["other_configs"] = other
-            # a digest inside `roofline` (an object the driver keeps whole)
-            if out.get("roofline") is not None:
-                dig = {}
-                for cfg, o in other.items():
-                    if "error" in o:
-                        dig[cfg] = o
-                    elif cfg == "exact":
-                        dig[cfg] = {q: {"queries_per_s": o[q]["value"], "ms_per_call": o[q]["ms_per_call"], "kernel": o[q]["roofline"]["kernel"],
-                                        "hbm_frac": o[q]["roofline"]["frac"], "tflops": o[q]["roofline"]["flops"]["achieved_tflops"]} for q in ("Q1", "Q64")}
-                        dig[cfg]["cpu_queries_per_s"] = o["cpu_baseline"]["value"]
-                        dig[cfg]["parity"] = o["cpu_baseline"]["parity_with_gpu_on_sample"]
-                    else:
-                        dig[cfg] = {"value": o.get("value"), "unit": o.get("unit"), "ms_per_step": o.get("ms_per_step"),
-                                    "kernel": (o.get("roofline") or {}).get("kernel"), "hbm_frac": (o.get("roofline") or {}).get("frac"),
-                                    "traffic": (o.get("roofline") or {}).get("traffic"),
-                                    "cpu_queries_per_s": (o.get("cpu_baseline") or {}).get("value"),
-                                    "parity": (o.get("cpu_baseline") or {}).get("parity_with_gpu_on_sample")}
-                        if "single_query_host_abi_ms" in o:
-                            dig[cfg]["single_query_ms"] = o["single_query_host_abi_ms"]
-                out["roofline"]["other_configs"] = dig
     elif a.config == "pq":
         out = run_pq(a, rank, world, dev, dev_index)
     elif a.config == "exact":
@@ -996,9 +1116,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        if isinstance(out, dict):
-            out.pop("_exact", None)
-        print(json.dumps(out), flush=True)
+        emit(out)
 
 
 if __name__ == "__main__":

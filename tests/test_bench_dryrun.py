@@ -2,6 +2,7 @@
 (no torchrun environment given), shard the batch, run its double-buffered asynchronous gather
 (freddy_amd.shard.PipelinedGather, gloo here, RCCL on the GPU box) and print one JSON line with n_gpus = 2.
 The search itself is stood in by a (rank, step) pattern -- this is about the distributed plumbing."""
+import copy
 import json
 import os
 import subprocess
@@ -17,9 +18,9 @@ def _run(*args):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=env,
                        timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout
-    return json.loads(lines[0])
+    last = p.stdout.rstrip("\n").splitlines()[-1]
+    assert len(last.encode()) < 2000, len(last)      # the driver keeps a 2000-character tail (BENCH_r04: a 21 KB line -> parsed: null)
+    return json.loads(last)
 
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
@@ -61,3 +62,63 @@ def test_pipelined_gather_detects_a_wrong_slot():
     pg.submit()
     pg.drain()
     assert bench.verify_gather(pg, 0, 1)
+
+
+def _record():
+    """Round 4's committed full record in the shape main() builds now (the duplicates inside `roofline` are gone)."""
+    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_h_bench_20steps.json")))
+    abi = rec["roofline"].pop("host_buffer_abi")
+    rec["roofline"].pop("other_configs")
+    rec["roofline"]["host_abi_q1024_qps"] = abi["Q1024"]["queries_per_s"]
+    return rec
+
+
+def _worst_case_record():
+    """A full measurement record as run_ivfadc / main() build it: round 4's committed one (21 KB on one line) with every string
+    field inflated, so the size guard is tested against more than any real run produces."""
+    rec = _record()
+    rec["config"]["workload"] *= 3
+    rec["cpu_baseline"]["sample"] *= 4
+    rec["dtype"] *= 2
+    rec["other_configs"]["more"] = copy.deepcopy(rec["other_configs"])
+    return rec
+
+
+def test_headline_is_what_the_driver_can_keep():
+    """the LAST stdout line must parse, stay under 2000 bytes and carry the metric, roofline.frac and
+    cpu_baseline.value; the details go to bench_details.json and a digest line of at most 5 KB, each once."""
+    sys.path[:0] = [ROOT]
+    import bench
+    rec = _worst_case_record()
+    line = json.dumps(bench.headline(rec))
+    assert len(line.encode()) <= bench.HEADLINE_MAX_BYTES < 2000
+    got = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in got, k
+    assert got["value"] == rec["value"] and got["ms_per_step"] == rec["ms_per_step"]
+    assert got["config"]["workload"].startswith("IVFADC batch") and got["config"]["recall_at_5"] == rec["config"]["recall_at_5"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us"):
+        assert got["roofline"][k] == rec["roofline"][k], k
+    for k in ("value", "unit", "cores", "kind", "value_1_core", "parity_with_gpu_on_sample"):
+        assert got["cpu_baseline"][k] == rec["cpu_baseline"][k], k
+    assert got["cpu_baseline"]["queries_checked"] == rec["cpu_baseline"]["timed_region_parity"]["queries_checked"]
+    assert "other_configs" not in got and "host_buffer_abi" not in got and "other_configs" not in got["roofline"]
+    dg = bench.digest(rec)
+    assert dg is None or len(json.dumps(dg).encode()) <= bench.DIGEST_MAX_BYTES
+
+
+def test_emit_prints_the_headline_last_and_the_details_once(tmp_path, monkeypatch, capsys):
+    sys.path[:0] = [ROOT]
+    import bench
+    rec = _record()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.mkdir(tmp_path / "gpurun_out")
+    bench.emit(rec)
+    lines = capsys.readouterr().out.rstrip("\n").splitlines()
+    assert len(lines) == 2 and all(len(l.encode()) <= bench.DIGEST_MAX_BYTES for l in lines)
+    last = json.loads(lines[-1])
+    assert len(lines[-1].encode()) < 2000 and last["roofline"]["frac"] == rec["roofline"]["frac"] and last["cpu_baseline"]["value"] > 0
+    assert "bench_digest" in json.loads(lines[0])
+    for d in (tmp_path, tmp_path / "gpurun_out"):
+        full = json.load(open(d / "bench_details.json"))
+        assert full["other_configs"].keys() == rec["other_configs"].keys() and "other_configs" not in full["roofline"]
