@@ -1,4 +1,4 @@
-// coarse.h -- coarse-cell selection (a6 / a7) as FILTER + REFINE, like the scan of fused4.h.
+// coarse.h -- coarse-cell selection (a6 / a7) as FILTER + REFINE, like the scan of fused5.h.
 //
 // The reference computes squareDistance(q, cq[j], d) for EVERY (query, cell) pair (freddy.c:272-283, :855-866):
 // Q*C*d separately rounded sub / mul / add triples (0.92 G lane-operations per 1024-query batch, 28-34 us as
@@ -29,7 +29,7 @@
 
 #include "kernels.h"
 #include "wave_topk.h"
-#include "fused4.h"   // item_bounds, filter_width5: the record fields of the scan's DIRECT mode are written by the plan
+#include "refine.h"
 
 namespace freddy {
 
@@ -353,14 +353,6 @@ struct Plan2Args {
   int d;
   int refine_all;           // tests: every unused cell is refined (exhaustive check of the bracket)
   long long* prof;          // NULL, or [queries][16] cycle sums per phase of wave 0 (tools/ubench_plan)
-  // DIRECT mode of the integer-slab scan (fused5.h): the record fields of every item go straight into the static slot
-  // (cell, item number / 16) -- no work-table and no record kernel between this kernel and the scan
-  int32_t* drecs;           // [C][submax][144] or NULL
-  const float* qn;          // [Q][12] |q_p| (table units of the launch before)
-  const float* qscale;      // [Q]
-  const float* pmax;        // [12]
-  int submax;
-  float sentinel;
   // STREAM, first round: the minima of the (query, 128-cell tile) blocks (coarse_approx_body) -- NULL: every cell is read twice
   const float* tmin;        // [Q][Cpad / 128]
 };
@@ -734,19 +726,6 @@ __global__ __launch_bounds__(64 * NWP, NWP == 1 ? 4 : 4) void probe_plan2_kernel
     if (a.cell_count) {
       const int at = atomicAdd(a.cell_count + c_slot, 1);
       a.cell_items[(size_t)c_slot * a.cell_cap + at] = x * W + lane;
-      if (g.drecs) {   // what entry_record5_kernel writes for an item, at [field + item number mod 16] of the slot
-        const float sc = g.qscale[q];
-        const ItemBounds ib = item_bounds(d_slot, filter_width5<12>(g.qn + (size_t)q * 12, g.pmax, sc), g.sentinel);
-        int32_t* rec = g.drecs + ((size_t)c_slot * g.submax + (size_t)(at >> 4)) * 144 + (at & 15);
-        rec[8] = x * W + lane;
-        rec[24] = q;
-        rec[40] = (int32_t)__float_as_uint(ib.off);
-        rec[56] = (int32_t)__float_as_uint(ib.e);
-        rec[72] = (int32_t)__float_as_uint(ib.shift);
-        rec[88] = (int32_t)ib.lo_bits;
-        rec[104] = (int32_t)ib.hi_bits;
-        rec[128] = (int32_t)__float_as_uint(sc < 1e30f ? sc : 0.0f);
-      }
     }
   }
   const bool any_cell = __ballot(have) != 0ull;

@@ -65,47 +65,35 @@ extern "C" const char* freddy_gpu_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------
 enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3, KIND_VEC = 4 };
 
-// Tuning / debug switches.  Read from the environment ONCE, when an index is pinned (never on the search
-// path); freddy_gpu_set_option changes them on a pinned index (tests and tools).  None of them is needed
-// for results: every setting gives the same lists.
+// Options.  Read from the environment ONCE, when an index is pinned (never on the search path); freddy_gpu_set_option
+// changes them on a pinned index.  None of them changes a result: every setting gives the same lists.  The first group
+// is for deployments, the second selects the alternative paths the tests compare with each other (every one of them has a
+// GPU test), the third the self-checks.  (INTEGRATION.md lists them; timing experiments of earlier rounds are gone --
+// profiles/HISTORY.md has their numbers.)
 struct Tuning {
-  int fused = -1;              // FREDDY_GPU_FUSED: -1 auto (cell-grouped scans for >= 256 items), 0 generic kernels, 1 always
-  int scan_kernel = 5;         // FREDDY_GPU_FUSED_KERNEL: 5 filter + refine, int16 slabs (fused5.h), 4 the same with fp32 slabs (fused4.h), 3 exact fused scan (fused3.h)
-  uint32_t scan_ablate = 0;    // FREDDY_GPU_FUSED_ABLATE: timing experiments / 8 = keep every row (tests)
-  uint32_t merge_ablate = 0;   // FREDDY_GPU_MERGE_ABLATE: timing experiments / 32 = refine every row (tests)
-  int coarse_approx = 1;       // FREDDY_GPU_COARSE_APPROX: cell selection as filter + refine (coarse.h); 0 = every distance exact
-  int coarse_refine_all = 0;   // tests: refine every cell (exhaustive check of the coarse bracket)
-  int qc_first = 1;            // FREDDY_GPU_QC_FIRST: 1 = the query x codebook table is forked BEFORE the coarse kernel (beside it), 0 = after it
-  int side_stream = 1;         // FREDDY_GPU_SIDE_STREAM: query x codebook table beside the coarse kernel
-  int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams
-  int plan_waves = 0;          // FREDDY_GPU_PLAN_WAVES: waves per query of the cell-selection plan: 0 = four for one batch at a time, one with batches in flight (scan_share > 1); 4 = always four
-  int one_launch = 1;          // FREDDY_GPU_ONE_LAUNCH: a single pq_search query through the host-buffer call as ONE launch (one.h) instead of three
-  int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
-  int merge_waves = 0;         // FREDDY_GPU_MERGE_WAVES: waves per query in merge_refine_kernel: 4, 1, or 0 = four for one batch at a time, one with batches in flight
+  // -- deployment
   int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches the CALLER keeps in flight on this handle through the *_dev entry points
                                // (one stream each): a persistent scan takes n_cus / share CUs so that the scans run side by side (DESIGN.md
-                               // 5.2c).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
+                               // 5.1).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
+  int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams (RCCL beside the scans)
   int pipeline_batch = 2048;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
-  int scan_quota = 0;          // FREDDY_GPU_SCAN_QUOTA: work entries a quota-limited scan workgroup takes before it leaves its CU (0 = every workgroup persistent)
-  int fuse_table = 1;          // FREDDY_GPU_FUSE_TABLE: the MFMA cell-selection distances and the query x codebook table as ONE launch (heterogeneous workgroups)
-  int sparse_pairs = 1;        // FREDDY_GPU_SPARSE_PAIRS: the item-wise scan reads a cell that exactly two queries probe once for both (sparse5.h NI = 2)
-  int sparse_items = 2;        // FREDDY_GPU_SPARSE_ITEMS: cells that at most this many queries of a batch probe are scanned item by item (sparse5.h) instead of as cell-grouped work entries (0 = never)
-  int scan_quota_wgs = 0;      // FREDDY_GPU_SCAN_QUOTA_WGS: number of quota-limited workgroups in front of the persistent ones (0 = from the batch's size)
-  int pipe_trace = 0;          // FREDDY_GPU_PIPE_TRACE: host timestamps of the pipeline's steps on stderr
-  int partition_cus = 0;       // FREDDY_GPU_PARTITION_CUS: R > 0 = CU-masked streams: the cell selection / table / merge kernels of a batch run on
-                               // R CUs (R / 8 per XCD), the persistent scan on the other n_cus - R; 0 = everything on the caller's stream
-  int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF: per-phase cycle sums of the scan kernel on stderr
-  int debug_surv = 0;          // FREDDY_GPU_DEBUG_SURV: survivor statistics on stderr
-  int direct = 0;              // FREDDY_GPU_DIRECT: the integer-slab scan claims static (cell, chunk) units and reads record slots the probe plan filled --
-                               // no work-table / record kernels in a batch's chain (fused5.h): 0 never (the default: measured no faster, profiles/HISTORY.md
-                               // round 4), -1 = dense first rounds, 1 whenever possible
+  int64_t lut_budget_mb = 8192;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit); 288 GB of HBM: 8 GiB = 12 800 queries at nprobe 10
+  // -- path selection (tests)
+  int fused = -1;              // FREDDY_GPU_FUSED: -1 auto (cell-grouped scans for >= 256 items), 0 generic kernels, 1 always
+  int scan_kernel = 5;         // FREDDY_GPU_FUSED_KERNEL: 5 filter + refine on int16 slabs (fused5.h), 3 the reference's arithmetic for every row (fused3.h)
+  int coarse_approx = 1;       // FREDDY_GPU_COARSE_APPROX: cell selection as filter + refine (coarse.h); 0 = every distance exact
+  int one_launch = 1;          // FREDDY_GPU_ONE_LAUNCH: a single query through the host-buffer calls as ONE launch (one.h) instead of a chain
+  int pq_fused = -1;           // FREDDY_GPU_PQ_FUSED: batches over the flat PQ table through the cell-grouped filter + refine scan: -1 = from 16 queries on, 0 never, 1 always
+  int sparse_items = 2;        // FREDDY_GPU_SPARSE_ITEMS: cells that at most this many queries of a batch probe are scanned item by item (sparse5.h) instead of as cell-grouped work entries (0 = never, < 0 = always for cells of up to that many items)
   int codes_u8 = 1;            // FREDDY_GPU_CODES_U8: K <= 256: the integer-slab scans read one byte per code (packed8, 16 instead of 28 B per row); 0 = the int16 layout
   int exact_filter = -1;       // FREDDY_GPU_EXACT_FILTER: exact kNN as MFMA filter + exact refine (exact2.h): -1 auto (tables of >= 8192 rows, k <= 32), 0 never, 1 always
-  int exact_refine_all = 0;    // tests: every row is refined (exhaustive check of the similarity bracket)
-  int arrange_rows = 1;        // FREDDY_GPU_ARRANGE_ROWS (pin time): rows of a list arranged against LDS bank conflicts
-  int64_t lut_budget_mb = 8192;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit); 288 GB of HBM: 8 GiB = 12 800 queries at nprobe 10
-  int64_t filter_table_mb = 8192;    // FREDDY_GPU_FILTER_TABLE_MB (pin time): 0 = no filter + refine tables
+  // -- self-checks (tests): bit 0 = the scan keeps every row and the merge refines every row (every probed row's bracket is checked),
+  //    bit 1 = the cell selection refines every cell, bit 2 = exact kNN refines every row
+  int check_brackets = 0;
+#ifdef FREDDY_LAB
+  int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF (lab builds only): per-phase cycle sums of the scan kernel on stderr
+#endif
 };
 static int64_t env_int(const char* name, int64_t dflt) {
   const char* e = getenv(name);
@@ -115,34 +103,20 @@ static Tuning read_tuning() {
   Tuning t;
   t.fused = (int)env_int("FREDDY_GPU_FUSED", t.fused);
   t.scan_kernel = (int)env_int("FREDDY_GPU_FUSED_KERNEL", t.scan_kernel);
-  t.scan_ablate = (uint32_t)env_int("FREDDY_GPU_FUSED_ABLATE", 0);
-  t.merge_ablate = (uint32_t)env_int("FREDDY_GPU_MERGE_ABLATE", 0);
-  t.side_stream = (int)env_int("FREDDY_GPU_SIDE_STREAM", 1);
   t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
-  t.partition_cus = (int)env_int("FREDDY_GPU_PARTITION_CUS", t.partition_cus);
   t.scan_share = (int)std::max<int64_t>(1, env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share));
-  t.merge_waves = (int)env_int("FREDDY_GPU_MERGE_WAVES", t.merge_waves);
   t.pipeline_batch = (int)std::max<int64_t>(16, env_int("FREDDY_GPU_PIPELINE_BATCH", t.pipeline_batch));
   t.pipeline_lanes = (int)std::min<int64_t>(4, std::max<int64_t>(1, env_int("FREDDY_GPU_PIPELINE_LANES", t.pipeline_lanes)));
   t.pq_fused = (int)env_int("FREDDY_GPU_PQ_FUSED", t.pq_fused);
   t.one_launch = (int)env_int("FREDDY_GPU_ONE_LAUNCH", t.one_launch);
-  t.plan_waves = (int)env_int("FREDDY_GPU_PLAN_WAVES", t.plan_waves);
   t.coarse_approx = (int)env_int("FREDDY_GPU_COARSE_APPROX", 1);
-  t.qc_first = (int)env_int("FREDDY_GPU_QC_FIRST", 1);
-  t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
-  t.pipe_trace = (int)env_int("FREDDY_GPU_PIPE_TRACE", 0);
-  t.scan_quota = (int)env_int("FREDDY_GPU_SCAN_QUOTA", t.scan_quota);
-  t.scan_quota_wgs = (int)env_int("FREDDY_GPU_SCAN_QUOTA_WGS", t.scan_quota_wgs);
   t.sparse_items = (int)env_int("FREDDY_GPU_SPARSE_ITEMS", t.sparse_items);
-  t.sparse_pairs = (int)env_int("FREDDY_GPU_SPARSE_PAIRS", t.sparse_pairs);
-  t.fuse_table = (int)env_int("FREDDY_GPU_FUSE_TABLE", t.fuse_table);
-  t.debug_surv = getenv("FREDDY_GPU_DEBUG_SURV") != nullptr;
   t.exact_filter = (int)env_int("FREDDY_GPU_EXACT_FILTER", t.exact_filter);
-  t.direct = (int)env_int("FREDDY_GPU_DIRECT", t.direct);
   t.codes_u8 = (int)env_int("FREDDY_GPU_CODES_U8", t.codes_u8);
-  t.arrange_rows = (int)env_int("FREDDY_GPU_ARRANGE_ROWS", 1);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
-  t.filter_table_mb = env_int("FREDDY_GPU_FILTER_TABLE_MB", t.filter_table_mb);
+#ifdef FREDDY_LAB
+  t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
+#endif
   return t;
 }
 
@@ -169,34 +143,16 @@ struct Workspace {
   bool used = false;
   hipStream_t owner = nullptr;
   uint64_t last_use = 0;           // claim order (the slot a new stream takes over is the least recently used one)
-  hipStream_t stream2 = nullptr;   // side stream: the per-batch query x codebook table is built beside the coarse/plan kernels
-  hipEvent_t ev_q = nullptr, ev_qc = nullptr;
-  // CU-partitioned mode (Tuning::partition_cus): the batch's small kernels on a stream masked to the reserved CUs, its
-  // scan on a stream masked to the rest; events chain caller stream -> fe -> scan -> fe -> caller stream
-  hipStream_t fe_stream = nullptr, scan_stream = nullptr;
-  int part_cus = 0;                // the R the two streams were created for
-  hipEvent_t ev_in = nullptr, ev_fe = nullptr, ev_scan = nullptr, ev_out = nullptr;
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_drecs, w_tmin, w_one, w_oneb;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_tmin, w_one, w_oneb;
   uint64_t one_shape = 0;          // the one-launch kernels' buffer (w_oneb): shape of the call that wrote it last, and that call's epoch (one.h)
   uint32_t one_epoch = 0;
-  void release_partition() {
-    if (fe_stream) { (void)hipStreamSynchronize(fe_stream); (void)hipStreamDestroy(fe_stream); fe_stream = nullptr; }
-    if (scan_stream) { (void)hipStreamSynchronize(scan_stream); (void)hipStreamDestroy(scan_stream); scan_stream = nullptr; }
-    for (hipEvent_t* e : {&ev_in, &ev_fe, &ev_scan, &ev_out})
-      if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
-    part_cus = 0;
-  }
   void release() {
-    if (stream2) { (void)hipStreamSynchronize(stream2); (void)hipStreamDestroy(stream2); stream2 = nullptr; }
-    if (ev_q) { (void)hipEventDestroy(ev_q); ev_q = nullptr; }
-    if (ev_qc) { (void)hipEventDestroy(ev_qc); ev_qc = nullptr; }
-    release_partition();
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_drecs, &w_tmin, &w_one, &w_oneb};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -210,8 +166,7 @@ static constexpr int FREDDY_MAX_WS = 12;
 struct IvfRun {
   freddy_gpu_index* ix;
   Workspace* ws;
-  hipStream_t s;       // the stream the small kernels are enqueued on (the caller's, or the workspace's masked fe stream)
-  hipStream_t s_scan;  // the stream of the scan kernel (== s unless the CUs are partitioned)
+  hipStream_t s;       // the stream the search is enqueued on
   int share;           // batches in flight on this handle (the scan takes n_cus / share CUs)
   const float* d_q;
   int Q, k, W, L, found_rule, upi;
@@ -219,19 +174,16 @@ struct IvfRun {
   int32_t *d_out_ids, *d_status;
   float* d_out_dist;
   bool fused;          // cell-grouped scans (fused3.h / fused4.h) instead of lut_build + adc_scan
-  int scan_kernel;     // 4: filter + refine, 3: exact fused scan
+  int scan_kernel;     // 5: filter + refine, 3: exact fused scan
   bool tiled;          // batch coarse kernels (tiles of queries)
   bool zeroed;         // the coarse kernel has cleared the round-one scratch (ZeroArgs): no memsets in round one
   bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
-  bool qc_pending;     // the query x codebook table is being built on the side stream
-  bool direct;         // round one without work-table / record kernels (fused5.h DIRECT mode)
   bool records_ready;  // a batch over the flat PQ table: the entry records were written by pq_records_kernel (no work-table / record kernels)
   int merge_slices;    // > 0: the merge of such a batch as `merge_slices` partial merges per query + merge_replay_kernel
   // per round
   int n_active, round;
   const int32_t* active;
   int32_t* next;
-  hipStream_t s_caller; // the stream the search was enqueued on (results are complete on it after rejoin)
   bool first() const { return round == 0; }
 };
 
@@ -289,8 +241,6 @@ struct freddy_gpu_index {
   int32_t* blk_cell = nullptr;  // [blocks]   list of every row block
   int32_t* list_off = nullptr;  // [lists+1] rows
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
-  int32_t* scan_units = nullptr;  // IVF: [n_scan_units][4] static (cell, chunk) units of the scan's DIRECT mode, longest first
-  int n_scan_units = 0;
   uint32_t* packed = nullptr;   // [blocks][M2][64]
   uint32_t* packed8 = nullptr;  // K <= 256, m = 12: [blocks][3][64], one BYTE per code -- what the integer-slab scans read (16 B per row with its row term)
   bool packed8_own = false;     // (a PQ handle's view shares its owner's array)
@@ -418,7 +368,7 @@ static void free_index(freddy_gpu_index* ix) {
   }
   if (ix->pq_shadow) { free_index(ix->pq_shadow); ix->pq_shadow = nullptr; }
   if (ix->pq_sub_view) { free_index(ix->pq_sub_view); ix->pq_sub_view = nullptr; }
-  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->coarseH, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->cbF, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->scan_units, ix->packed8_own ? ix->packed8 : nullptr};
+  void* ptrs[] = {ix->xb, ix->coarse, ix->coarseT, ix->coarseP, ix->coarseH, ix->cn2, ix->cbT, ix->cbP, ix->cbR, ix->rterm, ix->pmax, ix->cmaxp, ix->cbF, ix->viol, ix->blk_cell, ix->list_off, ix->blk_off, ix->packed, ix->pos, ix->ids, ix->packed8_own ? ix->packed8 : nullptr};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   join_free(&ix->join);
   for (auto& kv : ix->prof)
@@ -503,7 +453,7 @@ static int pack_lists(freddy_gpu_index* ix, int n_lists, const int32_t* list_off
   std::vector<uint32_t> packed((size_t)std::max<int64_t>(n_blocks, 1) * M2 * 64, 0u);
   std::vector<int32_t> pos((size_t)std::max<int64_t>(n_blocks, 1) * 64, -1);
   // (inverted lists only: the flat PQ table is addressed by row index)
-  const bool arrange = row_pos != nullptr && ix->tune.arrange_rows != 0;
+  const bool arrange = row_pos != nullptr;
   std::vector<std::vector<int64_t>> orders(arrange ? (size_t)n_lists : 0);
   if (arrange) {
     std::atomic<int> next_list{0};
@@ -579,37 +529,6 @@ static int build_packed8(freddy_gpu_index* ix) {
   return 0;
 }
 
-// The scan's DIRECT mode (fused5.h): one unit per (cell, 4096-row chunk) of every non-empty list, longest first -- what the
-// work table's longest-processing-time order is made of when every cell holds items.  (Re)built whenever the lists change.
-static int build_scan_units(freddy_gpu_index* ix) {
-  const int C = ix->C;
-  if (ix->scan_units) { (void)hipFree(ix->scan_units); ix->scan_units = nullptr; ix->n_scan_units = 0; }
-  if (C <= 0 || C >= (1 << 24) || (int)ix->h_list_off.size() != C + 1) return 0;
-  struct U { int32_t w[4]; int rows; };
-  std::vector<U> us;
-  int64_t b = 0;
-  for (int c = 0; c < C; ++c) {
-    const int64_t len = (int64_t)ix->h_list_off[(size_t)c + 1] - ix->h_list_off[(size_t)c];
-    const int64_t nblk = (len + 63) / 64;
-    for (int64_t ch = 0; ch * FUSED_UNIT_BLOCKS < nblk; ++ch) {
-      if (ch > 255) return 0;   // (never: the cell-grouped scans take lists of <= 8 chunks)
-      const int nb = (int)std::min<int64_t>(FUSED_UNIT_BLOCKS, nblk - ch * FUSED_UNIT_BLOCKS);
-      const int rows = (int)std::min<int64_t>((int64_t)FUSED_UNIT_BLOCKS * 64, len - ch * FUSED_UNIT_BLOCKS * 64);
-      U u;
-      u.w[0] = c | (int32_t)((uint32_t)ch << 24); u.w[1] = (int32_t)(b + ch * FUSED_UNIT_BLOCKS); u.w[2] = nb | (rows << 8); u.w[3] = 0; u.rows = rows;
-      us.push_back(u);
-    }
-    b += nblk;
-  }
-  std::stable_sort(us.begin(), us.end(), [](const U& x, const U& y) { return x.rows > y.rows; });
-  std::vector<int32_t> flat(us.size() * 4);
-  for (size_t i = 0; i < us.size(); ++i) memcpy(&flat[i * 4], us[i].w, 16);
-  if (flat.empty()) return 0;
-  if (upload(&ix->scan_units, flat.data(), flat.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
-  ix->n_scan_units = (int)us.size();
-  return 0;
-}
-
 // Kernels that want more than the default 64 KiB of dynamic LDS: the limit is a per-device function
 // attribute, so it is raised once for every device an index is pinned on.
 static int raise_lds_limits(int device) {
@@ -622,15 +541,16 @@ static int raise_lds_limits(int device) {
       (const void*)&adc_scan_kernel<12, 8>, (const void*)&adc_scan_kernel<12, 16>, (const void*)&adc_scan_kernel<0, 1>,
       (const void*)&adc_scan_kernel<0, 2>, (const void*)&adc_scan_kernel<0, 4>, (const void*)&adc_scan_kernel<0, 8>,
       (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
-      (const void*)&ivf_spec2_kernel<25, 12, false>, (const void*)&ivf_filter_kernel<12, true>,
-      (const void*)&ivf_filter_kernel<12, false>, (const void*)&ivf_filter5_kernel<12, true, false>, (const void*)&ivf_filter5_kernel<12, true, false, true>,
-      (const void*)&ivf_filter5_kernel<12, false, false>, (const void*)&ivf_filter5_kernel<12, true, true>,
-      (const void*)&ivf_filter5_kernel<12, false, true>, (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
+      (const void*)&ivf_spec2_kernel<25, 12, false>,
+      (const void*)&ivf_filter5_kernel<12, true, false>, (const void*)&ivf_filter5_kernel<12, false, false>,
+      (const void*)&ivf_filter5_kernel<12, true, true>, (const void*)&ivf_filter5_kernel<12, false, true>,
+      (const void*)&ivf_filter5_kernel<12, false, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, true>,
+#ifdef FREDDY_LAB
+      (const void*)&ivf_filter5_kernel<12, true, false, true>,
+#endif
+      (const void*)&grouping_kernel<6>, (const void*)&grouping_kernel<15>,
       (const void*)&grouping_kernel<0>, (const void*)&coarse_approx_kernel, (const void*)&coarse_approx16_kernel, (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
       (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>,
-      (const void*)&ivf_filter5_kernel<12, false, false, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, false, true>,
-      (const void*)&ivf_filter5_kernel<12, true, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, false, false, true>,
-      (const void*)&ivf_filter5_kernel<12, true, true, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, true>,
       (const void*)&exf_filter_kernel<1, false>, (const void*)&exf_filter_kernel<2, false>, (const void*)&exf_filter_kernel<1, true>,
       (const void*)&exf_filter_kernel<2, true>};
   for (const void* k : kernels)
@@ -699,7 +619,7 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
   if (ix->kind == KIND_PQ) {
     // batches over the flat table take the cell-grouped filter + refine scan (pq_shadow_build): its codebook-derived tables,
     // with "centroids" that are zero
-    if (ix->m == 12 && ix->S == 25 && ix->K <= FUSED_T * FUSED_E && ix->tune.filter_table_mb > 0) {
+    if (ix->m == 12 && ix->S == 25 && ix->K <= FUSED_T * FUSED_E) {
       std::vector<float> cmaxp((size_t)ix->m);
       for (int p = 0; p < ix->m; ++p) {
         double cmax = 0.0;
@@ -738,7 +658,7 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
     if (upload(&ix->cbP, cbP.data(), cbP.size(), &ix->bytes)) return fail(FREDDY_E_NOMEM, "device allocation failed");
   }
   // filter + refine tables (fused4.h)
-  if (ix->cbP && ix->m == 12 && ix->S == 25 && ix->tune.filter_table_mb > 0) {
+  if (ix->cbP && ix->m == 12 && ix->S == 25) {
     std::vector<float> pmax((size_t)ix->m), cmaxp((size_t)ix->m);
     for (int p = 0; p < ix->m; ++p) {
       double comax = 0.0, cmax = 0.0;
@@ -915,7 +835,6 @@ extern "C" int freddy_gpu_pin_ivf(const freddy_ivf_desc* t, int device, freddy_g
     if (!rc) { ix->h_coarse.assign(t->coarse, t->coarse + (size_t)t->C * t->d); rc = derive_codebook_tables(ix, t->codebook); }
   }
   if (!rc) rc = pack_lists(ix, t->C, t->list_off, t->codes, t->ids);
-  if (!rc) rc = build_scan_units(ix);
   if (!rc) rc = build_packed8(ix);
   if (!rc) rc = refresh_row_terms(ix);   // one float per row slot: the (cell, row) part of the filter's cheap distance
   if (!rc) {
@@ -1056,35 +975,23 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   const std::string n(name);
   if (n == "fused") t.fused = (int)value;
   else if (n == "fused_kernel") t.scan_kernel = (int)value;
-  else if (n == "fused_ablate") t.scan_ablate = (uint32_t)value;
-  else if (n == "merge_ablate") t.merge_ablate = (uint32_t)value;
-  else if (n == "side_stream") t.side_stream = (int)value;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
-  else if (n == "partition_cus") t.partition_cus = (int)value;
   else if (n == "scan_share") t.scan_share = (int)std::max<int64_t>(1, value);
-  else if (n == "pipe_trace") t.pipe_trace = (int)value;
   else if (n == "join_host_traversal") ix->join.host_traversal = value != 0;
   else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
-  else if (n == "scan_quota") t.scan_quota = (int)value;
-  else if (n == "scan_quota_wgs") t.scan_quota_wgs = (int)value;
-  else if (n == "fuse_table") t.fuse_table = (int)value;
   else if (n == "sparse_items") t.sparse_items = std::max(-16, std::min(16, (int)value));
-  else if (n == "sparse_pairs") t.sparse_pairs = value != 0;
   else if (n == "pipeline_batch") t.pipeline_batch = (int)std::max<int64_t>(16, value);
   else if (n == "pipeline_lanes") t.pipeline_lanes = (int)std::min<int64_t>(FREDDY_LANES, std::max<int64_t>(1, value));
-  else if (n == "merge_waves") t.merge_waves = (int)value;
   else if (n == "pq_fused") t.pq_fused = (int)value;
   else if (n == "one_launch") t.one_launch = (int)value;
-  else if (n == "plan_waves") t.plan_waves = (int)value;
   else if (n == "coarse_approx") t.coarse_approx = (int)value;
-  else if (n == "coarse_refine_all") t.coarse_refine_all = (int)value;
-  else if (n == "fused_prof") t.scan_prof = (int)value;
-  else if (n == "debug_surv") t.debug_surv = (int)value;
+  else if (n == "check_brackets") t.check_brackets = (int)value;
   else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
   else if (n == "exact_filter") t.exact_filter = (int)value;
-  else if (n == "direct") t.direct = (int)value;
   else if (n == "codes_u8") t.codes_u8 = (int)value;
-  else if (n == "exact_refine_all") t.exact_refine_all = (int)value;
+#ifdef FREDDY_LAB
+  else if (n == "fused_prof") t.scan_prof = (int)value;
+#endif
   else return fail(FREDDY_E_ARG, "unknown option '%s'", name);
   return FREDDY_OK;
 }
@@ -1224,14 +1131,10 @@ static int ivf_coarse(IvfRun& r) {
     HIP_TRY(hipGetLastError());
     return 0;
   };
-  // The query x codebook table is independent of the coarse distances / probe plan / work table: it is built on
-  // the side stream and joined before the entry records need it.  Beside the MFMA coarse kernel (a few us) it
-  // would only delay it -- the kernel launched first gets the CUs -- so there it is forked AFTER the coarse
-  // kernel and runs beside the latency-bound plan / work-table kernels; the all-exact coarse kernel is long
-  // and VALU-bound like the table kernel, and the table beside it measured 2 % faster than after it.
-  r.qc_pending = false;
-  if (r.approx && r.fused && r.scan_kernel == 5 && ix->tune.fuse_table) {
-    // coarse tiles and table units as the workgroups of one launch (fused5.h coarse_table5_kernel)
+  // The query x codebook table is independent of the coarse distances: with the MFMA cell selection the coarse tiles and
+  // the table units are the workgroups of ONE launch (fused5.h coarse_table5_kernel); otherwise the table kernel runs in
+  // line before the coarse kernel.
+  if (r.approx && r.fused && r.scan_kernel == 5) {
     CoarseTableArgs ct;
     ct.queries = r.d_q; ct.coarseF = ix->coarseP; ct.cn2 = ix->cn2; ct.dist = ws->w_distT.as<float>(); ct.qn2 = ws->w_qn2.as<float>();
     ct.Q = Q; ct.Cpad = Cpad; ct.d = d; ct.dp = ix->dp; ct.z = za; ct.coarse_gx = Cpad / 128; ct.coarse_gy = (Q + COARSE_TQ - 1) / COARSE_TQ;
@@ -1247,40 +1150,14 @@ static int ivf_coarse(IvfRun& r) {
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  const bool coarse_first = r.approx && !ix->tune.qc_first;
-  if (coarse_first) if (int rc = launch_coarse()) return rc;
-  if (r.fused && r.scan_kernel >= 4) {
-    if (!ws->stream2) {
-      HIP_TRY(hipStreamCreateWithFlags(&ws->stream2, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&ws->ev_q, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&ws->ev_qc, hipEventDisableTiming));
-    }
-    // (only while ONE stream searches: the runtime maps streams onto four hardware queues, and a side stream per
-    // workspace ends up sharing an in-order queue with another batch's main stream -- measured: no overlap at all)
-    const bool side = ix->tune.side_stream != 0 && r.share == 1 && r.s_scan == r.s;
-    hipStream_t sq = side ? ws->stream2 : s;
-    if (side) {
-      HIP_TRY(hipEventRecord(ws->ev_q, s));
-      HIP_TRY(hipStreamWaitEvent(ws->stream2, ws->ev_q, 0));
-    }
-    if (r.scan_kernel == 5) {
-      timed_launch(ix, sq, "query_codebook", [&] {
-        hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbF, ix->cmaxp,
-                             ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
-      });
-    } else
-    timed_launch(ix, sq, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, sq, r.d_q, ix->cbT, ix->cmaxp,
-                         ws->w_qc.as<uint32_t>(), ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, Q, d, m, K);
+  if (r.fused && r.scan_kernel == 5) {
+    timed_launch(ix, s, "query_codebook", [&] {
+      hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, r.d_q, ix->cbF, ix->cmaxp,
+                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
     });
     HIP_TRY(hipGetLastError());
-    if (side) {
-      HIP_TRY(hipEventRecord(ws->ev_qc, ws->stream2));
-      r.qc_pending = true;
-    }
   }
-  if (!coarse_first) if (int rc = launch_coarse()) return rc;
-  return 0;
+  return launch_coarse();
 }
 
 // a7: the W nearest not-yet-used cells of every active query (+ their items appended to the cells' buckets)
@@ -1308,16 +1185,11 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
   if (r.approx) {
     Plan2Args g;
     g.p = pa; g.queries = r.d_q; g.coarse = ix->coarse; g.qn2 = ws->w_qn2.as<float>(); g.item_dist = pa.item_dist;
-    g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = ix->tune.coarse_refine_all; g.prof = nullptr;
-    g.drecs = nullptr; g.qn = nullptr; g.qscale = nullptr; g.pmax = nullptr; g.submax = 0; g.sentinel = r.sentinel;
+    g.violations = ix->viol; g.cmax = ix->cmax; g.d = ix->d; g.refine_all = (ix->tune.check_brackets & 2) ? 1 : 0; g.prof = nullptr;
     g.tmin = (r.first() && ix->Cpad > COARSE_MAX_CPAD && ws->w_tmin.p) ? ws->w_tmin.as<float>() : nullptr;
-    if (r.direct && r.first()) {
-      g.drecs = ws->w_drecs.as<int32_t>(); g.qn = ws->w_qn.as<float>(); g.qscale = ws->w_qn.as<float>() + (size_t)r.Q * ix->m;
-      g.pmax = ix->pmax; g.submax = (r.n_active + SCAN5_G - 1) / SCAN5_G;
-    }
     timed_launch(ix, s, "probe_plan", [&] {
       // (one batch at a time: four waves per query, the shortest latency; batches in flight: one wave per query, the smallest footprint)
-      if (ix->Cpad <= COARSE_MAX_CPAD && r.share > 1 && ix->tune.plan_waves != 4 && !r.direct) hipLaunchKernelGGL((probe_plan2_kernel<0, false, 1>), dim3(r.n_active), dim3(64), 0, s, g);
+      if (ix->Cpad <= COARSE_MAX_CPAD && r.share > 1) hipLaunchKernelGGL((probe_plan2_kernel<0, false, 1>), dim3(r.n_active), dim3(64), 0, s, g);
       else if (ix->Cpad <= COARSE_MAX_CPAD) hipLaunchKernelGGL((probe_plan2_kernel<0, false>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);
       else hipLaunchKernelGGL((probe_plan2_kernel<0, true>), dim3(r.n_active), dim3(64 * PLAN2_NW), 0, s, g);   // (more than 1024 cells: streamed)
     });
@@ -1370,10 +1242,10 @@ static int ivf_work_table(IvfRun& r, WorkTable& wt) {
   wt.sp_cell = base + 3 * wt.max_groups; wt.sp_first = wt.sp_cell + wt.sp_cap; wt.sp_chunk = wt.sp_first + wt.sp_cap;
   timed_launch(ix, s, "work_table", [&] {
     hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ws->w_cellcnt.as<int32_t>(), ix->C, r.n_active, r.scan_kernel == 5 ? SCAN5_G : SPEC2_G, ix->blk_off,
-                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : r.scan_kernel == 4 ? 1 : 0,
-                       sparse_max, wt.sp_cell, wt.sp_first, wt.sp_chunk, wt.n_sparse, (sparse_max >= 2 && ix->tune.sparse_pairs) ? 1 : 0);
+                       wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : 0,
+                       sparse_max, wt.sp_cell, wt.sp_first, wt.sp_chunk, wt.n_sparse, sparse_max >= 2 ? 1 : 0);
   });
-  wt.sp_pairs = sparse_max >= 2 && ix->tune.sparse_pairs;
+  wt.sp_pairs = sparse_max >= 2;
   HIP_TRY(hipGetLastError());
   if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(wt.work_counter, 0, 2 * sizeof(int32_t), s));   // (both work counters)
   return 0;
@@ -1381,12 +1253,18 @@ static int ivf_work_table(IvfRun& r, WorkTable& wt) {
 
 static int scan_prof_buffer(freddy_gpu_index* ix, Workspace* ws, long long** prof) {
   *prof = nullptr;
+#ifndef FREDDY_LAB
+  (void)ix; (void)ws;
+  return 0;
+#else
   if (!ix->tune.scan_prof) return 0;
   if (ws->w_prof.ensure(sizeof(long long) * 8 * 1024)) return fail(FREDDY_E_NOMEM, "profile buffer");
   *prof = ws->w_prof.as<long long>();
   return 0;
+#endif
 }
 
+#ifdef FREDDY_LAB
 // debugging aid (option fused_prof): per-phase shader-clock sums of every persistent workgroup's builder wave 0
 static int scan_prof_print(freddy_gpu_index* ix, hipStream_t s, const long long* prof, unsigned n_persist) {
   std::vector<long long> h(8 * (size_t)n_persist);
@@ -1404,146 +1282,100 @@ static int scan_prof_print(freddy_gpu_index* ix, hipStream_t s, const long long*
   (void)ix;
   return 0;
 }
+#endif
 
-// Default scan: filter + refine (fused4.h).  entry records -> ivf_filter_kernel -> merge_refine_kernel.
+// Default scan: filter + refine.  entry records -> ivf_filter5_kernel (+ the item-wise scan of thin cells) -> merge_refine_kernel.
 static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int Q = r.Q, m = ix->m, K = ix->K;
-  const bool v5 = r.scan_kernel == 5;
-  if (!(r.direct && r.first()) && !r.records_ready && ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (!r.records_ready && ws->w_records.ensure(sizeof(int32_t) * REC_DW * wt.max_groups)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
   ra.sorted_item = ws->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
   ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
   ra.records = ws->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
-  if (r.qc_pending) { HIP_TRY(hipStreamWaitEvent(s, ws->ev_qc, 0)); r.qc_pending = false; }
-  const bool direct = r.direct && r.first();
-  if (!direct && !r.records_ready) {
-  timed_launch(ix, s, "entry_records", [&] {
-    if (v5) hipLaunchKernelGGL((entry_record5_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
-    else hipLaunchKernelGGL((entry_record_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
-  });
-  HIP_TRY(hipGetLastError());
+  if (!r.records_ready) {
+    timed_launch(ix, s, "entry_records", [&] {
+      hipLaunchKernelGGL((entry_record5_kernel<12>), dim3((unsigned)((wt.max_groups + 3) / 4)), dim3(256), 0, s, ra);
+    });
+    HIP_TRY(hipGetLastError());
   }
   FilterArgs fl;
   fl.qc = ws->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ws->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
   fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
   fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
-  fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.ablate = ix->tune.scan_ablate;
-  fl.units = direct ? ix->scan_units : nullptr; fl.n_units = direct ? ix->n_scan_units : 0; fl.cell_count = ws->w_cellcnt.as<int32_t>();
-  fl.drecs = direct ? ws->w_drecs.as<int32_t>() : nullptr; fl.submax = (r.n_active + SCAN5_G - 1) / SCAN5_G;
+  fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.keep_all = (ix->tune.check_brackets & 1) ? 1 : 0;
   if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
-  // slabs: [2 buffers][K][12 items] fp32, or [2 buffers][2 positions][K][16 items] int16 (fused5.h)
-  const size_t desc_off = v5 ? (size_t)4 * SCAN5_G * 2 * K : (((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15);
-  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float) + (v5 ? DQ_INTS * sizeof(int32_t) : 0);
+  // LDS: slabs [2 buffers][2 positions][K][16 items] int16, then column minima / thresholds, two entry records, row terms
+  const size_t desc_off = (size_t)4 * SCAN5_G * 2 * K;
+  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
   fl.desc_offset = (uint32_t)desc_off;
-  // one persistent workgroup per CU (LDS admits exactly one), never more than there is work
-  const bool parted = r.s_scan != s;
-  // Batches in flight share the chip: a persistent scan that took every CU would hold up the small kernels of the
-  // other batches until it drains, and their scans behind them; with n_cus / share workgroups each, the scans of
-  // `share` batches run side by side, the small kernels fit in between, and a scan's workgroups pull more entries
-  // each (a shorter tail).  Measured: 4 batches in flight, 256 / 192 / 128 / 64 workgroups: 7.86 / 8.0 / 8.26 / 8.6 M q/s.
-  const int scan_cus = parted ? ix->n_cus - ws->part_cus
-                              : std::max(ix->n_cus / std::max(1, r.share), std::min(ix->n_cus, 32)) - ix->tune.reserve_cus;
-  unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
-  fl.quota = 0; fl.quota_wgs = 0;
-  if (v5 && ix->tune.scan_quota > 0 && !parted) {
-    // quota-limited workgroups in front of the persistent ones: grid > CUs, the hardware hands a CU to whatever is queued
-    // next whenever one of them leaves -- the batches in flight share the chip at work-entry granularity
-    const size_t est = std::min<size_t>(wt.max_groups, (size_t)r.n_active * r.W / SCAN5_G + std::min<size_t>((size_t)ix->C, (size_t)r.n_active * r.W));
-    const int qw = ix->tune.scan_quota_wgs > 0 ? ix->tune.scan_quota_wgs : (int)(est * 6 / 10 / (size_t)ix->tune.scan_quota);
-    fl.quota = ix->tune.scan_quota;
-    fl.quota_wgs = std::max(0, qw);
-    n_persist += (unsigned)fl.quota_wgs;
-  }
-  // K <= 256: one byte per code (packed8); the DIRECT and profiling instantiations stay with the int16 layout
-  const bool u8 = v5 && !direct && ix->packed8 && ix->tune.codes_u8 != 0 && K <= 256 && !fl.prof;
+  // One persistent workgroup per CU (LDS admits exactly one), never more than there is work.  Batches in flight share the
+  // chip: a persistent scan that took every CU would hold up the small kernels of the other batches until it drains, and
+  // their scans behind them; with n_cus / share workgroups each, the scans of `share` batches run side by side, the small
+  // kernels fit in between, and a scan's workgroups pull more entries each (a shorter tail).
+  const int scan_cus = std::max(ix->n_cus / std::max(1, r.share), std::min(ix->n_cus, 32)) - ix->tune.reserve_cus;
+  const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
+  // K <= 256: one byte per code (packed8); the profiling instantiation stays with the int16 layout
+  const bool u8 = ix->packed8 && ix->tune.codes_u8 != 0 && K <= 256 && !fl.prof;
   fl.packed8 = u8 ? ix->packed8 : nullptr;
-  hipStream_t ss = r.s_scan;
-  if (parted) {   // records (and everything before them) -> scan, on the stream masked to the scan's CUs
-    HIP_TRY(hipEventRecord(ws->ev_fe, s));
-    HIP_TRY(hipStreamWaitEvent(ss, ws->ev_fe, 0));
-  }
-  timed_launch(ix, ss, "ivf_filter", [&] {
-    if (v5 && direct) {
-      if (fl.cand_count) {
-        if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-        else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      } else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-    } else if (u8) {
-      if (fl.cand_count) hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-    } else if (v5) {
-      // (four instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is
-      // larger than the instruction cache as it is)
-      if (fl.cand_count) {
-        if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-        else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      } else if (K == 1024 && fl.prof) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-    } else if (K == 1024) hipLaunchKernelGGL((ivf_filter_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
-    else hipLaunchKernelGGL((ivf_filter_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, ss, fl);
+  timed_launch(ix, s, "ivf_filter", [&] {
+    // (instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is larger than the
+    // instruction cache as it is)
+    if (u8) {
+      if (fl.cand_count) hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    } else if (fl.cand_count) {
+      if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    }
+#ifdef FREDDY_LAB
+    else if (K == 1024 && fl.prof) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+#endif
+    else if (K == 1024) hipLaunchKernelGGL((ivf_filter5_kernel<12, true, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
   });
   HIP_TRY(hipGetLastError());
-  if (v5 && wt.sp_cap > 0) {
+  if (wt.sp_cap > 0) {
     // cells that one or two queries of the batch probe: item by item (sparse5.h), six workgroups of four waves per CU
     SparseArgs sp;
     sp.qc = fl.qc; sp.qscale = ra.qscale; sp.qn = ra.qn; sp.pmax = ix->pmax; sp.rterm = ix->rterm; sp.packed = ix->packed;
     sp.blk_off = ix->blk_off; sp.list_off = ix->list_off; sp.sorted_item = ra.sorted_item; sp.item_query = pa.item_query;
     sp.item_dist = pa.item_dist; sp.sp_cell = wt.sp_cell; sp.sp_first = wt.sp_first; sp.sp_chunk = wt.sp_chunk;
     sp.n_units = wt.n_sparse; sp.work_counter = wt.sp_counter; sp.surv = fl.surv; sp.surv_count = fl.surv_count; sp.packed8 = fl.packed8;
-    sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.ablate = fl.ablate;
+    sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.keep_all = fl.keep_all;
     const unsigned sp_grid = (unsigned)std::min<size_t>(wt.sp_cap, (size_t)std::max(1, scan_cus) * (wt.sp_pairs ? 3 : 6));
-    timed_launch(ix, ss, "sparse_items", [&] {
+    timed_launch(ix, s, "sparse_items", [&] {
       if (wt.sp_pairs) {   // (cell, chunk) units of one or two items: the rows of a two-item cell are read once
         if (u8) {
-          if (fl.cand_count) hipLaunchKernelGGL((sparse_pair5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
-          else hipLaunchKernelGGL((sparse_pair5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
-        } else if (fl.cand_count) hipLaunchKernelGGL((sparse_pair5_kernel<12, true, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
-        else hipLaunchKernelGGL((sparse_pair5_kernel<12, false, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
+          if (fl.cand_count) hipLaunchKernelGGL((sparse_pair5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, s, sp);
+          else hipLaunchKernelGGL((sparse_pair5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, s, sp);
+        } else if (fl.cand_count) hipLaunchKernelGGL((sparse_pair5_kernel<12, true, false>), dim3(sp_grid), dim3(256), 0, s, sp);
+        else hipLaunchKernelGGL((sparse_pair5_kernel<12, false, false>), dim3(sp_grid), dim3(256), 0, s, sp);
       } else if (u8) {
-        if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
-        else hipLaunchKernelGGL((sparse_item5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
-      } else if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true>), dim3(sp_grid), dim3(256), 0, ss, sp);
-      else hipLaunchKernelGGL((sparse_item5_kernel<12, false>), dim3(sp_grid), dim3(256), 0, ss, sp);
+        if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true, true>), dim3(sp_grid), dim3(256), 0, s, sp);
+        else hipLaunchKernelGGL((sparse_item5_kernel<12, false, true>), dim3(sp_grid), dim3(256), 0, s, sp);
+      } else if (fl.cand_count) hipLaunchKernelGGL((sparse_item5_kernel<12, true>), dim3(sp_grid), dim3(256), 0, s, sp);
+      else hipLaunchKernelGGL((sparse_item5_kernel<12, false>), dim3(sp_grid), dim3(256), 0, s, sp);
     });
     HIP_TRY(hipGetLastError());
   }
-  if (parted) {
-    HIP_TRY(hipEventRecord(ws->ev_scan, ss));
-    HIP_TRY(hipStreamWaitEvent(s, ws->ev_scan, 0));
-  }
-  if (fl.prof && (!v5 || (K == 1024 && !fl.cand_count))) if (int rc = scan_prof_print(ix, ss, fl.prof, n_persist)) return rc;   // (v5: the counters live in one instantiation)
+#ifdef FREDDY_LAB
+  if (fl.prof && K == 1024 && !fl.cand_count) if (int rc = scan_prof_print(ix, s, fl.prof, n_persist)) return rc;   // (the counters live in one instantiation)
+#endif
 
   MergeRefineArgs mr;
   mr.surv = fl.surv; mr.surv_count = fl.surv_count; mr.active = r.active; mr.round_rows = pa.round_rows;
   mr.item_cell = pa.item_cell; mr.queries = r.d_q; mr.coarse = ix->coarse; mr.cbR = ix->cbR;
-  mr.qn = ws->w_qn.as<float>(); mr.pmax = ix->pmax; mr.qscale5 = v5 ? ws->w_qn.as<float>() + (size_t)Q * m : nullptr; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
+  mr.qn = ws->w_qn.as<float>(); mr.pmax = ix->pmax; mr.qscale5 = ws->w_qn.as<float>() + (size_t)Q * m; mr.packed = ix->packed; mr.pos = ix->pos; mr.blk_cell = ix->blk_cell;
   mr.cand_count = fl.cand_count; mr.violations = ix->viol; mr.out_ids = r.d_out_ids; mr.out_dist = r.d_out_dist;
   mr.found = ws->w_found.as<int32_t>(); mr.next_active = r.next; mr.n_next = ws->w_cnt.as<int32_t>();
   mr.status = r.d_status;
   mr.n_active = r.n_active; mr.W = r.W; mr.upi = r.upi; mr.L = r.L; mr.k = r.k; mr.found_rule = r.found_rule;
   mr.first_round = r.first() ? 1 : 0; mr.K = K; mr.d = ix->d; mr.sentinel = r.sentinel;
-  mr.ablate = ix->tune.merge_ablate;
-  if (ix->tune.debug_surv) {   // debugging aid: survivor statistics of the round
-    const int n_items = r.n_active * r.W;
-    const size_t nreg = (size_t)n_items * r.upi * FUSED_NW;
-    std::vector<int32_t> h(nreg);
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipMemcpy(h.data(), fl.surv_count, sizeof(int32_t) * nreg, hipMemcpyDeviceToHost));
-    long long tot = 0; int mx = 0; long long item_mx = 0;
-    for (size_t it = 0; it < (size_t)n_items; ++it) {
-      long long si = 0;
-      for (size_t g = 0; g < (size_t)r.upi * FUSED_NW; ++g) { const int c = h[it * r.upi * FUSED_NW + g]; si += c; mx = std::max(mx, c); }
-      tot += si; item_mx = std::max(item_mx, si);
-    }
-    fprintf(stderr, "[surv] items=%d survivors=%lld (%.2f per item, max %lld), largest region %d\n", n_items, tot,
-            (double)tot / std::max(n_items, 1), item_mx, mx);
-  }
+  mr.refine_all = (ix->tune.check_brackets & 1) ? 1 : 0;
   mr.slices = 0; mr.part = nullptr;
   if (r.merge_slices > 0) {
     // a batch over the flat PQ table: `merge_slices` workgroups per query, each over its share of the pseudo-lists (r.W is the
@@ -1565,7 +1397,7 @@ static int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     // (one batch at a time: four waves per query, the shortest latency; batches in flight: one wave per query, the smallest footprint)
     // (hundreds of survivor regions per query -- a batch over the flat PQ table: four waves, which split the selection)
     const bool many_regions = (size_t)r.W * r.upi * FUSED_NW > 256;
-    if (!many_regions && (r.share > 1 ? ix->tune.merge_waves != 4 : ix->tune.merge_waves == 1))
+    if (!many_regions && r.share > 1)
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 1>), dim3(r.n_active), dim3(64), 0, s, mr);
     else if (many_regions && r.n_active <= 256)   // (a few queries with many qualifying rows each: twelve waves, 64 rows per round of the exact stage)
       hipLaunchKernelGGL((merge_refine_kernel<25, 12, 12, true>), dim3(r.n_active), dim3(768), 0, s, mr);
@@ -1593,7 +1425,6 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   fa.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fa.d = ix->d; fa.K = K; fa.L = r.L; fa.upi = r.upi;
   memcpy(&fa.sentinel_bits, &r.sentinel, 4);
-  fa.ablate = ix->tune.scan_ablate;
   if (int rc = scan_prof_buffer(ix, ws, &fa.prof)) return rc;
   const size_t desc_off = ((size_t)2 * SPEC2_G * K * sizeof(float) + 15) & ~(size_t)15;
   const size_t flds = desc_off + 4096 + 64 + 512 + (size_t)SPEC2_G * 12 * 28 * sizeof(float);
@@ -1604,7 +1435,9 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     else hipLaunchKernelGGL((ivf_spec2_kernel<25, 12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fa);
   });
   HIP_TRY(hipGetLastError());
+#ifdef FREDDY_LAB
   if (fa.prof) if (int rc = scan_prof_print(ix, s, fa.prof, n_persist)) return rc;
+#endif
   MergeSurvArgs ms;
   ms.surv = fa.surv; ms.surv_count = fa.surv_count; ms.active = r.active; ms.round_rows = pa.round_rows;
   ms.cand_count = fa.cand_count; ms.out_ids = r.d_out_ids; ms.out_dist = r.d_out_dist;
@@ -1650,49 +1483,16 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   return launch_merge(ix, s, ma);
 }
 
-// The workspace's two CU-masked streams.  Bit b of a mask is CU (b / 8) of XCD (b % 8) on this chip (tools/ubench_cumask:
-// bits 0..31 = 4 CUs of every XCD; a mask that leaves an XCD without CUs is ignored by the driver), so the reserved
-// partition is bits [0, R) and the scan's is [R, n_cus), R a multiple of 8.
-static int partition_streams(freddy_gpu_index* ix, Workspace* ws) {
-  int R = ix->tune.partition_cus < 0 ? -ix->tune.partition_cus : ix->tune.partition_cus;
-  R = std::max(8, std::min(R, ix->n_cus - 8)) & ~7;
-  if (ws->fe_stream && ws->part_cus == R) return 0;
-  ws->release_partition();
-  const int words = (ix->n_cus + 31) / 32;
-  std::vector<uint32_t> fe((size_t)words, 0u), sc((size_t)words, 0u);
-  for (int b = 0; b < ix->n_cus; ++b) (b < R ? fe : sc)[(size_t)b >> 5] |= 1u << (b & 31);
-  HIP_TRY(hipExtStreamCreateWithCUMask(&ws->fe_stream, (uint32_t)words, fe.data()));
-  HIP_TRY(hipExtStreamCreateWithCUMask(&ws->scan_stream, (uint32_t)words, sc.data()));
-  for (hipEvent_t* e : {&ws->ev_in, &ws->ev_fe, &ws->ev_scan, &ws->ev_out}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-  ws->part_cus = R;
-  return 0;
-}
-
-static int ix_units(const IvfRun& r) { return r.ix->n_scan_units; }
 // One probing round of a chunk: cell selection, then the scan + merge of the path the chunk takes.
 static int ivfadc_round(IvfRun& r) {
   PlanArgs pa;
   if (int rc = ivf_plan(r, pa)) return rc;
   if (r.fused) {
     WorkTable wt;
-    if (r.direct && r.first()) {   // no work table: the scan claims static units (fused5.h DIRECT mode)
-      wt.max_groups = (size_t)ix_units(r); wt.group_cell = wt.group_first = wt.group_cnt = nullptr;
-      wt.n_groups = r.ws->w_cnt.as<int32_t>() + 1; wt.work_counter = r.ws->w_cnt.as<int32_t>() + 2;
-      wt.sp_cap = 0; wt.sp_cell = wt.sp_first = wt.sp_chunk = nullptr; wt.n_sparse = r.ws->w_cnt.as<int32_t>() + 4; wt.sp_counter = r.ws->w_cnt.as<int32_t>() + 3;
-      return ivf_scan_filter(r, pa, wt);
-    }
     if (int rc = ivf_work_table(r, wt)) return rc;
-    return (r.scan_kernel >= 4) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt);
+    return (r.scan_kernel == 5) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt);
   }
   return ivf_scan_generic(r, pa);
-}
-
-// (the caller's stream continues after everything enqueued on the internal streams)
-static int ivfadc_rejoin(IvfRun& r) {
-  if (r.s == r.s_caller) return 0;
-  HIP_TRY(hipEventRecord(r.ws->ev_out, r.s));
-  HIP_TRY(hipStreamWaitEvent(r.s_caller, r.ws->ev_out, 0));
-  return 0;
 }
 
 // One chunk of queries (device pointers): workspace, coarse distances and round one are enqueued on s, nothing is
@@ -1719,36 +1519,12 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   r.upi = std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   r.fused = ix->tune.fused != 0 && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && r.L <= 64 && r.upi <= 8 &&
             (ix->tune.fused == 1 || items >= 256);
-  r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : ix->tune.scan_kernel == 5 ? 5 : 4;
+  r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : 5;
   r.tiled = Q >= 32;
   r.zeroed = r.tiled || ix->d <= 1024;
-  r.direct = false; r.records_ready = false; r.merge_slices = 0;
+  r.records_ready = false; r.merge_slices = 0;
   // (the MFMA tile is 64 queries wide and the plan keeps a query's distances in registers: batches, <= 1024 cells)
   r.approx = ix->tune.coarse_approx != 0 && r.tiled && ix->Cpad <= COARSE_STREAM_MAX_CPAD && 2 * W <= 64 && ix->d <= 300 && ix->d % 4 == 0 && ix->coarseP;
-  // DIRECT mode of the scan (no work-table / record kernels): round one of a DENSE batch -- (almost) every cell holds items,
-  // so the static unit list has no holes worth a table -- with the MFMA cell selection (whose plan kernel writes the slots)
-  {
-    const size_t submax = ((size_t)Q + SCAN5_G - 1) / SCAN5_G;
-    const size_t drec_bytes = sizeof(int32_t) * (size_t)C * submax * DREC_DW;
-    const bool sparse_batch = items < 4 * (size_t)C;
-    r.direct = r.fused && r.scan_kernel == 5 && r.approx && ix->tune.fuse_table && ix->scan_units && ix->n_scan_units > 0 && !ix->shadow_of &&
-               ix->tune.direct != 0 && (ix->tune.direct == 1 || !sparse_batch) && drec_bytes <= ((size_t)512 << 20) &&
-               !ix->tune.scan_prof && ix->tune.scan_quota == 0 && ix->tune.sparse_items >= 0;
-    if (r.direct && ws->w_drecs.ensure(drec_bytes)) return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-  }
-  // CU partition: only for the filter + refine scan, whose persistent workgroups take whole CUs
-  r.s_caller = s;
-  r.s_scan = s;
-  if (ix->tune.partition_cus != 0 && r.fused && r.scan_kernel >= 4) {
-    if (int rc = partition_streams(ix, ws)) return rc;
-    if (ix->tune.partition_cus > 0) {
-      HIP_TRY(hipEventRecord(ws->ev_in, r.s_caller));
-      HIP_TRY(hipStreamWaitEvent(ws->fe_stream, ws->ev_in, 0));
-      r.s = s = ws->fe_stream;
-    }
-    // (negative: only the scan is masked -- the R CUs it never takes stay open to the small kernels of every stream)
-    r.s_scan = ws->scan_stream;
-  }
   const int Cpad = ix->Cpad, used_words = (C + 31) / 32;
   if (ws->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ws->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
@@ -1765,7 +1541,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
         ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
         ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
-    if (r.scan_kernel >= 4 &&
+    if (r.scan_kernel == 5 &&
         (ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
@@ -1781,8 +1557,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   ix->last_Q = Q;
   r.n_active = Q; r.active = nullptr; r.next = ws->w_act0.as<int32_t>();
   r.round = 0;
-  if (int rc = ivfadc_round(r)) return rc;
-  return ivfadc_rejoin(r);
+  return ivfadc_round(r);
 }
 
 // The extra rounds of the reference's "while (foundInstances < k)" loop (freddy.c:262, :835), one host sync per
@@ -1808,7 +1583,7 @@ static int ivfadc_finish(IvfRun& r, int n_next) {
     if (int rc = ivfadc_round(r)) return rc;
     n_next = -1;
   }
-  return ivfadc_rejoin(r);
+  return 0;
 }
 
 static int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q, int k, const void* oi,
@@ -2145,7 +1920,11 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
   const size_t row = sizeof(float) * (size_t)ix->d;
   const PipeCall pc{ix, queries, k, W, found_rule, sentinel, out_ids, out_dist};
   int rc = 0;
-  const bool trace = ix->tune.pipe_trace != 0;
+#ifdef FREDDY_LAB
+  static const bool trace = getenv("FREDDY_GPU_PIPE_TRACE") != nullptr;   // host timestamps of the pipeline's steps on stderr (lab builds)
+#else
+  constexpr bool trace = false;
+#endif
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_start = trace ? now_us() : 0.0;
   auto slot_of = [&](int j) -> LaneSlot& { return ix->lanes[j % n_lanes].slot[(j / n_lanes) & 1]; };
@@ -2514,13 +2293,12 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   const int SL = (lists >= 32 && Q <= 256 && (size_t)lists * FUSED_NW > 256) ? 4 : 0;
   const int W = SL ? ((lists + SL - 1) / SL) * SL : lists;
   IvfRun r;
-  r.ix = fx; r.ws = ws; r.s = s; r.s_scan = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = 2 * k;
+  r.ix = fx; r.ws = ws; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = 2 * k;
   r.sentinel = sentinel; r.cell_limit = 0.0f; r.d_out_ids = d_out_ids; r.d_out_dist = d_out_dist; r.d_status = nullptr;
-  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false; r.qc_pending = false; r.direct = false;
+  r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false;
   r.records_ready = true; r.merge_slices = SL;
   r.n_active = Q; r.round = 0; r.active = nullptr;
   r.share = std::max(1, ix->tune.scan_share);   // (the caller's contract: its batches in flight on this handle)
-  r.s_caller = s;
   const size_t items = (size_t)Q * W;
   const size_t n_entries = (size_t)((Q + SCAN5_G - 1) / SCAN5_G) * lists;
   if (ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
@@ -3154,7 +2932,6 @@ static int append_packed_rows(freddy_gpu_index* ix, int n_lists, int64_t n, cons
   ix->h_list_off = new_list_off;
   ix->N += n;
   if (!ix->shadow_of) { if (int rc = build_packed8(ix)) return rc; }
-  if (ix->kind == KIND_IVF && !ix->shadow_of) return build_scan_units(ix);
   return 0;
 }
 
@@ -3381,7 +3158,7 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
   *fell_back = 0;
   const int d = ix->d, T = (d + 15) / 16, L = k, V = pick_V(L);
   const int64_t N = ix->N;
-  const bool all = ix->tune.exact_refine_all != 0;
+  const bool all = (ix->tune.check_brackets & 4) != 0;
   const int64_t cap64 = all ? N : std::min<int64_t>(N, 8192);
   const int cap = (int)cap64;
   const int n_sample = (int)std::min<int64_t>(N, EXF_SAMPLE);

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
       for (int p = 0; p + 1 < M; ++p) {
         float* nxt = slab + (size_t)((p + 1) & 1) * G * K;
         tick(5);
-        if (!(a.ablate & 1)) build_slab(p + 1, nxt, 0, cnt, cnt);
+        build_slab(p + 1, nxt, 0, cnt, cnt);
         tick(0);   // builds of the main loop
         __builtin_amdgcn_sched_barrier(0);
         // (Issued in one go.  The builder wave blocks ~2.8k cycles per position while the 28 wide loads
@@ -306,12 +306,12 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
       // free (the gatherers read buffer 1, then select), position 0 of the next residuals was staged in
       // P(STAGE_P0), position 0 of the codebook was requested after the last build.
       const int c1 = next_cnt < 4 ? next_cnt : 4, c2 = next_cnt < 8 ? next_cnt : 8;
-      if (!(a.ablate & 1)) build_slab(0, slab, 0, c1, next_cnt);
+      build_slab(0, slab, 0, c1, next_cnt);
       lds_barrier();
       tick(2);   // P(M-1)
-      if (!(a.ablate & 1)) build_slab(0, slab, c1, c2, next_cnt);
+      build_slab(0, slab, c1, c2, next_cnt);
       lds_barrier();
-      if (!(a.ablate & 1)) build_slab(0, slab, c2, next_cnt, next_cnt);
+      build_slab(0, slab, c2, next_cnt, next_cnt);
       load_cb(1);
       lds_barrier();
       tick(3);   // S1 + S2
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
         for (int r = 0; r < RMAX; ++r) acc[h][r] = v2f{0.0f, 0.0f};
       load_codes(0);
       for (int p = 0; p + 1 < M; ++p) {
-        if (!(a.ablate & 2)) gather(p, slab + (size_t)(p & 1) * G * K);
+        gather(p, slab + (size_t)(p & 1) * G * K);
         __builtin_amdgcn_sched_barrier(0);
         if (p & 1) load_codes((p + 1) >> 1);
         if (p >= STAGE_P0) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
         lds_barrier();
       }
       // P(M-1)
-      if (!(a.ablate & 2)) gather(M - 1, slab + (size_t)((M - 1) & 1) * G * K);
+      gather(M - 1, slab + (size_t)((M - 1) & 1) * G * K);
       int32_t pid[RMAX];
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) pid[r] = a.pos[row_block(r) * 64u + (uint32_t)lane];
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
               if (dead[r]) acc[h][r] = v2f{__uint_as_float(0xffffffffu), __uint_as_float(0xffffffffu)};
         }
       }
-      if (!(a.ablate & 4)) {
+      {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
       }
       lds_barrier();
       // S1: thresholds, two items per gatherer wave, the two sorts interleaved
-      if (!(a.ablate & 4)) {
+      {
         static_assert(G <= 2 * NG, "at most two items per gatherer wave");
         const int g0 = gw, g1 = gw + NG;   // (colmin / tau_s have 16 rows: g1 may be an unused one)
         uint32_t c0 = colmin[g0 * 64 + lane], c1 = colmin[g1 * 64 + lane];
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_spec2_kernel(FusedArgs a) {
       }
       lds_barrier();
       // S2: survivors -> this wave's region of each item's buffer
-      if (!(a.ablate & 4)) {
+      {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {

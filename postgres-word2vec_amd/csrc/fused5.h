@@ -41,18 +41,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "fused4.h"
+#include "refine.h"
 #include "coarse.h"
 
 namespace freddy {
 
 // (FILT5_VMAX, filter_width5: fused4.h, next to the merge that shares them)
 static constexpr int SCAN5_G = 16;   // items per work entry
-// DIRECT mode (no work-table / record kernels in a batch's chain): the scan's workgroups claim (cell, chunk) UNITS from a
-// static list (pin time, longest lists first) and cut each unit into entries of <= 16 items themselves from the cell's item
-// count; the per-item record fields were written by the probe plan into the static slot (cell, item number / 16).
-static constexpr int DREC_DW = 144;      // dwords of a static record slot (same offsets as the entry record: [8 + g] item ... [128 + g] scale)
-static constexpr int DQ_INTS = 64;       // LDS ints of the unit pipeline: entry descriptors [2][12], ready queue [4][8]
 
 // order-preserving 32-bit key of a float (NaNs sort above +inf or below -inf: only met with non-finite inputs)
 __device__ __forceinline__ uint32_t float_key(float x) {
@@ -273,7 +268,7 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
 // U8: the rows' codes as one byte each (K <= 256: what the reference's shipped default indexes use) -- packed8[block][3][64],
 // dword t of a row = its codes 4 t .. 4 t + 3: 12 instead of 24 bytes of codes per row, three code loads per row and entry
 // instead of six (the dword of phases 2 t and 2 t + 1 is the same)
-template <int M, bool FULLK, bool CAND, bool PROF = false, bool DIRECT = false, bool U8 = false>
+template <int M, bool FULLK, bool CAND, bool PROF = false, bool U8 = false>
 __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   static_assert(!(U8 && FULLK), "one byte per code: K <= 256");
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
@@ -290,7 +285,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   int32_t* dsc = reinterpret_cast<int32_t*>(smem + a.desc_offset + 4096 + 64);    // [2][REC_DW] entry records
   int32_t* gidq = dsc + 2 * REC_DW;
   float* rt_s = reinterpret_cast<float*>(gidq + 4);                                // [4096] row terms of the entry about to start
-  int32_t* dq = reinterpret_cast<int32_t*>(rt_s + 4096);                           // DIRECT: [DQ_INTS] entry descriptors + ready queue
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,108 +293,15 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   const uint32_t HALFB = (uint32_t)K * HROWB;        // bytes of one plane: the values of 8 items for every code of a position
   const uint32_t POSB = 2u * HALFB;                  // bytes of one position's slab
   const uint32_t BUFB = 2u * POSB;                   // bytes of one buffer
-  const int n_work = DIRECT ? 0 : a.n_groups[0];
+  const int n_work = a.n_groups[0];
 
   int cur = 0, ei = 0;
-  // entries this workgroup may take: the first quota_wgs workgroups of the grid leave after `quota` entries (their CU goes
-  // to whatever is queued next -- another batch's scan or small kernels), the others stay until the table is empty
-  const int quota = ((int)blockIdx.x < a.quota_wgs) ? a.quota : 0x7fffffff;
-  // ---- DIRECT: the unit pipeline.  Builder wave 0 runs it with wave-uniform decisions; what it hands over goes through LDS.
-  // One unit per entry: the ticket (a returning atomic: vmcnt) is requested where the work-table path requested its
-  // ticket and consumed where that path consumed it; the unit's descriptor and its cell's item count are SCALAR loads
-  // (lgkmcnt: complete at the phase's barrier, where the builders wait for the gatherers anyway) -- a vector load
-  // consumed a phase later would make the wave wait for its table words a phase early, every phase (84 -> 119 us).
-  // Every LDS round trip of wave 0 that a decision waits for is on the entry's critical path (fifteen of them: +2.6 k
-  // cycles per entry): a descriptor's decision fields are ONE 16-byte read, the queue's state is one packed register.
-  // entry descriptor ed[slot][12]: kind (0 end, 1 entry, 2 bubble: nothing ready yet), cell, sub, n | cnt, chunk, b0, nb | rows
-  // ready queue rq[4][8] at dq + 24: cell, chunk, b0, nb | rows, n  (units whose cell holds items, in claim order)
-  // pstate (uniform register): queue head (bits 0-1), fill (bits 8-10), no tickets left (bit 16)
-  typedef int32_t i4v __attribute__((ext_vector_type(4)));
-  typedef uint32_t u4s __attribute__((ext_vector_type(4)));
-  const i4v* units4 = reinterpret_cast<const i4v*>(a.units);
-  int pstate = 0;
-  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-  auto rq_push = [&](uint32_t d0, uint32_t d1, uint32_t d2, int n) {   // (wave 0; lane 0 writes)
-    const int head = pstate & 3, fill = (pstate >> 8) & 7;
-    if (lane == 0) {
-      i4v* r = reinterpret_cast<i4v*>(dq + 24 + ((head + fill) & 3) * 8);
-      r[0] = i4v{(int32_t)(d0 & 0xffffffu), (int32_t)(d0 >> 24), (int32_t)d1, (int32_t)(d2 & 0xffu)};
-      r[1] = i4v{(int32_t)(d2 >> 8), n, 0, 0};
-    }
-    pstate += 1 << 8;
-  };
-  // the entry after the one whose decision fields are (pk, pcell, psub, pn) and whose descriptor is `prev` (pk = 3: none --
-  // the workgroup's first); uniform decisions, lane 0 writes.  pending: a unit is still on its way into the queue
-  auto next_entry = [&](int pk, int pcell, int psub, int pn, const int32_t* prev, int32_t* out, bool pending) {
-    i4v* o = reinterpret_cast<i4v*>(out);
-    const int fill = (pstate >> 8) & 7;
-    if (pk == 1 && (psub + 1) * 16 < pn) {
-      if (lane == 0) {
-        const int s2 = psub + 1, left = pn - 16 * s2;
-        const i4v tail4 = *reinterpret_cast<const i4v*>(prev + 4);
-        const int rows = prev[8];
-        o[0] = i4v{1, pcell, s2, pn};
-        o[1] = i4v{left < 16 ? left : 16, tail4.y, tail4.z, tail4.w};
-        out[8] = rows;
-      }
-    } else if (pk == 0) {
-      if (lane == 0) out[0] = 0;
-    } else if (fill > 0) {
-      if (lane == 0) {
-        const i4v* r = reinterpret_cast<const i4v*>(dq + 24 + (pstate & 3) * 8);
-        const i4v r0 = r[0], r1 = r[1];     // cell, chunk, b0, nb | rows, n
-        o[0] = i4v{1, r0.x, 0, r1.y};
-        o[1] = i4v{r1.y < 16 ? r1.y : 16, r0.y, r0.z, r0.w};
-        out[8] = r1.x;
-      }
-      pstate = (pstate & ~3) | ((pstate + 1) & 3);
-      pstate -= 1 << 8;
-    } else if ((pstate >> 16) && !pending) {
-      if (lane == 0) out[0] = 0;
-    } else if (lane == 0) {   // nothing ready yet (empty cells in a row): an entry without items, one row block
-      o[0] = i4v{2, 0, 0, 0};
-      o[1] = i4v{0, 0, 0, 1};
-      out[8] = 0;
-    }
-  };
-  if constexpr (DIRECT) {
-    if (wave == 0) {
-      // the first units: a few tickets at once, their descriptors and counts fetched side by side (lanes 0 .. pc-1)
-      int pc = a.n_units / (2 * (int)gridDim.x);
-      pc = pc >= 1 ? 2 : 1;   // (the units of the first two entries)
-      int t0 = 0;
-      if (lane == 0) t0 = atomicAdd(a.work_counter, pc);
-      t0 = uni(t0);
-      if (t0 + pc >= a.n_units) pstate |= 1 << 16;
-      const bool mine = lane < pc && t0 + lane < a.n_units;
-      const i4v d = mine ? units4[t0 + lane] : i4v{0, 0, 0, 0};
-      const int n = mine ? a.cell_count[d.x & 0xffffff] : 0;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ni = __builtin_amdgcn_readlane(n, i);
-        if (ni > 0) rq_push((uint32_t)__builtin_amdgcn_readlane(d.x, i), (uint32_t)__builtin_amdgcn_readlane(d.y, i), (uint32_t)__builtin_amdgcn_readlane(d.z, i), ni);
-      }
-      next_entry(3, 0, 0, 0, nullptr, dq, false);            // entry 0
-      const i4v e0 = *reinterpret_cast<const i4v*>(dq);
-      next_entry(uni(e0.x), uni(e0.y), uni(e0.z), uni(e0.w), dq, dq + 12, false);   // entry 1
-    }
-    for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
-    __syncthreads();
-    if (dq[0] == 0) return;
-    {
-      const int32_t* e0 = dq;
-      if (tid >= 8 && tid < DREC_DW) dsc[tid] = e0[0] == 1 ? a.drecs[((size_t)e0[1] * a.submax + e0[2]) * DREC_DW + tid] : 0;
-      if (tid < 6) dsc[tid] = e0[tid == 0 ? 1 : tid + 3];   // cell, cnt, chunk, b0, nb, rows
-    }
-    __syncthreads();
-  } else {
-  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = quota > 1 ? atomicAdd(a.work_counter, 1) : 0x7fffffff; }
+  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = atomicAdd(a.work_counter, 1); }
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
   __syncthreads();
   if (gidq[0] >= n_work) return;
   if (tid < REC_DW) dsc[tid] = a.records[(size_t)gidq[0] * REC_DW + tid];
   __syncthreads();
-  }
 
   if (builder) {
     // =====================================================================================
@@ -424,7 +325,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     typedef const char __attribute__((address_space(1))) * gptrc;
     typedef const u4 __attribute__((address_space(1))) * gptr4u;
     auto issue = [&](int set, int phase, const int (&qids)[8], int nh) {   // position 2 phase + hpos of the half's 8 items
-      if (half >= nh || (a.ablate & 32)) return;
+      if (half >= nh) return;
       uint32_t voff = vq + (uint32_t)phase * 4096u;
       asm volatile("" : "+v"(voff));
 #pragma unroll
@@ -435,7 +336,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     };
     // the eight table words of code pair b = li + 128 k interleaved: low halves -> half row b, high halves -> b + 512
     auto emit = [&](int set, unsigned char* dst, int nh) {
-      if (half >= nh || (a.ablate & 16)) return;
+      if (half >= nh) return;
       unsigned char* dp = dst + qoff;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -460,14 +361,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     int nq = (__builtin_amdgcn_readfirstlane(dsc[1]) + 7) >> 3;   // halves in use
     const int g0 = half * 8;
     int qid[8], nqid[8];
-    {
-      // (DIRECT: the slots of a static record beyond the entry's items hold stale numbers: never used as a query index)
-      const int cnt0 = __builtin_amdgcn_readfirstlane(dsc[1]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        qid[u] = (!DIRECT || g0 + u < cnt0) ? __builtin_amdgcn_readfirstlane(dsc[24 + g0 + u]) : (cnt0 > 0 ? __builtin_amdgcn_readfirstlane(dsc[24]) : 0);
-        nqid[u] = qid[u];
-      }
+    for (int u = 0; u < 8; ++u) {
+      qid[u] = __builtin_amdgcn_readfirstlane(dsc[24 + g0 + u]);
+      nqid[u] = qid[u];
     }
     float rtv[RMAX];
     auto fetch_row_terms = [&](const int32_t* rc) {
@@ -491,59 +388,25 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     lds_barrier();
     for (;;) {
       const int nb = cur ^ 1;
-      const int ngid = DIRECT ? 0 : __builtin_amdgcn_readfirstlane(gidq[(ei + 1) & 1]);
-      // DIRECT: the descriptor of entry e + 1 (written during entry e - 1, or by the prologue)
-      const int32_t* d1 = dq + ((ei + 1) & 1) * 12;
-      int kind1 = 0, cell1 = 0, sub1 = 0, n1 = 0;
-      if constexpr (DIRECT) {
-        const i4v dv = *reinterpret_cast<const i4v*>(d1);
-        kind1 = uni(dv.x); cell1 = uni(dv.y); sub1 = uni(dv.z); n1 = uni(dv.w);
-      }
-      const bool have_next = DIRECT ? kind1 != 0 : ngid < n_work;
+      const int ngid = __builtin_amdgcn_readfirstlane(gidq[(ei + 1) & 1]);
+      const bool have_next = ngid < n_work;
       int gid2 = 0;
       int next_nq = 0;
       int32_t rr0 = 0;
-      // DIRECT, wave 0: the unit this entry claims -- only when entry e + 2 needs one (entry e + 1 is the last of its unit)
-      // and none is waiting: a workgroup holds the units of its next two entries and nothing more, as the work-table path
-      // holds two tickets (a ready queue of three units per workgroup cost the launch its balance: +27 us of tail).
-      // Ticket in phase 0 (consumed in phase 1, where the work-table path consumed its ticket), descriptor requested in
-      // phase 1, item count in phase 2 (scalar loads: complete at the phases' barriers), decision before the last barrier.
-      int pf_tk = 0;
-      bool have_tk = false, have_d = false;
-      i4v pf_dv = i4v{0, 0, 0, 0};
-      int pf_n = 0;
-      const bool need_unit = DIRECT && kind1 != 0 && !(kind1 == 1 && (sub1 + 1) * 16 < n1);
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         // the next entry's record: requested in phase 0, stored in phase 1, first read in phase 2
-        if constexpr (DIRECT) {
-          if (j == 1) {
-            if (tid >= 8 && tid < DREC_DW) dsc[nb * REC_DW + tid] = rr0;
-            if (tid < 6) dsc[nb * REC_DW + tid] = d1[tid == 0 ? 1 : tid + 3];   // cell, cnt, chunk, b0, nb, rows
-            if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
-            if (wave == 0 && have_tk) {   // (the ticket is consumed HERE, before the phase's table words are requested: nothing younger has to arrive with it)
-              typedef const i4v __attribute__((address_space(4))) * cptr4;
-              const int tk = uni(pf_tk);
-              if (tk < a.n_units) { pf_dv = *(cptr4)(uintptr_t)(units4 + tk); have_d = true; }
-              else pstate |= 1 << 16;
-            }
-          }
-        } else {
         if (j == 1 && tid < REC_DW) {
           if (tid == 0) gidq[ei & 1] = gid2;
           dsc[nb * REC_DW + tid] = rr0;
           if (wave == 0 && lane == 6) dsc[nb * REC_DW + 6] = have_next ? 1 : -1;
         }
-        }
         if (j == NP - 3) {   // (the next entry's record is in LDS since the barrier of phase 1)
           const int ncnt = have_next ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 1]) : 0;
           next_nq = (ncnt + 7) >> 3;
-          // (DIRECT: the slots of a static record beyond the entry's items hold stale numbers: never used as a query index)
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            nqid[u] = !have_next ? qid[u]
-                      : (!DIRECT || g0 + u < ncnt) ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g0 + u])
-                      : (ncnt > 0 ? __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24]) : qid[u]);
+            nqid[u] = !have_next ? qid[u] : __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 24 + g0 + u]);
         }
         // slab of phase j + 1 of this entry -- or phase 0 of the next one -- from the set requested two phases ago,
         // then the same set again for phase j + 3
@@ -553,35 +416,14 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         if (j + 3 < NP) issue(set, j + 3, qid, nq);
         else issue(set, j + 3 - NP, nqid, next_nq);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
         if (j == 2) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
-        if constexpr (DIRECT) {
-          if (j == 0 && kind1 == 1 && tid >= 8 && tid < DREC_DW)
-            rr0 = a.drecs[((size_t)(uint32_t)cell1 * (size_t)a.submax + (size_t)(uint32_t)sub1) * DREC_DW + tid];
-          if (j == 0 && wave == 0 && need_unit && (pstate >> 16) == 0 && ((pstate >> 8) & 7) == 0) {
-            if (lane == 0) pf_tk = atomicAdd(a.work_counter, 1);
-            have_tk = true;
-          }
-          if (wave == 0) {
-            typedef const i4v __attribute__((address_space(4))) * cptr4;
-            typedef const int32_t __attribute__((address_space(4))) * cptr1;
-            if (j == 2 && have_d) pf_n = *(cptr1)(uintptr_t)(a.cell_count + (uint32_t)(uni(pf_dv.x) & 0xffffff));
-            // the decision for entry e + 2, into the slot of the entry that is running -- where the builders are idle: the
-            // gatherers reach the last phase's barrier only after their last gather and the column minima
-            if (j == NP - 1) {
-              if (have_d && pf_n > 0) rq_push((uint32_t)uni(pf_dv.x), (uint32_t)uni(pf_dv.y), (uint32_t)uni(pf_dv.z), uni(pf_n));
-              const i4v dv = *reinterpret_cast<const i4v*>(d1);
-              next_entry(uni(dv.x), uni(dv.y), uni(dv.z), uni(dv.w), d1, dq + (ei & 1) * 12, false);
-            }
-          }
-        } else {
         if (j == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
-        if (j == 0 && tid == 0) gid2 = ei + 2 < quota ? atomicAdd(a.work_counter, 1) : 0x7fffffff;
-        }
+        if (j == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
         tick(0);
         lds_barrier();
         tick(1);
       }
       // S1: thresholds tau + E (builder wave w: items w and w + 8), while the gatherers are in their tail
-      if (!(a.ablate & 4)) {
+      {
         const int32_t* rec = dsc + cur * REC_DW;
         const int cnt = __builtin_amdgcn_readfirstlane(rec[1]);
         const int i0 = wave, i1 = wave + NG;
@@ -590,8 +432,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           wave_sort32_x2(c0, c1);   // (order-preserving keys of the float column minima)
           const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
           if (lane == 0) {
-            thr_s[i0] = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
-            thr_s[i1] = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
+            thr_s[i0] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
+            thr_s[i1] = a.keep_all ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
           }
           colmin[i0 * 64 + lane] = 0xffffffffu;
           colmin[i1 * 64 + lane] = 0xffffffffu;
@@ -696,11 +538,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         load_codes(cwb, 1);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-          if (!(a.ablate & 2)) {
-            if (j & 1) gather(cwb, j); else gather(cwa, j);
-          }
+          if (j & 1) gather(cwb, j); else gather(cwa, j);
           __builtin_amdgcn_sched_barrier(0);
-          if (j + 2 < NP && !(a.ablate & 64)) {   // the codes of phase j + 2 into the set phase j has just used
+          if (j + 2 < NP) {   // the codes of phase j + 2 into the set phase j has just used
             if (j & 1) load_codes(cwb, j + 2); else load_codes(cwa, j + 2);
           }
           if (j + 1 < NP) lds_barrier();
@@ -713,8 +553,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>;
         using I6 = std::integral_constant<int, 6>; using I8 = std::integral_constant<int, 8>;
-        // (DIRECT: a bubble of the unit pipeline -- an entry without items, one row block -- takes the cheapest instantiation:
-        // its sums are never looked at.  A branch around the main loop cost the tail 60 spilled registers.)
         switch ((nq < 1 ? 1 : nq) * 4 + rc) {
           case 1 * 4 + 1: main_loop(I1{}, I2{}); break;
           case 1 * 4 + 2: main_loop(I1{}, I4{}); break;
@@ -768,7 +606,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       for (int g = 0; g < G; ++g) best[g] = __uint_as_float(0x7f800000u);
 #pragma unroll
       for (int i = 0; i < G / 2; ++i) sec16[i] = 0x7f807f80u;
-      if (!(a.ablate & 4)) {
+      {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
@@ -802,7 +640,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       gtick(-1);
       // S2: survivors -> this wave's region of each item's buffer.  Normally every lane has at most one (its smallest
       // sum, kept from the pass above); otherwise the pass bits of the lane's 8 rows, branch free, then per-row ballots.
-      if (!(a.ablate & 4)) {
+      {
         const float p_thr = __uint_as_float(thr_s[gi]);
         const int p_it = rec[8 + gi];
         const float p_shift = __int_as_float(rec[72 + gi]);
@@ -840,7 +678,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
 #pragma unroll
               for (int r = RMAX - 1; r >= 0; --r) m8 = m8 + m8 + (!(sval(g, r, sc) > thr) ? 1u : 0u);   // (a NaN passes: exact stage)
               m8 &= live8;
-              if ((a.ablate & 128) == 0 && __ballot(m8 != 0u) != 0ull) {
+              if (__ballot(m8 != 0u) != 0ull) {
 #pragma unroll
                 for (int r = 0; r < RMAX; ++r) {
                   const bool pass = (m8 >> r) & 1u;

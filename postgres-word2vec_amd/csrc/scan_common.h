@@ -1,7 +1,7 @@
 // scan_common.h -- what the fused IVFADC scan kernels share: chunk geometry, the cell-major work table,
 // the argument block of the exact scan (fused3.h), the LDS-only barrier and the survivor merge.
 //
-// Both scans (fused3.h: the reference's arithmetic for every row; fused4.h: filter + refine, default) walk
+// Both scans (fused3.h: the reference's arithmetic for every row; fused5.h: filter + refine, default) walk
 // work entries = (<= 12 items of ONE cell, one 4096-row chunk of its list) with persistent workgroups;
 // every gatherer wave appends the rows that pass the item's threshold to its own survivor region, and a
 // merge kernel picks the query's 2k smallest keys and replays the reference's insertion.
@@ -154,7 +154,6 @@ struct FusedArgs {
   int d, K, L, upi;            // upi: chunks per item the buffers are laid out for
   uint32_t sentinel_bits;
   uint32_t desc_offset;        // byte offset of the item-descriptor scratch inside dynamic LDS
-  uint32_t ablate;             // timing experiments only (FREDDY_GPU_FUSED_ABLATE)
   long long* prof;             // NULL, or [gridDim.x][8] cycle sums per phase (FREDDY_GPU_FUSED_PROF)
 };
 

@@ -44,7 +44,7 @@ struct SparseArgs {
   int32_t* cand_count;         // [Q] or NULL
   int K, L, upi;
   float sentinel;
-  uint32_t ablate;             // debugging: 8 = keep every row (as ivf_filter5_kernel)
+  int keep_all;                // option filter_keep_all (tests): every row survives (as ivf_filter5_kernel)
 };
 
 template <int M, bool CAND, bool U8 = false>   // U8: one byte per code (K <= 256), packed8[block][3][64]
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
     if (wave == 0) {
       const uint32_t c0 = wave_sort32(colmin[lane]);
       const uint32_t t0 = __shfl(c0, a.L - 1, 64);
-      if (lane == 0) thr_sh = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t0, ib.e);
+      if (lane == 0) thr_sh = a.keep_all ? 0x7f800000u : widen_threshold5(t0, ib.e);
     }
     __syncthreads();
     const float thr = __uint_as_float(thr_sh);
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 3) void sparse_pair5_kernel(SparseArgs a) {
       if (wave == i && i < cnt) {     // (wave i: item i's threshold)
         const uint32_t c0 = wave_sort32(colmin[i][lane]);
         const uint32_t t0 = __shfl(c0, a.L - 1, 64);
-        if (lane == 0) thr_sh[i] = (a.ablate & 8) ? 0x7f800000u : widen_threshold5(t0, ib[i].e);
+        if (lane == 0) thr_sh[i] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, ib[i].e);
       }
     }
     __syncthreads();

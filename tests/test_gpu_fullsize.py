@@ -65,12 +65,11 @@ def test_config3_ivfadc_batch_3m(oracle):
     # kept by the scan and refined by the merge): the proven bracket [d_lo, d_lo + E] is compared with the
     # reference's distance for EVERY probed row of this batch, and the lists must not change.
     gi0, gd0 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
-    for kernel in (5, 4):   # both filter + refine scans (int16 / fp32 slabs)
+    for kernel in (5,):   # the filter + refine scan
         idx.set_option("fused_kernel", kernel)
         gi1, gd1 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
         assert np.array_equal(gi0, gi1) and np.array_equal(gd0.view(np.uint32), gd1.view(np.uint32)), f"kernel {kernel}"
-        idx.set_option("fused_ablate", 8)
-        idx.set_option("merge_ablate", 32)
+        idx.set_option("check_brackets", 1)
         before = idx.bound_checked()
         gi1, gd1 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
         rows = idx.last_scanned_rows()
@@ -78,17 +77,16 @@ def test_config3_ivfadc_batch_3m(oracle):
         assert idx.bound_checked() - before == rows, f"{idx.bound_checked() - before} brackets checked, {rows} rows probed"
         assert idx.bound_violations() == 0
         assert np.array_equal(gi0, gi1) and np.array_equal(gd0.view(np.uint32), gd1.view(np.uint32))
-        idx.set_option("fused_ablate", 0)
-        idx.set_option("merge_ablate", 0)
+        idx.set_option("check_brackets", 0)
     idx.set_option("fused_kernel", 5)
     # the coarse filter + refine's bracket for EVERY (query, cell) pair of the batch (1024 x 1000)
-    idx.set_option("coarse_refine_all", 1)
+    idx.set_option("check_brackets", 2)
     before = idx.coarse_bound_checked()
     gi2, gd2 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
     assert idx.coarse_bound_checked() - before == 1024 * 1000
     assert idx.bound_violations() == 0
     assert np.array_equal(gi0, gi2) and np.array_equal(gd0.view(np.uint32), gd2.view(np.uint32))
-    idx.set_option("coarse_refine_all", 0)
+    idx.set_option("check_brackets", 0)
     idx.set_option("coarse_approx", 0)     # every coarse distance exact (coarse_tile_kernel)
     gi2, gd2 = idx.search(qs, 5, 10, sentinel=1000.0, found_rule=0)
     assert np.array_equal(gi0, gi2) and np.array_equal(gd0.view(np.uint32), gd2.view(np.uint32))

@@ -177,7 +177,7 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
     idx.close()
 
 
-@pytest.mark.parametrize("variant", ["3", "4", "5"])
+@pytest.mark.parametrize("variant", ["3", "5"])
 @pytest.mark.parametrize("K", [256, 1024])
 def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
     """The cell-grouped scans (FREDDY_GPU_FUSED_KERNEL: 3 = the reference's arithmetic for every row,
@@ -196,31 +196,6 @@ def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
                             found_rule=gpu.FOUND_ROWS if rule == 0 else gpu.FOUND_ACCEPTED)
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0 if rule == 0 else 100.0, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"variant {variant} K={K} k={k} W={W} rule={rule}")
-    idx.close()
-
-
-@pytest.mark.parametrize("C,Q,W,k,rule", [(32, 200, 4, 5, 0), (32, 200, 1, 3, 1), (32, 64, 2, 32, 0), (3, 300, 2, 5, 0), (128, 48, 3, 5, 0), (32, 1000, 6, 5, 2)])
-def test_scan_direct_mode_equals_the_work_table_path(gpu, oracle, C, Q, W, k, rule):
-    """fused5.h DIRECT mode: the scan's workgroups claim static (cell, chunk) units and cut them into entries from the cells'
-    item counts; the record fields come from static slots the probe plan filled -- no work-table and no record kernel.
-    Same lists as the work-table path and as the oracle: cells with several entries (hundreds of items), lists of two
-    chunks (C = 3: ~6 700 rows), mostly EMPTY cells (48 queries x 3 probes over 128 cells: bubbles of the unit pipeline),
-    both found rules and the batch UDF's rule."""
-    N = 20000
-    t = util.ivf_tables(N=N, C=C, K=256)
-    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
-    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
-    idx.set_option("fused", 1)
-    _, qs = util.queries_from_corpus(N, Q)
-    W_ = 1 if rule == 2 else W
-    sentinel = 1000.0 if rule == 0 else 100.0
-    fr = {0: gpu.FOUND_ROWS, 1: gpu.FOUND_ACCEPTED, 2: gpu.FOUND_BATCH_UDF}[rule]
-    exp = oracle.ivfadc_batch_search(ot, qs, k) if rule == 2 else oracle.ivfadc_search_many(ot, qs, k, W_, sentinel=sentinel, found_rule=rule)
-    for direct in (1, 0):
-        idx.set_option("direct", direct)
-        gi, gd = idx.search(qs, k, W_, sentinel=sentinel, found_rule=fr)
-        util.assert_same_lists(gi, gd, exp, f"direct={direct} C={C} Q={Q} W={W_} k={k} rule={rule}")
-    assert idx.bound_violations() == 0
     idx.close()
 
 
@@ -525,7 +500,7 @@ def test_exact_knn_filter_bracket_holds_for_every_row(gpu, oracle):
     ids = np.arange(1, N + 1, dtype=np.int32)
     idx = gpu.VectorIndex(ids, x)
     qs = np.concatenate([x[::777][:20], rng.standard_normal((4, x.shape[1])).astype(np.float32) * np.float32(0.01)])
-    idx.set_option("exact_refine_all", 1)
+    idx.set_option("check_brackets", 4)
     gi, gs = idx.search(qs, 5)
     assert idx.bound_violations() == 0
     assert int(idx.lib.freddy_gpu_filter_bound_checked(idx.h)) == qs.shape[0] * N
@@ -761,8 +736,7 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     for scale in (1.0, 1e-12, 8.0):   # (x8: coarse distances stay below the probe plan's limit of 100)
         t, ot, idx, qs = _fr_setup(gpu, oracle, scale=scale)
-        idx.set_option("fused_ablate", 8)
-        idx.set_option("merge_ablate", 32)
+        idx.set_option("check_brackets", 1)
         qs = qs[:48]
         gi, gd = idx.search(qs, 5, 2, sentinel=1000.0, found_rule=0)
         exp = oracle.ivfadc_search_many(ot, qs, 5, 2, sentinel=1000.0, found_rule=0)
@@ -776,26 +750,24 @@ def test_filter_refine_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
 # item-wise scan of thin cells (sparse5.h): the same brackets, regions and lists as the cell-grouped scan
 # ---------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("pairs", [1, 0])
 @pytest.mark.parametrize("K", [256, 1024])
-def test_sparse_item_scan_matches_oracle(gpu, oracle, K, pairs, monkeypatch):
+def test_sparse_item_scan_matches_oracle(gpu, oracle, K, monkeypatch):
     """Option sparse_items < 0 forces the item-wise scan for every cell with at most that many items: all cells (-16: the
     cell-grouped scan gets nothing), a mix (-2), none (0); every rule of counting found rows; multi-round searches.
-    sparse_pairs: cells of exactly two items as one unit (their rows read once) or as two."""
+    Cells of exactly two items are one unit (their rows read once)."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     t, ot, idx, qs = _fr_setup(gpu, oracle, K=K, dup_rows=3)
-    idx.set_option("sparse_pairs", pairs)
     for force in (-16, -2, 0):
         idx.set_option("sparse_items", force)
         for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 4, 1, 100.0), (5, 1, 2, 100.0), (32, 2, 0, 1000.0)):
             gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
             exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} pairs {pairs} K={K} k={k} W={W} rule={rule}")
+            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} K={K} k={k} W={W} rule={rule}")
         # few queries: most probed cells have one or two items (the pair units' case)
         for nq in (2, 7):
             gi, gd = idx.search(qs[:nq], 5, 3, sentinel=1000.0, found_rule=0)
             exp = oracle.ivfadc_search_many(ot, qs[:nq], 5, 3, sentinel=1000.0, found_rule=0)
-            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} pairs {pairs} K={K} {nq} queries")
+            util.assert_same_lists(gi, gd, exp, f"sparse_items {force} K={K} {nq} queries")
     assert idx.bound_violations() == 0
     idx.close()
 
@@ -807,8 +779,7 @@ def test_sparse_item_scan_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
     for scale in (1.0, 1e-12, 8.0):
         t, ot, idx, qs = _fr_setup(gpu, oracle, scale=scale)
         idx.set_option("sparse_items", -16)
-        idx.set_option("fused_ablate", 8)
-        idx.set_option("merge_ablate", 32)
+        idx.set_option("check_brackets", 1)
         g2, d2 = idx.search(qs[:12], 5, 2, sentinel=1000.0, found_rule=0)   # (many cells with exactly two items: pair units)
         util.assert_same_lists(g2, d2, oracle.ivfadc_search_many(ot, qs[:12], 5, 2, sentinel=1000.0, found_rule=0), f"12 queries, scale {scale}")
         qs = qs[:48]
@@ -837,12 +808,12 @@ def test_one_byte_code_layout_equals_the_int16_layout(gpu, oracle, monkeypatch):
                 util.assert_same_lists(gi, gd, exp, f"codes_u8={u8} sparse_items={sparse} k={k} W={W} rule={rule}")
     # every probed row through the exact stage: the brackets of the byte layout
     idx.set_option("sparse_items", 0); idx.set_option("codes_u8", 1)
-    idx.set_option("fused_ablate", 8); idx.set_option("merge_ablate", 32)
+    idx.set_option("check_brackets", 1)
     before = idx.bound_checked()
     gi, gd = idx.search(qs[:48], 5, 2, sentinel=1000.0, found_rule=0)
     util.assert_same_lists(gi, gd, oracle.ivfadc_search_many(ot, qs[:48], 5, 2, sentinel=1000.0, found_rule=0), "every row, byte layout")
     assert idx.bound_checked() - before > 20000
-    idx.set_option("fused_ablate", 0); idx.set_option("merge_ablate", 0)
+    idx.set_option("check_brackets", 0)
     # appended rows
     rng = np.random.default_rng(3)
     n_new = 500
@@ -891,32 +862,6 @@ def test_sparse_item_scan_by_its_own_rule(gpu, oracle, monkeypatch):
     idx.close()
 
 
-@pytest.mark.gpu
-def test_combined_coarse_table_launch_matches_separate_kernels(gpu, oracle, monkeypatch):
-    """coarse_table5_kernel (cell-selection tiles and query-table units as the workgroups of one launch) against the two
-    kernels launched separately (option fuse_table = 0): the same lists, bit for bit, and the oracle's; batch sizes that
-    leave partial tiles / query groups."""
-    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
-    t, ot, idx, qs = _fr_setup(gpu, oracle, K=1024)
-    for Q in (120, 33, 17):
-        q = qs[:Q]
-        exp = oracle.ivfadc_search_many(ot, q, 5, 3, sentinel=1000.0, found_rule=0)
-        res = []
-        for fuse in (1, 0):
-            idx.set_option("fuse_table", fuse)
-            idx.profile_enable(True)
-            gi, gd = idx.search(q, 5, 3, sentinel=1000.0, found_rule=0)
-            prof = idx.profile_read()
-            idx.profile_enable(False)
-            if Q >= 32:   # (below 32 queries the cell-selection distances are exact and a kernel of their own either way)
-                assert ("coarse_table" in prof) == bool(fuse), sorted(prof)
-            util.assert_same_lists(gi, gd, exp, f"fuse_table {fuse} Q={Q}")
-            res.append((gi, gd))
-        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1].view(np.uint32), res[1][1].view(np.uint32))
-    assert idx.bound_violations() == 0
-    idx.close()
-
-
 # ---------------------------------------------------------------------------------------
 # coarse-cell selection as filter + refine (coarse.h): MFMA distances with a proven bracket, the reference's
 # squareDistance for the candidate cells only
@@ -932,12 +877,12 @@ def test_coarse_filter_refine_every_cell(gpu, oracle, scale, monkeypatch):
     for k, W, rule, sent in ((5, 3, 0, 1000.0), (3, 1, 1, 100.0), (8, 10, 0, 1000.0)):
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
         idx.set_option("coarse_approx", 1)
-        idx.set_option("coarse_refine_all", 1)
+        idx.set_option("check_brackets", 2)
         before = idx.coarse_bound_checked()
         gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"coarse refine all, scale {scale} k={k} W={W}")
         assert idx.coarse_bound_checked() - before >= len(qs) * C      # first round: every cell of every query
-        idx.set_option("coarse_refine_all", 0)
+        idx.set_option("check_brackets", 0)
         gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"coarse filter + refine, scale {scale} k={k} W={W}")
         idx.set_option("coarse_approx", 0)
@@ -993,22 +938,20 @@ def _every_row_check(idx, oracle, ot, qs, k, W, what, kernel=5):
     proven bracket with the reference's distance for ALL of them.  Returns the lists."""
     idx.set_option("fused", 1)
     idx.set_option("fused_kernel", kernel)
-    idx.set_option("fused_ablate", 8)
-    idx.set_option("merge_ablate", 32)
+    idx.set_option("check_brackets", 1)
     before = idx.bound_checked()
     gi, gd = idx.search(qs, k, W, sentinel=1000.0, found_rule=0)
     checked = idx.bound_checked() - before
     rows = idx.last_scanned_rows()
     assert checked == rows, f"{what}: {checked} brackets checked, {rows} rows probed"
     assert idx.bound_violations() == 0, f"{what}: a row's distance left its proven bracket"
-    idx.set_option("fused_ablate", 0)
-    idx.set_option("merge_ablate", 0)
+    idx.set_option("check_brackets", 0)
     exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0, found_rule=0)
     util.assert_same_lists(gi, gd, exp, what)
     return gi, gd
 
 
-@pytest.mark.parametrize("kernel", [4, 5])
+@pytest.mark.parametrize("kernel", [5])
 def test_filter_refine_bracket_every_row_K1024(gpu, oracle, kernel, monkeypatch):
     """The instantiations the benchmark runs -- ivf_filter5_kernel<12, true> / ivf_filter_kernel<12, true>, K = 1024 --
     in the every-row mode: brackets checked == rows probed, none violated, lists equal to the oracle's, to the exact
@@ -1066,27 +1009,26 @@ def test_filter_refine_adversarial_fixed_point(gpu, oracle, kind, monkeypatch):
             qs[i, p * 25:(p + 1) * 25] *= np.float32(40.0 if i % 2 else 6.0)
     for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 2, 1, 100.0)):
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-        for kernel in (5, 4):
+        for kernel in (5,):
             idx.set_option("fused_kernel", kernel)
             gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
             util.assert_same_lists(gi, gd, exp, f"{kind} kernel={kernel} k={k} W={W} rule={rule}")
     assert idx.bound_violations() == 0
-    for kernel in (5, 4):
+    for kernel in (5,):
         _every_row_check(idx, oracle, ot, qs[:40], 5, 2, f"{kind}, every row, kernel {kernel}", kernel)
     idx.close()
 
 
-@pytest.mark.parametrize("arrange", ["0", "1"])
-def test_row_order_inside_a_list_is_free(gpu, oracle, arrange, monkeypatch):
+def test_row_order_inside_a_list_is_free(gpu, oracle, monkeypatch):
     """The pin-time arrangement of the rows inside a list (against LDS bank conflicts in the scans) must
-    not be observable: same lists with it and without, on every scan path."""
-    monkeypatch.setenv("FREDDY_GPU_ARRANGE_ROWS", arrange)
+    not be observable: the oracle's lists (canonical scan order = ascending id) on every scan path."""
+    arrange = "1"
     t = util.ivf_tables(N=20000, C=32, K=256)
     ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
     _, qs = util.queries_from_corpus(20000, 150)
     exp = oracle.ivfadc_search_many(ot, qs, 10, 3, sentinel=1000.0, found_rule=0)
-    for fused, variant in ((1, 5), (1, 4), (1, 3), (0, 4)):
+    for fused, variant in ((1, 5), (1, 3), (0, 5)):
         idx.set_option("fused", fused)
         idx.set_option("fused_kernel", variant)
         gi, gd = idx.search(qs, 10, 3, sentinel=1000.0, found_rule=0)
@@ -1154,8 +1096,7 @@ def test_searches_on_two_streams_overlap_safely(gpu, oracle):
 def test_in_flight_instantiations_match_oracle(gpu, oracle, K, monkeypatch):
     """scan_share > 1 -- the caller keeps batches in flight -- selects the small-footprint instantiations: ONE wave per query
     in the cell-selection plan (probe_plan2_kernel<0, false, 1>: seven candidates per round, the whole 300-dimensional query
-    staged by 64 lanes) and in the merge (merge_refine_kernel<25, 12, 1>).  Same lists as the oracle, with options plan_waves
-    = 4 / merge_waves = 4 (the one-batch instantiations) and without; every probed row's bracket holds."""
+    staged by 64 lanes) and in the merge (merge_refine_kernel<25, 12, 1>).  Same lists as the oracle; every probed row's bracket holds."""
     import torch
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     dev = torch.device("cuda", 0)
@@ -1170,8 +1111,7 @@ def test_in_flight_instantiations_match_oracle(gpu, oracle, K, monkeypatch):
     idx.set_option("scan_share", 4)
     for k, W, rule, sent in ((5, 10, 0, 1000.0), (10, 4, 1, 100.0), (5, 32, 0, 1000.0)):
         exp = oracle.ivfadc_search_many(ot, qa, k, W, sentinel=sent, found_rule=rule)
-        for plan_waves, merge_waves in ((0, 0), (4, 4)):
-            idx.set_option("plan_waves", plan_waves); idx.set_option("merge_waves", merge_waves)
+        for plan_waves in (0,):
             res = torch.zeros((2, 300, k), dtype=torch.int32, device=dev)
             with torch.cuda.stream(stream):
                 idx.search_dev(dq.data_ptr(), 300, k, W, sent, rule, res[0].data_ptr(), res[1].data_ptr(), st.data_ptr(), stream.cuda_stream)
@@ -1183,42 +1123,6 @@ def test_in_flight_instantiations_match_oracle(gpu, oracle, K, monkeypatch):
                                    f"in flight K={K} k={k} W={W} rule={rule} plan_waves={plan_waves}")
     assert idx.bound_violations() == 0
     idx.set_option("scan_share", 1)
-    idx.close()
-
-
-@pytest.mark.parametrize("partition", [32, -16])
-def test_cu_partitioned_streams_give_the_same_lists(gpu, oracle, partition):
-    """Option partition_cus: the small kernels of a batch on a stream masked to R CUs and the scan on
-    a stream masked to the rest (R > 0), or only the scan masked (R < 0), chained by events to the caller's stream.
-    Five batches in flight on five streams (more than the runtime's four default hardware queues), host-buffer call
-    afterwards on the same handle: the lists are the oracle's in every mode."""
-    import torch
-    dev = torch.device("cuda", 0)
-    N = 60000
-    t = util.ivf_tables(N=N, C=64, K=256)
-    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
-    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
-    idx.set_option("partition_cus", partition)
-    _, qa = util.queries_from_corpus(N, 300)
-    qs = [np.ascontiguousarray(np.roll(qa, 7 * i, axis=0) * np.float32(1.0 + 0.01 * i)) for i in range(5)]
-    exp = [oracle.ivfadc_search_many(ot, q, 5, 4, sentinel=1000.0, found_rule=0) for q in qs]
-    dq = [torch.from_numpy(q).to(dev) for q in qs]
-    res = [torch.zeros((2, 300, 5), dtype=torch.int32, device=dev) for _ in qs]
-    st = torch.zeros(4, dtype=torch.int32, device=dev)
-    streams = [torch.cuda.Stream(dev) for _ in qs]
-    torch.cuda.synchronize(dev)
-    for rounds in range(4):
-        for i in range(len(qs)):
-            with torch.cuda.stream(streams[i]):
-                res[i].zero_()
-                idx.search_dev(dq[i].data_ptr(), 300, 5, 4, 1000.0, gpu.FOUND_ROWS, res[i][0].data_ptr(), res[i][1].data_ptr(),
-                               st.data_ptr(), streams[i].cuda_stream)
-    torch.cuda.synchronize(dev)
-    for i in range(len(qs)):
-        util.assert_same_lists(res[i][0].cpu().numpy(), res[i][1].view(torch.float32).cpu().numpy(), exp[i], f"stream {i}")
-    got_i, got_d = idx.search(qs[1], 5, 4, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
-    util.assert_same_lists(got_i, got_d, exp[1], "host-buffer call")
-    assert idx.bound_violations() == 0
     idx.close()
 
 
@@ -1325,13 +1229,13 @@ def test_coarse_filter_refine_beyond_1024_cells(gpu, oracle, kind, monkeypatch):
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
         idx.set_option("coarse_approx", 1)
         if kind == "refine_all":
-            idx.set_option("coarse_refine_all", 1)
+            idx.set_option("check_brackets", 2)
             before = idx.coarse_bound_checked()
         gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"{kind}: streamed plan k={k} W={W} rule={rule}")
         if kind == "refine_all":
             assert idx.coarse_bound_checked() - before >= len(qs) * C
-            idx.set_option("coarse_refine_all", 0)
+            idx.set_option("check_brackets", 0)
         idx.set_option("coarse_approx", 0)
         gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
         util.assert_same_lists(gi, gd, exp, f"{kind}: all-exact coarse kernel k={k} W={W} rule={rule}")
