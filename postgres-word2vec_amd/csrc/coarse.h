@@ -312,7 +312,7 @@ __device__ __forceinline__ void coarse_approx16_body(const float* __restrict__ q
 }
 // LDS of the f16-split tile: [T][2][64] fragments + row norms + scales
 __host__ __device__ inline size_t coarse_approx16_lds(int d) { return (size_t)((d + 15) >> 4) * 128 * 16 + 128 * 4 + 32 * 4 + 32 * 4; }
-__global__ __launch_bounds__(256) void coarse_approx16_kernel(const float* __restrict__ queries, const ch8v* __restrict__ coarseH, int ec,
+static __global__ __launch_bounds__(256) void coarse_approx16_kernel(const float* __restrict__ queries, const ch8v* __restrict__ coarseH, int ec,
                                                              const float* __restrict__ cn2, float* __restrict__ out,
                                                              float* __restrict__ qn2, int Q, int Cpad, int d, ZeroArgs z,
                                                              float* __restrict__ tmin, int C) {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void coarse_approx16_kernel(const float* __res
   coarse_approx16_body(queries, coarseH, ec, cn2, out, qn2, Q, Cpad, d, z, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem, tmin, C);
 }
 
-__global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
+static __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* __restrict__ queries, const float* __restrict__ coarseF,
                                                            const float* __restrict__ cn2, float* __restrict__ out,
                                                            float* __restrict__ qn2, int Q, int Cpad, int d, int dp, ZeroArgs z,
                                                            float* __restrict__ tmin = nullptr, int C = 0) {

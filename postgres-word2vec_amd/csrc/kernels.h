@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64) void probe_plan_kernel(PlanArgs a) {
 // a8 residual r = q - cq[cell], elementwise binary32 (freddy.c:296-303, :876-879)
 // ---------------------------------------------------------------------------------------
 // Output row layout: [m][SP] with each position's S values padded to SP (SP == S: dense [d]).
-__global__ __launch_bounds__(WG) void residual_kernel(const float* __restrict__ queries,
+static __global__ __launch_bounds__(WG) void residual_kernel(const float* __restrict__ queries,
                                                      const float* __restrict__ coarse,
                                                      const int32_t* __restrict__ item_cell,
                                                      const int32_t* __restrict__ item_query,
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(WG) void encode_pq_kernel(const float* __restrict__
 
 // Coarse assignment: nearest of C centroids by squareDistance over all d dimensions, lowest index on
 // ties (faiss IndexFlatL2 search k=1 / ivfadc.py); one wave per vector, lane <-> centroid.
-__global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restrict__ vecs, const float* __restrict__ coarseT,
+static __global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restrict__ vecs, const float* __restrict__ coarseT,
                                                           int32_t* __restrict__ cell, int n, int C, int Cpad, int d,
                                                           float limit, int32_t* __restrict__ too_far) {
   const int it = blockIdx.x, lane = threadIdx.x;
@@ -595,13 +595,13 @@ __global__ __launch_bounds__(64) void assign_coarse_kernel(const float* __restri
 // dimension-parallel, member-sequential -- a binary32 sum in a fixed order, so the result does not depend on
 // the launch and equals the restatement in oracle/ bit for bit.  An empty cluster keeps its centroid.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kmeans_transpose_kernel(const float* __restrict__ cent, float* __restrict__ centT, int k, int kpad, int d) {
+static __global__ __launch_bounds__(256) void kmeans_transpose_kernel(const float* __restrict__ cent, float* __restrict__ centT, int k, int kpad, int d) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= d * kpad) return;
   const int dim = i / kpad, c = i - dim * kpad;
   centT[i] = c < k ? cent[(size_t)c * d + dim] : 0.0f;
 }
-__global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ vecs, const int32_t* __restrict__ assign, int64_t n,
+static __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restrict__ vecs, const int32_t* __restrict__ assign, int64_t n,
                                                            int d, float* __restrict__ cent) {
   __shared__ int32_t members[256];
   __shared__ int wcount[4];
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void kmeans_update_kernel(const float* __restr
 }
 
 // generic sub-vector size (runtime S): no register cache, codebook streamed from L2
-__global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __restrict__ vecs,
+static __global__ __launch_bounds__(WG) void lut_build_generic_kernel(const float* __restrict__ vecs,
                                                               const int32_t* __restrict__ item_cell,
                                                               const float* __restrict__ cbT,
                                                               float* __restrict__ lut, int n_items,
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(WG) void grouping_kernel(const float* __restrict__ 
 // pq_search_in: gather the packed codes of a row subset into a temporary list
 // ("SELECT id, vector FROM pq_quantization WHERE id IN (...)", freddy.c:1100-1114)
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(WG) void gather_rows_kernel(const int32_t* __restrict__ rows, int n_rows,
+static __global__ __launch_bounds__(WG) void gather_rows_kernel(const int32_t* __restrict__ rows, int n_rows,
                                                         const uint32_t* __restrict__ packed,
                                                         uint32_t* __restrict__ packed_out,
                                                         int32_t* __restrict__ pos_out, int M2,

@@ -99,7 +99,7 @@ __device__ __forceinline__ uint32_t widen_threshold(uint32_t tau_bits, float E) 
 // rterm[row] = sum_p (|c|^2 + 2 co_p . c) over the row's 12 codewords c and its cell's centroid co, in fp64,
 // rounded once (pin time).  The part of the cheap distance that depends on (cell, row) only: it is the
 // initial value of the row's running sum, so the scan streams nothing per cell.
-__global__ __launch_bounds__(256) void row_term_kernel(const uint32_t* __restrict__ packed, const int32_t* __restrict__ blk_cell,
+static __global__ __launch_bounds__(256) void row_term_kernel(const uint32_t* __restrict__ packed, const int32_t* __restrict__ blk_cell,
                                                       const float* __restrict__ coarse, const float* __restrict__ cbR,
                                                       float* __restrict__ rterm, int64_t n_slots, int M2, int d, int m, int K, int S) {
   const int64_t slot = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -34,7 +34,7 @@ static constexpr int FUSED_UNIT_BLOCKS = FUSED_RMAX * FUSED_NW;   // 64 row bloc
 // cell x 4096-row chunk; first = index into cell_items), so the fused kernels' grids have no holes, in
 // longest-processing-time-first order: entries with more items (more slab arithmetic) are pulled first,
 // the tail of the launch is made of small entries (counting sort on (items, rows) classes).
-__global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
+static __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* __restrict__ cell_count, int C, int cell_cap, int gsz,
                                                          const int32_t* __restrict__ blk_off, int32_t* __restrict__ out_cell,
                                                          int32_t* __restrict__ out_first, int32_t* __restrict__ out_cnt,
                                                          int32_t* __restrict__ n_groups, int cost_mode,
@@ -186,7 +186,7 @@ struct MergeSurvArgs {
 // One wave per query.  Lane <-> survivor region: the query's W items x upi chunks x 8 waves regions
 // mostly hold one or two keys each, so the lanes walk their own regions in lock step and feed the
 // streaming selection one key per lane and step.
-__global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
+static __global__ __launch_bounds__(64) void merge_surv_kernel(MergeSurvArgs a) {
   __shared__ u64 stage[64];
   const int x = blockIdx.x, lane = threadIdx.x;
   const int q = a.active ? a.active[x] : x;

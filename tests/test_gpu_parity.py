@@ -181,7 +181,7 @@ def test_ivfadc_matches_oracle(gpu, oracle, K, W, fused, monkeypatch):
 @pytest.mark.parametrize("K", [256, 1024])
 def test_fused_kernel_variants(gpu, oracle, K, variant, monkeypatch):
     """The cell-grouped scans (FREDDY_GPU_FUSED_KERNEL: 3 = the reference's arithmetic for every row,
-    fused3.h; 4 = filter + refine with fp32 slabs, fused4.h; 5 = filter + refine with int16 slabs, fused5.h)
+    fused3.h; 5 = filter + refine with int16 slabs, fused5.h)
     against the oracle: many queries per cell (entries of
     every size incl. split cells), both found rules, k up to 32."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
@@ -650,7 +650,7 @@ def test_hip_path_reproduces_committed_golden_vectors(gpu, monkeypatch):
 
 
 # ---------------------------------------------------------------------------------------
-# filter + refine scan (fused4.h, the default for batches): the cases its bounds have to survive
+# filter + refine scan (fused5.h + refine.h, the default for batches): the cases its bounds have to survive
 # ---------------------------------------------------------------------------------------
 def _fr_setup(gpu, oracle, K=256, scale=1.0, dup_rows=0):
     t = dict(util.ivf_tables(N=20000, C=32, K=K))
