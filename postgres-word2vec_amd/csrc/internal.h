@@ -104,13 +104,18 @@ struct Workspace {
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
       w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_tmin, w_one, w_oneb;
+  // the batch's table scale, formed inside the launch that builds the query x codebook table (fused5.h ScaleSync): two maxima
+  // taken in turn, a counter of arrived producers that only grows; the host keeps the running target
+  DevBuf w_scale;
+  uint32_t scale_calls = 0, scale_arrived = 0;
+  bool scale_pending = false;     // a call was prepared and its launch not confirmed (an error in between): the words are cleared before the next use
   uint64_t one_shape = 0;          // the one-launch kernels' buffer (w_oneb): shape of the call that wrote it last, and that call's epoch (one.h)
   uint32_t one_epoch = 0;
   void release() {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb, &w_scale};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -305,6 +310,10 @@ int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_it
 int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a);
 int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int32_t* item_cell, float* lut, int n_items,
                const float* coarse = nullptr, const int32_t* item_query = nullptr);
+namespace freddy { struct ScaleSync; }
+// the hand-off words of the batch's table scale for a launch with n_norm producer workgroups (enqueued on s); confirm after the launch
+int scale_sync_prepare(Workspace* ws, hipStream_t s, int n_norm, freddy::ScaleSync* z);
+inline void scale_sync_confirm(Workspace* ws) { ws->scale_pending = false; }
 int ivf_work_table(IvfRun& r, WorkTable& wt);
 int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt);
 int max_queries_per_chunk(const freddy_gpu_index* ix, int W);

@@ -96,6 +96,24 @@ int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int
 // IVFADC
 // ---------------------------------------------------------------------------------------
 
+int scale_sync_prepare(Workspace* ws, hipStream_t s, int n_norm, ScaleSync* z) {
+  const bool fresh = ws->w_scale.p == nullptr;
+  if (ws->w_scale.ensure(4 * sizeof(uint32_t))) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (fresh || ws->scale_pending) {
+    HIP_TRY(hipMemsetAsync(ws->w_scale.p, 0, 4 * sizeof(uint32_t), s));
+    ws->scale_calls = 0; ws->scale_arrived = 0;
+  }
+  uint32_t* w = ws->w_scale.as<uint32_t>();
+  z->tmax_cur = w + (ws->scale_calls & 1u);
+  z->tmax_next = w + ((ws->scale_calls + 1u) & 1u);
+  z->arrived = w + 2;
+  ws->scale_arrived += (uint32_t)n_norm;
+  z->target = ws->scale_arrived;
+  ws->scale_calls += 1;
+  ws->scale_pending = true;
+  return 0;
+}
+
 // coarse distances (a6/a7) of every query of the chunk, and -- for the filter + refine scan -- the
 // per-batch query x codebook table beside them on the side stream
 static int ivf_coarse(IvfRun& r) {
@@ -158,21 +176,28 @@ static int ivf_coarse(IvfRun& r) {
     ct.cbT = ix->cbF; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
     ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K; ct.tmin = tile_min; ct.C = C;
     ct.coarseH = (const ch8v*)ix->coarseH; ct.ec = ix->coarse_ec;
+    const int n_norm = (Q + 15) / 16;
+    if (int rc = scale_sync_prepare(ws, s, n_norm, &ct.ss)) return rc;
     const size_t lds = std::max<size_t>(ix->coarseH ? coarse_approx16_lds(d) : (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
-    const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
+    const unsigned grid = (unsigned)(n_norm + ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
     timed_launch(ix, s, "coarse_table", [&] {
       if (ix->coarseH) hipLaunchKernelGGL((coarse_table5_kernel<25, 16, true>), dim3(grid), dim3(256), lds, s, ct);
       else hipLaunchKernelGGL((coarse_table5_kernel<25, 16>), dim3(grid), dim3(256), lds, s, ct);
     });
     HIP_TRY(hipGetLastError());
+    scale_sync_confirm(ws);
     return 0;
   }
   if (r.fused && r.scan_kernel == 5) {
+    ScaleSync z;
+    const int n_norm = (Q + 15) / 16;
+    if (int rc = scale_sync_prepare(ws, s, n_norm, &z)) return rc;
     timed_launch(ix, s, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, r.d_q, ix->cbF, ix->cmaxp,
-                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
+      hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3((unsigned)(n_norm + m * n_norm)), dim3(256), 0, s, r.d_q, ix->cbF, ix->cmaxp,
+                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K, z);
     });
     HIP_TRY(hipGetLastError());
+    scale_sync_confirm(ws);
   }
   return launch_coarse();
 }
@@ -317,7 +342,7 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
   // LDS: slabs [2 buffers][2 positions][K][16 items] int16, then column minima / thresholds, two entry records, row terms
   const size_t desc_off = (size_t)4 * SCAN5_G * 2 * K;
-  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
+  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + (4096 + 8) * sizeof(float);
   fl.desc_offset = (uint32_t)desc_off;
   // One persistent workgroup per CU (LDS admits exactly one), never more than there is work.  Batches in flight share the
   // chip: a persistent scan that took every CU would hold up the small kernels of the other batches until it drains, and
