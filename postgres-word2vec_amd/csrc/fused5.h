@@ -86,23 +86,25 @@ __device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_
 // searches google_vecs_norm, freddy--0.0.1.sql) the scales of a batch differ by a few per cent.
 //
 // The maximum is formed inside the launch that builds the table: the FIRST workgroups of the grid (one per 16 queries:
-// query_norms5_body) write qn[q][p] = |q_p| (rounded up), fold max_p 2 |q_p| max|c_p| into tmax[cur] with an atomic
-// maximum (values are >= +0: the order of the bits is the order of the floats; a query with non-finite components takes
-// no part -- its margin E is not finite and all its rows go to the exact stage) and count themselves in `arrived`; every workgroup that needs
-// T polls `arrived` until it reaches `target` (workgroups are dispatched in grid order, so the producers are resident or
-// done when a consumer starts: the wait is bounded by their ~2 us).  Nothing is reset by the host: `arrived` only grows
-// (the host keeps the running target per workspace) and the calls alternate between two maxima, each call's first
-// producer clearing the word of the NEXT call (the stream serialises the calls of a workspace).
+// query_norms5_body) write qn[q][p] = |q_p| (rounded up) and ONE word each: the largest 2 |q_p| max|c_p| of their queries
+// (>= +0, so the sign bit is free) with the call's EPOCH in bit 31 -- a word validates itself, there is no counter and no
+// same-address atomic (256 atomic maxima on one word took 25 us).  A workgroup that needs T reads the n words (wave 0: lane <->
+// word, again until every word carries the epoch), takes their maximum and hands it to its other waves through LDS.
+// Workgroups are dispatched in grid order, so the producers are resident or done when a consumer starts; a consumer asks
+// after its own prologue and normally finds the words on its first read.  The host flips the epoch from call to call
+// while the number of words stays the same -- each call then overwrites exactly the words of its predecessor, which carry
+// the other epoch -- and clears the words when it changes (scale_sync_prepare).  A query with non-finite components takes
+// no part: its own margin E is not finite, so all its rows go to the exact stage.
 struct ScaleSync {
-  uint32_t* tmax_cur;    // this call's maximum (bits of a float >= +0)
-  uint32_t* tmax_next;   // the next call's: cleared by this call
-  uint32_t* arrived;     // producers done, all calls of the workspace
-  uint32_t target;       // value of `arrived` when this call's producers are all done
+  uint32_t* part;     // [n] partial maxima, bit 31 = epoch
+  int n;              // producer workgroups = (Q + 15) / 16
+  uint32_t epoch;     // 0 / 1
 };
 // producers: workgroup `blk` of 256 threads <-> queries 16 blk .. 16 blk + 15, 16 lanes per query, lane <-> position
 template <int S>
 __device__ __forceinline__ void query_norms5_body(const float* __restrict__ queries, const float* __restrict__ cmax, float* __restrict__ qn,
                                                   int Q, int d, int m, int blk, const ScaleSync z) {
+  __shared__ uint32_t wmax[4];
   const int tid = threadIdx.x;
   const int qi = tid >> 4, pp = tid & 15, q = blk * 16 + qi;
   float best = 0.0f;
@@ -112,23 +114,35 @@ __device__ __forceinline__ void query_norms5_body(const float* __restrict__ quer
     const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
     qn[(size_t)q * m + pp] = nrm;
     best = 2.0f * nrm * cmax[pp];
-    if (!(best < 3e38f)) best = 0.0f;   // (a query with non-finite components takes no part: its own margin E is not finite, so all its rows go to the exact stage)
+    if (!(best < 3e38f)) best = 0.0f;
   }
   uint32_t bb = __float_as_uint(best);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)bb, o, 64); bb = t > bb ? t : bb; }
-  if ((tid & 63) == 0 && bb != 0u) __hip_atomic_fetch_max(z.tmax_cur, bb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (blk == 0 && tid == 0) __hip_atomic_store(z.tmax_next, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((tid & 63) == 0) wmax[tid >> 6] = bb;
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(z.arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) {
+    uint32_t w = wmax[0];
+    w = wmax[1] > w ? wmax[1] : w; w = wmax[2] > w ? wmax[2] : w; w = wmax[3] > w ? wmax[3] : w;
+    __hip_atomic_store(z.part + blk, w | (z.epoch << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
-// consumers: the batch's table scale T (every thread of the workgroup gets it); a block-wide barrier inside
-__device__ __forceinline__ float batch_scale5(const ScaleSync z) {
-  if (threadIdx.x == 0)
-    while ((int32_t)(__hip_atomic_load(z.arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - z.target) < 0) __builtin_amdgcn_s_sleep(4);
+// consumers: the batch's table scale T for every thread of the workgroup (a block-wide barrier inside); `slot` = one LDS word
+__device__ __forceinline__ float batch_scale5(const ScaleSync z, uint32_t* slot) {
+  if (threadIdx.x < 64) {
+    uint32_t mx = 0u;
+    for (int i = threadIdx.x; i < z.n; i += 64) {
+      uint32_t w;
+      while (((w = __hip_atomic_load(z.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 31) != z.epoch) __builtin_amdgcn_s_sleep(8);
+      w &= 0x7fffffffu;
+      mx = w > mx ? w : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
+    if (threadIdx.x == 0) *slot = mx;
+  }
   __syncthreads();
-  const float best = __uint_as_float(__hip_atomic_load(z.tmax_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  return best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
+  return __uint_as_float(*slot) * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
 }
 
 // The table: values rint(-2 q_p . c / T) + bias(p), T the batch's scale (above);
@@ -140,8 +154,9 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
                                                      int Q, int d, int m, int K, int bx, int by, unsigned char* smem, const ScaleSync z) {
   static_assert(QT == 16, "one 16-lane group per query");
   constexpr int SP = (S + 3) & ~3;
-  // LDS from the caller: qs [QT][SP] floats
+  // LDS from the caller: qs [QT][SP] floats, one word for the batch's scale
   float (*qs)[SP] = reinterpret_cast<float (*)[SP]>(smem);
+  uint32_t* scale_slot = reinterpret_cast<uint32_t*>(smem + QT * SP * 4);
   const int tid = threadIdx.x, p = bx, q0 = by * QT;
   // MFMA path: the B operands of the wave's FIRST group of code slots are requested before anything else -- the codebook
   // round trip runs under the prologue and the wait for the batch's scale; the second
@@ -163,9 +178,8 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
   }
-  const float sc = batch_scale5(z);   // (barrier inside: qs is staged)
-  const float inv = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
-  if (p == 0 && tid < QT && q0 + tid < Q) qscale[q0 + tid] = sc;
+  __syncthreads();   // (qs)
+  float inv = 0.0f;   // 1 / T: asked for after the first group's matrix instructions -- the products do not depend on it
   {
     // The dot products on the matrix cores (v_mfma_f32_16x16x4_f32: A = 16 queries x 4 dimensions, B = 4 dimensions x 16
     // codes, seven steps for S = 25): a wave takes two groups of 16 code slots and, per group, the eight tiles whose codes
@@ -194,7 +208,12 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st][i][e], acc[i][e], 0, 0, 0);
-      if (gg == 0) load_b(g + 1);
+      if (gg == 0) {
+        load_b(g + 1);
+        const float sc = batch_scale5(z, scale_slot);
+        inv = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
+        if (p == 0 && tid < QT && q0 + tid < Q) qscale[q0 + tid] = sc;
+      }
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int qi = 4 * kq + reg;
@@ -213,7 +232,7 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
   }
 }
 template <int S, int QT>
-static constexpr int query_codebook5_lds() { return QT * ((S + 3) & ~3) * 4; }
+static constexpr int query_codebook5_lds() { return QT * ((S + 3) & ~3) * 4 + 16; }
 // grid: (Q + 15) / 16 norm workgroups, then m x (Q + 15) / 16 table units
 template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
@@ -287,6 +306,7 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
     if (rows > FUSED_UNIT_BLOCKS * 64) rows = FUSED_UNIT_BLOCKS * 64;
     rec[0] = cell; rec[1] = cnt; rec[2] = chunk; rec[3] = b0; rec[4] = nb; rec[5] = rows;
     rec[7] = (int32_t)__float_as_uint(a.qscale[a.item_query[a.sorted_item[first]]]);   // the batch's table scale T
+    rec[120] = (int32_t)__float_as_uint(a.listmin[cell]);                               // a lower bound of the rows' own terms
   }
   if (lane < 16) {
     const int it = lane < cnt ? a.sorted_item[first + lane] : -1;
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     typedef const char __attribute__((address_space(1))) * gptrc;
     typedef const u4 __attribute__((address_space(1))) * gptr4u;
     auto issue = [&](int set, int phase, const int (&qids)[8], int nh) {   // position 2 phase + hpos of the half's 8 items
-      if (half >= nh) return;
+      if (half >= nh || (a.fence & 32)) return;
       uint32_t voff = vq + (uint32_t)phase * 4096u;
       asm volatile("" : "+v"(voff));
 #pragma unroll
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     };
     // the eight table words of code pair b = li + 128 k interleaved: low halves -> half row b, high halves -> b + 512
     auto emit = [&](int set, unsigned char* dst, int nh) {
-      if (half >= nh) return;
+      if (half >= nh || (a.fence & 16)) return;
       unsigned char* dp = dst + qoff;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -422,22 +442,11 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         rtv[r] = a.rterm[(size_t)(uint32_t)(b0 + (bl < nbk - 1 ? bl : nbk - 1)) * 64u + (uint32_t)lane];
       }
     };
-    float rt_min = 0.0f;   // the smallest of this wave's staged row terms (the integer selection's common offset)
-    auto reduce_row_terms = [&]() {
-      float mn = rtv[0];
-#pragma unroll
-      for (int r = 1; r < RMAX; ++r) mn = fminf(mn, rtv[r]);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-      rt_min = mn;
-    };
     auto stash_row_terms = [&]() {
 #pragma unroll
       for (int r = 0; r < RMAX; ++r) rt_s[(r * NG + wave) * 64 + lane] = rtv[r];
-      if (lane == 0) rt_s[4096 + wave] = rt_min;
     };
     fetch_row_terms(dsc);
-    reduce_row_terms();
     stash_row_terms();
     issue(0, 0, qid, nq);
     issue(1, 1, qid, nq);
@@ -506,7 +515,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           colmin[i1 * 64 + lane] = 0xffffffffu;
         }
       }
-      reduce_row_terms();   // (the next entry's row terms, requested in phase 2; the gatherers are in their tail)
       lds_barrier();   // S1
       lds_barrier();   // S2 (the gatherers' survivor pass reads the CURRENT entry's staged row terms: the next entry's are staged in its phase 1)
       tick(3);
@@ -605,9 +613,11 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         load_codes(cwb, 1);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-          if (j & 1) gather(cwb, j); else gather(cwa, j);
+          if (!(a.fence & 2)) {
+            if (j & 1) gather(cwb, j); else gather(cwa, j);
+          }
           __builtin_amdgcn_sched_barrier(0);
-          if (j + 2 < NP) {   // the codes of phase j + 2 into the set phase j has just used
+          if (j + 2 < NP && !(a.fence & 64)) {   // the codes of phase j + 2 into the set phase j has just used
             if (j & 1) load_codes(cwb, j + 2); else load_codes(cwa, j + 2);
           }
           if (j + 1 < NP) lds_barrier();
@@ -654,34 +664,36 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         // INTEGER selection (the common rule: freddy.c:366 counts retrieved rows, nothing but the threshold test).  All items of
         // an entry share the batch's table scale T, so a row's own term joins the integer sum once per ROW:
         //   X(row, item) = U + Rq,   U = V + 2^15 the biased sum the gathers left (16 bits),  Rq = rint((rterm[row] - rmin) / T) >= 0,
-        // rmin = the smallest row term of the entry's rows (builders, one LDS word per builder wave).  T X is s' = T V + rterm
+        // rmin = the smallest row term of the entry's list (pin time, in the entry's record).  T X is s' = T V + rterm
         // shifted by a constant, +- (0.5 + 2^-6) T -- the selection needs only differences: with tau_X the L-th smallest lane
         // minimum of X, every row with X <= tau_X + WI survives, WI = ceil(E / T) + 2 (entry record).  Why that is enough:
         // T X is within e' = e + 0.52 T of the exact distance up to the item's constant (e as in the header: 107 u B + 6 T), the
         // rows that can matter have X <= X_(L) + 2 e' / T (X_(L) the L-th smallest X of the chunk, <= tau_X), and
         // E >= 4.2 e, e >= 6 T give WI > 2 e / T + 1.04 + 2.  A survivor's LOWER BOUND is formed from the float value
         // s' = fma(T, V, rterm) as before (V = X - Rq - 2^15 exactly), so brackets, the merge and its self-check see the same
-        // numbers as with the float selection.  X is kept as KEY = 8 X + r (r = the row slot): the lane's smallest key names its
-        // row; three instructions per (item, row): v_mad_u32_u16 (op_sel picks the item's half), v_med3_u32, v_min_u32.
+        // numbers as with the float selection.  X is kept as KEY = 8 X + r (r = the row slot) in 32 bits: the lane's smallest key
+        // names its row; three instructions per (item, row): v_mad_u32_u16 (8 U + (8 Rq + r); op_sel picks the item's half),
+        // v_med3_u32, v_min_u32.
         const float T = __int_as_float(__builtin_amdgcn_readfirstlane(rec[7]));
         const float invT = (T > 0.0f && T < 1e30f) ? 1.0f / T : 0.0f;
-        float rmin;
-        {
-          const u4 m0 = *reinterpret_cast<const u4*>(rt_s + 4096), m1 = *reinterpret_cast<const u4*>(rt_s + 4100);
-          rmin = fminf(fminf(fminf(__uint_as_float(m0.x), __uint_as_float(m0.y)), fminf(__uint_as_float(m0.z), __uint_as_float(m0.w))),
-                       fminf(fminf(__uint_as_float(m1.x), __uint_as_float(m1.y)), fminf(__uint_as_float(m1.z), __uint_as_float(m1.w))));
-        }
-        auto row_q8 = [&](float b, int r) -> uint32_t {   // 8 Rq + r; a dead slot (+inf) and a row term of a non-finite table: 2^28
-          const float t = fmaxf(fminf(__builtin_rintf((b - rmin) * invT), 33554432.0f), 0.0f);
-          return ((uint32_t)t << 3) + (uint32_t)r;
+        const float rmin = __int_as_float(__builtin_amdgcn_readfirstlane(rec[120]));
+        auto row_q = [&](float b) -> uint32_t {   // Rq; a dead slot (+inf) and a row term of a non-finite table: 2^25
+          return (uint32_t)fmaxf(fminf(__builtin_rintf((b - rmin) * invT), 33554432.0f), 0.0f);
         };
-        uint32_t rq8[RMAX];
+        uint32_t rq8[RMAX];   // 8 Rq + r
         bool nan_row = false;
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
-          rq8[r] = row_q8(base[r], r);
+          rq8[r] = (row_q(base[r]) << 3) + (uint32_t)r;
           nan_row = nan_row || (base[r] != base[r]);
         }
+        // key of (item g, row slot r) = 8 X + r
+        auto row_key = [&](int g, int r) -> uint32_t {
+          uint32_t key;
+          if (g & 1) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
+          else asm("v_mad_u32_u16 %0, %1, 8, %2" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
+          return key;
+        };
         gtick(0);
         uint32_t best[G];                // the lane's smallest key of every item
         uint32_t sec16[G / 2];           // the X of its second smallest (capped at 0xffff), two items per register
@@ -695,9 +707,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
             uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu;
 #pragma unroll
             for (int r = 0; r < RMAX; ++r) {
-              uint32_t key;
-              if (g & 1) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
-              else asm("v_mad_u32_u16 %0, %1, 8, %2" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
+              const uint32_t key = row_key(g, r);
               asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b2) : "v"(b1), "v"(b2), "v"(key));   // (b1 <= b2: the median is the new second smallest)
               b1 = b1 < key ? b1 : key;
             }
@@ -725,10 +735,12 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           const int p_it = rec[8 + gi];
           const float p_shift = __int_as_float(rec[72 + gi]);
           const float p_off = __int_as_float(rec[40 + gi]);
+          // (row by row -- the rare path: the rows' own terms come from the staged copy again, no registers are kept for them)
+          auto term = [&](int r) -> float { return rt_s[(r * NG + gw) * 64 + lane]; };
           auto sval = [&](int g, int r) -> float {
             const uint32_t w = acc[g >> 1][r];
             const int v = (int)((g & 1) ? (w >> 16) : (w & 0xffffu)) - 32768;
-            return __builtin_fmaf(T, (float)v, base[r]);
+            return __builtin_fmaf(T, (float)v, term(r));
           };
 #pragma unroll
           for (int g = 0; g < G; ++g) {
@@ -750,9 +762,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
                   if (pass) {
                     const uint32_t r = best[g] & 7u;
                     const float b = rt_s[(r * (uint32_t)NG + (uint32_t)gw) * 64u + (uint32_t)lane];   // (a passing row is a live one: its staged term)
-                    const int v = (int)((best[g] - row_q8(b, (int)r)) >> 3) - 32768;                  // = the row's V: X - Rq - 2^15
-                    const float sv = __builtin_fmaf(T, (float)v, b);
-                    const float dlo = fmaxf(0.0f, (sv + off) - shift);
+                    const int v = (int)((best[g] >> 3) - row_q(b)) - 32768;                           // = the row's V: X - Rq - 2^15
+                    const float dlo = fmaxf(0.0f, (__builtin_fmaf(T, (float)v, b) + off) - shift);
                     const uint32_t loc = ((uint32_t)(blk0 + gw) + r * (uint32_t)NG) * 64u + (uint32_t)lane;
                     dst[lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
                   }
@@ -761,11 +772,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
               } else {
                 uint32_t m8 = 0u;
 #pragma unroll
-                for (int r = RMAX - 1; r >= 0; --r) {
-                  uint32_t key;
-                  if (g & 1) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
-                  else asm("v_mad_u32_u16 %0, %1, 8, %2" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
-                  m8 = m8 + m8 + ((key <= thr_key || base[r] != base[r]) ? 1u : 0u);   // (a NaN passes: exact stage)
+                for (int r = 0; r < RMAX; ++r) {
+                  const float tr = term(r);
+                  m8 |= (row_key(g, r) <= thr_key || tr != tr) ? (1u << r) : 0u;   // (a NaN passes: exact stage)
                 }
                 m8 &= live8;
                 if (__ballot(m8 != 0u) != 0ull) {

@@ -97,19 +97,16 @@ int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int
 // ---------------------------------------------------------------------------------------
 
 int scale_sync_prepare(Workspace* ws, hipStream_t s, int n_norm, ScaleSync* z) {
-  const bool fresh = ws->w_scale.p == nullptr;
-  if (ws->w_scale.ensure(4 * sizeof(uint32_t))) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (fresh || ws->scale_pending) {
-    HIP_TRY(hipMemsetAsync(ws->w_scale.p, 0, 4 * sizeof(uint32_t), s));
-    ws->scale_calls = 0; ws->scale_arrived = 0;
+  if (ws->w_scale.ensure(sizeof(uint32_t) * (size_t)std::max(n_norm, 64))) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+  if (ws->scale_pending || ws->scale_n != n_norm) {   // another number of words (or an unconfirmed launch): all words to epoch 0
+    HIP_TRY(hipMemsetAsync(ws->w_scale.p, 0, sizeof(uint32_t) * (size_t)n_norm, s));
+    ws->scale_epoch = 0;
+    ws->scale_n = n_norm;
   }
-  uint32_t* w = ws->w_scale.as<uint32_t>();
-  z->tmax_cur = w + (ws->scale_calls & 1u);
-  z->tmax_next = w + ((ws->scale_calls + 1u) & 1u);
-  z->arrived = w + 2;
-  ws->scale_arrived += (uint32_t)n_norm;
-  z->target = ws->scale_arrived;
-  ws->scale_calls += 1;
+  ws->scale_epoch ^= 1u;
+  z->part = ws->w_scale.as<uint32_t>();
+  z->n = n_norm;
+  z->epoch = ws->scale_epoch;
   ws->scale_pending = true;
   return 0;
 }
@@ -326,7 +323,7 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
   ra.sorted_item = ws->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
-  ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
+  ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax; ra.listmin = ix->rt_listmin;
   ra.records = ws->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
   if (!r.records_ready) {
     timed_launch(ix, s, "entry_records", [&] {
@@ -338,11 +335,11 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   fl.qc = ws->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ws->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
   fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
   fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
-  fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.keep_all = (ix->tune.check_brackets & 1) ? 1 : 0;
+  fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.keep_all = (ix->tune.check_brackets & 1) ? 1 : 0; fl.fence = 0;
   if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
   // LDS: slabs [2 buffers][2 positions][K][16 items] int16, then column minima / thresholds, two entry records, row terms
   const size_t desc_off = (size_t)4 * SCAN5_G * 2 * K;
-  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + (4096 + 8) * sizeof(float);
+  const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
   fl.desc_offset = (uint32_t)desc_off;
   // One persistent workgroup per CU (LDS admits exactly one), never more than there is work.  Batches in flight share the
   // chip: a persistent scan that took every CU would hold up the small kernels of the other batches until it drains, and

@@ -79,7 +79,7 @@ static bool pq_use_fused(const freddy_gpu_index* ix, int Q, int k) {
 struct PqFrontArgs {
   const float* queries; int Q, d, lists, W; int64_t n_rows;
   const int32_t* blk_off; const int32_t* list_off;
-  const float* cbT; const float* cmax; const float* pmax;
+  const float* cbT; const float* cmax; const float* pmax; const float* listmin;
   float* qn; float* qscale; uint32_t* qc; int m, K;
   float sentinel;
   ScaleSync z;
@@ -109,7 +109,7 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
       qn_s[pp] = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
     }
   }
-  const float T = batch_scale5(a.z);   // (a barrier inside)
+  const float T = batch_scale5(a.z, reinterpret_cast<uint32_t*>(fs + 2));
   if (tid == 0) fs[1] = T;
   if (tid == 0) {
     float acc = 0.0f;
@@ -140,6 +140,7 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
       const int b0 = blk_off[c];
       rec[0] = c; rec[1] = cnt; rec[2] = 0; rec[3] = b0; rec[4] = blk_off[c + 1] - b0; rec[5] = list_off[c + 1] - list_off[c];
       rec[7] = (int32_t)__float_as_uint(sc);   // the batch's table scale
+      rec[120] = (int32_t)__float_as_uint(a.listmin[c]);
       // the slots beyond the group's queries: no item, the first query's number (a valid table), no bounds (entry_record5_kernel)
       const ItemBounds none = item_bounds(0.0f, 0.0f, sentinel);
       for (int u = cnt; u < SCAN5_G; ++u) {
@@ -197,15 +198,16 @@ static int pq_view_refresh(freddy_gpu_index* ix, freddy_gpu_index** view, hipStr
   const size_t slots = (size_t)n_blocks * 64;
   if (fx->v_coarse.ensure(sizeof(float) * (size_t)lists * ix->d) || fx->v_list_off.ensure(sizeof(int32_t) * ((size_t)lists + 1)) ||
       fx->v_blk_off.ensure(sizeof(int32_t) * ((size_t)lists + 1)) || fx->v_blk_cell.ensure(sizeof(int32_t) * (size_t)n_blocks) ||
-      fx->v_pos.ensure(sizeof(int32_t) * slots) || fx->v_rterm.ensure(sizeof(float) * slots))
+      fx->v_pos.ensure(sizeof(int32_t) * slots) || fx->v_rterm.ensure(sizeof(float) * (slots + (size_t)lists)))
     return fail(FREDDY_E_NOMEM, "device allocation failed (PQ table as pseudo-lists)");
   fx->coarse = fx->v_coarse.as<float>(); fx->list_off = fx->v_list_off.as<int32_t>(); fx->blk_off = fx->v_blk_off.as<int32_t>();
-  fx->blk_cell = fx->v_blk_cell.as<int32_t>(); fx->pos = fx->v_pos.as<int32_t>(); fx->rterm = fx->v_rterm.as<float>();
+  fx->blk_cell = fx->v_blk_cell.as<int32_t>(); fx->pos = fx->v_pos.as<int32_t>(); fx->rterm = fx->v_rterm.as<float>(); fx->rt_listmin = fx->rterm + slots;
   HIP_TRY(hipMemsetAsync(fx->coarse, 0, sizeof(float) * (size_t)lists * ix->d, s));
   hipLaunchKernelGGL(pq_shadow_meta_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, pos, ix->ids, n_blocks, n_rows, lists,
                      fx->list_off, fx->blk_off, fx->blk_cell, fx->pos);
   hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, fx->packed, fx->blk_cell, fx->coarse, fx->cbR,
                      fx->rterm, (int64_t)slots, fx->M2, fx->d, fx->m, fx->K, fx->S);
+  hipLaunchKernelGGL(row_term_min_kernel, dim3((unsigned)lists), dim3(256), 0, s, fx->rterm, fx->blk_off, fx->rt_listmin, lists);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -264,10 +266,10 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   // queries' table scales: no item / work-table / record kernels (pq_front_kernel)
   PqFrontArgs fa;
   fa.queries = d_q; fa.Q = Q; fa.d = fx->d; fa.lists = lists; fa.W = W; fa.n_rows = fx->N; fa.blk_off = fx->blk_off; fa.list_off = fx->list_off;
-  fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
+  fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.listmin = fx->rt_listmin; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
   fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
   fa.item_dist = pa.item_dist; fa.round_rows = pa.round_rows; fa.records = ws->w_records.as<int32_t>(); fa.n_groups = wt.n_groups;
-  const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 2) * sizeof(float));
+  const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 4) * sizeof(float));
   if (int rc = scale_sync_prepare(ws, s, (Q + 15) / 16, &fa.z)) return rc;
   timed_launch(fx, s, "pq_front", [&] {
     hipLaunchKernelGGL(pq_front_kernel, dim3((unsigned)((m + 1) * ((Q + 15) / 16) + Q)), dim3(256), front_lds, s, fa);

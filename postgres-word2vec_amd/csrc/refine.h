@@ -41,6 +41,7 @@ struct FilterArgs {
   int K, L, upi;
   float sentinel;
   uint32_t desc_offset;
+  uint32_t fence;              // always 0: conditions the compiler cannot see through keep the code of ivf_filter5_kernel's phases in basic blocks of their own -- without them the register allocator spills in the main loop (86.5 instead of 82 us; sched_barriers do not have the same effect)
   int keep_all;                // option filter_keep_all (tests): every row survives the filter -- with refine_all, every bracket is checked
   long long* prof;
   const uint32_t* packed8;     // U8 instantiation: [blocks][3][64], one byte per code (K <= 256)
@@ -118,6 +119,26 @@ static __global__ __launch_bounds__(256) void row_term_kernel(const uint32_t* __
   rterm[slot] = (float)acc;
 }
 
+// listmin[c] = the smallest row term of list c (padding slots included: any lower bound will do) -- the common offset of the
+// scan's integer selection (fused5.h); kept behind the row terms, rterm[n_slots + c].  One workgroup per list.
+static __global__ __launch_bounds__(256) void row_term_min_kernel(const float* __restrict__ rterm, const int32_t* __restrict__ blk_off,
+                                                                 float* __restrict__ listmin, int n_lists) {
+  __shared__ float wm[4];
+  const int c = blockIdx.x;
+  if (c >= n_lists) return;
+  const int64_t lo = (int64_t)blk_off[c] * 64, hi = (int64_t)blk_off[c + 1] * 64;
+  float mn = __uint_as_float(0x7f800000u);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) mn = fminf(mn, rterm[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mn = fminf(fminf(wm[0], wm[1]), fminf(wm[2], wm[3]));
+    listmin[c] = mn < 3e38f ? mn : 0.0f;
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // Work-entry records: everything the scan needs to know about an entry in one 512-byte row, so that the
 // persistent workgroups fetch the next entry with ONE load instead of a chain of dependent ones
@@ -141,6 +162,7 @@ struct RecordArgs {
   const float* qn;
   const float* qscale;
   const float* pmax;
+  const float* listmin;     // [lists] smallest row term of every list (behind the row terms)
   int32_t* records;
   float sentinel;
 };

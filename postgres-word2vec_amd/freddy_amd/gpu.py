@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "libfreddy_gpu.so")
+LIB_PATH = os.environ.get("FREDDY_GPU_SO") or os.path.join(_PKG, "libfreddy_gpu.so")   # (FREDDY_GPU_SO: the tools' -DFREDDY_LAB build)
 
 FOUND_ROWS = 0
 FOUND_ACCEPTED = 1
