@@ -298,8 +298,9 @@ int freddy_gpu_last_track(const freddy_gpu_index_t* ivpq, freddy_track* out);
 int freddy_gpu_last_track_sized(const freddy_gpu_index_t* ivpq, void* out, size_t out_size);
 
 /* ABI version of the library: bumped whenever a struct of this header grows or an entry point changes meaning.  A host
- * compares it with the FREDDY_GPU_ABI_VERSION it was compiled against when it loads the library (pg/freddy_gpu_glue.c
- * does, in _PG_init) and refuses a mismatch instead of overrunning a stack variable. */
+ * compares it with the FREDDY_GPU_ABI_VERSION it was compiled against before its first other call into the library
+ * (pg/freddy_gpu_glue.c: ensure_exit_hook(), at the top of every freddy_glue_* entry) and refuses a mismatch instead of
+ * overrunning a stack variable. */
 #define FREDDY_GPU_ABI_VERSION 4
 int freddy_gpu_abi_version(void);
 

@@ -78,7 +78,10 @@ static void pins_after_commit(int level)
 static void freddy_xact_cb(XactEvent event, void *arg)
 {
     if (event == XACT_EVENT_ABORT || event == XACT_EVENT_PARALLEL_ABORT) pins_after_abort(1);
-    else if (event == XACT_EVENT_COMMIT || event == XACT_EVENT_PARALLEL_COMMIT || event == XACT_EVENT_PREPARE) pins_after_commit(1);
+    else if (event == XACT_EVENT_COMMIT || event == XACT_EVENT_PARALLEL_COMMIT) pins_after_commit(1);
+    /* PREPARE TRANSACTION: the rows may still be rolled back (ROLLBACK PREPARED) -- a pin that holds rows of this transaction is
+     * dropped like after an abort and pinned again from whatever has committed by then */
+    else if (event == XACT_EVENT_PREPARE) pins_after_abort(1);
 }
 static void freddy_subxact_cb(SubXactEvent event, SubTransactionId mySubid, SubTransactionId parentSubid, void *arg)
 {
@@ -406,6 +409,7 @@ static int32 last_id(const int32 *ids, int64 n, bool ascending)
 /* ---- the three handles ----------------------------------------------------------------------------- */
 freddy_gpu_index_t *freddy_glue_pq(void)
 {
+    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     char names[MAX_TABS][100];
     FreddyStamp now;
     bool appended, codebook;
@@ -443,6 +447,7 @@ freddy_gpu_index_t *freddy_glue_pq(void)
 
 freddy_gpu_index_t *freddy_glue_ivf(void)
 {
+    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     char names[MAX_TABS][100];
     FreddyStamp now;
     bool appended, codebook;
@@ -501,6 +506,7 @@ freddy_gpu_index_t *freddy_glue_ivf(void)
 
 freddy_gpu_index_t *freddy_glue_ivpq(void)
 {
+    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     char names[MAX_TABS][100];
     FreddyStamp now;
     bool appended, codebook;

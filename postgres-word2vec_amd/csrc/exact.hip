@@ -13,6 +13,7 @@
 int exf_table_stats(freddy_gpu_index* ix, int64_t r0, int64_t n) {
   const bool shape_ok = ix->d % 4 == 0 && ix->d <= 512 && ix->d >= 16;
   if (!shape_ok) { ix->exf_ok = false; return 0; }
+  if (ix->tune.exact_filter == 0) { ix->exf_ok = false; return 0; }   // (option exact_filter = 0 when the table is pinned: no third copy of it)
   if (n <= 0) return 0;
   if (ix->exf_small.ensure(4096)) return fail(FREDDY_E_NOMEM, "device allocation failed");
   uint32_t* st = ix->exf_small.as<uint32_t>() + 512;   // (the upper part of the small buffer; the lower one is per-call state)
@@ -66,7 +67,11 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
   const bool all = (ix->tune.check_brackets & 4) != 0;
   const int64_t cap64 = all ? N : std::min<int64_t>(N, 8192);
   const int cap = (int)cap64;
-  const int n_sample = (int)std::min<int64_t>(N, EXF_SAMPLE);
+  // the threshold's sample: whole 32-row strips of REAL rows (a zero-padded row would be a similarity of 0 that no row has),
+  // spread evenly over the table
+  const int64_t full_strips = N / 32;
+  const int n_sample = (int)(std::min<int64_t>(full_strips, EXF_SAMPLE / 32) * 32);
+  const int64_t sample_stride = n_sample > 0 ? std::max<int64_t>(1, full_strips / (n_sample / 32)) : 1;
   // small per-call state: [0..63] thr, [64..127] qeps, [128..191] qunscale, [192..255] cand_cnt, [256] qbad
   if (ix->exf_small.ensure(4096) || ix->exf_qfrag.ensure((size_t)2 * T * 2 * 64 * 16) ||
       ix->exf_sample.ensure(sizeof(float) * (size_t)EXF_QT * n_sample) || ix->exf_cand.ensure(sizeof(uint2) * (size_t)EXF_QT * cap) ||
@@ -93,7 +98,7 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
     timed_launch(ix, s, "exact_prep", [&] { hipLaunchKernelGGL(exf_prep_kernel, dim3(EXF_QT), dim3(256), 0, s, pa); });
     HIP_TRY(hipGetLastError());
     ExfArgs fa;
-    fa.xf = ix->exf_xf.as<h8v>(); fa.n_rows = n_sample; fa.T = T; fa.qfrag = ix->exf_qfrag.as<h8v>();
+    fa.xf = ix->exf_xf.as<h8v>(); fa.n_rows = n_sample; fa.strip_stride = sample_stride; fa.T = T; fa.qfrag = ix->exf_qfrag.as<h8v>();
     fa.qunscale = qunscale; fa.sample_out = ix->exf_sample.as<float>(); fa.thr = thr; fa.cand_cnt = cand_cnt; fa.cand = ix->exf_cand.as<uint2>(); fa.cap = cap;
     auto grid_for = [&](int64_t rows) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>((rows + 255) / 256, (int64_t)ix->n_cus * 2)); };
     timed_launch(ix, s, "exact_sample", [&] {
@@ -106,7 +111,7 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
     timed_launch(ix, s, "exact_threshold", [&] { hipLaunchKernelGGL(exf_threshold_kernel, dim3(EXF_QT), dim3(64 * EXF_TW), 0, s, ta); });
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemsetAsync(cand_cnt, 0, sizeof(int32_t) * EXF_QT, s));
-    fa.n_rows = N; fa.sample_out = nullptr;
+    fa.n_rows = N; fa.strip_stride = 1; fa.sample_out = nullptr;
     timed_launch(ix, s, "exact_filter", [&] {
       if (NT == 1) hipLaunchKernelGGL((exf_filter_kernel<1, false>), dim3(grid_for(N)), dim3(EXF_WG), lds1, s, fa);
       else hipLaunchKernelGGL((exf_filter_kernel<2, false>), dim3(grid_for(N)), dim3(EXF_WG), lds2, s, fa);

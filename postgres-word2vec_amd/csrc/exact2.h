@@ -191,6 +191,8 @@ __global__ __launch_bounds__(256) void exf_prep_kernel(ExfPrepArgs a) {
 struct ExfArgs {
   const h8v* xf;            // the table in fragment order (exf_layout_kernel)
   int64_t n_rows;           // rows [0, n_rows) of this launch
+  int64_t strip_stride;     // SAMPLE mode: strip i of the launch is strip i * strip_stride of the table (a strided sample: on an id-ordered
+                            // or clustered table the first rows are no sample of it); 1 otherwise
   int T;
   const h8v* qfrag;         // [NT][T][2][64]
   const float* qunscale;    // [EXF_QT]
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(EXF_WG, 2) void exf_filter_kernel(ExfArgs a) {
   }
   const int64_t n_strips = (a.n_rows + 31) >> 5;
   for (int64_t strip = (int64_t)blockIdx.x * (EXF_WG / 64) + wave; strip < n_strips; strip += (int64_t)gridDim.x * (EXF_WG / 64)) {
-    const h8v* xs = a.xf + (size_t)strip * T * 128 + lane;
+    const h8v* xs = a.xf + (size_t)(SAMPLE ? strip * a.strip_stride : strip) * T * 128 + lane;
     f16acc acc[NT];
 #pragma unroll
     for (int n = 0; n < NT; ++n)

@@ -133,7 +133,11 @@ __device__ __forceinline__ float batch_scale5(const ScaleSync z, uint32_t* slot)
     uint32_t mx = 0u;
     for (int i = threadIdx.x; i < z.n; i += 64) {
       uint32_t w;
+#ifdef FREDDY_NO_WAIT
+      w = __hip_atomic_load(z.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
       while (((w = __hip_atomic_load(z.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 31) != z.epoch) __builtin_amdgcn_s_sleep(8);
+#endif
       w &= 0x7fffffffu;
       mx = w > mx ? w : mx;
     }

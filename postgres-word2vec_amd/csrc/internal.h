@@ -112,6 +112,7 @@ struct Workspace {
   bool scale_pending = false;     // a call was prepared and its launch not confirmed (an error in between): the words are cleared before the next use
   uint64_t one_shape = 0;          // the one-launch kernels' buffer (w_oneb): shape of the call that wrote it last, and that call's epoch (one.h)
   uint32_t one_epoch = 0;
+  bool one_pending = false;        // one_buffer() flipped the epoch and the kernel was not (yet) launched
   void release() {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
@@ -208,6 +209,7 @@ struct freddy_gpu_index {
   int32_t* blk_off = nullptr;   // [lists+1] row blocks
   uint32_t* packed = nullptr;   // [blocks][M2][64]
   uint32_t* packed8 = nullptr;  // K <= 256, m = 12: [blocks][3][64], one BYTE per code -- what the integer-slab scans read (16 B per row with its row term)
+  int64_t packed8_bytes = 0;    // its share of `bytes`
   bool packed8_own = false;     // (a PQ handle's view shares its owner's array)
   int32_t* pos = nullptr;       // [blocks*64]
   int32_t* ids = nullptr;       // PQ: [N] position -> id

@@ -781,7 +781,9 @@ const void* pinned_device_pointer(const void* p) {
 int one_buffer(Workspace* ws, hipStream_t s, uint64_t shape, size_t bytes, uint32_t* epoch) {
   void* before = ws->w_oneb.p;
   if (ws->w_oneb.ensure(bytes)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (ws->w_oneb.p != before || ws->one_shape != shape) {
+  // (one_pending: the previous call flipped the epoch and then did not launch -- an allocation or launch error in between --
+  // so the words still carry the epoch of the call before it, which is this call's: cleared like a change of shape)
+  if (ws->w_oneb.p != before || ws->one_shape != shape || ws->one_pending) {
     HIP_TRY(hipMemsetAsync(ws->w_oneb.p, 0, ws->w_oneb.cap, s));
     ws->one_shape = shape;
     ws->one_epoch = 1;
@@ -789,6 +791,7 @@ int one_buffer(Workspace* ws, hipStream_t s, uint64_t shape, size_t bytes, uint3
     ws->one_epoch ^= 1u;
   }
   *epoch = ws->one_epoch;
+  ws->one_pending = true;   // until the caller has seen its kernel launched (one_buffer_launched)
   return 0;
 }
 
@@ -847,6 +850,7 @@ static int ivf_one(freddy_gpu_index* ix, const float* queries, int k, int W, flo
   if (lds > 60 * 1024) return 0;
   timed_launch(ix, s, "ivf_one", [&] { hipLaunchKernelGGL((ivf_one_kernel<25>), dim3((unsigned)G), dim3(ONE_WG), lds, s, a); });
   HIP_TRY(hipGetLastError());
+  ws->one_pending = false;
   {   // (the kernel's last store is this word: polled for up to a millisecond, then the stream is waited for the usual way)
     volatile int32_t* flag = err;
     const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(1000);

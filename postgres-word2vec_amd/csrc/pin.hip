@@ -142,12 +142,13 @@ __global__ __launch_bounds__(256) void pack8_kernel(const uint32_t* __restrict__
 }
 // (Re)build the one-byte code array of a handle whose codes fit a byte (K <= 256, m = 12: the cell-grouped scans' shape).
 static int build_packed8(freddy_gpu_index* ix) {
-  if (ix->packed8 && ix->packed8_own) { (void)hipFree(ix->packed8); }
-  ix->packed8 = nullptr; ix->packed8_own = false;
+  if (ix->packed8 && ix->packed8_own) { (void)hipFree(ix->packed8); ix->bytes -= ix->packed8_bytes; }   // (rebuilt after append_rows: the old copy no longer counts)
+  ix->packed8 = nullptr; ix->packed8_own = false; ix->packed8_bytes = 0;
   if (ix->K > 256 || ix->m != 12 || ix->M2 != 6 || !ix->packed || ix->n_blocks <= 0) return 0;
   const size_t bytes = sizeof(uint32_t) * (size_t)ix->n_blocks * 3 * 64;
   if (hipMalloc((void**)&ix->packed8, bytes) != hipSuccess) { ix->packed8 = nullptr; return 0; }   // (no room: the int16 layout serves)
   ix->packed8_own = true;
+  ix->packed8_bytes = (int64_t)bytes;
   ix->bytes += (int64_t)bytes;
   const int64_t n = ix->n_blocks * 3 * 64;
   hipLaunchKernelGGL(pack8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ix->stream, ix->packed, ix->packed8, ix->n_blocks);

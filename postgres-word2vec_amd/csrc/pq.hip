@@ -311,6 +311,7 @@ static int pq_one(freddy_gpu_index* ix, hipStream_t s, const float* h_q, int k, 
                               (size_t)ONE_WAVES * 64 * sizeof(u64) + (size_t)G * L * sizeof(u64));
   timed_launch(ix, s, "pq_one", [&] { hipLaunchKernelGGL((pq_one_kernel<25>), dim3((unsigned)G), dim3(ONE_WG), lds, s, a); });
   HIP_TRY(hipGetLastError());
+  ws->one_pending = false;
   return 0;
 }
 

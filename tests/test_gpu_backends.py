@@ -1,0 +1,77 @@
+"""Two and four BACKENDS on one GPU: separate processes (a PostgreSQL server is N forked backends, one process each -- SURVEY 8b
+"Threading / process model"), each with its own HIP context, its own pinned copy of the index and its own persistent scans,
+searching at the same time: single queries (the one-launch kernels of one.h, whose in-kernel hand-offs assume that the grid is
+co-resident -- here beside the grids of OTHER processes), 64-query and 1024-query host-buffer calls, single pq_search queries.
+Every list must equal the oracle's, nothing may hang (a timeout kills the children and fails), and the one-launch kernels must
+either have run (kernel "ivf_one" in the profile records) or the library must have fallen back to the multi-launch chain by
+itself -- both are correct; which one happened is printed."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run_backends(path, n_procs, seconds, mode="mixed", timeout=240):
+    with tempfile.TemporaryDirectory() as sync:
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "backend_worker.py"), path, str(r), str(n_procs), str(seconds), sync, mode],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n_procs)]
+        outs = []
+        try:
+            for p in procs:
+                so, se = p.communicate(timeout=timeout)
+                assert p.returncode == 0, f"backend failed ({p.returncode}): {se[-1500:]}"
+                outs.append(json.loads(so.strip().splitlines()[-1]))
+        finally:
+            for p in procs:   # (a hang: kill exactly the children this test started)
+                if p.poll() is None:
+                    p.kill()
+    return outs
+
+
+@pytest.fixture(scope="module")
+def tables_file(oracle):
+    N, C, K, k, W = 60000, 64, 256, 5, 4
+    t = util.ivf_tables(N=N, C=C, K=K)
+    p = util.pq_tables(N=20000, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    pt = oracle.pq_table(p["codebook"], p["ids"], p["codes"])
+    _, qs = util.queries_from_corpus(N, 1400, seed=31)
+    exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0, found_rule=0)
+    # (pq queries are 300-d rows of the same corpus; the PQ table holds its first 20 000 rows)
+    pexp = np.stack([oracle.pq_search(pt, q, k) for q in qs[:64]])
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    path = os.path.join(d, "tables.npz")
+    np.savez(path, coarse=t["coarse"], codebook=t["codebook"], list_off=t["list_off"], ids=t["ids"], codes=t["codes"],
+             pq_codebook=p["codebook"], pq_ids=p["ids"], pq_codes=p["codes"], queries=qs, k=k, W=W,
+             exp_ids=exp["id"].reshape(len(qs), k), exp_dist=exp["dist"].reshape(len(qs), k),
+             pq_exp_ids=np.concatenate([pexp["id"], np.zeros((len(qs) - 64, k), np.int32)]).astype(np.int32),
+             pq_exp_dist=np.concatenate([pexp["dist"], np.zeros((len(qs) - 64, k), np.float32)]).astype(np.float32),
+             shapes=np.array([1, 64, 1, 1024, 1, 2], np.int32))
+    yield path
+    os.remove(path)
+    os.rmdir(d)
+
+
+@pytest.mark.parametrize("n_procs", [2, 4])
+def test_backends_on_one_gpu_give_the_oracles_lists(tables_file, n_procs):
+    outs = _run_backends(tables_file, n_procs, seconds=4.0)
+    assert len(outs) == n_procs
+    for o in outs:
+        assert "error" not in o, o
+        assert o["mismatches"] == 0 and o["pq_mismatches"] == 0, o
+        assert o["bound_violations"] == 0, o
+        assert o["calls"].get("1", 0) > 20 and o["calls"].get("1024", 0) > 3, o     # every call shape really ran beside the others
+        # the one-query calls: the one-launch kernel, or -- had a bounded poll run out under the other processes' load -- the
+        # multi-launch chain (coarse_small + probe_plan + lut_build + adc_scan + merge_replay); either way the lists above are right
+        assert o["kernels"].get("ivf_one", 0) > 0 or o["kernels"].get("adc_scan", 0) > 0, o
+    print("\n[backends]", n_procs, "processes:", [{"q/s": o["queries_per_s"], "ivf_one": o["kernels"].get("ivf_one", 0),
+                                                    "multi_launch_single_queries": o["kernels"].get("lut_build", 0)} for o in outs])
