@@ -79,95 +79,28 @@ __device__ __forceinline__ uint32_t pk_add_i16(uint32_t x, uint32_t y) {   // v_
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s2v, x) + __builtin_bit_cast(s2v, y));
 }
 
-// ONE table scale per BATCH.  The table stores rint(-2 q_p . c / T) with T = max over the batch's queries and positions of
-// 2 |q_p| max|c_p| / 2730 (so no value is ever clamped).  With one scale for all items of a work entry the scan's selection
-// tail runs on integers (ivf_filter5_kernel); a query whose own maximum is smaller than the batch's pays with a wider
-// margin E = 512 u B + 28 T -- more survivors for the merge, never a different result.  For rows of one norm (the reference
-// searches google_vecs_norm, freddy--0.0.1.sql) the scales of a batch differ by a few per cent.
-//
-// The maximum is formed inside the launch that builds the table: the FIRST workgroups of the grid (one per 16 queries:
-// query_norms5_body) write qn[q][p] = |q_p| (rounded up) and ONE word each: the largest 2 |q_p| max|c_p| of their queries
-// (>= +0, so the sign bit is free) with the call's EPOCH in bit 31 -- a word validates itself, there is no counter and no
-// same-address atomic (256 atomic maxima on one word took 25 us).  A workgroup that needs T reads the n words (wave 0: lane <->
-// word, again until every word carries the epoch), takes their maximum and hands it to its other waves through LDS.
-// Workgroups are dispatched in grid order, so the producers are resident or done when a consumer starts; a consumer asks
-// after its own prologue and normally finds the words on its first read.  The host flips the epoch from call to call
-// while the number of words stays the same -- each call then overwrites exactly the words of its predecessor, which carry
-// the other epoch -- and clears the words when it changes (scale_sync_prepare).  A query with non-finite components takes
-// no part: its own margin E is not finite, so all its rows go to the exact stage.
-struct ScaleSync {
-  uint32_t* part;     // [n] partial maxima, bit 31 = epoch
-  int n;              // producer workgroups = (Q + 15) / 16
-  uint32_t epoch;     // 0 / 1
-};
-// producers: workgroup `blk` of 256 threads <-> queries 16 blk .. 16 blk + 15, 16 lanes per query, lane <-> position
-template <int S>
-__device__ __forceinline__ void query_norms5_body(const float* __restrict__ queries, const float* __restrict__ cmax, float* __restrict__ qn,
-                                                  int Q, int d, int m, int blk, const ScaleSync z) {
-  __shared__ uint32_t wmax[4];
-  const int tid = threadIdx.x;
-  const int qi = tid >> 4, pp = tid & 15, q = blk * 16 + qi;
-  float best = 0.0f;
-  if (pp < m && q < Q) {
-    float n2 = 0.0f;
-    for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + pp * S + j]; n2 = __builtin_fmaf(v, v, n2); }
-    const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
-    qn[(size_t)q * m + pp] = nrm;
-    best = 2.0f * nrm * cmax[pp];
-    if (!(best < 3e38f)) best = 0.0f;
-  }
-  uint32_t bb = __float_as_uint(best);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)bb, o, 64); bb = t > bb ? t : bb; }
-  if ((tid & 63) == 0) wmax[tid >> 6] = bb;
-  __syncthreads();
-  if (tid == 0) {
-    uint32_t w = wmax[0];
-    w = wmax[1] > w ? wmax[1] : w; w = wmax[2] > w ? wmax[2] : w; w = wmax[3] > w ? wmax[3] : w;
-    __hip_atomic_store(z.part + blk, w | (z.epoch << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-// consumers: the batch's table scale T for every thread of the workgroup (a block-wide barrier inside); `slot` = one LDS word
-__device__ __forceinline__ float batch_scale5(const ScaleSync z, uint32_t* slot) {
-  if (threadIdx.x < 64) {
-    uint32_t mx = 0u;
-    for (int i = threadIdx.x; i < z.n; i += 64) {
-      uint32_t w;
-#ifdef FREDDY_NO_WAIT
-      w = __hip_atomic_load(z.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-      while (((w = __hip_atomic_load(z.part + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 31) != z.epoch) __builtin_amdgcn_s_sleep(8);
-#endif
-      w &= 0x7fffffffu;
-      mx = w > mx ? w : mx;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)mx, o, 64); mx = t > mx ? t : mx; }
-    if (threadIdx.x == 0) *slot = mx;
-  }
-  __syncthreads();
-  return __uint_as_float(*slot) * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
-}
-
-// The table: values rint(-2 q_p . c / T) + bias(p), T the batch's scale (above);
-// row (query, position) = 128 uint4, word j of uint4 s = codes 128 j + s (low half) and 128 j + s + 512 (high half).  The
-// workgroups of position 0 also write scale[q] = T for the record and merge kernels.
+// The table: values rint(-2 q_p . c / scale[q]) clamped to +-2730, scale[q] = max_p 2 |q_p| max|c_p| / 2730 -- ONE per query;
+// row (query, position) = 128 uint4, word j of uint4 s = codes 128 j + s (low half) and 128 j + s + 512 (high half).  Every workgroup (position p, 16
+// queries) derives the scales of its queries itself (16 lanes per query, lane <-> position: the same fmaf chain and
+// the same maximum in every workgroup); the workgroups of position 0 also write qn[q][p] = |q_p| (rounded up) and
+// scale[q] for the record and merge kernels.
 template <int S, int QT>
 __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ queries, const float* __restrict__ cbT,
+                                                     const float* __restrict__ cmax, float* __restrict__ qn,
                                                      float* __restrict__ qscale, uint32_t* __restrict__ qc,
-                                                     int Q, int d, int m, int K, int bx, int by, unsigned char* smem, const ScaleSync z) {
+                                                     int Q, int d, int m, int K, int bx, int by, unsigned char* smem) {
   static_assert(QT == 16, "one 16-lane group per query");
   constexpr int SP = (S + 3) & ~3;
-  // LDS from the caller: qs [QT][SP] floats, one word for the batch's scale
+  // LDS from the caller: qs [QT][SP] floats, inv_s [QT]
   float (*qs)[SP] = reinterpret_cast<float (*)[SP]>(smem);
-  uint32_t* scale_slot = reinterpret_cast<uint32_t*>(smem + QT * SP * 4);
+  float* inv_s = reinterpret_cast<float*>(smem + QT * SP * 4);
   const int tid = threadIdx.x, p = bx, q0 = by * QT;
   // MFMA path: the B operands of the wave's FIRST group of code slots are requested before anything else -- the codebook
-  // round trip runs under the prologue and the wait for the batch's scale; the second
+  // round trip runs under the prologue (the workgroup is a chain of latencies: all 768 are resident at once); the second
   // group's are requested into the same registers right after the first group's matrix instructions, under its conversion
   constexpr int STEPS_B = (S + 3) / 4;
   float bv[STEPS_B][4][2];
-  auto load_b = [&](int g) {   // (cbT here = the fragment-order copy, pin.hip build_fragment_codebook)
+  auto load_b = [&](int g) {   // (cbT here = the fragment-order copy, freddy_gpu.hip build_fragment_codebook)
     typedef float f4b __attribute__((ext_vector_type(4)));
     const f4b* src = reinterpret_cast<const f4b*>(cbT + ((((size_t)p * 8 + g) * STEPS_B) * 64 + (tid & 63)) * 8);
 #pragma unroll
@@ -182,8 +115,24 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
     const int qi = i / SP, j = i - qi * SP;
     qs[qi][j] = (j < S && q0 + qi < Q) ? queries[(size_t)(q0 + qi) * d + p * S + j] : 0.0f;
   }
-  __syncthreads();   // (qs)
-  float inv = 0.0f;   // 1 / T: asked for after the first group's matrix instructions -- the products do not depend on it
+  {
+    const int qi = tid >> 4, pp = tid & 15, q = q0 + qi;
+    float best = 0.0f;
+    if (pp < m && q < Q) {
+      float n2 = 0.0f;
+      for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + pp * S + j]; n2 = __builtin_fmaf(v, v, n2); }
+      const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+      if (p == 0) qn[(size_t)q * m + pp] = nrm;
+      best = 2.0f * nrm * cmax[pp];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (pp == 0) {
+      const float sc = q < Q ? best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f) : 0.0f;
+      inv_s[qi] = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
+      if (p == 0 && q < Q) qscale[q] = sc;
+    }
+  }
   {
     // The dot products on the matrix cores (v_mfma_f32_16x16x4_f32: A = 16 queries x 4 dimensions, B = 4 dimensions x 16
     // codes, seven steps for S = 25): a wave takes two groups of 16 code slots and, per group, the eight tiles whose codes
@@ -192,6 +141,7 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
     // the fmaf chain's (order, product rounding): within the 28 u 2|q_p||c| -> 56 u the bracket's derivation (top of this
     // file) leaves room for (e = 105 u B + 6 scale <= E / 4.2 = 122 u B + 6.67 scale).
     typedef float f4v __attribute__((ext_vector_type(4)));
+    __syncthreads();   // (qs, inv_s)
     const int wave = tid >> 6, lane = tid & 63, col = lane & 15, kq = lane >> 4;
     const int nq = (Q - q0 < QT) ? Q - q0 : QT;
     constexpr int STEPS = (S + 3) / 4;
@@ -212,16 +162,12 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int e = 0; e < 2; ++e) acc[i][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st][i][e], acc[i][e], 0, 0, 0);
-      if (gg == 0) {
-        load_b(g + 1);
-        const float sc = batch_scale5(z, scale_slot);
-        inv = (sc > 0.0f && sc < 1e30f) ? 1.0f / sc : 0.0f;
-        if (p == 0 && tid < QT && q0 + tid < Q) qscale[q0 + tid] = sc;
-      }
+      if (gg == 0) load_b(g + 1);
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int qi = 4 * kq + reg;
         if (qi < nq) {
+          const float inv = inv_s[qi];
           uint32_t wd[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -236,24 +182,18 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
   }
 }
 template <int S, int QT>
-static constexpr int query_codebook5_lds() { return QT * ((S + 3) & ~3) * 4 + 16; }
-// grid: (Q + 15) / 16 norm workgroups, then m x (Q + 15) / 16 table units
+static constexpr int query_codebook5_lds() { return QT * ((S + 3) & ~3) * 4 + QT * 4; }
 template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
                                                              const float* __restrict__ cmax, float* __restrict__ qn,
                                                              float* __restrict__ qscale, uint32_t* __restrict__ qc,
-                                                             int Q, int d, int m, int K, ScaleSync z) {
+                                                             int Q, int d, int m, int K) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[query_codebook5_lds<S, QT>()];
-  const int n_norm = (Q + QT - 1) / QT;
-  const int b = blockIdx.x;
-  if (b < n_norm) { query_norms5_body<S>(queries, cmax, qn, Q, d, m, b, z); return; }
-  const int t = b - n_norm;
-  query_codebook5_body<S, QT>(queries, cbT, qscale, qc, Q, d, m, K, t % m, t / m, smem, z);
+  query_codebook5_body<S, QT>(queries, cbT, cmax, qn, qscale, qc, Q, d, m, K, blockIdx.x, blockIdx.y, smem);
 }
 
 // The MFMA cell-selection distances (coarse.h) and the query x codebook table in ONE launch: the first `n_coarse`
-// workgroups compute the queries' norms (the batch's table scale, above), the next `n_coarse` are coarse tiles, the others
-// table units (position, 16 queries).  Tiles and units do not depend on each other and both are a
+// workgroups are coarse tiles, the others table units (position, 16 queries).  Neither depends on the other and both are a
 // few tens of microseconds of small workgroups; as two kernels of a batch's chain they cost two launches, two
 // dependencies (with batches in flight the table kernel runs in line: a side stream per batch collides with the other
 // batches' streams in the hardware queues).  The workgroups keep their own shape and lifetime -- a version in which every
@@ -265,15 +205,12 @@ struct CoarseTableArgs {
   const float* cbT; const float* cmax; float* qn; float* qscale; uint32_t* qc; int m, K;
   float* tmin; int C;   // many cells: the (query, 128-cell tile) minima for the plan's two-level selection (NULL: not wanted)
   const ch8v* coarseH; int ec;   // many cells: the centroids split into f16 hi / lo (coarse_approx16_body); NULL: the fp32 tile
-  ScaleSync ss;
 };
 template <int S, int QT, bool H16 = false>   // H16: the coarse tiles on f16-split operands (many cells); an instantiation of its own, so
 __global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {   // that the <= 1024-cell kernel compiles as before
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int n_norm = (a.Q + QT - 1) / QT;
   const int n_coarse = a.coarse_gx * a.coarse_gy;
-  if ((int)blockIdx.x < n_norm) { query_norms5_body<S>(a.queries, a.cmax, a.qn, a.Q, a.d, a.m, (int)blockIdx.x, a.ss); return; }
-  const int b = (int)blockIdx.x - n_norm;
+  const int b = blockIdx.x;
   if (b < n_coarse) {
     if constexpr (H16)
       coarse_approx16_body(a.queries, a.coarseH, a.ec, a.cn2, a.dist, a.qn2, a.Q, a.Cpad, a.d, a.z, b % a.coarse_gx, b / a.coarse_gx,
@@ -283,17 +220,11 @@ __global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {
                        a.coarse_gx, a.coarse_gy, smem, a.tmin, a.C);
   } else {
     const int t = b - n_coarse;
-    query_codebook5_body<S, QT>(a.queries, a.cbT, a.qscale, a.qc, a.Q, a.d, a.m, a.K, t % a.m, t / a.m, smem, a.ss);
+    query_codebook5_body<S, QT>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, t % a.m, t / a.m, smem);
   }
 }
 
-// the selection margin in table units (ivf_filter5_kernel's integer selection): rows with X <= tau_X + WI are kept; all ones = every row
-__device__ __forceinline__ uint32_t filter_width_int5(float E, float T) {
-  if (!(E < 1e30f) || !(T > 0.0f) || !(T < 1e30f)) return 0xffffffffu;
-  const float w = E / T;   // (>= 28)
-  return w < 60000.0f ? (uint32_t)w + 3u : 0xffffffffu;
-}
-// Entry records (layout: refine.h); [7] = the batch's table scale T, [128 + g] = item g's selection margin in table units.
+// Entry records as entry_record_kernel; [128 + g] = the table scale of item g's query.
 template <int M>
 __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
   const int lane = threadIdx.x & 63;
@@ -309,8 +240,6 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
     int rows = a.list_off[cell + 1] - a.list_off[cell] - chunk * (FUSED_UNIT_BLOCKS * 64);
     if (rows > FUSED_UNIT_BLOCKS * 64) rows = FUSED_UNIT_BLOCKS * 64;
     rec[0] = cell; rec[1] = cnt; rec[2] = chunk; rec[3] = b0; rec[4] = nb; rec[5] = rows;
-    rec[7] = (int32_t)__float_as_uint(a.qscale[a.item_query[a.sorted_item[first]]]);   // the batch's table scale T
-    rec[120] = (int32_t)__float_as_uint(a.listmin[cell]);                               // a lower bound of the rows' own terms
   }
   if (lane < 16) {
     const int it = lane < cnt ? a.sorted_item[first + lane] : -1;
@@ -325,7 +254,7 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
     rec[72 + lane] = (int32_t)__float_as_uint(ib.shift);
     rec[88 + lane] = (int32_t)ib.lo_bits;
     rec[104 + lane] = (int32_t)ib.hi_bits;
-    rec[128 + lane] = (int32_t)filter_width_int5(ib.e, sc);
+    rec[128 + lane] = (int32_t)__float_as_uint((it >= 0 && sc < 1e30f) ? sc : 0.0f);
   }
 }
 
@@ -466,9 +395,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       int32_t rr0 = 0;
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        // this entry's row terms (fetched during the previous entry): staged once the previous entry's survivor pass is over
-        // (the barrier of phase 0), read by the gatherers in this entry's tail
-        if (j == 1 && ei > 0) stash_row_terms();
         // the next entry's record: requested in phase 0, stored in phase 1, first read in phase 2
         if (j == 1 && tid < REC_DW) {
           if (tid == 0) gidq[ei & 1] = gid2;
@@ -497,30 +423,25 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         tick(1);
       }
       // S1: thresholds tau + E (builder wave w: items w and w + 8), while the gatherers are in their tail
-      {
+      if (!(a.fence & 4)) {
         const int32_t* rec = dsc + cur * REC_DW;
         const int cnt = __builtin_amdgcn_readfirstlane(rec[1]);
         const int i0 = wave, i1 = wave + NG;
         if (i0 < cnt) {
           uint32_t c0 = colmin[i0 * 64 + lane], c1 = colmin[i1 * 64 + lane];
-          wave_sort32_x2(c0, c1);   // (CAND: order-preserving keys of the float column minima; else the integer X)
+          wave_sort32_x2(c0, c1);   // (order-preserving keys of the float column minima)
           const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
           if (lane == 0) {
-            if constexpr (CAND) {
-              thr_s[i0] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
-              thr_s[i1] = a.keep_all ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
-            } else {   // tau_X + WI; all ones (every row) where the L-th minimum or the margin is out of the 16-bit range
-              const uint32_t w0 = (uint32_t)rec[128 + i0], w1 = (uint32_t)rec[128 + i1];
-              thr_s[i0] = (a.keep_all || t0 >= 0xffffu || w0 >= 0xffffu || t0 + w0 >= 0xffffu) ? 0xffffffffu : t0 + w0;
-              thr_s[i1] = (a.keep_all || t1 >= 0xffffu || w1 >= 0xffffu || t1 + w1 >= 0xffffu) ? 0xffffffffu : t1 + w1;
-            }
+            thr_s[i0] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
+            thr_s[i1] = a.keep_all ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
           }
           colmin[i0 * 64 + lane] = 0xffffffffu;
           colmin[i1 * 64 + lane] = 0xffffffffu;
         }
       }
       lds_barrier();   // S1
-      lds_barrier();   // S2 (the gatherers' survivor pass reads the CURRENT entry's staged row terms: the next entry's are staged in its phase 1)
+      stash_row_terms();   // (the gatherers took the current entry's into registers before their S1 barrier)
+      lds_barrier();   // S2
       tick(3);
       if constexpr (PROF) pt[7] += 1;
       if (!have_next) break;
@@ -645,8 +566,11 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           default: main_loop(I2{}, I8{}); break;
         }
       }
-      // ---- tail.  base[r] = the row's own term (staged by the builders in the previous entry's tail, replaced in this one's
-      // after the S1 barrier); +inf for the slots of this wave beyond its last block and for the lanes past the end of the list.
+      // ---- tail.  The selection works on s' = fma(scale[item], V, rterm[row]) -- the stored sum WITHOUT the item's
+      // constant OFF -- compared as floats: a constant shift changes neither the order nor tau' + E.  OFF (which keeps
+      // the stored bits positive for the merge) is added for the survivors only: s = s' + OFF.
+      // base[r] = the row's own term (staged by the builders in the previous entry's tail, replaced in this one's after the S1 barrier); +inf for the slots of this wave beyond its last block and for the lanes
+      // past the end of the list (s = +inf: above every finite threshold; S2 skips the former and masks the latter)
       float base[RMAX];
       const int last_blk = nrows > 0 ? (nrows - 1) >> 6 : -1;     // chunk-relative block holding the last row
       const int rs2 = (last_blk >= 0 && (last_blk % NG) == gw && (nrows & 63)) ? last_blk / NG : -1;
@@ -658,153 +582,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
           if (r >= rl_wave || (r == rs2 && !live_lane)) base[r] = __uint_as_float(0x7f800000u);
         }
       }
-      // rows this lane really holds: bit r of live8
-      uint32_t live8 = 0u;
-#pragma unroll
-      for (int r = 0; r < RMAX; ++r)
-        if (r < rl_wave && !(r == rs2 && !live_lane)) live8 |= 1u << r;
-      const int gi = lane & 15;
-      if constexpr (!CAND) {
-        // INTEGER selection (the common rule: freddy.c:366 counts retrieved rows, nothing but the threshold test).  All items of
-        // an entry share the batch's table scale T, so a row's own term joins the integer sum once per ROW:
-        //   X(row, item) = U + Rq,   U = V + 2^15 the biased sum the gathers left (16 bits),  Rq = rint((rterm[row] - rmin) / T) >= 0,
-        // rmin = the smallest row term of the entry's list (pin time, in the entry's record).  T X is s' = T V + rterm
-        // shifted by a constant, +- (0.5 + 2^-6) T -- the selection needs only differences: with tau_X the L-th smallest lane
-        // minimum of X, every row with X <= tau_X + WI survives, WI = ceil(E / T) + 2 (entry record).  Why that is enough:
-        // T X is within e' = e + 0.52 T of the exact distance up to the item's constant (e as in the header: 107 u B + 6 T), the
-        // rows that can matter have X <= X_(L) + 2 e' / T (X_(L) the L-th smallest X of the chunk, <= tau_X), and
-        // E >= 4.2 e, e >= 6 T give WI > 2 e / T + 1.04 + 2.  A survivor's LOWER BOUND is formed from the float value
-        // s' = fma(T, V, rterm) as before (V = X - Rq - 2^15 exactly), so brackets, the merge and its self-check see the same
-        // numbers as with the float selection.  X is kept as KEY = 8 X + r (r = the row slot) in 32 bits: the lane's smallest key
-        // names its row; three instructions per (item, row): v_mad_u32_u16 (8 U + (8 Rq + r); op_sel picks the item's half),
-        // v_med3_u32, v_min_u32.
-        const float T = __int_as_float(__builtin_amdgcn_readfirstlane(rec[7]));
-        const float invT = (T > 0.0f && T < 1e30f) ? 1.0f / T : 0.0f;
-        const float rmin = __int_as_float(__builtin_amdgcn_readfirstlane(rec[120]));
-        auto row_q = [&](float b) -> uint32_t {   // Rq; a dead slot (+inf) and a row term of a non-finite table: 2^25
-          return (uint32_t)fmaxf(fminf(__builtin_rintf((b - rmin) * invT), 33554432.0f), 0.0f);
-        };
-        uint32_t rq8[RMAX];   // 8 Rq + r
-        bool nan_row = false;
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          rq8[r] = (row_q(base[r]) << 3) + (uint32_t)r;
-          nan_row = nan_row || (base[r] != base[r]);
-        }
-        // key of (item g, row slot r) = 8 X + r
-        auto row_key = [&](int g, int r) -> uint32_t {
-          uint32_t key;
-          if (g & 1) asm("v_mad_u32_u16 %0, %1, 8, %2 op_sel:[1,0,0,0]" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
-          else asm("v_mad_u32_u16 %0, %1, 8, %2" : "=v"(key) : "v"(acc[g >> 1][r]), "v"(rq8[r]));
-          return key;
-        };
-        gtick(0);
-        uint32_t best[G];                // the lane's smallest key of every item
-        uint32_t sec16[G / 2];           // the X of its second smallest (capped at 0xffff), two items per register
-#pragma unroll
-        for (int g = 0; g < G; ++g) best[g] = 0xffffffffu;
-#pragma unroll
-        for (int i = 0; i < G / 2; ++i) sec16[i] = 0xffffffffu;
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (g < cnt) {
-            uint32_t b1 = 0xffffffffu, b2 = 0xffffffffu;
-#pragma unroll
-            for (int r = 0; r < RMAX; ++r) {
-              const uint32_t key = row_key(g, r);
-              asm("v_med3_u32 %0, %1, %2, %3" : "=v"(b2) : "v"(b1), "v"(b2), "v"(key));   // (b1 <= b2: the median is the new second smallest)
-              b1 = b1 < key ? b1 : key;
-            }
-            best[g] = b1;
-            const uint32_t x2 = (b2 < 0x7ffffu ? b2 : 0x7ffffu) >> 3;
-            sec16[g >> 1] = (g & 1) ? ((sec16[g >> 1] & 0x0000ffffu) | (x2 << 16)) : ((sec16[g >> 1] & 0xffff0000u) | x2);
-            if (rl_wave > 0) atomicMin(colmin + g * 64 + lane, b1 >> 3);
-          }
-        }
-        if (__ballot(nan_row) != 0ull) {   // (a non-finite row term: the lane takes the row-by-row path and the row passes)
-#pragma unroll
-          for (int g = 0; g < G; ++g) best[g] = nan_row ? 0u : best[g];
-#pragma unroll
-          for (int i = 0; i < G / 2; ++i) sec16[i] = nan_row ? 0u : sec16[i];
-        }
-        gtick(1);
-        lds_barrier();
-        // (S1, the thresholds tau_X + WI, is computed by the builder waves between these two barriers)
-        lds_barrier();
-        gtick(-1);
-        // S2: survivors -> this wave's region of each item's buffer.  Normally every lane has at most one (its smallest key, kept
-        // from the pass above); otherwise the pass bits of the lane's 8 rows, then per-row ballots.
-        {
-          const uint32_t p_thr = thr_s[gi];
-          const int p_it = rec[8 + gi];
-          const float p_shift = __int_as_float(rec[72 + gi]);
-          const float p_off = __int_as_float(rec[40 + gi]);
-          // (row by row -- the rare path: the rows' own terms come from the staged copy again, no registers are kept for them)
-          auto term = [&](int r) -> float { return rt_s[(r * NG + gw) * 64 + lane]; };
-          auto sval = [&](int g, int r) -> float {
-            const uint32_t w = acc[g >> 1][r];
-            const int v = (int)((g & 1) ? (w >> 16) : (w & 0xffffu)) - 32768;
-            return __builtin_fmaf(T, (float)v, term(r));
-          };
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-            if (g < cnt) {
-              const uint32_t thr = (uint32_t)__builtin_amdgcn_readlane((int)p_thr, g);          // X threshold; all ones: keep every row
-              const uint32_t thr_key = thr >= 0xffffu ? 0xffffffffu : (thr << 3) + 7u;
-              const float off = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_off), g));
-              const float shift = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_shift), g));
-              const int it = __builtin_amdgcn_readlane(p_it, g);
-              const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
-              u64* dst = a.surv + region * (size_t)(RMAX * 64);
-              int run = 0;
-              const uint32_t second = (g & 1) ? (sec16[g >> 1] >> 16) : (sec16[g >> 1] & 0xffffu);
-              const u64 multi = __ballot(second <= thr);   // lanes with two survivors (or: keep every row, non-finite row terms)
-              if (__builtin_expect(multi == 0ull, 1)) {
-                const bool pass = best[g] <= thr_key;
-                const u64 mask = __ballot(pass);
-                if (mask != 0ull) {
-                  if (pass) {
-                    const uint32_t r = best[g] & 7u;
-                    const float b = rt_s[(r * (uint32_t)NG + (uint32_t)gw) * 64u + (uint32_t)lane];   // (a passing row is a live one: its staged term)
-                    const int v = (int)((best[g] >> 3) - row_q(b)) - 32768;                           // = the row's V: X - Rq - 2^15
-                    const float dlo = fmaxf(0.0f, (__builtin_fmaf(T, (float)v, b) + off) - shift);
-                    const uint32_t loc = ((uint32_t)(blk0 + gw) + r * (uint32_t)NG) * 64u + (uint32_t)lane;
-                    dst[lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
-                  }
-                  run = __popcll(mask);
-                }
-              } else {
-                uint32_t m8 = 0u;
-#pragma unroll
-                for (int r = 0; r < RMAX; ++r) {
-                  const float tr = term(r);
-                  m8 |= (row_key(g, r) <= thr_key || tr != tr) ? (1u << r) : 0u;   // (a NaN passes: exact stage)
-                }
-                m8 &= live8;
-                if (__ballot(m8 != 0u) != 0ull) {
-#pragma unroll
-                  for (int r = 0; r < RMAX; ++r) {
-                    const bool pass = (m8 >> r) & 1u;
-                    const u64 mask = __ballot(pass);
-                    if (mask != 0ull) {
-                      if (pass) {
-                        const float dlo = fmaxf(0.0f, (sval(g, r) + off) - shift);
-                        const uint32_t loc = (uint32_t)(blk0 + r * NG + gw) * 64u + (uint32_t)lane;
-                        dst[run + lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
-                      }
-                      run += __popcll(mask);
-                    }
-                  }
-                }
-              }
-              if (lane == 0) a.surv_count[region] = run;
-            }
-          }
-        }
-      } else {
-        // FLOAT selection (the rule that counts rows below the sentinel, freddy.c:971): s' = fma(T, V, rterm[row]) -- the stored
-        // sum WITHOUT the item's constant OFF -- compared as floats: a constant shift changes neither the order nor tau' + E.
-        // OFF (which keeps the stored bits positive for the merge) is added where the bits are needed: s = s' + OFF.
 #pragma unroll
       for (int h = 0; h < G / 2; ++h)
 #pragma unroll
@@ -817,7 +594,13 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       };
       // Per-item parameters: lane g holds item g's (one LDS read each, fetched with v_readlane below -- a chain of
       // dependent LDS round trips per item was a quarter of the entry's time).
-      const float p_sc = __int_as_float(rec[7]);   // (one table scale per batch)
+      const int gi = lane & 15;
+      const float p_sc = __int_as_float(rec[128 + gi]);
+      // rows this lane really holds: bit r of live8
+      uint32_t live8 = 0u;
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r)
+        if (r < rl_wave && !(r == rs2 && !live_lane)) live8 |= 1u << r;
       float best[G];
       uint32_t sec16[G / 2];           // second smallest, rounded DOWN to 16 bits (sign, exponent, 7 bits): two items per register
       uint32_t apack[2] = {0u, 0u};
@@ -825,7 +608,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       for (int g = 0; g < G; ++g) best[g] = __uint_as_float(0x7f800000u);
 #pragma unroll
       for (int i = 0; i < G / 2; ++i) sec16[i] = 0x7f807f80u;
-      {
+      if (!(a.fence & 4)) {
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
@@ -859,7 +642,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       gtick(-1);
       // S2: survivors -> this wave's region of each item's buffer.  Normally every lane has at most one (its smallest
       // sum, kept from the pass above); otherwise the pass bits of the lane's 8 rows, branch free, then per-row ballots.
-      {
+      if (!(a.fence & 4)) {
         const float p_thr = __uint_as_float(thr_s[gi]);
         const int p_it = rec[8 + gi];
         const float p_shift = __int_as_float(rec[72 + gi]);
@@ -877,7 +660,43 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
             const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
             u64* dst = a.surv + region * (size_t)(RMAX * 64);
             int run = 0;
-            {   // rows below the sentinel are counted (freddy.c:971): bounds on the bits of s = s' + OFF > 0
+            if constexpr (!CAND) {   // the common case (freddy.c:366 counts retrieved rows): nothing but the threshold test
+             const float second = __uint_as_float((g & 1) ? (sec16[g >> 1] & 0xffff0000u) : (sec16[g >> 1] << 16));
+             const u64 multi = __ballot(!(second > thr));   // lanes with two survivors (or: keep every row, NaNs)
+             if (__builtin_expect(multi == 0ull, 1)) {
+              const bool pass = !(best[g] > thr);
+              const u64 mask = __ballot(pass);
+              if (mask != 0ull) {
+                if (pass) {
+                  const uint32_t r = (apack[g >> 3] >> (3 * (g & 7))) & 7u;
+                  const float dlo = fmaxf(0.0f, (best[g] + off) - shift);
+                  const uint32_t loc = ((uint32_t)(blk0 + gw) + r * (uint32_t)NG) * 64u + (uint32_t)lane;
+                  dst[lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+                }
+                run = __popcll(mask);
+              }
+             } else {
+              uint32_t m8 = 0u;
+#pragma unroll
+              for (int r = RMAX - 1; r >= 0; --r) m8 = m8 + m8 + (!(sval(g, r, sc) > thr) ? 1u : 0u);   // (a NaN passes: exact stage)
+              m8 &= live8;
+              if ((a.fence & 128) == 0 && __ballot(m8 != 0u) != 0ull) {
+#pragma unroll
+                for (int r = 0; r < RMAX; ++r) {
+                  const bool pass = (m8 >> r) & 1u;
+                  const u64 mask = __ballot(pass);
+                  if (mask != 0ull) {
+                    if (pass) {
+                      const float dlo = fmaxf(0.0f, (sval(g, r, sc) + off) - shift);
+                      const uint32_t loc = (uint32_t)(blk0 + r * NG + gw) * 64u + (uint32_t)lane;
+                      dst[run + lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
+                    }
+                    run += __popcll(mask);
+                  }
+                }
+              }
+             }
+            } else {   // rows below the sentinel are counted (freddy.c:971): bounds on the bits of s = s' + OFF > 0
               const uint32_t lo_b = (uint32_t)__builtin_amdgcn_readlane((int)p_lo, g);
               const uint32_t hi_b = (uint32_t)__builtin_amdgcn_readlane((int)p_hi, g);
               int accepted = 0;
@@ -905,7 +724,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
             if (lane == 0) a.surv_count[region] = run;
           }
         }
-      }
       }
       gtick(2);
       const int next_ok = __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 6]);

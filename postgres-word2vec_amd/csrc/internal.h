@@ -104,12 +104,6 @@ struct Workspace {
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
       w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_tmin, w_one, w_oneb;
-  // the batch's table scale, formed inside the launch that builds the query x codebook table (fused5.h ScaleSync): one
-  // self-validating word per producer workgroup, the epoch flipped from call to call while their number stays the same
-  DevBuf w_scale;
-  uint32_t scale_epoch = 0;
-  int scale_n = -1;
-  bool scale_pending = false;     // a call was prepared and its launch not confirmed (an error in between): the words are cleared before the next use
   uint64_t one_shape = 0;          // the one-launch kernels' buffer (w_oneb): shape of the call that wrote it last, and that call's epoch (one.h)
   uint32_t one_epoch = 0;
   bool one_pending = false;        // one_buffer() flipped the epoch and the kernel was not (yet) launched
@@ -117,7 +111,7 @@ struct Workspace {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb, &w_scale};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -198,8 +192,7 @@ struct freddy_gpu_index {
   float* cbP = nullptr;         // fused kernel layout [m][SP/4][512 slots][4 dims][2 codes] (NULL unless K <= 1024)
   // filter + refine path (fused4.h); NULL unless the shape is the fused one and the table fits the budget
   float* cbR = nullptr;         // [m][K][S] row-major codebook for the exact stage
-  float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row, then [lists] the smallest of every list
-  float* rt_listmin = nullptr;  // = rterm + blocks*64
+  float* rterm = nullptr;       // [blocks*64] sum_p (|c|^2 + 2 co_p . c) of every row
   float* pmax = nullptr;        // [m]        max |co_p| + max |c_p|, rounded up
   float* cmaxp = nullptr;       // [m]        max |c_p|, rounded up
   float* cbF = nullptr;         // [m][8 groups][7 steps][64 lanes][8] the codebook in the B-fragment order of the table kernel's matrix instructions (fused5.h query_codebook5_body)
@@ -314,10 +307,6 @@ int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_it
 int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a);
 int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int32_t* item_cell, float* lut, int n_items,
                const float* coarse = nullptr, const int32_t* item_query = nullptr);
-namespace freddy { struct ScaleSync; }
-// the hand-off words of the batch's table scale for a launch with n_norm producer workgroups (enqueued on s); confirm after the launch
-int scale_sync_prepare(Workspace* ws, hipStream_t s, int n_norm, freddy::ScaleSync* z);
-inline void scale_sync_confirm(Workspace* ws) { ws->scale_pending = false; }
 int ivf_work_table(IvfRun& r, WorkTable& wt);
 int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt);
 int max_queries_per_chunk(const freddy_gpu_index* ix, int W);

@@ -96,21 +96,6 @@ int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int
 // IVFADC
 // ---------------------------------------------------------------------------------------
 
-int scale_sync_prepare(Workspace* ws, hipStream_t s, int n_norm, ScaleSync* z) {
-  if (ws->w_scale.ensure(sizeof(uint32_t) * (size_t)std::max(n_norm, 64))) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-  if (ws->scale_pending || ws->scale_n != n_norm) {   // another number of words (or an unconfirmed launch): all words to epoch 0
-    HIP_TRY(hipMemsetAsync(ws->w_scale.p, 0, sizeof(uint32_t) * (size_t)n_norm, s));
-    ws->scale_epoch = 0;
-    ws->scale_n = n_norm;
-  }
-  ws->scale_epoch ^= 1u;
-  z->part = ws->w_scale.as<uint32_t>();
-  z->n = n_norm;
-  z->epoch = ws->scale_epoch;
-  ws->scale_pending = true;
-  return 0;
-}
-
 // coarse distances (a6/a7) of every query of the chunk, and -- for the filter + refine scan -- the
 // per-batch query x codebook table beside them on the side stream
 static int ivf_coarse(IvfRun& r) {
@@ -173,28 +158,21 @@ static int ivf_coarse(IvfRun& r) {
     ct.cbT = ix->cbF; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
     ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K; ct.tmin = tile_min; ct.C = C;
     ct.coarseH = (const ch8v*)ix->coarseH; ct.ec = ix->coarse_ec;
-    const int n_norm = (Q + 15) / 16;
-    if (int rc = scale_sync_prepare(ws, s, n_norm, &ct.ss)) return rc;
     const size_t lds = std::max<size_t>(ix->coarseH ? coarse_approx16_lds(d) : (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
-    const unsigned grid = (unsigned)(n_norm + ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
+    const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
     timed_launch(ix, s, "coarse_table", [&] {
       if (ix->coarseH) hipLaunchKernelGGL((coarse_table5_kernel<25, 16, true>), dim3(grid), dim3(256), lds, s, ct);
       else hipLaunchKernelGGL((coarse_table5_kernel<25, 16>), dim3(grid), dim3(256), lds, s, ct);
     });
     HIP_TRY(hipGetLastError());
-    scale_sync_confirm(ws);
     return 0;
   }
   if (r.fused && r.scan_kernel == 5) {
-    ScaleSync z;
-    const int n_norm = (Q + 15) / 16;
-    if (int rc = scale_sync_prepare(ws, s, n_norm, &z)) return rc;
     timed_launch(ix, s, "query_codebook", [&] {
-      hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3((unsigned)(n_norm + m * n_norm)), dim3(256), 0, s, r.d_q, ix->cbF, ix->cmaxp,
-                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K, z);
+      hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, r.d_q, ix->cbF, ix->cmaxp,
+                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
     });
     HIP_TRY(hipGetLastError());
-    scale_sync_confirm(ws);
   }
   return launch_coarse();
 }
@@ -323,7 +301,7 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   RecordArgs ra;
   ra.group_cell = wt.group_cell; ra.group_first = wt.group_first; ra.group_cnt = wt.group_cnt; ra.n_groups = wt.n_groups;
   ra.sorted_item = ws->w_sorted.as<int32_t>(); ra.item_query = pa.item_query; ra.blk_off = ix->blk_off; ra.list_off = ix->list_off;
-  ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax; ra.listmin = ix->rt_listmin;
+  ra.item_dist = pa.item_dist; ra.qn = ws->w_qn.as<float>(); ra.qscale = ws->w_qn.as<float>() + (size_t)Q * m; ra.pmax = ix->pmax;
   ra.records = ws->w_records.as<int32_t>(); ra.sentinel = r.sentinel;
   if (!r.records_ready) {
     timed_launch(ix, s, "entry_records", [&] {
@@ -404,7 +382,7 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   mr.status = r.d_status;
   mr.n_active = r.n_active; mr.W = r.W; mr.upi = r.upi; mr.L = r.L; mr.k = r.k; mr.found_rule = r.found_rule;
   mr.first_round = r.first() ? 1 : 0; mr.K = K; mr.d = ix->d; mr.sentinel = r.sentinel;
-  mr.refine_all = (ix->tune.check_brackets & 1) ? 1 : 0;
+  mr.refine_all = (ix->tune.check_brackets & 1) ? 1 : 0; mr.fence = 0;
   mr.slices = 0; mr.part = nullptr;
   if (r.merge_slices > 0) {
     // a batch over the flat PQ table: `merge_slices` workgroups per query, each over its share of the pseudo-lists (r.W is the

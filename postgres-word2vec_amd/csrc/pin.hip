@@ -283,17 +283,13 @@ static int derive_codebook_tables_into(freddy_gpu_index* ix, const float* codebo
 
 // rterm[slot] for every row slot of the pinned lists (the (cell, row) part of the filter's cheap distance)
 static int refresh_row_terms(freddy_gpu_index* ix) {
-  if (ix->rterm) { (void)hipFree(ix->rterm); ix->rterm = nullptr; ix->rt_listmin = nullptr; }
+  if (ix->rterm) { (void)hipFree(ix->rterm); ix->rterm = nullptr; }
   if (!ix->cbR) return 0;
   const int64_t n_slots = std::max<int64_t>(ix->n_blocks, 1) * 64;
-  const int n_lists = ix->kind == KIND_IVF ? ix->C : 1;
-  if (hipMalloc((void**)&ix->rterm, sizeof(float) * ((size_t)n_slots + (size_t)n_lists)) != hipSuccess) return fail(FREDDY_E_NOMEM, "device allocation failed");
-  ix->rt_listmin = ix->rterm + n_slots;
-  HIP_TRY(hipMemsetAsync(ix->rt_listmin, 0, sizeof(float) * (size_t)n_lists, ix->stream));
+  if (hipMalloc((void**)&ix->rterm, sizeof(float) * (size_t)n_slots) != hipSuccess) return fail(FREDDY_E_NOMEM, "device allocation failed");
   if (ix->n_blocks > 0) {
     hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((ix->n_blocks * 64 + 255) / 256)), dim3(256), 0, ix->stream, ix->packed,
                        ix->blk_cell, ix->coarse, ix->cbR, ix->rterm, ix->n_blocks * 64, ix->M2, ix->d, ix->m, ix->K, ix->S);
-    hipLaunchKernelGGL(row_term_min_kernel, dim3((unsigned)n_lists), dim3(256), 0, ix->stream, ix->rterm, ix->blk_off, ix->rt_listmin, n_lists);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
       return fail(FREDDY_E_HIP, "building the row terms failed");
   }

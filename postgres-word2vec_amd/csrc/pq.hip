@@ -79,10 +79,9 @@ static bool pq_use_fused(const freddy_gpu_index* ix, int Q, int k) {
 struct PqFrontArgs {
   const float* queries; int Q, d, lists, W; int64_t n_rows;
   const int32_t* blk_off; const int32_t* list_off;
-  const float* cbT; const float* cmax; const float* pmax; const float* listmin;
+  const float* cbT; const float* cmax; const float* pmax;
   float* qn; float* qscale; uint32_t* qc; int m, K;
   float sentinel;
-  ScaleSync z;
   int32_t* item_cell; int32_t* item_query; float* item_dist; int32_t* round_rows; int32_t* records; int32_t* n_groups;
 };
 __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, unsigned char* smem) {
@@ -99,18 +98,23 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
   float* fs = qn_s + 16;                                 // [0] A, [1] scale
   const int tid = threadIdx.x;
   for (int i = tid; i < d; i += 256) { const float t = queries[(size_t)q * d + i] - 0.0f; sqs[i] = t * t; }
-  // the query's per-position norms: the very operations of query_norms5_body (same order, same roundings), so that this
-  // workgroup reads nothing the norm workgroups of the same launch write -- except the batch's table scale, which it waits for
+  // the query's per-position norms and its table scale: the very operations of query_codebook5_body (same order, same roundings),
+  // so that this workgroup needs nothing from the table units of the same launch
   if (tid < 16) {
     const int pp = tid, S = d / a.m;
+    float best = 0.0f;
     if (pp < a.m) {
       float n2 = 0.0f;
       for (int j = 0; j < S; ++j) { const float v = queries[(size_t)q * d + pp * S + j]; n2 = __builtin_fmaf(v, v, n2); }
-      qn_s[pp] = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+      const float nrm = __builtin_sqrtf(n2) * (1.0f + 1e-5f);
+      qn_s[pp] = nrm;
+      best = 2.0f * nrm * a.cmax[pp];
     }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) best = fmaxf(best, __shfl_xor(best, o, 64));
+    if (pp == 0) fs[1] = best * (1.0f / (float)FILT5_VMAX) * (1.0f + 1e-6f);
   }
-  const float T = batch_scale5(a.z, reinterpret_cast<uint32_t*>(fs + 2));
-  if (tid == 0) fs[1] = T;
+  __syncthreads();
   if (tid == 0) {
     float acc = 0.0f;
     for (int i = 0; i < d; ++i) acc = acc + sqs[i];     // index_utils.c:500-508, i ascending
@@ -135,18 +139,16 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
     rec[72 + slot] = (int32_t)__float_as_uint(ib.shift);
     rec[88 + slot] = (int32_t)ib.lo_bits;
     rec[104 + slot] = (int32_t)ib.hi_bits;
-    rec[128 + slot] = (int32_t)filter_width_int5(ib.e, sc);
+    rec[128 + slot] = (int32_t)__float_as_uint(sc < 1e30f ? sc : 0.0f);
     if (slot == 0) {
       const int b0 = blk_off[c];
       rec[0] = c; rec[1] = cnt; rec[2] = 0; rec[3] = b0; rec[4] = blk_off[c + 1] - b0; rec[5] = list_off[c + 1] - list_off[c];
-      rec[7] = (int32_t)__float_as_uint(sc);   // the batch's table scale
-      rec[120] = (int32_t)__float_as_uint(a.listmin[c]);
       // the slots beyond the group's queries: no item, the first query's number (a valid table), no bounds (entry_record5_kernel)
       const ItemBounds none = item_bounds(0.0f, 0.0f, sentinel);
       for (int u = cnt; u < SCAN5_G; ++u) {
         rec[8 + u] = -1; rec[24 + u] = q;
         rec[40 + u] = (int32_t)__float_as_uint(none.off); rec[56 + u] = (int32_t)__float_as_uint(none.e); rec[72 + u] = (int32_t)__float_as_uint(none.shift);
-        rec[88 + u] = (int32_t)none.lo_bits; rec[104 + u] = (int32_t)none.hi_bits; rec[128 + u] = (int32_t)0xffffffffu;
+        rec[88 + u] = (int32_t)none.lo_bits; rec[104 + u] = (int32_t)none.hi_bits; rec[128 + u] = 0;
       }
     }
   }
@@ -156,11 +158,9 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
 // workgroups form the query's scale themselves): a dependent launch less in a PQ batch's chain.
 __global__ __launch_bounds__(256) void pq_front_kernel(PqFrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int n_norm = (a.Q + 15) / 16;
-  const int n_table = a.m * n_norm;
-  if ((int)blockIdx.x < n_norm) { query_norms5_body<25>(a.queries, a.cmax, a.qn, a.Q, a.d, a.m, (int)blockIdx.x, a.z); return; }
-  const int b = (int)blockIdx.x - n_norm;
-  if (b < n_table) query_codebook5_body<25, 16>(a.queries, a.cbT, a.qscale, a.qc, a.Q, a.d, a.m, a.K, b % a.m, b / a.m, smem, a.z);
+  const int n_table = a.m * ((a.Q + 15) / 16);
+  const int b = blockIdx.x;
+  if (b < n_table) query_codebook5_body<25, 16>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, b % a.m, b / a.m, smem);
   else pq_records_body(a, b - n_table, smem);
 }
 
@@ -198,16 +198,15 @@ static int pq_view_refresh(freddy_gpu_index* ix, freddy_gpu_index** view, hipStr
   const size_t slots = (size_t)n_blocks * 64;
   if (fx->v_coarse.ensure(sizeof(float) * (size_t)lists * ix->d) || fx->v_list_off.ensure(sizeof(int32_t) * ((size_t)lists + 1)) ||
       fx->v_blk_off.ensure(sizeof(int32_t) * ((size_t)lists + 1)) || fx->v_blk_cell.ensure(sizeof(int32_t) * (size_t)n_blocks) ||
-      fx->v_pos.ensure(sizeof(int32_t) * slots) || fx->v_rterm.ensure(sizeof(float) * (slots + (size_t)lists)))
+      fx->v_pos.ensure(sizeof(int32_t) * slots) || fx->v_rterm.ensure(sizeof(float) * slots))
     return fail(FREDDY_E_NOMEM, "device allocation failed (PQ table as pseudo-lists)");
   fx->coarse = fx->v_coarse.as<float>(); fx->list_off = fx->v_list_off.as<int32_t>(); fx->blk_off = fx->v_blk_off.as<int32_t>();
-  fx->blk_cell = fx->v_blk_cell.as<int32_t>(); fx->pos = fx->v_pos.as<int32_t>(); fx->rterm = fx->v_rterm.as<float>(); fx->rt_listmin = fx->rterm + slots;
+  fx->blk_cell = fx->v_blk_cell.as<int32_t>(); fx->pos = fx->v_pos.as<int32_t>(); fx->rterm = fx->v_rterm.as<float>();
   HIP_TRY(hipMemsetAsync(fx->coarse, 0, sizeof(float) * (size_t)lists * ix->d, s));
   hipLaunchKernelGGL(pq_shadow_meta_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, pos, ix->ids, n_blocks, n_rows, lists,
                      fx->list_off, fx->blk_off, fx->blk_cell, fx->pos);
   hipLaunchKernelGGL(row_term_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, s, fx->packed, fx->blk_cell, fx->coarse, fx->cbR,
                      fx->rterm, (int64_t)slots, fx->M2, fx->d, fx->m, fx->K, fx->S);
-  hipLaunchKernelGGL(row_term_min_kernel, dim3((unsigned)lists), dim3(256), 0, s, fx->rterm, fx->blk_off, fx->rt_listmin, lists);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -266,16 +265,14 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   // queries' table scales: no item / work-table / record kernels (pq_front_kernel)
   PqFrontArgs fa;
   fa.queries = d_q; fa.Q = Q; fa.d = fx->d; fa.lists = lists; fa.W = W; fa.n_rows = fx->N; fa.blk_off = fx->blk_off; fa.list_off = fx->list_off;
-  fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.listmin = fx->rt_listmin; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
+  fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
   fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
   fa.item_dist = pa.item_dist; fa.round_rows = pa.round_rows; fa.records = ws->w_records.as<int32_t>(); fa.n_groups = wt.n_groups;
-  const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 4) * sizeof(float));
-  if (int rc = scale_sync_prepare(ws, s, (Q + 15) / 16, &fa.z)) return rc;
+  const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 2) * sizeof(float));
   timed_launch(fx, s, "pq_front", [&] {
-    hipLaunchKernelGGL(pq_front_kernel, dim3((unsigned)((m + 1) * ((Q + 15) / 16) + Q)), dim3(256), front_lds, s, fa);
+    hipLaunchKernelGGL(pq_front_kernel, dim3((unsigned)(m * ((Q + 15) / 16) + Q)), dim3(256), front_lds, s, fa);
   });
   HIP_TRY(hipGetLastError());
-  scale_sync_confirm(ws);
   return ivf_scan_filter(r, pa, wt);
 }
 

@@ -119,26 +119,6 @@ static __global__ __launch_bounds__(256) void row_term_kernel(const uint32_t* __
   rterm[slot] = (float)acc;
 }
 
-// listmin[c] = the smallest row term of list c (padding slots included: any lower bound will do) -- the common offset of the
-// scan's integer selection (fused5.h); kept behind the row terms, rterm[n_slots + c].  One workgroup per list.
-static __global__ __launch_bounds__(256) void row_term_min_kernel(const float* __restrict__ rterm, const int32_t* __restrict__ blk_off,
-                                                                 float* __restrict__ listmin, int n_lists) {
-  __shared__ float wm[4];
-  const int c = blockIdx.x;
-  if (c >= n_lists) return;
-  const int64_t lo = (int64_t)blk_off[c] * 64, hi = (int64_t)blk_off[c + 1] * 64;
-  float mn = __uint_as_float(0x7f800000u);
-  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) mn = fminf(mn, rterm[i]);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mn;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    mn = fminf(fminf(wm[0], wm[1]), fminf(wm[2], wm[3]));
-    listmin[c] = mn < 3e38f ? mn : 0.0f;
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 // Work-entry records: everything the scan needs to know about an entry in one 512-byte row, so that the
 // persistent workgroups fetch the next entry with ONE load instead of a chain of dependent ones
@@ -162,7 +142,6 @@ struct RecordArgs {
   const float* qn;
   const float* qscale;
   const float* pmax;
-  const float* listmin;     // [lists] smallest row term of every list (behind the row terms)
   int32_t* records;
   float sentinel;
 };
@@ -196,6 +175,7 @@ struct MergeRefineArgs {
   int n_active, W, upi, L, k, found_rule, first_round, K, d;
   float sentinel;
   int refine_all;    // option refine_all (tests): every survivor goes through the exact stage and is counted in violations[1]
+  uint32_t fence;    // always 0 (as FilterArgs::fence: never-true conditions that keep the stages' code in blocks of their own: 25.2 instead of 26.6 us)
   // PARTIAL instantiation (a batch over the flat PQ table): workgroup x = (query x / slices, slice x % slices) merges the
   // survivors of ITS W items (the query's items are slices * W wide) and leaves its L smallest exact keys in part[x][L];
   // merge_replay_kernel selects among the slices' keys and replays.  (Each slice's 2k smallest exact keys contain the
@@ -247,8 +227,8 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
   const int R = a.W * per_item;
   constexpr int NBATCH = 4;
 
-  for (int j = threadIdx.x; j < M * S; j += 64 * NWV) qs[j] = a.queries[(size_t)q * a.d + j];
-  const float E = filter_width5<M>(a.qn + (size_t)q * M, a.pmax, a.qscale5[q]);
+  if (!(a.fence & 2)) for (int j = threadIdx.x; j < M * S; j += 64 * NWV) qs[j] = a.queries[(size_t)q * a.d + j];
+  const float E = (a.fence & 2) ? 0.0f : filter_width5<M>(a.qn + (size_t)q * M, a.pmax, a.qscale5[q]);
 
   // one tile of the exact stage: chains [t*64, t*64+64) of the first n queue entries -> lutv
   auto tile_work = [&](int t, float* sqb, int n) {
@@ -313,7 +293,7 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
 
   // ---- pass 1: the L smallest lower bounds ----
   // (a few more than L are kept: the rows to refine are normally all among them)
-  const int LW = (a.L + 22 < 64 && R <= 64 * NBATCH) ? a.L + 22 : 64;
+  const int LW = (a.fence & 4) ? a.L : ((a.L + 22 < 64 && R <= 64 * NBATCH) ? a.L + 22 : 64);
   // Dense sweep.  The survivors of a query sit in R regions (item x chunk x gatherer wave) of a few keys each; walking them
   // region by region (a lane per region) is a chain of dependent round trips as long as the fullest region.  Instead: the
   // counts of a block of <= PB regions (one round trip) -> exclusive prefix in LDS -> lane s of the wave takes the s-th key
@@ -460,6 +440,12 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
               });
   }
   sel.finish();
+  if (a.fence & 8) {
+    if (lane < k) a.out_ids[(size_t)q * k + lane] = (int32_t)sel.acc[0];
+    if (lane == 0) sh_n = 0;
+    __syncthreads();
+    return;
+  }
   // T = (L-th smallest d_lo) + E, rounded up; every key of the query if there are fewer than L or E is not finite
   uint32_t T_bits;
   {
@@ -566,11 +552,12 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
         }
         queued = n;
         __builtin_amdgcn_wave_barrier();
-        round4(n);
+        if (!(a.fence & 1)) round4(n); else queued = 0;
       }
     }
   }
   if (revisit) sweep([&](u64 kk, bool valid, int j) { offer(kk, valid, valid ? a.item_cell[(size_t)x * a.W + j / per_item] : 0); }, 0, PB);
+  if (a.fence & 1) queued = 0;
   // the queued rows are refined by the four waves together, NC per round (normally one round: <= NC rows; a batch over
   // the flat PQ table has 20 .. 60 rows within E of its 2k-th smallest bound)
   if (NWV > 1) {
