@@ -52,9 +52,10 @@ enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3, KIND_VEC = 4 };
 // profiles/HISTORY.md has their numbers.)
 struct Tuning {
   // -- deployment
-  int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches the CALLER keeps in flight on this handle through the *_dev entry points
-                               // (one stream each): a persistent scan takes n_cus / share CUs so that the scans run side by side (DESIGN.md
-                               // 5.1).  An explicit contract -- the library does not guess it; the host-buffer calls pass their own lane count
+  int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches that share the chip with one of this handle's -- the batches the CALLER keeps
+                               // in flight through the *_dev entry points (one stream each), or the other BACKENDS (processes) searching at
+                               // the same time: a persistent scan takes n_cus / share CUs so that the scans run side by side.
+                               // An explicit contract -- the library does not guess it; the host-buffer calls multiply it by their lane count
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams (RCCL beside the scans)
   int pipeline_batch = 2048;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)

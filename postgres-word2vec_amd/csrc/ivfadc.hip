@@ -676,7 +676,7 @@ static int ivfadc_sync_search(freddy_gpu_index* ix, const float* queries, int Q,
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
-    if (int rc = ivfadc_begin(ix, s, 1, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+    if (int rc = ivfadc_begin(ix, s, ix->tune.scan_share, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
                               ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k, nullptr, r))
       return rc;
     if (int rc = ivfadc_finish(r, -1)) return rc;
@@ -924,7 +924,7 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
       if (trace) t2 = now_us();
     }
     IvfRun r;
-    if ((rc = ivfadc_begin(ix, l.stream, n_lanes, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
+    if ((rc = ivfadc_begin(ix, l.stream, n_lanes * ix->tune.scan_share, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
                            c.d_dist.as<float>(), nullptr, r)))
       break;
     if (trace) t3 = now_us();

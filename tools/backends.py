@@ -29,10 +29,17 @@ np.savez(path, coarse=np.asarray(tab["coarse"]), codebook=np.asarray(tab["codebo
          codes=np.asarray(tab["codes"]), queries=qs, k=5, W=10, exp_ids=ei, exp_dist=ed, shapes=np.array([1024], np.int32))
 print(f"# backends on one MI355X: {N} x 300, C = 1000, K = 1024, nprobe 10, k = 5; every process pins its own copy ({index_mb:.0f} MB) and makes")
 print(f"# 1024-query host-buffer calls for {seconds:.0f} s; lists compared bit for bit with the single-process lists")
-for P in (1, 2, 4):
+CONFIGS = [(1, 1, None), (1, 1, 2), (2, 1, None), (2, 2, None), (2, 2, 2), (4, 1, None), (4, 4, None), (4, 2, 1), (4, 2, 2), (4, 2, 3), (4, 2, 4), (4, 4, 2),
+           (8, 2, 1), (8, 4, 1), (8, 4, 2)]
+if len(sys.argv) > 3:   # e.g. "4:2:2,8:4:1" = processes : scan_share : GPU_MAX_HW_QUEUES (0 = the library's default of 6)
+    CONFIGS = [tuple(int(v) or None for v in c.split(":")) for c in sys.argv[3].split(",")]
+for P, share, hwq in CONFIGS:
+    env = dict(os.environ, FREDDY_GPU_SCAN_SHARE=str(share))   # (the option every backend is given: how many batches share the chip)
+    if hwq:
+        env["GPU_MAX_HW_QUEUES"] = str(hwq)
     with tempfile.TemporaryDirectory() as sync:
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "backend_worker.py"), path, str(r), str(P), str(seconds), sync, "batch"],
-                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(P)]
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(P)]
         outs = []
         for p in procs:
             so, se = p.communicate(timeout=600)
@@ -41,6 +48,6 @@ for P in (1, 2, 4):
         print(P, "processes: FAILED", outs)
         continue
     per = [o["queries_per_s"] for o in outs]
-    print(f"{P} process(es): aggregate {sum(per) / 1e6:6.2f} M queries/s   per process {[round(v / 1e6, 2) for v in per]} M   "
+    print(f"{P} process(es), scan_share {share}, GPU_MAX_HW_QUEUES {hwq or 'default (6)'}: aggregate {sum(per) / 1e6:6.2f} M queries/s   per process {[round(v / 1e6, 2) for v in per]} M   "
           f"mismatching calls {sum(o['mismatches'] for o in outs)}   bracket violations {sum(o['bound_violations'] for o in outs)}   pin {outs[0]['pin_seconds']} s")
 os.remove(path); os.rmdir(d)
