@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void join_mark_kernel(const int32_t* __restric
   win[i] = w;
 }
 __global__ __launch_bounds__(256) void join_offsets_kernel(const int32_t* __restrict__ cnt, int cells, int32_t* __restrict__ off,
-                                                          int32_t* __restrict__ fill) {
+                                                          int32_t* __restrict__ fill, int32_t* __restrict__ off_host) {
   __shared__ int scan[256];
   const int tid = threadIdx.x, per = (cells + 255) / 256;
   const int c0 = tid * per, c1 = (c0 + per < cells) ? c0 + per : cells;
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256) void join_offsets_kernel(const int32_t* __rest
     __syncthreads();
   }
   int run = scan[tid] - sum;
-  for (int c = c0; c < c1; ++c) { off[c] = run; fill[c] = run; run += cnt[c]; }
-  if (tid == 255) off[cells] = scan[255];
+  for (int c = c0; c < c1; ++c) { off[c] = run; fill[c] = run; off_host[c] = run; run += cnt[c]; }   // (off_host: mapped host memory)
+  if (tid == 255) { off[cells] = scan[255]; off_host[cells] = scan[255]; }
 }
 __global__ __launch_bounds__(256) void join_place_kernel(const int32_t* __restrict__ win, int n, const int32_t* __restrict__ cell,
                                                         int32_t* __restrict__ fill, int32_t* __restrict__ trow) {
@@ -912,43 +912,64 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   if (lds > 160 * 1024) return join_fail(FREDDY_E_LIMIT, "LDS need of %zu bytes exceeds 160 KiB (m=%d K=%d k*pvf=%d)", lds, m, K, L);
 
   // "fq.id IN (targets)": resolved, de-duplicated and bucketed by cell on the device (see join_mark_kernel)
-  std::vector<int32_t> tcell_off(cells + 1, 0);
-  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells = nullptr, *d_oi, *d_od, *d_tids, *d_win, *d_cnt, *d_sorted;
+  void *d_q, *d_sub, *d_tcell, *d_trow, *d_scan, *d_qoff, *d_qcells = nullptr, *d_oi, *d_od, *d_win, *d_cnt, *d_sorted;
   if (join_buf(j, 0, sizeof(float) * (size_t)Q * d, &d_q) || join_buf(j, 1, sizeof(float) * (size_t)Q * 2 * Kc, &d_sub) ||
       join_buf(j, 2, sizeof(int32_t) * (size_t)(cells + 1), &d_tcell) ||
       join_buf(j, 3, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_trow) ||
       join_buf(j, 4, sizeof(int32_t) * (size_t)Q, &d_scan) || join_buf(j, 5, sizeof(int32_t) * (size_t)(Q + 1), &d_qoff) ||
       join_buf(j, 7, sizeof(int32_t) * (size_t)Q * k, &d_oi) || join_buf(j, 8, sizeof(float) * (size_t)Q * k, &d_od) ||
-      join_buf(j, 9, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_tids) ||
       join_buf(j, 10, sizeof(int32_t) * std::max<size_t>((size_t)n_targets, 1), &d_win) ||
       join_buf(j, 11, sizeof(int32_t) * (size_t)cells * 2, &d_cnt) || join_buf(j, 12, sizeof(u64) * (size_t)Q * 2 * Kc, &d_sorted))
     return FREDDY_E_NOMEM;
-  const bool tl_hit = j->tl_valid && (int64_t)j->tl_ids.size() == n_targets && (int)j->tl_tcell_off.size() == cells + 1 &&
-                      (n_targets == 0 || memcmp(j->tl_ids.data(), target_ids, sizeof(int32_t) * (size_t)n_targets) == 0);
-  if (tl_hit) {
-    tcell_off = j->tl_tcell_off;    // (d_tcell / d_trow still hold this target array's buckets)
-  } else {
+  {
+    const size_t tl_bytes = sizeof(int32_t) * ((size_t)cells + 1 + (size_t)std::max<int64_t>(n_targets, 1));
+    if (tl_bytes > j->h_tl_cap) {
+      if (j->h_tl) (void)hipHostFree(j->h_tl);
+      j->h_tl = nullptr; j->h_tl_cap = 0; j->tl_valid = false;
+      if (hipHostMalloc(&j->h_tl, tl_bytes + tl_bytes / 4 + 256, hipHostMallocDefault) != hipSuccess) { j->h_tl = nullptr; return join_fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+      j->h_tl_cap = tl_bytes + tl_bytes / 4 + 256;
+    }
+  }
+  const int32_t* tcell_off = static_cast<const int32_t*>(j->h_tl);          // [cells + 1]; complete on the host after the first synchronisation
+  int32_t* h_tids = static_cast<int32_t*>(j->h_tl) + (size_t)cells + 1;     // the target array as the mark kernel reads it
+  const bool tl_hit = j->tl_valid && j->tl_n == n_targets && j->tl_cells == cells &&
+                      (n_targets == 0 || memcmp(h_tids, target_ids, sizeof(int32_t) * (size_t)n_targets) == 0);
+  if (!tl_hit) {   // (a hit: d_tcell / d_trow and the pinned offsets still hold this target array's buckets)
     j->tl_valid = false;
     int32_t* cnt = (int32_t*)d_cnt;
     int32_t* fill = cnt + cells;
     JOIN_HIP(hipMemsetAsync(j->markbits, 0, sizeof(uint32_t) * (size_t)((j->N + 31) / 32 + 1), s));
     JOIN_HIP(hipMemsetAsync(d_cnt, 0, sizeof(int32_t) * (size_t)cells * 2, s));
+    void* p_tl = nullptr;
+    JOIN_HIP(hipHostGetDevicePointer(&p_tl, j->h_tl, 0));
     if (n_targets > 0) {
-      JOIN_HIP(hipMemcpyAsync(d_tids, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(join_mark_kernel, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, s, (const int32_t*)d_tids,
+      memcpy(h_tids, target_ids, sizeof(int32_t) * (size_t)n_targets);
+      hipLaunchKernelGGL(join_mark_kernel, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, s, static_cast<const int32_t*>(p_tl) + (size_t)cells + 1,
                          (int)n_targets, (const int32_t*)j->ids, j->N, j->ids_affine ? 1 : 0, (const int32_t*)j->cell, j->markbits,
                          (int32_t*)d_win, cnt);
     }
-    hipLaunchKernelGGL(join_offsets_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)cnt, cells, (int32_t*)d_tcell, fill);
+    hipLaunchKernelGGL(join_offsets_kernel, dim3(1), dim3(256), 0, s, (const int32_t*)cnt, cells, (int32_t*)d_tcell, fill, static_cast<int32_t*>(p_tl));
     if (n_targets > 0)
       hipLaunchKernelGGL(join_place_kernel, dim3((unsigned)((n_targets + 255) / 256)), dim3(256), 0, s, (const int32_t*)d_win,
                          (int)n_targets, (const int32_t*)j->cell, fill, (int32_t*)d_trow);
     JOIN_HIP(hipGetLastError());
-    JOIN_HIP(hipMemcpyAsync(tcell_off.data(), d_tcell, sizeof(int32_t) * (size_t)(cells + 1), hipMemcpyDeviceToHost, s));
-    j->tl_ids.assign(target_ids, target_ids + n_targets);   // (becomes valid once the offsets have arrived: first synchronisation below)
+    j->tl_n = n_targets; j->tl_cells = cells;   // (valid once the offsets have arrived: first synchronisation below)
   }
   track(&freddy_track::data_retrieval_time);   // "fq.id IN (targets)" (enqueue only: the device work overlaps what follows)
-  {   // queries: host copy into pinned staging, read by a copy kernel (1.2 KB per query over PCIe)
+  // a query buffer that is pinned already (freddy_gpu_host_alloc: what pg/freddy_gpu_glue.c's query_buffer() hands over) is read
+  // where it is -- the 6 MB staging copy of 5 000 queries is the longest host step of a call
+  const float* p_queries = nullptr;
+  {
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof(attr));
+    if (hipPointerGetAttributes(&attr, queries) == hipSuccess && attr.type == hipMemoryTypeHost) p_queries = static_cast<const float*>(attr.devicePointer);
+    else (void)hipGetLastError();
+  }
+  const bool fused_front_p = (d & 1) == 0 && d / 2 <= 512;
+  if (p_queries && fused_front_p) {
+    hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, p_queries, j->coarseT, (float*)d_sub, d, Kc, (float*)d_q, 0);
+    JOIN_HIP(hipGetLastError());
+  } else {   // queries: host copy into pinned staging, read by a copy kernel (1.2 KB per query over PCIe)
     const size_t qbytes = sizeof(float) * (size_t)Q * d;
     if (qbytes > j->h_q_cap) {
       if (j->h_q) (void)hipHostFree(j->h_q);
@@ -1291,7 +1312,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     alpha += alpha;                                                                         // :680
     track(&freddy_track::recalculate_query_indices_time);
   }
-  if (!tl_hit) { j->tl_tcell_off = tcell_off; j->tl_valid = true; }   // (the offsets arrived with the first synchronisation)
+  if (!tl_hit) j->tl_valid = true;   // (the offsets arrived with the first synchronisation)
   j->track.iterations = iterations;
   j->track.total_time = std::chrono::duration<double>(now() - t_start).count();
   if (iterations_out) *iterations_out = iterations;

@@ -68,7 +68,12 @@ struct JoinIndex {
   bool ids_affine = false;       // ids[r] == ids[0] + r: O(1) id -> row
   // "fq.id IN (targets)" of the previous call: the same target array (compared word for word) finds its rows resolved,
   // de-duplicated and bucketed by cell already (workspaces 2 and 3 stay as they are); invalidated when rows are appended
-  std::vector<int32_t> tl_ids, tl_tcell_off;
+  // (kept in ONE pinned block: [cells + 1] bucket offsets, written by the offsets kernel, then the target array, which the mark
+  // kernel reads over PCIe -- no SDMA copy in either direction, and the copy the next call is compared with is the staging copy)
+  void* h_tl = nullptr;
+  size_t h_tl_cap = 0;
+  int64_t tl_n = -1;
+  int tl_cells = -1;
   bool tl_valid = false;
   // workspaces
   void* w[16] = {nullptr};
@@ -98,6 +103,7 @@ static inline void join_free(JoinIndex* j) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (j->h_q) (void)hipHostFree(j->h_q);
   if (j->h_sum) (void)hipHostFree(j->h_sum);
+  if (j->h_tl) (void)hipHostFree(j->h_tl);
   for (int i = 0; i < 16; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
   if (j->ev0) (void)hipEventDestroy(j->ev0);
   if (j->ev1) (void)hipEventDestroy(j->ev1);

@@ -299,6 +299,16 @@ def test_knn_join_matches_oracle(gpu, oracle, method, use_tl):
         exp, eit = oracle.ivpq_search_in(ot, qs, k, targets, alpha, pvf, method, use_target_lists=use_tl, confidence=0.8)
         assert git == eit, (git, eit)
         util.assert_same_lists(gi, gd, exp, f"knn_join method={method} tl={use_tl} k={k} alpha={alpha} pvf={pvf}")
+    # the query batch in a pinned buffer (freddy_gpu_host_alloc: read by the kernels where it is, no staging copy), a changed and
+    # a repeated target array (the repeated one finds its buckets in place)
+    pb = gpu.PinnedBuffer(qs.shape)
+    pb.array[:] = qs
+    for tg in (targets[::-1].copy(), targets, targets, targets[:1000].copy()):
+        gi, gd, git = idx.knn_join(pb.array, 5, tg, 10, 20, method, use_target_lists=use_tl, confidence=0.8)
+        exp, eit = oracle.ivpq_search_in(ot, qs, 5, tg, 10, 20, method, use_target_lists=use_tl, confidence=0.8)
+        assert git == eit, (git, eit)
+        util.assert_same_lists(gi, gd, exp, f"knn_join pinned queries method={method} tl={use_tl} targets={len(tg)}")
+    pb.close()
     idx.close()
 
 
