@@ -34,7 +34,7 @@ for _ in range(10):
 prof = index.profile_read()
 index.profile_enable(False)
 print({n: round(1e3 * ms / max(l, 1), 2) for n, (l, ms) in prof.items()}, "sum", round(sum(1e3 * ms / max(l, 1) for l, ms in prof.values()), 1))
-index.set_option("pipe_trace", 1)
+os.environ["FREDDY_GPU_PIPE_TRACE"] = "1"   # (read by -DFREDDY_LAB builds: FREDDY_GPU_SO=...libfreddy_gpu_lab.so)
 for _ in range(3):
     index.search(hq, 5, 10)
 t0 = time.perf_counter(); hq2 = hq.copy(); print(f"host memcpy of the queries ({hq.nbytes} B): {(time.perf_counter() - t0) * 1e6:.0f} us")

@@ -26,6 +26,6 @@ for Q in (1024, 4096, 8192):
             dt = (time.perf_counter() - t0) / 5
             print(f"Q={Q} lanes={lanes} batch={batch}: {dt * 1e3:.3f} ms  {Q / dt / 1e6:.2f} M q/s", flush=True)
 if "--trace" in sys.argv:
-    index.set_option("pipeline_lanes", 4); index.set_option("pipeline_batch", 1024); index.set_option("pipe_trace", 1)
+    index.set_option("pipeline_lanes", 4); index.set_option("pipeline_batch", 1024)   # (the host timeline: FREDDY_GPU_PIPE_TRACE=1 with a -DFREDDY_LAB build)
     index.search(hq[:4096], 5, 10)
     index.search(hq[:8192], 5, 10)

@@ -35,7 +35,6 @@ for seed in range(seeds):
     idx.set_option("pipeline_batch", int(rng.choice([16, 100, 256, 1024])))
     idx.set_option("pipeline_lanes", int(rng.choice([1, 2, 4])))
     idx.set_option("sparse_items", int(rng.choice([2, 0, -1, -3, -16])))   # (negative: the item-wise scan forced for cells of up to that many items)
-    idx.set_option("fuse_table", int(rng.integers(0, 2)))
     for (W, k, rule, sent) in [(int(rng.choice([1, 2, 5])), int(rng.choice([1, 5, 20])), 0, 1000.0), (1, 5, 2, 100.0), (3, 10, 1, 100.0)]:
         W = min(W, C)
         exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule, n_threads=8)
