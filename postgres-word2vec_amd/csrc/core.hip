@@ -34,6 +34,7 @@ Tuning read_tuning() {
   t.sparse_items = (int)env_int("FREDDY_GPU_SPARSE_ITEMS", t.sparse_items);
   t.exact_filter = (int)env_int("FREDDY_GPU_EXACT_FILTER", t.exact_filter);
   t.codes_u8 = (int)env_int("FREDDY_GPU_CODES_U8", t.codes_u8);
+  t.running_bound = (int)env_int("FREDDY_GPU_RUNNING_BOUND", t.running_bound);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
 #ifdef FREDDY_LAB
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -226,6 +227,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "lut_budget_mb") t.lut_budget_mb = std::max<int64_t>(1, value);
   else if (n == "exact_filter") t.exact_filter = (int)value;
   else if (n == "codes_u8") t.codes_u8 = (int)value;
+  else if (n == "running_bound") t.running_bound = (int)value;
 #ifdef FREDDY_LAB
   else if (n == "fused_prof") t.scan_prof = (int)value;
 #endif

@@ -255,6 +255,12 @@ __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
     rec[88 + lane] = (int32_t)ib.lo_bits;
     rec[104 + lane] = (int32_t)ib.hi_bits;
     rec[128 + lane] = (int32_t)__float_as_uint((it >= 0 && sc < 1e30f) ? sc : 0.0f);
+    // the item's coarse distance as an interval (item_bounds: relative error < 2e-5): what makes the cheap distances of
+    // different cells comparable (running bound of the query, ivf_filter5_kernel S1); +inf / 0: no part in it
+    const float A = it >= 0 ? a.item_dist[it] : -1.0f;
+    const bool fin = it >= 0 && ib.e < 1e30f && A >= 0.0f && A < 1e30f;
+    rec[144 + lane] = (int32_t)__float_as_uint(fin ? A * (1.0f + 2e-5f) : __uint_as_float(0x7f800000u));
+    rec[160 + lane] = (int32_t)__float_as_uint(fin ? A * (1.0f - 2e-5f) : 0.0f);
   }
 }
 
@@ -393,6 +399,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       int gid2 = 0;
       int next_nq = 0;
       int32_t rr0 = 0;
+      uint32_t run0 = 0u, run1 = 0u;
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         // the next entry's record: requested in phase 0, stored in phase 1, first read in phase 2
@@ -416,6 +423,12 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         if (j + 3 < NP) issue(set, j + 3, qid, nq);
         else issue(set, j + 3 - NP, nqid, next_nq);   // (nqid is the next entry's from phase NP - 3 on: j + 3 >= NP <=> j >= NP - 3)
         if (j == 2) fetch_row_terms(dsc + (have_next ? nb : cur) * REC_DW);
+        if (j == NP - 1 && a.tau_run) {   // the running bounds of this wave's two items (S1): on their way while the gatherers finish
+          const int32_t* rc = dsc + cur * REC_DW;
+          const int cn = __builtin_amdgcn_readfirstlane(rc[1]);
+          run0 = wave < cn ? a.tau_run[(uint32_t)rc[24 + wave]] : 0u;
+          run1 = wave + NG < cn ? a.tau_run[(uint32_t)rc[24 + wave + NG]] : 0u;
+        }
         if (j == 0 && tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
         if (j == 0 && tid == 0) gid2 = atomicAdd(a.work_counter, 1);
         tick(0);
@@ -430,8 +443,36 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         if (i0 < cnt) {
           uint32_t c0 = colmin[i0 * 64 + lane], c1 = colmin[i1 * 64 + lane];
           wave_sort32_x2(c0, c1);   // (order-preserving keys of the float column minima)
-          const uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
+          uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
           if (lane == 0) {
+            if (a.tau_run) {
+              // The query's running bound (FilterArgs::tau_run).  tau' + A_up of this (item, chunk) is reported (no answer is
+              // waited for); the bound read at the start of the last phase -- whatever other workgroups had reported by
+              // then -- lowers this item's cut to bound - A_lo.  Why any such value is valid: tau' is at least the L-th smallest s'
+              // of the chunk, s' + A is the cheap distance up to the item-independent part of its error, and the L-th smallest
+              // over MORE rows is never larger -- so every reported value is an upper bound of the query's L-th smallest cheap
+              // distance D_L, and the rows that can matter have s' + A <= D_L + 2 e.  (The three float roundings here are
+              // below 10 u B of the 2.2 e = 230 u B + 13 T that E leaves over 2 e.)
+              auto lower = [&](uint32_t t, int i, uint32_t inv) -> uint32_t {
+                const uint32_t tb = (t & 0x80000000u) ? (t ^ 0x80000000u) : ~t;   // key -> bits
+                const float tau = __uint_as_float(tb);
+                const float a_up = __int_as_float(rec[144 + i]), a_lo = __int_as_float(rec[160 + i]);
+                if (tau < 3e38f && tau > -3e38f && a_up < 3e38f) {
+                  // (only a value that improves on what was read goes out: a batch over the flat PQ table has a few dozen queries
+                  // and a thousand entries -- sixteen unconditional atomics per entry on the same two cache lines doubled the scan's time)
+                  const uint32_t mine = ~float_key(tau + a_up);
+                  if (mine > inv) atomicMax(a.tau_run + (uint32_t)rec[24 + i], mine);
+                  if (inv != 0u) {
+                    const uint32_t bk = ~inv;
+                    const float alt = __uint_as_float((bk & 0x80000000u) ? (bk ^ 0x80000000u) : ~bk) - a_lo;
+                    if (alt < tau) return float_key(alt);
+                  }
+                }
+                return t;
+              };
+              t0 = lower(t0, i0, run0);
+              if (i1 < cnt) t1 = lower(t1, i1, run1);
+            }
             thr_s[i0] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
             thr_s[i1] = a.keep_all ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
           }

@@ -117,7 +117,7 @@ static int ivf_coarse(IvfRun& r) {
   za.p[0] = ws->w_used.as<uint32_t>(); za.n[0] = Q * used_words;
   za.p[1] = ws->w_cnt.as<uint32_t>(); za.n[1] = 8;
   za.p[2] = r.fused ? ws->w_cellcnt.as<uint32_t>() : nullptr; za.n[2] = r.fused ? C * 2 : 0;
-  za.p[3] = ws->w_cand.as<uint32_t>(); za.n[3] = Q;
+  za.p[3] = ws->w_cand.as<uint32_t>(); za.n[3] = 2 * Q;   // accepted-row counts, then the queries' running bounds (FilterArgs::tau_run)
   // survivor counts: regions of chunks a list does not have, or of items without a cell, stay at zero
   za.p[4] = r.fused ? ws->w_surv_cnt.as<uint32_t>() : nullptr; za.n[4] = r.fused ? (int)(items * r.upi * FUSED_NW) : 0;
 
@@ -221,7 +221,7 @@ static int ivf_plan(IvfRun& r, PlanArgs& pa) {
     }
   });
   HIP_TRY(hipGetLastError());
-  if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(ws->w_cand.p, 0, sizeof(int32_t) * r.Q, s));
+  if (!(r.zeroed && r.first())) HIP_TRY(hipMemsetAsync(ws->w_cand.p, 0, sizeof(int32_t) * 2 * r.Q, s));   // (every round starts without bounds)
   return 0;
 }
 
@@ -314,6 +314,9 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
   fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.keep_all = (ix->tune.check_brackets & 1) ? 1 : 0; fl.fence = 0;
+  // (not for a batch over the flat PQ table: a few dozen queries x a thousand entries read and update the same two cache lines --
+  // 96 -> 128 us -- and its merge gains nothing; an IVFADC batch: +2.6 % queries/s with four batches in flight)
+  fl.tau_run = (ix->tune.running_bound && !r.records_ready) ? ws->w_cand.as<uint32_t>() + Q : nullptr;
   if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
   // LDS: slabs [2 buffers][2 positions][K][16 items] int16, then column minima / thresholds, two entry records, row terms
   const size_t desc_off = (size_t)4 * SCAN5_G * 2 * K;
@@ -536,7 +539,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   if (ws->w_distT.ensure(sizeof(float) * (size_t)Q * Cpad) ||
       ws->w_used.ensure(sizeof(uint32_t) * (size_t)Q * used_words) ||
       ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
-      ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * 2 * Q) ||
       ws->w_qn2.ensure(sizeof(float) * Q) || ws->w_item_dist.ensure(sizeof(float) * items) ||
       ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) ||
       ws->w_act1.ensure(sizeof(int32_t) * Q) || ws->w_cnt.ensure(sizeof(int32_t) * 8))

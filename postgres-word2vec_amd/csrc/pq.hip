@@ -140,6 +140,11 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
     rec[88 + slot] = (int32_t)ib.lo_bits;
     rec[104 + slot] = (int32_t)ib.hi_bits;
     rec[128 + slot] = (int32_t)__float_as_uint(sc < 1e30f ? sc : 0.0f);
+    {   // (entry_record5_kernel: the item's coarse distance -- here |q|^2, the zero centroid's -- as an interval)
+      const bool fin = ib.e < 1e30f && A >= 0.0f && A < 1e30f;
+      rec[144 + slot] = (int32_t)__float_as_uint(fin ? A * (1.0f + 2e-5f) : __uint_as_float(0x7f800000u));
+      rec[160 + slot] = (int32_t)__float_as_uint(fin ? A * (1.0f - 2e-5f) : 0.0f);
+    }
     if (slot == 0) {
       const int b0 = blk_off[c];
       rec[0] = c; rec[1] = cnt; rec[2] = 0; rec[3] = b0; rec[4] = blk_off[c + 1] - b0; rec[5] = list_off[c + 1] - list_off[c];
@@ -149,6 +154,7 @@ __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, uns
         rec[8 + u] = -1; rec[24 + u] = q;
         rec[40 + u] = (int32_t)__float_as_uint(none.off); rec[56 + u] = (int32_t)__float_as_uint(none.e); rec[72 + u] = (int32_t)__float_as_uint(none.shift);
         rec[88 + u] = (int32_t)none.lo_bits; rec[104 + u] = (int32_t)none.hi_bits; rec[128 + u] = 0;
+        rec[144 + u] = (int32_t)0x7f800000; rec[160 + u] = 0;
       }
     }
   }
@@ -243,7 +249,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   const size_t items = (size_t)Q * W;
   const size_t n_entries = (size_t)((Q + SCAN5_G - 1) / SCAN5_G) * lists;
   if (ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
-      ws->w_item_dist.ensure(sizeof(float) * items) || ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * Q) ||
+      ws->w_item_dist.ensure(sizeof(float) * items) || ws->w_rows.ensure(sizeof(int32_t) * Q) || ws->w_cand.ensure(sizeof(int32_t) * 2 * Q) ||
       ws->w_found.ensure(sizeof(int32_t) * Q) || ws->w_act0.ensure(sizeof(int32_t) * Q) || ws->w_act1.ensure(sizeof(int32_t) * Q) ||
       ws->w_cnt.ensure(sizeof(int32_t) * 8) || ws->w_records.ensure(sizeof(int32_t) * REC_DW * n_entries) ||
       ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
@@ -252,6 +258,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d over %d pseudo-lists)", Q, lists);
   r.next = ws->w_act0.as<int32_t>();
   HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 8, s));
+  HIP_TRY(hipMemsetAsync(ws->w_cand.as<int32_t>() + Q, 0, sizeof(int32_t) * Q, s));   // the queries' running bounds (FilterArgs::tau_run)
   HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * items * r.upi * FUSED_NW, s));
   PlanArgs pa;
   memset(&pa, 0, sizeof(pa));

@@ -45,6 +45,12 @@ struct FilterArgs {
   int keep_all;                // option filter_keep_all (tests): every row survives the filter -- with refine_all, every bracket is checked
   long long* prof;
   const uint32_t* packed8;     // U8 instantiation: [blocks][3][64], one byte per code (K <= 256)
+  // The query's RUNNING bound (ivf_filter5_kernel, S1): tau_run[q] = ~key of the smallest (tau' + A_up) any finished (item, chunk)
+  // of query q has reported this round -- an upper bound of the query's L-th smallest cheap distance over everything it probes;
+  // 0 = none yet.  A later entry cuts at min(tau', bound - A_lo) + E instead of tau' + E.  Purely opportunistic: a workgroup
+  // reads whatever is there (no waiting, any stale value is a valid bound), so the survivors differ from run to run and the
+  // lists never do.  NULL: off.
+  uint32_t* tau_run;
 };
 
 // The integer-slab scan (fused5.h) quantises the table with one scale per query; its margin (derivation there):
@@ -127,7 +133,7 @@ static __global__ __launch_bounds__(256) void row_term_kernel(const uint32_t* __
 //   [8+g] item  [24+g] query (slots past the last item repeat item 0: always loadable)
 //   [40+g] OFF  [56+g] E  [72+g] SHIFT  [88+g] lo bits  [104+g] hi bits        (item_bounds)
 // ---------------------------------------------------------------------------------------
-static constexpr int REC_DW = 144;   // + [128 + g] the table scale of item g's query (entry_record5_kernel)
+static constexpr int REC_DW = 176;   // + [128 + g] the table scale of item g's query, [144 + g] / [160 + g] A_up / A_lo of the item (entry_record5_kernel)
 
 struct RecordArgs {
   const int32_t* group_cell;

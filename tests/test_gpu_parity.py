@@ -1103,6 +1103,24 @@ def test_searches_on_two_streams_overlap_safely(gpu, oracle):
 
 
 @pytest.mark.parametrize("K", [256, 1024])
+def test_running_bound_changes_survivors_not_lists(gpu, oracle, K, monkeypatch):
+    """Option running_bound (default on): the scan's work entries share, per query, the smallest (threshold + coarse distance)
+    any finished (item, chunk) has reported, and cut at it -- opportunistically, without waiting, so which rows survive the
+    filter depends on timing and the lists must not: the oracle's, with the option on and off, for every found rule, several
+    probing rounds (tiny cells) and repeated runs."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    t, ot, idx, qs = _fr_setup(gpu, oracle, K=K, dup_rows=3)
+    for k, W, rule, sent in ((5, 6, 0, 1000.0), (10, 4, 1, 100.0), (5, 1, 2, 100.0), (32, 3, 0, 1000.0)):
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        for rb in (1, 0, 1, 1):
+            idx.set_option("running_bound", rb)
+            gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+            util.assert_same_lists(gi, gd, exp, f"running_bound {rb} K={K} k={k} W={W} rule={rule}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
+@pytest.mark.parametrize("K", [256, 1024])
 def test_in_flight_instantiations_match_oracle(gpu, oracle, K, monkeypatch):
     """scan_share > 1 -- the caller keeps batches in flight -- selects the small-footprint instantiations: ONE wave per query
     in the cell-selection plan (probe_plan2_kernel<0, false, 1>: seven candidates per round, the whole 300-dimensional query
