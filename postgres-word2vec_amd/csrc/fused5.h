@@ -224,6 +224,24 @@ __global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {
   }
 }
 
+// The query's running bound (FilterArgs::tau_run), one (item, chunk)'s part: t = key of its own tau', [a_lo, a_up] its coarse
+// distance, inv = the bound as read earlier (0: none).  Reports tau' + a_up if that improves on what was read (one atomic at
+// most), returns the key the item cuts at: min(tau', bound - a_lo).  (Derivation: ivf_filter5_kernel, S1.)
+__device__ __forceinline__ uint32_t running_bound5(uint32_t* __restrict__ tau_run, uint32_t q, uint32_t t, float a_up, float a_lo, uint32_t inv) {
+  const uint32_t tb = (t & 0x80000000u) ? (t ^ 0x80000000u) : ~t;   // key -> bits
+  const float tau = __uint_as_float(tb);
+  if (tau < 3e38f && tau > -3e38f && a_up < 3e38f) {
+    const uint32_t mine = ~float_key(tau + a_up);
+    if (mine > inv) atomicMax(tau_run + q, mine);
+    if (inv != 0u) {
+      const uint32_t bk = ~inv;
+      const float alt = __uint_as_float((bk & 0x80000000u) ? (bk ^ 0x80000000u) : ~bk) - a_lo;
+      if (alt < tau) return float_key(alt);
+    }
+  }
+  return t;
+}
+
 // Entry records as entry_record_kernel; [128 + g] = the table scale of item g's query.
 template <int M>
 __global__ __launch_bounds__(256) void entry_record5_kernel(RecordArgs a) {
@@ -454,21 +472,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
               // distance D_L, and the rows that can matter have s' + A <= D_L + 2 e.  (The three float roundings here are
               // below 10 u B of the 2.2 e = 230 u B + 13 T that E leaves over 2 e.)
               auto lower = [&](uint32_t t, int i, uint32_t inv) -> uint32_t {
-                const uint32_t tb = (t & 0x80000000u) ? (t ^ 0x80000000u) : ~t;   // key -> bits
-                const float tau = __uint_as_float(tb);
-                const float a_up = __int_as_float(rec[144 + i]), a_lo = __int_as_float(rec[160 + i]);
-                if (tau < 3e38f && tau > -3e38f && a_up < 3e38f) {
-                  // (only a value that improves on what was read goes out: a batch over the flat PQ table has a few dozen queries
-                  // and a thousand entries -- sixteen unconditional atomics per entry on the same two cache lines doubled the scan's time)
-                  const uint32_t mine = ~float_key(tau + a_up);
-                  if (mine > inv) atomicMax(a.tau_run + (uint32_t)rec[24 + i], mine);
-                  if (inv != 0u) {
-                    const uint32_t bk = ~inv;
-                    const float alt = __uint_as_float((bk & 0x80000000u) ? (bk ^ 0x80000000u) : ~bk) - a_lo;
-                    if (alt < tau) return float_key(alt);
-                  }
-                }
-                return t;
+                // (only a value that improves on what was read goes out: see running_bound5)
+                return running_bound5(a.tau_run, (uint32_t)rec[24 + i], t, __int_as_float(rec[144 + i]), __int_as_float(rec[160 + i]), inv);
               };
               t0 = lower(t0, i0, run0);
               if (i1 < cnt) t1 = lower(t1, i1, run1);

@@ -355,7 +355,7 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     sp.blk_off = ix->blk_off; sp.list_off = ix->list_off; sp.sorted_item = ra.sorted_item; sp.item_query = pa.item_query;
     sp.item_dist = pa.item_dist; sp.sp_cell = wt.sp_cell; sp.sp_first = wt.sp_first; sp.sp_chunk = wt.sp_chunk;
     sp.n_units = wt.n_sparse; sp.work_counter = wt.sp_counter; sp.surv = fl.surv; sp.surv_count = fl.surv_count; sp.packed8 = fl.packed8;
-    sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.keep_all = fl.keep_all;
+    sp.cand_count = fl.cand_count; sp.K = K; sp.L = r.L; sp.upi = r.upi; sp.sentinel = r.sentinel; sp.keep_all = fl.keep_all; sp.tau_run = fl.tau_run;
     const unsigned sp_grid = (unsigned)std::min<size_t>(wt.sp_cap, (size_t)std::max(1, scan_cus) * (wt.sp_pairs ? 3 : 6));
     timed_launch(ix, s, "sparse_items", [&] {
       if (wt.sp_pairs) {   // (cell, chunk) units of one or two items: the rows of a two-item cell are read once

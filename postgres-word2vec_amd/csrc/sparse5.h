@@ -45,6 +45,7 @@ struct SparseArgs {
   int K, L, upi;
   float sentinel;
   int keep_all;                // option filter_keep_all (tests): every row survives (as ivf_filter5_kernel)
+  uint32_t* tau_run;           // [Q] the queries' running bounds (FilterArgs::tau_run), or NULL
 };
 
 template <int M, bool CAND, bool U8 = false>   // U8: one byte per code (K <= 256), packed8[block][3][64]
@@ -72,7 +73,9 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
     const int q = a.item_query[it];
     const float sc0 = a.qscale[q];
     const float sc = sc0 < 1e30f ? sc0 : 0.0f;
-    const ItemBounds ib = item_bounds(a.item_dist[it], filter_width5<M>(a.qn + (size_t)q * M, a.pmax, sc0), a.sentinel);
+    const float A = a.item_dist[it];
+    const ItemBounds ib = item_bounds(A, filter_width5<M>(a.qn + (size_t)q * M, a.pmax, sc0), a.sentinel);
+    const uint32_t run_inv = a.tau_run ? a.tau_run[q] : 0u;   // the query's running bound as it is now (used after the scan of the rows)
     const int b0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
     int nb = a.blk_off[cell + 1] - b0;
     nb = nb > FUSED_UNIT_BLOCKS ? FUSED_UNIT_BLOCKS : nb;
@@ -141,8 +144,11 @@ __global__ __launch_bounds__(256, 6) void sparse_item5_kernel(SparseArgs a) {
     __syncthreads();
     if (wave == 0) {
       const uint32_t c0 = wave_sort32(colmin[lane]);
-      const uint32_t t0 = __shfl(c0, a.L - 1, 64);
-      if (lane == 0) thr_sh = a.keep_all ? 0x7f800000u : widen_threshold5(t0, ib.e);
+      uint32_t t0 = __shfl(c0, a.L - 1, 64);
+      if (lane == 0) {
+        if (a.tau_run && ib.e < 1e30f && A >= 0.0f && A < 1e30f) t0 = running_bound5(a.tau_run, (uint32_t)q, t0, A * (1.0f + 2e-5f), A * (1.0f - 2e-5f), run_inv);
+        thr_sh = a.keep_all ? 0x7f800000u : widen_threshold5(t0, ib.e);
+      }
     }
     __syncthreads();
     const float thr = __uint_as_float(thr_sh);
@@ -271,7 +277,8 @@ __global__ __launch_bounds__(256, 3) void sparse_pair5_kernel(SparseArgs a) {
     const int chunk = chw & 0xff;
     const int cnt = (chw >> 8) >= 2 ? 2 : 1;
     int it[NI], q[NI];
-    float sc[NI];
+    float sc[NI], Ad[NI];
+    uint32_t run_inv[NI];
     ItemBounds ib[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -279,7 +286,9 @@ __global__ __launch_bounds__(256, 3) void sparse_pair5_kernel(SparseArgs a) {
       q[i] = a.item_query[it[i]];
       const float sc0 = a.qscale[q[i]];
       sc[i] = sc0 < 1e30f ? sc0 : 0.0f;
-      ib[i] = item_bounds(a.item_dist[it[i]], filter_width5<M>(a.qn + (size_t)q[i] * M, a.pmax, sc0), a.sentinel);
+      Ad[i] = a.item_dist[it[i]];
+      ib[i] = item_bounds(Ad[i], filter_width5<M>(a.qn + (size_t)q[i] * M, a.pmax, sc0), a.sentinel);
+      run_inv[i] = a.tau_run ? a.tau_run[q[i]] : 0u;
     }
     const int b0 = a.blk_off[cell] + chunk * FUSED_UNIT_BLOCKS;
     int nb = a.blk_off[cell + 1] - b0;
@@ -327,8 +336,12 @@ __global__ __launch_bounds__(256, 3) void sparse_pair5_kernel(SparseArgs a) {
     for (int i = 0; i < NI; ++i) {
       if (wave == i && i < cnt) {     // (wave i: item i's threshold)
         const uint32_t c0 = wave_sort32(colmin[i][lane]);
-        const uint32_t t0 = __shfl(c0, a.L - 1, 64);
-        if (lane == 0) thr_sh[i] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, ib[i].e);
+        uint32_t t0 = __shfl(c0, a.L - 1, 64);
+        if (lane == 0) {
+          if (a.tau_run && ib[i].e < 1e30f && Ad[i] >= 0.0f && Ad[i] < 1e30f)
+            t0 = running_bound5(a.tau_run, (uint32_t)q[i], t0, Ad[i] * (1.0f + 2e-5f), Ad[i] * (1.0f - 2e-5f), run_inv[i]);
+          thr_sh[i] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, ib[i].e);
+        }
       }
     }
     __syncthreads();
