@@ -304,29 +304,30 @@ int freddy_gpu_last_track_sized(const freddy_gpu_index_t* ivpq, void* out, size_
 #define FREDDY_GPU_ABI_VERSION 4
 int freddy_gpu_abi_version(void);
 
-/* Tuning / debug switches of a pinned index (the FREDDY_GPU_* environment variables are read once, at pin
- * time): "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel" (5 filter +
- * refine with int16 slabs, 4 the same with fp32 slabs, 3 exact scan), "fused_ablate", "merge_ablate" (timing experiments; 8 / 32 = keep / refine every
- * row, used by the tests' exhaustive bound check), "side_stream", "reserve_cus", "scan_share" (the batches the caller keeps in flight through the *_dev entry points, one stream each: a persistent scan takes n_cus / scan_share CUs; default 1 = the whole chip), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls: queries per sub-batch, 2048; sub-batches in flight, 1..4), "pq_fused" (batches over the flat PQ table through the cell-grouped filter + refine scan over pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "merge_waves" (waves per query in the merge: 4, 1, or 0 = four for one batch at a time, one with batches in flight), "partition_cus" (R > 0: a batch's small kernels on a stream masked to R CUs, its scan on a stream masked to the rest; R < 0: only the scan masked; 0 = off, the default -- measured slower), "coarse_approx" (1: cell selection as filter + refine, 0: every coarse distance exact),
- * "fuse_table" (1, the default: the cell-selection distances and the query x codebook table of a batch are the workgroups of
- * one launch; 0: two kernels),
- * "sparse_items" (cells that at most this many queries of a batch probe are scanned item by item instead of as cell-grouped
- * work entries -- used where such cells are the rule: fewer than four (query, probe) items per cell and at least 16 per CU;
- * default 2, 0 = never, a negative value forces it for cells of up to that many items whatever the batch),
- * "plan_waves" (0, the default: the cell-selection plan runs four waves per query for one batch at a time and ONE wave per
- * query -- a quarter of the registers and of the LDS -- when the caller keeps batches in flight (scan_share > 1); 4: always four),
- * "one_launch" (1, the default: a host-buffer call with ONE query -- the reference's own call shape -- is a single launch,
- * pq_one_kernel / ivf_one_kernel: the stages of the multi-launch path behind in-kernel grid barriers, the host polls the
- * kernel's completion word; 0: the multi-launch path.  A handle whose grid once failed to meet at a barrier within the
- * kernel's bounded polls switches itself to 0),
- * "sparse_pairs" (1, the default: the item-wise scan reads a cell that exactly two queries probe once for both; 0: twice),
- * "coarse_refine_all", "fused_prof", "debug_surv",
- * "lut_budget_mb",
- * "codes_u8" (1, the default: indexes with K <= 256 are scanned from one byte per code -- 16 instead of 28 bytes per row; 0: the
- * int16 layout), "exact_filter" (exact brute-force kNN as f16-split MFMA filter + exact refine: -1 = tables of >= 8192 rows and
- * k <= 32, 0 never, 1 always), "exact_refine_all" (tests: every row refined, every similarity bracket checked), "direct" (the
- * integer-slab scan without work-table / record kernels: 0 off -- the default, measured no faster --, -1 dense first rounds, 1 always).  No setting changes a result -- except "fused_ablate" / "merge_ablate", which switch parts of a kernel
- * off for timing experiments (tools/ablate.sh) and are not for production use. */
+/* Options of a pinned index (the FREDDY_GPU_* environment variables of the same names are read once, at pin time).  No setting
+ * changes a result.
+ *   deployment:  "scan_share" (the batches that share the chip with one of this handle's: the batches the caller keeps in flight
+ *                through the *_dev entry points, one stream each, or the other BACKENDS searching at the same time -- a persistent
+ *                scan takes n_cus / scan_share CUs; default 1 = the whole chip), "reserve_cus" (CUs a persistent
+ *                scan leaves free), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls: queries per sub-batch, 2048;
+ *                sub-batches in flight, 1..4), "lut_budget_mb" (workspace cap per call)
+ *   paths (each has GPU tests of its own):  "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel"
+ *                (5 filter + refine on int16 slabs, 3 the reference's arithmetic for every row), "coarse_approx" (1: cell selection
+ *                as filter + refine, 0: every coarse distance exact), "one_launch" (1: a host-buffer call with ONE query -- the
+ *                reference's own call shape -- is a single launch, pq_one_kernel / ivf_one_kernel, the host polls the kernel's
+ *                completion word; 0: the multi-launch path.  A handle whose grid once failed to meet within the kernel's bounded
+ *                polls switches itself to 0), "pq_fused" (batches over the flat PQ table through the cell-grouped scan over
+ *                pseudo-lists of 4096 rows: -1 = from 16 queries on, 0 never, 1 always), "sparse_items" (cells that at most this
+ *                many queries of a batch probe are scanned item by item; default 2, 0 = never, a negative value forces it for
+ *                cells of up to that many items whatever the batch), "running_bound" (1: the scan's work entries share a
+ *                per-query bound of the L-th smallest cheap distance), "codes_u8" (1: indexes with K <= 256 are scanned from one
+ *                byte per code; 0: the int16 layout), "exact_filter" (exact brute-force kNN as f16-split MFMA filter + exact
+ *                refine: -1 = tables of >= 8192 rows and k <= 32, 0 never -- and no fragment copy of a table pinned with it --,
+ *                1 always)
+ *   self-checks (tests):  "check_brackets" (bit 0: the scan keeps and the merge refines EVERY probed row, bit 1: the cell
+ *                selection refines every cell, bit 2: exact kNN refines every row -- each with its proven bracket compared with
+ *                the reference's value: freddy_gpu_filter_bound_violations / _checked), "join_host_traversal",
+ *                "join_libm_margin_ppm" */
 int freddy_gpu_set_option(freddy_gpu_index_t* index, const char* name, int64_t value);
 
 /* Thread-local message of the last failing call; valid until the next call. */
@@ -353,12 +354,12 @@ int freddy_gpu_last_probed_cells(const freddy_gpu_index_t* index, int64_t* n_cel
  * wrong for some input; <0 on a HIP error).  Synchronises the device. */
 int64_t freddy_gpu_filter_bound_violations(const freddy_gpu_index_t* index);
 /* How many rows that check has seen -- counted only in the tests' refine-every-row mode
- * (option merge_ablate = 32), where it is the number of probed rows; 0 otherwise. */
+ * (option check_brackets, bit 0), where it is the number of probed rows; 0 otherwise. */
 int64_t freddy_gpu_filter_bound_checked(const freddy_gpu_index_t* index);
 /* The coarse-cell selection is a filter + refine too (MFMA distances with a proven bracket, the reference's
  * squareDistance for the candidate cells): refined cells whose distance left the bracket are
  * INCLUDED in freddy_gpu_filter_bound_violations; this returns how many cells the tests' refine-every-cell mode
- * (option coarse_refine_all = 1) has checked. */
+ * (option check_brackets, bit 1) has checked. */
 int64_t freddy_gpu_coarse_bound_checked(const freddy_gpu_index_t* index);
 
 #ifdef __cplusplus
