@@ -11,6 +11,7 @@
 #include "one.h"
 #include "sparse5.h"
 #include "coarse.h"
+#include "multi.h"
 #include "io_kernels.h"
 
 // ---------------------------------------------------------------------------------------
@@ -230,7 +231,7 @@ int ivf_work_table(IvfRun& r, WorkTable& wt) {
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int n_items = r.n_active * r.W;
-  wt.max_groups = ((size_t)n_items / SPEC2_G + (size_t)ix->C + 1) * r.upi;   // (group, chunk) work entries
+  wt.max_groups = ((size_t)n_items / MULTI_G + (size_t)ix->C + 1) * r.upi;   // (group, chunk) work entries (the smallest group size: a bound for every scan)
   int32_t* base = ws->w_groups.as<int32_t>();
   wt.group_cell = base; wt.group_first = base + wt.max_groups; wt.group_cnt = base + 2 * wt.max_groups;
   wt.n_groups = ws->w_cnt.as<int32_t>() + 1;
@@ -248,7 +249,7 @@ int ivf_work_table(IvfRun& r, WorkTable& wt) {
   wt.sp_cap = sparse_max > 0 ? (size_t)n_items * r.upi : 0;
   wt.sp_cell = base + 3 * wt.max_groups; wt.sp_first = wt.sp_cell + wt.sp_cap; wt.sp_chunk = wt.sp_first + wt.sp_cap;
   timed_launch(ix, s, "work_table", [&] {
-    hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ws->w_cellcnt.as<int32_t>(), ix->C, r.n_active, r.scan_kernel == 5 ? SCAN5_G : SPEC2_G, ix->blk_off,
+    hipLaunchKernelGGL(work_table_kernel, dim3(1), dim3(1024), 0, s, ws->w_cellcnt.as<int32_t>(), ix->C, r.n_active, r.scan_kernel == 5 ? SCAN5_G : r.scan_kernel == 2 ? MULTI_G : SPEC2_G, ix->blk_off,
                        wt.group_cell, wt.group_first, wt.group_cnt, wt.n_groups, r.scan_kernel == 5 ? 2 : 0,
                        sparse_max, wt.sp_cell, wt.sp_first, wt.sp_chunk, wt.n_sparse, sparse_max >= 2 ? 1 : 0);
   });
@@ -460,6 +461,39 @@ static int ivf_scan_exact(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   return 0;
 }
 
+// Every other index shape (multi.h): exact LUTs of all items -> ivf_multi_kernel -> merge_surv_kernel.
+static int ivf_scan_multi(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
+  Workspace* ws = r.ws;
+  freddy_gpu_index* ix = r.ix;
+  hipStream_t s = r.s;
+  const int n_items = r.n_active * r.W;
+  if (int rc = launch_lut(ix, s, r.d_q, pa.item_cell, ws->w_lut.as<float>(), n_items, ix->coarse, pa.item_query)) return rc;
+  MultiArgs ma;
+  ma.lut = ws->w_lut.as<float>(); ma.item_query = pa.item_query; ma.sorted_item = ws->w_sorted.as<int32_t>();
+  ma.group_cell = wt.group_cell; ma.group_first = wt.group_first; ma.group_cnt = wt.group_cnt; ma.n_groups = wt.n_groups;
+  ma.work_counter = wt.work_counter; ma.blk_off = ix->blk_off; ma.packed = ix->packed; ma.pos = ix->pos;
+  ma.surv = ws->w_surv.as<u64>(); ma.surv_count = ws->w_surv_cnt.as<int32_t>();
+  ma.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
+  ma.m = ix->m; ma.M2 = ix->M2; ma.K = ix->K; ma.L = r.L; ma.upi = r.upi;
+  memcpy(&ma.sentinel_bits, &r.sentinel, 4);
+  const size_t lds = multi_lds_bytes(ix->m, ix->K);
+  // persistent workgroups: as many as fit (LDS, 8 waves of ~100 registers), never more than there is work
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(2, (size_t)(150 * 1024) / lds));
+  const unsigned grid = (unsigned)std::min<size_t>(wt.max_groups, (size_t)ix->n_cus * per_cu);
+  timed_launch(ix, s, "ivf_multi_scan", [&] { hipLaunchKernelGGL(ivf_multi_kernel, dim3(grid), dim3(MULTI_T), lds, s, ma); });
+  HIP_TRY(hipGetLastError());
+  MergeSurvArgs ms;
+  ms.surv = ma.surv; ms.surv_count = ma.surv_count; ms.active = r.active; ms.round_rows = pa.round_rows;
+  ms.cand_count = ma.cand_count; ms.out_ids = r.d_out_ids; ms.out_dist = r.d_out_dist;
+  ms.found = ws->w_found.as<int32_t>(); ms.next_active = r.next; ms.n_next = ws->w_cnt.as<int32_t>();
+  ms.status = r.d_status;
+  ms.n_active = r.n_active; ms.W = r.W; ms.upi = r.upi; ms.L = r.L; ms.k = r.k; ms.found_rule = r.found_rule;
+  ms.first_round = r.first() ? 1 : 0; ms.sentinel = r.sentinel;
+  timed_launch(ix, s, "merge_surv", [&] { hipLaunchKernelGGL(merge_surv_kernel, dim3(r.n_active), dim3(64), 0, s, ms); });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 // row blocks per workgroup of the generic scan: one workgroup per (query, probed cell) unless the list is huge -- but a
 // handful of items (the reference's single-query ivfadc_search: W of them) would leave the chip to W workgroups: 32-block
 // chunks then (one query over 10 lists of 3 000 rows: 30 instead of 10 workgroups)
@@ -500,7 +534,7 @@ static int ivfadc_round(IvfRun& r) {
   if (r.fused) {
     WorkTable wt;
     if (int rc = ivf_work_table(r, wt)) return rc;
-    return (r.scan_kernel == 5) ? ivf_scan_filter(r, pa, wt) : ivf_scan_exact(r, pa, wt);
+    return (r.scan_kernel == 5) ? ivf_scan_filter(r, pa, wt) : (r.scan_kernel == 2) ? ivf_scan_multi(r, pa, wt) : ivf_scan_exact(r, pa, wt);
   }
   return ivf_scan_generic(r, pa);
 }
@@ -530,6 +564,15 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   r.fused = ix->tune.fused != 0 && m == 12 && ix->S == 25 && K <= 1024 && ix->cbP && r.L <= 64 && r.upi <= 8 &&
             (ix->tune.fused == 1 || items >= 256);
   r.scan_kernel = (ix->tune.scan_kernel == 3 || !ix->rterm) ? 3 : 5;
+  if (!r.fused) {
+    // every other shape whose interleaved LUT slab fits the LDS: the cell-grouped exact scan of multi.h (option fused = 0
+    // keeps the generic kernels, fused = 1 takes it for small batches too)
+    const bool special = m == 12 && ix->S == 25 && K <= 1024 && ix->cbP;
+    // (lists of up to 32 chunks: the reference's shipped 32-cell configuration has 37 000 rows per list)
+    r.fused = ix->tune.fused != 0 && !special && multi_lds_bytes(m, K) <= (size_t)150 * 1024 && r.L <= 64 && r.upi <= 32 &&
+              (ix->tune.fused == 1 || items >= 256);
+    if (r.fused) r.scan_kernel = 2;
+  }
   r.tiled = Q >= 32;
   r.zeroed = r.tiled || ix->d <= 1024;
   r.records_ready = false; r.merge_slices = 0;
@@ -547,9 +590,11 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   if (r.fused) {
     // cell_count[C] + cursors; cell_items[C][Q]; work table: 3 arrays of (items/G + C + 1) * upi entries
     if (ws->w_cellcnt.ensure(sizeof(int32_t) * (size_t)C * 3) || ws->w_sorted.ensure(sizeof(int32_t) * (size_t)C * Q) ||
-        ws->w_groups.ensure(sizeof(int32_t) * 3 * ((items / SPEC2_G + (size_t)C + 1) * r.upi + items * r.upi)) ||   // + the (item, chunk) units of sparse cells
+        ws->w_groups.ensure(sizeof(int32_t) * 3 * ((items / MULTI_G + (size_t)C + 1) * r.upi + items * r.upi)) ||   // + the (item, chunk) units of sparse cells
         ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
         ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW))
+      return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
+    if (r.scan_kernel == 2 && ws->w_lut.ensure(sizeof(float) * items * (size_t)m * K))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
     if (r.scan_kernel == 5 &&
         (ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
@@ -600,8 +645,9 @@ int max_queries_per_chunk(const freddy_gpu_index* ix, int W) {
   // workspace per query: the LUTs of its W items (generic path) or their survivor regions (fused path)
   const size_t upi = (size_t)std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
   const size_t lut_bytes = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
-  const size_t surv_bytes = upi <= 8 ? sizeof(u64) * (size_t)W * upi * FUSED_NW * FUSED_RMAX * 64 : 0;
-  const size_t per_query = std::max(lut_bytes, surv_bytes);
+  const bool special = ix->m == 12 && ix->S == 25 && ix->K <= 1024 && ix->cbP;
+  const size_t surv_bytes = upi <= (special ? 8u : 32u) ? sizeof(u64) * (size_t)W * upi * FUSED_NW * FUSED_RMAX * 64 : 0;
+  const size_t per_query = special ? std::max(lut_bytes, surv_bytes) : lut_bytes + surv_bytes;   // (multi.h: the LUTs of all items AND their survivor regions)
   size_t n = ((size_t)ix->tune.lut_budget_mb << 20) / std::max<size_t>(per_query, 1);
   // the fused path's per-cell item buckets are [C][queries of the chunk]: keep them within 256 MiB
   if (surv_bytes) n = std::min<size_t>(n, ((size_t)256 << 20) / (sizeof(int32_t) * (size_t)std::max(ix->C, 1)));
@@ -991,7 +1037,7 @@ int raise_lds_limits_ivfadc(int device) {
 #ifdef FREDDY_LAB
       (const void*)&ivf_filter5_kernel<12, true, false, true>,
 #endif
-      (const void*)&coarse_approx_kernel, (const void*)&coarse_approx16_kernel};
+      (const void*)&coarse_approx_kernel, (const void*)&coarse_approx16_kernel, (const void*)&ivf_multi_kernel};
   for (const void* k : kernels)
     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);

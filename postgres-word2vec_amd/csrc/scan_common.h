@@ -59,10 +59,13 @@ static __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* 
   __syncthreads();
   // Two sweeps over this thread's cells: count the entries per class, then emit them into their class's
   // range.  Order inside a class is irrelevant.
-  auto cell = [&](bool emit, int c, int n, int nblk) {
+  // (j, J): a cell's groups of items are dealt to J threads -- few cells with many items each (the reference's shipped 32-cell
+  // configuration: 64 items per cell at 1024 queries x 2 probes, ten chunks per list) left the table to 32 of 1024 threads: 55 us
+  auto cell = [&](bool emit, int c, int n, int nblk, int j = 0, int J = 1) {
     if (n == 0) return;
     const int chunks = (nblk + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS;
     if (n <= sparse_max) {
+      if (j != 0) return;
       // sp_pairs: units of two items (and a last one of one: sparse_pair5_kernel reads a unit's rows once for both);
       // bits 8.. of sp_chunk = items of the unit
       const int per = sp_pairs ? 2 : 1;
@@ -76,7 +79,7 @@ static __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* 
           }
       return;
     }
-    for (int f = 0; f < n; f += gsz) {
+    for (int f = j * gsz; f < n; f += J * gsz) {
       const int cnt = (n - f < gsz) ? n - f : gsz;
       for (int ch = 0; ch < chunks; ++ch) {
         int nb = nblk - ch * FUSED_UNIT_BLOCKS;
@@ -109,7 +112,13 @@ static __global__ __launch_bounds__(1024) void work_table_kernel(const int32_t* 
       }
     }
   };
+  const int J = (C > 0 && C <= T / 2) ? T / C : 1;
   auto sweep = [&](bool emit) {
+    if (J > 1) {   // thread <-> (cell tid % C, share tid / C of its groups)
+      const int c = tid % C, j = tid / C;
+      if (j < J) cell(emit, c, cell_count[c], blk_off[c + 1] - blk_off[c], j, J);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < CPT; ++i) cell(emit, tid + i * T, cn[i], cb[i]);
     for (int c = tid + CPT * T; c < C; c += T) cell(emit, c, cell_count[c], blk_off[c + 1] - blk_off[c]);

@@ -1,6 +1,8 @@
 """-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle on the same seeded
 tables.  Bar: bit-exact (id, rank) AND bit-exact binary32 distance for every ADC result
 (the ADC distance is an order-fixed fp32 sum, so there is no tolerance to grant)."""
+import functools
+
 import numpy as np
 import pytest
 
@@ -1358,4 +1360,57 @@ def test_knn_join_device_traversal_hands_ties_to_the_host(gpu, oracle):
         util.assert_same_lists(gi, gd, exp, f"ties k={k} alpha={alpha} conf={conf}")
         total += idx.last_track()["host_traversals"]
     assert total > 0
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------
+# every other index shape: the cell-grouped exact scan of multi.h (the reference's primitives are shape-generic,
+# index_utils.c:445-455, :1126-1133; it ships m = 5 / K = 256 / 25-d / 32 cells: index_creation/config/ivfadc_complete_config.json)
+# ---------------------------------------------------------------------------------------
+@functools.lru_cache(maxsize=None)
+def _shape_tables(d, m, K, C, N):
+    import torch
+    from freddy_amd import index_build as ib
+    torch.manual_seed(0)
+    x = ib.make_corpus(N, d=d, seed=17 + d + m, n_clusters=120, latent=min(10, d), dup_frac=0.01, device="cpu")
+    t = ib.build_ivf_index(x, C=C, m=m, K=K, train_size=min(N, 6000), iters=4, seed=3)
+    return x, t
+
+
+@pytest.mark.parametrize("d,m,K,C", [(25, 5, 256, 32), (300, 6, 256, 24), (300, 10, 64, 40), (300, 15, 128, 16), (300, 30, 32, 32), (300, 12, 1024, 3000)])
+def test_other_shapes_cell_grouped_scan_matches_oracle(gpu, oracle, d, m, K, C):
+    """Shapes the filter + refine scan is not built for take ivf_multi_kernel (<= 8 items of a cell share its rows; exact LUTs
+    interleaved in LDS; the sums are the reference's distances) from 256 (query, cell) items on; option fused = 1 forces it for
+    small batches, fused = 0 keeps lut_build + adc_scan (the yardstick).  All of them: the oracle's lists -- every found rule,
+    odd and even m (code dwords hold two positions), k up to 32, several probing rounds (tiny cells), duplicated rows (ties),
+    and the filter scan's own shape with more than 1024 cells' worth of LDS-free... (m = 12 / K = 1024 stays with fused5.h: the
+    last case checks that the dispatch leaves it there)."""
+    N = 24000
+    x, t = _shape_tables(d, m, K, C, N)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    rng = np.random.default_rng(3)
+    qs = x[rng.choice(N, size=300, replace=False)].numpy().astype(np.float32)
+    for k, W, rule, sent in ((5, 4, 0, 1000.0), (10, 3, 1, 100.0), (5, 1, 2, 100.0), (32, 2, 0, 1000.0)):
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        kernels = {}
+        for fused in (-1, 1, 0):
+            idx.set_option("fused", fused)
+            idx.profile_enable(True)
+            gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+            kernels[fused] = set(idx.profile_read())
+            idx.profile_enable(False)
+            util.assert_same_lists(gi, gd, exp, f"shape d={d} m={m} K={K} C={C} fused={fused} k={k} W={W} rule={rule}")
+        if (m, d // m) != (12, 25):
+            assert "ivf_multi_scan" in kernels[1] and "ivf_multi_scan" not in kernels[0] and "adc_scan" in kernels[0], kernels
+            if 300 * W >= 256:
+                assert "ivf_multi_scan" in kernels[-1], kernels
+        else:
+            assert "ivf_multi_scan" not in kernels[1] and "ivf_filter" in kernels[1], kernels
+    # few queries with fused = 1: entries of one or two items
+    idx.set_option("fused", 1)
+    for nq in (1, 3, 17):
+        gi, gd = idx.search(qs[:nq], 5, 3, sentinel=1000.0, found_rule=0)
+        exp = oracle.ivfadc_search_many(ot, qs[:nq], 5, 3, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(gi, gd, exp, f"shape d={d} m={m} K={K} {nq} queries")
     idx.close()
