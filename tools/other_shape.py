@@ -1,8 +1,8 @@
 """GPU-box helper: the reference's OTHER shipped index shape -- index_creation/config/ivfadc_complete_config.json: m = 5
-sub-vectors of 5 dimensions (25-d GloVe twitter vectors, 1.19 M rows), K = 256, 32 coarse cells -- which the cell-grouped
-scan does not cover (it is built for m = 12, S = 25, K <= 1024): what the generic path (LUT in LDS + streaming scan) costs
-there.  Prints one JSON object: parity with the oracle on a sample, queries/s for batches of 1 / 100 / 1024 queries (the
-reference's ivfadc_batch_search call shapes), the kernels' durations.
+sub-vectors of 5 dimensions (25-d GloVe twitter vectors, 1.19 M rows), K = 256, 32 coarse cells -- which the filter + refine scan
+does not cover (it is built for m = 12, S = 25, K <= 1024).  Batches take the cell-grouped exact scan of multi.h (round 5), single
+queries and small batches the generic LUT + streaming-scan kernels.  Prints one JSON object: parity with the oracle on a sample,
+queries/s for batches of 1 / 100 / 1024 queries (the reference's ivfadc_batch_search call shapes), the kernels' durations.
 usage: python tools/other_shape.py [N]"""
 import json, os, sys, time
 import numpy as np
