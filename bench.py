@@ -31,11 +31,12 @@ import subprocess
 import sys
 import time
 
-# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the
-# runtime starts.  The batches in flight want a queue each, beside the queues the default stream, the library's
-# own streams and RCCL take; measured (tools/sweep_queues.sh): 4 queues / 3 batches 7.5 M q/s,
-# 6 queues / 4 batches 7.9 M, 8 queues 6.3-6.8 M (queues start sharing the four pipes of the command processor).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the runtime starts.  The
+# four batches in flight want a queue each, beside the queues the default stream, the library's own stream and -- with --gpus N --
+# RCCL's stream take: wherever two of the searching streams share a queue their chains serialise (profiles/r05_queue_sweep.txt:
+# 4 batches on 4 / 5 queues 5.7-5.9 M q/s, on 6 / 7 / 8 / 12 / 16 queues 9.8-9.9 M; a FIFTH active stream costs 6 queues 40 %, 8
+# queues 25 %).  Eight: the same for every --gpus N, so rank 0 of an N-GPU run is the single-GPU configuration.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # the CPU oracle's OpenMP workers (cpu_baseline: one per core) go to sleep after their parallel region instead of spinning on the
 # cores the host side of the measurements that follow needs (the kNN-join pass right after it read 1.5 instead of 1.1 ms)
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
@@ -462,7 +463,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     # Everything of a step -- the search kernels (through the C ABI, on this stream's handle) and the RCCL
     # gather -- is ordered on ONE explicit non-default stream, so the collective reads a shard's results
     # only after the search wrote them and the buffer is rewritten only after the collective read it.
-    # (GPU_MAX_HW_QUEUES = 6 above: a hardware queue per stream plus spares for the default stream and RCCL.)
+    # (GPU_MAX_HW_QUEUES = 8 above: a hardware queue per stream plus spares for the default stream and RCCL.)
     # Consecutive steps alternate between `in_flight` streams (each with its own query set, its own result buffer and,
     # inside the library, its own workspace): a batch is a chain of dependent kernels, and the latency-bound ends of
     # the batches overlap with the scans of the others.  --in-flight 1 is the strict sequence.
