@@ -242,7 +242,7 @@ int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q
   if (ix->poisoned) return fail(FREDDY_E_HIP, "this handle's devices hold different tables (an append / codebook update failed part-way): unpin it and pin again");
   if (Q < 0 || k <= 0) return fail(FREDDY_E_ARG, "Q must be >= 0 and k > 0");
   if (Q > 0 && (!q || !oi || !od)) return fail(FREDDY_E_ARG, "NULL buffer");
-  if (2 * k > 1024) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 512", k);
+  if (k > 4096) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 4096", k);
   return 0;
 }
 

@@ -106,7 +106,7 @@ struct Workspace {
   uint64_t last_use = 0;           // claim order (the slot a new stream takes over is the least recently used one)
   DevBuf w_q, w_distT, w_used, w_item_cell, w_item_query, w_rows, w_resid, w_lut,
       w_part, w_cand, w_found, w_act0, w_act1, w_cnt, w_out_ids, w_out_dist, w_sub_rows,
-      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_tmin, w_one, w_oneb;
+      w_sub_packed, w_sub_pos, w_sub_blk, w_cellcnt, w_sorted, w_groups, w_surv, w_surv_cnt, w_prof, w_qc, w_qn, w_records, w_qn2, w_item_dist, w_tmin, w_one, w_oneb, w_bigsel, w_floor;
   uint64_t one_shape = 0;          // the one-launch kernels' buffer (w_oneb): shape of the call that wrote it last, and that call's epoch (one.h)
   uint32_t one_epoch = 0;
   bool one_pending = false;        // one_buffer() flipped the epoch and the kernel was not (yet) launched
@@ -114,7 +114,7 @@ struct Workspace {
     DevBuf* bufs[] = {&w_q, &w_distT, &w_used, &w_item_cell, &w_item_query, &w_rows, &w_resid, &w_lut, &w_part,
                       &w_cand, &w_found, &w_act0, &w_act1, &w_cnt, &w_out_ids, &w_out_dist, &w_sub_rows, &w_sub_packed,
                       &w_sub_pos, &w_sub_blk, &w_cellcnt, &w_sorted, &w_groups, &w_surv, &w_surv_cnt, &w_prof, &w_qc,
-                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb};
+                      &w_qn, &w_records, &w_qn2, &w_item_dist, &w_tmin, &w_one, &w_oneb, &w_bigsel, &w_floor};
     for (DevBuf* b : bufs) b->release();
     used = false;
     owner = nullptr;
@@ -308,6 +308,7 @@ struct WorkTable {
 int pick_V(int L);
 int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_items);
 int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a);
+int bigk_select_replay(freddy_gpu_index* ix, hipStream_t s, Workspace* ws, ScanArgs sa, int n_items, const MergeArgs& ma, int Q);
 int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int32_t* item_cell, float* lut, int n_items,
                const float* coarse = nullptr, const int32_t* item_query = nullptr);
 int ivf_work_table(IvfRun& r, WorkTable& wt);

@@ -13,6 +13,7 @@
 #include "coarse.h"
 #include "multi.h"
 #include "io_kernels.h"
+#include "bigk.h"
 
 // ---------------------------------------------------------------------------------------
 // kernel dispatch helpers
@@ -52,6 +53,15 @@ int launch_scan(freddy_gpu_index* ix, hipStream_t s, const ScanArgs& a, int n_it
                               (size_t)SCAN_WAVES * 64 * Vl * sizeof(u64));
   dim3 grid((unsigned)a.nchunk, (unsigned)n_items);
   const int V = pick_V(a.L);
+  if (a.floor) {   // a later selection pass of a list of more than 512 entries (bigk.h)
+    if (V != 16) return fail(FREDDY_E_ARG, "selection passes are 1024 keys wide");
+    timed_launch(ix, s, "adc_scan", [&] {
+      if (a.m == 12) hipLaunchKernelGGL((adc_scan_kernel<12, 16, true>), grid, dim3(SCAN_WG), lds, s, a);
+      else hipLaunchKernelGGL((adc_scan_kernel<0, 16, true>), grid, dim3(SCAN_WG), lds, s, a);
+    });
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (a.m == 12) return launch_scan_m<12>(ix, s, a, grid, lds, V);
   return launch_scan_m<0>(ix, s, a, grid, lds, V);
 }
@@ -68,6 +78,42 @@ int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a) {
       case 8: hipLaunchKernelGGL((merge_replay_kernel<8>), grid, block, 0, s, a); break;
       case 16: hipLaunchKernelGGL((merge_replay_kernel<16>), grid, block, 0, s, a); break;
     }
+  });
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// k > 512 (bigk.h): the 2k smallest keys of every active query, 1024 per pass over the same rows, then the list in closed form.
+// sa: the generic scan's arguments with L = 1024; ma: what merge_replay_kernel would get (its L is not used); Q: queries of the chunk.
+int bigk_select_replay(freddy_gpu_index* ix, hipStream_t s, Workspace* ws, ScanArgs sa, int n_items, const MergeArgs& ma, int Q) {
+  if (ma.n_active <= 0) return 0;
+  const int k = ma.k;
+  if (k > BIGK_KMAX || sa.L != BIGK_PASS) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of %d", k, BIGK_KMAX);
+  const int passes = (2 * k + BIGK_PASS - 1) / BIGK_PASS;
+  const int nsel = passes * BIGK_PASS;
+  int npad = 2048;
+  while (npad < k + nsel) npad *= 2;
+  if (ws->w_bigsel.ensure(sizeof(u64) * (size_t)ma.n_active * nsel) || ws->w_floor.ensure(sizeof(u64) * (size_t)std::max(Q, 1)))
+    return fail(FREDDY_E_NOMEM, "workspace allocation failed (k=%d)", k);
+  SelectArgs se;
+  se.part = sa.part; se.active = ma.active; se.sel = ws->w_bigsel.as<u64>(); se.floor = ws->w_floor.as<u64>();
+  se.parts_per_query = ma.parts_per_query; se.nsel = nsel;
+  int32_t* const cand_count = sa.cand_count;
+  for (int p = 0; p < passes; ++p) {
+    sa.floor = p ? ws->w_floor.as<u64>() : nullptr;
+    sa.cand_count = p ? nullptr : cand_count;   // (the accepted-rows rule counts every row once)
+    if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
+    se.pass = p;
+    timed_launch(ix, s, "merge_select", [&] { hipLaunchKernelGGL(merge_select_kernel, dim3(ma.n_active), dim3(64), 0, s, se); });
+    HIP_TRY(hipGetLastError());
+  }
+  BigkArgs b;
+  b.sel = se.sel; b.active = ma.active; b.pos_to_id = ma.pos_to_id; b.round_rows = ma.round_rows; b.cand_count = ma.cand_count;
+  b.out_ids = ma.out_ids; b.out_dist = ma.out_dist; b.found = ma.found; b.next_active = ma.next_active; b.n_next = ma.n_next;
+  b.status = ma.status; b.n_active = ma.n_active; b.nsel = nsel; b.npad = npad; b.k = k; b.found_rule = ma.found_rule;
+  b.first_round = ma.first_round; b.sentinel = ma.sentinel;
+  timed_launch(ix, s, "bigk_replay", [&] {
+    hipLaunchKernelGGL(bigk_replay_kernel, dim3(ma.n_active), dim3(BIGK_T), bigk_lds_bytes(npad, k), s, b);
   });
   HIP_TRY(hipGetLastError());
   return 0;
@@ -516,7 +562,6 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   sa.cand_count = ws->w_cand.as<int32_t>();
   sa.m = ix->m; sa.K = ix->K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = r.L;
   memcpy(&sa.sentinel_bits, &r.sentinel, 4);
-  if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
   MergeArgs ma;
   ma.part = sa.part; ma.active = r.active; ma.pos_to_id = nullptr; ma.round_rows = pa.round_rows;
   ma.cand_count = sa.cand_count; ma.out_ids = r.d_out_ids; ma.out_dist = r.d_out_dist;
@@ -524,6 +569,8 @@ static int ivf_scan_generic(IvfRun& r, const PlanArgs& pa) {
   ma.status = r.d_status;
   ma.n_active = r.n_active; ma.parts_per_query = r.W * nchunk; ma.L = r.L; ma.k = r.k;
   ma.found_rule = r.found_rule; ma.first_round = r.first() ? 1 : 0; ma.sentinel = r.sentinel;
+  if (2 * r.k > 1024) return bigk_select_replay(ix, s, ws, sa, n_items, ma, r.Q);
+  if (int rc = launch_scan(ix, s, sa, n_items)) return rc;
   return launch_merge(ix, s, ma);
 }
 
@@ -1029,7 +1076,8 @@ int raise_lds_limits_ivfadc(int device) {
       (const void*)&adc_scan_kernel<12, 1>, (const void*)&adc_scan_kernel<12, 2>, (const void*)&adc_scan_kernel<12, 4>,
       (const void*)&adc_scan_kernel<12, 8>, (const void*)&adc_scan_kernel<12, 16>, (const void*)&adc_scan_kernel<0, 1>,
       (const void*)&adc_scan_kernel<0, 2>, (const void*)&adc_scan_kernel<0, 4>, (const void*)&adc_scan_kernel<0, 8>,
-      (const void*)&adc_scan_kernel<0, 16>, (const void*)&ivf_spec2_kernel<25, 12, true>,
+      (const void*)&adc_scan_kernel<0, 16>, (const void*)&adc_scan_kernel<12, 16, true>, (const void*)&adc_scan_kernel<0, 16, true>,
+      (const void*)&ivf_spec2_kernel<25, 12, true>,
       (const void*)&ivf_spec2_kernel<25, 12, false>,
       (const void*)&ivf_filter5_kernel<12, true, false>, (const void*)&ivf_filter5_kernel<12, false, false>,
       (const void*)&ivf_filter5_kernel<12, true, true>, (const void*)&ivf_filter5_kernel<12, false, true>,
@@ -1040,6 +1088,8 @@ int raise_lds_limits_ivfadc(int device) {
       (const void*)&coarse_approx_kernel, (const void*)&coarse_approx16_kernel, (const void*)&ivf_multi_kernel};
   for (const void* k : kernels)
     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  // (static LDS beside the dynamic: 16384 keys + 4096 carried ids = 144 KB)
+  HIP_TRY(hipFuncSetAttribute((const void*)&bigk_replay_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bigk_lds_bytes(16384, BIGK_KMAX)));
   if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);
   done[(size_t)device] = 1;
   return 0;

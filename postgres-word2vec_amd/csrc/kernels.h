@@ -691,6 +691,8 @@ struct ScanArgs {
   int32_t* cand_count;        // [Q] += candidates with dist < sentinel (FOUND_ACCEPTED rule)
   int m, K, chunk_blocks, nchunk, L;
   uint32_t sentinel_bits;
+  // FLOOR instantiations (k > 512, bigk.h: the 2k smallest keys are selected 1024 at a time): only keys ABOVE the query's floor
+  const u64* floor = nullptr;   // [Q] the largest key the passes so far have selected
 };
 
 template <int M2T>
@@ -699,7 +701,7 @@ struct RowBlock {
   int32_t p;
 };
 
-template <int M, int V>
+template <int M, int V, bool FLOOR = false>
 __global__ __launch_bounds__(SCAN_WG) void adc_scan_kernel(ScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int M2T = (M > 0) ? (M + 1) / 2 : 1;
@@ -717,6 +719,8 @@ __global__ __launch_bounds__(SCAN_WG) void adc_scan_kernel(ScanArgs a) {
   const u64 sentinel_key = (u64)a.sentinel_bits << 32;   // key < this  <=>  dist < sentinel
   sel.init(stage + wave * 64, sentinel_key, a.L);
   int accepted = 0;
+  u64 flo = 0;
+  if constexpr (FLOOR) flo = a.floor[a.item_query ? a.item_query[item] : item];
 
   int b0 = 0, b1 = 0;
   if (list >= 0) {
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(SCAN_WG) void adc_scan_kernel(ScanArgs a) {
               dist = dist + lut[l * K + code];
             }
             const u64 key = make_key(dist, (uint32_t)cur.p);
-            const bool valid = (cur.p >= 0);
+            const bool valid = (cur.p >= 0) && (!FLOOR || key > flo);
             accepted += __popcll(__ballot(valid && key < sentinel_key));
             sel.push(key, valid);
           }
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(SCAN_WG) void adc_scan_kernel(ScanArgs a) {
           if (l + 1 < m) dist = dist + lut[(l + 1) * K + (w >> 16)];
         }
         const u64 key = make_key(dist, (uint32_t)p);
-        const bool valid = (p >= 0);
+        const bool valid = (p >= 0) && (!FLOOR || key > flo);
         accepted += __popcll(__ballot(valid && key < sentinel_key));
         sel.push(key, valid);
       }

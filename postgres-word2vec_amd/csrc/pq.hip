@@ -341,13 +341,14 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   sa.cand_count = nullptr;
   sa.m = m; sa.K = K; sa.chunk_blocks = chunk_blocks; sa.nchunk = nchunk; sa.L = L;
   memcpy(&sa.sentinel_bits, &sentinel, 4);
-  if (int rc = launch_scan(ix, s, sa, Q)) return rc;
   MergeArgs ma;
   ma.part = sa.part; ma.active = nullptr; ma.pos_to_id = ix->ids; ma.round_rows = nullptr; ma.cand_count = nullptr;
   ma.out_ids = d_out_ids; ma.out_dist = d_out_dist; ma.found = nullptr; ma.next_active = nullptr; ma.n_next = nullptr;
   ma.status = nullptr;
   ma.n_active = Q; ma.parts_per_query = nchunk; ma.L = L; ma.k = k; ma.found_rule = 0; ma.first_round = 1;
   ma.sentinel = sentinel;
+  if (2 * k > 1024) return bigk_select_replay(ix, s, ws, sa, Q, ma, Q);   // (k > 512: bigk.h)
+  if (int rc = launch_scan(ix, s, sa, Q)) return rc;
   return launch_merge(ix, s, ma);
 }
 

@@ -692,7 +692,7 @@ static int knn_pv(freddy_session_t* s, bool ivf, const float* query, int32_t dim
   if (dim != (ivf ? s->ivf_d : s->pq_d)) return fail(-1, "query has %d dimensions, index has %d", dim, ivf ? s->ivf_d : s->pq_d);
   if (k <= 0 || !query || !out) return fail(-1, "bad argument");
   const int64_t kc = (int64_t)k * std::max(s->pvf, 1);
-  if (kc > 512) return fail(-1, "pvf * k = %lld exceeds this build's limit of 512 candidates", (long long)kc);
+  if (kc > 4096) return fail(-1, "pvf * k = %lld exceeds this build's limit of 4096 candidates", (long long)kc);
   std::vector<int32_t> ids((size_t)kc); std::vector<float> dist((size_t)kc);
   const int rc = ivf ? freddy_gpu_ivfadc_search(s->ivf, query, 1, (int)kc, s->w, 1000.0f, FREDDY_FOUND_ROWS, ids.data(), dist.data())
                      : freddy_gpu_pq_search(s->pq, query, 1, (int)kc, 100.0f, nullptr, 0, ids.data(), dist.data());

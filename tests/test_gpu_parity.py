@@ -279,6 +279,53 @@ def test_large_k(gpu, oracle):
     idx.close()
 
 
+@pytest.mark.parametrize("k", [513, 600, 2000, 4096])
+def test_k_beyond_512_ivfadc(gpu, oracle, k):
+    """The reference allocates k entries for any k (freddy.c:236,258).  Lists of more than 512 entries (bigk.h): the 2k smallest
+    keys selected 1024 at a time over the same rows, the guarded insertion's result in closed form.  300 rows per cell share one
+    code row (the k-th place falls among equal distances), W = 1 needs several probing rounds (the carried list), both found
+    rules, a sentinel that bites."""
+    N = 20000
+    t = dict(util.ivf_tables(N=N, C=32, K=256))
+    codes = t["codes"].copy()
+    lo = t["list_off"]
+    for c in range(len(lo) - 1):
+        n = min(300, int(lo[c + 1] - lo[c]))
+        codes[lo[c]:lo[c] + n] = codes[lo[c]]
+    t["codes"] = codes
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, 5, seed=3)
+    for W, rule, sent in ((3, 0, 1000.0), (1, 0, 1000.0), (2, 1, 1000.0), (4, 0, 1.5)):
+        gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
+        exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
+        util.assert_same_lists(gi, gd, exp, f"k={k} W={W} rule={rule} sentinel={sent}")
+    idx.close()
+
+
+@pytest.mark.parametrize("k", [600, 2000])
+def test_k_beyond_512_pq(gpu, oracle, k):
+    """pq_search and pq_search_in with k > 512 (freddy.c:66,89): equal distances at the k-th place, a subset smaller than k."""
+    N = 20000
+    t = util.pq_tables(N=N, K=256)
+    codes = t["codes"].copy()
+    codes[1000:1900] = codes[999]   # 900 rows with the same code row
+    ot = oracle.pq_table(t["codebook"], t["ids"], codes)
+    idx = gpu.PQIndex(t["codebook"], t["ids"], codes)
+    _, qs = util.queries_from_corpus(N, 3, seed=9)
+    qs[0] = np.asarray(util.corpus(N)[1200].numpy(), np.float32)   # (a query that is one of the equal rows' neighbours)
+    gi, gd = idx.search(qs, k, sentinel=100.0)
+    exp = np.stack([oracle.pq_search(ot, q, k) for q in qs])
+    util.assert_same_lists(gi, gd, exp, f"pq_search k={k}")
+    rng = np.random.default_rng(3)
+    for n_t in (3000, k - 50):
+        targets = rng.choice(np.arange(1, N + 1), size=n_t, replace=False).astype(np.int32)
+        gi, gd = idx.search(qs, k, sentinel=1000.0, subset_ids=targets)
+        exp = oracle.pq_search_in_batch(ot, qs, k, targets, use_target_lists=True)
+        util.assert_same_lists(gi, gd, exp, f"pq_search_in k={k} targets={n_t}")
+    idx.close()
+
+
 def _join_setup(oracle, gpu, N=20000, k_coarse=8, K=32, m=30):
     t = util.ivpq_tables(N=N, m=m, K=K, k_coarse=k_coarse)
     ot = oracle.ivpq_table(t["codebook"], t["coarse"], t["ids"], t["coarse_id"], t["codes"], t["vectors"], t["stats"])

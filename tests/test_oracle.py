@@ -195,6 +195,61 @@ def test_selection_then_replay_equals_full_replay():
         assert full == part
 
 
+def _replay_closed_form(carried, d, pos, k, sentinel, kmax=4096):
+    """What bigk_replay_kernel (postgres-word2vec_amd/csrc/bigk.h) computes, restated: the list the guarded insertion leaves
+    behind, without performing the insertions.  carried: the k (id, dist) entries of an earlier round or None; (d, pos): the
+    new rows (the 2k smallest keys are enough), arrival = ascending position."""
+    E = []   # (distance bits, arrival, id)
+    if carried is not None:
+        for s, (i, dd) in enumerate(carried):
+            E.append((int(f32(dd).view(np.uint32)), k - 1 - s, i))
+    for dd, p in zip(d, pos):
+        E.append((int(f32(dd).view(np.uint32)), kmax + int(p), int(p)))
+    E.sort(key=lambda e: (e[0], e[1]))
+    sb = int(f32(sentinel).view(np.uint32))
+    S = [e for e in E if e[0] < sb]       # (bit order = float order for non-negative floats; NaN bits are larger)
+    runs_reversed = lambda rows: sorted(rows, key=lambda e: (e[0], -e[1]))
+    if len(S) <= k:
+        out = runs_reversed(S)
+    else:
+        ds = S[k - 1][0]
+        lt = [e for e in S if e[0] < ds]
+        ties = [e for e in S if e[0] == ds]
+        A = sum(1 for j, t in enumerate(ties[:k]) if sum(1 for e in lt if e[1] < t[1]) + j < k)
+        e_ = A + len(lt) - k
+        out = runs_reversed(lt) + list(reversed(ties[e_:A]))
+    res = [(e[2], np.uint32(e[0]).view(f32)) for e in out]
+    return res + [(-1, f32(sentinel))] * (k - len(res))
+
+
+def test_big_k_closed_form_equals_replay():
+    """k > 512 (bigk.h): the list after the reference's guarded insertions, in closed form -- rows below the k-th smallest
+    distance d* all stay; a row AT d* is accepted iff fewer than k rows with d <= d* arrived before it, and the earliest accepted
+    ones are pushed out again by later rows below d*; equal distances end up in descending arrival order; a carried list counts
+    as a prefix of the stream, last slot first.  Tie-heavy streams, sentinel and NaN rows, carried lists with fewer than k real
+    entries, against the insertion loop."""
+    rng = np.random.default_rng(1)
+    for trial in range(4000):
+        k = int(rng.integers(1, 12))
+        n = int(rng.integers(0, 120))
+        levels = int(rng.integers(1, 10))
+        d = (rng.integers(0, levels, size=n) / 4).astype(f32)
+        if trial % 7 == 0 and n:
+            d[rng.integers(0, n)] = f32(100.0)
+        if trial % 11 == 0 and n:
+            d[rng.integers(0, n)] = f32(np.nan)
+        pos = np.sort(rng.permutation(1000)[:n])
+        carried = None
+        if trial % 2 == 0:
+            c = int(rng.integers(0, 3 * k))
+            cd = (rng.integers(0, levels, size=c) / 4).astype(f32)
+            carried = py_stream(cd, -2 - np.arange(c), k, 100.0)
+        full = py_stream(d, pos, k, 100.0, carried)
+        order = np.lexsort((pos, d.view(np.uint32)))[:2 * k]   # the 2k smallest (distance, position) keys, in any order
+        got = _replay_closed_form(carried, d[order], pos[order], k, 100.0)
+        assert [(i, float(x)) for i, x in full] == [(i, float(x)) for i, x in got], (trial, k)
+
+
 def test_pv_buffer_closed_form():
     """updateTopKPVFast/reorderTopKPV (ivpq_search_in.c:40-57) with a stable sort keep exactly
     the `keep` smallest (distance, arrival) entries, ascending."""
