@@ -34,7 +34,7 @@ extern "C" {
 #define FREDDY_E_NOMEM (-3)    /* host or device allocation failed */
 #define FREDDY_E_KIND (-4)     /* index handle of the wrong kind for this call */
 #define FREDDY_E_LIMIT (-5)    /* parameter beyond what this build supports (see message): k > 4096, W > 512 probes per round,
-                                * k * pvf > 1024 in the kNN-join, K > 32767, d > 1024 for training */
+                                * k * pvf > 8192 (or k > 512) in the kNN-join, K > 32767, d > 1024 for training */
 
 /* found_rule for freddy_gpu_ivfadc_search */
 #define FREDDY_FOUND_ROWS 0      /* ivfadc_search:       found += rows retrieved  (freddy.c:377) */

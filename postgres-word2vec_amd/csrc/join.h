@@ -254,6 +254,9 @@ struct JoinArgs {
   int32_t* out_ids;           // [n_scan][k]
   float* out_dist;            // [n_scan][k]
   int d, m, K, S, k, L, method, double_codes;
+  // BIG instantiation (post verification of more than 1024 candidates: k * pvf up to 8192): the candidates and their exact distances
+  u64* big_keys = nullptr;    // [n_scan][L]
+  float* big_exact = nullptr; // [n_scan][L]
 };
 
 __device__ __forceinline__ float sqdist_seq(const float* a, const float* __restrict__ b, int n) {
@@ -280,8 +283,12 @@ __device__ __forceinline__ float sqdist_seq4(const float* a, const float* __rest
   return acc;
 }
 
-template <int V>
+// BIG (method 2 with 1024 < k * pvf <= 8192; V = 16): the k * pvf smallest (ADC distance, row) keys are selected 1024 at a time
+// -- pass p walks the query's candidate rows again and admits only keys above the largest key of pass p - 1 (keys are unique:
+// the row is part of them) -- into a list in memory; post verification and the replay read it there.
+template <int V, bool BIG = false>
 __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
+  static_assert(!BIG || V == 16, "selection passes are 1024 keys wide");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int d = a.d, m = a.m, K = a.K, S = a.S, k = a.k, L = a.L;
   const int lutN = m * K;
@@ -297,7 +304,8 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
   float* s_d = reinterpret_cast<float*>(smem + off);           off += ((size_t)k * 4 + 15) & ~(size_t)15;
   int32_t* s_id = reinterpret_cast<int32_t*>(smem + off);      off += ((size_t)k * 4 + 15) & ~(size_t)15;
   int32_t* c_start = reinterpret_cast<int32_t*>(smem + off);   off += (size_t)JOIN_CELL_CHUNK * 4;        // first target slot of a cell of the chunk
-  int32_t* c_pref = reinterpret_cast<int32_t*>(smem + off);                                               // [chunk + 1] rows before it
+  int32_t* c_pref = reinterpret_cast<int32_t*>(smem + off);    off += (size_t)(JOIN_CELL_CHUNK + 1) * 4;  // [chunk + 1] rows before it
+  u64* const s_floor_p = reinterpret_cast<u64*>(smem + ((off + 7) & ~(size_t)7));                          // (BIG; inside the carve's 16 spare bytes)
 
   const int x = blockIdx.x;
   const int q = a.scan_query[x];
@@ -326,9 +334,12 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
   const bool vec4 = (d & 3) == 0;   // (rows of d floats are then 16-byte aligned: hipMalloc'd base, pitch 4 d)
 
   WaveSelect<V> sel;
-  sel.init(stage + wave * 64, (u64)__float_as_uint(JOIN_MAX_DIST) << 32, L);
   const int c_begin = a.qcell_off ? a.qcell_off[x] : q * a.qstride;
   const int c_end = a.qcell_off ? a.qcell_off[x + 1] : c_begin + a.qcell_cnt[q];
+  u64 floor_key = 0;
+  const int n_pass = BIG ? (L + 64 * V - 1) / (64 * V) : 1;
+  for (int pass = 0; pass < n_pass; ++pass) {
+  sel.init(stage + wave * 64, (u64)__float_as_uint(JOIN_MAX_DIST) << 32, BIG ? 64 * V : L);
   // The target rows of the query's cells as ONE index space: a query takes ~40 cells of ~16 target rows each, and a loop
   // "cell by cell, 64 rows at a time" left three quarters of the lanes idle and paid three dependent round trips (cell
   // offsets -> row number -> codes) per cell and wave -- 25-33 us of a 48 us workgroup.  Here the cells' offsets are read
@@ -403,7 +414,8 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
           }
         }
       }
-      sel.push(make_key(dist, (uint32_t)row), valid);
+      const u64 key = make_key(dist, (uint32_t)row);
+      sel.push(key, valid && (!BIG || pass == 0 || key > floor_key));
     }
   }
   sel.finish();
@@ -419,6 +431,15 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
         wave_topk_absorb_sorted<V>(sel.acc, key);
       }
     }
+    if constexpr (BIG) {   // this pass's keys behind the earlier ones: (ADC distance, row) ascending over all passes
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int e = pass * 64 * V + v * 64 + lane;
+        if (e < L) a.big_keys[(size_t)x * L + e] = sel.acc[v];
+      }
+      const u64 top = wave_topk_at<V>(sel.acc, 64 * V - 1);   // KEY_INF: fewer keys than a pass holds -- the rows are exhausted
+      if (lane == 0) *s_floor_p = top;
+    } else
     if (a.method == FREDDY_METHOD_PQ_PV) {
       // survivors stay in (ADC distance, row) order: that is the order postverify walks them
 #pragma unroll
@@ -433,6 +454,17 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
       for (int v = 0; v < V; ++v) lists[v * 64 + lane] = byp[v];
     }
   }
+  if constexpr (BIG) {
+    __syncthreads();
+    floor_key = *s_floor_p;
+    if (floor_key == KEY_INF) {   // (the slots of the passes that would follow stay empty)
+      for (int e = (pass + 1) * 64 * V + (int)threadIdx.x; e < L; e += JOIN_WG) a.big_keys[(size_t)x * L + e] = KEY_INF;
+      break;
+    }
+  }
+  }   // passes
+  const u64* const cand = BIG ? a.big_keys + (size_t)x * L : lists;
+  float* const exact_d = BIG ? a.big_exact + (size_t)x * L : exact;
   for (int i = threadIdx.x; i < k; i += JOIN_WG) { s_d[i] = JOIN_MAX_DIST; s_id[i] = -1; }
   __syncthreads();
   if (a.method == FREDDY_METHOD_PQ_PV) {
@@ -441,8 +473,8 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
     for (int e0 = 0; e0 < L; e0 += JOIN_WG) {
       const int e = e0 + (int)(threadIdx.x & 63) * JOIN_WAVES + (int)(threadIdx.x >> 6);
       if (e < L) {
-        const u64 c = lists[e];
-        exact[e] = (c == KEY_INF) ? 0.0f
+        const u64 c = cand[e];
+        exact_d[e] = (c == KEY_INF) ? 0.0f
                    : vec4 ? sqdist_seq4(qv, a.vectors + (size_t)key_pos(c) * d, d) : sqdist_seq(qv, a.vectors + (size_t)key_pos(c) * d, d);
       }
     }
@@ -454,11 +486,11 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
     int32_t id_slot = -1;
     float maxd = JOIN_MAX_DIST;
     for (int e = 0; e < L; ++e) {
-      const u64 c = lists[e];
+      const u64 c = cand[e];
       if (c == KEY_INF) break;
       float dist;
       uint32_t row;
-      if (a.method == FREDDY_METHOD_PQ_PV) { dist = exact[e]; row = key_pos(c); }
+      if (a.method == FREDDY_METHOD_PQ_PV) { dist = exact_d[e]; row = key_pos(c); }
       else { dist = __uint_as_float((uint32_t)c); row = (uint32_t)(c >> 32); }
       if (dist < maxd) {
         wave_list_insert(d_slot, id_slot, k, dist, a.ids[row]);
@@ -469,11 +501,11 @@ __global__ __launch_bounds__(JOIN_WG) void join_query_kernel(JoinArgs a) {
   } else if (threadIdx.x == 0 && k > 64) {
     float maxd = JOIN_MAX_DIST;
     for (int e = 0; e < L; ++e) {
-      const u64 c = lists[e];
+      const u64 c = cand[e];
       if (c == KEY_INF) break;
       float dist;
       uint32_t row;
-      if (a.method == FREDDY_METHOD_PQ_PV) { dist = exact[e]; row = key_pos(c); }
+      if (a.method == FREDDY_METHOD_PQ_PV) { dist = exact_d[e]; row = key_pos(c); }
       else { dist = __uint_as_float((uint32_t)c); row = (uint32_t)(c >> 32); }
       if (dist < maxd) {
         int slot = k - 1;                                // updateTopK, index_utils.c:19-33
@@ -862,6 +894,11 @@ static inline int join_pick_V(int L) {
 
 static inline int join_launch(hipStream_t s, const JoinArgs& a, int n_scan, int V, size_t lds) {
   dim3 grid((unsigned)n_scan), block(JOIN_WG);
+  if (a.big_keys) {
+    hipLaunchKernelGGL((join_query_kernel<16, true>), grid, block, lds, s, a);
+    JOIN_HIP(hipGetLastError());
+    return 0;
+  }
 #define JOIN_CASE(v)                                                                                         \
   case v: hipLaunchKernelGGL((join_query_kernel<v>), grid, block, lds, s, a); break;
   switch (V) {
@@ -896,9 +933,13 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   if (method != FREDDY_METHOD_EXACT) double_codes = ((int64_t)alpha * k > double_threshold);  // :262-266
   if (double_codes && (int64_t)K * K > 32768) return join_fail(FREDDY_E_LIMIT, "pair codes of K=%d overflow the reference's int16", K);
   const int64_t Lw = (method == FREDDY_METHOD_PQ_PV) ? (int64_t)k * pvf : 2 * (int64_t)k;
-  if (Lw > 1024) return join_fail(FREDDY_E_LIMIT, "k*pvf=%lld (or 2k) exceeds this build's limit of 1024", (long long)Lw);
+  // (post verification walks its candidates in (ADC distance, row) order whatever their number: up to 8192 of them, selected 1024
+  // per pass -- join_query_kernel<16, true>; the replay of methods 0 / 1 holds 2k keys in one wave's registers)
+  const bool big = method == FREDDY_METHOD_PQ_PV && Lw > 1024;
+  if (Lw > (big ? 8192 : 1024))
+    return join_fail(FREDDY_E_LIMIT, big ? "k*pvf=%lld exceeds this build's limit of 8192" : "2k=%lld exceeds this build's limit of 1024", (long long)Lw);
   const int L = (int)Lw;
-  const int V = join_pick_V(L);
+  const int V = big ? 16 : join_pick_V(L);
   for (int i = 0; i < Q * k; ++i) { out_ids[i] = -1; out_dist[i] = JOIN_MAX_DIST; }            // initTopKs :238
   if (iterations_out) *iterations_out = 0;
   if (Q == 0) return 0;
@@ -1253,6 +1294,11 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       a.queries = (const float*)d_q; a.tcell_off = (const int32_t*)d_tcell; a.trow = (const int32_t*)d_trow;
       a.ids = j->ids; a.codes = j->codes; a.MP = j->MP; a.vectors = j->vectors; a.cbT = j->cbT;
       a.d = d; a.m = m; a.K = K; a.S = j->S; a.k = k; a.L = L; a.method = method; a.double_codes = double_codes ? 1 : 0;
+      if (big) {
+        void *bk = nullptr, *be = nullptr;
+        if (join_buf(j, 16, sizeof(u64) * (size_t)n_scan * L, &bk) || join_buf(j, 17, sizeof(float) * (size_t)n_scan * L, &be)) return FREDDY_E_NOMEM;
+        a.big_keys = (u64*)bk; a.big_exact = (float*)be;
+      }
       if (!j->ev0) { JOIN_HIP(hipEventCreate(&j->ev0)); JOIN_HIP(hipEventCreate(&j->ev1)); }
       JOIN_HIP(hipEventRecord(j->ev0, s));
       // (a separate launch for the host-traversed queries ran behind the main one -- a lone workgroup's 45 us -- and its two

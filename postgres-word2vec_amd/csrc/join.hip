@@ -65,7 +65,7 @@ int raise_lds_limits_join(int device) {
   if ((size_t)device < done.size() && done[(size_t)device]) return 0;
   const void* kernels[] = {
       (const void*)&join_query_kernel<1>, (const void*)&join_query_kernel<2>,
-      (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>};
+      (const void*)&join_query_kernel<4>, (const void*)&join_query_kernel<8>, (const void*)&join_query_kernel<16>, (const void*)&join_query_kernel<16, true>};
   for (const void* k : kernels)
     HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   if (done.size() <= (size_t)device) done.resize((size_t)device + 1, 0);

@@ -76,8 +76,8 @@ struct JoinIndex {
   int tl_cells = -1;
   bool tl_valid = false;
   // workspaces
-  void* w[16] = {nullptr};
-  size_t wcap[16] = {0};
+  void* w[18] = {nullptr};
+  size_t wcap[18] = {0};
   float libm_margin = 1e-5f;     // option join_libm_margin_ppm: device confidences this close to the threshold are re-evaluated by the host's libm
   bool host_traversal = false;   // option join_host_traversal / FREDDY_GPU_JOIN_HOST_TRAVERSAL: every traversal on the host heap
   // stage timers of the last call under the reference's TRACK names (ivpq_search_in.c:234-697)
@@ -104,7 +104,7 @@ static inline void join_free(JoinIndex* j) {
   if (j->h_q) (void)hipHostFree(j->h_q);
   if (j->h_sum) (void)hipHostFree(j->h_sum);
   if (j->h_tl) (void)hipHostFree(j->h_tl);
-  for (int i = 0; i < 16; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
+  for (int i = 0; i < 18; ++i) if (j->w[i]) (void)hipFree(j->w[i]);
   if (j->ev0) (void)hipEventDestroy(j->ev0);
   if (j->ev1) (void)hipEventDestroy(j->ev1);
   *j = JoinIndex();

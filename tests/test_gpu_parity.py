@@ -361,6 +361,28 @@ def test_knn_join_matches_oracle(gpu, oracle, method, use_tl):
     idx.close()
 
 
+def test_knn_join_post_verification_beyond_1024_candidates(gpu, oracle):
+    """k * pvf > 1024 (the SQL default pvf = 20 with k > 51; ivpq_search_in.c:238-259 allocates k * pvf entries for any value):
+    the candidates of the post verification selected 1024 per pass over the query's rows (join_query_kernel<16, true>).  Queries
+    with more candidate rows than k * pvf and with fewer; pair codes; lists and iteration counts equal the oracle's."""
+    N = 20000
+    t, ot, idx = _join_setup(oracle, gpu, N)
+    _, qs = util.queries_from_corpus(N, 24, seed=23)
+    rng = np.random.default_rng(8)
+    targets = rng.choice(np.arange(1, N + 1), size=15000, replace=False).astype(np.int32)
+    for (k, alpha, pvf, tg) in [(20, 150, 100, targets), (100, 30, 20, targets), (20, 300, 400, targets), (60, 5, 20, targets[:3000])]:
+        for use_tl in (True, False):
+            gi, gd, git = idx.knn_join(qs, k, tg, alpha, pvf, 2, use_target_lists=use_tl, confidence=0.8)
+            exp, eit = oracle.ivpq_search_in(ot, qs, k, tg, alpha, pvf, 2, use_target_lists=use_tl, confidence=0.8)
+            assert git == eit, (git, eit)
+            util.assert_same_lists(gi, gd, exp, f"knn_join k={k} alpha={alpha} pvf={pvf} tl={use_tl} targets={len(tg)}")
+    gi, gd, git = idx.knn_join(qs, 20, targets, 150, 100, 2, double_threshold=20)
+    exp, eit = oracle.ivpq_search_in(ot, qs, 20, targets, 150, 100, 2, double_threshold=20)
+    assert git == eit
+    util.assert_same_lists(gi, gd, exp, "knn_join k*pvf=2000, pair codes")
+    idx.close()
+
+
 def test_knn_join_edge_cases(gpu, oracle):
     N = 20000
     t, ot, idx = _join_setup(oracle, gpu, N)
