@@ -60,7 +60,11 @@ int exf_table_stats(freddy_gpu_index* ix, int64_t r0, int64_t n) {
 
 // The filter + refine path for all rows of the table.  *fell_back = 1: a candidate buffer overflowed or a query was not
 // finite -- nothing was written, the caller runs the all-exact kernels.
-static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t s, const float* d_queries, int Q, int k, int* fell_back) {
+// q_copy: NULL, or device memory for the queries when d_queries is mapped host memory (exf_prep_kernel copies them).
+// h_out: mapped host memory [Q*k ids][Q*k similarities][2 verdict words], p_out the same block as the device sees it: the merge
+// writes there, ONE synchronisation ends the call (four 12-us copies and a second synchronisation before).
+static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t s, const float* d_queries, int Q, int k, int* fell_back,
+                               int32_t* h_out, int32_t* p_out, float* q_copy) {
   *fell_back = 0;
   const int d = ix->d, T = (d + 15) / 16, L = k, V = pick_V(L);
   const int64_t N = ix->N;
@@ -75,19 +79,27 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
   // small per-call state: [0..63] thr, [64..127] qeps, [128..191] qunscale, [192..255] cand_cnt, [256] qbad
   if (ix->exf_small.ensure(4096) || ix->exf_qfrag.ensure((size_t)2 * T * 2 * 64 * 16) ||
       ix->exf_sample.ensure(sizeof(float) * (size_t)EXF_QT * n_sample) || ix->exf_cand.ensure(sizeof(uint2) * (size_t)EXF_QT * cap) ||
-      ws->w_part.ensure(sizeof(u64) * (size_t)Q * EXF_TW * L) || ws->w_out_ids.ensure(sizeof(int32_t) * (size_t)Q * k) ||
-      ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
+      false)
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   if (!ix->viol) {
     HIP_TRY(hipMalloc((void**)&ix->viol, 4 * sizeof(int32_t)));
     HIP_TRY(hipMemset(ix->viol, 0, 4 * sizeof(int32_t)));
   }
+  if (ix->exf_dirty) {   // (the handle's first call, or the one after a call that failed part-way: the verdict words and the arrival counter may be anything; a call's last workgroup leaves them at zero)
+    HIP_TRY(hipMemsetAsync(ix->exf_small.as<float>() + 256, 0, 8, s));
+    HIP_TRY(hipMemsetAsync(ix->viol + 3, 0, 4, s));
+  }
+  ix->exf_dirty = true;
+  int32_t* const flags = h_out + 2 * (size_t)Q * k;
+  flags[0] = flags[1] = -1;   // (before anything is enqueued: the call's last workgroup overwrites both)
   float* sm = ix->exf_small.as<float>();
   float* thr = sm; float* qeps = sm + 64; float* qunscale = sm + 128;
   int32_t* cand_cnt = reinterpret_cast<int32_t*>(sm + 192);
   int32_t* qbad = reinterpret_cast<int32_t*>(sm + 256);
-  HIP_TRY(hipMemsetAsync(qbad, 0, 4, s));
-  HIP_TRY(hipMemsetAsync(ix->viol + 3, 0, 4, s));
+  int32_t* arrived = reinterpret_cast<int32_t*>(sm + 257);
+  int32_t* const o_ids = p_out;
+  float* const o_sim = reinterpret_cast<float*>(p_out + (size_t)Q * k);
+  int32_t* const o_flags = p_out + 2 * (size_t)Q * k;
   const size_t lds1 = (size_t)1 * T * 2 * 64 * 16, lds2 = 2 * lds1;
   for (int q0 = 0; q0 < Q; q0 += EXF_QT) {
     const int nq = std::min(EXF_QT, Q - q0);
@@ -95,6 +107,7 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
     ExfPrepArgs pa;
     pa.queries = d_queries + (size_t)q0 * d; pa.nq = nq; pa.d = d; pa.T = T; pa.xmax_norm = ix->exf_xnorm; pa.ex = ix->exf_ex;
     pa.eps_factor = exf_eps_factor(d); pa.qfrag = ix->exf_qfrag.as<h8v>(); pa.qeps = qeps; pa.qunscale = qunscale; pa.qbad = qbad;
+    pa.copy_out = q_copy ? q_copy + (size_t)q0 * d : nullptr;
     timed_launch(ix, s, "exact_prep", [&] { hipLaunchKernelGGL(exf_prep_kernel, dim3(EXF_QT), dim3(256), 0, s, pa); });
     HIP_TRY(hipGetLastError());
     ExfArgs fa;
@@ -107,10 +120,9 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
     });
     HIP_TRY(hipGetLastError());
     ExfThrArgs ta;
-    ta.sample = fa.sample_out; ta.n_sample = n_sample; ta.nq = nq; ta.k = k; ta.qeps = qeps; ta.qunscale = qunscale; ta.thr = thr; ta.refine_all = all ? 1 : 0;
+    ta.sample = fa.sample_out; ta.n_sample = n_sample; ta.nq = nq; ta.k = k; ta.qeps = qeps; ta.qunscale = qunscale; ta.thr = thr; ta.refine_all = all ? 1 : 0; ta.cand_cnt = cand_cnt;
     timed_launch(ix, s, "exact_threshold", [&] { hipLaunchKernelGGL(exf_threshold_kernel, dim3(EXF_QT), dim3(64 * EXF_TW), 0, s, ta); });
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemsetAsync(cand_cnt, 0, sizeof(int32_t) * EXF_QT, s));
     fa.n_rows = N; fa.strip_stride = 1; fa.sample_out = nullptr;
     timed_launch(ix, s, "exact_filter", [&] {
       if (NT == 1) hipLaunchKernelGGL((exf_filter_kernel<1, false>), dim3(grid_for(N)), dim3(EXF_WG), lds1, s, fa);
@@ -118,9 +130,11 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
     });
     HIP_TRY(hipGetLastError());
     ExfRefineArgs ra;
-    ra.rows = ix->coarse; ra.queries = d_queries + (size_t)q0 * d; ra.cand = fa.cand; ra.cand_cnt = cand_cnt; ra.qeps = qeps;
-    ra.part = ws->w_part.as<u64>() + (size_t)q0 * EXF_TW * L; ra.viol = ix->viol; ra.cap = cap; ra.d = d; ra.L = L; ra.count_checked = all ? 1 : 0;
-    const size_t rlds = (((size_t)d * 4 + 15) & ~(size_t)15) + (size_t)EXF_TW * 64 * sizeof(u64);
+    ra.rows = ix->coarse; ra.queries = (q_copy ? q_copy : d_queries) + (size_t)q0 * d; ra.cand = fa.cand; ra.cand_cnt = cand_cnt; ra.qeps = qeps;
+    ra.viol = ix->viol; ra.cap = cap; ra.d = d; ra.L = L; ra.count_checked = all ? 1 : 0;
+    ra.ids = ix->ids; ra.out_ids = o_ids + (size_t)q0 * k; ra.out_sim = o_sim + (size_t)q0 * k; ra.k = k; ra.arrived = arrived; ra.total_wgs = Q;
+    ra.qbad = qbad; ra.flags_out = o_flags;
+    const size_t rlds = exf_refine_lds(d, V == 1 ? 1 : 2);
     timed_launch(ix, s, "exact_refine", [&] {
       switch (V) {
         case 1: hipLaunchKernelGGL((exf_refine_kernel<1>), dim3(nq), dim3(64 * EXF_TW), rlds, s, ra); break;
@@ -129,17 +143,9 @@ static int exact_filter_search(freddy_gpu_index* ix, Workspace* ws, hipStream_t 
     });
     HIP_TRY(hipGetLastError());
   }
-  timed_launch(ix, s, "exact_merge", [&] {
-    switch (V) {
-      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (1 + 1) * sizeof(u64), s, ws->w_part.as<u64>(), EXF_TW, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
-      default: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (2 + 1) * sizeof(u64), s, ws->w_part.as<u64>(), EXF_TW, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
-    }
-  });
-  HIP_TRY(hipGetLastError());
-  int32_t flags[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(&flags[0], ix->viol + 3, 4, hipMemcpyDeviceToHost, s));
-  HIP_TRY(hipMemcpyAsync(&flags[1], qbad, 4, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
+  if (flags[0] == -1 || flags[1] == -1) return fail(FREDDY_E_HIP, "exact search: the verdict words did not arrive");
+  ix->exf_dirty = false;
   if (flags[0] || flags[1]) *fell_back = 1;
   return 0;
 }
@@ -229,14 +235,34 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
   const bool want_filter = !subset_ids && ix->exf_ok && k <= 32 && ix->tune.exact_filter != 0 &&
                            (ix->tune.exact_filter == 1 || n_rows >= 8192) && n_rows >= 1;
   if (want_filter) {
-    if (ws->w_q.ensure(sizeof(float) * (size_t)Q * d)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
-    HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
+    // one block of mapped host memory: [lists][verdict words][the queries, when they are few]: the kernels read a handful of
+    // queries where the host put them (1.2 KB each over PCIe) and write the lists where the host reads them
+    const size_t n_out = (size_t)Q * k, q_bytes = sizeof(float) * (size_t)Q * d;
+    const bool q_pinned = q_bytes <= (256u << 10);
+    const size_t out_bytes = (n_out * 8 + 8 + 255) & ~(size_t)255, need = out_bytes + (q_pinned ? q_bytes : 0);
+    if (need > ix->hio_out_cap) {
+      if (ix->hio_out) (void)hipHostFree(ix->hio_out);
+      ix->hio_out = nullptr; ix->hio_out_cap = 0;
+      if (hipHostMalloc(&ix->hio_out, need + need / 4 + 256, hipHostMallocDefault) != hipSuccess) { ix->hio_out = nullptr; return fail(FREDDY_E_NOMEM, "pinned staging allocation failed"); }
+      ix->hio_out_cap = need + need / 4 + 256;
+    }
+    void* dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, ix->hio_out, 0));
+    int32_t* const h_out = static_cast<int32_t*>(ix->hio_out);
+    const float* d_q = nullptr;
+    if (ws->w_q.ensure(q_bytes)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    if (q_pinned) {
+      memcpy(static_cast<char*>(ix->hio_out) + out_bytes, queries, q_bytes);
+      d_q = reinterpret_cast<const float*>(static_cast<char*>(dp) + out_bytes);
+    } else {
+      HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, q_bytes, hipMemcpyHostToDevice, s));
+      d_q = ws->w_q.as<float>();
+    }
     int fell_back = 0;
-    if (int rc = exact_filter_search(ix, ws, s, ws->w_q.as<float>(), Q, k, &fell_back)) return rc;
+    if (int rc = exact_filter_search(ix, ws, s, d_q, Q, k, &fell_back, h_out, static_cast<int32_t*>(dp), q_pinned ? ws->w_q.as<float>() : nullptr)) return rc;
     if (!fell_back) {
-      HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipMemcpyAsync(out_sim, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipStreamSynchronize(s));
+      memcpy(out_ids, h_out, n_out * 4);
+      memcpy(out_sim, h_out + n_out, n_out * 4);
       return FREDDY_OK;
     }
   }

@@ -137,6 +137,7 @@ struct ExfPrepArgs {
   float* qeps;            // [EXF_QT] eps(q)
   float* qunscale;        // [EXF_QT] 2^-(eq + ex)
   int32_t* qbad;          // [1] |= 1 if a query is not finite
+  float* copy_out;        // NULL, or [nq][d]: `queries` is mapped host memory -- read once here, the refine kernel reads this copy
 };
 __global__ __launch_bounds__(256) void exf_prep_kernel(ExfPrepArgs a) {
   const int q = blockIdx.x;        // 0 .. EXF_QT-1
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void exf_prep_kernel(ExfPrepArgs a) {
   if (live)
     for (int i = tid; i < a.d; i += 256) {
       const float v = qv[i];
+      if (a.copy_out) a.copy_out[(size_t)q * a.d + i] = v;
       if (!(__builtin_fabsf(v) < 3e38f)) bad = true;
       amax = fmaxf(amax, __builtin_fabsf(v));
       n2 = __builtin_fmaf(v, v, n2);
@@ -170,6 +172,7 @@ __global__ __launch_bounds__(256) void exf_prep_kernel(ExfPrepArgs a) {
   }
   __syncthreads();
   const int eq = eq_s;
+  if (a.copy_out && live) qv = a.copy_out + (size_t)q * a.d;   // (this workgroup's own stores, behind the barrier)
   const int n = q >> 5, j = q & 31;
   for (int i = tid; i < a.T * 2; i += 256) {   // (k-step t, lane group g)
     const int t = i >> 1, g = i & 1;
@@ -288,6 +291,7 @@ struct ExfThrArgs {
   const float* qunscale;
   float* thr;              // [EXF_QT]
   int refine_all;          // tests: every row is a candidate
+  int32_t* cand_cnt;       // [EXF_QT] <- 0 (the filter pass behind this launch counts from there)
 };
 static constexpr int EXF_TW = 16;   // waves per query of the threshold and refine kernels (one query: the launch is one workgroup)
 __global__ __launch_bounds__(64 * EXF_TW) void exf_threshold_kernel(ExfThrArgs a) {
@@ -296,17 +300,30 @@ __global__ __launch_bounds__(64 * EXF_TW) void exf_threshold_kernel(ExfThrArgs a
   __shared__ int nan_s[EXF_TW];
   const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float NEG_INF = -__builtin_huge_valf();
+  if (threadIdx.x == 0) a.cand_cnt[q] = 0;
   if (q >= a.nq) { if (threadIdx.x == 0) a.thr[q] = __builtin_huge_valf(); return; }   // padding columns never pass
-  WaveSelect<1> sel;
-  sel.init(stage[wave], KEY_INF, a.k < 64 ? a.k : 64);
+  // the k-th best of the 1024 lanes' best sample rows: every one of them is some row's approximate similarity, so their k-th
+  // best is not above the sample's k-th best -- a valid threshold, and within a row or two of it (two of a query's k best rows
+  // in one lane's 32: k^2 / 2048) -- for one selection step per wave instead of 32 (30 -> 9 us, a twentieth of a one-query call)
   const float* s = a.sample + (size_t)q * a.n_sample;
   bool nan = false;
-  for (int base = wave * 64; base < a.n_sample; base += 64 * EXF_TW) {
-    const bool v = base + lane < a.n_sample;
-    const float x = v ? s[base + lane] : 0.0f;
-    if (v && !(x == x)) nan = true;
-    sel.push(sim_key(x, (uint32_t)(base + lane)), v && x == x);
+  u64 best = KEY_INF;
+  for (int base0 = wave * 64; base0 < a.n_sample; base0 += 64 * EXF_TW * 8) {   // (eight loads in flight)
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { const int i = base0 + u * 64 * EXF_TW + lane; x[u] = i < a.n_sample ? s[i] : NEG_INF; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base0 + u * 64 * EXF_TW + lane;
+      if (i < a.n_sample) {
+        if (!(x[u] == x[u])) nan = true;
+        else { const u64 key = sim_key(x[u], (uint32_t)i); best = key < best ? key : best; }
+      }
+    }
   }
+  WaveSelect<1> sel;
+  sel.init(stage[wave], KEY_INF, a.k < 64 ? a.k : 64);
+  sel.push(best, best != KEY_INF);
   sel.finish();
   lists[wave][lane] = sel.acc[0];
   const bool wave_nan = __ballot(nan) != 0ull;
@@ -335,22 +352,35 @@ __global__ __launch_bounds__(64 * EXF_TW) void exf_threshold_kernel(ExfThrArgs a
   }
 }
 
-// ---- the reference's chain for the candidates; per-wave partial lists for exact_merge_kernel ------------------
+// ---- the reference's chain for the candidates, and the query's list -----------------------------------------------
 struct ExfRefineArgs {
   const float* rows;        // [N][d]
   const float* queries;     // [nq][d]
   const uint2* cand;        // [EXF_QT][cap]
   const int32_t* cand_cnt;  // [EXF_QT]
   const float* qeps;
-  u64* part;                // [nq][EXF_TW waves][L] (this pass's slice)
   int32_t* viol;            // [4]: [0] += rows whose similarity left the bracket, [1] += rows refined (refine_all only), [3] |= overflow (a query had more candidates than the buffer holds)
   int cap, d, L, count_checked;
+  // the query's list straight from this workgroup (its sixteen waves' lists meet in LDS: no merge launch), and -- from the call's
+  // LAST workgroup to finish, nobody waits -- the call's two verdict words behind the lists; both are cleared for the next call
+  const int32_t* ids;       // [N]
+  int32_t* out_ids;         // [Q][k] (mapped host memory), this pass's slice
+  float* out_sim;
+  int k;
+  int32_t* arrived;         // [1] workgroups of this CALL that have finished (zero between calls)
+  int total_wgs;            // of the call
+  int32_t* qbad;            // the other verdict word (exf_prep_kernel)
+  int32_t* flags_out;       // [2]
 };
+static inline size_t exf_refine_lds(int d, int V) {
+  return (((size_t)d * 4 + 15) & ~(size_t)15) + (size_t)EXF_TW * 64 * sizeof(u64) + (size_t)EXF_TW * 64 * V * sizeof(u64);
+}
 template <int V>
 __global__ __launch_bounds__(64 * EXF_TW) void exf_refine_kernel(ExfRefineArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* qs = reinterpret_cast<float*>(smem);                                                     // [d]
   u64* stage = reinterpret_cast<u64*>(smem + (((size_t)a.d * 4 + 15) & ~(size_t)15));             // [EXF_TW][64]
+  u64* lists = stage + EXF_TW * 64;                                                               // [EXF_TW][64 * V]
   const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, d = a.d;
   for (int i = threadIdx.x; i < d; i += 64 * EXF_TW) qs[i] = a.queries[(size_t)q * d + i];
   __syncthreads();
@@ -382,16 +412,40 @@ __global__ __launch_bounds__(64 * EXF_TW) void exf_refine_kernel(ExfRefineArgs a
     sel.push(sim_key(acc, c.x), v);
   }
   sel.finish();
-  u64* out = a.part + ((size_t)q * EXF_TW + wave) * a.L;
 #pragma unroll
-  for (int v = 0; v < V; ++v) {
-    const int r = v * 64 + lane;
-    if (r < a.L) out[r] = sel.acc[v];
-  }
+  for (int v = 0; v < V; ++v) lists[(size_t)wave * 64 * V + v * 64 + lane] = sel.acc[v];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) viol += __shfl_xor(viol, o, 64);
   if (lane == 0 && viol) atomicAdd(a.viol + 0, viol);
   if (a.count_checked && threadIdx.x == 0) atomicAdd(a.viol + 1, cnt);
+  __syncthreads();
+  if (wave != 0) return;
+  for (int w = 1; w < EXF_TW; ++w)
+    for (int v = 0; v < V; ++v) {
+      const u64 key = lists[(size_t)w * 64 * V + v * 64 + lane];
+      if (__ballot(key != KEY_INF) == 0ull) break;   // ascending: the rest of this list is empty too
+      wave_topk_absorb_sorted<V>(sel.acc, key);
+    }
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int r = v * 64 + lane;
+    if (r < a.k) {
+      const u64 key = sel.acc[v];
+      a.out_ids[(size_t)q * a.k + r] = (key == KEY_INF) ? -1 : a.ids[key_pos(key)];
+      a.out_sim[(size_t)q * a.k + r] = (key == KEY_INF) ? -__builtin_huge_valf() : key_sim(key);
+    }
+  }
+  // the call's last workgroup hands the verdict over (every workgroup's overflow flag is in memory before its ticket)
+  __threadfence();
+  int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(a.arrived, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket == a.total_wgs - 1 && lane == 0) {
+    a.flags_out[0] = __hip_atomic_load(a.viol + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.flags_out[1] = __hip_atomic_load(a.qbad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.viol[3] = 0; *a.qbad = 0;
+    __hip_atomic_store(a.arrived, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace freddy

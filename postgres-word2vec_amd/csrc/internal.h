@@ -217,6 +217,7 @@ struct freddy_gpu_index {
   float* xb = nullptr;
   // exact kNN as filter + refine (exact2.h): the table's statistics (pin time / append) and the per-call buffers
   bool exf_ok = false;          // every element finite, d % 4 == 0, d <= 512
+  bool exf_dirty = true;        // no filter + refine call has completed yet, or the last one failed part-way: its device-side words are cleared before the next
   float exf_xnorm = 0.0f;       // largest row norm, rounded up
   int exf_ex = 0;               // power-of-two scale of the rows for the f16 split
   DevBuf exf_qfrag, exf_small, exf_sample, exf_cand;
