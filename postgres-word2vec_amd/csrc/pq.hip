@@ -83,6 +83,7 @@ struct PqFrontArgs {
   float* qn; float* qscale; uint32_t* qc; int m, K;
   float sentinel;
   int32_t* item_cell; int32_t* item_query; float* item_dist; int32_t* round_rows; int32_t* records; int32_t* n_groups;
+  ZeroArgs z;   // the call's scratch that must start at zero (counters, running bounds, survivor counts): no memset launches in front
 };
 __device__ __forceinline__ void pq_records_body(const PqFrontArgs& a, int q, unsigned char* smem) {
   const float* __restrict__ queries = a.queries;
@@ -166,6 +167,12 @@ __global__ __launch_bounds__(256) void pq_front_kernel(PqFrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int n_table = a.m * ((a.Q + 15) / 16);
   const int b = blockIdx.x;
+  {
+    const int gtid = b * 256 + (int)threadIdx.x, gsz = (int)gridDim.x * 256;
+#pragma unroll
+    for (int r = 0; r < 5; ++r)
+      for (int i = gtid; i < a.z.n[r]; i += gsz) a.z.p[r][i] = 0u;
+  }
   if (b < n_table) query_codebook5_body<25, 16>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, b % a.m, b / a.m, smem);
   else pq_records_body(a, b - n_table, smem);
 }
@@ -257,9 +264,6 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
       ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d over %d pseudo-lists)", Q, lists);
   r.next = ws->w_act0.as<int32_t>();
-  HIP_TRY(hipMemsetAsync(ws->w_cnt.p, 0, sizeof(int32_t) * 8, s));
-  HIP_TRY(hipMemsetAsync(ws->w_cand.as<int32_t>() + Q, 0, sizeof(int32_t) * Q, s));   // the queries' running bounds (FilterArgs::tau_run)
-  HIP_TRY(hipMemsetAsync(ws->w_surv_cnt.p, 0, sizeof(int32_t) * items * r.upi * FUSED_NW, s));
   PlanArgs pa;
   memset(&pa, 0, sizeof(pa));
   pa.item_cell = ws->w_item_cell.as<int32_t>(); pa.item_query = ws->w_item_query.as<int32_t>(); pa.item_dist = ws->w_item_dist.as<float>();
@@ -275,6 +279,12 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
   fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
   fa.item_dist = pa.item_dist; fa.round_rows = pa.round_rows; fa.records = ws->w_records.as<int32_t>(); fa.n_groups = wt.n_groups;
+  // (w_cnt[1] = n_groups is WRITTEN by this launch's record workgroups: not among the words it clears)
+  fa.z.p[0] = ws->w_cnt.as<uint32_t>(); fa.z.n[0] = 1;
+  fa.z.p[1] = ws->w_cnt.as<uint32_t>() + 2; fa.z.n[1] = 6;
+  fa.z.p[2] = ws->w_cand.as<uint32_t>() + Q; fa.z.n[2] = Q;   // the queries' running bounds (FilterArgs::tau_run)
+  fa.z.p[3] = ws->w_surv_cnt.as<uint32_t>(); fa.z.n[3] = (int)(items * r.upi * FUSED_NW);
+  fa.z.p[4] = nullptr; fa.z.n[4] = 0;
   const size_t front_lds = std::max<size_t>((size_t)query_codebook5_lds<25, 16>(), (size_t)(1024 + 16 + 2) * sizeof(float));
   timed_launch(fx, s, "pq_front", [&] {
     hipLaunchKernelGGL(pq_front_kernel, dim3((unsigned)(m * ((Q + 15) / 16) + Q)), dim3(256), front_lds, s, fa);
