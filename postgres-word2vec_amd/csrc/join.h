@@ -923,6 +923,12 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
   auto now = [] { return std::chrono::steady_clock::now(); };
   const auto t_start = now();
   auto t_last = t_start;
+#ifdef FREDDY_LAB
+  static const bool jtrace = getenv("FREDDY_GPU_JOIN_TRACE") != nullptr;   // host timeline of a call on stderr (lab builds; tools/lab/join_trace_host.py)
+  auto mark = [&](const char* what) { if (jtrace) fprintf(stderr, "[join] %7.1f us  %s\n", std::chrono::duration<double, std::micro>(now() - t_start).count(), what); };
+#else
+  auto mark = [](const char*) {};
+#endif
   auto track = [&](double freddy_track::*stage) {
     const auto t = now();
     j->track.*stage += std::chrono::duration<double>(t - t_last).count();
@@ -996,6 +1002,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     JOIN_HIP(hipGetLastError());
     j->tl_n = n_targets; j->tl_cells = cells;   // (valid once the offsets have arrived: first synchronisation below)
   }
+  mark("target array enqueued");
   track(&freddy_track::data_retrieval_time);   // "fq.id IN (targets)" (enqueue only: the device work overlaps what follows)
   // a query buffer that is pinned already (freddy_gpu_host_alloc: what pg/freddy_gpu_glue.c's query_buffer() hands over) is read
   // where it is -- the 6 MB staging copy of 5 000 queries is the longest host step of a call
@@ -1035,6 +1042,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       hipLaunchKernelGGL(sub_dist_kernel, dim3((unsigned)Q, 2), dim3(64), 0, s, (const float*)d_q, j->coarseT, (float*)d_sub, d, Kc, (float*)nullptr, 0);
     JOIN_HIP(hipGetLastError());
   }
+  mark("queries staged, sub-distances enqueued");
   const int SV = join_pick_V(Kc);
   if (SV == 0) return join_fail(FREDDY_E_LIMIT, "coarse_codes=%d exceeds this build's limit of 1024", Kc);
   // The multi-index traversal runs on the device for <= 1024 cells (join_traverse_kernel; the host's libm checks every
@@ -1191,7 +1199,9 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
       hipLaunchKernelGGL(join_copy_kernel, dim3((unsigned)((n_active + 255) / 256)), dim3(256), 0, s, (const uint32_t*)p_active, (uint32_t*)d_active, (size_t)n_active);
       if (!spec_valid) {
         if (int rc = launch_traverse(n_active, min_target)) return rc;
+        mark("traversal enqueued");
         JOIN_HIP(hipStreamSynchronize(s));
+        mark("traversal synchronised");
         for (int x = 0; x < n_active; ++x) spec_index[(size_t)active[x]] = x;
       }
       spec_valid = false;
@@ -1233,6 +1243,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
         }
       }
       for (int q : active) if (q_host[q]) fb.push_back(q);
+      mark("summaries checked");
     } else {
       fb = active;
     }
@@ -1286,6 +1297,7 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     }
     const int n_dev = (int)scan.size(), n_fb = (int)scan_fb.size(), n_scan = n_dev + n_fb;
     scan.insert(scan.end(), scan_fb.begin(), scan_fb.end());
+    mark("scan list built");
     track(&freddy_track::query_construction_time);
     if (n_scan > 0) {
       memcpy(h_scan, scan.data(), sizeof(int32_t) * (size_t)n_scan);
@@ -1335,13 +1347,16 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
         for (int x = 0; x < n_active; ++x) spec_index[(size_t)active[x]] = x;
         spec_valid = true;
       }
+      mark("join (+ next traversal) enqueued");
       JOIN_HIP(hipStreamSynchronize(s));
+      mark("join synchronised");
       { float ms = 0.0f; if (hipEventElapsedTime(&ms, j->ev0, j->ev1) == hipSuccess) j->track.join_kernel_time += 1e-3 * ms; }
       for (int x = 0; x < n_scan; ++x) {
         memcpy(out_ids + (size_t)scan[x] * k, h_oi_p + (size_t)x * k, sizeof(int32_t) * k);
         memcpy(out_dist + (size_t)scan[x] * k, h_od_p + (size_t)x * k, sizeof(float) * k);
       }
     }
+    mark("lists copied out");
     track(&freddy_track::computation_time);   // LUTs, ADC / exact distances, post verification: one kernel
     if (!last) {                                                                            // :639-669
       std::vector<int32_t> next;
