@@ -587,6 +587,8 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             try:
                 if a.no_host_abi:
                     raise RuntimeError("skipped (--no-host-abi)")
+                if world > 1:   # (a side measurement of ONE backend's call: reported at N = 1, like the CPU baseline; the other ranks would wait for it)
+                    raise RuntimeError("skipped (reported at --gpus 1 only)")
                 cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 host_abi = json.loads(cp.stdout.strip().splitlines()[-1])
             except Exception as e:   # the headline line must not be lost to a side measurement
