@@ -1,3 +1,4 @@
+# GPU-box helper: the library in the tree against postgres-word2vec_amd/libfreddy_gpu_prev.so (a build of the commit before) on the 40 M-row corpus, alternating in one call
 for r in 1 2; do for v in new prev; do if [ $v = prev ]; then export FREDDY_GPU_SO=$PWD/postgres-word2vec_amd/libfreddy_gpu_prev.so; else unset FREDDY_GPU_SO; fi
 timeout 600 python bench.py --steps 20 --warmup 4 --N 40000000 --C 13000 --cpu-sample 0 --no-recall --no-host-abi > /tmp/n.out 2>/dev/null
 python - "$v" <<'P'
