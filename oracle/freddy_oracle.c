@@ -949,8 +949,17 @@ float fo_text_roundtrip(float v) {                      /* sprintf("%f") -> '{..
 
 /* updateCodebook + updateCodebookRelation.  codebook [m][K][s] and counts [m*K] are updated in place (what the
  * table holds afterwards); codes [n][m] = nearestCentroids; count_incs [m*K]. */
+/* `order` (NULL: position-major, code-minor): order[j] = pos * K + code of the j-th tuple the SPI scan returns -- the order
+ * decides which entry wins a tie and which vector `nearestCentroidRaw` ends up pointing at (:928-939), and insert_batch's own
+ * UPDATEs move codebook tuples, so from the second call on the heap order is no longer the export's. */
+int fo_update_codebook_ordered(float* codebook, int32_t* counts, int m, int K, int s, const float* vecs, int n,
+                               int16_t* codes, int32_t* count_incs, const int32_t* order);
 int fo_update_codebook(float* codebook, int32_t* counts, int m, int K, int s, const float* vecs, int n,
                        int16_t* codes, int32_t* count_incs) {
+  return fo_update_codebook_ordered(codebook, counts, m, K, s, vecs, n, codes, count_incs, NULL);
+}
+int fo_update_codebook_ordered(float* codebook, int32_t* counts, int m, int K, int s, const float* vecs, int n,
+                               int16_t* codes, int32_t* count_incs, const int32_t* order) {
   const int d = m * s, E = m * K;
   float* differences = (float*)calloc((size_t)E * s, sizeof(float));        /* :913-921 */
   float* min_dist = (float*)xmalloc(sizeof(float) * (size_t)m);
@@ -964,7 +973,8 @@ int fo_update_codebook(float* codebook, int32_t* counts, int m, int K, int s, co
   for (int i = 0; i < n && !rc; ++i) {                                      /* :923 */
     const float* nearest_raw = NULL;
     for (int j = 0; j < m; ++j) { min_dist[j] = 100; nearest[j] = -1; }     /* :925-927 */
-    for (int j = 0; j < E; ++j) {                                           /* :928-939 */
+    for (int jj = 0; jj < E; ++jj) {                                         /* :928-939 */
+      const int j = order ? order[jj] : jj;                                 /* cb[jj] = the jj-th tuple; its slot */
       const int pos = j / K, code = j % K;
       const float dist = fo_sqdist(vecs + (size_t)i * d + (size_t)pos * s, work + (size_t)j * s, s);
       if (dist < min_dist[pos]) {

@@ -197,13 +197,16 @@ class Oracle:
         self.lib.fo_text_roundtrip.restype = C.c_float
         return np.array([self.lib.fo_text_roundtrip(C.c_float(float(v))) for v in a.ravel()], np.float32).reshape(a.shape)
 
-    def update_codebook(self, codebook, counts, vecs):
-        """-> (new codebook, new counts, codes[n, m], count_incs[m*K]); raises on the reference's undefined case."""
+    def update_codebook(self, codebook, counts, vecs, order=None):
+        """-> (new codebook, new counts, codes[n, m], count_incs[m*K]); raises on the reference's undefined case.
+        order: the slots (pos * K + code) in the order the codebook table's tuples are scanned (None: position-major)."""
         cb, cnt, v = _f32(codebook).copy(), _i32(counts).copy(), _f32(vecs)
         m, K, s_ = cb.shape
         codes = np.empty((v.shape[0], m), np.int16)
         incs = np.empty(m * K, np.int32)
-        rc = self.lib.fo_update_codebook(_p(cb), _p(cnt), m, K, s_, _p(v), v.shape[0], _p(codes), _p(incs))
+        od = None if order is None else _i32(order)
+        assert od is None or sorted(od.tolist()) == list(range(m * K))
+        rc = self.lib.fo_update_codebook_ordered(_p(cb), _p(cnt), m, K, s_, _p(v), v.shape[0], _p(codes), _p(incs), _p(od))
         if rc:
             raise ValueError(f"fo_update_codebook: {rc}")
         return cb, cnt, codes, incs

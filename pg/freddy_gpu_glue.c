@@ -409,10 +409,10 @@ static int32 last_id(const int32 *ids, int64 n, bool ascending)
 /* ---- the three handles ----------------------------------------------------------------------------- */
 freddy_gpu_index_t *freddy_glue_pq(void)
 {
-    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     char names[MAX_TABS][100];
     FreddyStamp now;
     bool appended, codebook;
+    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     getTableName(PQ_QUANTIZATION, names[0], 100);
     getTableName(CODEBOOK, names[1], 100);
     take_stamp(&now, 2, names);
@@ -447,11 +447,11 @@ freddy_gpu_index_t *freddy_glue_pq(void)
 
 freddy_gpu_index_t *freddy_glue_ivf(void)
 {
-    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     char names[MAX_TABS][100];
     FreddyStamp now;
     bool appended, codebook;
     static int pinned_C = 0;
+    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     getTableName(RESIDUAL_QUANTIZATION, names[0], 100);
     getTableName(RESIDUAL_CODEBOOK, names[1], 100);
     getTableName(COARSE_QUANTIZATION, names[2], 100);
@@ -506,11 +506,11 @@ freddy_gpu_index_t *freddy_glue_ivf(void)
 
 freddy_gpu_index_t *freddy_glue_ivpq(void)
 {
-    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     char names[MAX_TABS][100];
     FreddyStamp now;
     bool appended, codebook;
     static int pinned_cells = 0;
+    ensure_exit_hook();   /* the ABI check and the transaction callbacks BEFORE the first library call of this backend */
     getTableName(IVPQ_QUANTIZATION, names[0], 100);
     getTableName(IVPQ_CODEBOOK, names[1], 100);
     getTableName(COARSE_QUANTIZATION_MULTI, names[2], 100);

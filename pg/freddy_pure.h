@@ -137,8 +137,14 @@ typedef struct FreddyCbEntry { int pos; int code; float *vector; int count; } Fr
  * new row r at position p).  Flat working arrays, three passes:
  *   1. slot (p, c) = p*K + c.  Every new row adds ONE vector to the bucket of each of its m slots and bumps the slot's
  *      increment.  Documented behaviour of the reference kept on purpose (the rows written must equal its rows): the
- *      vector added is the same for all positions of a row -- the entry of the row's code at the LAST position (its
- *      1-NN loop keeps a single pointer across positions, and the tables are position-major).
+ *      vector added is the same for all positions of a row -- its 1-NN loop keeps a single pointer `nearestCentroidRaw`
+ *      across positions (index_utils.c:925-939), which ends up at the entry that improved some position's minimum LAST in
+ *      the order the entries are GIVEN (SPI order).  A position's last improvement is at its final nearest entry, so that
+ *      entry is the one with the largest array index among the row's m nearest entries.  (Position-major tables: the
+ *      nearest entry of the last position -- but insert_batch's own UPDATEs move codebook tuples, so the heap order is the
+ *      export's only until the first call.)  The device's 1-NN takes the lowest code where two entries of a position are
+ *      EQUALLY near (bit-equal distances); the reference takes the first in SPI order: the two differ only for such ties
+ *      in a table that is no longer position-major.
  *   2. an entry's count grows by its slot's increment.
  *   3. an entry's vector moves by bucket[pos + code] / count, the quotient formed as (1.0 / count) in double -- the
  *      bucket index is the SUM pos + code, not the slot (documented behaviour, kept).
@@ -149,13 +155,19 @@ static inline void freddy_update_codebook_known_codes(int n, int s, FreddyCbEntr
 {
     const size_t slots = (size_t) m * (size_t) K;
     float *bucket = (float *) FREDDY_ALLOC(sizeof(float) * slots * (size_t) s);
-    const float **vec_of_slot = (const float **) FREDDY_ALLOC(sizeof(float *) * slots);
+    size_t *entry_of_slot = (size_t *) FREDDY_ALLOC(sizeof(size_t) * slots);
     memset(bucket, 0, sizeof(float) * slots * (size_t) s);
     memset(incs, 0, sizeof(int) * slots);
-    for (size_t e = 0; e < slots; e++) vec_of_slot[(size_t) entries[e].pos * K + entries[e].code] = entries[e].vector;
+    for (size_t e = 0; e < slots; e++) entry_of_slot[(size_t) entries[e].pos * K + entries[e].code] = e;
     for (int r = 0; r < n; r++) {
         const int16_t *rc = codes + (size_t) r * m;
-        const float *added = vec_of_slot[(size_t) (m - 1) * K + rc[m - 1]];
+        size_t last = 0;
+        const float *added;
+        for (int p = 0; p < m; p++) {
+            const size_t e = entry_of_slot[(size_t) p * K + rc[p]];
+            if (e > last) last = e;
+        }
+        added = entries[last].vector;
         for (int p = 0; p < m; p++) {
             const size_t slot = (size_t) p * K + rc[p];
             float *b = bucket + slot * (size_t) s;
@@ -171,7 +183,7 @@ static inline void freddy_update_codebook_known_codes(int n, int s, FreddyCbEntr
         for (int t = 0; t < s; t++) en->vector[t] += (1.0 / en->count) * b[t];
     }
     FREDDY_FREE(bucket);
-    FREDDY_FREE((void *) vec_of_slot);
+    FREDDY_FREE((void *) entry_of_slot);
 }
 
 #endif /* FREDDY_PURE_H */

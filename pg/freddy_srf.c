@@ -129,8 +129,11 @@ Datum ivfadc_batch_search(PG_FUNCTION_ARGS)
         float *qs = NULL;
         int32 *found_ids = NULL;
         FreddyRows *r;
-        /* unchanged: the query vectors are the rows of the normalised table with id IN (...), in the order SPI
-         * returns them, duplicates collapsed, unknown ids dropped (freddy.c:767-804) */
+        /* the query vectors are the rows of the normalised table with id IN (...), duplicates collapsed, unknown ids dropped
+         * (freddy.c:767-804).  ONE deliberate difference: ORDER BY id is appended.  The reference emits the queries in the
+         * order SPI happens to return them (freddy.c:767-804, :986) -- a heap / index scan order that depends on the planner
+         * and on where UPDATEs have moved tuples; the SRF's rows carry the query id, so the SET of rows is the same and only
+         * the unspecified order of the result set is made canonical (ascending query id). */
         getTableName(NORMALIZED, vecName, 100);
         sql = palloc(200 + 12 * (n_qids > 0 ? n_qids : 1));
         cur = sql + sprintf(sql, "SELECT id, vector FROM %s WHERE id IN (", vecName);

@@ -314,7 +314,7 @@ int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int
                const float* coarse = nullptr, const int32_t* item_query = nullptr);
 int ivf_work_table(IvfRun& r, WorkTable& wt);
 int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt);
-int max_queries_per_chunk(const freddy_gpu_index* ix, int W);
+int max_queries_per_chunk(const freddy_gpu_index* ix, int W, int k);
 int one_buffer(Workspace* ws, hipStream_t s, uint64_t shape, size_t bytes, uint32_t* epoch);
 const void* pinned_device_pointer(const void* p);
 

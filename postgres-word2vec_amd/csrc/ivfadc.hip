@@ -88,7 +88,8 @@ int launch_merge(freddy_gpu_index* ix, hipStream_t s, const MergeArgs& a) {
 int bigk_select_replay(freddy_gpu_index* ix, hipStream_t s, Workspace* ws, ScanArgs sa, int n_items, const MergeArgs& ma, int Q) {
   if (ma.n_active <= 0) return 0;
   const int k = ma.k;
-  if (k > BIGK_KMAX || sa.L != BIGK_PASS) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of %d", k, BIGK_KMAX);
+  if (k > BIGK_KMAX) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of %d", k, BIGK_KMAX);
+  if (sa.L != BIGK_PASS) return fail(FREDDY_E_ARG, "selection passes are %d keys wide (got L=%d)", BIGK_PASS, sa.L);
   const int passes = (2 * k + BIGK_PASS - 1) / BIGK_PASS;
   const int nsel = passes * BIGK_PASS;
   int npad = 2048;
@@ -651,7 +652,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
     const size_t nchunk_big = (size_t)std::max(1, (ix->max_list_blocks + 255) / 256), nchunk_small = (size_t)std::max(1, (ix->max_list_blocks + 31) / 32);
     const size_t parts = std::max(items * nchunk_big, std::min<size_t>(items, 64) * nchunk_small);
     if (ws->w_resid.ensure(sizeof(float) * items * (size_t)ix->d) || ws->w_lut.ensure(sizeof(float) * items * (size_t)m * K) ||
-        ws->w_part.ensure(sizeof(u64) * parts * SCAN_WAVES * r.L))
+        ws->w_part.ensure(sizeof(u64) * parts * r.L))   // (adc_scan_kernel leaves ONE list of L keys per (item, chunk): kernels.h)
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   }
 
@@ -688,10 +689,17 @@ static int ivfadc_finish(IvfRun& r, int n_next) {
   return 0;
 }
 
-int max_queries_per_chunk(const freddy_gpu_index* ix, int W) {
+int max_queries_per_chunk(const freddy_gpu_index* ix, int W, int k) {
   // workspace per query: the LUTs of its W items (generic path) or their survivor regions (fused path)
   const size_t upi = (size_t)std::max(1, (ix->max_list_blocks + FUSED_UNIT_BLOCKS - 1) / FUSED_UNIT_BLOCKS);
-  const size_t lut_bytes = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
+  size_t lut_bytes = sizeof(float) * (size_t)ix->m * ix->K * (size_t)W;
+  if (2 * k > 64) {
+    // lists beyond the cell-grouped scans' selection width take the generic kernels: one list of L keys per (item, chunk) beside
+    // the LUTs, and from k = 513 on the passes' selected keys (bigk.h: ceil(2k / 1024) x 1024 per query)
+    const size_t L = (size_t)std::min(2 * k, 1024), nchunk = (size_t)std::max(1, (ix->max_list_blocks + 255) / 256);
+    lut_bytes += sizeof(u64) * (size_t)W * nchunk * L;
+    if (2 * k > 1024) lut_bytes += sizeof(u64) * (size_t)((2 * k + BIGK_PASS - 1) / BIGK_PASS) * BIGK_PASS;
+  }
   const bool special = ix->m == 12 && ix->S == 25 && ix->K <= 1024 && ix->cbP;
   const size_t surv_bytes = upi <= (special ? 8u : 32u) ? sizeof(u64) * (size_t)W * upi * FUSED_NW * FUSED_RMAX * 64 : 0;
   const size_t per_query = special ? std::max(lut_bytes, surv_bytes) : lut_bytes + surv_bytes;   // (multi.h: the LUTs of all items AND their survivor regions)
@@ -713,7 +721,7 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
   if (W > ix->C) W = ix->C;
   HIP_TRY(hipSetDevice(ix->device));
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ix->stream;
-  const int qc = max_queries_per_chunk(ix, W);
+  const int qc = max_queries_per_chunk(ix, W, k);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
@@ -768,7 +776,7 @@ static int ivfadc_sync_search(freddy_gpu_index* ix, const float* queries, int Q,
       ws->w_out_dist.ensure(sizeof(float) * (size_t)Q * k))
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * ix->d, hipMemcpyHostToDevice, s));
-  const int qc = max_queries_per_chunk(ix, W);
+  const int qc = max_queries_per_chunk(ix, W, k);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
@@ -967,7 +975,7 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
     if (int rc = ivf_one(ix, queries, k, W, sentinel, found_rule, out_ids, out_dist, &verdict)) return rc;
     if (verdict == 2) return FREDDY_OK;
   }
-  const int cap = std::max(1, std::min(max_queries_per_chunk(ix, W), ix->tune.pipeline_batch));
+  const int cap = std::max(1, std::min(max_queries_per_chunk(ix, W, k), ix->tune.pipeline_batch));
   const int n_sub = (Q + cap - 1) / cap;
   const int per = (Q + n_sub - 1) / n_sub;               // equal sub-batches rather than full ones and a remainder
   const int n_lanes = std::min(n_sub, std::min(ix->tune.pipeline_lanes, FREDDY_LANES));

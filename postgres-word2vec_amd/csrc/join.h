@@ -1012,6 +1012,9 @@ static inline int join_run(JoinIndex* j, hipStream_t s, const float* queries, in
     memset(&attr, 0, sizeof(attr));
     if (hipPointerGetAttributes(&attr, queries) == hipSuccess && attr.type == hipMemoryTypeHost) p_queries = static_cast<const float*>(attr.devicePointer);
     else (void)hipGetLastError();
+    // sub_dist_kernel reads with 16-byte loads: a VIEW into a pinned buffer at an odd offset goes through the staging copy (whose
+    // base hipHostMalloc aligns), and so does a buffer another device's context pinned (no device address here)
+    if (p_queries && (reinterpret_cast<uintptr_t>(p_queries) & 15u)) p_queries = nullptr;
   }
   const bool fused_front_p = (d & 1) == 0 && d / 2 <= 512;
   if (p_queries && fused_front_p) {

@@ -329,6 +329,16 @@ static int pq_one(freddy_gpu_index* ix, hipStream_t s, const float* h_q, int k, 
   return 0;
 }
 
+// Queries per chunk of the generic scan over `n_blocks` row blocks: a LUT per query, one list of L keys per (query, 4096-row
+// chunk) -- the finest chunks pq_chunk may choose -- and, from k = 513 on, the keys the selection passes keep (bigk.h).
+static int pq_queries_per_chunk(const freddy_gpu_index* ix, int64_t n_blocks, int k) {
+  const size_t L = (size_t)std::min(2 * k, 1024), nchunk = (size_t)std::max<int64_t>(1, (n_blocks + 63) / 64);
+  size_t per_query = sizeof(float) * (size_t)ix->m * ix->K + sizeof(u64) * nchunk * L;
+  if (2 * k > 1024) per_query += sizeof(u64) * (size_t)((2 * k + 1024 - 1) / 1024) * 1024;
+  const size_t n = ((size_t)ix->tune.lut_budget_mb << 20) / per_query;
+  return (int)std::min<size_t>(std::max<size_t>(n, 1), (size_t)1 << 20);
+}
+
 static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q, int k, float sentinel,
                     const int32_t* blk_off, const uint32_t* packed, const int32_t* pos, int64_t n_blocks,
                     int32_t* d_out_ids, float* d_out_dist) {
@@ -342,7 +352,7 @@ static int pq_chunk(freddy_gpu_index* ix, hipStream_t s, const float* d_q, int Q
   while ((n_blocks + chunk_blocks - 1) / chunk_blocks * (int64_t)Q > 4096 && chunk_blocks < 8192) chunk_blocks *= 2;
   const int nchunk = (int)std::max<int64_t>(1, (n_blocks + chunk_blocks - 1) / chunk_blocks);
   if (ws->w_lut.ensure(sizeof(float) * (size_t)Q * lutN) ||
-      ws->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * SCAN_WAVES * L))
+      ws->w_part.ensure(sizeof(u64) * (size_t)Q * nchunk * L))   // (one list of L keys per (query, chunk): kernels.h adc_scan_kernel)
     return fail(FREDDY_E_NOMEM, "workspace allocation failed");
   if (int rc = launch_lut(ix, s, d_q, nullptr, ws->w_lut.as<float>(), Q)) return rc;
   ScanArgs sa;
@@ -378,7 +388,7 @@ extern "C" int freddy_gpu_pq_search_dev(freddy_gpu_index_t* ix, const float* d_q
     }
     return FREDDY_OK;
   }
-  const int qc = max_queries_per_chunk(ix, 1);
+  const int qc = pq_queries_per_chunk(ix, ix->n_blocks, k);
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     if (int rc = pq_chunk(ix, s, d_queries + (size_t)q0 * ix->d, n, k, sentinel, ix->blk_off, ix->packed, ix->pos,
@@ -478,7 +488,7 @@ extern "C" int freddy_gpu_pq_search(freddy_gpu_index_t* ix, const float* queries
     if (int rc = pq_view_refresh(ix, &ix->pq_sub_view, s, packed, pos, n_blocks, n_rows)) return rc;
     view = ix->pq_sub_view;
   }
-  const int qc = fused_path ? pq_fused_queries_per_chunk(ix, n_blocks) : max_queries_per_chunk(ix, 1);
+  const int qc = fused_path ? pq_fused_queries_per_chunk(ix, n_blocks) : pq_queries_per_chunk(ix, n_blocks, k);
   if (!fused_path && direct && pq_one_shape(ix, Q, k, n_blocks)) {
     int32_t* err = reinterpret_cast<int32_t*>(static_cast<char*>(ix->hio_out) + n_out * 8);   // (the staging block's spare 16 bytes)
     *err = 0;

@@ -2,6 +2,7 @@
 tables.  Bar: bit-exact (id, rank) AND bit-exact binary32 distance for every ADC result
 (the ADC distance is an order-fixed fp32 sum, so there is no tolerance to grant)."""
 import functools
+import os
 
 import numpy as np
 import pytest
@@ -303,6 +304,22 @@ def test_k_beyond_512_ivfadc(gpu, oracle, k):
     idx.close()
 
 
+def test_k_4096_large_host_batch_is_chunked_not_refused(gpu, oracle):
+    """a host-buffer batch of a few thousand queries at k = 4096 used to size its chunks by the LUT bytes alone and
+    then fail with FREDDY_E_NOMEM on the partial-list / selected-key buffers (bigk.h).  max_queries_per_chunk counts them now:
+    with a 48 MB budget the 2100 queries go through in several chunks, lists equal to the oracle's."""
+    N, k, W = 20000, 4096, 2
+    t = util.ivf_tables(N=N, C=32, K=256)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx.set_option("lut_budget_mb", 48)
+    _, qs = util.queries_from_corpus(N, 2100, seed=17)
+    gi, gd = idx.search(qs, k, W, sentinel=1000.0, found_rule=0)
+    exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=1000.0, found_rule=0, n_threads=min(32, os.cpu_count() or 1))
+    util.assert_same_lists(gi, gd, exp, "k=4096, 2100 queries per host-buffer call")
+    idx.close()
+
+
 @pytest.mark.parametrize("k", [600, 2000])
 def test_k_beyond_512_pq(gpu, oracle, k):
     """pq_search and pq_search_in with k > 512 (freddy.c:66,89): equal distances at the k-th place, a subset smaller than k."""
@@ -357,6 +374,18 @@ def test_knn_join_matches_oracle(gpu, oracle, method, use_tl):
         exp, eit = oracle.ivpq_search_in(ot, qs, 5, tg, 10, 20, method, use_target_lists=use_tl, confidence=0.8)
         assert git == eit, (git, eit)
         util.assert_same_lists(gi, gd, exp, f"knn_join pinned queries method={method} tl={use_tl} targets={len(tg)}")
+    pb.close()
+    # a VIEW into a pinned buffer that starts one float in (4-byte aligned only): the kernel's 16-byte loads must not see it --
+    # the call stages it like pageable memory
+    pb = gpu.PinnedBuffer((qs.size + 1,))
+    view = pb.array[1:].reshape(qs.shape)
+    view[:] = qs
+    assert view.ctypes.data % 16 == 4
+    gi, gd, git = idx.knn_join(view, 5, targets, 10, 20, method, use_target_lists=use_tl, confidence=0.8)
+    exp, eit = oracle.ivpq_search_in(ot, qs, 5, targets, 10, 20, method, use_target_lists=use_tl, confidence=0.8)
+    assert git == eit, (git, eit)
+    util.assert_same_lists(gi, gd, exp, f"knn_join pinned view at an odd offset method={method} tl={use_tl}")
+    del view
     pb.close()
     idx.close()
 

@@ -147,13 +147,19 @@ def test_bytea_payload_codecs(drv):
 def test_codebook_bookkeeping_equals_the_oracles_update_codebook(drv, oracle, m, K, s, n):
     """pg/freddy_insert.c runs the 1-NN search on the device and then freddy_update_codebook_known_codes: given the codes
     the oracle's literal updateCodebook finds, the bookkeeping must leave the same counts and -- after the "%f" text round
-    trip updateCodebookRelation applies to the entries it writes -- the same vectors, whatever the table's row order."""
+    trip updateCodebookRelation applies to the entries it writes -- the same vectors.  The table's row order matters
+    (index_utils.c:925-939: ONE `nearestCentroidRaw` pointer, left at the entry that improved last in SPI order; insert_batch's
+    own UPDATEs move tuples): position-major and shuffled entries, each against the oracle scanning in that same order."""
     rng = np.random.default_rng(m * 1000 + K)
     cb = (rng.standard_normal((m, K, s)) * 0.2).astype(np.float32)
     counts = rng.integers(1, 50, m * K).astype(np.int32)
     vecs = (rng.standard_normal((n, m * s)) * 0.2).astype(np.float32)
-    exp_cb, exp_cnt, codes, incs = oracle.update_codebook(cb, counts, vecs)
-    for order in (np.arange(m * K), rng.permutation(m * K)):
+    base = oracle.update_codebook(cb, counts, vecs)
+    differs = False
+    for order in (np.arange(m * K), rng.permutation(m * K), rng.permutation(m * K)):
+        exp_cb, exp_cnt, codes, incs = oracle.update_codebook(cb, counts, vecs, order=order)
+        assert np.array_equal(codes, base[2])      # (no two entries equally near in these tables: the codes do not depend on the order)
+        differs = differs or not np.array_equal(exp_cb.view(np.uint32), base[0].view(np.uint32))
         work, cnt = cb.copy(), counts.copy()
         got_incs = np.zeros(m * K, np.int32)
         order = order.astype(np.int32)
@@ -168,3 +174,4 @@ def test_codebook_bookkeeping_equals_the_oracles_update_codebook(drv, oracle, m,
         new_cnt[written] = cnt[written]
         assert np.array_equal(new_cnt, exp_cnt)
         assert np.array_equal(cnt[~written], counts[~written])
+    assert differs or m == 1, "a shuffled table must change which vector a row adds (else this test does not see the order)"
