@@ -74,6 +74,7 @@ def parse(argv=None):
     ap.add_argument("--same-queries", action="store_true",
                     help="every in-flight stream searches the SAME query set (round 2's setup; the default gives each stream its own)")
     ap.add_argument("--no-host-abi", action="store_true", help="skip the host-buffer ABI measurement (a child process); profiling runs")
+    ap.add_argument("--no-collective-child", action="store_true", help="skip the one-rank collective side measurement (a child process)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="config ivfadc on one GPU also runs bounded passes of --config pq and --config join and reports them "
                          "under other_configs; this switches that off")
@@ -82,6 +83,15 @@ def parse(argv=None):
     ap.add_argument("--in-flight", type=int, default=4,
                     help="batches in flight per GPU (config ivfadc): consecutive steps alternate between this many HIP streams, "
                          "so the front end of batch i+1 runs beside the merge of batch i; 1 = strictly one batch at a time")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1 through the N > 1 code path: a ONE-rank process group of --backend, the asynchronous all_gather, option "
+                         "reserve_cus, RCCL's stream beside the searching streams (what rank 0 of an N-GPU run does, priced on one GPU)")
+    ap.add_argument("--gather-every", type=int, default=0,
+                    help="steps per all_gather of the per-shard top-k (0 = the batches in flight: one collective per group of in-flight "
+                         "batches, a ring of two groups; 1 = a collective per step)")
+    ap.add_argument("--collective-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--ab-rounds", type=int, default=2, help="--force-collective: rounds of (without, with) timed regions")
+    ap.add_argument("--reserve-cus", type=int, default=2, help="option reserve_cus of the collective path (CUs every persistent scan leaves free)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only with --dry-run)")
     ap.add_argument("--dry-run", action="store_true", help="CPU tensors + stand-in search: exercises the sharded step / gather only")
     return ap.parse_args(argv)
@@ -122,7 +132,7 @@ def sharded_steps(step_fn, pg, steps, warmup, sync, world):
     def barrier():
         pg.drain()
         sync()
-        if world > 1:
+        if world > 1 or (pg.collective and dist.is_initialized()):
             dist.barrier()
         sync()
 
@@ -146,7 +156,7 @@ def verify_gather(pg, rank, world):
     """The gathered buffer of the last step must hold every rank's own result: slot `rank` equals the local
     buffer, and every slot's checksum equals the checksum its owner reports."""
     import torch.distributed as dist
-    if world == 1:
+    if pg.gathered is None:
         return True
     local, gathered = pg.last()
     ok = bool(torch.equal(gathered[rank], local))
@@ -169,7 +179,8 @@ def run_dry(a, rank, world):
     q_local = Q if a.scaling == "weak" else shard.shard_bounds(Q, rank, world)[1] - shard.shard_bounds(Q, rank, world)[0]
     if a.scaling == "strong" and Q % world:
         raise SystemExit("--scaling strong needs --Q divisible by the number of ranks")
-    pg = shard.PipelinedGather(q_local, a.k, torch.device("cpu"))
+    G = max(1, a.gather_every)
+    pg = shard.PipelinedGather(q_local, a.k, torch.device("cpu"), depth=2 * G if G > 1 else 2, gather_every=G, force=a.force_collective)
     n = [0]
 
     def step():
@@ -180,7 +191,7 @@ def run_dry(a, rank, world):
 
     dt, _ = sharded_steps(step, pg, a.steps, a.warmup, lambda: None, world)
     ok = verify_gather(pg, rank, world)
-    if world > 1:   # every slot must hold ITS rank's pattern of the last step
+    if pg.gathered is not None:   # every slot must hold ITS rank's pattern of the last step
         _, gathered = pg.last()
         for r in range(world):
             exp = torch.empty_like(gathered[r])
@@ -191,10 +202,12 @@ def run_dry(a, rank, world):
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
            "scaling": a.scaling, "vs_baseline": None, "dtype": "none (dry run)", "data": "synthetic",
            "config": {"workload": "DRY RUN: stand-in search on CPU tensors, gloo", "batch_per_gpu": q_local,
-                      "parallelism": f"dp{world}", "world_size": (dist.get_world_size() if world > 1 else 1),
-                      "backend": (dist.get_backend() if world > 1 else "none (single rank)")},
+                      "parallelism": f"dp{world}", "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
+                      "backend": (dist.get_backend() if dist.is_initialized() else "none (single rank)")},
            "dry_run": True, "gather_verified": ok, "roofline": None, "cpu_baseline": None}
-    if world > 1:
+    out["config"]["gather_every"] = pg.G
+    out["config"]["collective"] = bool(pg.collective)
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -252,9 +265,10 @@ def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
 # ---------------------------------------------------------------------------------------------------
 HEADLINE_MAX_BYTES = 1900
 DIGEST_MAX_BYTES = 5000
-_CONFIG_KEYS = ("workload", "N", "d", "C", "m", "K", "nprobe", "k", "Q", "targets", "batch", "batch_per_gpu", "parallelism", "world_size",
-                "backend", "batches_in_flight", "recall_at_5")
-_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us",
+_CONFIG_KEYS = ("gather_every", "collective", "workload", "N", "d", "C", "m", "K", "nprobe", "k", "Q", "targets", "batch", "batch_per_gpu", "parallelism", "world_size",
+                "backend", "batches_in_flight", "recall_at_5", "recall_at_5_without_self", "host_abi_q1024_qps", "host_abi_q4096_qps",
+                "collective_1rank_ratio")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_us",
               "survey_8d_step_frac", "serial_ms_per_step", "host_abi_q1024_qps")
 _CPU_KEYS = ("value", "unit", "cores", "value_1_core", "kind", "sample", "parity_with_gpu_on_sample", "queries_checked")
 
@@ -277,6 +291,9 @@ def headline(out):
         line["roofline"] = None
     else:
         r = {k: roof.get(k) for k in _ROOF_KEYS if k in roof}
+        # where `traffic` comes from, in a word: the PMC passes are separate rocprofv3 runs of this command (committed under
+        # profiles/), never counters of THIS process; null traffic = no pass on this workload shape
+        r["traffic_source"] = "committed_pmc_passes:profiles/latest_pmc*.json" if roof.get("traffic") else None
         step = roof.get("step") or {}
         if "serial_ms_per_step" in step:
             r["serial_ms_per_step"] = step["serial_ms_per_step"]
@@ -353,7 +370,7 @@ def _digest_errors(o, out, path=""):
 
 
 def digest(out):
-    d = {"bench_digest": {k: _numbers_only(out[k]) for k in ("pipelining", "host_buffer_abi", "other_configs", "timed_region_parity")
+    d = {"bench_digest": {k: _numbers_only(out[k]) for k in ("pipelining", "host_buffer_abi", "collective_1rank", "other_configs", "timed_region_parity")
                           if isinstance(out.get(k), dict)}}
     errs = _digest_errors({k: out.get(k) for k in ("host_buffer_abi", "other_configs", "collective_1rank", "backends")}, {})
     if errs:
@@ -368,7 +385,7 @@ def digest(out):
     return d if len(json.dumps(d)) <= DIGEST_MAX_BYTES else None
 
 
-def emit(out):
+def emit(out, details_name="bench_details.json"):
     """Details into bench_details.json (once), a digest line, then the headline as the LAST stdout line."""
     if not isinstance(out, dict):
         print(json.dumps(out), flush=True)
@@ -378,7 +395,7 @@ def emit(out):
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
         if os.path.isdir(d):
             try:
-                with open(os.path.join(d, "bench_details.json"), "w") as f:
+                with open(os.path.join(d, details_name), "w") as f:
                     f.write(blob + "\n")
             except OSError as e:
                 print(f"[bench] could not write {d}/bench_details.json: {e}", file=sys.stderr)
@@ -503,46 +520,52 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         _skipped = [torch.cuda.Stream(dev) for _ in range(a.stream_skip)]   # (tools/sweep_queues.sh: shifts the streams' hardware queues)
         _BENCH_STREAMS[key] = (_skipped, [torch.cuda.Stream(dev) for _ in range(n_fl)])
     streams = _BENCH_STREAMS[key][1]
+    # the N > 1 path: every rank's lists are gathered (RCCL all_gather) -- one collective per GROUP of `gather_every` steps (default:
+    # the batches in flight), a ring of two groups; --force-collective takes this path with a single rank
+    collective = world > 1 or bool(a.force_collective)
+    G = (a.gather_every or n_fl) if collective else 1
+    depth = 2 * G if (collective and G > 1) else max(2, n_fl)
     with torch.cuda.stream(streams[0]):
-        pg = shard.PipelinedGather(q_local, a.k, dev, depth=max(2, n_fl))
+        pg = shard.PipelinedGather(q_local, a.k, dev, depth=depth, force=collective, gather_every=G)
     torch.cuda.synchronize(dev)
     counter = [0]
-    depth = max(2, n_fl)
     # world == 1: there is no collective to order, so a step is nothing but the C call -- one pre-bound ctypes call per
     # (stream, result buffer) pair (tools/burst_trace.py: torch's stream context + the gather bookkeeping cost 4 us of host
     # time per step, and the chains of a 20-step burst start that much later one after the other).  Steps and buffers both
     # advance round-robin: step c runs on stream c % n_fl and writes buffer c % depth (== the stream's own buffer: depth = n_fl).
-    bound = {}
+    def step_on(n_streams, pg=pg, collective=collective):
+        bound = {}
+        depth = pg.depth
 
-    def step_on(n_streams):
         def step():
             c = counter[0]
             i = c % n_streams
             st = streams[i]
             counter[0] = c + 1
-            if world == 1:
+            if not collective:
                 b = c % depth
                 pg.steps, pg.cur = c + 1, b
-                fn = bound.get((i, b))
-                if fn is None:
-                    res = pg.res[b]
-                    fn = bound[(i, b)] = index.bind_search_dev(d_qs[i].data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS,
-                                                               res[0].data_ptr(), res[1].data_ptr(), d_status.data_ptr(), st.cuda_stream)
-                fn()
-                return
-            with torch.cuda.stream(st):
-                res = pg.next_buffer()
-                index.search_dev(d_qs[i].data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(),
-                                 res[1].data_ptr(), d_status.data_ptr(), st.cuda_stream)
-                pg.submit()
+            else:
+                # the gather's bookkeeping on THIS step's stream: wait for the gather that last read the buffer (two groups
+                # back), and -- after the search -- an event, or for the group's last step the all_gather itself
+                pg.next_buffer(st)
+                b = pg.cur
+            fn = bound.get((i, b))
+            if fn is None:
+                res = pg.res[b]
+                fn = bound[(i, b)] = index.bind_search_dev(d_qs[i].data_ptr(), q_local, a.k, a.nprobe, 1000.0, gpu.FOUND_ROWS,
+                                                           res[0].data_ptr(), res[1].data_ptr(), d_status.data_ptr(), st.cuda_stream)
+            fn()
+            if collective:
+                pg.submit(st)
         return step
 
     if True:
         sync = lambda: torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             # an RCCL kernel must never queue behind 4 x 64 persistent scan workgroups that hold every CU: each scan leaves
-            # CUs free (untested on hardware: no multi-GPU node was available to the builder)
-            index.set_option("reserve_cus", 2)
+            # CUs free (measured with a one-rank group on one GPU: other_configs.collective_1rank, profiles/r06_collective_1rank.txt)
+            index.set_option("reserve_cus", a.reserve_cus)
         # ---- the side measurements FIRST: the same steps strictly one after the other, and the per-kernel durations (HIP
         # events on the launch stream; instrumented re-runs).  They are this very workload, so the timed region below starts
         # on a chip in its steady state: after an idle period (pinning the index is host work) the first ~10 ms of bursts
@@ -580,8 +603,32 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         timed_results = []
         for back in range(min(n_fl, a.steps)):
             sidx = total_steps - 1 - back
-            timed_results.append((sidx % n_fl, pg.res[sidx % depth].clone()))
+            timed_results.append((sidx % n_fl, pg.res[sidx % depth].clone()))   # (depth is a multiple of n_fl or equal to it)
         straggler = int(d_status[0].item())
+        # ---- --force-collective on one rank: the SAME process, streams and steps without the collective, alternating with the
+        # collective path (what the gather, its stream and the reserved CUs cost rank 0 of an N-GPU run)
+        coll_ab = None
+        if a.force_collective and world == 1:
+            with torch.cuda.stream(streams[0]):
+                pg0 = shard.PipelinedGather(q_local, a.k, dev, depth=max(2, n_fl))
+            plain = step_on(n_fl, pg0, False)
+            rounds = []
+            for _ in range(max(1, a.ab_rounds)):
+                row = {}
+                for name, fn, pgx, rc in (("without", plain, pg0, 0), ("with", step, pg, a.reserve_cus)):
+                    index.set_option("reserve_cus", rc)
+                    counter[0] = 0
+                    pgx.steps = 0
+                    dtx, _ = sharded_steps(fn, pgx, a.steps, a.warmup, sync, world)
+                    row[name] = round(q_local * a.steps / dtx, 1)
+                rounds.append(row)
+            index.set_option("reserve_cus", a.reserve_cus)
+            w = float(np.mean([r["with"] for r in rounds])); wo = float(np.mean([r["without"] for r in rounds]))
+            coll_ab = {"with_collective_qps": round(w, 1), "without_qps": round(wo, 1), "ratio": round(w / wo, 4), "rounds": rounds,
+                       "gather_every": G, "reserve_cus": a.reserve_cus, "backend": a.backend, "steps": a.steps,
+                       "gather_verified": gather_ok,
+                       "note": "one process, the same four streams: steps through the world > 1 branch (1-rank process group, asynchronous "
+                               "all_gather_into_tensor per group of gather_every steps, option reserve_cus) against the plain --gpus 1 steps"}
         index.set_option("scan_share", 1)
     scanned_rows = index.last_scanned_rows()
     n_cells, cell_rows = index.last_probed_cells()
@@ -695,12 +742,21 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             truth, exact_info = exact_truth(x, d_qs, a.k, dev_index)
             rec = [ib.recall_at_k(r[0].cpu().numpy(), truth[i]) for i, r in timed_results]
             recall = float(np.mean(rec))
+            # ... and over the OTHER k - 1 neighbours: a query is an indexed row, so its own id leads the exact list
+            def _without_self(res_ids, exact_ids, self_ids):
+                hits = n = 0
+                for a, e, me in zip(res_ids, exact_ids, self_ids):
+                    es = set(int(v) for v in e) - {int(me)}
+                    hits += len((set(int(v) for v in a if v >= 0) - {int(me)}) & es)
+                    n += len(es)
+                return hits / float(max(n, 1))
+            recall_wo = float(np.mean([_without_self(r[0].cpu().numpy(), truth[i], qids[i]) for i, r in timed_results]))
             i0, r0 = timed_results[0]
             rec_torch = ib.recall_at_k(r0[0].cpu().numpy(), ib.exact_topk(x, d_qs[i0], a.k))
             recall_info = {"ground_truth": "freddy_gpu_exact_search (exact.h) over the 3 M raw vectors, k = 5, every query of the timed region's batches",
                            "cross_check_torch_matmul_one_batch": {"recall_exact_kernel": round(ib.recall_at_k(r0[0].cpu().numpy(), truth[i0]), 5),
                                                                   "recall_torch": round(rec_torch, 5)},
-                           "includes_self_match": True,
+                           "includes_self_match": True, "recall_at_5_without_self": round(recall_wo, 4),
                            "note": "queries are indexed rows (ivfadc_batch_search takes ids, freddy.c:679-999): rank 1 of the exact list is "
                                    "the query itself, so 0.2 of the value is the self-match (found whenever the query's own cell is probed)"}
             other_exact = exact_info
@@ -772,9 +828,13 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                        "N": N, "d": 300, "C": a.C, "m": a.m, "K": a.K, "nprobe": a.nprobe, "k": a.k,
                        "batch_per_gpu": q_local, "parallelism": f"dp{world}",
                        "batches_in_flight": n_fl, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "world_size": (dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1),
-                       "backend": (("rccl (torch.distributed nccl)" if a.backend == "nccl" else a.backend) if world > 1 else "none (single GPU)"),
+                       "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
+                       "backend": (("rccl (torch.distributed nccl)" if a.backend == "nccl" else a.backend) if collective else "none (single GPU)"),
+                       "gather_every": (G if collective else None),
                        "recall_at_5": None if recall is None else round(recall, 4),
+                       "recall_at_5_without_self": None if recall_info is None else recall_info["recall_at_5_without_self"],
+                       "host_abi_q1024_qps": (abi_brief.get("Q1024") or {}).get("queries_per_s"),
+                       "host_abi_q4096_qps": (abi_brief.get("Q4096") or {}).get("queries_per_s"),
                        "recall": recall_info,
                        "queries_needing_extra_round": straggler,
                        "measurement_order": "serial and instrumented passes of the same steps first, then W warmup steps, barrier, the K timed steps, "
@@ -792,6 +852,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                                    "scan_share workgroups so the scans run side by side); serial_* = the same steps strictly one "
                                    "after the other (scan_share = 1: the scan takes every CU)"},
             "timed_region_parity": timed_parity,
+            "collective_1rank": coll_ab,
             "host_buffer_abi": dict(host_abi, queries_per_s=host_qps, same_results_as_device_path=host_same,
                                     note="freddy_gpu_ivfadc_search, the call the PostgreSQL hosts make (pageable host buffers in and "
                                          "out, synchronous): sub-batches of up to 2048 queries on up to four library-owned lanes with pinned "
@@ -1113,7 +1174,9 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if a.dry_run:
-        if world > 1:
+        if world > 1 or a.force_collective:
+            if world == 1 and "RANK" not in os.environ:
+                os.environ["MASTER_PORT"] = str(_free_port())
             dist.init_process_group("gloo", rank=rank, world_size=world)   # CPU tensors: always gloo
         sys.exit(run_dry(a, rank, world))
     if not torch.cuda.is_available():
@@ -1122,9 +1185,11 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in single-GPU dry runs
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if world > 1 or a.force_collective:
         if a.config != "ivfadc":
             raise SystemExit("--config pq / join / exact are single-GPU measurements")
+        if world == 1 and "RANK" not in os.environ:   # --force-collective started by hand: a one-rank group of this process
+            os.environ["MASTER_PORT"] = str(_free_port())
         if a.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -1160,17 +1225,32 @@ def main():
             if out is not None and out.get("_exact") is not None:
                 other["exact"] = out.pop("_exact")
             out["other_configs"] = other
+            # the N > 1 code path on this one GPU (a child process with a one-rank RCCL group: the asynchronous all_gather,
+            # RCCL's stream beside the four searching streams, option reserve_cus), with and without the collective in ONE process
+            if not a.force_collective and not a.no_collective_child and a.in_flight > 1:
+                try:
+                    torch.cuda.empty_cache()
+                    cmd = [sys.executable, os.path.abspath(__file__), "--force-collective", "--no-other-configs", "--no-host-abi", "--no-recall",
+                           "--cpu-sample", "0", "--steps", str(max(a.steps, 100)), "--warmup", str(a.warmup), "--in-flight", str(a.in_flight),
+                           "--backend", a.backend]
+                    cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
+                                        env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
+                    det = json.load(open(os.path.join(ROOT, "bench_details_collective.json")))
+                    out["collective_1rank"] = det["collective_1rank"]
+                    out["config"]["collective_1rank_ratio"] = det["collective_1rank"]["ratio"]
+                except Exception as e:
+                    out["collective_1rank"] = {"error": f"{type(e).__name__}: {e}"}
     elif a.config == "pq":
         out = run_pq(a, rank, world, dev, dev_index)
     elif a.config == "exact":
         out = run_exact(a, rank, world, dev, dev_index)
     else:
         out = run_join(a, rank, world, dev, dev_index)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        emit(out)
+        emit(out, "bench_details_collective.json" if (a.force_collective and world == 1) else "bench_details.json")
 
 
 if __name__ == "__main__":

@@ -52,50 +52,102 @@ def sharded_search(search_fn, queries, k, group=None):
 
 
 class PipelinedGather:
-    """Double-buffered, asynchronous gather of the per-shard top-k (what bench.py times).
+    """Pipelined, asynchronous gather of the per-shard top-k (what bench.py times).
 
     ids and distances of a shard live in ONE [2][q_local][k] int32 buffer (row 0 = ids, row 1 = the
     distances' bits), so a step's results cross xGMI in a single all_gather (40 KB per rank at Q=1024, k=5:
     pure latency).  `depth` such buffers alternate: the gather of step i only has to be finished before its
-    buffers are reused by step i+depth, so its latency hides under the next step's kernels.
+    buffer is reused by step i+depth, so its latency hides under the next steps' kernels.
 
-    Ordering contract: the search of a step must be enqueued on torch's CURRENT stream (pass its handle to
-    the C ABI) between next_buffer() and submit().  The collective is enqueued behind that stream's work,
-    and wait() makes the current stream wait for it before the buffer is written again."""
+    gather_every = G > 1: the buffers form a ring of depth / G GROUPS of G consecutive steps, and ONE all_gather
+    moves a whole group (fewer, larger collectives: with four batches in flight on four streams a collective per
+    step is a fifth active stream beside them all the time -- hardware queues, bench.py -- and costs the host a
+    collective call per 0.1 ms step).  The group's gather is enqueued behind the LAST of its steps after that
+    step's stream has been made to wait for the other steps' events; a group is rewritten depth steps later, so a
+    ring of two groups (depth = 2 G) leaves a whole group of slack.
 
-    def __init__(self, q_local, k, device, group=None, depth=2):
+    Ordering contract: the search of a step must be enqueued on the stream passed to next_buffer() / submit()
+    (torch's CURRENT stream when none is passed) between the two calls.  The collective is enqueued behind that
+    stream's work, and next_buffer() makes the stream wait for the gather that last read the buffer.
+
+    force: run the collective path with a single rank too (a 1-rank process group: bench.py --force-collective)."""
+
+    def __init__(self, q_local, k, device, group=None, depth=2, force=False, gather_every=1):
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.group, self.depth = group, depth
-        self.res = [torch.zeros((2, q_local, k), dtype=torch.int32, device=device) for _ in range(depth)]
-        self.gathered = ([torch.zeros((self.world, 2, q_local, k), dtype=torch.int32, device=device) for _ in range(depth)]
-                         if self.world > 1 else None)
-        self.pending = [None] * depth
+        self.collective = (self.world > 1 or force) and dist.is_initialized()
+        G = max(1, int(gather_every))
+        if depth % G:
+            raise ValueError("depth must be a multiple of gather_every")
+        self.group, self.depth, self.G = group, depth, G
+        self.cuda = torch.device(device).type == "cuda"
+        self.ring = torch.zeros((depth, 2, q_local, k), dtype=torch.int32, device=device)
+        self.res = [self.ring[b] for b in range(depth)]
+        self.n_groups = depth // G
+        self.gathered = ([torch.zeros((self.world, G, 2, q_local, k), dtype=torch.int32, device=device) for _ in range(self.n_groups)]
+                         if self.collective else None)
+        self.pending = [None] * self.n_groups
+        self.events = [torch.cuda.Event() for _ in range(depth)] if (self.cuda and G > 1) else None
         self.steps = 0
         self.cur = 0
+        self.unsent = 0      # steps of the current group whose gather has not been enqueued yet
 
-    def next_buffer(self):
-        """The [2][q_local][k] buffer of the coming step (its previous gather is waited for first)."""
+    def _ctx(self, stream):
+        import contextlib
+        return torch.cuda.stream(stream) if (stream is not None and self.cuda) else contextlib.nullcontext()
+
+    def next_buffer(self, stream=None):
+        """The [2][q_local][k] buffer of the coming step (the gather that last read it is waited for first)."""
         b = self.steps % self.depth
         self.steps += 1
-        if self.pending[b] is not None:
-            self.pending[b].wait()
-            self.pending[b] = None
+        g = b // self.G
+        if self.pending[g] is not None:
+            with self._ctx(stream):
+                self.pending[g].wait()          # (the given stream waits; the host does not unless the backend is gloo)
+            if b % self.G == self.G - 1:        # every stream that writes into the group has been told
+                self.pending[g] = None
         self.cur = b
         return self.res[b]
 
-    def submit(self):
-        """Start the gather of the buffer handed out last."""
-        if self.world > 1:
-            b = self.cur
-            self.pending[b] = dist.all_gather_into_tensor(self.gathered[b].view(-1), self.res[b].view(-1),
+    def _gather_group(self, g, stream, upto):
+        """all_gather of group g behind `stream`, which first waits for the group's other steps (events)."""
+        with self._ctx(stream):
+            if self.events is not None:
+                cs = torch.cuda.current_stream()
+                for j in range(upto):
+                    cs.wait_event(self.events[g * self.G + j])
+            lo = g * self.G
+            self.pending[g] = dist.all_gather_into_tensor(self.gathered[g].view(-1), self.ring[lo:lo + self.G].view(-1),
                                                           group=self.group, async_op=True)
+        self.unsent = 0
+
+    def submit(self, stream=None):
+        """The step that wrote the buffer handed out last is enqueued: start the gather it completes."""
+        if not self.collective:
+            return
+        b = self.cur
+        if self.G == 1:
+            with self._ctx(stream):
+                self.pending[b] = dist.all_gather_into_tensor(self.gathered[b].view(-1), self.res[b].view(-1),
+                                                              group=self.group, async_op=True)
+            return
+        self.unsent += 1
+        if b % self.G == self.G - 1:
+            self._gather_group(b // self.G, stream, self.G - 1)
+        elif self.events is not None:
+            self.events[b].record(stream if stream is not None else torch.cuda.current_stream())
 
     def drain(self):
-        for b in range(self.depth):
-            if self.pending[b] is not None:
-                self.pending[b].wait()
-                self.pending[b] = None
+        """Every gather enqueued and waited for (a group that is only partly written is gathered as it is)."""
+        if self.collective and self.G > 1 and self.unsent:
+            b = self.cur          # (not the last step of its group: every step written so far has recorded its event in submit())
+            self._gather_group(b // self.G, None, (b % self.G) + 1)
+        for g in range(self.n_groups):
+            if self.pending[g] is not None:
+                self.pending[g].wait()
+                self.pending[g] = None
 
     def last(self):
         """(local buffer, gathered [world][2][q_local][k] or None) of the most recent step; drain() first."""
-        return self.res[self.cur], (self.gathered[self.cur] if self.gathered is not None else None)
+        if self.gathered is None:
+            return self.res[self.cur], None
+        return self.res[self.cur], self.gathered[self.cur // self.G][:, self.cur % self.G]

@@ -45,6 +45,23 @@ def test_bench_strong_scaling_preset_q8192():
     assert out["gather_verified"] is True
 
 
+@pytest.mark.parametrize("every,steps,warmup", [(4, 7, 3), (2, 8, 2), (4, 5, 1)])
+def test_bench_grouped_gathers(every, steps, warmup):
+    """--gather-every G: one all_gather per group of G steps over a ring of two groups (what --gpus N does by default with G = the
+    batches in flight); step counts that end inside a group exercise the flush of a partly written group."""
+    out = _run("--gpus", "2", "--dry-run", "--backend", "gloo", "--steps", str(steps), "--warmup", str(warmup), "--Q", "64",
+               "--gather-every", str(every))
+    assert out["n_gpus"] == 2 and out["gather_verified"] is True
+    assert out["config"]["gather_every"] == every and out["config"]["collective"] is True
+
+
+def test_bench_force_collective_single_rank():
+    """--force-collective: the world > 1 branch with a ONE-rank process group (on the GPU box: nccl; here: gloo)."""
+    out = _run("--dry-run", "--force-collective", "--backend", "gloo", "--steps", "9", "--warmup", "2", "--Q", "32", "--gather-every", "4")
+    assert out["n_gpus"] == 1 and out["gather_verified"] is True
+    assert out["config"]["collective"] is True and out["config"]["world_size"] == 1 and out["config"]["backend"] == "gloo"
+
+
 def test_bench_single_rank_dry_run():
     out = _run("--dry-run", "--steps", "3", "--warmup", "1", "--Q", "16")
     assert out["n_gpus"] == 1 and out["gather_verified"] is True
