@@ -16,6 +16,94 @@ int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* freddy_gpu_last_error(void) { return g_err; }
 
+// ---------------------------------------------------------------------------------------
+// Backends on one GPU (one PostgreSQL backend = one process = one HIP context).  The processes cannot see each other
+// through HIP, and two things must be decided per process: how many hardware queues the runtime may create (read ONCE, when the
+// runtime starts) and how much of the chip a persistent scan takes while other backends are searching.  A small registry in
+// /dev/shm -- one slot per process: pid, the number of host-buffer searches it has in flight -- answers both without any
+// configuration: a process that finds other live backends when it starts takes GPU_MAX_HW_QUEUES = 2 (profiles/r05_backends.txt:
+// 2 / 4 backends at six queues each are together SLOWER than one; at two queues each 4.9 / 6.9 M queries/s), one that starts
+// alone takes six (four pipeline lanes + spares); a host-buffer search that starts while another backend is searching runs its
+// scan on half of the CUs (option scan_share = 0, the default: auto).  Slots of processes that died are recognised by kill(pid, 0).
+// Everything here is advisory: a registry that cannot be opened means "alone".
+// ---------------------------------------------------------------------------------------
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+namespace {
+struct BackendSlot { std::atomic<int32_t> pid; std::atomic<int32_t> busy; };
+constexpr int kBackendSlots = 256;
+BackendSlot* g_slots = nullptr;
+int g_my_slot = -1;
+std::once_flag g_registry_once;
+
+bool pid_alive(int32_t pid) { return pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM); }
+
+void registry_release() {
+  if (g_slots && g_my_slot >= 0) {
+    g_slots[g_my_slot].busy.store(0);
+    g_slots[g_my_slot].pid.store(0);
+  }
+}
+
+void registry_open() {
+  static_assert(sizeof(BackendSlot) == 8 && std::atomic<int32_t>::is_always_lock_free, "slot layout");
+  if (env_int("FREDDY_GPU_REGISTRY", 1) == 0) return;
+  char name[64];
+  snprintf(name, sizeof name, "/freddy_gpu_backends.%u", (unsigned)geteuid());
+  const int fd = shm_open(name, O_RDWR | O_CREAT, 0600);
+  if (fd < 0) return;
+  const size_t bytes = sizeof(BackendSlot) * kBackendSlots;
+  if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return; }
+  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (p == MAP_FAILED) return;
+  g_slots = static_cast<BackendSlot*>(p);
+  const int32_t me = (int32_t)getpid();
+  for (int pass = 0; pass < 2 && g_my_slot < 0; ++pass)
+    for (int i = 0; i < kBackendSlots && g_my_slot < 0; ++i) {
+      int32_t cur = g_slots[i].pid.load();
+      if (cur == me) { g_my_slot = i; break; }                       // (a forked child re-registers under its own pid below)
+      if (cur != 0 && (pass == 0 || pid_alive(cur))) continue;       // first pass: free slots only; second: slots of dead processes
+      if (g_slots[i].pid.compare_exchange_strong(cur, me)) { g_slots[i].busy.store(0); g_my_slot = i; }
+    }
+  if (g_my_slot >= 0) atexit(registry_release);
+}
+}  // namespace
+
+// live backends other than this process: registered (searching = false) or inside a host-buffer search right now (searching = true)
+int backends_other(bool searching) {
+  std::call_once(g_registry_once, registry_open);
+  if (!g_slots) return 0;
+  const int32_t me = (int32_t)getpid();
+  int n = 0;
+  for (int i = 0; i < kBackendSlots; ++i) {
+    const int32_t pid = g_slots[i].pid.load(std::memory_order_relaxed);
+    if (pid == 0 || pid == me) continue;
+    if (searching && g_slots[i].busy.load(std::memory_order_relaxed) <= 0) continue;
+    if (pid_alive(pid)) ++n;
+  }
+  return n;
+}
+void backend_busy(int delta) {
+  std::call_once(g_registry_once, registry_open);
+  if (g_slots && g_my_slot >= 0 && g_slots[g_my_slot].pid.load(std::memory_order_relaxed) == (int32_t)getpid())
+    g_slots[g_my_slot].busy.fetch_add(delta);
+}
+// Before the process's first HIP call: the hardware queues the runtime may create (never overrides the environment).
+void choose_hw_queues() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* policy = getenv("FREDDY_GPU_HWQ_POLICY");   // "6" / "2": fixed; default: by the registry
+    const bool alone = backends_other(false) == 0;
+    const char* q = (policy && *policy && strcmp(policy, "registry") != 0) ? policy : (alone ? "6" : "2");
+    setenv("GPU_MAX_HW_QUEUES", q, 0);
+  });
+}
+
 int64_t env_int(const char* name, int64_t dflt) {
   const char* e = getenv(name);
   return (e && *e) ? (int64_t)strtoll(e, nullptr, 10) : dflt;
@@ -25,7 +113,7 @@ Tuning read_tuning() {
   t.fused = (int)env_int("FREDDY_GPU_FUSED", t.fused);
   t.scan_kernel = (int)env_int("FREDDY_GPU_FUSED_KERNEL", t.scan_kernel);
   t.reserve_cus = (int)env_int("FREDDY_GPU_RESERVE_CUS", 0);
-  t.scan_share = (int)std::max<int64_t>(1, env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share));
+  t.scan_share = (int)std::max<int64_t>(0, env_int("FREDDY_GPU_SCAN_SHARE", t.scan_share));
   t.pipeline_batch = (int)std::max<int64_t>(16, env_int("FREDDY_GPU_PIPELINE_BATCH", t.pipeline_batch));
   t.pipeline_lanes = (int)std::min<int64_t>(4, std::max<int64_t>(1, env_int("FREDDY_GPU_PIPELINE_LANES", t.pipeline_lanes)));
   t.pq_fused = (int)env_int("FREDDY_GPU_PQ_FUSED", t.pq_fused);
@@ -36,6 +124,9 @@ Tuning read_tuning() {
   t.codes_u8 = (int)env_int("FREDDY_GPU_CODES_U8", t.codes_u8);
   t.running_bound = (int)env_int("FREDDY_GPU_RUNNING_BOUND", t.running_bound);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
+  t.lane0_own = (int)env_int("FREDDY_GPU_LANE0_OWN", t.lane0_own);
+  t.merge_to_host = (int)env_int("FREDDY_GPU_MERGE_TO_HOST", t.merge_to_host);
+  t.coarse_pieces = (int)env_int("FREDDY_GPU_COARSE_PIECES", t.coarse_pieces);
 #ifdef FREDDY_LAB
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
 #endif
@@ -75,7 +166,7 @@ void free_index(freddy_gpu_index* ix) {
   if (ix->hio_in) { (void)hipHostFree(ix->hio_in); ix->hio_in = nullptr; ix->hio_in_cap = 0; }
   if (ix->hio_out) { (void)hipHostFree(ix->hio_out); ix->hio_out = nullptr; ix->hio_out_cap = 0; }
   for (Lane& l : ix->lanes) {
-    if (l.stream) (void)hipStreamDestroy(l.stream);
+    if (l.stream && l.stream != ix->stream) (void)hipStreamDestroy(l.stream);
     for (LaneSlot& c : l.slot) {
       if (c.done) (void)hipEventDestroy(c.done);
       if (c.h_in) (void)hipHostFree(c.h_in);
@@ -214,7 +305,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   if (n == "fused") t.fused = (int)value;
   else if (n == "fused_kernel") t.scan_kernel = (int)value;
   else if (n == "reserve_cus") t.reserve_cus = (int)value;
-  else if (n == "scan_share") t.scan_share = (int)std::max<int64_t>(1, value);
+  else if (n == "scan_share") t.scan_share = (int)std::max<int64_t>(0, value);
   else if (n == "join_host_traversal") ix->join.host_traversal = value != 0;
   else if (n == "join_libm_margin_ppm") ix->join.libm_margin = (float)value * 1e-6f;
   else if (n == "sparse_items") t.sparse_items = std::max(-16, std::min(16, (int)value));
@@ -228,6 +319,8 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "exact_filter") t.exact_filter = (int)value;
   else if (n == "codes_u8") t.codes_u8 = (int)value;
   else if (n == "running_bound") t.running_bound = (int)value;
+  else if (n == "merge_to_host") t.merge_to_host = (int)value;
+  else if (n == "coarse_pieces") t.coarse_pieces = (int)value;
 #ifdef FREDDY_LAB
   else if (n == "fused_prof") t.scan_prof = (int)value;
 #endif
@@ -247,7 +340,7 @@ int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q
 }
 
 extern "C" int freddy_gpu_host_alloc(void** out, size_t bytes) {
-  setenv("GPU_MAX_HW_QUEUES", "6", 0);   // (as open_device: this call may be the process's first HIP call; a deployment sets it in the environment)
+  choose_hw_queues();   // (as open_device: this call may be the process's first HIP call)
   if (!out) return fail(FREDDY_E_ARG, "NULL argument");
   *out = nullptr;
   if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(FREDDY_E_NOMEM, "pinned host allocation of %zu bytes failed", bytes); }

@@ -52,13 +52,16 @@ enum { KIND_PQ = 1, KIND_IVF = 2, KIND_IVPQ = 3, KIND_VEC = 4 };
 // profiles/HISTORY.md has their numbers.)
 struct Tuning {
   // -- deployment
-  int scan_share = 1;          // FREDDY_GPU_SCAN_SHARE: the batches that share the chip with one of this handle's -- the batches the CALLER keeps
+  int scan_share = 0;          // FREDDY_GPU_SCAN_SHARE (0 = auto: 1, or 2 for a host-buffer search that starts while another BACKEND is searching -- core.hip registry): the batches that share the chip with one of this handle's -- the batches the CALLER keeps
                                // in flight through the *_dev entry points (one stream each), or the other BACKENDS (processes) searching at
                                // the same time: a persistent scan takes n_cus / share CUs so that the scans run side by side.
                                // An explicit contract -- the library does not guess it; the host-buffer calls multiply it by their lane count
   int reserve_cus = 0;         // FREDDY_GPU_RESERVE_CUS: CUs the persistent scan leaves to the kernels of other streams (RCCL beside the scans)
   int pipeline_batch = 2048;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
+  int lane0_own = 0;           // FREDDY_GPU_LANE0_OWN: 1 = the first pipeline lane on a stream of its own (until round 6) instead of the handle's stream
+  int merge_to_host = 1;       // FREDDY_GPU_MERGE_TO_HOST: round one's merge of a host-buffer sub-batch writes lists + completion word into the lane's pinned block itself (0 = a copy-out launch)
+  int coarse_pieces = 1;       // FREDDY_GPU_COARSE_PIECES: the cell-selection / table launch of a host-buffer sub-batch per staged piece of its queries
   int64_t lut_budget_mb = 8192;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit); 288 GB of HBM: 8 GiB = 12 800 queries at nprobe 10
   // -- path selection (tests)
   int fused = -1;              // FREDDY_GPU_FUSED: -1 auto (cell-grouped scans for >= 256 items), 0 generic kernels, 1 always
@@ -79,6 +82,12 @@ struct Tuning {
 #endif
 };
 int64_t env_int(const char* name, int64_t dflt);
+int backends_other(bool searching);   // core.hip: live backends (processes) besides this one -- registered / inside a host-buffer search
+void backend_busy(int delta);         // this process enters (+1) / leaves (-1) a host-buffer search
+void choose_hw_queues();              // GPU_MAX_HW_QUEUES before the first HIP call (never overrides the environment)
+struct BackendBusy { BackendBusy() { backend_busy(1); } ~BackendBusy() { backend_busy(-1); } };
+// option scan_share as a number: the explicit value, or (0 = auto) 2 while another backend is searching, else 1
+static inline int scan_share_now(int option, bool host_call) { return option > 0 ? option : (host_call && backends_other(true) > 0 ? 2 : 1); }
 Tuning read_tuning();
 
 struct DevBuf {
@@ -142,6 +151,8 @@ struct IvfRun {
   bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
   bool records_ready;  // a batch over the flat PQ table: the entry records were written by pq_records_kernel (no work-table / record kernels)
   int merge_slices;    // > 0: the merge of such a batch as `merge_slices` partial merges per query + merge_replay_kernel
+  int32_t* h_out = nullptr;   // host-buffer pipeline: the lane's pinned block, written by round one's merge itself (MergeRefineArgs::h_out)
+  bool host_written = false;  // ... and whether the path this chunk took did so (else: the copy-out kernel)
   // per round
   int n_active, round;
   const int32_t* active;

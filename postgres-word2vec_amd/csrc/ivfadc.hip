@@ -4,6 +4,8 @@
 // loop (freddy.c:262, :835).  No arithmetic that influences a result happens on the host.
 #include "internal.h"
 
+#include <functional>
+
 #include "kernels.h"
 #include "scan_common.h"
 #include "fused3.h"
@@ -146,11 +148,16 @@ int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int
 
 // coarse distances (a6/a7) of every query of the chunk, and -- for the filter + refine scan -- the
 // per-batch query x codebook table beside them on the side stream
-static int ivf_coarse(IvfRun& r) {
+// (q_lo, q_n): the combined MFMA cell-selection + table launch for the queries [q_lo, q_lo + q_n) of the chunk only -- the host-buffer
+// pipeline launches it piece by piece behind the pieces of the staged queries (q_lo a multiple of 32); q_n < 0: the whole chunk
+static bool ivf_coarse_by_pieces(const IvfRun& r) { return r.approx && r.fused && r.scan_kernel == 5; }
+static int ivf_coarse(IvfRun& r, int q_lo = 0, int q_n = -1) {
   Workspace* ws = r.ws;
   freddy_gpu_index* ix = r.ix;
   hipStream_t s = r.s;
   const int Q = r.Q, d = ix->d, C = ix->C, m = ix->m, K = ix->K, Cpad = ix->Cpad;
+  if (q_n < 0) { q_lo = 0; q_n = Q; }
+  if ((q_lo != 0 || q_n != Q) && !ivf_coarse_by_pieces(r)) return fail(FREDDY_E_ARG, "internal: this path launches its coarse kernel once");
   const int used_words = (C + 31) / 32;
   const size_t items = (size_t)Q * r.W;
   // round-one scratch that must start at zero: the probe bitmaps, the counters (n_next, n_groups, work
@@ -200,14 +207,15 @@ static int ivf_coarse(IvfRun& r) {
   // the table units are the workgroups of ONE launch (fused5.h coarse_table5_kernel); otherwise the table kernel runs in
   // line before the coarse kernel.
   if (r.approx && r.fused && r.scan_kernel == 5) {
-    CoarseTableArgs ct;
-    ct.queries = r.d_q; ct.coarseF = ix->coarseP; ct.cn2 = ix->cn2; ct.dist = ws->w_distT.as<float>(); ct.qn2 = ws->w_qn2.as<float>();
-    ct.Q = Q; ct.Cpad = Cpad; ct.d = d; ct.dp = ix->dp; ct.z = za; ct.coarse_gx = Cpad / 128; ct.coarse_gy = (Q + COARSE_TQ - 1) / COARSE_TQ;
-    ct.cbT = ix->cbF; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>(); ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
-    ct.qc = ws->w_qc.as<uint32_t>(); ct.m = m; ct.K = K; ct.tmin = tile_min; ct.C = C;
+    CoarseTableArgs ct;   // (every array is query-major: a piece is the same launch on offset pointers)
+    ct.queries = r.d_q + (size_t)q_lo * d; ct.coarseF = ix->coarseP; ct.cn2 = ix->cn2; ct.dist = ws->w_distT.as<float>() + (size_t)q_lo * Cpad;
+    ct.qn2 = ws->w_qn2.as<float>() + q_lo;
+    ct.Q = q_n; ct.Cpad = Cpad; ct.d = d; ct.dp = ix->dp; ct.z = za; ct.coarse_gx = Cpad / 128; ct.coarse_gy = (q_n + COARSE_TQ - 1) / COARSE_TQ;
+    ct.cbT = ix->cbF; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>() + (size_t)q_lo * m; ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m + q_lo;
+    ct.qc = ws->w_qc.as<uint32_t>() + (size_t)q_lo * m * 512; ct.m = m; ct.K = K; ct.tmin = tile_min ? tile_min + (size_t)q_lo * (Cpad / 128) : nullptr; ct.C = C;
     ct.coarseH = (const ch8v*)ix->coarseH; ct.ec = ix->coarse_ec;
     const size_t lds = std::max<size_t>(ix->coarseH ? coarse_approx16_lds(d) : (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
-    const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((Q + 15) / 16));
+    const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((q_n + 15) / 16));
     timed_launch(ix, s, "coarse_table", [&] {
       if (ix->coarseH) hipLaunchKernelGGL((coarse_table5_kernel<25, 16, true>), dim3(grid), dim3(256), lds, s, ct);
       else hipLaunchKernelGGL((coarse_table5_kernel<25, 16>), dim3(grid), dim3(256), lds, s, ct);
@@ -435,6 +443,11 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   mr.first_round = r.first() ? 1 : 0; mr.K = K; mr.d = ix->d; mr.sentinel = r.sentinel;
   mr.refine_all = (ix->tune.check_brackets & 1) ? 1 : 0; mr.fence = 0;
   mr.slices = 0; mr.part = nullptr;
+  // round one of a host-buffer sub-batch: the lists straight into the lane's pinned block (w_cnt[5] = the arrival counter, cleared
+  // with the round's other counters by the coarse kernel)
+  const bool to_host = r.h_out && r.first() && r.zeroed && r.merge_slices == 0 && r.active == nullptr;
+  mr.h_out = to_host ? r.h_out : nullptr; mr.h_arrive = ws->w_cnt.as<int32_t>() + 5; mr.h_n = r.n_active;
+  r.host_written = to_host;
   if (r.merge_slices > 0) {
     // a batch over the flat PQ table: `merge_slices` workgroups per query, each over its share of the pseudo-lists (r.W is the
     // padded item count per query, a multiple of the slices), then merge_replay_kernel over the slices' keys
@@ -592,8 +605,12 @@ static int ivfadc_round(IvfRun& r) {
 // state for further rounds stays in r (and in the stream's workspace): ivfadc_finish() runs them.
 static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const float* d_q, int Q, int k, int W,
                         float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
-                        int32_t* d_status, IvfRun& r) {
+                        int32_t* d_status, IvfRun& r, int32_t* h_out = nullptr,
+                        const std::function<int(int, int)>* stage = nullptr) {
+  // stage(q_lo, q_hi) (host-buffer pipeline): brings the queries [q_lo, q_hi) of this chunk into d_q on stream s -- called once for
+  // the whole chunk, or piece by piece with the piece's cell-selection / table launch right behind it
   Workspace* ws = workspace_for(ix, s);
+  r.h_out = h_out; r.host_written = false;
   const int C = ix->C, m = ix->m, K = ix->K;
   if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
   r.ix = ix; r.ws = ws; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
@@ -656,7 +673,14 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   }
 
-  if (int rc = ivf_coarse(r)) return rc;
+  // pieces of whole 32-query tiles; a piece of fewer than 128 queries is not worth a launch of its own
+  int pieces = (stage && ix->tune.coarse_pieces && ivf_coarse_by_pieces(r) && Q >= 512) ? 4 : 1;
+  const int per = ((Q + pieces - 1) / pieces + 31) & ~31;
+  for (int q_lo = 0; q_lo < Q; q_lo += (pieces > 1 ? per : Q)) {
+    const int q_n = pieces > 1 ? std::min(per, Q - q_lo) : Q;
+    if (stage) if (int rc = (*stage)(q_lo, q_lo + q_n)) return rc;
+    if (int rc = ivf_coarse(r, q_lo, q_n)) return rc;
+  }
   ix->last_Q = Q;
   r.n_active = Q; r.active = nullptr; r.next = ws->w_act0.as<int32_t>();
   r.round = 0;
@@ -725,7 +749,7 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
-    if (int rc = ivfadc_begin(ix, s, ix->tune.scan_share, d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+    if (int rc = ivfadc_begin(ix, s, scan_share_now(ix->tune.scan_share, false), d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
                               d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_status, r))
       return rc;
   }
@@ -743,7 +767,11 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
 // rounds run and its lists are copied out: the transfers and the latency-bound ends of one sub-batch hide under the
 // scans of its neighbours, and ONE stream synchronisation per lane ends the call.
 // ---------------------------------------------------------------------------------------
-static int lane_open(Lane& l, LaneSlot& c, size_t in_bytes, size_t n, size_t n_out) {
+static int lane_open(freddy_gpu_index* ix, Lane& l, LaneSlot& c, size_t in_bytes, size_t n, size_t n_out) {
+  // lane 0 is the handle's own stream: a call of one sub-batch (<= pipeline_batch queries: what a PostgreSQL backend makes) uses
+  // ONE stream per process, and only larger calls create further streams -- every stream a process creates takes a hardware
+  // queue, and the queues of several backends on one GPU are what decides their aggregate rate (profiles/r06_backends.txt)
+  if (!l.stream && &l == &ix->lanes[0] && !ix->tune.lane0_own) l.stream = ix->stream;
   if (!l.stream) HIP_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
   if (!c.done) HIP_TRY(hipEventCreateWithFlags(&c.done, hipEventDisableTiming));
   if (in_bytes > c.h_in_cap) {
@@ -780,7 +808,7 @@ static int ivfadc_sync_search(freddy_gpu_index* ix, const float* queries, int Q,
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
-    if (int rc = ivfadc_begin(ix, s, ix->tune.scan_share, ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+    if (int rc = ivfadc_begin(ix, s, scan_share_now(ix->tune.scan_share, true), ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
                               ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k, nullptr, r))
       return rc;
     if (int rc = ivfadc_finish(r, -1)) return rc;
@@ -982,6 +1010,8 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
   const float* pinned_in = static_cast<const float*>(pinned_device_pointer(queries));
   const size_t row = sizeof(float) * (size_t)ix->d;
   const PipeCall pc{ix, queries, k, W, found_rule, sentinel, out_ids, out_dist};
+  const BackendBusy busy;   // (the registry of backends on this GPU: core.hip)
+  const int share_call = scan_share_now(ix->tune.scan_share, true);
   int rc = 0;
 #ifdef FREDDY_LAB
   static const bool trace = getenv("FREDDY_GPU_PIPE_TRACE") != nullptr;   // host timestamps of the pipeline's steps on stderr (lab builds)
@@ -998,7 +1028,7 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
     if ((rc = lane_retire(c, pc))) break;
     if (trace) t1 = now_us();
     const int q0 = j * per, n = std::min(per, Q - q0);
-    if ((rc = lane_open(l, c, row * n, (size_t)n, (size_t)n * k))) break;
+    if ((rc = lane_open(ix, l, c, row * n, (size_t)n, (size_t)n * k))) break;
     c.q0 = q0; c.n = n;
     const float* src = pinned_in ? pinned_in + (size_t)q0 * ix->d : nullptr;
     const bool stage = !src || reinterpret_cast<uintptr_t>(src) % 16 || (row * n) % 16;   // (the copy kernel moves whole 16-byte words)
@@ -1007,36 +1037,42 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
       // a handful of queries: the kernels read them where they are staged (pinned, mapped) -- one launch less
       if (stage) { memcpy(c.h_in, queries + (size_t)q0 * ix->d, row * n); src = static_cast<const float*>(c.h_in); }
       d_queries = src;
-      if (trace) t2 = now_us();
-    } else {
-      // pageable queries cross in pieces: the copy kernel of a piece reads it over PCIe while the host stages the next one
-      // (1.2 MB per 1024 queries: 28 us of memcpy + 25 us of PCIe, back to back until round 4)
-      const size_t total = row * n, n16_all = (total + 15) / 16;
-      const int pieces = stage && total >= (size_t)512 * 1024 ? 4 : 1;
-      const size_t per16 = (n16_all + pieces - 1) / pieces;
-      for (int pi = 0; pi < pieces; ++pi) {
-        const size_t w0 = (size_t)pi * per16, w1 = std::min(n16_all, w0 + per16);
-        if (w0 >= w1) break;
-        const size_t b0 = w0 * 16, b1 = std::min(total, w1 * 16);
-        if (stage) memcpy(static_cast<char*>(c.h_in) + b0, reinterpret_cast<const char*>(queries + (size_t)q0 * ix->d) + b0, b1 - b0);
-        const char* from = stage ? static_cast<const char*>(c.h_in) : reinterpret_cast<const char*>(src);
-        hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((w1 - w0 + 255) / 256, 512)), dim3(256), 0, l.stream,
-                           reinterpret_cast<const uint4*>(from + b0), reinterpret_cast<uint4*>(c.d_q.as<char>() + b0), w1 - w0);
-        if (hipGetLastError() != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the query copy failed"); break; }
-      }
-      if (rc) break;
-      if (trace) t2 = now_us();
     }
+    // pageable queries cross in pieces: the copy kernel of a piece reads it over PCIe while the host stages the next one (1.2 MB per
+    // 1024 queries: 28 us of memcpy + 25 us of PCIe, back to back until round 4) -- and, since round 6, the piece's cell-selection /
+    // table launch runs behind its copy while the next piece is staged (ivfadc_begin calls this once per piece)
+    const std::function<int(int, int)> stage_piece = [&](int q_lo, int q_hi) -> int {
+      if (n <= 8) return 0;
+      const size_t b_lo = row * (size_t)q_lo, b_hi = row * (size_t)q_hi;
+      // (a range of whole queries; whole 16-byte words except at the end of the sub-batch, whose buffers are padded)
+      const size_t w0 = b_lo / 16, w1 = (b_hi + 15) / 16;
+      if (b_lo % 16) return fail(FREDDY_E_ARG, "internal: a staged piece must start at a 16-byte word");
+      if (stage) memcpy(static_cast<char*>(c.h_in) + b_lo, reinterpret_cast<const char*>(queries + (size_t)q0 * ix->d) + b_lo, b_hi - b_lo);
+      const char* from = stage ? static_cast<const char*>(c.h_in) : reinterpret_cast<const char*>(src);
+      // without per-piece coarse launches (every other path) the whole range still crosses as four copy launches
+      const int cuts = (q_lo == 0 && q_hi == n && stage && b_hi >= (size_t)512 * 1024) ? 4 : 1;
+      const size_t per16 = (w1 - w0 + cuts - 1) / cuts;
+      for (int ci = 0; ci < cuts; ++ci) {
+        const size_t a0 = w0 + (size_t)ci * per16, a1 = std::min(w1, a0 + per16);
+        if (a0 >= a1) break;
+        hipLaunchKernelGGL(lane_copy_in_kernel, dim3((unsigned)std::min<size_t>((a1 - a0 + 255) / 256, 512)), dim3(256), 0, l.stream,
+                           reinterpret_cast<const uint4*>(from) + a0, reinterpret_cast<uint4*>(c.d_q.as<char>()) + a0, a1 - a0);
+      }
+      if (hipGetLastError() != hipSuccess) return fail(FREDDY_E_HIP, "launch of the query copy failed");
+      return 0;
+    };
+    if (trace) t2 = now_us();
     IvfRun r;
-    if ((rc = ivfadc_begin(ix, l.stream, n_lanes * ix->tune.scan_share, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
-                           c.d_dist.as<float>(), nullptr, r)))
-      break;
-    if (trace) t3 = now_us();
     const int n_out = n * k;
     int32_t* h_flag = static_cast<int32_t*>(c.h_out) + 2 * (size_t)n_out + 1 + (size_t)n;
-    *h_flag = 0;
-    hipLaunchKernelGGL(lane_copy_out_flag_kernel, dim3(1), dim3(1024), 0, l.stream, c.d_ids.as<int32_t>(),
-                       c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n, h_flag);
+    *h_flag = 0;   // (before the first launch: the merge of the filter + refine path writes the lists and this word itself)
+    if ((rc = ivfadc_begin(ix, l.stream, n_lanes * share_call, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
+                           c.d_dist.as<float>(), nullptr, r, ix->tune.merge_to_host ? static_cast<int32_t*>(c.h_out) : nullptr, &stage_piece)))
+      break;
+    if (trace) t3 = now_us();
+    if (!r.host_written)   // (every other path: one workgroup copies lists, straggler count and stragglers, then the completion word)
+      hipLaunchKernelGGL(lane_copy_out_flag_kernel, dim3(1), dim3(1024), 0, l.stream, c.d_ids.as<int32_t>(),
+                         c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n, h_flag);
     if (hipGetLastError() != hipSuccess || hipEventRecord(c.done, l.stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the result copy failed"); break; }
     c.busy = true;
     if (trace)

@@ -298,9 +298,11 @@ static int refresh_row_terms(freddy_gpu_index* ix) {
 
 int open_device(freddy_gpu_index* ix, int device) {
   // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), read once when the
-  // runtime starts: the pipeline's four lanes want a queue each beside the library's own stream (DESIGN.md 5.2c:
-  // 6 queues measured best).  Set here unless the host chose a value; without effect if the runtime is already up.
-  setenv("GPU_MAX_HW_QUEUES", "6", 0);
+  // runtime starts: the pipeline's four lanes want a queue each beside the library's own stream (6 queues measured
+  // best for ONE process) -- but several backends with six queues each are together slower than one, so a process that
+  // finds other live backends takes two (core.hip choose_hw_queues).  Never overrides the environment; without effect if
+  // the runtime is already up.
+  choose_hw_queues();
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));
   if (device < 0 || device >= n) return fail(FREDDY_E_ARG, "device %d out of range (%d visible)", device, n);

@@ -61,6 +61,7 @@ def main():
     out["queries_per_s"] = round(out["queries"] / out["seconds"], 1)
     prof = ivf.profile_read()
     out["kernels"] = {name: int(l) for name, (l, ms) in prof.items()}
+    out["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES")   # (what the library chose for this process unless the environment had it)
     out["bound_violations"] = int(ivf.bound_violations())
     ivf.close()
     if pq is not None:

@@ -21,9 +21,12 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_backends(path, n_procs, seconds, mode="mixed", timeout=240):
+    # NO deployment settings in the environment: queues and scan share are the library's own decision (core.hip: the registry of
+    # live backends in /dev/shm)
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FREDDY_GPU_SCAN_SHARE")}
     with tempfile.TemporaryDirectory() as sync:
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "backend_worker.py"), path, str(r), str(n_procs), str(seconds), sync, mode],
-                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(n_procs)]
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(n_procs)]
         outs = []
         try:
             for p in procs:
@@ -75,3 +78,17 @@ def test_backends_on_one_gpu_give_the_oracles_lists(tables_file, n_procs):
         assert o["kernels"].get("ivf_one", 0) > 0 or o["kernels"].get("adc_scan", 0) > 0, o
     print("\n[backends]", n_procs, "processes:", [{"q/s": o["queries_per_s"], "ivf_one": o["kernels"].get("ivf_one", 0),
                                                     "multi_launch_single_queries": o["kernels"].get("lut_build", 0)} for o in outs])
+
+
+def test_four_backends_together_beat_one(tables_file):
+    """VERDICT r5 task 4: with the library's defaults (nothing in the environment) four backends searching at once must deliver more
+    than one backend alone -- at six hardware queues per process (the default until round 5) two or four backends fell BELOW one
+    (profiles/r05_backends.txt).  1024-query host-buffer calls, every list checked."""
+    one = _run_backends(tables_file, 1, seconds=3.0, mode="batch")
+    four = _run_backends(tables_file, 4, seconds=3.0, mode="batch")
+    for o in one + four:
+        assert "error" not in o and o["mismatches"] == 0 and o["bound_violations"] == 0, o
+    a1, a4 = one[0]["queries_per_s"], sum(o["queries_per_s"] for o in four)
+    print(f"\n[backends] 1 backend {a1 / 1e6:.2f} M q/s (hw queues {one[0].get('hw_queues')}), 4 backends {a4 / 1e6:.2f} M q/s aggregate "
+          f"(hw queues {[o.get('hw_queues') for o in four]})")
+    assert a4 > a1, (a1, a4)

@@ -2,7 +2,7 @@
 """1 / 2 / 4 BACKENDS (processes) on one GPU at config-3 size (3 M x 300, C = 1000, m = 12, K = 1024, nprobe 10, k = 5): every
 process pins its own copy of the index and makes 1024-query host-buffer calls (freddy_gpu_ivfadc_search) for a few seconds,
 all at the same time (tests/backend_worker.py; the test of the same situation is tests/test_gpu_backends.py).
-Prints per-process and aggregate queries/s -> profiles/r05_backends.txt.   usage: tools/backends.py [seconds] [N]"""
+Prints per-process and aggregate queries/s -> profiles/r06_backends.txt.   usage: tools/backends.py [seconds] [N] [configs]"""
 import json, os, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "postgres-word2vec_amd")]
@@ -29,12 +29,20 @@ np.savez(path, coarse=np.asarray(tab["coarse"]), codebook=np.asarray(tab["codebo
          codes=np.asarray(tab["codes"]), queries=qs, k=5, W=10, exp_ids=ei, exp_dist=ed, shapes=np.array([1024], np.int32))
 print(f"# backends on one MI355X: {N} x 300, C = 1000, K = 1024, nprobe 10, k = 5; every process pins its own copy ({index_mb:.0f} MB) and makes")
 print(f"# 1024-query host-buffer calls for {seconds:.0f} s; lists compared bit for bit with the single-process lists")
-CONFIGS = [(1, 1, None), (1, 1, 2), (2, 1, None), (2, 2, None), (2, 2, 2), (4, 1, None), (4, 4, None), (4, 2, 1), (4, 2, 2), (4, 2, 3), (4, 2, 4), (4, 4, 2),
-           (8, 2, 1), (8, 4, 1), (8, 4, 2)]
-if len(sys.argv) > 3:   # e.g. "4:2:2,8:4:1" = processes : scan_share : GPU_MAX_HW_QUEUES (0 = the library's default of 6)
-    CONFIGS = [tuple(int(v) or None for v in c.split(":")) for c in sys.argv[3].split(",")]
-for P, share, hwq in CONFIGS:
-    env = dict(os.environ, FREDDY_GPU_SCAN_SHARE=str(share))   # (the option every backend is given: how many batches share the chip)
+# (processes, scan_share, GPU_MAX_HW_QUEUES, extra environment); None = not set: the LIBRARY decides (core.hip: registry of live backends
+# -> two queues when others are alive, six when alone; scan_share auto = 2 while another backend is searching)
+CONFIGS = [(1, None, None, {}), (2, None, None, {}), (4, None, None, {}), (8, None, None, {}),
+           (1, 1, 6, {}), (2, 2, 2, {}), (4, 2, 2, {}), (4, 1, 6, {"FREDDY_GPU_REGISTRY": "0"})]
+if len(sys.argv) > 3:   # e.g. "4:2:2,8:0:0,4:0:6:FREDDY_GPU_LANE0_OWN=1" = processes : scan_share : GPU_MAX_HW_QUEUES [: NAME=value ...] (0 = not set)
+    CONFIGS = []
+    for c in sys.argv[3].split(","):
+        f = c.split(":")
+        CONFIGS.append((int(f[0]), int(f[1]) or None, int(f[2]) or None, dict(kv.split("=", 1) for kv in f[3:])))
+base_env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "FREDDY_GPU_SCAN_SHARE")}
+for P, share, hwq, extra in CONFIGS:
+    env = dict(base_env, **extra)
+    if share:
+        env["FREDDY_GPU_SCAN_SHARE"] = str(share)
     if hwq:
         env["GPU_MAX_HW_QUEUES"] = str(hwq)
     with tempfile.TemporaryDirectory() as sync:
@@ -48,6 +56,8 @@ for P, share, hwq in CONFIGS:
         print(P, "processes: FAILED", outs)
         continue
     per = [o["queries_per_s"] for o in outs]
-    print(f"{P} process(es), scan_share {share}, GPU_MAX_HW_QUEUES {hwq or 'default (6)'}: aggregate {sum(per) / 1e6:6.2f} M queries/s   per process {[round(v / 1e6, 2) for v in per]} M   "
-          f"mismatching calls {sum(o['mismatches'] for o in outs)}   bracket violations {sum(o['bound_violations'] for o in outs)}   pin {outs[0]['pin_seconds']} s")
+    what = f"scan_share {share or 'auto'}, GPU_MAX_HW_QUEUES {hwq or 'by the library'}" + (f", {extra}" if extra else "")
+    print(f"{P} process(es), {what}: aggregate {sum(per) / 1e6:6.2f} M queries/s   per process {[round(v / 1e6, 2) for v in per]} M   "
+          f"hw queues {[o.get('hw_queues') for o in outs]}   mismatching calls {sum(o['mismatches'] for o in outs)}   "
+          f"bracket violations {sum(o['bound_violations'] for o in outs)}   pin {outs[0]['pin_seconds']} s", flush=True)
 os.remove(path); os.rmdir(d)
