@@ -87,8 +87,12 @@ def parse(argv=None):
                     help="--gpus 1 through the N > 1 code path: a ONE-rank process group of --backend, the asynchronous all_gather, option "
                          "reserve_cus, RCCL's stream beside the searching streams (what rank 0 of an N-GPU run does, priced on one GPU)")
     ap.add_argument("--gather-every", type=int, default=0,
-                    help="steps per all_gather of the per-shard top-k (0 = the batches in flight: one collective per group of in-flight "
-                         "batches, a ring of two groups; 1 = a collective per step)")
+                    help="steps per all_gather of the per-shard top-k (0 or 1 = a collective per step, in the step's stream; G > 1 = one "
+                         "collective per group of G steps over a ring of two groups)")
+    ap.add_argument("--gather-path", default="rccl", choices=["rccl", "c10d", "c10d-async"],
+                    help="rccl: ONE ncclAllGather call on the searching stream of the step (freddy_amd/rccl.py: a communicator of its own over "
+                         "the ranks torch.distributed started); c10d: torch.distributed.all_gather_into_tensor with async_op=False under the "
+                         "step's stream; c10d-async: async_op=True on ProcessGroupNCCL's internal stream")
     ap.add_argument("--collective-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--ab-rounds", type=int, default=2, help="--force-collective: rounds of (without, with) timed regions")
     ap.add_argument("--reserve-cus", type=int, default=2, help="option reserve_cus of the collective path (CUs every persistent scan leaves free)")
@@ -265,7 +269,7 @@ def roofline(kernel, avg_s, algorithmic_bytes, model, traffic, extra=None):
 # ---------------------------------------------------------------------------------------------------
 HEADLINE_MAX_BYTES = 1900
 DIGEST_MAX_BYTES = 5000
-_CONFIG_KEYS = ("gather_every", "collective", "workload", "N", "d", "C", "m", "K", "nprobe", "k", "Q", "targets", "batch", "batch_per_gpu", "parallelism", "world_size",
+_CONFIG_KEYS = ("gather_every", "gather_path", "collective", "workload", "N", "d", "C", "m", "K", "nprobe", "k", "Q", "targets", "batch", "batch_per_gpu", "parallelism", "world_size",
                 "backend", "batches_in_flight", "recall_at_5", "recall_at_5_without_self", "host_abi_q1024_qps", "host_abi_q4096_qps",
                 "collective_1rank_ratio")
 _ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_us",
@@ -402,6 +406,11 @@ def emit(out, details_name="bench_details.json"):
     dg = digest(out)
     if dg and dg["bench_digest"]:
         print(json.dumps(dg), flush=True)
+    try:   # what C libraries still hold in stdio's buffer (RCCL prints a version banner to stdout) leaves BEFORE the contract line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(headline(out)), flush=True)
 
 
@@ -474,6 +483,22 @@ def exact_truth(x, d_qs, k, dev_index, cpu_queries=4, steps=5):
 _BENCH_STREAMS = {}
 
 
+def bench_streams(a, dev):
+    """The searching streams of this process, created ONCE and before anything else creates streams (main() calls this before the
+    process group exists: RCCL's own streams would otherwise take hardware queues first, and the four searching streams ended up
+    sharing -- 5.9 instead of 9.4 M queries/s for the very same steps in a process that merely HAD a communicator)."""
+    n_fl = max(1, min(a.in_flight, 8))
+    key = (str(dev), n_fl, a.stream_skip)
+    if key not in _BENCH_STREAMS:
+        _skipped = [torch.cuda.Stream(dev) for _ in range(a.stream_skip)]   # (tools/sweep_queues.sh: shifts the streams' hardware queues)
+        _BENCH_STREAMS[key] = (_skipped, [torch.cuda.Stream(dev) for _ in range(n_fl)])
+        for st in _BENCH_STREAMS[key][1]:   # (a hardware queue is bound when a stream first runs something)
+            with torch.cuda.stream(st):
+                torch.zeros(1, device=dev)
+        torch.cuda.synchronize(dev)
+    return _BENCH_STREAMS[key][1]
+
+
 def run_ivfadc(a, rank, world, dev, dev_index):
     import torch.distributed as dist
     from freddy_amd import gpu, shard, index_build as ib
@@ -515,18 +540,24 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         raise SystemExit(f"--steps must be at least --in-flight ({n_fl}): every stream's buffer is verified after the timed region")
     # (the streams are created ONCE per process: the K = 256 side configuration runs this function a second time, and four MORE
     #  streams landed on hardware queues the first four already used -- 6.1 instead of 10.4 M queries/s for that side figure)
-    key = (str(dev), n_fl, a.stream_skip)
-    if key not in _BENCH_STREAMS:
-        _skipped = [torch.cuda.Stream(dev) for _ in range(a.stream_skip)]   # (tools/sweep_queues.sh: shifts the streams' hardware queues)
-        _BENCH_STREAMS[key] = (_skipped, [torch.cuda.Stream(dev) for _ in range(n_fl)])
-    streams = _BENCH_STREAMS[key][1]
+    streams = bench_streams(a, dev)
     # the N > 1 path: every rank's lists are gathered (RCCL all_gather) -- one collective per GROUP of `gather_every` steps (default:
     # the batches in flight), a ring of two groups; --force-collective takes this path with a single rank
     collective = world > 1 or bool(a.force_collective)
-    G = (a.gather_every or n_fl) if collective else 1
+    G = (a.gather_every or 1) if collective else 1   # (default: a gather per step, in the step's stream)
     depth = 2 * G if (collective and G > 1) else max(2, n_fl)
+    comm, gather_path = None, ("none" if not collective else a.gather_path)
+    if collective and a.gather_path == "rccl" and a.backend == "nccl":
+        try:
+            from freddy_amd import rccl
+            comm = rccl.Communicator(dev_index)
+        except Exception as e:   # (the run goes on through c10d: correct, slower -- and says so in config.gather_path)
+            log(rank, f"direct RCCL communicator unavailable ({type(e).__name__}: {e}); the gather goes through c10d")
+            gather_path = "c10d (fallback)"
+    elif collective and a.gather_path == "rccl":
+        gather_path = "c10d"   # (gloo etc.)
     with torch.cuda.stream(streams[0]):
-        pg = shard.PipelinedGather(q_local, a.k, dev, depth=depth, force=collective, gather_every=G)
+        pg = shard.PipelinedGather(q_local, a.k, dev, depth=depth, force=collective, gather_every=G, in_stream=(a.gather_path != "c10d-async"), comm=comm)
     torch.cuda.synchronize(dev)
     counter = [0]
     # world == 1: there is no collective to order, so a step is nothing but the C call -- one pre-bound ctypes call per
@@ -619,17 +650,30 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                     index.set_option("reserve_cus", rc)
                     counter[0] = 0
                     pgx.steps = 0
-                    dtx, _ = sharded_steps(fn, pgx, a.steps, a.warmup, sync, world)
+                    for _ in range(a.warmup):
+                        fn()
+                    barrier_x = (lambda p=pgx: (p.drain(), sync()))
+                    barrier_x()
+                    t0 = time.perf_counter()
+                    for _ in range(a.steps):
+                        fn()
+                    t_host = time.perf_counter() - t0     # the host's share: the steps are enqueued, nothing is waited for
+                    barrier_x()
+                    dtx = time.perf_counter() - t0
                     row[name] = round(q_local * a.steps / dtx, 1)
+                    row[name + "_host_us_per_step"] = round(1e6 * t_host / a.steps, 1)
                 rounds.append(row)
             index.set_option("reserve_cus", a.reserve_cus)
             w = float(np.mean([r["with"] for r in rounds])); wo = float(np.mean([r["without"] for r in rounds]))
             coll_ab = {"with_collective_qps": round(w, 1), "without_qps": round(wo, 1), "ratio": round(w / wo, 4), "rounds": rounds,
-                       "gather_every": G, "reserve_cus": a.reserve_cus, "backend": a.backend, "steps": a.steps,
+                       "gather_every": G, "gather_path": gather_path, "reserve_cus": a.reserve_cus, "backend": a.backend, "steps": a.steps,
                        "gather_verified": gather_ok,
                        "note": "one process, the same four streams: steps through the world > 1 branch (1-rank process group, asynchronous "
                                "all_gather_into_tensor per group of gather_every steps, option reserve_cus) against the plain --gpus 1 steps"}
         index.set_option("scan_share", 1)
+        if comm is not None:
+            torch.cuda.synchronize(dev)
+            comm.close()
     scanned_rows = index.last_scanned_rows()
     n_cells, cell_rows = index.last_probed_cells()
     bound_violations = index.bound_violations()   # self-check of the filter + refine scan (must be 0)
@@ -659,7 +703,9 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                     raise RuntimeError("skipped (--no-host-abi)")
                 if world > 1:   # (a side measurement of ONE backend's call: reported at N = 1, like the CPU baseline; the other ranks would wait for it)
                     raise RuntimeError("skipped (reported at --gpus 1 only)")
-                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                # (ONE backend that has the GPU to itself: six hardware queues, what the library picks for a process that finds no
+                # other live backend -- this parent, with its pinned index, would count as one)
+                cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, GPU_MAX_HW_QUEUES="6"))
                 host_abi = json.loads(cp.stdout.strip().splitlines()[-1])
             except Exception as e:   # the headline line must not be lost to a side measurement
                 host_abi = {"error": f"{type(e).__name__}: {e}"}
@@ -830,7 +876,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                        "batches_in_flight": n_fl, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
                        "backend": (("rccl (torch.distributed nccl)" if a.backend == "nccl" else a.backend) if collective else "none (single GPU)"),
-                       "gather_every": (G if collective else None),
+                       "gather_every": (G if collective else None), "gather_path": gather_path,
                        "recall_at_5": None if recall is None else round(recall, 4),
                        "recall_at_5_without_self": None if recall_info is None else recall_info["recall_at_5_without_self"],
                        "host_abi_q1024_qps": (abi_brief.get("Q1024") or {}).get("queries_per_s"),
@@ -1185,6 +1231,8 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()   # one rank per GPU; wraps only in single-GPU dry runs
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    if a.config == "ivfadc":
+        bench_streams(a, dev)   # (before RCCL creates its streams)
     if world > 1 or a.force_collective:
         if a.config != "ivfadc":
             raise SystemExit("--config pq / join / exact are single-GPU measurements")

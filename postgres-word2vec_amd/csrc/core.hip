@@ -49,6 +49,10 @@ void registry_release() {
   }
 }
 
+std::mutex g_reg_mu;
+int g_handles = 0;      // pinned handles of this process: it is a registered backend while this is > 0
+
+void registry_claim();
 void registry_open() {
   static_assert(sizeof(BackendSlot) == 8 && std::atomic<int32_t>::is_always_lock_free, "slot layout");
   if (env_int("FREDDY_GPU_REGISTRY", 1) == 0) return;
@@ -62,6 +66,10 @@ void registry_open() {
   close(fd);
   if (p == MAP_FAILED) return;
   g_slots = static_cast<BackendSlot*>(p);
+  atexit(registry_release);
+}
+void registry_claim() {   // (g_reg_mu held)
+  if (!g_slots || g_my_slot >= 0) return;
   const int32_t me = (int32_t)getpid();
   for (int pass = 0; pass < 2 && g_my_slot < 0; ++pass)
     for (int i = 0; i < kBackendSlots && g_my_slot < 0; ++i) {
@@ -70,9 +78,17 @@ void registry_open() {
       if (cur != 0 && (pass == 0 || pid_alive(cur))) continue;       // first pass: free slots only; second: slots of dead processes
       if (g_slots[i].pid.compare_exchange_strong(cur, me)) { g_slots[i].busy.store(0); g_my_slot = i; }
     }
-  if (g_my_slot >= 0) atexit(registry_release);
 }
 }  // namespace
+
+// A process is a registered backend while it holds pinned handles (+1 per pinned index, -1 when it is freed).
+void backend_handles(int delta) {
+  std::call_once(g_registry_once, registry_open);
+  std::lock_guard<std::mutex> lock(g_reg_mu);
+  g_handles += delta;
+  if (g_handles > 0) registry_claim();
+  else if (g_slots && g_my_slot >= 0) { registry_release(); g_my_slot = -1; }
+}
 
 // live backends other than this process: registered (searching = false) or inside a host-buffer search right now (searching = true)
 int backends_other(bool searching) {
@@ -125,7 +141,6 @@ Tuning read_tuning() {
   t.running_bound = (int)env_int("FREDDY_GPU_RUNNING_BOUND", t.running_bound);
   t.lut_budget_mb = std::max<int64_t>(1, env_int("FREDDY_GPU_LUT_BUDGET_MB", t.lut_budget_mb));
   t.lane0_own = (int)env_int("FREDDY_GPU_LANE0_OWN", t.lane0_own);
-  t.merge_to_host = (int)env_int("FREDDY_GPU_MERGE_TO_HOST", t.merge_to_host);
   t.coarse_pieces = (int)env_int("FREDDY_GPU_COARSE_PIECES", t.coarse_pieces);
 #ifdef FREDDY_LAB
   t.scan_prof = getenv("FREDDY_GPU_FUSED_PROF") != nullptr;
@@ -157,6 +172,7 @@ Workspace* workspace_for(freddy_gpu_index* ix, hipStream_t s) {
 
 void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
+  if (ix->registered) { ix->registered = false; backend_handles(-1); }
   for (freddy_gpu_index* r : ix->replicas) free_index(r);
   ix->replicas.clear();
   (void)hipSetDevice(ix->device);
@@ -319,7 +335,6 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "exact_filter") t.exact_filter = (int)value;
   else if (n == "codes_u8") t.codes_u8 = (int)value;
   else if (n == "running_bound") t.running_bound = (int)value;
-  else if (n == "merge_to_host") t.merge_to_host = (int)value;
   else if (n == "coarse_pieces") t.coarse_pieces = (int)value;
 #ifdef FREDDY_LAB
   else if (n == "fused_prof") t.scan_prof = (int)value;

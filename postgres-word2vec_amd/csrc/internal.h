@@ -60,8 +60,7 @@ struct Tuning {
   int pipeline_batch = 2048;   // FREDDY_GPU_PIPELINE_BATCH: queries per sub-batch of the host-buffer pipeline (freddy_gpu_ivfadc_search)
   int pipeline_lanes = 4;      // FREDDY_GPU_PIPELINE_LANES: sub-batches in flight inside one host-buffer call (1..4)
   int lane0_own = 0;           // FREDDY_GPU_LANE0_OWN: 1 = the first pipeline lane on a stream of its own (until round 6) instead of the handle's stream
-  int merge_to_host = 1;       // FREDDY_GPU_MERGE_TO_HOST: round one's merge of a host-buffer sub-batch writes lists + completion word into the lane's pinned block itself (0 = a copy-out launch)
-  int coarse_pieces = 1;       // FREDDY_GPU_COARSE_PIECES: the cell-selection / table launch of a host-buffer sub-batch per staged piece of its queries
+  int coarse_pieces = 1;       // FREDDY_GPU_COARSE_PIECES: a host-buffer call of ONE sub-batch launches its cell selection / table kernel per staged piece of the queries (0 = once, behind the last piece)
   int64_t lut_budget_mb = 8192;      // FREDDY_GPU_LUT_BUDGET_MB: per-call workspace cap (queries are chunked to fit); 288 GB of HBM: 8 GiB = 12 800 queries at nprobe 10
   // -- path selection (tests)
   int fused = -1;              // FREDDY_GPU_FUSED: -1 auto (cell-grouped scans for >= 256 items), 0 generic kernels, 1 always
@@ -83,6 +82,7 @@ struct Tuning {
 };
 int64_t env_int(const char* name, int64_t dflt);
 int backends_other(bool searching);   // core.hip: live backends (processes) besides this one -- registered / inside a host-buffer search
+void backend_handles(int delta);      // +1 per pinned index of this process, -1 when it is freed: registered while > 0
 void backend_busy(int delta);         // this process enters (+1) / leaves (-1) a host-buffer search
 void choose_hw_queues();              // GPU_MAX_HW_QUEUES before the first HIP call (never overrides the environment)
 struct BackendBusy { BackendBusy() { backend_busy(1); } ~BackendBusy() { backend_busy(-1); } };
@@ -151,8 +151,6 @@ struct IvfRun {
   bool approx;         // cell selection as filter + refine: MFMA distances with a proven bracket, exact ones for the candidates
   bool records_ready;  // a batch over the flat PQ table: the entry records were written by pq_records_kernel (no work-table / record kernels)
   int merge_slices;    // > 0: the merge of such a batch as `merge_slices` partial merges per query + merge_replay_kernel
-  int32_t* h_out = nullptr;   // host-buffer pipeline: the lane's pinned block, written by round one's merge itself (MergeRefineArgs::h_out)
-  bool host_written = false;  // ... and whether the path this chunk took did so (else: the copy-out kernel)
   // per round
   int n_active, round;
   const int32_t* active;
@@ -258,6 +256,7 @@ struct freddy_gpu_index {
   std::vector<freddy_gpu_index*> replicas;
   // set when a mutation (append_rows / update_codebook / set_option) failed after it had already changed some of the devices
   // behind this handle: the replicas no longer hold the same tables, so every search fails loudly until the handle is unpinned
+  bool registered = false;        // counted in the registry of backends (core.hip backend_handles)
   bool poisoned = false;
   bool one_launch_failed = false;   // pq_one_kernel once ran out of its bounded polls on this handle: three launches from then on
   // profiling

@@ -443,11 +443,6 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   mr.first_round = r.first() ? 1 : 0; mr.K = K; mr.d = ix->d; mr.sentinel = r.sentinel;
   mr.refine_all = (ix->tune.check_brackets & 1) ? 1 : 0; mr.fence = 0;
   mr.slices = 0; mr.part = nullptr;
-  // round one of a host-buffer sub-batch: the lists straight into the lane's pinned block (w_cnt[5] = the arrival counter, cleared
-  // with the round's other counters by the coarse kernel)
-  const bool to_host = r.h_out && r.first() && r.zeroed && r.merge_slices == 0 && r.active == nullptr;
-  mr.h_out = to_host ? r.h_out : nullptr; mr.h_arrive = ws->w_cnt.as<int32_t>() + 5; mr.h_n = r.n_active;
-  r.host_written = to_host;
   if (r.merge_slices > 0) {
     // a batch over the flat PQ table: `merge_slices` workgroups per query, each over its share of the pseudo-lists (r.W is the
     // padded item count per query, a multiple of the slices), then merge_replay_kernel over the slices' keys
@@ -605,12 +600,10 @@ static int ivfadc_round(IvfRun& r) {
 // state for further rounds stays in r (and in the stream's workspace): ivfadc_finish() runs them.
 static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const float* d_q, int Q, int k, int W,
                         float sentinel, int found_rule, int32_t* d_out_ids, float* d_out_dist,
-                        int32_t* d_status, IvfRun& r, int32_t* h_out = nullptr,
-                        const std::function<int(int, int)>* stage = nullptr) {
+                        int32_t* d_status, IvfRun& r, const std::function<int(int, int)>* stage = nullptr, bool by_pieces = false) {
   // stage(q_lo, q_hi) (host-buffer pipeline): brings the queries [q_lo, q_hi) of this chunk into d_q on stream s -- called once for
   // the whole chunk, or piece by piece with the piece's cell-selection / table launch right behind it
   Workspace* ws = workspace_for(ix, s);
-  r.h_out = h_out; r.host_written = false;
   const int C = ix->C, m = ix->m, K = ix->K;
   if (2 * W > 1024) return fail(FREDDY_E_LIMIT, "W=%d exceeds this build's limit of 512 probes per round", W);
   r.ix = ix; r.ws = ws; r.s = s; r.d_q = d_q; r.Q = Q; r.k = k; r.W = W; r.L = std::min(2 * k, 64 * 16);
@@ -674,7 +667,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
   }
 
   // pieces of whole 32-query tiles; a piece of fewer than 128 queries is not worth a launch of its own
-  int pieces = (stage && ix->tune.coarse_pieces && ivf_coarse_by_pieces(r) && Q >= 512) ? 4 : 1;
+  const int pieces = (stage && by_pieces && ix->tune.coarse_pieces && ivf_coarse_by_pieces(r) && Q >= 512) ? 4 : 1;
   const int per = ((Q + pieces - 1) / pieces + 31) & ~31;
   for (int q_lo = 0; q_lo < Q; q_lo += (pieces > 1 ? per : Q)) {
     const int q_n = pieces > 1 ? std::min(per, Q - q_lo) : Q;
@@ -1065,14 +1058,15 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
     IvfRun r;
     const int n_out = n * k;
     int32_t* h_flag = static_cast<int32_t*>(c.h_out) + 2 * (size_t)n_out + 1 + (size_t)n;
-    *h_flag = 0;   // (before the first launch: the merge of the filter + refine path writes the lists and this word itself)
+    *h_flag = 0;
+    // (a call of ONE sub-batch launches its cell selection piece by piece behind the staged pieces: 0.398 -> 0.374 ms at 2048 queries;
+    // with several lanes the extra launches only get in the way of the other lanes' chains: 0.613 -> 0.666 ms at 4096)
     if ((rc = ivfadc_begin(ix, l.stream, n_lanes * share_call, d_queries, n, k, W, sentinel, found_rule, c.d_ids.as<int32_t>(),
-                           c.d_dist.as<float>(), nullptr, r, ix->tune.merge_to_host ? static_cast<int32_t*>(c.h_out) : nullptr, &stage_piece)))
+                           c.d_dist.as<float>(), nullptr, r, &stage_piece, n_sub == 1)))
       break;
     if (trace) t3 = now_us();
-    if (!r.host_written)   // (every other path: one workgroup copies lists, straggler count and stragglers, then the completion word)
-      hipLaunchKernelGGL(lane_copy_out_flag_kernel, dim3(1), dim3(1024), 0, l.stream, c.d_ids.as<int32_t>(),
-                         c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n, h_flag);
+    hipLaunchKernelGGL(lane_copy_out_flag_kernel, dim3(1), dim3(1024), 0, l.stream, c.d_ids.as<int32_t>(),
+                       c.d_dist.as<float>(), r.ws->w_cnt.as<int32_t>(), r.next, static_cast<int32_t*>(c.h_out), n_out, n, h_flag);
     if (hipGetLastError() != hipSuccess || hipEventRecord(c.done, l.stream) != hipSuccess) { rc = fail(FREDDY_E_HIP, "launch of the result copy failed"); break; }
     c.busy = true;
     if (trace)

@@ -302,6 +302,7 @@ int open_device(freddy_gpu_index* ix, int device) {
   // best for ONE process) -- but several backends with six queues each are together slower than one, so a process that
   // finds other live backends takes two (core.hip choose_hw_queues).  Never overrides the environment; without effect if
   // the runtime is already up.
+  if (!ix->registered) { ix->registered = true; backend_handles(+1); }   // (before the count of the others: two backends that start together see each other)
   choose_hw_queues();
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));

@@ -188,13 +188,6 @@ struct MergeRefineArgs {
   // query's 2k smallest that lie in the slice: selection-then-replay as before, on 4 x as many workgroups.)
   int slices;
   u64* part;
-  // Host-buffer calls (ivfadc.hip, lane pipeline): the lists also go STRAIGHT into the lane's pinned block -- mapped host memory,
-  // [ids n*k][distance bits n*k][n_next][unfinished queries n][completion word] -- and the launch's LAST workgroup (an arrival
-  // counter; nobody waits) puts the straggler count, the stragglers and the completion word the host polls behind them: no copy-out
-  // launch between the merge and the host (one.h / exact2.h hand their lists over the same way).  NULL: device buffers only.
-  int32_t* h_out;
-  int32_t* h_arrive;   // [1] device memory, zero when the launch starts
-  int h_n;             // queries of the sub-batch (n_active of round one)
 };
 
 // MANY = true (with NWV = 12): the instantiation for queries with hundreds of survivor regions (a batch over the flat PQ
@@ -606,27 +599,6 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
       const int slot = atomicAdd(a.n_next, 1);
       a.next_active[slot] = q;
       if (a.status) a.status[0] = 1;
-    }
-  }
-  if (a.h_out) {
-    const size_t n_out = (size_t)a.h_n * k;
-    if (lane < k) {
-      a.h_out[(size_t)q * k + lane] = id_slot;
-      a.h_out[n_out + (size_t)q * k + lane] = __float_as_int(d_slot);
-    }
-    // this workgroup's words are on their way to host memory before it arrives (system-scope release); the last arrival has
-    // therefore seen every list, every straggler and the final count leave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    int last = 0;
-    if (lane == 0) last = __hip_atomic_fetch_add(a.h_arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == a.n_active - 1;
-    if (__builtin_amdgcn_readfirstlane(last)) {
-      int nn = __hip_atomic_load(a.n_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      nn = nn < a.h_n ? nn : a.h_n;
-      if (lane == 0) a.h_out[2 * n_out] = nn;
-      for (int i = lane; i < nn; i += 64)
-        a.h_out[2 * n_out + 1 + i] = __hip_atomic_load(a.next_active + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-      if (lane == 0) __hip_atomic_store(a.h_out + 2 * n_out + 1 + (size_t)a.h_n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }

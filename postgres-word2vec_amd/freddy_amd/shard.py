@@ -3,6 +3,8 @@ queries is split contiguously across ranks, every rank searches its slice, and t
 top-k lists are gathered (RCCL all_gather over xGMI when the backend is "nccl"; gloo on CPU
 for the tests).  There is no exchange step during the search itself -- queries are independent
 (freddy.c:835-982 keeps no cross-query state)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -51,6 +53,17 @@ def sharded_search(search_fn, queries, k, group=None):
     return gather_topk(ids, dd, Q, group)
 
 
+class _AfterEvent:
+    """What next_buffer() waits for when the collective ran on the step's OWN stream: an event behind it."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        if self.event is not None:
+            torch.cuda.current_stream().wait_event(self.event)
+
+
 class PipelinedGather:
     """Pipelined, asynchronous gather of the per-shard top-k (what bench.py times).
 
@@ -70,9 +83,19 @@ class PipelinedGather:
     (torch's CURRENT stream when none is passed) between the two calls.  The collective is enqueued behind that
     stream's work, and next_buffer() makes the stream wait for the gather that last read the buffer.
 
-    force: run the collective path with a single rank too (a 1-rank process group: bench.py --force-collective)."""
+    force: run the collective path with a single rank too (a 1-rank process group: bench.py --force-collective).
 
-    def __init__(self, q_local, k, device, group=None, depth=2, force=False, gather_every=1):
+    in_stream: the collective is called with async_op=False under the step's stream, which makes ProcessGroupNCCL enqueue the
+    RCCL kernel ON THAT STREAM (no internal communication stream, no event hop in and out of it: the searching streams stay the
+    only active ones -- with four batches in flight every further active stream costs hardware-queue sharing, bench.py); the
+    host does not block (stream-ordered); later writers of the group wait for an event recorded behind the collective."""
+
+    def __init__(self, q_local, k, device, group=None, depth=2, force=False, gather_every=1, in_stream=False, comm=None):
+        # comm: a freddy_amd.rccl.Communicator -- the gather is ONE ncclAllGather call on the step's stream (no c10d work object,
+        # events or stream context: rccl.py has the measurements); implies in_stream
+        self.comm = comm
+        self.bound = {}
+        self.in_stream = bool(in_stream) or comm is not None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.collective = (self.world > 1 or force) and dist.is_initialized()
         G = max(1, int(gather_every))
@@ -116,19 +139,44 @@ class PipelinedGather:
                 for j in range(upto):
                     cs.wait_event(self.events[g * self.G + j])
             lo = g * self.G
-            self.pending[g] = dist.all_gather_into_tensor(self.gathered[g].view(-1), self.ring[lo:lo + self.G].view(-1),
-                                                          group=self.group, async_op=True)
+            self.pending[g] = self._all_gather(self.gathered[g].view(-1), self.ring[lo:lo + self.G].view(-1))
         self.unsent = 0
+
+    def _all_gather(self, dst, src):
+        if self.comm is not None and self.cuda:   # (grouped gathers: the caller has set the stream context and waited for the group's events)
+            st = torch.cuda.current_stream()
+            self.comm.all_gather_i32(dst, src, st)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            return _AfterEvent(ev)
+        fake = os.environ.get("FREDDY_LAB_GATHER_FAKE")   # lab: "copy" = a plain device copy, "none" = nothing, in place of the collective
+        if fake and self.cuda:
+            if fake == "copy":
+                dst[:src.numel()].copy_(src, non_blocking=True)
+            return _AfterEvent(None)
+        if not (self.in_stream and self.cuda):
+            return dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+        dist.all_gather_into_tensor(dst, src, group=self.group, async_op=False)   # on the CURRENT stream (set by the caller)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        return _AfterEvent(ev)
 
     def submit(self, stream=None):
         """The step that wrote the buffer handed out last is enqueued: start the gather it completes."""
         if not self.collective:
             return
         b = self.cur
+        if self.G == 1 and self.comm is not None and stream is not None:
+            # RCCL directly on the step's stream.  Nothing to wait for later either: buffer b is rewritten `depth` steps on, and
+            # with depth a multiple of the streams in turn that is the SAME stream -- stream order is the dependency
+            fn = self.bound.get((b, stream.cuda_stream))
+            if fn is None:
+                fn = self.bound[(b, stream.cuda_stream)] = self.comm.bind_all_gather_i32(self.gathered[b].view(-1), self.res[b].view(-1), stream)
+            fn()
+            return
         if self.G == 1:
             with self._ctx(stream):
-                self.pending[b] = dist.all_gather_into_tensor(self.gathered[b].view(-1), self.res[b].view(-1),
-                                                              group=self.group, async_op=True)
+                self.pending[b] = self._all_gather(self.gathered[b].view(-1), self.res[b].view(-1))
             return
         self.unsent += 1
         if b % self.G == self.G - 1:

@@ -19,13 +19,13 @@ def _bench(*args):
     return json.loads(p.stdout.rstrip("\n").splitlines()[-1])
 
 
-@pytest.mark.parametrize("every", [0, 1])
-def test_one_rank_rccl_gather_equals_the_local_buffer(every):
-    line = _bench("--force-collective", "--gather-every", str(every), "--N", "200000", "--C", "100", "--steps", "22", "--warmup", "5",
-                  "--cpu-sample", "1024", "--no-other-configs", "--no-host-abi", "--no-recall", "--ab-rounds", "1")
+@pytest.mark.parametrize("path,every", [("rccl", 1), ("rccl", 4), ("c10d", 1), ("c10d-async", 4)])
+def test_one_rank_rccl_gather_equals_the_local_buffer(path, every):
+    line = _bench("--force-collective", "--gather-path", path, "--gather-every", str(every), "--N", "200000", "--C", "100", "--steps", "22",
+                  "--warmup", "5", "--cpu-sample", "1024", "--no-other-configs", "--no-host-abi", "--no-recall", "--ab-rounds", "1")
     assert line["n_gpus"] == 1 and line["gather_verified"] is True
     assert line["config"]["backend"].startswith("rccl") and line["config"]["world_size"] == 1
-    assert line["config"]["gather_every"] == (every or 4)
+    assert line["config"]["gather_every"] == every and line["config"]["gather_path"] == path
     assert line["cpu_baseline"]["parity_with_gpu_on_sample"] is True      # the buffers the collective path left behind
     det = json.load(open(os.path.join(ROOT, "bench_details_collective.json")))
     ab = det["collective_1rank"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """The host-buffer call (freddy_gpu_ivfadc_search: what pg/freddy_srf.c makes) under the round-6 options, alternating on ONE box:
-merge_to_host (the merge writes lists + completion word into the lane's pinned block itself) x coarse_pieces (the cell-selection /
+coarse_pieces (the cell-selection /
 table launch per staged piece) x pipeline_batch, at 1024 / 2048 / 4096 / 8192 queries per call.   usage: host_abi_ab.py [reps]"""
 import itertools, os, sys, time
 import numpy as np, torch
@@ -23,16 +23,18 @@ print(f"# GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}  reps={reps}",
 ref = {}
 for rnd in range(2):
     for Q in (1024, 2048, 4096, 8192):
-        batches = (2048,) if Q <= 1024 else (1024, 2048) if Q <= 4096 else (1024, 2048)
-        for pb, mth, cp in itertools.product(batches, (0, 1), (0, 1)):
-            index.set_option("pipeline_batch", pb); index.set_option("merge_to_host", mth); index.set_option("coarse_pieces", cp)
+        batches = (512, 2048) if Q <= 1024 else (1024, 2048) if Q <= 4096 else (1024, 2048)
+        for pb, cp in itertools.product(batches, (0, 1)):
+            index.set_option("pipeline_batch", pb); index.set_option("coarse_pieces", cp)
             gi, gd = index.search(hq[:Q], 5, 10)
             if Q not in ref:
                 ref[Q] = (gi.copy(), gd.copy())
             same = np.array_equal(gi, ref[Q][0]) and np.array_equal(gd.view(np.uint32), ref[Q][1].view(np.uint32))
-            n = max(4, reps * 1024 // Q)
+            n = max(8, reps * 1024 // Q)
+            for _ in range(3):
+                index.search(hq[:Q], 5, 10)
             t0 = time.perf_counter()
             for _ in range(n):
                 index.search(hq[:Q], 5, 10)
             dt = (time.perf_counter() - t0) / n
-            print(f"round {rnd} Q={Q:5d} pipeline_batch={pb:5d} merge_to_host={mth} coarse_pieces={cp}: {dt * 1e3:7.4f} ms  {Q / dt / 1e6:6.3f} M q/s  same_lists={same}", flush=True)
+            print(f"round {rnd} Q={Q:5d} pipeline_batch={pb:5d} coarse_pieces={cp}: {dt * 1e3:7.4f} ms  {Q / dt / 1e6:6.3f} M q/s  same_lists={same}", flush=True)
