@@ -58,9 +58,13 @@ struct ExactArgs {
   u64* part;                // [Q][nchunk][EX_WAVES][L]
   int64_t n_rows;
   int n_blocks, chunk_blocks, nchunk, Q, d, L;
+  const u64* floor;         // FLOOR instantiation (k > 1024: a later pass of 1024 keys): [Q] only keys ABOVE the query's floor are offered
 };
 
-template <int V, int EX_QT>
+// FLOOR: lists of more than 1024 entries are selected 1024 keys per pass over the same rows (the reference's ORDER BY ... FETCH FIRST k
+// takes any k, freddy--0.0.1.sql:426-454): pass p admits only keys above the last key pass p - 1 selected.  Keys are unique (the row
+// is part of them) and totally ordered (similarity DESC, row ASC), so the passes' lists simply follow each other.
+template <int V, int EX_QT, bool FLOOR = false>
 __global__ __launch_bounds__(EX_WG) void exact_scan_kernel(ExactArgs a) {
   typedef float v2f __attribute__((ext_vector_type(2)));
   constexpr int QT = EX_QT;
@@ -119,7 +123,10 @@ __global__ __launch_bounds__(EX_WG) void exact_scan_kernel(ExactArgs a) {
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       const float sim = (t & 1) ? acc[t >> 1].y : acc[t >> 1].x;
-      sel[t].push(sim_key(sim, (uint32_t)row), row >= 0);
+      const u64 key = sim_key(sim, (uint32_t)row);
+      bool ok = row >= 0;
+      if constexpr (FLOOR) ok = ok && key > a.floor[(q0 + t < a.Q) ? (q0 + t) : (a.Q - 1)];
+      sel[t].push(key, ok);
     }
   }
 #pragma unroll
@@ -143,7 +150,11 @@ static constexpr int EX_MW = 16;   // at most; the launch uses fewer waves for w
 template <int V>
 __global__ __launch_bounds__(EX_MW * 64) void exact_merge_kernel(const u64* __restrict__ part, int parts_per_query, int L, int k,
                                                                 const int32_t* __restrict__ ids, int32_t* __restrict__ out_ids,
-                                                                float* __restrict__ out_sim) {
+                                                                float* __restrict__ out_sim, int out_off = 0, int out_n = -1,
+                                                                u64* __restrict__ floor_out = nullptr) {
+  // (out_off, out_n, floor_out: a pass of a list of more than 1024 entries -- ranks [0, out_n) go to places out_off.. of the
+  // query's k, and the last selected key becomes the next pass's floor; KEY_INF when the rows ran out: nothing is above it)
+  if (out_n < 0) out_n = k;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int MW = blockDim.x >> 6;
   u64* stage = reinterpret_cast<u64*>(smem);        // [MW][64]
@@ -177,11 +188,12 @@ __global__ __launch_bounds__(EX_MW * 64) void exact_merge_kernel(const u64* __re
 #pragma unroll
   for (int v = 0; v < V; ++v) {
     const int r = v * 64 + lane;
-    if (r < k) {
+    if (r < out_n) {
       const u64 key = fin.acc[v];
-      out_ids[(size_t)q * k + r] = (key == KEY_INF) ? -1 : ids[key_pos(key)];
-      out_sim[(size_t)q * k + r] = (key == KEY_INF) ? -__builtin_huge_valf() : key_sim(key);
+      out_ids[(size_t)q * k + out_off + r] = (key == KEY_INF) ? -1 : ids[key_pos(key)];
+      out_sim[(size_t)q * k + out_off + r] = (key == KEY_INF) ? -__builtin_huge_valf() : key_sim(key);
     }
+    if (floor_out && r == L - 1) floor_out[q] = fin.acc[v];
   }
 }
 

@@ -197,12 +197,12 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
   if (ix->kind != KIND_VEC) return fail(FREDDY_E_KIND, "index handle has the wrong kind for this call");
   if (Q < 0 || k <= 0 || n_subset < 0 || (n_subset > 0 && !subset_ids)) return fail(FREDDY_E_ARG, "bad sizes");
   if (Q > 0 && (!queries || !out_ids || !out_sim)) return fail(FREDDY_E_ARG, "NULL buffer");
-  if (k > 1024) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 1024", k);
+  if (k > 4096) return fail(FREDDY_E_LIMIT, "k=%d exceeds this build's limit of 4096", k);
   if (Q == 0) return FREDDY_OK;
   HIP_TRY(hipSetDevice(ix->device));
   Workspace* ws = workspace_for(ix, ix->stream);
   hipStream_t s = ix->stream;
-  const int d = ix->d, L = k, V = pick_V(L);
+  const int d = ix->d, L = std::min(k, 1024), V = pick_V(L);   // (k > 1024: passes of 1024 keys, below)
   const float* xb = ix->xb;
   const int32_t* pos = nullptr;
   int64_t n_rows = ix->N, n_blocks = ix->n_blocks;
@@ -278,36 +278,55 @@ extern "C" int freddy_gpu_exact_search(freddy_gpu_index_t* ix, const float* quer
   HIP_TRY(hipMemcpyAsync(ws->w_q.p, queries, sizeof(float) * (size_t)Q * d, hipMemcpyHostToDevice, s));
   ExactArgs ea;
   ea.xb = xb; ea.pos = pos; ea.queries = ws->w_q.as<float>(); ea.part = ws->w_part.as<u64>();
-  ea.n_rows = n_rows; ea.n_blocks = (int)n_blocks; ea.chunk_blocks = chunk_blocks; ea.nchunk = nchunk; ea.Q = Q; ea.d = d; ea.L = L;
+  ea.n_rows = n_rows; ea.n_blocks = (int)n_blocks; ea.chunk_blocks = chunk_blocks; ea.nchunk = nchunk; ea.Q = Q; ea.d = d; ea.L = L; ea.floor = nullptr;
   const size_t lds = (((size_t)d * EX_QT * 4 + 15) & ~(size_t)15) + (size_t)EX_WAVES * EX_QT * 64 * sizeof(u64);
   dim3 grid((unsigned)nchunk, (unsigned)qgroups);
-  timed_launch(ix, s, "exact_scan", [&] {
-    switch (V) {
-      case 1: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<1, 16>), grid, dim3(EX_WG), lds, s, ea);
-              else hipLaunchKernelGGL((exact_scan_kernel<1, 8>), grid, dim3(EX_WG), lds, s, ea);
-              break;
-      case 2: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<2, 16>), grid, dim3(EX_WG), lds, s, ea);
-              else hipLaunchKernelGGL((exact_scan_kernel<2, 8>), grid, dim3(EX_WG), lds, s, ea);
-              break;
-      case 4: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<4, 16>), grid, dim3(EX_WG), lds, s, ea);
-              else hipLaunchKernelGGL((exact_scan_kernel<4, 8>), grid, dim3(EX_WG), lds, s, ea);
-              break;
-      case 8: hipLaunchKernelGGL((exact_scan_kernel<8, 8>), grid, dim3(EX_WG), lds, s, ea); break;
-      default: hipLaunchKernelGGL((exact_scan_kernel<16, 8>), grid, dim3(EX_WG), lds, s, ea); break;
-    }
-  });
-  HIP_TRY(hipGetLastError());
   const int ppq = nchunk * EX_WAVES;
-  timed_launch(ix, s, "exact_merge", [&] {
-    switch (V) {
-      case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (1 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
-      case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (2 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
-      case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (4 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
-      case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(8 * 64), (size_t)8 * 64 * (8 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
-      default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (16 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+  if (k > 1024) {
+    // lists of 1025 .. 4096 entries: 1024 keys per pass over the same rows, each pass above the last key of the one before
+    if (ws->w_floor.ensure(sizeof(u64) * (size_t)Q)) return fail(FREDDY_E_NOMEM, "workspace allocation failed");
+    for (int p0 = 0; p0 < k; p0 += 1024) {
+      const int Lp = std::min(1024, k - p0);
+      ea.L = Lp; ea.floor = p0 ? ws->w_floor.as<u64>() : nullptr;
+      timed_launch(ix, s, "exact_scan", [&] {
+        if (p0) hipLaunchKernelGGL((exact_scan_kernel<16, 8, true>), grid, dim3(EX_WG), lds, s, ea);
+        else hipLaunchKernelGGL((exact_scan_kernel<16, 8>), grid, dim3(EX_WG), lds, s, ea);
+      });
+      HIP_TRY(hipGetLastError());
+      timed_launch(ix, s, "exact_merge", [&] {
+        hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (16 + 1) * sizeof(u64), s, ea.part, ppq, Lp, k, ix->ids,
+                           ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>(), p0, Lp, ws->w_floor.as<u64>());
+      });
+      HIP_TRY(hipGetLastError());
     }
-  });
-  HIP_TRY(hipGetLastError());
+  } else {
+    timed_launch(ix, s, "exact_scan", [&] {
+      switch (V) {
+        case 1: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<1, 16>), grid, dim3(EX_WG), lds, s, ea);
+                else hipLaunchKernelGGL((exact_scan_kernel<1, 8>), grid, dim3(EX_WG), lds, s, ea);
+                break;
+        case 2: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<2, 16>), grid, dim3(EX_WG), lds, s, ea);
+                else hipLaunchKernelGGL((exact_scan_kernel<2, 8>), grid, dim3(EX_WG), lds, s, ea);
+                break;
+        case 4: if (EX_QT == 16) hipLaunchKernelGGL((exact_scan_kernel<4, 16>), grid, dim3(EX_WG), lds, s, ea);
+                else hipLaunchKernelGGL((exact_scan_kernel<4, 8>), grid, dim3(EX_WG), lds, s, ea);
+                break;
+        case 8: hipLaunchKernelGGL((exact_scan_kernel<8, 8>), grid, dim3(EX_WG), lds, s, ea); break;
+        default: hipLaunchKernelGGL((exact_scan_kernel<16, 8>), grid, dim3(EX_WG), lds, s, ea); break;
+      }
+    });
+    HIP_TRY(hipGetLastError());
+    timed_launch(ix, s, "exact_merge", [&] {
+      switch (V) {
+        case 1: hipLaunchKernelGGL((exact_merge_kernel<1>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (1 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+        case 2: hipLaunchKernelGGL((exact_merge_kernel<2>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (2 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+        case 4: hipLaunchKernelGGL((exact_merge_kernel<4>), dim3(Q), dim3(16 * 64), (size_t)16 * 64 * (4 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+        case 8: hipLaunchKernelGGL((exact_merge_kernel<8>), dim3(Q), dim3(8 * 64), (size_t)8 * 64 * (8 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+        default: hipLaunchKernelGGL((exact_merge_kernel<16>), dim3(Q), dim3(4 * 64), (size_t)4 * 64 * (16 + 1) * sizeof(u64), s, ea.part, ppq, L, k, ix->ids, ws->w_out_ids.as<int32_t>(), ws->w_out_dist.as<float>()); break;
+      }
+    });
+    HIP_TRY(hipGetLastError());
+  }
   HIP_TRY(hipMemcpyAsync(out_ids, ws->w_out_ids.p, sizeof(int32_t) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipMemcpyAsync(out_sim, ws->w_out_dist.p, sizeof(float) * (size_t)Q * k, hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));

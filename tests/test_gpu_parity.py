@@ -571,6 +571,31 @@ def _exact_expect(oracle, x, ids, qs, k):
     return [oracle.exact_knn(x, ids, q, k) for q in qs]
 
 
+def test_exact_knn_lists_beyond_1024_entries(gpu, oracle):
+    """ORDER BY ... FETCH FIRST k takes any k (freddy--0.0.1.sql:426-454): lists of 1025 .. 4096 entries are selected 1024 keys per
+    pass over the same rows (exact.h FLOOR).  Duplicate rows put equal similarities across a pass boundary; a subset smaller than k
+    pads with (-1, -inf); k = 4097 is refused."""
+    N = 9000
+    x = util.corpus(N).numpy()
+    x[3000:4100] = x[2999]                            # 1101 copies: equal similarities around the 1024-th place for a query near them
+    ids = (np.arange(N) * 2 + 5).astype(np.int32)
+    idx = gpu.VectorIndex(ids, x)
+    qs = np.stack([x[2999], x[17], -x[500]]).astype(np.float32)
+    for k in (1025, 2048, 3000, 4096):
+        gi, gs = idx.search(qs, k)
+        for qi, q in enumerate(qs):
+            exp = oracle.exact_knn(x, ids, q, k)
+            assert gi[qi].tolist() == exp["id"].tolist(), (k, qi)
+            assert np.array_equal(gs[qi].view(np.uint32), exp["dist"].view(np.uint32)), (k, qi)
+    sub = ids[100:1500]                               # 1400 rows, k = 2000: two passes, the second runs out of rows
+    gi, gs = idx.search(qs[:2], 2000, subset_ids=sub)
+    exp = oracle.exact_knn(x, ids, qs[0], 2000, sub)
+    assert gi[0, :1400].tolist() == exp["id"].tolist() and (gi[:, 1400:] == -1).all() and np.isneginf(gs[:, 1400:]).all()
+    with pytest.raises(Exception):
+        idx.search(qs[:1], 4097)
+    idx.close()
+
+
 @pytest.mark.parametrize("scale", [1.0, 3000.0, 2e-4])
 def test_exact_knn_filter_refine_matches_oracle(gpu, oracle, scale):
     """exact2.h: f16-split MFMA similarities with a proven bracket rank the rows, the reference's chain runs for the rows
