@@ -309,9 +309,12 @@ int freddy_gpu_abi_version(void);
  * changes a result.
  *   deployment:  "scan_share" (the batches that share the chip with one of this handle's: the batches the caller keeps in flight
  *                through the *_dev entry points, one stream each, or the other BACKENDS searching at the same time -- a persistent
- *                scan takes n_cus / scan_share CUs; default 1 = the whole chip), "reserve_cus" (CUs a persistent
- *                scan leaves free), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls: queries per sub-batch, 2048;
- *                sub-batches in flight, 1..4), "lut_budget_mb" (workspace cap per call)
+ *                scan takes n_cus / scan_share CUs; default 0 = auto: the whole chip, or half of it for a host-buffer call that
+ *                starts while another backend (process) is searching: the library keeps a registry of live backends in /dev/shm and
+ *                also picks GPU_MAX_HW_QUEUES from it before its first HIP call -- 6 alone, 2 beside others),
+ *                "reserve_cus" (CUs a persistent scan leaves free), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls:
+ *                queries per sub-batch, 2048; sub-batches in flight, 1..4), "coarse_pieces" (1: a call of one sub-batch launches its
+ *                cell selection per staged piece of the queries), "lut_budget_mb" (workspace cap per call)
  *   paths (each has GPU tests of its own):  "fused" (-1 auto, 0 generic kernels, 1 cell-grouped scans always), "fused_kernel"
  *                (5 filter + refine on int16 slabs, 3 the reference's arithmetic for every row), "coarse_approx" (1: cell selection
  *                as filter + refine, 0: every coarse distance exact), "one_launch" (1: a host-buffer call with ONE query -- the

@@ -330,7 +330,7 @@ static __global__ __launch_bounds__(256) void coarse_approx_kernel(const float* 
 
 // ---------------------------------------------------------------------------------------
 // a7 probe plan on the approximate distances: FOUR waves per active query (a single wave per query spends its
-// time waiting on its own dependent instructions: 41 us for the batch, tools/ubench_plan).
+// time waiting on its own dependent instructions: 41 us for the batch, tools/lab/ubench_plan).
 //   1. wave w takes cells [256 w, 256 w + 256): approximate distances into registers (4 per lane), cells
 //      already probed masked;
 //   2. tau = the 2W-th smallest of the 64 per-lane minima over all four waves (>= the 2W-th smallest
@@ -352,7 +352,7 @@ struct Plan2Args {
   float cmax;               // max_j |c_j|, rounded up
   int d;
   int refine_all;           // tests: every unused cell is refined (exhaustive check of the bracket)
-  long long* prof;          // NULL, or [queries][16] cycle sums per phase of wave 0 (tools/ubench_plan)
+  long long* prof;          // NULL, or [queries][16] cycle sums per phase of wave 0 (tools/lab/ubench_plan)
   // STREAM, first round: the minima of the (query, 128-cell tile) blocks (coarse_approx_body) -- NULL: every cell is read twice
   const float* tmin;        // [Q][Cpad / 128]
 };
@@ -378,7 +378,7 @@ __device__ __forceinline__ uint32_t float_order_bits(float f) {   // monotone ma
 // everything, seven candidates per round -- a quarter of the wave slots and of the LDS per query: with several batches in
 // flight, when this kernel has to fit into the CUs the other batches' scans leave, a whole batch is resident on a quarter of
 // the chip (as merge_refine_kernel's one-wave instantiation).
-template <int ABL, bool STREAM = false, int NWP = PLAN2_NW>   // ABL: 0 in production; > 0: timing experiments of tools/ubench_plan (results are wrong)
+template <int ABL, bool STREAM = false, int NWP = PLAN2_NW>   // ABL: 0 in production; > 0: timing experiments of tools/lab/ubench_plan (results are wrong)
 __global__ __launch_bounds__(64 * NWP, NWP == 1 ? 4 : 4) void probe_plan2_kernel(Plan2Args g) {   // (<= 128 registers: four waves per SIMD)
   const PlanArgs& a = g.p;
   constexpr int NW = NWP, NCB = PLAN2_NCB, RC = NW * NCB;   // RC candidates per round
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(64 * NWP, NWP == 1 ? 4 : 4) void probe_plan2_kernel
   if (g.violations && viol) atomicAdd(g.violations + 2, viol);
   if (ABL == 4) { if (n_all == 12345) g.item_dist[0] = 1.0f; return; }
   if (g.violations) {
-#ifdef FREDDY_PLAN2_STATS   // (tools/ubench_plan: candidates per query)
+#ifdef FREDDY_PLAN2_STATS   // (tools/lab/ubench_plan: candidates per query)
     if (lane == 0) atomicAdd(g.violations + 3, n_all);
 #else
     if (g.refine_all && lane == 0) atomicAdd(g.violations + 3, n_all);

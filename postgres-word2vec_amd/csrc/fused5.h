@@ -4,7 +4,7 @@
 // What bounds ivf_filter_kernel (fused4.h) in its main loop is the LDS pipe: per position 48 KB of fp32 slab are
 // written (48 wave-level ds_write_b128) and gathered (8 waves x 8 rows x <= 3 ds_read_b128, a third of the read
 // cycles being bank conflicts), 87 % of the phase (rocprofv3 SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT) -- and the
-// cost of a gather is per ACCESS, not per byte (tools/ubench6.hip).  Here a slab entry is the table's own 16-bit
+// cost of a gather is per ACCESS, not per byte (tools/lab/ubench6.hip).  Here a slab entry is the table's own 16-bit
 // integer:
 //
 //   * the query x codebook table is quantised with ONE scale per query (not per (query, position)) to

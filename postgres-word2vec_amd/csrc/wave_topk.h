@@ -39,7 +39,7 @@ __device__ __forceinline__ int lane_xor(int v, int j) {
     return __builtin_amdgcn_update_dpp(0, t, 0x1B, 0xF, 0xF, true);              // quad_perm [3,2,1,0]
   }
   if (j == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);   // row_ror:8
-  // gfx950's row swaps (checked on the hardware with tools/ubench5): v_permlane16_swap(v, v) leaves the
+  // gfx950's row swaps (checked on the hardware with tools/lab/ubench5): v_permlane16_swap(v, v) leaves the
   // even row's value of each row pair in [0] and the odd row's in [1]; v_permlane32_swap the lower half's
   // in [0] and the upper half's in [1]
   if (j == 16) {

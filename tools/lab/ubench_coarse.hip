@@ -1,11 +1,11 @@
 // GPU-box micro-benchmark: the MFMA coarse-distance kernel (csrc/coarse.h) in isolation, plus ablations of
 // a local copy of it (MODE 1: no query staging, 2: no MFMAs, 3: no centroid loads, 4: no epilogue).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_coarse.hip -o tools/ubench_coarse
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/ubench_coarse.hip -o tools/lab/ubench_coarse
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../postgres-word2vec_amd/csrc/coarse.h"
+#include "../../postgres-word2vec_amd/csrc/coarse.h"
 using namespace freddy;
 
 template <int MODE>

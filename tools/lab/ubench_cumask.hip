@@ -1,7 +1,7 @@
-// tools/ubench_cumask.hip -- which CUs does a CU-masked stream (hipExtStreamCreateWithCUMask) get on this chip?
+// tools/lab/ubench_cumask.hip -- which CUs does a CU-masked stream (hipExtStreamCreateWithCUMask) get on this chip?
 // Every workgroup records (XCC_ID, SE, SH, CU) from the hardware registers; the host prints the distinct CUs per XCC
 // for a few mask patterns, and whether a kernel on the complement mask runs BESIDE a long kernel on the mask.
-//   hipcc --offload-arch=gfx950 -O2 -o tools/ubench_cumask tools/ubench_cumask.hip
+//   hipcc --offload-arch=gfx950 -O2 -o tools/lab/ubench_cumask tools/lab/ubench_cumask.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>

@@ -1,11 +1,11 @@
 // GPU-box micro-benchmark: coarse_approx_kernel + probe_plan2_kernel (csrc/coarse.h) in isolation on clustered data.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/ubench_plan.hip -o tools/ubench_plan
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/lab/ubench_plan.hip -o tools/lab/ubench_plan
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <vector>
-#include "../postgres-word2vec_amd/csrc/coarse.h"
+#include "../../postgres-word2vec_amd/csrc/coarse.h"
 using namespace freddy;
 static float rnd() { return (float)rand() / RAND_MAX - 0.5f; }
 int main(int argc, char** argv) {
