@@ -83,7 +83,7 @@ def test_pipelined_gather_detects_a_wrong_slot():
 
 def _record():
     """Round 4's committed full record in the shape main() builds now (the duplicates inside `roofline` are gone)."""
-    rec = json.load(open(os.path.join(ROOT, "profiles", "r04_h_bench_20steps.json")))
+    rec = json.load(open(os.path.join(ROOT, "tests", "golden", "bench_record_r04.json")))
     abi = rec["roofline"].pop("host_buffer_abi")
     rec["roofline"].pop("other_configs")
     rec["roofline"]["host_abi_q1024_qps"] = abi["Q1024"]["queries_per_s"]
