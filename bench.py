@@ -93,6 +93,7 @@ def parse(argv=None):
                     help="rccl: ONE ncclAllGather call on the searching stream of the step (freddy_amd/rccl.py: a communicator of its own over "
                          "the ranks torch.distributed started); c10d: torch.distributed.all_gather_into_tensor with async_op=False under the "
                          "step's stream; c10d-async: async_op=True on ProcessGroupNCCL's internal stream")
+    ap.add_argument("--one-comm", action="store_true", help="--gather-path rccl with ONE communicator for all searching streams (default: one each)")
     ap.add_argument("--collective-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--ab-rounds", type=int, default=2, help="--force-collective: rounds of (without, with) timed regions")
     ap.add_argument("--reserve-cus", type=int, default=2, help="option reserve_cus of the collective path (CUs every persistent scan leaves free)")
@@ -550,7 +551,9 @@ def run_ivfadc(a, rank, world, dev, dev_index):
     if collective and a.gather_path == "rccl" and a.backend == "nccl":
         try:
             from freddy_amd import rccl
-            comm = rccl.Communicator(dev_index)
+            # one communicator per searching stream (shard.PipelinedGather: RCCL orders the operations of ONE communicator among
+            # themselves across streams); --one-comm: a single communicator for all four
+            comm = rccl.Communicator(dev_index) if a.one_comm else {st.cuda_stream: rccl.Communicator(dev_index) for st in streams}
         except Exception as e:   # (the run goes on through c10d: correct, slower -- and says so in config.gather_path)
             log(rank, f"direct RCCL communicator unavailable ({type(e).__name__}: {e}); the gather goes through c10d")
             gather_path = "c10d (fallback)"
@@ -676,7 +679,8 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         index.set_option("scan_share", 1)
         if comm is not None:
             torch.cuda.synchronize(dev)
-            comm.close()
+            for cm in (comm.values() if isinstance(comm, dict) else [comm]):
+                cm.close()
     scanned_rows = index.last_scanned_rows()
     n_cells, cell_rows = index.last_probed_cells()
     bound_violations = index.bound_violations()   # self-check of the filter + refine scan (must be 0)
@@ -880,6 +884,7 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                        "world_size": (dist.get_world_size() if dist.is_initialized() else 1),
                        "backend": (("rccl (torch.distributed nccl)" if a.backend == "nccl" else a.backend) if collective else "none (single GPU)"),
                        "gather_every": (G if collective else None), "gather_path": gather_path,
+                       "communicators": (len(comm) if isinstance(comm, dict) else (1 if comm is not None else None)),
                        "recall_at_5": None if recall is None else round(recall, 4),
                        "recall_at_5_without_self": None if recall_info is None else recall_info["recall_at_5_without_self"],
                        "host_abi_q1024_qps": (abi_brief.get("Q1024") or {}).get("queries_per_s"),

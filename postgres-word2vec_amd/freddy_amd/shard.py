@@ -91,8 +91,11 @@ class PipelinedGather:
     host does not block (stream-ordered); later writers of the group wait for an event recorded behind the collective."""
 
     def __init__(self, q_local, k, device, group=None, depth=2, force=False, gather_every=1, in_stream=False, comm=None):
-        # comm: a freddy_amd.rccl.Communicator -- the gather is ONE ncclAllGather call on the step's stream (no c10d work object,
-        # events or stream context: rccl.py has the measurements); implies in_stream
+        # comm: a freddy_amd.rccl.Communicator, or {stream handle: Communicator} with one communicator per searching stream -- the
+        # gather is ONE ncclAllGather call on the step's stream (no c10d work object, events or stream context: rccl.py has the
+        # measurements); implies in_stream.  One communicator per stream: RCCL orders the operations of ONE communicator among
+        # themselves (an operation issued on another stream than its predecessor first waits for it), which would tie the four
+        # searching streams' chains together rank by rank; with a communicator each, stream order is the only dependency
         self.comm = comm
         self.bound = {}
         self.in_stream = bool(in_stream) or comm is not None
@@ -145,7 +148,8 @@ class PipelinedGather:
     def _all_gather(self, dst, src):
         if self.comm is not None and self.cuda:   # (grouped gathers: the caller has set the stream context and waited for the group's events)
             st = torch.cuda.current_stream()
-            self.comm.all_gather_i32(dst, src, st)
+            cm = (self.comm.get(st.cuda_stream) or next(iter(self.comm.values()))) if isinstance(self.comm, dict) else self.comm
+            cm.all_gather_i32(dst, src, st)
             ev = torch.cuda.Event()
             ev.record(st)
             return _AfterEvent(ev)
@@ -171,7 +175,8 @@ class PipelinedGather:
             # with depth a multiple of the streams in turn that is the SAME stream -- stream order is the dependency
             fn = self.bound.get((b, stream.cuda_stream))
             if fn is None:
-                fn = self.bound[(b, stream.cuda_stream)] = self.comm.bind_all_gather_i32(self.gathered[b].view(-1), self.res[b].view(-1), stream)
+                cm = self.comm.get(stream.cuda_stream) if isinstance(self.comm, dict) else self.comm
+                fn = self.bound[(b, stream.cuda_stream)] = cm.bind_all_gather_i32(self.gathered[b].view(-1), self.res[b].view(-1), stream)
             fn()
             return
         if self.G == 1:
