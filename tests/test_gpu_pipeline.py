@@ -37,6 +37,29 @@ def test_host_pipeline_cuts_change_nothing(gpu, oracle, batch, lanes):
     idx.close()
 
 
+@pytest.mark.parametrize("Q", [512, 545, 1024, 1999])
+def test_one_lane_call_launches_its_cell_selection_by_pieces(gpu, oracle, Q):
+    """A host-buffer call of ONE sub-batch (>= 512 queries) stages its queries in four pieces of whole 32-query tiles and launches
+    the MFMA cell selection + query table per piece (option coarse_pieces, round 6): lists equal with the option on and off, from
+    pageable and from pinned query buffers, and equal to the oracle's; batch sizes that are not multiples of 32 or 16."""
+    N = 60000
+    t = util.ivf_tables(N=N, C=64, K=1024)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qs = util.queries_from_corpus(N, Q, seed=11)
+    exp = oracle.ivfadc_search_many(ot, qs, 5, 6, sentinel=1000.0, found_rule=0, n_threads=8)
+    pb = gpu.PinnedBuffer(qs.shape)
+    pb.array[:] = qs
+    for pieces in (1, 0, 1):
+        idx.set_option("coarse_pieces", pieces)
+        for src, what in ((qs, "pageable"), (pb.array, "pinned")):
+            got_i, got_d = idx.search(src, 5, 6, sentinel=1000.0, found_rule=gpu.FOUND_ROWS)
+            util.assert_same_lists(got_i, got_d, exp, f"Q={Q} coarse_pieces={pieces} {what}")
+    assert idx.bound_violations() == 0
+    pb.close()
+    idx.close()
+
+
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_host_pipeline_with_extra_probing_rounds(gpu, oracle, fused, monkeypatch):
     """Cells with fewer than k rows force the reference's extra probing rounds (freddy.c:262, :377, :971) -- inside the
