@@ -1279,6 +1279,46 @@ def test_in_flight_instantiations_match_oracle(gpu, oracle, K, monkeypatch):
     idx.close()
 
 
+def test_search_dev_can_be_captured_into_a_graph(gpu, oracle):
+    """freddy_gpu_ivfadc_search_dev only enqueues (kernel launches and memsets on the caller's stream, no allocation once the stream's
+    workspace exists, no synchronisation): a caller may capture a batch's chain into a hipGraph and replay it.  Replays with NEW
+    queries in the same buffers give the oracle's lists.  (Round 6 measured the replay against the plain calls with four batches
+    in flight: 0.0997 against 0.1003 ms per step -- the chain is not launch-bound; tools/lab/graph_replay.py.)"""
+    import torch
+    dev = torch.device("cuda", 0)
+    N = 60000
+    t = util.ivf_tables(N=N, C=64, K=1024)
+    ot = oracle.ivf_table(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    idx = gpu.IVFIndex(t["coarse"], t["codebook"], t["list_off"], t["ids"], t["codes"])
+    _, qa = util.queries_from_corpus(N, 300, seed=29)
+    _, qb = util.queries_from_corpus(N, 300, seed=31)
+    dq = torch.from_numpy(qa).to(dev)
+    st = torch.zeros(4, dtype=torch.int32, device=dev)
+    res = torch.zeros((2, 300, 5), dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(dev)
+    call = idx.bind_search_dev(dq.data_ptr(), 300, 5, 4, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(), res[1].data_ptr(), st.data_ptr(), stream.cuda_stream)
+    call()                                  # (the stream's workspace is allocated by its first search)
+    torch.cuda.synchronize(dev)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=stream):
+        call()
+    for qs in (qa, qb, qa):
+        dq.copy_(torch.from_numpy(qs).to(dev))
+        res.zero_()
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(stream):
+            g.replay()
+        torch.cuda.synchronize(dev)
+        if int(st[0].item()) != 0:
+            st.zero_()
+            continue
+        exp = oracle.ivfadc_search_many(ot, qs, 5, 4, sentinel=1000.0, found_rule=0)
+        util.assert_same_lists(res[0].cpu().numpy(), res[1].view(torch.float32).cpu().numpy(), exp, "graph replay")
+    assert idx.bound_violations() == 0
+    del g
+    idx.close()
+
+
 @pytest.mark.parametrize("share", [0, 3, 8])
 def test_scan_share_gives_the_same_lists(gpu, oracle, share):
     """Option scan_share: the persistent scan on n_cus / share workgroups (the caller's statement of its
