@@ -5,8 +5,8 @@ One "step" = one pass of the hot path over one batch of synthetic queries that a
 HBM: coarse distances (+ the query x codebook table on a side stream) -> probe plan (items bucketed by
 cell) -> work table -> entry records -> the filter kernel (bounded cheap distances, LDS slabs, sums and
 survivor selection) -> merge with the exact stage (the reference's arithmetic for the rows
-that can matter) and the updateTopK replay (+ the asynchronous RCCL gather of the per-shard top-k when
-N > 1).  Results are checked bit for bit against the CPU oracle on the bench queries
+that can matter) and the updateTopK replay (+ with N > 1 the RCCL gather of the per-shard top-k: one ncclAllGather
+call on the step's own stream, freddy_amd/rccl.py; `--force-collective` runs that path with a one-rank group on one GPU).  Results are checked bit for bit against the CPU oracle on the bench queries
 (cpu_baseline.parity_with_gpu_on_sample).
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): 3,000,000 x 300-d synthetic
@@ -85,7 +85,7 @@ def parse(argv=None):
                          "so the front end of batch i+1 runs beside the merge of batch i; 1 = strictly one batch at a time")
     ap.add_argument("--force-collective", action="store_true",
                     help="--gpus 1 through the N > 1 code path: a ONE-rank process group of --backend, the asynchronous all_gather, option "
-                         "reserve_cus, RCCL's stream beside the searching streams (what rank 0 of an N-GPU run does, priced on one GPU)")
+                         "reserve_cus, the per-step ncclAllGather on the searching streams (what rank 0 of an N-GPU run does, priced on one GPU)")
     ap.add_argument("--gather-every", type=int, default=0,
                     help="steps per all_gather of the per-shard top-k (0 or 1 = a collective per step, in the step's stream; G > 1 = one "
                          "collective per group of G steps over a ring of two groups)")
@@ -674,8 +674,8 @@ def run_ivfadc(a, rank, world, dev, dev_index):
             coll_ab = {"with_collective_qps": round(w, 1), "without_qps": round(wo, 1), "ratio": round(w / wo, 4), "rounds": rounds,
                        "gather_every": G, "gather_path": gather_path, "reserve_cus": a.reserve_cus, "backend": a.backend, "steps": a.steps,
                        "gather_verified": gather_ok,
-                       "note": "one process, the same four streams: steps through the world > 1 branch (1-rank process group, asynchronous "
-                               "all_gather_into_tensor per group of gather_every steps, option reserve_cus) against the plain --gpus 1 steps"}
+                       "note": "one process, the same four streams: steps through the world > 1 branch (1-rank process group, the gather of "
+                               "--gather-path per group of gather_every steps, option reserve_cus) against the plain --gpus 1 steps"}
         index.set_option("scan_share", 1)
         if comm is not None:
             torch.cuda.synchronize(dev)
@@ -1282,7 +1282,7 @@ def main():
                 other["exact"] = out.pop("_exact")
             out["other_configs"] = other
             # the N > 1 code path on this one GPU (a child process with a one-rank RCCL group: the asynchronous all_gather,
-            # RCCL's stream beside the four searching streams, option reserve_cus), with and without the collective in ONE process
+            # option reserve_cus), with and without the collective in ONE process
             if not a.force_collective and not a.no_collective_child and a.in_flight > 1:
                 try:
                     torch.cuda.empty_cache()
