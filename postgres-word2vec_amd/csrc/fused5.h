@@ -88,7 +88,10 @@ template <int S, int QT>
 __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ queries, const float* __restrict__ cbT,
                                                      const float* __restrict__ cmax, float* __restrict__ qn,
                                                      float* __restrict__ qscale, uint32_t* __restrict__ qc,
-                                                     int Q, int d, int m, int K, int bx, int by, unsigned char* smem) {
+                                                     int Q, int d, int m, int K, int bx, int by, unsigned char* smem,
+                                                     uint32_t* __restrict__ qc8 = nullptr) {
+  // qc8 (K <= 256, fused8.h): a COMPACT copy of the table beside the general one -- row (query, position) = 128 dwords, dword s =
+  // code s (low half) | code s + 128 (high half): 512 B instead of the 2 KB row of which K = 256 uses a quarter
   static_assert(QT == 16, "one 16-lane group per query");
   constexpr int SP = (S + 3) & ~3;
   // LDS from the caller: qs [QT][SP] floats, inv_s [QT]
@@ -176,6 +179,7 @@ __device__ __forceinline__ void query_codebook5_body(const float* __restrict__ q
             wd[i] = (uint32_t)i0 | ((uint32_t)i1 << 16);
           }
           *reinterpret_cast<uint4*>(qc + ((size_t)(q0 + qi) * m + p) * 512 + 4 * (16 * g + col)) = uint4{wd[0], wd[1], wd[2], wd[3]};
+          if (qc8) qc8[((size_t)(q0 + qi) * m + p) * 128 + (16 * g + col)] = (wd[0] & 0xffffu) | (wd[1] << 16);
         }
       }
     }
@@ -187,9 +191,9 @@ template <int S, int QT>
 __global__ __launch_bounds__(256) void query_codebook5_kernel(const float* __restrict__ queries, const float* __restrict__ cbT,
                                                              const float* __restrict__ cmax, float* __restrict__ qn,
                                                              float* __restrict__ qscale, uint32_t* __restrict__ qc,
-                                                             int Q, int d, int m, int K) {
+                                                             int Q, int d, int m, int K, uint32_t* __restrict__ qc8) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[query_codebook5_lds<S, QT>()];
-  query_codebook5_body<S, QT>(queries, cbT, cmax, qn, qscale, qc, Q, d, m, K, blockIdx.x, blockIdx.y, smem);
+  query_codebook5_body<S, QT>(queries, cbT, cmax, qn, qscale, qc, Q, d, m, K, blockIdx.x, blockIdx.y, smem, qc8);
 }
 
 // The MFMA cell-selection distances (coarse.h) and the query x codebook table in ONE launch: the first `n_coarse`
@@ -205,6 +209,7 @@ struct CoarseTableArgs {
   const float* cbT; const float* cmax; float* qn; float* qscale; uint32_t* qc; int m, K;
   float* tmin; int C;   // many cells: the (query, 128-cell tile) minima for the plan's two-level selection (NULL: not wanted)
   const ch8v* coarseH; int ec;   // many cells: the centroids split into f16 hi / lo (coarse_approx16_body); NULL: the fp32 tile
+  uint32_t* qc8;                 // K <= 256: the compact copy of the table (query_codebook5_body); NULL: not wanted
 };
 template <int S, int QT, bool H16 = false>   // H16: the coarse tiles on f16-split operands (many cells); an instantiation of its own, so
 __global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {   // that the <= 1024-cell kernel compiles as before
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void coarse_table5_kernel(CoarseTableArgs a) {
                        a.coarse_gx, a.coarse_gy, smem, a.tmin, a.C);
   } else {
     const int t = b - n_coarse;
-    query_codebook5_body<S, QT>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, t % a.m, t / a.m, smem);
+    query_codebook5_body<S, QT>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, t % a.m, t / a.m, smem, a.qc8);
   }
 }
 

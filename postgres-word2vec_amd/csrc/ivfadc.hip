@@ -10,6 +10,7 @@
 #include "scan_common.h"
 #include "fused3.h"
 #include "fused5.h"
+#include "fused8.h"
 #include "one.h"
 #include "sparse5.h"
 #include "coarse.h"
@@ -150,6 +151,9 @@ int launch_lut(freddy_gpu_index* ix, hipStream_t s, const float* vecs, const int
 // per-batch query x codebook table beside them on the side stream
 // (q_lo, q_n): the combined MFMA cell-selection + table launch for the queries [q_lo, q_lo + q_n) of the chunk only -- the host-buffer
 // pipeline launches it piece by piece behind the pieces of the staged queries (q_lo a multiple of 32); q_n < 0: the whole chunk
+// K <= 256 with one-byte codes: the scan that keeps the whole entry's slab in LDS (fused8.h) reads a compact copy of the query table,
+// written by the table kernel behind the general one (w_qc: [Q][m][512] + [Q][m][128] dwords)
+static bool scan_whole_slab(const freddy_gpu_index* ix) { return ix->packed8 && ix->tune.codes_u8 == 1 && ix->K <= 256 && ix->m == 12; }
 static bool ivf_coarse_by_pieces(const IvfRun& r) { return r.approx && r.fused && r.scan_kernel == 5; }
 static int ivf_coarse(IvfRun& r, int q_lo = 0, int q_n = -1) {
   Workspace* ws = r.ws;
@@ -214,6 +218,7 @@ static int ivf_coarse(IvfRun& r, int q_lo = 0, int q_n = -1) {
     ct.cbT = ix->cbF; ct.cmax = ix->cmaxp; ct.qn = ws->w_qn.as<float>() + (size_t)q_lo * m; ct.qscale = ws->w_qn.as<float>() + (size_t)Q * m + q_lo;
     ct.qc = ws->w_qc.as<uint32_t>() + (size_t)q_lo * m * 512; ct.m = m; ct.K = K; ct.tmin = tile_min ? tile_min + (size_t)q_lo * (Cpad / 128) : nullptr; ct.C = C;
     ct.coarseH = (const ch8v*)ix->coarseH; ct.ec = ix->coarse_ec;
+    ct.qc8 = scan_whole_slab(ix) ? ws->w_qc.as<uint32_t>() + (size_t)Q * m * 512 + (size_t)q_lo * m * 128 : nullptr;
     const size_t lds = std::max<size_t>(ix->coarseH ? coarse_approx16_lds(d) : (size_t)(COARSE_TQ * (ix->dp + 4) + 128) * sizeof(float), (size_t)query_codebook5_lds<25, 16>());
     const unsigned grid = (unsigned)(ct.coarse_gx * ct.coarse_gy + m * ((q_n + 15) / 16));
     timed_launch(ix, s, "coarse_table", [&] {
@@ -226,7 +231,8 @@ static int ivf_coarse(IvfRun& r, int q_lo = 0, int q_n = -1) {
   if (r.fused && r.scan_kernel == 5) {
     timed_launch(ix, s, "query_codebook", [&] {
       hipLaunchKernelGGL((query_codebook5_kernel<25, 16>), dim3(m, (Q + 15) / 16), dim3(256), 0, s, r.d_q, ix->cbF, ix->cmaxp,
-                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K);
+                         ws->w_qn.as<float>(), ws->w_qn.as<float>() + (size_t)Q * m, ws->w_qc.as<uint32_t>(), Q, d, m, K,
+                         scan_whole_slab(ix) ? ws->w_qc.as<uint32_t>() + (size_t)Q * m * 512 : nullptr);
     });
     HIP_TRY(hipGetLastError());
   }
@@ -366,7 +372,7 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     HIP_TRY(hipGetLastError());
   }
   FilterArgs fl;
-  fl.qc = ws->w_qc.as<uint32_t>(); fl.rterm = ix->rterm; fl.records = ws->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
+  fl.qc = ws->w_qc.as<uint32_t>(); fl.qc8 = ws->w_qc.as<uint32_t>() + (size_t)Q * m * 512; fl.rterm = ix->rterm; fl.records = ws->w_records.as<int32_t>(); fl.n_groups = wt.n_groups;
   fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
   fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.keep_all = (ix->tune.check_brackets & 1) ? 1 : 0; fl.fence = 0;
@@ -374,8 +380,13 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   // 96 -> 128 us -- and its merge gains nothing; an IVFADC batch: +2.6 % queries/s with four batches in flight)
   fl.tau_run = (ix->tune.running_bound && !r.records_ready) ? ws->w_cand.as<uint32_t>() + Q : nullptr;
   if (int rc = scan_prof_buffer(ix, ws, &fl.prof)) return rc;
-  // LDS: slabs [2 buffers][2 positions][K][16 items] int16, then column minima / thresholds, two entry records, row terms
-  const size_t desc_off = (size_t)4 * SCAN5_G * 2 * K;
+  // K <= 256: one byte per code (packed8); the profiling instantiation stays with the int16 layout
+  const bool u8 = ix->packed8 && ix->tune.codes_u8 != 0 && K <= 256;
+  // ... and by default the kernel that keeps the WHOLE entry's slab in LDS (fused8.h; option codes_u8 = 2: fused5.h's one-byte instantiation)
+  const bool whole = u8 && scan_whole_slab(ix);
+  // LDS: slabs [2 buffers][2 positions][K][16 items] int16 (whole: [12 positions][2 halves][256][8 items]), then column minima /
+  // thresholds, two entry records, row terms
+  const size_t desc_off = whole ? (size_t)scan8_slab_bytes(12) : (size_t)4 * SCAN5_G * 2 * K;
   const size_t flds = desc_off + 4096 + 64 + (2 * REC_DW + 4) * sizeof(int32_t) + 4096 * sizeof(float);
   fl.desc_offset = (uint32_t)desc_off;
   // One persistent workgroup per CU (LDS admits exactly one), never more than there is work.  Batches in flight share the
@@ -384,13 +395,18 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   // kernels fit in between, and a scan's workgroups pull more entries each (a shorter tail).
   const int scan_cus = std::max(ix->n_cus / std::max(1, r.share), std::min(ix->n_cus, 32)) - ix->tune.reserve_cus;
   const unsigned n_persist = (unsigned)std::min<size_t>(wt.max_groups, (size_t)std::max(1, scan_cus));
-  // K <= 256: one byte per code (packed8); the profiling instantiation stays with the int16 layout
-  const bool u8 = ix->packed8 && ix->tune.codes_u8 != 0 && K <= 256 && !fl.prof;
   fl.packed8 = u8 ? ix->packed8 : nullptr;
   timed_launch(ix, s, "ivf_filter", [&] {
     // (instantiations: the rule that counts accepted rows doubles the selection code, and the kernel is larger than the
     // instruction cache as it is)
-    if (u8) {
+    if (whole) {
+#ifdef FREDDY_LAB
+      if (fl.prof && !fl.cand_count) hipLaunchKernelGGL((ivf_filter8_kernel<12, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      else
+#endif
+      if (fl.cand_count) hipLaunchKernelGGL((ivf_filter8_kernel<12, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+      else hipLaunchKernelGGL((ivf_filter8_kernel<12, false>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
+    } else if (u8) {
       if (fl.cand_count) hipLaunchKernelGGL((ivf_filter5_kernel<12, false, true, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
       else hipLaunchKernelGGL((ivf_filter5_kernel<12, false, false, false, true>), dim3(n_persist), dim3(SPEC2_T), flds, s, fl);
     } else if (fl.cand_count) {
@@ -430,6 +446,22 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   }
 #ifdef FREDDY_LAB
   if (fl.prof && K == 1024 && !fl.cand_count) if (int rc = scan_prof_print(ix, s, fl.prof, n_persist)) return rc;   // (the counters live in one instantiation)
+  if (fl.prof && whole && !fl.cand_count) {   // fused8.h: gatherer wave 0's stages
+    std::vector<long long> h(8 * (size_t)n_persist);
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(h.data(), fl.prof, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    double sum[8] = {0}, life_max = 0, life_min = 1e30;
+    for (unsigned b = 0; b < n_persist; ++b) {
+      for (int i = 0; i < 8; ++i) sum[i] += (double)h[b * 8 + i];
+      life_max = std::max(life_max, (double)h[b * 8 + 7]); life_min = std::min(life_min, (double)h[b * 8 + 7]);
+    }
+    int32_t ng = 0;
+    HIP_TRY(hipMemcpy(&ng, wt.n_groups, 4, hipMemcpyDeviceToHost));
+    const double e = std::max(1, ng);
+    fprintf(stderr, "[scan8 prof] wgs=%u entries=%d  gatherer wave 0 cycles/entry: gather=%.0f B1=%.0f colmin=%.0f B2=%.0f S1=%.0f B3=%.0f S2+B4=%.0f | workgroup life cycles: mean %.0f min %.0f max %.0f, sum of stages per workgroup %.0f\n",
+            n_persist, ng, sum[0] / e, sum[1] / e, sum[2] / e, sum[3] / e, sum[4] / e, sum[5] / e, sum[6] / e, sum[7] / n_persist, life_min, life_max,
+            (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6]) / n_persist);
+  }
 #endif
 
   MergeRefineArgs mr;
@@ -655,7 +687,7 @@ static int ivfadc_begin(freddy_gpu_index* ix, hipStream_t s, int share, const fl
     if (r.scan_kernel == 2 && ws->w_lut.ensure(sizeof(float) * items * (size_t)m * K))
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
     if (r.scan_kernel == 5 &&
-        (ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))
+        (ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 640) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2)))   // (512 + 128: the compact copy, fused8.h)
       return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d, W=%d)", Q, W);
   } else {
     // (a later probing round has fewer items and may take the finer chunks: room for either)
@@ -1120,8 +1152,9 @@ int raise_lds_limits_ivfadc(int device) {
       (const void*)&ivf_filter5_kernel<12, true, false>, (const void*)&ivf_filter5_kernel<12, false, false>,
       (const void*)&ivf_filter5_kernel<12, true, true>, (const void*)&ivf_filter5_kernel<12, false, true>,
       (const void*)&ivf_filter5_kernel<12, false, false, false, true>, (const void*)&ivf_filter5_kernel<12, false, true, false, true>,
+      (const void*)&ivf_filter8_kernel<12, false>, (const void*)&ivf_filter8_kernel<12, true>,
 #ifdef FREDDY_LAB
-      (const void*)&ivf_filter5_kernel<12, true, false, true>,
+      (const void*)&ivf_filter5_kernel<12, true, false, true>, (const void*)&ivf_filter8_kernel<12, false, true>,
 #endif
       (const void*)&coarse_approx_kernel, (const void*)&coarse_approx16_kernel, (const void*)&ivf_multi_kernel};
   for (const void* k : kernels)

@@ -81,6 +81,7 @@ struct PqFrontArgs {
   const int32_t* blk_off; const int32_t* list_off;
   const float* cbT; const float* cmax; const float* pmax;
   float* qn; float* qscale; uint32_t* qc; int m, K;
+  uint32_t* qc8;   // K <= 256: the compact copy of the table (fused8.h); NULL: not wanted
   float sentinel;
   int32_t* item_cell; int32_t* item_query; float* item_dist; int32_t* round_rows; int32_t* records; int32_t* n_groups;
   ZeroArgs z;   // the call's scratch that must start at zero (counters, running bounds, survivor counts): no memset launches in front
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void pq_front_kernel(PqFrontArgs a) {
     for (int r = 0; r < 5; ++r)
       for (int i = gtid; i < a.z.n[r]; i += gsz) a.z.p[r][i] = 0u;
   }
-  if (b < n_table) query_codebook5_body<25, 16>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, b % a.m, b / a.m, smem);
+  if (b < n_table) query_codebook5_body<25, 16>(a.queries, a.cbT, a.cmax, a.qn, a.qscale, a.qc, a.Q, a.d, a.m, a.K, b % a.m, b / a.m, smem, a.qc8);
   else pq_records_body(a, b - n_table, smem);
 }
 
@@ -261,7 +262,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
       ws->w_cnt.ensure(sizeof(int32_t) * 8) || ws->w_records.ensure(sizeof(int32_t) * REC_DW * n_entries) ||
       ws->w_surv.ensure(sizeof(u64) * items * r.upi * FUSED_NW * FUSED_RMAX * 64) ||
       ws->w_surv_cnt.ensure(sizeof(int32_t) * items * r.upi * FUSED_NW) ||
-      ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 512) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))
+      ws->w_qc.ensure(sizeof(uint32_t) * (size_t)Q * m * 640) || ws->w_qn.ensure(sizeof(float) * (size_t)Q * m * 2))   // (512 + 128: the compact copy for K <= 256, fused8.h)
     return fail(FREDDY_E_NOMEM, "workspace allocation failed (Q=%d over %d pseudo-lists)", Q, lists);
   r.next = ws->w_act0.as<int32_t>();
   PlanArgs pa;
@@ -277,7 +278,8 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   PqFrontArgs fa;
   fa.queries = d_q; fa.Q = Q; fa.d = fx->d; fa.lists = lists; fa.W = W; fa.n_rows = fx->N; fa.blk_off = fx->blk_off; fa.list_off = fx->list_off;
   fa.cbT = fx->cbF; fa.cmax = fx->cmaxp; fa.pmax = fx->pmax; fa.qn = ws->w_qn.as<float>(); fa.qscale = ws->w_qn.as<float>() + (size_t)Q * m;
-  fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
+  fa.qc = ws->w_qc.as<uint32_t>(); fa.m = m; fa.K = K; fa.sentinel = sentinel;
+  fa.qc8 = (fx->packed8 && fx->tune.codes_u8 == 1 && K <= 256 && m == 12) ? ws->w_qc.as<uint32_t>() + (size_t)Q * m * 512 : nullptr; fa.item_cell = pa.item_cell; fa.item_query = pa.item_query;
   fa.item_dist = pa.item_dist; fa.round_rows = pa.round_rows; fa.records = ws->w_records.as<int32_t>(); fa.n_groups = wt.n_groups;
   // (w_cnt[1] = n_groups is WRITTEN by this launch's record workgroups: not among the words it clears)
   fa.z.p[0] = ws->w_cnt.as<uint32_t>(); fa.z.n[0] = 1;

@@ -51,6 +51,7 @@ struct FilterArgs {
   // reads whatever is there (no waiting, any stale value is a valid bound), so the survivors differ from run to run and the
   // lists never do.  NULL: off.
   uint32_t* tau_run;
+  const uint32_t* qc8;         // fused8.h (K <= 256): [Q][M][128] the compact copy of the table: dword s = code s | code s + 128 << 16
 };
 
 // The integer-slab scan (fused5.h) quantises the table with one scale per query; its margin (derivation there):

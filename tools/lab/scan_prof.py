@@ -12,7 +12,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 3_000_000
 Q = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 dev = torch.device("cuda", 0)
 x = ib.make_corpus(N, d=300, seed=20260101, device=dev)
-tab = ib.build_ivf_index(x, C=1000, m=12, K=1024, train_size=100000, iters=10, seed=2)
+tab = ib.build_ivf_index(x, C=1000, m=12, K=int(os.environ.get("K", "1024")), train_size=100000, iters=10, seed=2)
 index = gpu.IVFIndex(tab["coarse"], tab["codebook"], tab["list_off"], tab["ids"], tab["codes"], device=0)
 rng = np.random.default_rng(7)
 qid = np.sort(rng.choice(np.arange(1, N + 1), size=Q, replace=False))
