@@ -28,6 +28,19 @@ static constexpr uint32_t SCAN8_HALFB = 256u * 16u;         // one plane: the va
 static constexpr uint32_t SCAN8_POSB = 2u * SCAN8_HALFB;    // one position: two planes (items 0-7, 8-15)
 static constexpr uint32_t scan8_slab_bytes(int m) { return (uint32_t)m * SCAN8_POSB; }
 
+// S1 for ONE item (every wave of the workgroup takes one: builders items 0-7, gatherers 8-15): tau' = the L-th smallest of the
+// item's 64 column minima, lowered by the query's running bound, widened by E -> thr_s[i]; the column is re-armed.
+__device__ __forceinline__ void scan8_threshold(const FilterArgs& a, const int32_t* rec, uint32_t* colmin, uint32_t* thr_s, int i, int lane, uint32_t run) {
+  uint32_t c = colmin[i * 64 + lane];
+  c = wave_sort32(c);   // (order-preserving keys of the float column minima)
+  uint32_t t = __shfl(c, a.L - 1, 64);
+  if (lane == 0) {
+    if (a.tau_run) t = running_bound5(a.tau_run, (uint32_t)rec[24 + i], t, __int_as_float(rec[144 + i]), __int_as_float(rec[160 + i]), run);
+    thr_s[i] = a.keep_all ? 0x7f800000u : widen_threshold5(t, __int_as_float(rec[56 + i]));
+  }
+  colmin[i * 64 + lane] = 0xffffffffu;
+}
+
 template <int M, bool CAND, bool PROF = false>   // PROF (lab builds): cycle sums of gatherer wave 0 per stage
 __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
   constexpr int G = SCAN5_G, RMAX = FUSED_RMAX, NG = SPEC2_NG;
@@ -161,7 +174,12 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
       }
       lds_barrier();   // B1: this entry's slab is consumed; the next record is visible
       if (have_next) emit_all(next_nh);     // (LDS stores only: the words arrived during the gather)
-      lds_barrier();   // B2: the gatherers have this entry's row terms in registers
+      // the running bound of this wave's item (S1 below): requested before the barrier
+      uint32_t run_b = 0u;
+      const int cnt_b = __builtin_amdgcn_readfirstlane(dsc[cur * REC_DW + 1]);
+      if (a.tau_run && wave < cnt_b) run_b = a.tau_run[(uint32_t)dsc[cur * REC_DW + 24 + wave]];
+      lds_barrier();   // B2: the gatherers have this entry's row terms in registers, every column minimum is in
+      if (wave < cnt_b) scan8_threshold(a, dsc + cur * REC_DW, colmin, thr_s, wave, lane, run_b);   // S1, item `wave`
       if (have_next) stash_row_terms();
       lds_barrier();   // B3
       lds_barrier();   // B4: the next entry's slab and row terms are complete
@@ -270,12 +288,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
           default: main_loop(I2{}, I8{}); break;
         }
       }
-      // the running bounds of this wave's two items (S1 below): on their way during the column minima
-      uint32_t run0 = 0u, run1 = 0u;
-      if (a.tau_run) {
-        run0 = gw < cnt ? a.tau_run[(uint32_t)rec[24 + gw]] : 0u;
-        run1 = gw + NG < cnt ? a.tau_run[(uint32_t)rec[24 + gw + NG]] : 0u;
-      }
+      // the running bound of this wave's item (S1 below: gatherer wave gw takes item gw + 8): on its way during the column minima
+      uint32_t run1 = 0u;
+      if (a.tau_run) run1 = gw + NG < cnt ? a.tau_run[(uint32_t)rec[24 + gw + NG]] : 0u;
       gtick(0);
       lds_barrier();   // B1: the slab is free for the next entry
       gtick(1);
@@ -337,25 +352,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
       gtick(2);
       lds_barrier();   // B2: every wave's column minima are in
       gtick(3);
-      // S1: thresholds tau' + E of items gw and gw + 8 (the builders are building the next slab)
-      {
-        const int i0 = gw, i1 = gw + NG;
-        if (i0 < cnt) {
-          uint32_t c0 = colmin[i0 * 64 + lane], c1 = colmin[i1 * 64 + lane];
-          wave_sort32_x2(c0, c1);
-          uint32_t t0 = __shfl(c0, a.L - 1, 64), t1 = __shfl(c1, a.L - 1, 64);
-          if (lane == 0) {
-            if (a.tau_run) {
-              t0 = running_bound5(a.tau_run, (uint32_t)rec[24 + i0], t0, __int_as_float(rec[144 + i0]), __int_as_float(rec[160 + i0]), run0);
-              if (i1 < cnt) t1 = running_bound5(a.tau_run, (uint32_t)rec[24 + i1], t1, __int_as_float(rec[144 + i1]), __int_as_float(rec[160 + i1]), run1);
-            }
-            thr_s[i0] = a.keep_all ? 0x7f800000u : widen_threshold5(t0, __int_as_float(rec[56 + i0]));
-            thr_s[i1] = a.keep_all ? 0x7f800000u : widen_threshold5(t1, __int_as_float(rec[56 + i1]));
-          }
-          colmin[i0 * 64 + lane] = 0xffffffffu;
-          colmin[i1 * 64 + lane] = 0xffffffffu;
-        }
-      }
+      // S1: the threshold tau' + E of item gw + 8 (the builder waves take items 0-7 at the same time)
+      if (gw + NG < cnt) scan8_threshold(a, rec, colmin, thr_s, gw + NG, lane, run1);
       gtick(4);
       lds_barrier();   // B3: thresholds
       gtick(5);

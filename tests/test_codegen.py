@@ -27,6 +27,7 @@ CEILINGS = os.path.join(ROOT, "tests", "golden", "codegen_ceilings.json")
 PROBES = {
     "ivf_filter5_kernel<12,FULLK>": ("fused5.h", "ivf_filter5_kernel<12, true, false>", "ivf_filter5_kernelILi12ELb1ELb0ELb0ELb0EE"),
     "ivf_filter5_kernel<12,U8>": ("fused5.h", "ivf_filter5_kernel<12, false, false, false, true>", "ivf_filter5_kernelILi12ELb0ELb0ELb0ELb1EE"),
+    "ivf_filter8_kernel<12>": ("fused8.h", "ivf_filter8_kernel<12, false>", "ivf_filter8_kernelILi12ELb0ELb0EE"),
     "merge_refine_kernel<25,12,1>": ("fused5.h", "merge_refine_kernel<25, 12, 1>", "merge_refine_kernelILi25ELi12ELi1ELb0ELb0EE"),
     "merge_refine_kernel<25,12,4>": ("fused5.h", "merge_refine_kernel<25, 12, 4>", "merge_refine_kernelILi25ELi12ELi4ELb0ELb0EE"),
     "exf_filter_kernel<2,false>": ("exact2.h", "exf_filter_kernel<2, false>", "exf_filter_kernelILi2ELb0EE"),
@@ -66,7 +67,7 @@ def probe(name, tmp):
 
 
 def measure(tmp):
-    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+    with ThreadPoolExecutor(max_workers=min(7, os.cpu_count() or 1)) as ex:
         return dict(zip(PROBES, ex.map(lambda n: probe(n, tmp), PROBES)))
 
 

@@ -929,15 +929,17 @@ def test_sparse_item_scan_bracket_holds_for_every_row(gpu, oracle, monkeypatch):
 @pytest.mark.gpu
 def test_one_byte_code_layout_equals_the_int16_layout(gpu, oracle, monkeypatch):
     """K <= 256 (the reference's shipped default indexes): the integer-slab scans read packed8 -- one byte per code, 16 instead of
-    28 B per row -- unless option codes_u8 = 0 keeps the int16 layout.  Same lists from both, for the cell-grouped scan and the
-    item-wise one, with every row's bracket checked, and after rows were appended (the byte array is rebuilt)."""
+    28 B per row -- unless option codes_u8 = 0 keeps the int16 layout.  codes_u8 = 1 (default) is the scan that keeps the whole work
+    entry's slab in LDS and reads the compact copy of the query table (fused8.h, round 6), 2 the six-phase kernel's one-byte
+    instantiation (fused5.h).  Same lists from all three, for the cell-grouped scan and the item-wise one, both found rules, with
+    every row's bracket checked, and after rows were appended (the byte array is rebuilt)."""
     monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
     t, ot, idx, qs = _fr_setup(gpu, oracle, K=256, dup_rows=3)
     for sparse in (0, -16):
         idx.set_option("sparse_items", sparse)
         for k, W, rule, sent in ((5, 3, 0, 1000.0), (10, 4, 1, 100.0), (32, 2, 0, 1000.0)):
             exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-            for u8 in (1, 0):
+            for u8 in (1, 2, 0):
                 idx.set_option("codes_u8", u8)
                 gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
                 util.assert_same_lists(gi, gd, exp, f"codes_u8={u8} sparse_items={sparse} k={k} W={W} rule={rule}")
@@ -966,7 +968,7 @@ def test_one_byte_code_layout_equals_the_int16_layout(gpu, oracle, monkeypatch):
         off2.append(off2[-1] + len(ids2[-1]))
     ot2 = oracle.ivf_table(t["coarse"], t["codebook"], np.array(off2, np.int32), np.concatenate(ids2), np.concatenate(codes2))
     exp = oracle.ivfadc_search_many(ot2, qs, 5, 3, sentinel=1000.0, found_rule=0)
-    for u8 in (1, 0):
+    for u8 in (1, 2, 0):
         idx.set_option("codes_u8", u8)
         gi, gd = idx.search(qs, 5, 3, sentinel=1000.0, found_rule=0)
         util.assert_same_lists(gi, gd, exp, f"after append, codes_u8={u8}")
