@@ -325,7 +325,8 @@ int freddy_gpu_abi_version(void);
  *                many queries of a batch probe are scanned item by item; default 2, 0 = never, a negative value forces it for
  *                cells of up to that many items whatever the batch), "running_bound" (1: the scan's work entries share a
  *                per-query bound of the L-th smallest cheap distance), "codes_u8" (1: indexes with K <= 256 are scanned from one
- *                byte per code; 0: the int16 layout), "exact_filter" (exact brute-force kNN as f16-split MFMA filter + exact
+ *                byte per code by the kernel that keeps a whole work entry's slab in LDS; 2: one byte per code, the six-phase kernel;
+ *                0: the int16 layout), "exact_filter" (exact brute-force kNN as f16-split MFMA filter + exact
  *                refine: -1 = tables of >= 8192 rows and k <= 32, 0 never -- and no fragment copy of a table pinned with it --,
  *                1 always)
  *   self-checks (tests):  "check_brackets" (bit 0: the scan keeps and the merge refines EVERY probed row, bit 1: the cell

@@ -71,7 +71,7 @@ struct Tuning {
   int sparse_items = 2;        // FREDDY_GPU_SPARSE_ITEMS: cells that at most this many queries of a batch probe are scanned item by item (sparse5.h) instead of as cell-grouped work entries (0 = never, < 0 = always for cells of up to that many items)
   int running_bound = 1;       // FREDDY_GPU_RUNNING_BOUND: the scan's entries share a per-query running bound of the L-th smallest cheap distance
                                // (FilterArgs::tau_run): fewer survivors for the merge; 0 = every (item, chunk) cuts at its own threshold
-  int codes_u8 = 1;            // FREDDY_GPU_CODES_U8: K <= 256: the integer-slab scans read one byte per code (packed8, 16 instead of 28 B per row); 0 = the int16 layout
+  int codes_u8 = 1;            // FREDDY_GPU_CODES_U8: K <= 256: the integer-slab scans read one byte per code (packed8, 16 instead of 28 B per row) -- 1: the scan with the whole entry's slab in LDS (fused8.h), 2: the six-phase scan (fused5.h); 0 = the int16 layout
   int exact_filter = -1;       // FREDDY_GPU_EXACT_FILTER: exact kNN as MFMA filter + exact refine (exact2.h): -1 auto (tables of >= 8192 rows, k <= 32), 0 never, 1 always
   // -- self-checks (tests): bit 0 = the scan keeps every row and the merge refines every row (every probed row's bracket is checked),
   //    bit 1 = the cell selection refines every cell, bit 2 = exact kNN refines every row
