@@ -66,12 +66,14 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
   const int n_work = a.n_groups[0];
 
   int cur = 0, ei = 0;
-  if (tid == 0) { gidq[0] = atomicAdd(a.work_counter, 1); gidq[1] = atomicAdd(a.work_counter, 1); }
+  // The first entry of a workgroup is its own number (the entries are ordered largest first: the grid takes the first gridDim.x of
+  // them, one each); the work counter deals out the entries BEYOND those.  A workgroup so starts with ONE round trip -- its record
+  // and the claim of its second entry together -- instead of two dependent atomics and then the record.
+  if (tid == 0) { gidq[0] = (int)blockIdx.x; gidq[1] = (int)gridDim.x + atomicAdd(a.work_counter, 1); }
+  if ((int)blockIdx.x < n_work && tid < REC_DW) dsc[tid] = a.records[(size_t)blockIdx.x * REC_DW + tid];
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
   __syncthreads();
-  if (gidq[0] >= n_work) return;
-  if (tid < REC_DW) dsc[tid] = a.records[(size_t)gidq[0] * REC_DW + tid];
-  __syncthreads();
+  if ((int)blockIdx.x >= n_work) return;
 
   if (builder) {
     // =====================================================================================
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
         int32_t rr0 = 0;
         int gid2 = 0;
         if (tid < REC_DW && have_next) rr0 = a.records[(size_t)ngid * REC_DW + tid];
-        if (tid == 0) gid2 = atomicAdd(a.work_counter, 1);
+        if (tid == 0) gid2 = (int)gridDim.x + atomicAdd(a.work_counter, 1);
         if (have_next) {
           const int32_t* grec = a.records + (size_t)ngid * REC_DW;
           next_nh = entry_queries(grec);
