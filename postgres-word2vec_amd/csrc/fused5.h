@@ -329,7 +329,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
   // them, one each); the work counter deals out the entries BEYOND those.  A workgroup so starts with ONE round trip -- its record
   // and the claim of its second entry together -- instead of two dependent atomics and then the record.
   if (tid == 0) { gidq[0] = (int)blockIdx.x; gidq[1] = (int)gridDim.x + atomicAdd(a.work_counter, 1); }
-  if ((int)blockIdx.x < n_work && tid < REC_DW) dsc[tid] = a.records[(size_t)blockIdx.x * REC_DW + tid];
+  if (tid < REC_DW) dsc[tid] = a.records[(size_t)blockIdx.x * REC_DW + tid];   // (before n_work is known: the grid never exceeds the records' capacity)
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
   __syncthreads();
   if ((int)blockIdx.x >= n_work) return;

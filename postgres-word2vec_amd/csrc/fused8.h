@@ -70,7 +70,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
   // them, one each); the work counter deals out the entries BEYOND those.  A workgroup so starts with ONE round trip -- its record
   // and the claim of its second entry together -- instead of two dependent atomics and then the record.
   if (tid == 0) { gidq[0] = (int)blockIdx.x; gidq[1] = (int)gridDim.x + atomicAdd(a.work_counter, 1); }
-  if ((int)blockIdx.x < n_work && tid < REC_DW) dsc[tid] = a.records[(size_t)blockIdx.x * REC_DW + tid];
+  if (tid < REC_DW) dsc[tid] = a.records[(size_t)blockIdx.x * REC_DW + tid];   // (before n_work is known: the grid never exceeds the records' capacity)
   for (int i = tid; i < 16 * 64; i += SPEC2_T) colmin[i] = 0xffffffffu;
   __syncthreads();
   if ((int)blockIdx.x >= n_work) return;
@@ -212,6 +212,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
     long long gt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gc = 0;
     auto gtick = [&](int slot) { if constexpr (PROF) { const long long t = clock64(); if (slot >= 0) gt[slot] += t - gc; gc = t; } };
     lds_barrier();   // B0
+    if constexpr (PROF) { gt[7] = clock64() - t_kernel; }   // (the prologue: kernel start .. first slab ready)
     for (;;) {
       gtick(-1);
       const int32_t* rec = dsc + cur * REC_DW;
@@ -446,14 +447,16 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
       }
       const int next_ok = __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 6]);
       if (next_ok > 0) prefetch_codes(dsc + nb * REC_DW);
-      gtick(6);
+      gtick(5);
       lds_barrier();   // B4
-      gtick(7);
+      gtick(5);
       if (next_ok < 0) break;
       cur = nb;
     }
     if (PROF && a.prof && gw == 0 && lane == 0) {
-      for (int i = 0; i < 7; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = gt[i] + (i == 6 ? gt[7] : 0);   // (S2 + B4 in one slot)
+      for (int i = 0; i < 6; ++i) a.prof[(size_t)blockIdx.x * 8 + i] = gt[i];
+      a.prof[(size_t)blockIdx.x * 8 + 6] = gt[6] + (clock64() - gc) * 0;                                   // S2 (the wait at B4 is in the life, not here)
+      a.prof[(size_t)blockIdx.x * 8 + 6] = gt[7];                                                          // slot 6: the prologue
       a.prof[(size_t)blockIdx.x * 8 + 7] = clock64() - t_kernel;                                           // the workgroup's whole life
     }
   }

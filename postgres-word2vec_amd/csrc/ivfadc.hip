@@ -458,9 +458,9 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
     int32_t ng = 0;
     HIP_TRY(hipMemcpy(&ng, wt.n_groups, 4, hipMemcpyDeviceToHost));
     const double e = std::max(1, ng);
-    fprintf(stderr, "[scan8 prof] wgs=%u entries=%d  gatherer wave 0 cycles/entry: gather=%.0f B1=%.0f colmin=%.0f B2=%.0f S1=%.0f B3=%.0f S2+B4=%.0f | workgroup life cycles: mean %.0f min %.0f max %.0f, sum of stages per workgroup %.0f\n",
-            n_persist, ng, sum[0] / e, sum[1] / e, sum[2] / e, sum[3] / e, sum[4] / e, sum[5] / e, sum[6] / e, sum[7] / n_persist, life_min, life_max,
-            (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5] + sum[6]) / n_persist);
+    fprintf(stderr, "[scan8 prof] wgs=%u entries=%d  gatherer wave 0 cycles/entry: gather=%.0f B1=%.0f colmin=%.0f B2=%.0f S1=%.0f B3+S2+B4=%.0f | per workgroup: prologue %.0f, stages %.0f, life mean %.0f min %.0f max %.0f\n",
+            n_persist, ng, sum[0] / e, sum[1] / e, sum[2] / e, sum[3] / e, sum[4] / e, sum[5] / e, sum[6] / n_persist,
+            (sum[0] + sum[1] + sum[2] + sum[3] + sum[4] + sum[5]) / n_persist, sum[7] / n_persist, life_min, life_max);
   }
 #endif
 
