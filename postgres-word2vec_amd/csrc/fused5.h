@@ -515,6 +515,23 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
     const int gw = wave - SPEC2_NB;
     uint32_t acc[G / 2][RMAX];     // [item pair][row]: low half = item 2i, high half = item 2i + 1
     uint32_t cwa[RMAX], cwb[RMAX]; // code dwords of the even / odd phases (double buffered: requested a phase ahead)
+    // the first two rows' code dwords of phase 0 of the COMING entry, requested an entry ahead (at the end of the survivor pass): a
+    // gatherer otherwise starts every entry with an exposed round trip for row 0's codes (the other rows' arrive behind it)
+    constexpr int NPRE = 2;
+    uint32_t cpre[NPRE] = {};
+    auto prefetch_first_codes = [&](const int32_t* rc) {
+      const int b0 = __builtin_amdgcn_readfirstlane(rc[3]), nbk = __builtin_amdgcn_readfirstlane(rc[4]);
+      const uint32_t l4 = lane_byte4();
+#pragma unroll
+      for (int r = 0; r < NPRE; ++r) {
+        const int bl = r * NG + gw;
+        const uint32_t blk = (uint32_t)(b0 + (bl < nbk - 1 ? bl : nbk - 1));
+        const char* rowp = U8 ? reinterpret_cast<const char*>(a.packed8) + (size_t)(blk * (uint32_t)(M / 4)) * 256u
+                              : reinterpret_cast<const char*>(a.packed) + (size_t)(blk * (uint32_t)(M / 2)) * 256u;
+        cpre[r] = *reinterpret_cast<const uint32_t*>(rowp + l4);
+      }
+    };
+    prefetch_first_codes(dsc);
     lds_barrier();   // (pairs with the builders' barrier after the first slab)
     long long gt[3] = {0, 0, 0}, gc = 0;
     auto gtick = [&](int slot) { if constexpr (PROF) { const long long t = clock64(); if (slot >= 0) gt[slot] += t - gc; gc = t; } };
@@ -588,6 +605,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
 #pragma unroll
           for (int r = 0; r < RMAX; ++r) acc[h][r] = 0u;
         load_codes(cwa, 0);
+#pragma unroll
+        for (int r = 0; r < NPRE; ++r) if (r < RL) cwa[r] = cpre[r];   // (requested an entry ahead; the loads above for these rows are dropped by the compiler)
         load_codes(cwb, 1);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -780,6 +799,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
       }
       gtick(2);
       const int next_ok = __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 6]);
+      if (next_ok > 0) prefetch_first_codes(dsc + nb * REC_DW);
       lds_barrier();
       if (next_ok < 0) break;
       cur = nb;
