@@ -30,6 +30,8 @@ cp profiles/latest_pmc.json gpurun_out/prof/${TAG}_latest_pmc.json
 # larger batches on one GPU (SURVEY 8e asks for a Q >= 8192 variant)
 bench ${TAG}_bench_Q8192 --steps 20 --warmup 4 --Q 8192 --cpu-sample 0 --no-recall --no-host-abi
 bench ${TAG}_bench_300steps --steps 300 --warmup 10 --no-other-configs
+# the same index shape with the reference's default codebook size K = 256 (one byte per code: ivf_filter8_kernel)
+bench ${TAG}_bench_K256 --steps 300 --warmup 10 --K 256 --cpu-sample 64 --no-recall --no-host-abi --no-other-configs --no-collective-child
 # a corpus that does NOT fit the 256 MiB Infinity Cache: N = 40 M rows (1.1 GB of lists), same list length
 # with its OWN FETCH / WRITE passes (bench.py's pmc_traffic() refuses the 3 M-row record for this shape)
 cp profiles/latest_pmc.json gpurun_out/prof/${TAG}_latest_pmc_3M.json
