@@ -729,7 +729,9 @@ def run_ivfadc(a, rank, world, dev, dev_index):
         if dom:
             avg_s = prof[dom][1] / max(prof[dom][0], 1) / 1e3
             scan_variant = os.environ.get("FREDDY_GPU_FUSED_KERNEL", "5")
-            kname = {"ivf_filter": "ivf_filter5_kernel" if scan_variant == "5" else "ivf_filter_kernel", "ivf_exact_scan": "ivf_spec2_kernel", "adc_scan": "adc_scan_kernel",
+            # K <= 256 with one byte per code (option codes_u8 = 1, the default) takes the whole-entry-slab kernel (fused8.h)
+            filt = "ivf_filter8_kernel" if (a.K <= 256 and os.environ.get("FREDDY_GPU_CODES_U8", "1") == "1") else "ivf_filter5_kernel"
+            kname = {"ivf_filter": filt if scan_variant == "5" else "ivf_filter_kernel", "ivf_exact_scan": "ivf_spec2_kernel", "adc_scan": "adc_scan_kernel",
                      "lut_build": "lut_build_kernel", "coarse_dist": "coarse_tile_kernel",
                      "probe_plan": "probe_plan_kernel"}.get(dom, dom)
             shape_now = {"N": N, "Q": q_local, "C": a.C, "nprobe": a.nprobe}
@@ -741,9 +743,11 @@ def run_ivfadc(a, rank, world, dev, dev_index):
                 # the scan is two launches here (thin cells item by item, the others cell-grouped): the algorithmic bytes are
                 # those of BOTH, so both durations and both kernels' counters are priced together
                 dom = "ivf_filter+sparse_items"
-                kname = "ivf_filter5_kernel + sparse_item5_kernel"
+                # (thin cells: units of two queries by default -- option sparse_items >= 2, sparse5.h)
+                sparse = "sparse_item5_kernel" if os.environ.get("FREDDY_GPU_SPARSE_ITEMS", "2") in ("0", "1") else "sparse_pair5_kernel"
+                kname = f"{filt} + {sparse}"
                 avg_s = sum(prof[n][1] / max(prof[n][0], 1) for n in ("ivf_filter", "sparse_items")) / 1e3
-                tr = [pmc_traffic(n, None, shape_now) for n in ("ivf_filter5_kernel", "sparse_item5_kernel")]
+                tr = [pmc_traffic(n, None, shape_now) for n in (filt, sparse)]
                 traffic = sum(tr) if all(t is not None for t in tr) else None
                 if all(n in prof_ov for n in ("ivf_filter", "sparse_items")):
                     ov_dom = (1, sum(prof_ov[n][1] / max(prof_ov[n][0], 1) for n in ("ivf_filter", "sparse_items")))
