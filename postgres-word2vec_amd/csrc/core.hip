@@ -338,6 +338,7 @@ extern "C" int freddy_gpu_set_option(freddy_gpu_index_t* ix, const char* name, i
   else if (n == "coarse_pieces") t.coarse_pieces = (int)value;
 #ifdef FREDDY_LAB
   else if (n == "fused_prof") t.scan_prof = (int)value;
+  else if (n == "scan_fence") t.scan_fence = (int)value;
 #endif
   else return fail(FREDDY_E_ARG, "unknown option '%s'", name);
   return FREDDY_OK;

@@ -78,6 +78,7 @@ struct Tuning {
   int check_brackets = 0;
 #ifdef FREDDY_LAB
   int scan_prof = 0;           // FREDDY_GPU_FUSED_PROF (lab builds only): per-phase cycle sums of the scan kernel on stderr
+  int scan_fence = 0;          // option scan_fence (lab builds only; tools/lab/ablate.py): FilterArgs::fence -- parts of the scan kernel switched OFF (results wrong, time only)
 #endif
 };
 int64_t env_int(const char* name, int64_t dflt);

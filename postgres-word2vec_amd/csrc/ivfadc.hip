@@ -376,6 +376,9 @@ int ivf_scan_filter(IvfRun& r, const PlanArgs& pa, const WorkTable& wt) {
   fl.work_counter = wt.work_counter; fl.packed = ix->packed; fl.surv = ws->w_surv.as<u64>(); fl.surv_count = ws->w_surv_cnt.as<int32_t>();
   fl.cand_count = (r.found_rule == 1) ? ws->w_cand.as<int32_t>() : nullptr;
   fl.K = K; fl.L = r.L; fl.upi = r.upi; fl.sentinel = r.sentinel; fl.keep_all = (ix->tune.check_brackets & 1) ? 1 : 0; fl.fence = 0;
+#ifdef FREDDY_LAB
+  fl.fence = (uint32_t)ix->tune.scan_fence;
+#endif
   // (not for a batch over the flat PQ table: a few dozen queries x a thousand entries read and update the same two cache lines --
   // 96 -> 128 us -- and its merge gains nothing; an IVFADC batch: +2.6 % queries/s with four batches in flight)
   fl.tau_run = (ix->tune.running_bound && !r.records_ready) ? ws->w_cand.as<uint32_t>() + Q : nullptr;

@@ -25,6 +25,8 @@ def run(n):
         index.search_dev(dq.data_ptr(), Q, 5, 10, 1000.0, gpu.FOUND_ROWS, res[0].data_ptr(), res[1].data_ptr(), st.data_ptr(), s.cuda_stream)
     torch.cuda.synchronize(dev)
 run(5)
+if os.environ.get("FENCE"):
+    index.set_option("scan_fence", int(os.environ["FENCE"]))   # (parts of the kernel off: tools/lab/ablate.py)
 index.set_option("fused_prof", 1)
 run(3)
 index.set_option("fused_prof", 0)
