@@ -310,8 +310,9 @@ int freddy_gpu_abi_version(void);
  *   deployment:  "scan_share" (the batches that share the chip with one of this handle's: the batches the caller keeps in flight
  *                through the *_dev entry points, one stream each, or the other BACKENDS searching at the same time -- a persistent
  *                scan takes n_cus / scan_share CUs; default 0 = auto: the whole chip, or half of it for a host-buffer call that
- *                starts while another backend (process) is searching: the library keeps a registry of live backends in /dev/shm and
- *                also picks GPU_MAX_HW_QUEUES from it before its first HIP call -- 6 alone, 2 beside others),
+ *                starts while another backend (process) of the same GPU is searching: the library keeps a registry of live backends per
+ *                physical GPU in /dev/shm and also picks GPU_MAX_HW_QUEUES from it before its first HIP call -- 6 alone, 2 beside
+ *                others),
  *                "reserve_cus" (CUs a persistent scan leaves free), "pipeline_batch" / "pipeline_lanes" (host-buffer IVFADC calls:
  *                queries per sub-batch, 2048; sub-batches in flight, 1..4), "coarse_pieces" (1: a call of one sub-batch launches its
  *                cell selection per staged piece of the queries), "lut_budget_mb" (workspace cap per call)

@@ -17,104 +17,19 @@ int fail(int code, const char* fmt, ...) {
 extern "C" const char* freddy_gpu_last_error(void) { return g_err; }
 
 // ---------------------------------------------------------------------------------------
-// Backends on one GPU (one PostgreSQL backend = one process = one HIP context).  The processes cannot see each other
-// through HIP, and two things must be decided per process: how many hardware queues the runtime may create (read ONCE, when the
-// runtime starts) and how much of the chip a persistent scan takes while other backends are searching.  A small registry in
-// /dev/shm -- one slot per process: pid, the number of host-buffer searches it has in flight -- answers both without any
-// configuration: a process that finds other live backends when it starts takes GPU_MAX_HW_QUEUES = 2 (profiles/r05_backends.txt:
-// 2 / 4 backends at six queues each are together SLOWER than one; at two queues each 4.9 / 6.9 M queries/s), one that starts
-// alone takes six (four pipeline lanes + spares); a host-buffer search that starts while another backend is searching runs its
-// scan on half of the CUs (option scan_share = 0, the default: auto).  Slots of processes that died are recognised by kill(pid, 0).
-// Everything here is advisory: a registry that cannot be opened means "alone".
+// Backends on one GPU: the registry of live backends per physical GPU is registry.h (plain C++, tested on its own)
 // ---------------------------------------------------------------------------------------
-#include <fcntl.h>
-#include <signal.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
+#include "registry.h"
 
-namespace {
-struct BackendSlot { std::atomic<int32_t> pid; std::atomic<int32_t> busy; };
-constexpr int kBackendSlots = 256;
-BackendSlot* g_slots = nullptr;
-int g_my_slot = -1;
-std::once_flag g_registry_once;
-
-bool pid_alive(int32_t pid) { return pid > 0 && (kill((pid_t)pid, 0) == 0 || errno == EPERM); }
-
-void registry_release() {
-  if (g_slots && g_my_slot >= 0) {
-    g_slots[g_my_slot].busy.store(0);
-    g_slots[g_my_slot].pid.store(0);
-  }
-}
-
-std::mutex g_reg_mu;
-int g_handles = 0;      // pinned handles of this process: it is a registered backend while this is > 0
-
-void registry_claim();
-void registry_open() {
-  static_assert(sizeof(BackendSlot) == 8 && std::atomic<int32_t>::is_always_lock_free, "slot layout");
-  if (env_int("FREDDY_GPU_REGISTRY", 1) == 0) return;
-  char name[64];
-  snprintf(name, sizeof name, "/freddy_gpu_backends.%u", (unsigned)geteuid());
-  const int fd = shm_open(name, O_RDWR | O_CREAT, 0600);
-  if (fd < 0) return;
-  const size_t bytes = sizeof(BackendSlot) * kBackendSlots;
-  if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return; }
-  void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-  close(fd);
-  if (p == MAP_FAILED) return;
-  g_slots = static_cast<BackendSlot*>(p);
-  atexit(registry_release);
-}
-void registry_claim() {   // (g_reg_mu held)
-  if (!g_slots || g_my_slot >= 0) return;
-  const int32_t me = (int32_t)getpid();
-  for (int pass = 0; pass < 2 && g_my_slot < 0; ++pass)
-    for (int i = 0; i < kBackendSlots && g_my_slot < 0; ++i) {
-      int32_t cur = g_slots[i].pid.load();
-      if (cur == me) { g_my_slot = i; break; }                       // (a forked child re-registers under its own pid below)
-      if (cur != 0 && (pass == 0 || pid_alive(cur))) continue;       // first pass: free slots only; second: slots of dead processes
-      if (g_slots[i].pid.compare_exchange_strong(cur, me)) { g_slots[i].busy.store(0); g_my_slot = i; }
-    }
-}
-}  // namespace
-
-// A process is a registered backend while it holds pinned handles (+1 per pinned index, -1 when it is freed).
-void backend_handles(int delta) {
-  std::call_once(g_registry_once, registry_open);
-  std::lock_guard<std::mutex> lock(g_reg_mu);
-  g_handles += delta;
-  if (g_handles > 0) registry_claim();
-  else if (g_slots && g_my_slot >= 0) { registry_release(); g_my_slot = -1; }
-}
-
-// live backends other than this process: registered (searching = false) or inside a host-buffer search right now (searching = true)
-int backends_other(bool searching) {
-  std::call_once(g_registry_once, registry_open);
-  if (!g_slots) return 0;
-  const int32_t me = (int32_t)getpid();
-  int n = 0;
-  for (int i = 0; i < kBackendSlots; ++i) {
-    const int32_t pid = g_slots[i].pid.load(std::memory_order_relaxed);
-    if (pid == 0 || pid == me) continue;
-    if (searching && g_slots[i].busy.load(std::memory_order_relaxed) <= 0) continue;
-    if (pid_alive(pid)) ++n;
-  }
-  return n;
-}
-void backend_busy(int delta) {
-  std::call_once(g_registry_once, registry_open);
-  if (g_slots && g_my_slot >= 0 && g_slots[g_my_slot].pid.load(std::memory_order_relaxed) == (int32_t)getpid())
-    g_slots[g_my_slot].busy.fetch_add(delta);
-}
+void backend_handles(int delta, int device) { freddy::registry::handles(delta, device); }
+int backends_other(bool searching, int device) { return freddy::registry::others(searching, device); }
+void backend_busy(int delta) { freddy::registry::busy(delta); }
 // Before the process's first HIP call: the hardware queues the runtime may create (never overrides the environment).
-void choose_hw_queues() {
+void choose_hw_queues(int device) {
   static std::once_flag once;
-  std::call_once(once, [] {
+  std::call_once(once, [device] {
     const char* policy = getenv("FREDDY_GPU_HWQ_POLICY");   // "6" / "2": fixed; default: by the registry
-    const bool alone = backends_other(false) == 0;
+    const bool alone = backends_other(false, device) == 0;
     const char* q = (policy && *policy && strcmp(policy, "registry") != 0) ? policy : (alone ? "6" : "2");
     setenv("GPU_MAX_HW_QUEUES", q, 0);
   });
@@ -172,7 +87,7 @@ Workspace* workspace_for(freddy_gpu_index* ix, hipStream_t s) {
 
 void free_index(freddy_gpu_index* ix) {
   if (!ix) return;
-  if (ix->registered) { ix->registered = false; backend_handles(-1); }
+  if (ix->registered) { ix->registered = false; backend_handles(-1, ix->device); }
   for (freddy_gpu_index* r : ix->replicas) free_index(r);
   ix->replicas.clear();
   (void)hipSetDevice(ix->device);
@@ -356,7 +271,7 @@ int check_search_args(const freddy_gpu_index* ix, int kind, const void* q, int Q
 }
 
 extern "C" int freddy_gpu_host_alloc(void** out, size_t bytes) {
-  choose_hw_queues();   // (as open_device: this call may be the process's first HIP call)
+  choose_hw_queues(-1);   // (as open_device: this call may be the process's first HIP call; -1: the device is not known here -- every registered backend counts)
   if (!out) return fail(FREDDY_E_ARG, "NULL argument");
   *out = nullptr;
   if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { *out = nullptr; return fail(FREDDY_E_NOMEM, "pinned host allocation of %zu bytes failed", bytes); }

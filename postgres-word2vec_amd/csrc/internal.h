@@ -82,13 +82,13 @@ struct Tuning {
 #endif
 };
 int64_t env_int(const char* name, int64_t dflt);
-int backends_other(bool searching);   // core.hip: live backends (processes) besides this one -- registered / inside a host-buffer search
-void backend_handles(int delta);      // +1 per pinned index of this process, -1 when it is freed: registered while > 0
+int backends_other(bool searching, int device);   // core.hip: live backends (processes) besides this one with handles on the same PHYSICAL GPU as HIP device `device` (-1: on any) -- registered / inside a host-buffer search
+void backend_handles(int delta, int device);   // +1 per pinned index of this process (on HIP device `device`), -1 when it is freed: registered while > 0
 void backend_busy(int delta);         // this process enters (+1) / leaves (-1) a host-buffer search
-void choose_hw_queues();              // GPU_MAX_HW_QUEUES before the first HIP call (never overrides the environment)
+void choose_hw_queues(int device);    // GPU_MAX_HW_QUEUES before the first HIP call (never overrides the environment)
 struct BackendBusy { BackendBusy() { backend_busy(1); } ~BackendBusy() { backend_busy(-1); } };
 // option scan_share as a number: the explicit value, or (0 = auto) 2 while another backend is searching, else 1
-static inline int scan_share_now(int option, bool host_call) { return option > 0 ? option : (host_call && backends_other(true) > 0 ? 2 : 1); }
+static inline int scan_share_now(int option, bool host_call, int device) { return option > 0 ? option : (host_call && backends_other(true, device) > 0 ? 2 : 1); }
 Tuning read_tuning();
 
 struct DevBuf {

@@ -777,7 +777,7 @@ extern "C" int freddy_gpu_ivfadc_search_dev(freddy_gpu_index_t* ix, const float*
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
-    if (int rc = ivfadc_begin(ix, s, scan_share_now(ix->tune.scan_share, false), d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+    if (int rc = ivfadc_begin(ix, s, scan_share_now(ix->tune.scan_share, false, ix->device), d_queries + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
                               d_out_ids + (size_t)q0 * k, d_out_dist + (size_t)q0 * k, d_status, r))
       return rc;
   }
@@ -836,7 +836,7 @@ static int ivfadc_sync_search(freddy_gpu_index* ix, const float* queries, int Q,
   for (int q0 = 0; q0 < Q; q0 += qc) {
     const int n = std::min(qc, Q - q0);
     IvfRun r;
-    if (int rc = ivfadc_begin(ix, s, scan_share_now(ix->tune.scan_share, true), ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
+    if (int rc = ivfadc_begin(ix, s, scan_share_now(ix->tune.scan_share, true, ix->device), ws->w_q.as<float>() + (size_t)q0 * ix->d, n, k, W, sentinel, found_rule,
                               ws->w_out_ids.as<int32_t>() + (size_t)q0 * k, ws->w_out_dist.as<float>() + (size_t)q0 * k, nullptr, r))
       return rc;
     if (int rc = ivfadc_finish(r, -1)) return rc;
@@ -1039,7 +1039,7 @@ static int ivfadc_host_search(freddy_gpu_index* ix, const float* queries, int Q,
   const size_t row = sizeof(float) * (size_t)ix->d;
   const PipeCall pc{ix, queries, k, W, found_rule, sentinel, out_ids, out_dist};
   const BackendBusy busy;   // (the registry of backends on this GPU: core.hip)
-  const int share_call = scan_share_now(ix->tune.scan_share, true);
+  const int share_call = scan_share_now(ix->tune.scan_share, true, ix->device);
   int rc = 0;
 #ifdef FREDDY_LAB
   static const bool trace = getenv("FREDDY_GPU_PIPE_TRACE") != nullptr;   // host timestamps of the pipeline's steps on stderr (lab builds)

@@ -302,8 +302,9 @@ int open_device(freddy_gpu_index* ix, int device) {
   // best for ONE process) -- but several backends with six queues each are together slower than one, so a process that
   // finds other live backends takes two (core.hip choose_hw_queues).  Never overrides the environment; without effect if
   // the runtime is already up.
-  if (!ix->registered) { ix->registered = true; backend_handles(+1); }   // (before the count of the others: two backends that start together see each other)
-  choose_hw_queues();
+  // (the registry counts backends per PHYSICAL GPU: one process per GPU -- bench.py --gpus N, one PostgreSQL cluster per GPU -- are not neighbours)
+  if (!ix->registered) { ix->registered = true; backend_handles(+1, device); }   // (before the count of the others: two backends that start together see each other)
+  choose_hw_queues(device);
   int n = 0;
   HIP_TRY(hipGetDeviceCount(&n));
   if (device < 0 || device >= n) return fail(FREDDY_E_ARG, "device %d out of range (%d visible)", device, n);

@@ -253,7 +253,7 @@ static int pq_fused_chunk(freddy_gpu_index* ix, freddy_gpu_index* fx, hipStream_
   r.found_rule = 0; r.upi = 1; r.fused = true; r.scan_kernel = 5; r.tiled = false; r.zeroed = false; r.approx = false;
   r.records_ready = true; r.merge_slices = SL;
   r.n_active = Q; r.round = 0; r.active = nullptr;
-  r.share = scan_share_now(ix->tune.scan_share, false);   // (the caller's contract: its batches in flight on this handle)
+  r.share = scan_share_now(ix->tune.scan_share, false, ix->device);   // (the caller's contract: its batches in flight on this handle)
   const size_t items = (size_t)Q * W;
   const size_t n_entries = (size_t)((Q + SCAN5_G - 1) / SCAN5_G) * lists;
   if (ws->w_item_cell.ensure(sizeof(int32_t) * items) || ws->w_item_query.ensure(sizeof(int32_t) * items) ||
