@@ -37,13 +37,18 @@ for seed in range(seeds):
     idx = gpu.IVFIndex(coarse, codebook, list_off, ids_sorted, codes)
     Q = int(rng.choice([1, 40, 300, 700]))
     qs = (coarse[rng.integers(0, C, size=Q)] + 0.2 * rng.standard_normal((Q, d))).astype(np.float32)
-    for variant in (5, 4, 3):
+    # (variant, codes_u8): K <= 256 has three scans behind variant 5 -- 1: the whole-entry-slab kernel (fused8.h, the default),
+    # 2: the six-phase kernel's one-byte instantiation, 0: the int16 layout
+    for variant, u8 in [(5, 1), (5, 2), (5, 0), (4, 1), (3, 1)]:
+        if u8 != 1 and K > 256:
+            continue
         idx.set_option("fused_kernel", variant)
+        idx.set_option("codes_u8", u8)
         for k, W in [(1, 1), (5, min(3, C)), (32, min(C, 12))]:
             for rule, sent in [(0, 1000.0), (1, 100.0)]:
                 gi, gd = idx.search(qs, k, W, sentinel=sent, found_rule=rule)
                 exp = oracle.ivfadc_search_many(ot, qs, k, W, sentinel=sent, found_rule=rule)
-                util.assert_same_lists(gi, gd, exp, f"seed={seed} variant={variant} K={K} C={C} N={N} Q={Q} k={k} W={W} rule={rule}")
+                util.assert_same_lists(gi, gd, exp, f"seed={seed} variant={variant} codes_u8={u8} K={K} C={C} N={N} Q={Q} k={k} W={W} rule={rule}")
                 n += 1
     idx.close()
 print(f"soak ok: {n} searches over {seeds} random indexes in {time.time() - t0:.1f}s")
