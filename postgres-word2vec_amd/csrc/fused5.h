@@ -721,6 +721,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
         const float p_off = __int_as_float(rec[40 + gi]);
         const uint32_t p_lo = (uint32_t)rec[88 + gi], p_hi = (uint32_t)rec[104 + gi];
         const int p_q = rec[24 + gi];
+        // lane g: item g's survivor region of this wave, and (collected below) its count -- ONE store of the counts per entry
+        const int p_reg = (p_it * a.upi + chunk) * NG + gw;
+        int cntv = 0;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
@@ -728,9 +731,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
             const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));
             const float off = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_off), g));
             const float shift = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_shift), g));
-            const int it = __builtin_amdgcn_readlane(p_it, g);
-            const size_t region = ((size_t)it * a.upi + chunk) * NG + gw;
-            u64* dst = a.surv + region * (size_t)(RMAX * 64);
+            const uint32_t region = (uint32_t)__builtin_amdgcn_readlane(p_reg, g);
+            u64* dst = a.surv + (size_t)region * (size_t)(RMAX * 64);
             int run = 0;
             if constexpr (!CAND) {   // the common case (freddy.c:366 counts retrieved rows): nothing but the threshold test
              const float second = __uint_as_float((g & 1) ? (sec16[g >> 1] & 0xffff0000u) : (sec16[g >> 1] << 16));
@@ -793,9 +795,10 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter5_kernel(FilterArgs a) {
               }
               if (lane == 0 && accepted) atomicAdd(a.cand_count + __builtin_amdgcn_readlane(p_q, g), accepted);
             }
-            if (lane == 0) a.surv_count[region] = run;
+            cntv = lane == g ? run : cntv;
           }
         }
+        if (lane < cnt) a.surv_count[(uint32_t)p_reg] = cntv;
       }
       gtick(2);
       const int next_ok = __builtin_amdgcn_readfirstlane(dsc[nb * REC_DW + 6]);
