@@ -376,7 +376,6 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
         for (int g = 0; g < G; ++g) {
           if (g < cnt) {
             const float thr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_thr), g));
-            const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));
             const float off = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_off), g));
             const float shift = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_shift), g));
             const uint32_t region = (uint32_t)__builtin_amdgcn_readlane(p_reg, g);
@@ -398,7 +397,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
                   run = __popcll(mask);
                 }
               } else {
-                uint32_t m8 = 0u;
+                const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));   // (this path only)
+              uint32_t m8 = 0u;
 #pragma unroll
                 for (int r = RMAX - 1; r >= 0; --r) m8 = m8 + m8 + (!(sval(g, r, sc) > thr) ? 1u : 0u);
                 m8 &= live8;
@@ -421,6 +421,7 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
             } else {
               const uint32_t lo_b = (uint32_t)__builtin_amdgcn_readlane((int)p_lo, g);
               const uint32_t hi_b = (uint32_t)__builtin_amdgcn_readlane((int)p_hi, g);
+              const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));
               int accepted = 0;
 #pragma unroll
               for (int r = 0; r < RMAX; ++r) {
@@ -443,7 +444,8 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
               }
               if (lane == 0 && accepted) atomicAdd(a.cand_count + __builtin_amdgcn_readlane(p_q, g), accepted);
             }
-            cntv = lane == g ? run : cntv;
+            // (v_writelane: the compiler's own select read its sixteen lane masks back from spilled scalar registers, five instructions per item)
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(run), "i"(g));
           }
         }
         if (lane < cnt) a.surv_count[(uint32_t)p_reg] = cntv;
