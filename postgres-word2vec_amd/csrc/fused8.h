@@ -349,6 +349,9 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
             const uint32_t dn = ((bb >> 31) ? bb + 0xffffu : bb) >> 16;
             sec16[g >> 1] = (g & 1) ? ((sec16[g >> 1] & 0x0000ffffu) | (dn << 16)) : ((sec16[g >> 1] & 0xffff0000u) | dn);
           }
+          // (opaque: the compiler otherwise folds the shift into the eight selects above, whose constants 128, 192, ... are no inline
+          // operands -- a v_mov per row and item)
+          asm volatile("" : "+v"(ar));
           apack[g >> 3] |= ar << (3 * (g & 7));
           if (rl_wave > 0) atomicMin(colmin + g * 64 + lane, float_key(b1));
         }
@@ -385,17 +388,16 @@ __global__ __launch_bounds__(SPEC2_T) void ivf_filter8_kernel(FilterArgs a) {
               const float second = __uint_as_float((g & 1) ? (sec16[g >> 1] & 0xffff0000u) : (sec16[g >> 1] << 16));
               const u64 multi = __ballot(!(second > thr));
               if (__builtin_expect(multi == 0ull, 1)) {
+                // (no uniform branch around the emission: nearly every (item, wave) has a survivor, the exec mask does the rest)
                 const bool pass = !(best[g] > thr);
                 const u64 mask = __ballot(pass);
-                if (mask != 0ull) {
-                  if (pass) {
-                    const uint32_t r = (apack[g >> 3] >> (3 * (g & 7))) & 7u;
-                    const float dlo = fmaxf(0.0f, (best[g] + off) - shift);
-                    const uint32_t loc = ((uint32_t)(blk0 + gw) + r * (uint32_t)NG) * 64u + (uint32_t)lane;
-                    dst[lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
-                  }
-                  run = __popcll(mask);
+                if (pass) {
+                  const uint32_t r = (apack[g >> 3] >> (3 * (g & 7))) & 7u;
+                  const float dlo = fmaxf(0.0f, (best[g] + off) - shift);
+                  const uint32_t loc = ((uint32_t)(blk0 + gw) + r * (uint32_t)NG) * 64u + (uint32_t)lane;
+                  dst[lanes_below(mask)] = ((u64)__float_as_uint(dlo) << 32) | (u64)loc;
                 }
+                run = __popcll(mask);
               } else {
                 const float sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p_sc), g));   // (this path only)
               uint32_t m8 = 0u;
