@@ -261,6 +261,47 @@ __global__ __launch_bounds__(64 * NWV, 4) void merge_refine_kernel(MergeRefineAr
     constexpr int H = (NWV == 1) ? (NSTEP + 1) / 2 : (S + 1) / 2;   // (one wave per query: 7 + 6 loads in flight -- with 13 the kernel spilled at 128 registers)
 #pragma unroll 1
     for (int hh = 0; hh < 64 / CH; ++hh) {
+    if constexpr (NWV == 1) {
+      // One wave per query: ONE round trip per staged half instead of two.  A chain's codeword / centroid slice (S = 25 floats, 4-byte
+      // aligned) is read as UN = 7 units of 16 bytes -- the last one overlaps its neighbour (floats S - 4 .. S - 1), so no unit leaves
+      // the slice --, a lane <-> a unit: 4 + 4 loads of 16 bytes in flight per lane instead of 7 + 6 dwords twice.  With batches in
+      // flight the memory system is loaded and a round trip of this latency chain is 3 - 4 us: three tiles x two halves save six.
+      constexpr int UN = (S + 3) / 4, W0 = UN * 4 - S;   // units per chain; the last unit's first NEW float
+      constexpr int NU = (CH * UN + 63) / 64;
+      typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+      f4u cv4[NU], cov4[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int unit = u * 64 + lane;
+        const int cl = unit / UN, part = unit - cl * UN;
+        const int chn = t * 64 + hh * CH + cl;
+        const bool live = unit < CH * UN && chn < chains;
+        const uint32_t j0 = part == UN - 1 ? (uint32_t)(S - 4) : (uint32_t)(part * 4);
+        const uint32_t off = ((uint32_t)cbo[live ? chn : t * 64] + (live ? j0 : 0u)) * 4u;
+        const uint32_t offc = ((uint32_t)coo[live ? chn : t * 64] + (live ? j0 : 0u)) * 4u;   // (C*d*4 < 2^32)
+        cv4[u] = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(a.cbR) + off);
+        cov4[u] = *reinterpret_cast<const f4u*>(reinterpret_cast<const char*>(a.coarse) + offc);
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int unit = u * 64 + lane;
+        const int cl = unit / UN, part = unit - cl * UN;
+        const int chn = t * 64 + hh * CH + cl;
+        if (unit < CH * UN && chn < chains) {
+          const int p = chn % M;
+          const int j0 = part == UN - 1 ? S - 4 : part * 4;
+          const int w0 = part == UN - 1 ? W0 : 0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            if (w >= w0) {
+              const float r = qs[p * S + j0 + w] - cov4[u][w];               // freddy.c:296-303
+              const float tt = r - cv4[u][w];
+              sqb[cl * SQ + j0 + w] = tt * tt;                               // index_utils.c:500-508
+            }
+          }
+        }
+      }
+    } else
 #pragma unroll 1
     for (int h0 = 0; h0 < NSTEP; h0 += H) {
       float cv[H], cov[H];
