@@ -11,7 +11,7 @@ import json, sys
 o = json.load(open("bench_details.json"))
 k = {n: v["avg_us"] for n, v in o["kernels"].items()}
 ko = {n: v["avg_us"] for n, v in o["kernels_overlapped"].items()}
-print(f"{sys.argv[1].split('libfreddy_gpu')[-1]:10s} {o['value']/1e6:6.3f} M q/s  {o['ms_per_step']:.4f} ms  serial {o['pipelining']['serial_ms_per_step']:.4f}  scan {k.get('ivf_filter')} / {ko.get('ivf_filter')}  merge {k.get('merge_refine')} / {ko.get('merge_refine')}")
+print(f"{sys.argv[1].split('libfreddy_gpu')[-1]:10s} {o['value']/1e6:6.3f} M q/s  {o['ms_per_step']:.4f} ms  serial {o['pipelining']['serial_ms_per_step']:.4f}  scan {k.get('ivf_filter')} / {ko.get('ivf_filter')}  merge {k.get('merge_refine')} / {ko.get('merge_refine')}  coarse {k.get('coarse_table')} / {ko.get('coarse_table')}  plan {k.get('probe_plan')} / {ko.get('probe_plan')}")
 P
   done
 done
