@@ -819,6 +819,38 @@ def test_filter_refine_many_equal_distances(gpu, oracle, monkeypatch):
     idx.close()
 
 
+def test_exact_stage_reads_the_last_codeword_and_the_last_centroid(gpu, oracle, monkeypatch):
+    """The merge's exact stage reads a chain's codeword / centroid slice as 16-byte units whose last one overlaps its neighbour (one
+    wave per query, refine.h): rows that carry the LAST code at every position, in the LAST cell, so the last unit of the last
+    codeword and of the last centroid row are read -- both merge instantiations (one batch at a time / batches in flight)."""
+    monkeypatch.setenv("FREDDY_GPU_FUSED", "1")
+    rng = np.random.default_rng(77)
+    d, m, K, C, N = 300, 12, 1024, 7, 6000
+    coarse = rng.standard_normal((C, d)).astype(np.float32)
+    codebook = (rng.standard_normal((m, K, 25)) * 0.3).astype(np.float32)
+    cell = np.sort(rng.integers(0, C, size=N))
+    codes = rng.integers(0, K, size=(N, m)).astype(np.int16)
+    last = np.flatnonzero(cell == C - 1)
+    codes[last[: len(last) // 2]] = K - 1                      # half of the last cell's rows: the last code everywhere
+    codes[last[len(last) // 2:], m - 1] = K - 1                # the others: the last code at the last position
+    list_off = np.zeros(C + 1, np.int32)
+    list_off[1:] = np.cumsum(np.bincount(cell, minlength=C))
+    ids = (np.arange(N) * 5 + 3).astype(np.int32)
+    ot = oracle.ivf_table(coarse, codebook, list_off, ids, codes)
+    idx = gpu.IVFIndex(coarse, codebook, list_off, ids, codes)
+    # queries at the last centroid shifted by the last codewords: their nearest rows are the rows above
+    tail = np.concatenate([codebook[p_, K - 1] for p_ in range(m)])
+    qs = (coarse[C - 1] + tail + 0.05 * rng.standard_normal((300, d))).astype(np.float32)
+    for share in (1, 4):
+        idx.set_option("scan_share", share)
+        for k, W in ((5, 2), (32, C)):
+            gi, gd = idx.search(qs, k, W)
+            exp = oracle.ivfadc_search_many(ot, qs, k, W)
+            util.assert_same_lists(gi, gd, exp, f"last codeword / centroid, scan_share={share} k={k} W={W}")
+    assert idx.bound_violations() == 0
+    idx.close()
+
+
 def test_filter_refine_sentinel_inside_the_data(gpu, oracle, monkeypatch):
     """The guard dist < sentinel (freddy.c:128-131) with the sentinel in the middle of the distances and
     exactly ON a row's distance: rows whose bound straddles it are decided by the exact stage, and with
