@@ -1293,9 +1293,14 @@ def main():
                     cmd = [sys.executable, os.path.abspath(__file__), "--force-collective", "--no-other-configs", "--no-host-abi", "--no-recall",
                            "--cpu-sample", "0", "--steps", str(max(a.steps, 100)), "--warmup", str(a.warmup), "--in-flight", str(a.in_flight),
                            "--backend", a.backend]
+                    side = os.path.join(ROOT, "bench_details_collective.json")
+                    if os.path.exists(side):
+                        os.unlink(side)   # (a record of an earlier run must not stand in for a child that failed)
                     cp = subprocess.run(cmd, capture_output=True, text=True, timeout=600,
                                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")})
-                    det = json.load(open(os.path.join(ROOT, "bench_details_collective.json")))
+                    if cp.returncode != 0:
+                        raise RuntimeError(f"child exited with {cp.returncode}: {cp.stderr.strip().splitlines()[-1] if cp.stderr.strip() else ''}")
+                    det = json.load(open(side))
                     out["collective_1rank"] = det["collective_1rank"]
                     out["config"]["collective_1rank_ratio"] = det["collective_1rank"]["ratio"]
                 except Exception as e:
